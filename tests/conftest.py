@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+PKG = os.path.join(ROOT, 'mode-2022_amd')
+for p in (ROOT, GOLDEN, PKG):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+  # GPU tests are never silently skipped on a GPU box; on a CPU-only host they are deselected by
+  # `-m "not gpu"`, and if someone runs them anyway they fail loudly in the native loader.
+  pass
+
+
+@pytest.fixture(scope='session')
+def golden():
+  def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+  return load
+
+
+@pytest.fixture(autouse=True)
+def _threads():
+  torch.set_num_threads(min(8, os.cpu_count() or 1))
