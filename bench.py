@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- MODE disparity stage on MI355X: stereo pairs/s, fwd+bwd(+Adam), synthetic Cassini 1024x512 (= 512x1024 ERP),
+192 disparities, batch 2 per GPU (BASELINE.json configs[2]; configs[3] when launched on 8 GPUs).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  A "step" is one training iteration of ModeDisparity over one synthetic batch that is already
+resident in HBM: zero-grad, forward (3 heads), masked smooth-L1 loss 0.5/0.7/1.0, backward, gradient all-reduce (N > 1),
+Adam step.  `roofline` describes the dominant hand-written kernel, timed with HIP events on its launch stream inside the
+timed region; `cpu_baseline` times the CPU oracle (a port, not the product) on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'mode-2022_amd'), os.path.join(ROOT, 'tests', 'golden')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+HBM_PEAK_GBPS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm'}
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--batch', type=int, default=2, help='pairs per GPU')
+  ap.add_argument('--height', type=int, default=1024)
+  ap.add_argument('--width', type=int, default=512)
+  ap.add_argument('--maxdisp', type=int, default=192)
+  ap.add_argument('--mode', default='train', choices=['train', 'eval'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-kernel-timing', action='store_true')
+  return ap.parse_args()
+
+
+def synthetic_batch(B, H, W, maxdisp, device, seed):
+  """left = ImageNet-normalised uniform noise; right = left shifted along W + noise; ground truth disparity in
+  [0, maxdisp/2] with 5 % NaN (mask of train_disparity.py:195)."""
+  g = torch.Generator(device='cpu').manual_seed(seed)
+  mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+  std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+  left = (torch.rand(B, 3, H, W, generator=g) - mean) / std
+  right = torch.roll(left, -7, 3) + 0.01 * torch.randn(B, 3, H, W, generator=g)
+  gt = torch.rand(B, 1, H, W, generator=g) * (maxdisp / 2.0)
+  gt[torch.rand(B, 1, H, W, generator=g) < 0.05] = float('nan')
+  return left.to(device), right.to(device), gt.to(device)
+
+
+def cpu_baseline(args):
+  """Time the CPU oracle (oracle/mode_ref.py, same arithmetic as the reference on torch's CPU backend) on this host.
+  Bounded: one fwd+bwd at BASELINE configs[0] size (Cassini 512x256, D=64, B=1); if that predicts < 45 s for the full
+  1024x512 / D=192 pair, the full-size pair is run and reported instead."""
+  import recipe
+  from oracle import mode_ref
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+
+  def run(maxdisp, H, W):
+    P = recipe.recipe_state(recipe.load_manifest(), 1)
+    for k, v in P.items():
+      if v.is_floating_point() and 'running' not in k:
+        v.requires_grad_(True)
+    left, right = recipe.recipe_images(1, H, W, 2)
+    gt = recipe.recipe_disparity(1, H, W, 3, maxdisp)
+    pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+    t0 = time.time()
+    preds = mode_ref.mode_disparity(P, left, right, maxdisp, pos, True)
+    mode_ref.training_loss(preds, gt, ~torch.isnan(gt)).backward()
+    return time.time() - t0
+
+  run(16, 64, 32)  # warm-up (thread pools, allocator)
+  t_small = run(64, 512, 256)
+  flop_ratio = 1574.6 / 224.7  # fwd GFLOP per pair, full size vs configs[0]
+  full = (args.maxdisp, args.height, args.width) == (192, 1024, 512)
+  if full and t_small * flop_ratio < 45.0:
+    t_full = run(192, 1024, 512)
+    return dict(value=1.0 / t_full, unit='pairs/s', cores=cores, kind='port',
+                sample='1 pair fwd+bwd at full size (Cassini 1024x512, D=192), oracle/mode_ref.py on torch CPU, %.1f s' % t_full)
+  return dict(value=1.0 / (t_small * flop_ratio), unit='pairs/s', cores=cores, kind='port',
+              sample='1 pair fwd+bwd at Cassini 512x256, D=64 (%.1f s), scaled to 1024x512/D=192 by the FLOP ratio %.2f; '
+              'oracle/mode_ref.py on torch CPU' % (t_small, flop_ratio))
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+  assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+
+  import models
+  from mode_hip import data_parallel, profiling
+  import mode_hip
+  mode_hip.lib()  # fail loudly if the native library is missing
+
+  torch.manual_seed(0)
+  net = models.ModeDisparity(args.maxdisp, 'Sphere', args.height, args.width, 'Cassini').to(dev)
+  reducer = data_parallel.GradAllReducer(net)
+  reducer.broadcast_parameters(net)
+  opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
+  left, right, gt = synthetic_batch(args.batch, args.height, args.width, args.maxdisp, dev, seed=1234 + rank)
+  mask = ~torch.isnan(gt)
+  gt0 = torch.nan_to_num(gt)
+
+  def train_step():
+    reducer.zero_grad()
+    o1, o2, o3 = net(left, right)
+    loss = 0
+    for wgt, o in ((0.5, o1), (0.7, o2), (1.0, o3)):
+      loss = loss + wgt * data_parallel.global_masked_mean(F.smooth_l1_loss(o, gt0, reduction='none'), mask)
+    loss.backward()
+    reducer.all_reduce()
+    opt.step()
+    return loss
+
+  def eval_step():
+    with torch.no_grad():
+      return net(left, right)
+
+  if args.mode == 'train':
+    net.train()
+    step = train_step
+  else:
+    net.eval()
+    step = eval_step
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step()
+  fence()
+  profiling.enable(not args.no_kernel_timing)
+  t0 = time.time()
+  for _ in range(args.steps):
+    step()
+  fence()
+  elapsed = time.time() - t0
+  kern = profiling.summary()
+  profiling.enable(False)
+  if world > 1:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+
+  if rank == 0:
+    pairs = args.batch * world * args.steps
+    out = {
+        'metric': 'ERP stereo pairs/sec (512x1024, 192 disp) fwd+bwd' if args.mode == 'train' else 'ERP stereo pairs/sec (512x1024, 192 disp) fwd',
+        'value': pairs / elapsed,
+        'unit': 'pairs/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'ModeDisparity(%d,Sphere,%dx%d Cassini) %s step, batch %d/GPU (BASELINE configs[%d])' %
+                        (args.maxdisp, args.height, args.width, 'fwd+bwd+Adam' if args.mode == 'train' else 'eval fwd',
+                         args.batch, 2 if world == 1 else 3),
+            'global_batch': args.batch * world,
+            'parallelism': 'dp%d' % world,
+            'stage3d_backend': models.stage3d.BACKEND,
+        },
+    }
+    if kern:
+      dom = max(kern, key=lambda k: kern[k]['total_ms'])
+      a = kern[dom]
+      bound = KERNEL_BOUND.get(dom, 'mfma')
+      if bound == 'hbm':
+        achieved, peak, unit = a['GBps'], HBM_PEAK_GBPS, 'GB/s'
+      else:
+        achieved, peak, unit = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+      out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
+                         'frac': achieved / peak, 'traffic': None, 'avg_ms': a['avg_ms'], 'calls': a['calls']}
+      out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
+                            'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}
+    else:
+      out['roofline'] = None
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(args)
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

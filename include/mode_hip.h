@@ -1,0 +1,105 @@
+/*
+ * mode_hip.h -- C-ABI of libmode_hip.so: the MI355X (gfx950) kernels of MODE's disparity-stage hot path.
+ *
+ * Drop-in boundary.  The reference binds its native code through a two-function pybind11 module
+ * (models/basic/spherical_conv/src/sphere_conv_cuda.cpp:339-345) that takes ATen tensors.  This
+ * library is what a reference-side binding (ctypes / pybind / cgo) binds instead: plain device
+ * pointers, sizes and a HIP stream -- no torch types.  Each entry point cites the reference
+ * interface it replaces; paths are relative to the upstream repository root.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to a contiguous fp32 buffer allocated by the caller
+ *     (the reference requires contiguous tensors too: sphere_conv_cuda.cpp:48, 138-140);
+ *   - the library never allocates or keeps device memory; scratch is passed in as `workspace`;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *     the call returns without synchronising (reference: at::cuda::getCurrentCUDAStream(),
+ *     sphere_conv_cuda_kernel.cu:280, 374);
+ *   - the return value is MODE_OK (0) or a negative MODE_ERR_* code for rejected arguments /
+ *     a positive hipError_t for a launch failure; mode_last_error() returns a description.  The
+ *     reference throws c10::Error on bad shapes (sphere_conv_cuda.cpp:43-125) but only printf()s
+ *     launch errors (sphere_conv_cuda_kernel.cu:286-289); the Python binding raises RuntimeError
+ *     for every non-zero code;
+ *   - re-entrant across devices and threads: no global mutable state except the thread-local
+ *     error string (nn.DataParallel calls forward from one thread per GPU).
+ */
+#ifndef MODE_HIP_H_
+#define MODE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mode_stream_t; /* hipStream_t */
+
+enum {
+  MODE_OK = 0,
+  MODE_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, inconsistent shapes */
+  MODE_ERR_UNSUPPORTED = -2,  /* valid request outside what the kernels implement */
+  MODE_ERR_WORKSPACE = -3     /* workspace missing or too small */
+};
+
+/* Version / diagnostics. */
+int mode_hip_abi_version(void);
+const char* mode_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spherical convolution.
+ *
+ * Replaces sphere_conv_forward_cuda (sphere_conv_cuda.cpp:129-210 = per-sample im2col kernel
+ * sphere_conv_cuda_kernel.cu:195-262 + addmm_) with ONE fused launch: the bilinear gather writes
+ * the column tile to LDS and the contraction over Ci*Kh*Kw runs on fp32 MFMA; no HBM column buffer.
+ *
+ *   x   (B, Ci, H, W)            pos (1, 2*Kh*Kw, H, W): channel 2k = row coordinate, 2k+1 = column
+ *   w   (Co, Ci/groups, Kh, Kw)  coordinate of tap k, sampled at (h_out*sH, w_out*sW)
+ *   y   (B, Co, Ho, Wo)          written (not accumulated)
+ *
+ * `wpack` is scratch for the MFMA-fragment-ordered copy of the weights, >= mode_sphere_conv_wpack_bytes().
+ * padding / dilation only enter the output-size formula (sphere_conv.py:112-113), so the caller
+ * passes Ho, Wo.
+ */
+size_t mode_sphere_conv_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups);
+
+int mode_sphere_conv_fwd(const float* x, const float* pos, const float* w, float* y, float* wpack,
+                         int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW,
+                         int Ho, int Wo, int groups, mode_stream_t stream);
+
+/* Replaces the grad_input half of sphere_conv_backward_cuda (sphere_conv_cuda.cpp:275-294:
+ * addmm_(W^T, gO) + col2im kernel sphere_conv_cuda_kernel.cu:293-356).  ACCUMULATES into gx, which
+ * the caller zero-fills first, exactly like the reference (sphere_conv.py:62). */
+int mode_sphere_conv_bwd_data(const float* gy, const float* pos, const float* w, float* gx, float* wpack,
+                              int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW,
+                              int Ho, int Wo, int groups, mode_stream_t stream);
+
+/* Replaces the grad_weight half (sphere_conv_cuda.cpp:296-315: second im2col + addmm_(gO, col^T),
+ * summed over the batch).  ACCUMULATES into gw (caller zero-fills, sphere_conv.py:63).  `workspace`
+ * holds the deterministic split-K partial sums: >= mode_sphere_conv_bwd_weight_workspace_bytes(). */
+size_t mode_sphere_conv_bwd_weight_workspace_bytes(int B, int Ci, int Co, int Kh, int Kw, int Ho, int Wo,
+                                                   int groups);
+
+int mode_sphere_conv_bwd_weight(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW,
+                                int Ho, int Wo, int groups, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Concatenation cost volume -- replaces the Python loop models/mode_disparity.py:104-113
+ * (host-side zero tensor + H2D copy + 2*D4 strided slice copies + .contiguous()).
+ *
+ *   ref, tgt (B, C, H, W)  ->  cost (B, 2C, D4, H, W):
+ *   cost[b, c, i, h, w] = ref[b, c, h, w], cost[b, C+c, i, h, w] = tgt[b, c, h, w-i] for w >= i, else 0.
+ * Every output element is written exactly once (no memset).
+ */
+int mode_cost_volume_fwd(const float* ref, const float* tgt, float* cost, int B, int C, int D4, int H, int W,
+                         mode_stream_t stream);
+
+/* Autograd of the loop above: g_ref[b,c,h,w] = sum_{i<=w} g[b,c,i,h,w];
+ * g_tgt[b,c,h,w] = sum_{i<W-w} g[b,C+c,i,h,w+i].  Writes (does not accumulate). */
+int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, int C, int D4, int H, int W,
+                         mode_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODE_HIP_H_ */

@@ -1,0 +1,55 @@
+// Shared host-side helpers for libmode_hip.so (gfx950 only; no CUDA path, no dual-platform macros).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "mode_hip.h"
+
+namespace mode {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return MODE_OK;
+}
+
+inline hipStream_t as_stream(mode_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Dynamic LDS above 64 KiB must be opted into per kernel (gfx950 has 160 KiB per CU).
+template <typename K>
+inline int allow_lds(K kernel, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return MODE_OK;
+  if (bytes > 160 * 1024) {
+    set_error("%s: needs %zu B of LDS (> 160 KiB)", what, bytes);
+    return MODE_ERR_UNSUPPORTED;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
+    return (int)e;
+  }
+  return MODE_OK;
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mode
+
+#define MODE_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::mode::set_error(__VA_ARGS__);  \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// MI355X: 256 CUs in 8 XCDs; block b is dispatched to XCD b % 8 (performance hint only).
+constexpr int kNumCU = 256;
+constexpr int kNumXCD = 8;

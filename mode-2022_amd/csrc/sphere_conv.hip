@@ -1,0 +1,515 @@
+// Spherical convolution for gfx950 (MI355X): fused bilinear gather + fp32-MFMA contraction.
+//
+// Reference being replaced (paths relative to the upstream repo):
+//   models/basic/spherical_conv/src/sphere_conv_cuda_kernel.cu:195-262  im2col gather (K1)
+//   models/basic/spherical_conv/src/sphere_conv_cuda_kernel.cu:293-356  col2im atomic scatter (K2)
+//   models/basic/spherical_conv/src/sphere_conv_cuda.cpp:129-336        per-sample loops + cuBLAS addmm_ (K3-K5)
+// The reference materialises a (Ci*Kh*Kw) x (Ho*Wo) column buffer in HBM per sample and per layer (151 MB at
+// 128 channels, 256x128) and runs SGEMM on it.  Here the column tile only ever exists in LDS:
+//
+//   forward      y[o, p]      = sum_kk W[o, kk] * col[kk, p]            D[i=o ][j=p ]   A = packed W (global/L2)
+//   bwd-data     gcol[kk, p]  = sum_o  W[o, kk] * gy[o, p]  -> scatter   D[i=kk][j=p ]   A = packed W^T, B = gy tile (LDS)
+//   bwd-weight   gW[o, kk]    = sum_p  gy[o, p] * col[kk, p]             D[i=o ][j=kk]   A = gy tile, B = col tile (LDS)
+//
+// with kk = c*Kh*Kw + tap, p = linear output pixel, all on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak).
+// Per output pixel and tap the sampling record (clamped corner offset + 4 bilinear weights with the per-corner
+// zero padding of cu:96-107 folded in) is computed once per tile into LDS and shared by every channel.
+//
+// MFMA operand maps (32x32x2 f32): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; it receives
+// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31] in accumulator register r (r = 0..15).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int P = 64;          // output pixels per tile (2 MFMA column tiles)
+constexpr int CCH = 8;         // input channels per forward K-chunk
+constexpr int NTHREADS = 256;  // 4 waves: one 32-row MFMA tile each
+
+struct Dims {
+  int B, Ci, H, W, Co, KK, sH, sW, Ho, Wo, G;
+  int Cig, Cog;   // channels per group
+  int npix;       // Ho*Wo
+  int tps;        // pixel tiles per sample
+  int MT;         // 32-row tiles over Cog
+  int NCHUNK;     // forward K-chunks (CCH channels each)
+  int CB;         // channels per 128-row block (bwd): floor(128 / KK)
+  int NB;         // such blocks over Cig
+  int KSQ;        // k-step quads over Cog (bwd-data): ceil(Cog / 8)
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sampling records.  tap_off: bits 0-29 offset of the (clamped) top-left corner, bit 30 = step to the right
+// corner (0/1), bit 31 = step to the lower row (0/1).  tap_w = weights of (top-left, top-right, bottom-left,
+// bottom-right) with invalid corners zeroed (cu:96-107) and the whole tap zeroed outside (-1,H)x(-1,W) (cu:246).
+__device__ __forceinline__ void compute_tapinfo(const float* __restrict__ pos, const Dims& d, int pix0,
+                                                unsigned* tap_off, float4* tap_w) {
+  const int HW = d.H * d.W;
+  for (int item = threadIdx.x; item < d.KK * P; item += NTHREADS) {
+    const int k = item / P;
+    const int p = item % P;
+    const int pix = pix0 + p;
+    unsigned off = 0;
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix < d.npix) {
+      const int ho = pix / d.Wo;
+      const int wo = pix - ho * d.Wo;
+      const int idx = (ho * d.sH) * d.W + wo * d.sW;
+      const float h = pos[(2 * k) * HW + idx];
+      const float w = pos[(2 * k + 1) * HW + idx];
+      if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
+        const float hf = floorf(h), wf = floorf(w);
+        const int hl = (int)hf, wl = (int)wf;
+        const int hh = hl + 1, wh = wl + 1;
+        const float lh = h - hf, lw = w - wf;
+        const float uh = 1.f - lh, uw = 1.f - lw;
+        wt.x = (hl >= 0 && wl >= 0) ? uh * uw : 0.f;
+        wt.y = (hl >= 0 && wh <= d.W - 1) ? uh * lw : 0.f;
+        wt.z = (hh <= d.H - 1 && wl >= 0) ? lh * uw : 0.f;
+        wt.w = (hh <= d.H - 1 && wh <= d.W - 1) ? lh * lw : 0.f;
+        const int hlc = max(hl, 0), hhc = min(hh, d.H - 1);
+        const int wlc = max(wl, 0), whc = min(wh, d.W - 1);
+        off = (unsigned)(hlc * d.W + wlc) | ((unsigned)(whc - wlc) << 30) | ((unsigned)(hhc - hlc) << 31);
+      }
+    }
+    tap_off[item] = off;
+    tap_w[item] = wt;
+  }
+}
+
+__device__ __forceinline__ float sample(const float* __restrict__ xc, unsigned po, const float4& tw, int W) {
+  const int off = (int)(po & 0x3fffffffu);
+  const int dw = (int)((po >> 30) & 1u);
+  const int dh = (po >> 31) ? W : 0;
+  // same operand order as cu:111
+  return tw.x * xc[off] + tw.y * xc[off + dw] + tw.z * xc[off + dh] + tw.w * xc[off + dh + dw];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight packing into MFMA A-fragment order (one float4 = the lane's operands of 4 consecutive k-steps).
+//
+// forward:  wp[((g*MT + mt)*NCHUNK + ch)*KK + quad][lane][j] = W[g*Cog + mt*32 + (lane&31)][ch*8 + kl/KK][kl%KK],
+//           kl = 2*(quad*4 + j) + (lane>>5), zero outside the real weight.
+__global__ void pack_w_fwd(const float* __restrict__ w, float* __restrict__ wp, Dims d) {
+  const long long total = (long long)d.G * d.MT * d.NCHUNK * d.KK * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int quad = (int)(r % d.KK);
+    r /= d.KK;
+    const int ch = (int)(r % d.NCHUNK);
+    r /= d.NCHUNK;
+    const int mt = (int)(r % d.MT);
+    const int g = (int)(r / d.MT);
+    const int kl = 2 * (quad * 4 + j) + (lane >> 5);
+    const int c = ch * CCH + kl / d.KK;
+    const int tap = kl % d.KK;
+    const int co = mt * 32 + (lane & 31);
+    float v = 0.f;
+    if (co < d.Cog && c < d.Cig) v = w[((long long)(g * d.Cog + co) * d.Cig + c) * d.KK + tap];
+    wp[idx] = v;
+  }
+}
+
+// bwd-data: wp[(((g*NB + nb)*4 + mtl)*KSQ + ks4)][lane][j] = W[g*Cog + co][nb*CB + rr/KK][rr%KK],
+//           rr = mtl*32 + (lane&31) (< CB*KK), co = 2*(ks4*4 + j) + (lane>>5).
+__global__ void pack_w_bwd(const float* __restrict__ w, float* __restrict__ wp, Dims d) {
+  const long long total = (long long)d.G * d.NB * 4 * d.KSQ * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int ks4 = (int)(r % d.KSQ);
+    r /= d.KSQ;
+    const int mtl = (int)(r & 3);
+    r >>= 2;
+    const int nb = (int)(r % d.NB);
+    const int g = (int)(r / d.NB);
+    const int rr = mtl * 32 + (lane & 31);
+    const int c = nb * d.CB + rr / d.KK;
+    const int tap = rr % d.KK;
+    const int co = 2 * (ks4 * 4 + j) + (lane >> 5);
+    float v = 0.f;
+    if (rr < d.CB * d.KK && c < d.Cig && co < d.Cog) v = w[((long long)(g * d.Cog + co) * d.Cig + c) * d.KK + tap];
+    wp[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward.  grid = (B*tps, ceil(MT/4), G); LDS = KK*P*(16+4) + 2 * CCH*KK*P*4 bytes.
+__global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                               const float4* __restrict__ wp, float* __restrict__ y,
+                                                               Dims d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* tap_w = reinterpret_cast<float4*>(smem);
+  unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
+  float* colbuf = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 20);
+  const int rows = CCH * d.KK;  // column-tile rows per chunk
+
+  const int tile = blockIdx.x;
+  const int b = tile / d.tps;
+  const int pix0 = (tile - b * d.tps) * P;
+  const int g = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int mt = blockIdx.y * 4 + wave;
+  const bool active = mt < d.MT;
+
+  compute_tapinfo(pos, d, pix0, tap_off, tap_w);
+  __syncthreads();
+
+  const int p = tid & (P - 1);
+  const int q = tid / P;  // 0..3 -> channels 2q, 2q+1 of the chunk
+  const long long HW = (long long)d.H * d.W;
+  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
+
+  auto produce = [&](int ch, float* buf) {
+    for (int k = 0; k < d.KK; ++k) {
+      const unsigned po = tap_off[k * P + p];
+      const float4 tw = tap_w[k * P + p];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int cl = q * 2 + cc;
+        const int c = ch * CCH + cl;
+        float v = 0.f;
+        if (c < d.Cig) v = sample(xg + c * HW, po, tw, d.W);
+        buf[(cl * d.KK + k) * P + p] = v;
+      }
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const float4* wpa = wp + ((long long)(g * d.MT + (active ? mt : 0)) * d.NCHUNK) * d.KK * 64 + lane;
+
+  produce(0, colbuf);
+  __syncthreads();
+  for (int ch = 0; ch < d.NCHUNK; ++ch) {
+    float* cur = colbuf + (ch & 1) * rows * P;
+    if (ch + 1 < d.NCHUNK) produce(ch + 1, colbuf + ((ch + 1) & 1) * rows * P);
+    if (active) {
+      const float4* wq = wpa + (long long)ch * d.KK * 64;
+      const float* bp = cur + (lane >> 5) * P + (lane & 31);
+      for (int quad = 0; quad < d.KK; ++quad) {
+        const float4 a4 = wq[quad * 64];
+        const float* bq = bp + quad * 8 * P;
+        acc0 = mfma32(a4.x, bq[0], acc0);
+        acc1 = mfma32(a4.x, bq[32], acc1);
+        acc0 = mfma32(a4.y, bq[2 * P], acc0);
+        acc1 = mfma32(a4.y, bq[2 * P + 32], acc1);
+        acc0 = mfma32(a4.z, bq[4 * P], acc0);
+        acc1 = mfma32(a4.z, bq[4 * P + 32], acc1);
+        acc0 = mfma32(a4.w, bq[6 * P], acc0);
+        acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+    float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co < d.Cog) {
+        const int px = pix0 + (lane & 31);
+        if (px < d.npix) yb[(long long)co * d.npix + px] = acc0[r];
+        if (px + 32 < d.npix) yb[(long long)co * d.npix + px + 32] = acc1[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward w.r.t. the input.  grid = (B*tps, 1, G); LDS = KK*P*20 + KSQ*8*P*4 bytes.
+// gcol rows come out of the MFMA in 128-row blocks (CB channels x KK taps) and are scattered with the same
+// bilinear weights as the forward gather (the transpose of cu:83-113, i.e. what cu:293-356 computes).
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ pos,
+                                                                    const float4* __restrict__ wp, float* __restrict__ gx,
+                                                                    Dims d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* tap_w = reinterpret_cast<float4*>(smem);
+  unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
+  float* gyl = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 20);  // [KSQ*8][P]
+
+  const int tile = blockIdx.x;
+  const int b = tile / d.tps;
+  const int pix0 = (tile - b * d.tps) * P;
+  const int g = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+
+  compute_tapinfo(pos, d, pix0, tap_off, tap_w);
+  const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+  for (int idx = tid; idx < d.KSQ * 8 * P; idx += NTHREADS) {
+    const int co = idx / P, p = idx % P;
+    float v = 0.f;
+    if (co < d.Cog && pix0 + p < d.npix) v = gyb[(long long)co * d.npix + pix0 + p];
+    gyl[idx] = v;
+  }
+  __syncthreads();
+
+  const long long HW = (long long)d.H * d.W;
+  float* gxg = gx + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
+  const float* bp = gyl + (lane >> 5) * P + (lane & 31);
+  const int nrows = d.CB * d.KK;
+
+  for (int nb = 0; nb < d.NB; ++nb) {
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float4* wq = wp + ((long long)((g * d.NB + nb) * 4 + wave) * d.KSQ) * 64 + lane;
+    for (int ks4 = 0; ks4 < d.KSQ; ++ks4) {
+      const float4 a4 = wq[ks4 * 64];
+      const float* bq = bp + ks4 * 8 * P;
+      acc0 = mfma32(a4.x, bq[0], acc0);
+      acc1 = mfma32(a4.x, bq[32], acc1);
+      acc0 = mfma32(a4.y, bq[2 * P], acc0);
+      acc1 = mfma32(a4.y, bq[2 * P + 32], acc1);
+      acc0 = mfma32(a4.z, bq[4 * P], acc0);
+      acc1 = mfma32(a4.z, bq[4 * P + 32], acc1);
+      acc0 = mfma32(a4.w, bq[6 * P], acc0);
+      acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int cl = rr / d.KK;
+      const int k = rr - cl * d.KK;
+      const int c = nb * d.CB + cl;
+      if (rr < nrows && c < d.Cig) {
+        float* gxc = gxg + c * HW;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int pp = nt * 32 + (lane & 31);
+          const float v = nt ? acc1[r] : acc0[r];
+          const unsigned po = tap_off[k * P + pp];
+          const float4 tw = tap_w[k * P + pp];
+          const int off = (int)(po & 0x3fffffffu);
+          const int dw = (int)((po >> 30) & 1u);
+          const int dh = (po >> 31) ? d.W : 0;
+          if (tw.x != 0.f) atomicAdd(gxc + off, tw.x * v);
+          if (tw.y != 0.f) atomicAdd(gxc + off + dw, tw.y * v);
+          if (tw.z != 0.f) atomicAdd(gxc + off + dh, tw.z * v);
+          if (tw.w != 0.f) atomicAdd(gxc + off + dh + dw, tw.w * v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward w.r.t. the weight.  grid = (S, NB, G*MG); LDS = KK*P*20 + 2 * 128*(P+1)*4 bytes.
+// Split-K over pixel tiles: slice s owns tiles s, s+S, ...; partial[s][g][mg][nb][128][128] is summed by
+// reduce_gw in a fixed order (deterministic, unlike the reference's cuBLAS/atomic path).
+constexpr int PS = P + 1;  // padded row stride: bank = (row*65 + k) % 32 -> conflict-free fragment reads
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ pos,
+                                                                      const float* __restrict__ x, float* __restrict__ part,
+                                                                      Dims d, int S, int MG) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* tap_w = reinterpret_cast<float4*>(smem);
+  unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
+  float* gyl = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 20);  // [128][PS]
+  float* col = gyl + 128 * PS;                                           // [128][PS]
+
+  const int s = blockIdx.x, nb = blockIdx.y;
+  const int g = blockIdx.z / MG, mg = blockIdx.z % MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p = tid & (P - 1), q = tid / P;
+  const long long HW = (long long)d.H * d.W;
+  const int nrows = d.CB * d.KK;
+  const int T = d.B * d.tps;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x16){0};
+
+  for (int t = s; t < T; t += S) {
+    const int b = t / d.tps;
+    const int pix0 = (t - b * d.tps) * P;
+    compute_tapinfo(pos, d, pix0, tap_off, tap_w);
+    const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+    for (int idx = tid; idx < 128 * P; idx += NTHREADS) {
+      const int row = idx / P, pp = idx % P;
+      const int co = mg * 128 + row;
+      float v = 0.f;
+      if (co < d.Cog && pix0 + pp < d.npix) v = gyb[(long long)co * d.npix + pix0 + pp];
+      gyl[row * PS + pp] = v;
+    }
+    __syncthreads();
+    const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
+    for (int i = 0; i < 32; ++i) {
+      const int rr = q * 32 + i;
+      const int cl = rr / d.KK;
+      const int k = rr - cl * d.KK;
+      const int c = nb * d.CB + cl;
+      float v = 0.f;
+      if (rr < nrows && c < d.Cig) v = sample(xg + c * HW, tap_off[k * P + p], tap_w[k * P + p], d.W);
+      col[rr * PS + p] = v;
+    }
+    __syncthreads();
+    const float* ap = gyl + (wave * 32 + (lane & 31)) * PS + (lane >> 5);
+    const float* bp = col + (lane & 31) * PS + (lane >> 5);
+#pragma unroll 4
+    for (int ks = 0; ks < P / 2; ++ks) {
+      const float a = ap[2 * ks];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma32(a, bp[nt * 32 * PS + 2 * ks], acc[nt]);
+    }
+    __syncthreads();
+  }
+
+  float* pb = part + ((((long long)s * d.G + g) * MG + mg) * d.NB + nb) * (128 * 128);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      pb[i * 128 + nt * 32 + (lane & 31)] = acc[nt][r];
+    }
+}
+
+__global__ void reduce_gw(const float* __restrict__ part, float* __restrict__ gw, Dims d, int S, int MG) {
+  const long long total = (long long)d.Co * d.Cig * d.KK;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % d.KK);
+    long long r = idx / d.KK;
+    const int c = (int)(r % d.Cig);
+    const int o = (int)(r / d.Cig);
+    const int g = o / d.Cog, ol = o % d.Cog;
+    const int mg = ol / 128, row = ol % 128;
+    const int nb = c / d.CB, colr = (c % d.CB) * d.KK + k;
+    const long long stride = (long long)d.G * MG * d.NB * (128 * 128);
+    const float* pp = part + (((long long)g * MG + mg) * d.NB + nb) * (128 * 128) + row * 128 + colr;
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += pp[s * stride];
+    gw[idx] += sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int make_dims(Dims& d, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups,
+              const char* who) {
+  MODE_REQUIRE(B >= 0 && Ci > 0 && H > 0 && W > 0 && Co > 0 && Kh > 0 && Kw > 0 && sH > 0 && sW > 0 && Ho > 0 && Wo > 0 &&
+                   groups > 0,
+               MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(Ci % groups == 0 && Co % groups == 0, MODE_ERR_BAD_ARG, "%s: channels (%d,%d) not divisible by groups %d", who,
+               Ci, Co, groups);
+  // the table is indexed at (h_out*sH, w_out*sW) and must stay inside (H, W)  (sphere_conv_cuda.cpp:107-109)
+  MODE_REQUIRE((long long)(Ho - 1) * sH < H && (long long)(Wo - 1) * sW < W, MODE_ERR_BAD_ARG,
+               "%s: output %dx%d with stride %dx%d reads the position table outside %dx%d", who, Ho, Wo, sH, sW, H, W);
+  MODE_REQUIRE(Kh * Kw <= 32, MODE_ERR_UNSUPPORTED, "%s: kernel %dx%d has more than 32 taps", who, Kh, Kw);
+  MODE_REQUIRE((long long)H * W < (1ll << 30), MODE_ERR_UNSUPPORTED, "%s: image larger than 2^30 pixels", who);
+  d.B = B; d.Ci = Ci; d.H = H; d.W = W; d.Co = Co; d.KK = Kh * Kw; d.sH = sH; d.sW = sW; d.Ho = Ho; d.Wo = Wo; d.G = groups;
+  d.Cig = Ci / groups; d.Cog = Co / groups;
+  d.npix = Ho * Wo;
+  d.tps = mode::cdiv(d.npix, P);
+  d.MT = mode::cdiv(d.Cog, 32);
+  d.NCHUNK = mode::cdiv(d.Cig, CCH);
+  d.CB = 128 / d.KK;
+  d.NB = mode::cdiv(d.Cig, d.CB);
+  d.KSQ = mode::cdiv(d.Cog, 8);
+  return MODE_OK;
+}
+
+size_t wpack_floats(const Dims& d) {
+  const size_t f = (size_t)d.G * d.MT * d.NCHUNK * d.KK * 256;
+  const size_t bw = (size_t)d.G * d.NB * 4 * d.KSQ * 256;
+  return f > bw ? f : bw;
+}
+
+int bww_splits(const Dims& d, int MG) {
+  const int T = d.B * d.tps;
+  int S = mode::cdiv(768, d.NB * d.G * MG);
+  if (S > T) S = T;
+  if (S < 1) S = 1;
+  return S;
+}
+
+}  // namespace
+
+extern "C" size_t mode_sphere_conv_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups) {
+  Dims d;
+  if (make_dims(d, 1, Ci, 1 << 14, 1 << 14, Co, Kh, Kw, 1, 1, 1, 1, groups, "mode_sphere_conv_wpack_bytes") != MODE_OK) return 0;
+  return wpack_floats(d) * sizeof(float);
+}
+
+extern "C" int mode_sphere_conv_fwd(const float* x, const float* pos, const float* w, float* y, float* wpack, int B, int Ci,
+                                    int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups,
+                                    mode_stream_t stream) {
+  MODE_REQUIRE(x && pos && w && y && wpack, MODE_ERR_BAD_ARG, "mode_sphere_conv_fwd: null pointer");
+  Dims d;
+  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, "mode_sphere_conv_fwd");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  hipStream_t st = mode::as_stream(stream);
+  const long long npack = (long long)d.G * d.MT * d.NCHUNK * d.KK * 256;
+  hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)CCH * d.KK * P * 4;
+  rc = mode::allow_lds(sphere_fwd_kernel, lds, "mode_sphere_conv_fwd");
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_fwd_kernel, dim3(B * d.tps, mode::cdiv(d.MT, 4), d.G), dim3(NTHREADS), lds, st, x, pos,
+                     reinterpret_cast<const float4*>(wpack), y, d);
+  return mode::check_launch("mode_sphere_conv_fwd");
+}
+
+extern "C" int mode_sphere_conv_bwd_data(const float* gy, const float* pos, const float* w, float* gx, float* wpack, int B,
+                                         int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
+                                         int groups, mode_stream_t stream) {
+  MODE_REQUIRE(gy && pos && w && gx && wpack, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_data: null pointer");
+  Dims d;
+  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, "mode_sphere_conv_bwd_data");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  hipStream_t st = mode::as_stream(stream);
+  const long long npack = (long long)d.G * d.NB * 4 * d.KSQ * 256;
+  hipLaunchKernelGGL(pack_w_bwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  const size_t lds = (size_t)d.KK * P * 20 + (size_t)d.KSQ * 8 * P * 4;
+  rc = mode::allow_lds(sphere_bwd_data_kernel, lds, "mode_sphere_conv_bwd_data (Co/groups too large)");
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_bwd_data_kernel, dim3(B * d.tps, 1, d.G), dim3(NTHREADS), lds, st, gy, pos,
+                     reinterpret_cast<const float4*>(wpack), gx, d);
+  return mode::check_launch("mode_sphere_conv_bwd_data");
+}
+
+extern "C" size_t mode_sphere_conv_bwd_weight_workspace_bytes(int B, int Ci, int Co, int Kh, int Kw, int Ho, int Wo,
+                                                              int groups) {
+  Dims d;
+  if (make_dims(d, B, Ci, 1 << 14, 1 << 14, Co, Kh, Kw, 1, 1, Ho, Wo, groups, "mode_sphere_conv_bwd_weight_workspace_bytes") !=
+      MODE_OK)
+    return 0;
+  const int MG = mode::cdiv(d.Cog, 128);
+  return (size_t)bww_splits(d, MG) * d.G * MG * d.NB * 128 * 128 * sizeof(float);
+}
+
+extern "C" int mode_sphere_conv_bwd_weight(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                           int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
+                                           int groups, mode_stream_t stream) {
+  MODE_REQUIRE(gy && pos && x && gw, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight: null pointer");
+  MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_sphere_conv_bwd_weight: workspace required");
+  Dims d;
+  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, "mode_sphere_conv_bwd_weight");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  hipStream_t st = mode::as_stream(stream);
+  const int MG = mode::cdiv(d.Cog, 128);
+  const int S = bww_splits(d, MG);
+  const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)128 * PS * 4;
+  rc = mode::allow_lds(sphere_bwd_weight_kernel, lds, "mode_sphere_conv_bwd_weight");
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_bwd_weight_kernel, dim3(S, d.NB, d.G * MG), dim3(NTHREADS), lds, st, gy, pos, x, workspace, d, S,
+                     MG);
+  rc = mode::check_launch("mode_sphere_conv_bwd_weight");
+  if (rc != MODE_OK) return rc;
+  const long long n = (long long)d.Co * d.Cig * d.KK;
+  hipLaunchKernelGGL(reduce_gw, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, MG);
+  return mode::check_launch("mode_sphere_conv_bwd_weight(reduce)");
+}

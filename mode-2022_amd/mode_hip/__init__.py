@@ -1,0 +1,81 @@
+"""ctypes binding of libmode_hip.so (C-ABI declared in include/mode_hip.h).
+
+This is the only place that touches the native library.  There is NO fallback: if the library is
+missing or a tensor is not on a GPU, the call raises.  PyTorch is used for device memory and
+streams only (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmode_hip.so')
+
+_c_int = ctypes.c_int
+_c_ptr = ctypes.c_void_p
+_c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mode_hip.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    'mode_hip_abi_version': (_c_int, []),
+    'mode_last_error': (ctypes.c_char_p, []),
+    'mode_sphere_conv_wpack_bytes': (_c_size, [_c_int] * 5),
+    'mode_sphere_conv_fwd': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_bwd_data': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
+    'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
+    'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
+    'mode_cost_volume_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+  """Load (once) and return the native library; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    with _lock:
+      if _lib is None:
+        if not os.path.exists(LIB_PATH):
+          raise RuntimeError('libmode_hip.so is not built (%s missing): run `python -c "import __graft_entry__ as g; '
+                             'g.build()"` or `python mode-2022_amd/mode_hip/build.py`' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+          fn = getattr(handle, name)
+          fn.restype = res
+          fn.argtypes = args
+        _lib = handle
+  return _lib
+
+
+def check(rc, what):
+  if rc != 0:
+    msg = lib().mode_last_error()
+    raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+  return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+  return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+  """Same refusal as the reference op (sphere_conv.py:33-34): no CPU path exists."""
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise NotImplementedError('Only support cuda tensor!')
+
+
+def require_f32c(*tensors):
+  for t in tensors:
+    if t.dtype != torch.float32:
+      raise TypeError('libmode_hip kernels are fp32 (got %s)' % t.dtype)
+    if not t.is_contiguous():
+      raise ValueError('libmode_hip kernels need contiguous tensors')

@@ -1,0 +1,66 @@
+"""Build libmode_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python mode-2022_amd/mode_hip/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+INCLUDE = os.path.join(ROOT, 'include')
+OBJ = os.path.join(CSRC, 'obj')
+LIB = os.path.join(HERE, 'libmode_hip.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
+         '-I' + INCLUDE, '-I' + CSRC]
+
+
+def sources():
+  return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _deps_mtime():
+  hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+  hs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+  hs.append(os.path.abspath(__file__))
+  return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+  obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+  if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
+    return obj, False
+  cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  if r.returncode != 0:
+    raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+  if r.stderr.strip():
+    sys.stderr.write(r.stderr)
+  return obj, True
+
+
+def build(force=False, verbose=True):
+  os.makedirs(OBJ, exist_ok=True)
+  srcs = sources()
+  with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    results = list(ex.map(lambda s: _compile(s, force), srcs))
+  objs = [o for o, _ in results]
+  if force or any(c for _, c in results) or not os.path.exists(LIB):
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError('link failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+    if verbose:
+      print('built', LIB)
+  elif verbose:
+    print('up to date', LIB)
+  return LIB
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

@@ -1,0 +1,88 @@
+"""Native seam of the spherical-convolution operator, MI355X edition.
+
+The reference imports a compiled pybind11 module of this name (sphere_conv.py:12) exposing
+``sphere_conv_forward_cuda`` / ``sphere_conv_backward_cuda`` (sphere_conv_cuda.cpp:339-345).  This
+module exposes the same two callables with the same positional arguments, so code written against
+the reference extension keeps working; the work is done by libmode_hip.so (hand-written gfx950
+kernels behind a C-ABI, include/mode_hip.h).  The module name is kept for drop-in compatibility only:
+there is no CUDA code path.
+
+Argument semantics follow the reference:
+  * ``ones`` and ``columns`` are caller-owned scratch tensors that the reference re-allocates
+    internally (cpp:164-175); they are accepted and ignored (no column buffer exists here);
+  * ``output`` is written in place; ``grad_input`` / ``grad_weight`` / ``grad_bias`` are
+    accumulated into and must be zero-filled by the caller (sphere_conv.py:62-64);
+  * pad / dilation only take part in the output-size check (cpp:159-162);
+  * shape violations raise RuntimeError (TORCH_CHECK / AT_ERROR in cpp:40-126, 152-157).
+"""
+import torch
+
+from mode_hip import functional as _F
+
+
+def _out_hw(h, w, kh, kw, sh, sw, ph, pw, dh, dw):
+  return ((h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
+
+
+def _shape_check(input, position, grad_output, weight, kH, kW, sH, sW, pH, pW, dH, dW, group):
+  """shape_check, sphere_conv_cuda.cpp:40-126."""
+  if weight.dim() != 4:
+    raise RuntimeError('4D weight tensor (nOutputPlane,nInputPlane,kH,kW) expected, but got: %d' % weight.dim())
+  if not weight.is_contiguous():
+    raise RuntimeError('weight tensor has to be contiguous')
+  if kW <= 0 or kH <= 0:
+    raise RuntimeError('kernel size should be greater than zero, but got kH: %d kW: %d' % (kH, kW))
+  if weight.size(2) != kH or weight.size(3) != kW:
+    raise RuntimeError('kernel size should be consistent with weight, but got kH: %d kW: %d weight.size(2): %d, '
+                       'weight.size(3): %d' % (kH, kW, weight.size(2), weight.size(3)))
+  if sW <= 0 or sH <= 0:
+    raise RuntimeError('stride should be greater than zero, but got dH: %d dW: %d' % (sH, sW))
+  if dW <= 0 or dH <= 0:
+    raise RuntimeError('dilation should be greater than 0, but got dilationH: %d dilationW: %d' % (dH, dW))
+  if input.dim() != 4:
+    raise RuntimeError('3D or 4D input tensor expected but got: %d' % input.dim())
+  n_in = weight.size(1) * group
+  H, W = input.size(2), input.size(3)
+  Ho, Wo = _out_hw(H, W, kH, kW, sH, sW, pH, pW, dH, dW)
+  if Ho < 1 or Wo < 1:
+    raise RuntimeError('Given input size: (%d x %d x %d). Calculated output size: (%d x %d x %d). Output size is too small' %
+                       (n_in, H, W, weight.size(0), Ho, Wo))
+  if input.size(1) != n_in:
+    raise RuntimeError('invalid number of input planes, expected: %d, but got: %d' % (n_in, input.size(1)))
+  if H < kH or W < kW:
+    raise RuntimeError('input image is smaller than kernel')
+  if position.size(2) != H or position.size(3) != W:
+    raise RuntimeError('invalid spatial size of position, expected height: %d, width: %d, BUT got height: %d, width: %d' %
+                       (H, W, position.size(2), position.size(3)))
+  if position.size(1) != 2 * kH * kW:
+    raise RuntimeError('invalid number of channels of position')
+  if grad_output is not None:
+    if grad_output.size(1) != weight.size(0):
+      raise RuntimeError('invalid number of gradOutput planes, expected: %d, but got: %d' % (weight.size(0), grad_output.size(1)))
+    if grad_output.size(2) != Ho or grad_output.size(3) != Wo:
+      raise RuntimeError('invalid size of gradOutput, expected height: %d width: %d , but got height: %d width: %d' %
+                         (Ho, Wo, grad_output.size(2), grad_output.size(3)))
+  return Ho, Wo
+
+
+def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, columns, kernel_h, kernel_w, stride_h, stride_w,
+                             pad_h, pad_w, dilation_h, dilation_w, group, has_bias):
+  Ho, Wo = _shape_check(input, position, None, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
+                        dilation_w, group)
+  if tuple(output.shape) != (input.size(0), weight.size(0), Ho, Wo):
+    raise RuntimeError('output has shape %s, expected %s' % (tuple(output.shape), (input.size(0), weight.size(0), Ho, Wo)))
+  _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group)
+  if has_bias:
+    output += bias.view(1, -1, 1, 1)  # cpp:207-209
+
+
+def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad_input, grad_weight, grad_bias, grad_output,
+                              kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, has_bias):
+  _shape_check(input, position, grad_output, grad_weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
+               dilation_w, group)
+  gy = grad_output.contiguous()
+  pos = position.contiguous()
+  _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group)
+  _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group)
+  if has_bias:
+    grad_bias += gy.sum((0, 2, 3))  # cpp:316-322

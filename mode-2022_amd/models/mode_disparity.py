@@ -1,0 +1,119 @@
+"""ModeDisparity -- the disparity stage of MODE on MI355X.
+
+Drop-in for the reference's models/mode_disparity.py: same constructor, ``forward(left, right)`` contract
+(train: (pred1, pred2, pred3); eval: pred3, or (pred3, confidence) with out_conf=True), same module tree and
+therefore the same 483 state_dict entries.  The forward pass itself is re-organised around the hand-written
+gfx950 kernels of libmode_hip.so: spherical convolutions (inside the feature extractor), the single-pass cost
+volume, and -- see ``stage3d`` -- the 3D regulariser and the fused soft-argmin head.
+"""
+from __future__ import print_function
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mode_hip import functional as HF
+
+from . import stage3d
+from .submodule import convbn_3d, feature_extraction, sphere_feature_extraction
+
+
+class hourglass(nn.Module):
+  """Encoder-decoder 3D block (mode_disparity.py:11-46): two stride-2 convs down, two transposed convs up, with
+  skip connections from an earlier hourglass (presqu/postsqu)."""
+
+  def __init__(self, inplanes):
+    super(hourglass, self).__init__()
+    c2 = inplanes * 2
+    self.conv1 = nn.Sequential(convbn_3d(inplanes, c2, kernel_size=3, stride=2, pad=1), nn.ReLU(inplace=True))
+    self.conv2 = convbn_3d(c2, c2, kernel_size=3, stride=1, pad=1)
+    self.conv3 = nn.Sequential(convbn_3d(c2, c2, kernel_size=3, stride=2, pad=1), nn.ReLU(inplace=True))
+    self.conv4 = nn.Sequential(convbn_3d(c2, c2, kernel_size=3, stride=1, pad=1), nn.ReLU(inplace=True))
+    self.conv5 = nn.Sequential(nn.ConvTranspose3d(c2, c2, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                               nn.BatchNorm3d(c2))
+    self.conv6 = nn.Sequential(nn.ConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                               nn.BatchNorm3d(inplanes))
+
+  def forward(self, x, presqu, postsqu):
+    out = stage3d.conv_bn(self.conv1[0], x, relu=True)  # 1/4 -> 1/8
+    pre = stage3d.conv_bn(self.conv2, out, relu=True, add=postsqu)  # relu(bn(conv) [+ postsqu])
+    out = stage3d.conv_bn(self.conv3[0], pre, relu=True)  # 1/8 -> 1/16
+    out = stage3d.conv_bn(self.conv4[0], out, relu=True)
+    post = stage3d.conv_bn(self.conv5, out, relu=True, add=presqu if presqu is not None else pre)  # 1/16 -> 1/8
+    out = stage3d.conv_bn(self.conv6, post)  # 1/8 -> 1/4
+    return out, pre, post
+
+
+class ModeDisparity(nn.Module):
+  """in_height, in_width: input image shape -- (1024,512) for Deep360, (640,320) fisheye, (512,256) 3D60."""
+
+  def __init__(self, maxdisp, conv='Sphere', in_height=1024, in_width=512, sphereType='Cassini', out_conf=False):
+    super(ModeDisparity, self).__init__()
+    print("MODE stereo matching network!")
+    self.maxdisp = maxdisp
+    self.out_conf = out_conf
+    if conv == 'Regular':
+      self.feature_extraction = feature_extraction()
+      print("using Regular feature extraction!")
+    elif conv == 'Sphere':
+      self.feature_extraction = sphere_feature_extraction(in_height, in_width, sphereType)
+      print("using Spherical feature extraction!")
+    else:
+      raise NotImplementedError("Convolution Type must be Regular or Sphere!")
+
+    relu = lambda: nn.ReLU(inplace=True)
+    self.dres0 = nn.Sequential(convbn_3d(64, 32, 3, 1, 1), relu(), convbn_3d(32, 32, 3, 1, 1), relu())
+    self.dres1 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), relu(), convbn_3d(32, 32, 3, 1, 1))
+    self.dres2 = hourglass(32)
+    self.dres3 = hourglass(32)
+    self.dres4 = hourglass(32)
+    for i in (1, 2, 3):
+      setattr(self, 'classif%d' % i,
+              nn.Sequential(convbn_3d(32, 32, 3, 1, 1), relu(), nn.Conv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False)))
+    self._psmnet_init()
+
+  def _psmnet_init(self):
+    """mode_disparity.py:82-96: Conv2d/Conv3d ~ N(0, sqrt(2/(prod(kernel)*Cout))), BN gamma=1 beta=0; SphereConv and
+    ConvTranspose3d keep their own default initialisation."""
+    for m in self.modules():
+      if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+        n = m.out_channels
+        for k in m.kernel_size:
+          n *= k
+        m.weight.data.normal_(0, math.sqrt(2. / n))
+      elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+        m.weight.data.fill_(1)
+        m.bias.data.zero_()
+      elif isinstance(m, nn.Linear):
+        m.bias.data.zero_()
+
+  def forward(self, left, right):
+    ref_fea = self.feature_extraction(left)
+    tgt_fea = self.feature_extraction(right)
+
+    cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
+
+    cost0 = stage3d.conv_bn(self.dres0[0], cost, relu=True)
+    cost0 = stage3d.conv_bn(self.dres0[2], cost0, relu=True)
+    t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
+    cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
+
+    out1, pre1, post1 = self.dres2(cost0, None, None)
+    out1 = out1 + cost0
+    out2, pre2, post2 = self.dres3(out1, pre1, post1)
+    out2 = out2 + cost0
+    out3, pre3, post3 = self.dres4(out2, pre1, post2)  # pre1 (not pre2), as in the reference (:124)
+    out3 = out3 + cost0
+
+    cost1 = stage3d.classify(self.classif1, out1)
+    cost2 = stage3d.classify(self.classif2, out2) + cost1
+    cost3 = stage3d.classify(self.classif3, out3) + cost2
+
+    size = (self.maxdisp, left.size(2), left.size(3))
+    if self.training:
+      return stage3d.head(cost1, size), stage3d.head(cost2, size), stage3d.head(cost3, size)
+    if self.out_conf:
+      return stage3d.head(cost3, size, with_confidence=True)
+    return stage3d.head(cost3, size)

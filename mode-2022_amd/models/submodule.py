@@ -1,0 +1,177 @@
+"""Sub-networks of the disparity stage (module tree and state_dict names of the reference's
+models/submodule.py; regular 2D convolutions run on the vendor library, spherical ones on libmode_hip)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .basic import SphereConv
+
+
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+  """Conv2d (no bias) + BatchNorm2d; a dilated conv pads by its dilation (submodule.py:15-17)."""
+  return nn.Sequential(
+      nn.Conv2d(in_planes, out_planes, kernel_size, stride, dilation if dilation > 1 else pad, dilation, bias=False),
+      nn.BatchNorm2d(out_planes))
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+  """Conv3d (no bias) + BatchNorm3d (submodule.py:20-22)."""
+  return nn.Sequential(nn.Conv3d(in_planes, out_planes, kernel_size, stride, pad, bias=False), nn.BatchNorm3d(out_planes))
+
+
+def sphereConvbn(in_height, in_width, sphereType, in_planes, out_planes, kernel_size, stride, pad, dilation):
+  """SphereConv (no bias) + BatchNorm2d (submodule.py:61-74)."""
+  return nn.Sequential(
+      SphereConv(in_height, in_width, sphereType, in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                 padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False), nn.BatchNorm2d(out_planes))
+
+
+def sphereConvbnrelu(in_height, in_width, sphereType, in_planes, out_planes, kernel_size, stride, pad, dilation):
+  seq = sphereConvbn(in_height, in_width, sphereType, in_planes, out_planes, kernel_size, stride, pad, dilation)
+  seq.add_module('2', nn.ReLU(inplace=True))
+  return seq
+
+
+class disparityregression(nn.Module):
+  """Expectation over the disparity axis (submodule.py:50-57).  Kept for API compatibility; ModeDisparity
+  itself uses the fused head."""
+
+  def __init__(self, maxdisp):
+    super(disparityregression, self).__init__()
+    self.maxdisp = maxdisp
+
+  def forward(self, x):
+    disp = torch.arange(self.maxdisp, dtype=x.dtype, device=x.device).view(1, self.maxdisp, 1, 1)
+    return torch.sum(x * disp, 1, keepdim=True)
+
+
+class _ResidualBlock(nn.Module):
+  expansion = 1
+
+  def _residual(self, x):
+    out = self.conv2(self.conv1(x))
+    if self.downsample is not None:
+      x = self.downsample(x)
+    out += x
+    return out
+
+
+class BasicBlock(_ResidualBlock):
+  """PSMNet block without the trailing ReLU (submodule.py:25-47); only used by conv='Regular'."""
+
+  def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+    super(BasicBlock, self).__init__()
+    self.conv1 = nn.Sequential(convbn(inplanes, planes, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+    self.conv2 = convbn(planes, planes, 3, 1, pad, dilation)
+    self.downsample = downsample
+    self.stride = stride
+
+  def forward(self, x):
+    return self._residual(x)
+
+
+class RegularBasicBlock(_ResidualBlock):
+  """conv-bn-relu, conv-bn, + skip, relu (submodule.py:94-119)."""
+
+  def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+    super(RegularBasicBlock, self).__init__()
+    self.conv1 = nn.Sequential(convbn(inplanes, planes, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+    self.conv2 = convbn(planes, planes, 3, 1, pad, dilation)
+    self.relu = nn.ReLU(inplace=True)
+    self.downsample = downsample
+    self.stride = stride
+
+  def forward(self, x):
+    return self.relu(self._residual(x))
+
+
+class SphereBasicBlock(_ResidualBlock):
+  """Same residual block with spherical convolutions (submodule.py:122-147)."""
+
+  def __init__(self, in_height, in_width, sphereType, inplanes, planes, stride, downsample, pad, dilation):
+    super(SphereBasicBlock, self).__init__()
+    self.conv1 = nn.Sequential(sphereConvbn(in_height, in_width, sphereType, inplanes, planes, 3, stride, pad, dilation),
+                               nn.ReLU(inplace=True))
+    self.conv2 = sphereConvbn(in_height // stride, in_width // stride, sphereType, planes, planes, 3, 1, pad, dilation)
+    self.relu = nn.ReLU(inplace=True)
+    self.downsample = downsample
+    self.stride = stride
+
+  def forward(self, x):
+    return self.relu(self._residual(x))
+
+
+def _downsample(inplanes, planes, stride):
+  return nn.Sequential(nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(planes))
+
+
+def _three_convs(cin, first_kernel, first_pad):
+  return nn.Sequential(convbn(cin, 32, first_kernel, 2, first_pad, 1), nn.ReLU(inplace=True), convbn(32, 32, 3, 1, 1, 1),
+                       nn.ReLU(inplace=True), convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+
+
+class sphere_feature_extraction(nn.Module):
+  """2D feature extractor with a spherical-convolution stage (submodule.py:151-201):
+  firstconv (7x7 s2 + 2x 3x3) -> layer1 (3 blocks 32->64) -> layer2 (8 blocks, s2) -> layer3 (4 blocks, dil 2)
+  -> layer4 (8 sphere blocks 64->128) ; cat(layer2, layer3, layer4) -> lastconv -> 32 ch at 1/4 resolution."""
+
+  def __init__(self, in_height, in_width, sphereType):
+    super(sphere_feature_extraction, self).__init__()
+    self.inplanes = 32
+    self.firstconv = _three_convs(3, 7, 3)
+    h2, w2, h4, w4 = in_height // 2, in_width // 2, in_height // 4, in_width // 4
+    self.layer1 = self._make_layer(RegularBasicBlock, h2, w2, sphereType, 32, 64, 3, 1, 1, 1)
+    self.layer2 = self._make_layer(RegularBasicBlock, h2, w2, sphereType, 64, 64, 8, 2, 1, 1)
+    self.layer3 = self._make_layer(RegularBasicBlock, h4, w4, sphereType, 64, 64, 4, 1, 1, 2)
+    self.layer4 = self._make_layer(SphereBasicBlock, h4, w4, sphereType, 64, 128, 8, 1, 1, 1)
+    self.lastconv = nn.Sequential(convbn(256, 128, 1, 1, 0, 1), nn.ReLU(inplace=True), convbn(128, 128, 3, 1, 1, 1),
+                                  nn.ReLU(inplace=True), convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True))
+
+  def _make_layer(self, block, height, width, sphereType, inplanes, planes, blocks, stride, pad, dilation):
+    down = _downsample(inplanes, planes, stride) if (stride != 1 or inplanes != planes * block.expansion) else None
+    sphere = block is SphereBasicBlock
+    print("add {} block. num: {}, inplanes: {}, planes: {}".format('sphere' if sphere else 'regular', blocks, inplanes, planes))
+    geo = (lambda s: (height // s, width // s, sphereType)) if sphere else (lambda s: ())
+    layers = [block(*geo(1), inplanes, planes, stride, down, pad, dilation)]
+    layers += [block(*geo(stride), planes * block.expansion, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+  def forward(self, x):
+    raw = self.layer2(self.layer1(self.firstconv(x)))
+    regular = self.layer3(raw)
+    sphere = self.layer4(regular)
+    return self.lastconv(torch.cat((raw, regular, sphere), 1))
+
+
+class feature_extraction(nn.Module):
+  """PSMNet SPP feature extractor, used only by ModeDisparity(conv='Regular') (submodule.py:205-268).
+  Stock layers only; kept so that the constructor contract is complete."""
+
+  def __init__(self):
+    super(feature_extraction, self).__init__()
+    self.inplanes = 32
+    self.firstconv = _three_convs(3, 3, 1)
+    self.layer1 = self._make_layer(BasicBlock, 32, 3, 1, 1, 1)
+    self.layer2 = self._make_layer(BasicBlock, 64, 16, 2, 1, 1)
+    self.layer3 = self._make_layer(BasicBlock, 128, 3, 1, 1, 1)
+    self.layer4 = self._make_layer(BasicBlock, 128, 3, 1, 1, 2)
+    for i, k in enumerate((64, 32, 16, 8), 1):
+      setattr(self, 'branch%d' % i, nn.Sequential(nn.AvgPool2d((k, k), stride=(k, k)), convbn(128, 32, 1, 1, 0, 1),
+                                                  nn.ReLU(inplace=True)))
+    self.lastconv = nn.Sequential(convbn(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+
+  def _make_layer(self, block, planes, blocks, stride, pad, dilation):
+    down = _downsample(self.inplanes, planes * block.expansion, stride) if (
+        stride != 1 or self.inplanes != planes * block.expansion) else None
+    layers = [block(self.inplanes, planes, stride, down, pad, dilation)]
+    self.inplanes = planes * block.expansion
+    layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+  def forward(self, x):
+    raw = self.layer2(self.layer1(self.firstconv(x)))
+    skip = self.layer4(self.layer3(raw))
+    size = skip.shape[2:]
+    pooled = [F.interpolate(getattr(self, 'branch%d' % i)(skip), size, mode='bilinear', align_corners=True) for i in (4, 3, 2, 1)]
+    return self.lastconv(torch.cat([raw, skip] + pooled, 1))

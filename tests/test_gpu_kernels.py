@@ -1,0 +1,183 @@
+"""GPU (-m gpu): parity of the hand-written HIP kernels against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import mode_ref, sphere_conv_ref
+
+import mode_hip
+from mode_hip import functional as HF
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+  # fail loudly (never skip) if the GPU tier is run on a box without a GPU or without the built library
+  assert torch.cuda.is_available(), 'GPU tests need a GPU'
+  mode_hip.lib()
+
+
+def _rand(shape, seed, scale=1.0, integer=False):
+  rs = np.random.RandomState(seed)
+  a = rs.randint(-4, 5, size=shape).astype(np.float32) if integer else (rs.standard_normal(shape) * scale).astype(np.float32)
+  return torch.from_numpy(a)
+
+
+# ------------------------------------------------------------------ cost volume (a9): bit-exact
+@pytest.mark.parametrize('B,C,D4,H,W', [(2, 4, 6, 5, 16), (1, 3, 7, 2, 5), (2, 2, 4, 3, 10), (1, 32, 48, 32, 128), (0, 4, 4, 4, 8)])
+def test_cost_volume_fwd_bit_exact(B, C, D4, H, W):
+  ref, tgt = _rand((B, C, H, W), 1), _rand((B, C, H, W), 2)
+  got = HF.cost_volume_fwd(ref.to(DEV), tgt.to(DEV), D4).cpu()
+  assert torch.equal(got, mode_ref.cost_volume(ref, tgt, D4))
+
+
+def test_cost_volume_fwd_golden(golden):
+  z = golden('model_tiny.npz')
+  got = HF.cost_volume_fwd(torch.from_numpy(z['train/fea_left']).to(DEV), torch.from_numpy(z['train/fea_right']).to(DEV), 4)
+  assert np.array_equal(got.cpu().numpy(), z['train/cost'])
+
+
+@pytest.mark.parametrize('B,C,D4,H,W', [(2, 4, 6, 5, 16), (1, 3, 7, 2, 5), (2, 2, 4, 3, 10), (1, 8, 48, 16, 128)])
+def test_cost_volume_bwd(B, C, D4, H, W):
+  # integer-valued gradients: every partial sum is exact in fp32, so any summation order must agree bit for bit
+  g = _rand((B, 2 * C, D4, H, W), 3, integer=True)
+  ref = torch.zeros(B, C, H, W, requires_grad=True)
+  tgt = torch.zeros(B, C, H, W, requires_grad=True)
+  mode_ref.cost_volume(ref, tgt, D4).backward(g)
+  g_ref, g_tgt = HF.cost_volume_bwd(g.to(DEV), C)
+  assert torch.equal(g_ref.cpu(), ref.grad) and torch.equal(g_tgt.cpu(), tgt.grad)
+  # random gradients: fp32 round-off only
+  g = _rand((B, 2 * C, D4, H, W), 4)
+  ref.grad = tgt.grad = None
+  mode_ref.cost_volume(ref, tgt, D4).backward(g)
+  g_ref, g_tgt = HF.cost_volume_bwd(g.to(DEV), C)
+  assert torch.allclose(g_ref.cpu(), ref.grad, rtol=1e-5, atol=1e-5) and torch.allclose(g_tgt.cpu(), tgt.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_cost_volume_full_size_properties():
+  """BASELINE configs 2-4: C=32, D4=48, 256x128 -- size-independent properties + exact comparison."""
+  B, C, D4, H, W = 1, 32, 48, 256, 128
+  ref, tgt = _rand((B, C, H, W), 5), _rand((B, C, H, W), 6)
+  cost = HF.cost_volume(ref.to(DEV).requires_grad_(True), tgt.to(DEV), D4)
+  assert cost.shape == (B, 2 * C, D4, H, W)
+  # checksum of checksums: sum over the volume = sum_i sum_{w>=i} (ref + tgt shifted)
+  exp = sum(float(ref[..., i:].double().sum() + tgt[..., :W - i].double().sum()) for i in range(D4))
+  assert abs(float(cost.double().sum()) - exp) < 1e-6 * max(1.0, abs(exp)) + 1e-3
+  assert torch.equal(cost.cpu(), mode_ref.cost_volume(ref, tgt, D4))
+  # linearity: cv(a*r1 + r2, .) = a*cv(r1, .) + cv(r2, .) on the ref half (exact for a power of two)
+  c2 = HF.cost_volume_fwd((2 * ref).to(DEV), tgt.to(DEV), D4)
+  assert torch.equal(c2[:, :C], 2 * cost[:, :C]) and torch.equal(c2[:, C:], cost[:, C:])
+
+
+# ------------------------------------------------------------------ sphere conv (a7/a8)
+def _sphere_case(typ, ih, iw, B, ci, co, stride, groups, seed):
+  pos = mode_ref.sphere_position(ih, iw, typ)
+  H, W = pos.shape[2:]
+  x = _rand((B, ci, H, W), seed)
+  w = _rand((co, ci // groups, 3, 3), seed + 1, 0.2)
+  Ho = sphere_conv_ref.out_size(H, 3, stride, 1, 1)
+  Wo = sphere_conv_ref.out_size(W, 3, stride, 1, 1)
+  gy = _rand((B, co, Ho, Wo), seed + 2)
+  return pos, x, w, gy
+
+
+SPHERE_CASES = [
+    ('ERP', 16, 32, 2, 3, 4, 1, 1),  # odd Ci: zero-padded K, single partial M tile
+    ('Cassini', 32, 16, 2, 8, 8, 1, 1),
+    ('ERP', 16, 32, 2, 4, 6, 2, 1),  # stride 2: table sampled at (2h, 2w)
+    ('Cassini', 32, 16, 2, 4, 4, 1, 2),  # groups
+    ('ERP', 10, 20, 1, 5, 7, 1, 1),  # 200 pixels: ragged last tile
+    ('Cassini', 64, 32, 2, 64, 128, 1, 1),  # layer4.0.conv1 shape at the tiny model size
+    ('Cassini', 64, 32, 1, 128, 128, 1, 1),  # layer4 body shape
+    ('ERP', 16, 32, 1, 40, 160, 1, 1),  # Co > 128: two M groups; Ci not a multiple of 8 or 14
+]
+
+
+@pytest.mark.parametrize('typ,ih,iw,B,ci,co,stride,groups', SPHERE_CASES)
+def test_sphere_conv_fwd_bwd(typ, ih, iw, B, ci, co, stride, groups):
+  pos, x, w, gy = _sphere_case(typ, ih, iw, B, ci, co, stride, groups, 11)
+  cfg = ((stride, stride), (1, 1), (1, 1), groups)
+  y_ref = sphere_conv_ref.forward(x.double(), pos, w.double(), *cfg)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x.double(), pos, w.double(), gy.double(), *cfg)
+  xd, wd, pd, gyd = x.to(DEV), w.to(DEV), pos.to(DEV), gy.to(DEV)
+  y = torch.full(tuple(y_ref.shape), float('nan'), device=DEV)
+  HF.sphere_conv_fwd(xd, pd, wd, y, (stride, stride), groups)
+  k = ci // groups * 9
+  tol = 2e-6 * k  # fp32 accumulation over K products of O(1) magnitude
+  assert (y.cpu().double() - y_ref).abs().max() < tol * max(1.0, float(y_ref.abs().max()))
+  gx = torch.zeros_like(xd)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, gx, (stride, stride), groups)
+  assert (gx.cpu().double() - gx_ref).abs().max() < 2e-6 * (co * 9) * max(1.0, float(gx_ref.abs().max()))
+  gw = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (stride, stride), groups)
+  assert (gw.cpu().double() - gw_ref).abs().max() < 1e-5 * max(1.0, float(gw_ref.abs().max()))
+  # accumulate semantics (sphere_conv.py:62-64): a second call adds on top
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (stride, stride), groups)
+  assert (gw.cpu().double() - 2 * gw_ref).abs().max() < 2e-5 * max(1.0, float(gw_ref.abs().max()))
+  # bwd-weight is deterministic (fixed-order split-K reduction)
+  gw2 = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw2, (stride, stride), groups)
+  gw3 = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw3, (stride, stride), groups)
+  assert torch.equal(gw2, gw3)
+
+
+@pytest.mark.parametrize('name', ['erp_s1', 'cas_s1', 'erp_s2', 'cas_g2'])
+def test_sphere_conv_golden(golden, name):
+  from models.basic.spherical_conv.sphere_conv import SphereConv
+  z = golden('sphere_conv.npz')
+  ih, iw, ci, co, s, g = [int(v) for v in z[name + '/cfg']]
+  m = SphereConv(ih, iw, str(z[name + '/type']), ci, co, 3, s, 1, 1, g, False).to(DEV)
+  with torch.no_grad():
+    m.weight.copy_(torch.from_numpy(z[name + '/w']))
+  x = torch.from_numpy(z[name + '/x']).to(DEV).requires_grad_(True)
+  y = m(x)
+  y.backward(torch.from_numpy(z[name + '/gy']).to(DEV))
+  assert np.abs(y.detach().cpu().numpy() - z[name + '/y']).max() < 1e-4
+  assert np.abs(x.grad.cpu().numpy() - z[name + '/gx']).max() < 1e-4
+  assert np.abs(m.weight.grad.cpu().numpy() - z[name + '/gw']).max() < 1e-3
+
+
+def test_sphere_conv_layer4_full_size():
+  """The benchmark shape: 128 -> 128 channels on the (1,18,256,128) Cassini table, fp32 oracle on the CPU."""
+  pos, x, w, gy = _sphere_case('Cassini', 256, 128, 1, 128, 128, 1, 1, 21)
+  w = w * 0.25
+  cfg = ((1, 1), (1, 1), (1, 1), 1)
+  y_ref = sphere_conv_ref.forward(x, pos, w, *cfg)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x, pos, w, gy, *cfg)
+  xd, wd, pd, gyd = x.to(DEV), w.to(DEV), pos.to(DEV), gy.to(DEV)
+  y = torch.empty_like(gyd)
+  HF.sphere_conv_fwd(xd, pd, wd, y, (1, 1), 1)
+  assert (y.cpu() - y_ref).abs().max() < 5e-4
+  gx = torch.zeros_like(xd)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, gx, (1, 1), 1)
+  assert (gx.cpu() - gx_ref).abs().max() < 5e-4
+  gw = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (1, 1), 1)
+  assert (gw.cpu() - gw_ref).abs().max() < 2e-3 * max(1.0, float(gw_ref.abs().max()))
+  # linearity in the input (size-independent property)
+  y2 = torch.empty_like(gyd)
+  HF.sphere_conv_fwd(2 * xd, pd, wd, y2, (1, 1), 1)
+  assert torch.equal(y2, 2 * y)
+
+
+def test_native_seam_signature():
+  """The reference's 17/20-argument pybind entry points (sphere_conv_cuda.cpp:339-345) work as documented."""
+  from models.basic.spherical_conv import sphere_conv_cuda as ext
+  pos, x, w, gy = _sphere_case('ERP', 16, 32, 2, 4, 8, 1, 1, 31)
+  xd, wd, pd, gyd = x.to(DEV), w.to(DEV), pos.to(DEV), gy.to(DEV)
+  bias = torch.arange(8, dtype=torch.float32, device=DEV)
+  out = torch.empty(2, 8, 16, 32, device=DEV)
+  ext.sphere_conv_forward_cuda(xd, wd, bias, xd.new_empty(0), pd, out, xd.new_empty(0), 3, 3, 1, 1, 1, 1, 1, 1, 1, True)
+  ref = sphere_conv_ref.forward(x, pos, w, (1, 1), (1, 1), (1, 1), 1) + bias.cpu().view(1, -1, 1, 1)
+  assert (out.cpu() - ref).abs().max() < 1e-4
+  gi, gw, gb = torch.zeros_like(xd), torch.zeros_like(wd), torch.zeros_like(bias)
+  ext.sphere_conv_backward_cuda(xd, wd, bias, xd.new_empty(0), pd, xd.new_empty(0), gi, gw, gb, gyd, 3, 3, 1, 1, 1, 1, 1, 1, 1, True)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x, pos, w, gy, (1, 1), (1, 1), (1, 1), 1)
+  assert (gi.cpu() - gx_ref).abs().max() < 1e-4 and (gw.cpu() - gw_ref).abs().max() < 1e-3
+  assert (gb.cpu() - gy.sum((0, 2, 3))).abs().max() < 1e-3
+  with pytest.raises(RuntimeError, match='invalid number of input planes'):
+    ext.sphere_conv_forward_cuda(xd[:, :3].contiguous(), wd, bias, None, pd, out, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, False)
