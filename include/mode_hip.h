@@ -99,6 +99,49 @@ int mode_cost_volume_fwd(const float* ref, const float* tgt, float* cost, int B,
 int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, int C, int D4, int H, int W,
                          mode_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3x3x3 convolution, padding 1, no bias -- replaces the cuDNN nn.Conv3d inside convbn_3d
+ * (models/submodule.py:20-22) for dres0/dres1, the hourglass stride-1 layers and the classifier bodies
+ * (models/mode_disparity.py:15-25, 66-80).  NCDHW fp32, implicit GEMM on fp32 MFMA.
+ *
+ *   x (B, Ci, D, H, W)   w (Co, Ci, 3, 3, 3)   y (B, Co, D, H, W)      stride 1 only (MODE_ERR_UNSUPPORTED otherwise;
+ *   the stride-2 / transposed layers still run on the vendor library), Co and Ci <= 64 per call.
+ * `wpack` >= mode_conv3d_wpack_bytes(Ci, Co) holds the fragment-ordered weights (rebuilt every call).
+ * bwd_data writes gx (no accumulation); bwd_weight writes gw (accumulate = 0) or adds to it (accumulate = 1) using
+ * `workspace` >= mode_conv3d_bwd_weight_workspace_bytes() for deterministic split-K partial sums.
+ */
+size_t mode_conv3d_wpack_bytes(int Ci, int Co);
+
+int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
+                    int stride, mode_stream_t stream);
+
+int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
+                         int Co, int stride, mode_stream_t stream);
+
+size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co);
+
+int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
+                           int W, int Co, int stride, int accumulate, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused soft-argmin head -- replaces F.upsample(trilinear, align_corners=True) + F.softmax +
+ * disparityregression (models/mode_disparity.py:131-152, models/submodule.py:50-57) and, when `conf` is non-NULL, the
+ * confidence map of models/mode_disparity.py:157-183.  The (B,D,H,W) upsampled logits / probabilities are never
+ * materialised.
+ *
+ *   logits (B, D4, H4, W4) [= the (B,1,D4,H4,W4) classifier output]  ->  pred (B, H, W) [, conf (B, H, W)]
+ *   pred = sum_d d * softmax_d(upsample(logits))[d],   d = 0 .. D-1
+ * mode_head_bwd: glogits (B,D4,H4,W4) = d(sum(gpred * pred)) / d logits, written (not accumulated); deterministic.
+ * `workspace` >= mode_head_bwd_workspace_bytes(B, D4, H, W).
+ */
+int mode_head_fwd(const float* logits, float* pred, float* conf, int B, int D4, int H4, int W4, int D, int H, int W,
+                  mode_stream_t stream);
+
+size_t mode_head_bwd_workspace_bytes(int B, int D4, int H, int W);
+
+int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float* workspace, int B, int D4, int H4,
+                  int W4, int D, int H, int W, mode_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,131 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
     check(lib().mode_sphere_conv_bwd_weight(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), *dims, stream_of(gy)),
           'mode_sphere_conv_bwd_weight')
   return gw
+
+
+# ------------------------------------------------------------------------------------ 3x3x3 convolution (stride 1)
+def _wpack3d(w):
+  n = lib().mode_conv3d_wpack_bytes(w.shape[1], w.shape[0])
+  return torch.empty(n // 4, dtype=torch.float32, device=w.device)
+
+
+def conv3d_fwd(x, w):
+  """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,D,H,W); k3 p1 s1, no bias (convbn_3d, submodule.py:20-22)."""
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.contiguous()
+  require_f32c(x, w)
+  B, Ci, D, H, W = x.shape
+  Co = w.shape[0]
+  if tuple(w.shape[1:]) != (Ci, 3, 3, 3):
+    raise RuntimeError('conv3d: weight %s does not match input channels %d / kernel 3' % (tuple(w.shape), Ci))
+  y = torch.empty((B, Co, D, H, W), dtype=x.dtype, device=x.device)
+  flops = 2 * y.numel() * Ci * 27
+  with torch.cuda.device_of(x), profiling.region('conv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+    wp = _wpack3d(w)
+    check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, 1, stream_of(x)), 'mode_conv3d_fwd')
+  return y
+
+
+def conv3d_bwd_data(gy, w):
+  require_gpu(gy, w)
+  gy, w = gy.contiguous(), w.contiguous()
+  require_f32c(gy, w)
+  B, Co, D, H, W = gy.shape
+  Ci = w.shape[1]
+  gx = torch.empty((B, Ci, D, H, W), dtype=gy.dtype, device=gy.device)
+  flops = 2 * gy.numel() * Ci * 27
+  with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_data', 4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
+    wp = _wpack3d(w)
+    check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, 1, stream_of(gy)),
+          'mode_conv3d_bwd_data')
+  return gx
+
+
+def conv3d_bwd_weight(gy, x):
+  require_gpu(gy, x)
+  gy, x = gy.contiguous(), x.contiguous()
+  require_f32c(gy, x)
+  B, Co, D, H, W = gy.shape
+  Ci = x.shape[1]
+  gw = torch.empty((Co, Ci, 3, 3, 3), dtype=gy.dtype, device=gy.device)
+  flops = 2 * gy.numel() * Ci * 27
+  with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_weight', 4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
+    n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co)
+    ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
+    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, 1, 0, stream_of(gy)),
+          'mode_conv3d_bwd_weight')
+  return gw
+
+
+class Conv3dFunction(torch.autograd.Function):
+  """k3 p1 s1 convolution on the HIP kernels; autograd of F.conv3d(x, w, None, 1, 1)."""
+
+  @staticmethod
+  def forward(ctx, x, w):
+    ctx.save_for_backward(x, w)
+    return conv3d_fwd(x, w)
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    gx = conv3d_bwd_data(gy, w) if ctx.needs_input_grad[0] else None
+    gw = conv3d_bwd_weight(gy, x) if ctx.needs_input_grad[1] else None
+    return gx, gw
+
+
+def conv3d(x, w):
+  return Conv3dFunction.apply(x, w)
+
+
+# ------------------------------------------------------------------------------------ fused soft-argmin head
+def head_fwd(logits, size, with_confidence=False):
+  """logits (B,1,D4,H4,W4) -> pred (B,1,H,W) [, conf (B,1,H,W)] for size = (D,H,W).
+  Replaces mode_disparity.py:131-152 (+ :157-183 for the confidence map)."""
+  require_gpu(logits)
+  logits = logits.contiguous()
+  require_f32c(logits)
+  B, one, D4, H4, W4 = logits.shape
+  if one != 1:
+    raise ValueError('head: expected (B,1,D/4,H/4,W/4) logits, got %s' % (tuple(logits.shape),))
+  D, H, W = size
+  pred = torch.empty((B, 1, H, W), dtype=logits.dtype, device=logits.device)
+  conf = torch.empty_like(pred) if with_confidence else None
+  nbytes = 4 * (logits.numel() + pred.numel() * (2 if with_confidence else 1))
+  with torch.cuda.device_of(logits), profiling.region('head_fwd', nbytes, 0, logits.device):
+    check(lib().mode_head_fwd(ptr(logits), ptr(pred), ptr(conf) if conf is not None else None, B, D4, H4, W4, D, H, W,
+                              stream_of(logits)), 'mode_head_fwd')
+  return (pred, conf) if with_confidence else pred
+
+
+def head_bwd(logits, gpred, size):
+  require_gpu(logits, gpred)
+  logits, gpred = logits.contiguous(), gpred.contiguous()
+  require_f32c(logits, gpred)
+  B, _, D4, H4, W4 = logits.shape
+  D, H, W = size
+  gl = torch.empty_like(logits)
+  nbytes = 4 * (2 * logits.numel() + gpred.numel())
+  with torch.cuda.device_of(logits), profiling.region('head_bwd', nbytes, 0, logits.device):
+    n = lib().mode_head_bwd_workspace_bytes(B, D4, H, W)
+    ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=logits.device)
+    check(lib().mode_head_bwd(ptr(logits), ptr(gpred), ptr(gl), ptr(ws), B, D4, H4, W4, D, H, W, stream_of(logits)),
+          'mode_head_bwd')
+  return gl
+
+
+class HeadFunction(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, logits, size):
+    ctx.save_for_backward(logits)
+    ctx.size = tuple(size)
+    return head_fwd(logits, size)
+
+  @staticmethod
+  def backward(ctx, gpred):
+    logits, = ctx.saved_tensors
+    return head_bwd(logits, gpred, ctx.size), None
+
+
+def head(logits, size):
+  return HeadFunction.apply(logits, size)

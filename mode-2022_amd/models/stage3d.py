@@ -1,10 +1,12 @@
 """3D regulariser + soft-argmin head building blocks used by ModeDisparity.forward.
 
 Each helper takes the nn.Module that owns the parameters (so the state_dict layout stays the reference's) and
-runs the layer.  ``BACKEND`` selects who does the arithmetic for the stock 3D layers:
-  'vendor' -- torch.nn.functional on the GPU (MIOpen);
-  'hip'    -- libmode_hip.so kernels (as they land; see DESIGN.md for the current coverage).
-Neither is a CPU path.
+runs the layer.  ``BACKEND`` selects who does the arithmetic of the 3x3x3 convolutions:
+  'hip'    -- libmode_hip.so fp32-MFMA kernels for every stride-1 Conv3d with <= 64 channels (dres0, dres1, hourglass
+              conv2/conv4, classifier bodies = 82 % of the 3D FLOPs); the stride-2 / transposed / 32->1 layers run on the
+              vendor library until their kernels land (DESIGN.md tracks the coverage);
+  'vendor' -- torch.nn.functional on the GPU (MIOpen) for everything; used for A/B measurements.
+Neither is a CPU path; BatchNorm / ReLU / residual adds are torch GPU ops for now.
 """
 import os
 
@@ -12,13 +14,31 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-BACKEND = os.environ.get('MODE_STAGE3D', 'vendor')
+from mode_hip import functional as HF
+
+BACKEND = os.environ.get('MODE_STAGE3D', 'hip')
+HEAD_BACKEND = os.environ.get('MODE_HEAD', 'hip')  # 'hip' = fused kernel (mode_head_fwd/bwd), 'vendor' = torch ops
+
+
+def _hip_conv_ok(conv):
+  return (BACKEND == 'hip' and type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and
+          conv.padding == (1, 1, 1) and conv.dilation == (1, 1, 1) and conv.groups == 1 and conv.bias is None and
+          conv.in_channels <= 64 and 8 <= conv.out_channels <= 64)
+
+
+def conv3(conv, x):
+  """One Conv3d / ConvTranspose3d layer."""
+  if not x.is_cuda:
+    raise NotImplementedError('Only support cuda tensor!')  # same refusal as the reference's native op
+  if _hip_conv_ok(conv):
+    return HF.conv3d(x, conv.weight)
+  return conv(x)
 
 
 def conv_bn(seq, x, relu=False, add=None):
   """seq = Sequential(Conv3d | ConvTranspose3d, BatchNorm3d): y = bn(conv(x)) [+ add] [relu]
   (convbn_3d submodule.py:20-22; transposed form mode_disparity.py:23, 25)."""
-  y = seq[1](seq[0](x))
+  y = seq[1](conv3(seq[0], x))
   if add is not None:
     y = y + add
   return F.relu(y, inplace=True) if relu else y
@@ -26,13 +46,24 @@ def conv_bn(seq, x, relu=False, add=None):
 
 def classify(seq, x):
   """classifN = Sequential(convbn_3d, ReLU, Conv3d(32->1)) (mode_disparity.py:76-80)."""
-  return seq[2](conv_bn(seq[0], x, relu=True))
+  return conv3(seq[2], conv_bn(seq[0], x, relu=True))
 
 
 def head(cost, size, with_confidence=False):
   """Trilinear upsample (align_corners=True) of (B,1,D/4,H/4,W/4) logits to `size`=(D,H,W), softmax over D and
   expectation of the disparity index (mode_disparity.py:131-152, submodule.py:50-57); optionally the confidence
   map of mode_disparity.py:157-183 = P(round(d)-1) + P(round(d)) + P(round(d)+1), indices clamped to [0, D-1]."""
+  if not cost.is_cuda:
+    raise NotImplementedError('Only support cuda tensor!')
+  if HEAD_BACKEND == 'hip':
+    if with_confidence:
+      return HF.head_fwd(cost, size, with_confidence=True)
+    return HF.head(cost, size)
+  return head_vendor(cost, size, with_confidence)
+
+
+def head_vendor(cost, size, with_confidence=False):
+  """The same head as separate torch GPU ops (A/B measurements; also what the CPU wiring tests substitute)."""
   D = size[0]
   up = F.interpolate(cost, list(size), mode='trilinear', align_corners=True).squeeze(1)
   prob = F.softmax(up, dim=1)

@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the gradient exchange of mode_hip.data_parallel reproduces the reference's
+nn.DataParallel semantics (masked mean over the GLOBAL batch, gradients summed over replicas)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mode_hip import data_parallel
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _net():
+  torch.manual_seed(3)
+  return nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 1, 3, padding=1))
+
+
+def _data():
+  g = torch.Generator().manual_seed(5)
+  x = torch.randn(4, 3, 8, 8, generator=g)
+  gt = torch.randn(4, 1, 8, 8, generator=g)
+  gt[0, 0, :6] = float('nan')  # very different valid-pixel counts on the two ranks
+  gt[3, 0, 0, :2] = float('nan')
+  return x, gt
+
+
+def _worker(rank, world, port, out):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  net = _net()
+  if rank == 1:  # replicas start different; broadcast must fix that
+    with torch.no_grad():
+      for p in net.parameters():
+        p.add_(1.0)
+  red = data_parallel.GradAllReducer(net)
+  red.broadcast_parameters(net)
+  x, gt = _data()
+  xs, gts = x[rank * 2:rank * 2 + 2], gt[rank * 2:rank * 2 + 2]
+  mask = ~torch.isnan(gts)
+  for step in range(2):
+    red.zero_grad()
+    o = net(xs)
+    loss = data_parallel.global_masked_mean(F.smooth_l1_loss(o, torch.nan_to_num(gts), reduction='none'), mask)
+    loss.backward()
+    red.all_reduce()
+    with torch.no_grad():
+      for p in net.parameters():
+        p -= 0.1 * p.grad
+  out[rank] = [p.detach().clone() for p in net.parameters()] + [red.flat.clone()]
+  dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_global_batch():
+  world = 2
+  port = _free_port()
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+  # single-process reference: the whole batch, masked mean over all valid pixels (train_disparity.py:151-160)
+  net = _net()
+  x, gt = _data()
+  mask = ~torch.isnan(gt)
+  for step in range(2):
+    net.zero_grad()
+    o = net(x)
+    loss = F.smooth_l1_loss(o[mask], gt[mask])
+    loss.backward()
+    with torch.no_grad():
+      for p in net.parameters():
+        p -= 0.1 * p.grad
+  ref = [p.detach() for p in net.parameters()]
+  for rank in range(world):
+    got = out[rank]
+    for a, b in zip(got[:-1], ref):
+      assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+  assert torch.equal(out[0][-1], out[1][-1])  # identical reduced gradient buffer on both ranks
+
+
+def test_single_process_is_a_noop():
+  net = _net()
+  red = data_parallel.GradAllReducer(net)
+  assert red.world == 1 and red.flat.numel() == sum(p.numel() for p in net.parameters())
+  net(torch.randn(1, 3, 8, 8)).sum().backward()
+  before = red.flat.clone()
+  red.all_reduce()
+  assert torch.equal(before, red.flat) and float(before.abs().sum()) > 0
+  assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())
+  net.zero_grad(set_to_none=True)
+  red.rebind()
+  assert all(p.grad is not None for p in net.parameters())

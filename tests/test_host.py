@@ -26,6 +26,8 @@ GOLDEN = os.path.dirname(os.path.abspath(recipe.__file__))
 def oracle_ops(monkeypatch):
   monkeypatch.setattr(sc_mod, 'sphere_conv', sphere_conv_ref.sphere_conv)
   monkeypatch.setattr(md_mod.HF, 'cost_volume', mode_ref.cost_volume)
+  monkeypatch.setattr(md_mod.stage3d, 'conv3', lambda conv, x: conv(x))  # torch CPU conv = what oracle/mode_ref.py uses
+  monkeypatch.setattr(md_mod.stage3d, 'head', md_mod.stage3d.head_vendor)
 
 
 @pytest.fixture(scope='module')
