@@ -42,6 +42,8 @@ def parse():
   ap.add_argument('--maxdisp', type=int, default=192)
   ap.add_argument('--mode', default='train', choices=['train', 'eval'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) run the CPU oracle timing and print its JSON')
+  ap.add_argument('--cpu-baseline-timeout', type=int, default=420)
   ap.add_argument('--no-kernel-timing', action='store_true')
   return ap.parse_args()
 
@@ -59,13 +61,32 @@ def synthetic_batch(B, H, W, maxdisp, device, seed):
   return left.to(device), right.to(device), gt.to(device)
 
 
+def usable_cores():
+  """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a container on a big host)."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(float(quota) / float(period))))
+  except (OSError, ValueError):
+    try:
+      with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+        q, p = int(f.read()), int(g.read())
+      if q > 0:
+        n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+      pass
+  return n
+
+
 def cpu_baseline(args):
   """Time the CPU oracle (oracle/mode_ref.py, same arithmetic as the reference on torch's CPU backend) on this host.
   Bounded: one fwd+bwd at BASELINE configs[0] size (Cassini 512x256, D=64, B=1); if that predicts < 45 s for the full
   1024x512 / D=192 pair, the full-size pair is run and reported instead."""
   import recipe
   from oracle import mode_ref
-  cores = os.cpu_count() or 1
+  cores = usable_cores()
   torch.set_num_threads(cores)
 
   def run(maxdisp, H, W):
@@ -94,8 +115,27 @@ def cpu_baseline(args):
               'oracle/mode_ref.py on torch CPU' % (t_small, flop_ratio))
 
 
+def cpu_baseline_subprocess(args):
+  """Run the CPU timing in a child process (never touches the GPU) so that a slow host cannot stall the bench line."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--height', str(args.height), '--width', str(args.width),
+         '--maxdisp', str(args.maxdisp)]
+  try:
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
+    for line in reversed(r.stdout.strip().splitlines()):
+      if line.startswith('{'):
+        return json.loads(line)
+    return dict(value=None, unit='pairs/s', cores=usable_cores(), kind='port', sample='failed: ' + r.stderr[-300:])
+  except subprocess.TimeoutExpired:
+    return dict(value=None, unit='pairs/s', cores=usable_cores(), kind='port',
+                sample='timed out after %d s (1 pair fwd+bwd at Cassini 512x256, D=64)' % args.cpu_baseline_timeout)
+
+
 def main():
   args = parse()
+  if args.cpu_baseline_only:
+    print(json.dumps(cpu_baseline(args)))
+    return
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -203,7 +243,7 @@ def main():
     else:
       out['roofline'] = None
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline(args)
+      out['cpu_baseline'] = cpu_baseline_subprocess(args)
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()

@@ -73,6 +73,21 @@ int mode_sphere_conv_bwd_data(const float* gy, const float* pos, const float* w,
                               int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW,
                               int Ho, int Wo, int groups, mode_stream_t stream);
 
+/* The same gradient in gather form: deterministic, no atomics, ~7x faster.  It needs the ADJOINT of the sampling table,
+ * which depends on the table only (a constant of the module, sphere_conv.py:150) and is built once on the HOST:
+ *   mode_sphere_adjoint_build(pos_host, ...) fills rowptr_host[Kh*Kw*H*W + 1] and entries_host[2 * n] (n <=
+ *   mode_sphere_adjoint_max_entries()) -- for tap k and input pixel q, entries rowptr[k*H*W+q] .. rowptr[k*H*W+q+1] are
+ *   (output pixel p, float bits of the bilinear weight) pairs.  The caller uploads both arrays and passes the device
+ *   copies to mode_sphere_conv_bwd_data_adj, which ACCUMULATES into gx like the scatter form. */
+size_t mode_sphere_adjoint_max_entries(int Kh, int Kw, int Ho, int Wo);
+
+int mode_sphere_adjoint_build(const float* pos_host, int H, int W, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
+                              int32_t* rowptr_host, int32_t* entries_host, int64_t* n_entries);
+
+int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                                  const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                                  int Ho, int Wo, int groups, mode_stream_t stream);
+
 /* Replaces the grad_weight half (sphere_conv_cuda.cpp:296-315: second im2col + addmm_(gO, col^T),
  * summed over the batch).  ACCUMULATES into gw (caller zero-fills, sphere_conv.py:63).  `workspace`
  * holds the deterministic split-K partial sums: >= mode_sphere_conv_bwd_weight_workspace_bytes(). */
@@ -104,11 +119,16 @@ int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, 
  * (models/submodule.py:20-22) for dres0/dres1, the hourglass stride-1 layers and the classifier bodies
  * (models/mode_disparity.py:15-25, 66-80).  NCDHW fp32, implicit GEMM on fp32 MFMA.
  *
- *   x (B, Ci, D, H, W)   w (Co, Ci, 3, 3, 3)   y (B, Co, D, H, W)      stride 1 only (MODE_ERR_UNSUPPORTED otherwise;
- *   the stride-2 / transposed layers still run on the vendor library), Co and Ci <= 64 per call.
- * `wpack` >= mode_conv3d_wpack_bytes(Ci, Co) holds the fragment-ordered weights (rebuilt every call).
- * bwd_data writes gx (no accumulation); bwd_weight writes gw (accumulate = 0) or adds to it (accumulate = 1) using
- * `workspace` >= mode_conv3d_bwd_weight_workspace_bytes() for deterministic split-K partial sums.
+ *   x (B, Ci, D, H, W)   w (Co, Ci, 3, 3, 3)   y (B, Co, Do, Ho, Wo),  Xo = (X - 1) / stride + 1,  stride 1 or 2,
+ *   Co and Ci <= 64 per call.  `wpack` >= mode_conv3d_wpack_bytes(Ci, Co) holds the fragment-ordered weights (rebuilt
+ *   every call).  bwd_data writes gx (no accumulation; stride 2 needs even D, H, W); bwd_weight writes gw
+ *   (accumulate = 0) or adds to it (accumulate = 1) using `workspace` >= mode_conv3d_bwd_weight_workspace_bytes() for
+ *   deterministic split-K partial sums.
+ *
+ * mode_deconv3d_fwd: ConvTranspose3d k3 s2 p1 op1, no bias (hourglass conv5/conv6, models/mode_disparity.py:23, 25):
+ *   x (B, Cin, D, H, W)   w (Cin, Cout, 3, 3, 3)   y (B, Cout, 2D, 2H, 2W).
+ *   Its backward-data is mode_conv3d_fwd(gy, w, ..., Ci = Cout, Co = Cin, stride = 2) (same memory layout) and its
+ *   backward-weight is mode_conv3d_bwd_weight(gy := x, x := gy_out, Ci = Cout, Co = Cin, stride = 2).
  */
 size_t mode_conv3d_wpack_bytes(int Ci, int Co);
 
@@ -118,10 +138,13 @@ int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int 
 int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
                          int Co, int stride, mode_stream_t stream);
 
-size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co);
+size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride);
 
 int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
                            int W, int Co, int stride, int accumulate, mode_stream_t stream);
+
+int mode_deconv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Cin, int D, int H, int W,
+                      int Cout, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused soft-argmin head -- replaces F.upsample(trilinear, align_corners=True) + F.softmax +

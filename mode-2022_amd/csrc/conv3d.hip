@@ -21,11 +21,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NT = 256;
 constexpr int CCH = 8;  // input channels per LDS chunk
-constexpr int IW = 34;  // 32 + halo
 
 struct CDims {
-  int B, Ci, Co, D, H, W;  // stride-1: output dims == input dims
-  int nWt, nHt, nDt;       // tiles per axis
+  int B, Ci, Co, D, H, W;  // input volume
+  int Do, Ho, Wo;          // output volume: (X + 2 - 3) / stride + 1
+  int nWt, nHt, nDt;       // output tiles per axis
   int MT, NCHUNK;
   int ntiles;
 };
@@ -37,6 +37,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // wp[((mt*NCHUNK + ch)*27 + tap)*64 + lane][cp] = Wsrc(o = mt*32 + (lane&31), c = ch*8 + 2*cp + (lane>>5), tap)
 //   flip == 0: Wsrc(o,c,tap) = w[o][c][tap]            (forward; w is (Co,Ci,3,3,3), rows = Co, K = Ci)
 //   flip == 1: Wsrc(o,c,tap) = w[c][o][26 - tap]       (backward-data: rows = Ci of the conv, K = Co)
+//   flip == 2: Wsrc(o,c,tap) = w[c][o][tap]            (transposed conv: w is (Cin,Cout,3,3,3), rows = Cout, K = Cin)
 __global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip) {
   const long long total = (long long)MT * NCHUNK * 27 * 64 * 4;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -51,7 +52,8 @@ __global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, in
     const int o = mt * 32 + (lane & 31);
     const int c = ch * CCH + 2 * cp + (lane >> 5);
     float v = 0.f;
-    if (o < rows && c < K) v = flip ? w[((long long)c * rows + o) * 27 + (26 - tap)] : w[((long long)o * K + c) * 27 + tap];
+    if (o < rows && c < K)
+      v = flip == 0 ? w[((long long)o * K + c) * 27 + tap] : w[((long long)c * rows + o) * 27 + (flip == 1 ? 26 - tap : tap)];
     wp[idx] = v;
   }
 }
@@ -64,11 +66,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int MT, int TD, int TH>
-__global__ __launch_bounds__(NT) void conv3d_s1_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
-                                                       float* __restrict__ y, CDims d) {
+// Stride 2 (S = 2): the 65 input columns of a row are stored de-interleaved, [33 odd-phase | 32 even-phase], so that the
+// 32 lanes of a fragment still read consecutive LDS words: tap kw = 0 -> O[j], kw = 1 -> E[j], kw = 2 -> O[j+1].
+template <int S>
+__device__ __forceinline__ constexpr int tap_woff(int kw) {
+  return S == 1 ? kw : (kw == 0 ? 0 : kw == 1 ? 33 : 1);
+}
+
+template <int MT, int TD, int TH, int S>
+__global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
+                                                    float* __restrict__ y, CDims d) {
   constexpr int R = TD * TH / 4;  // output rows per wave
-  constexpr int ID = TD + 2, IH = TH + 2;
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3;
+  constexpr int IW = (S == 1) ? 34 : 65;
   constexpr int PLANE = ID * IH * IW;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [CCH][PLANE]
 
@@ -84,6 +94,8 @@ __global__ __launch_bounds__(NT) void conv3d_s1_kernel(const float* __restrict__
   const int wave = tid >> 6, lane = tid & 63;
   const long long HW = (long long)d.H * d.W;
   const long long DHW = (long long)d.D * HW;
+  const long long oHW = (long long)d.Ho * d.Wo;
+  const long long oDHW = (long long)d.Do * oHW;
 
   f32x16 acc[MT][R];
 #pragma unroll
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(NT) void conv3d_s1_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = wave * R + r;
-    rowoff[r] = (row / TH) * (IH * IW) + (row % TH) * IW;
+    rowoff[r] = (row / TH) * S * (IH * IW) + (row % TH) * S * IW;
   }
   const float* bbase = tile + (lane >> 5) * PLANE + (lane & 31);
   const float* xb = x + (long long)b * d.Ci * DHW;
@@ -109,19 +121,20 @@ __global__ __launch_bounds__(NT) void conv3d_s1_kernel(const float* __restrict__
       rem -= dz * (IH * IW);
       const int hy = rem / IW;
       const int wx = rem - hy * IW;
-      const int gd = d0 + dz - 1, gh = h0 + hy - 1, gw = w0 + wx - 1;
+      const int gd = d0 * S + dz - 1, gh = h0 * S + hy - 1, gw = w0 * S + wx - 1;
       const int cin = ch * CCH + c;
       float v = 0.f;
       if (cin < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
         v = xb[cin * DHW + gd * HW + gh * d.W + gw];
-      tile[idx] = v;
+      const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
+      tile[idx - wx + lw] = v;
     }
     __syncthreads();
     // ---- 27 taps x 4 channel pairs x R rows x MT tiles of MFMA
     const float4* wq = wp + ((long long)ch * 27) * 64 + lane;
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      const int toff = (tap / 9) * (IH * IW) + ((tap / 3) % 3) * IW + (tap % 3);
+      const int toff = (tap / 9) * (IH * IW) + ((tap / 3) % 3) * IW + tap_woff<S>(tap % 3);
       float4 a4[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a4[m] = wq[((long long)m * d.NCHUNK * 27 + tap) * 64];
@@ -142,35 +155,35 @@ __global__ __launch_bounds__(NT) void conv3d_s1_kernel(const float* __restrict__
   }
 
   // ---- epilogue: D[i = o][j = w]
-  float* yb = y + (long long)b * d.Co * DHW;
+  float* yb = y + (long long)b * d.Co * oDHW;
   const int gw = w0 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = wave * R + r;
     const int gd = d0 + row / TH, gh = h0 + row % TH;
-    if (gd < d.D && gh < d.H && gw < d.W) {
-      const long long sp = gd * HW + (long long)gh * d.W + gw;
+    if (gd < d.Do && gh < d.Ho && gw < d.Wo) {
+      const long long sp = gd * oHW + (long long)gh * d.Wo + gw;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int o = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          if (o < d.Co) yb[o * DHW + sp] = acc[m][r][q];
+          if (o < d.Co) yb[o * oDHW + sp] = acc[m][r][q];
         }
     }
   }
 }
 
-template <int MT, int TD, int TH>
-int launch_s1(const float* x, const float* wpack, float* y, CDims d, hipStream_t st, const char* who) {
-  d.nWt = mode::cdiv(d.W, 32);
-  d.nHt = mode::cdiv(d.H, TH);
-  d.nDt = mode::cdiv(d.D, TD);
+template <int MT, int TD, int TH, int S>
+int launch_conv(const float* x, const float* wpack, float* y, CDims d, hipStream_t st, const char* who) {
+  d.nWt = mode::cdiv(d.Wo, 32);
+  d.nHt = mode::cdiv(d.Ho, TH);
+  d.nDt = mode::cdiv(d.Do, TD);
   d.ntiles = d.B * d.nDt * d.nHt * d.nWt;
-  const size_t lds = (size_t)CCH * (TD + 2) * (TH + 2) * IW * sizeof(float);
-  int rc = mode::allow_lds(conv3d_s1_kernel<MT, TD, TH>, lds, who);
+  const size_t lds = (size_t)CCH * ((TD - 1) * S + 3) * ((TH - 1) * S + 3) * (S == 1 ? 34 : 65) * sizeof(float);
+  int rc = mode::allow_lds(conv3d_kernel<MT, TD, TH, S>, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL((conv3d_s1_kernel<MT, TD, TH>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
+  hipLaunchKernelGGL((conv3d_kernel<MT, TD, TH, S>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
                      y, d);
   return mode::check_launch(who);
 }
@@ -180,6 +193,7 @@ int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int
               hipStream_t st, const char* who) {
   CDims d;
   d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
+  d.Do = D; d.Ho = H; d.Wo = W;
   d.MT = mode::cdiv(rows, 32);
   d.NCHUNK = mode::cdiv(K, CCH);
   MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
@@ -189,19 +203,152 @@ int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int
   const long long big = (long long)B * mode::cdiv(D, 2) * mode::cdiv(H, 8) * mode::cdiv(W, 32);
   const long long mid = (long long)B * mode::cdiv(D, 2) * mode::cdiv(H, 4) * mode::cdiv(W, 32);
   if (d.MT == 1) {
-    if (big >= 2 * kNumCU) return launch_s1<1, 2, 8>(x, wpack, y, d, st, who);
-    if (mid >= 2 * kNumCU) return launch_s1<1, 2, 4>(x, wpack, y, d, st, who);
-    return launch_s1<1, 1, 4>(x, wpack, y, d, st, who);
+    if (big >= 2 * kNumCU) return launch_conv<1, 2, 8, 1>(x, wpack, y, d, st, who);
+    if (mid >= 2 * kNumCU) return launch_conv<1, 2, 4, 1>(x, wpack, y, d, st, who);
+    return launch_conv<1, 1, 4, 1>(x, wpack, y, d, st, who);
   }
-  if (big >= 2 * kNumCU) return launch_s1<2, 2, 8>(x, wpack, y, d, st, who);
-  if (mid >= 2 * kNumCU) return launch_s1<2, 2, 4>(x, wpack, y, d, st, who);
-  return launch_s1<2, 1, 4>(x, wpack, y, d, st, who);
+  if (big >= 2 * kNumCU) return launch_conv<2, 2, 8, 1>(x, wpack, y, d, st, who);
+  if (mid >= 2 * kNumCU) return launch_conv<2, 2, 4, 1>(x, wpack, y, d, st, who);
+  return launch_conv<2, 1, 4, 1>(x, wpack, y, d, st, who);
+}
+
+// Stride-2 forward (also the backward-data of ConvTranspose3d k3 s2 p1 op1): output = ((X - 1) / 2 + 1).
+int conv3d_s2(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W,
+              hipStream_t st, const char* who) {
+  CDims d;
+  d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
+  d.Do = (D - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1;
+  d.MT = mode::cdiv(rows, 32);
+  d.NCHUNK = mode::cdiv(K, CCH);
+  MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
+  const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
+  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 0);
+  if (d.MT == 1) return launch_conv<1, 1, 4, 2>(x, wpack, y, d, st, who);
+  return launch_conv<2, 1, 4, 2>(x, wpack, y, d, st, who);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed convolution k3 s2 p1 op1 (ConvTranspose3d of hourglass conv5/conv6, mode_disparity.py:23, 25) = the
+// backward-data of the stride-2 convolution:   out[o, z] = sum_{c, k : z = 2q - 1 + k} Wsrc(o, c, k) * x[c, q],  out = 2 x in.
+// Split by output parity per axis: an even output coordinate z = 2q' uses only k = 1 (q = q'); an odd one z = 2q'+1 uses
+// k = 2 (q = q') and k = 0 (q = q'+1).  The 8 parity classes of one low-resolution voxel carry 1+2+2+2+4+4+4+8 = 27
+// taps, so no MFMA is spent on structural zeros.  D[i = o][j = 32 low-res w]; a wave owns one low-res row and keeps the
+// 8 class accumulators live; the two w-parities of a row are stored interleaved as one float2 per lane (coalesced).
+template <int TD, int TH>
+__global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
+                                                      float* __restrict__ y, CDims d) {
+  static_assert(TD * TH == 4, "one low-resolution row per wave");
+  constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
+  constexpr int PLANE = ID * IH * IW;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [CCH][PLANE]
+
+  int t = xcd_remap(blockIdx.x, d.ntiles);
+  const int wt = t % d.nWt;
+  t /= d.nWt;
+  const int ht = t % d.nHt;
+  t /= d.nHt;
+  const int dt = t % d.nDt;
+  const int b = t / d.nDt;
+  const int mt = blockIdx.y;
+  const int w0 = wt * 32, h0 = ht * TH, d0 = dt * TD;  // low-resolution (input) coordinates
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const long long HW = (long long)d.H * d.W;
+  const long long DHW = (long long)d.D * HW;
+  const long long oHW = (long long)d.Ho * d.Wo;
+  const long long oDHW = (long long)d.Do * oHW;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i >> 2][(i >> 1) & 1][i & 1] = (f32x16){0};
+
+  const int dz = wave / TH, hy = wave % TH;
+  const float* bbase = tile + (lane >> 5) * PLANE + dz * (IH * IW) + hy * IW + (lane & 31);
+  const float* xb = x + (long long)b * d.Ci * DHW;
+
+  for (int ch = 0; ch < d.NCHUNK; ++ch) {
+    for (int idx = tid; idx < CCH * PLANE; idx += NT) {
+      const int c = idx / PLANE;
+      int rem = idx - c * PLANE;
+      const int z = rem / (IH * IW);
+      rem -= z * (IH * IW);
+      const int yy = rem / IW;
+      const int xx = rem - yy * IW;
+      const int gd = d0 + z, gh = h0 + yy, gw = w0 + xx;
+      const int cin = ch * CCH + c;
+      float v = 0.f;
+      if (cin < d.Ci && gd < d.D && gh < d.H && gw < d.W) v = xb[cin * DHW + gd * HW + gh * d.W + gw];
+      tile[idx] = v;
+    }
+    __syncthreads();
+    const float4* wq = wp + (((long long)mt * d.NCHUNK + ch) * 27) * 64 + lane;
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+          for (int td = 0; td <= pd; ++td)
+#pragma unroll
+            for (int th = 0; th <= ph; ++th)
+#pragma unroll
+              for (int tw = 0; tw <= pw; ++tw) {
+                // parity 0: (k = 1, dq = 0); parity 1: t = 0 -> (k = 2, dq = 0), t = 1 -> (k = 0, dq = 1)
+                const int kd = pd ? (td ? 0 : 2) : 1, kh = ph ? (th ? 0 : 2) : 1, kw = pw ? (tw ? 0 : 2) : 1;
+                const int off = (pd ? td : 0) * (IH * IW) + (ph ? th : 0) * IW + (pw ? tw : 0);
+                const float4 a4 = wq[(kd * 9 + kh * 3 + kw) * 64];
+                acc[pd][ph][pw] = mfma32(a4.x, bbase[0 * PLANE + off], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.y, bbase[2 * PLANE + off], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.z, bbase[4 * PLANE + off], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.w, bbase[6 * PLANE + off], acc[pd][ph][pw]);
+              }
+    __syncthreads();
+  }
+
+  float* yb = y + (long long)b * d.Co * oDHW;
+  const int qd = d0 + dz, qh = h0 + hy, qw = w0 + (lane & 31);
+  if (qd < d.D && qh < d.H && qw < d.W) {
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const long long sp = (long long)(2 * qd + pd) * oHW + (long long)(2 * qh + ph) * d.Wo + 2 * qw;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          if (o < d.Co) *reinterpret_cast<float2*>(yb + o * oDHW + sp) = make_float2(acc[pd][ph][0][q], acc[pd][ph][1][q]);
+        }
+      }
+  }
+}
+
+// x (B,K,D,H,W) -> y (B,rows,2D,2H,2W);  flip selects how `w` is indexed (see pack_w3d): 2 for ConvTranspose3d weights
+// (Cin,Cout,27), and also 2 for the backward-data of a stride-2 Conv3d whose weight is (Co,Ci,27) with K = Co, rows = Ci.
+int deconv3d(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
+             const char* who) {
+  CDims d;
+  d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
+  d.Do = 2 * D; d.Ho = 2 * H; d.Wo = 2 * W;
+  d.MT = mode::cdiv(rows, 32);
+  d.NCHUNK = mode::cdiv(K, CCH);
+  const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
+  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 2);
+  constexpr int TD = 2, TH = 2;
+  d.nWt = mode::cdiv(W, 32);
+  d.nHt = mode::cdiv(H, TH);
+  d.nDt = mode::cdiv(D, TD);
+  d.ntiles = B * d.nDt * d.nHt * d.nWt;
+  const size_t lds = (size_t)CCH * (TD + 1) * (TH + 1) * 33 * sizeof(float);
+  hipLaunchKernelGGL((deconv3d_kernel<TD, TH>), dim3(d.ntiles, d.MT), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
+                     y, d);
+  return mode::check_launch(who);
 }
 
 int check_conv_args(const void* a, const void* b, const void* c, const void* wp, int B, int Ci, int D, int H, int W, int Co,
-                    int stride, const char* who) {
+                    int stride, const char* who, bool allow_s2 = false) {
   MODE_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
-  MODE_REQUIRE(stride == 1, MODE_ERR_UNSUPPORTED, "%s: stride %d not implemented (only 1)", who, stride);
+  MODE_REQUIRE(stride == 1 || (stride == 2 && allow_s2), MODE_ERR_UNSUPPORTED, "%s: stride %d not implemented", who, stride);
   MODE_REQUIRE((long long)Ci * D * H * W < (1ll << 31) && (long long)Co * D * H * W < (1ll << 31), MODE_ERR_UNSUPPORTED,
                "%s: a sample larger than 2^31 elements", who);
   if (B == 0) return MODE_OK;
@@ -220,39 +367,58 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
 
 extern "C" int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                int stride, mode_stream_t stream) {
-  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, stride, "mode_conv3d_fwd");
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, stride, "mode_conv3d_fwd", true);
   if (rc != MODE_OK || B == 0) return rc;
+  if (stride == 2) return conv3d_s2(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), "mode_conv3d_fwd");
   return conv3d_s1(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), "mode_conv3d_fwd");
 }
 
 extern "C" int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
                                     int Co, int stride, mode_stream_t stream) {
-  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, stride, "mode_conv3d_bwd_data");
+  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, stride, "mode_conv3d_bwd_data", true);
   if (rc != MODE_OK || B == 0) return rc;
+  if (stride == 2) {
+    // gx = transposed convolution of gy with the same weights, indexed w[o][c][tap] = w[cin_of_deconv][cout_of_deconv][tap]
+    MODE_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MODE_ERR_UNSUPPORTED,
+                 "mode_conv3d_bwd_data: stride 2 needs even input sizes (got %dx%dx%d)", D, H, W);
+    return deconv3d(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), "mode_conv3d_bwd_data");
+  }
   return conv3d_s1(gy, w, gx, wpack, B, Co, Ci, D, H, W, 1, mode::as_stream(stream), "mode_conv3d_bwd_data");
 }
 
 // =====================================================================================================================
-// Backward w.r.t. the weight (stride 1):  gW[o][c][tap] = sum_{b,d,h,w} gy[b,o,d,h,w] * x[b,c,d+kd-1,h+kh-1,w+kw-1].
+// Backward w.r.t. the weight:  gW[o][c][tap] = sum_{b,q} gy[b,o,q] * x[b,c, S*q + k - 1]   (q = output voxel, S = stride).
 //   D[i = o][j = c] per tap;  A[i = o][k = voxel] = gy tile (LDS),  B[k = voxel][j = c] = x tile shifted by the tap (LDS).
-// A workgroup owns a 32x32 (o,c) block and a slice of the spatial tiles (1 x 2 x 32 voxels = 32 k-steps each); its 4 waves
-// share the A fragment and split the 27 taps (7,7,7,6 accumulators).  Split-K partials are reduced in a fixed order.
+// A workgroup owns a 32x32 (o,c) block and a slice of the spatial tiles (WTH rows x 32 output voxels); its 4 waves share
+// the A fragment and split the 27 taps (7,7,7,6 accumulators).  Split-K partials are reduced in a fixed order.
+// The same kernel serves ConvTranspose3d (k3 s2 p1 op1): gWt[ci][co][k] = sum_q x_in[ci,q] * gy_out[co, 2q + k - 1], i.e.
+// call it with (gy := transposed-conv input, x := transposed-conv output gradient, S = 2).
 namespace {
 
-constexpr int WTH = 2;                                // rows per spatial tile
-constexpr int XPLANE = 3 * (WTH + 2) * IW + 1;        // 409: odd -> lanes (= channels) hit distinct banks
-constexpr int GPLANE = WTH * 32 + 1;                  // 65
-
 struct WDims {
-  int B, Ci, Co, D, H, W;
+  int B, Ci, Co, D, H, W;  // x volume (high resolution)
+  int Do, Ho, Wo;          // gy volume
   int nWt, nHt;
   int T;  // spatial tiles in total
   int S;  // split-K slices
   int MTo, MTc;
 };
 
+template <int S, int WTH>
+struct WGeom {
+  static constexpr int XR = (WTH - 1) * S + 3;          // x rows per tile
+  static constexpr int XW = (S == 1) ? 34 : 65;         // x columns per tile
+  static constexpr int XP0 = 3 * XR * XW;
+  static constexpr int XPLANE = XP0 | 1;                // odd -> lanes (= channels) hit distinct banks
+  static constexpr int GPLANE = WTH * 32 + 1;
+  static constexpr size_t LDS = (size_t)(32 * XPLANE + 32 * GPLANE) * sizeof(float);
+};
+
+template <int S, int WTH>
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                float* __restrict__ part, WDims d) {
+  using G = WGeom<S, WTH>;
+  constexpr int XR = G::XR, XW = G::XW, XP0 = G::XP0, XPLANE = G::XPLANE, GPLANE = G::GPLANE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xl = lds;                 // [32][XPLANE]
   float* gl = lds + 32 * XPLANE;   // [32][GPLANE]
@@ -260,6 +426,8 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long HW = (long long)d.H * d.W;
   const long long DHW = (long long)d.D * HW;
+  const long long oHW = (long long)d.Ho * d.Wo;
+  const long long oDHW = (long long)d.Do * oHW;
 
   f32x16 acc[7];
   int toff[7];
@@ -267,7 +435,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
   for (int t = 0; t < 7; ++t) {
     acc[t] = (f32x16){0};
     const int tap = wave + 4 * t;  // < 27 except wave 3, t = 6
-    toff[t] = (tap / 9) * ((WTH + 2) * IW) + ((tap / 3) % 3) * IW + (tap % 3);
+    toff[t] = (tap / 9) * (XR * XW) + ((tap / 3) % 3) * XW + (tap % 3);
   }
   const bool last_valid = (wave + 24) < 27;
 
@@ -277,23 +445,23 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
     t /= d.nWt;
     const int ht = t % d.nHt;
     t /= d.nHt;
-    const int gd0 = t % d.D;
-    const int b = t / d.D;
-    const int w0 = wt * 32, h0 = ht * WTH;
+    const int qd = t % d.Do;
+    const int b = t / d.Do;
+    const int w0 = wt * 32, h0 = ht * WTH;  // output (gy) coordinates
     const float* xb = x + ((long long)b * d.Ci + cb * 32) * DHW;
-    const float* gb = gy + ((long long)b * d.Co + ob * 32) * DHW;
-    for (int idx = tid; idx < 32 * (XPLANE - 1); idx += NT) {
-      const int c = idx / (XPLANE - 1);
-      int rem = idx - c * (XPLANE - 1);
-      const int dz = rem / ((WTH + 2) * IW);
-      rem -= dz * ((WTH + 2) * IW);
-      const int hy = rem / IW;
-      const int wx = rem - hy * IW;
-      const int gd = gd0 + dz - 1, gh = h0 + hy - 1, gw = w0 + wx - 1;
+    const float* gb = gy + ((long long)b * d.Co + ob * 32) * oDHW;
+    for (int idx = tid; idx < 32 * XP0; idx += NT) {
+      const int c = idx / XP0;
+      int rem = idx - c * XP0;
+      const int dz = rem / (XR * XW);
+      rem -= dz * (XR * XW);
+      const int hy = rem / XW;
+      const int wx = rem - hy * XW;
+      const int gd = qd * S + dz - 1, gh = h0 * S + hy - 1, gw = w0 * S + wx - 1;
       float v = 0.f;
       if (cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
         v = xb[c * DHW + gd * HW + gh * d.W + gw];
-      xl[c * XPLANE + (idx - c * (XPLANE - 1))] = v;
+      xl[c * XPLANE + (idx - c * XP0)] = v;
     }
     for (int idx = tid; idx < 32 * WTH * 32; idx += NT) {
       const int o = idx / (WTH * 32);
@@ -301,18 +469,18 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
       const int hy = rem / 32, wx = rem % 32;
       const int gh = h0 + hy, gw = w0 + wx;
       float v = 0.f;
-      if (ob * 32 + o < d.Co && gh < d.H && gw < d.W) v = gb[o * DHW + gd0 * HW + gh * d.W + gw];
+      if (ob * 32 + o < d.Co && gh < d.Ho && gw < d.Wo) v = gb[o * oDHW + qd * oHW + gh * d.Wo + gw];
       gl[o * GPLANE + rem] = v;
     }
     __syncthreads();
     const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);
-    const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5);
+    const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5) * S;
 #pragma unroll
     for (int row = 0; row < WTH; ++row) {
 #pragma unroll 4
       for (int ks = 0; ks < 16; ++ks) {
         const float a = ap[row * 32 + 2 * ks];
-        const float* bq = bp + row * IW + 2 * ks;
+        const float* bq = bp + row * S * XW + 2 * ks * S;
 #pragma unroll
         for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
         if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
@@ -352,11 +520,14 @@ __global__ void reduce_gw3d(const float* __restrict__ part, float* __restrict__ 
   }
 }
 
-void make_wdims(WDims& d, int B, int Ci, int D, int H, int W, int Co) {
+constexpr int WTH1 = 2, WTH2 = 1;  // output rows per spatial tile for stride 1 / 2
+
+void make_wdims(WDims& d, int B, int Ci, int D, int H, int W, int Co, int stride) {
   d.B = B; d.Ci = Ci; d.Co = Co; d.D = D; d.H = H; d.W = W;
-  d.nWt = mode::cdiv(W, 32);
-  d.nHt = mode::cdiv(H, WTH);
-  d.T = B * D * d.nHt * d.nWt;
+  d.Do = (D - 1) / stride + 1; d.Ho = (H - 1) / stride + 1; d.Wo = (W - 1) / stride + 1;
+  d.nWt = mode::cdiv(d.Wo, 32);
+  d.nHt = mode::cdiv(d.Ho, stride == 1 ? WTH1 : WTH2);
+  d.T = B * d.Do * d.nHt * d.nWt;
   d.MTo = mode::cdiv(Co, 32);
   d.MTc = mode::cdiv(Ci, 32);
   int S = mode::cdiv(2 * kNumCU, d.MTo * d.MTc);
@@ -367,16 +538,16 @@ void make_wdims(WDims& d, int B, int Ci, int D, int H, int W, int Co) {
 
 }  // namespace
 
-extern "C" size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+extern "C" size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
   WDims d;
-  make_wdims(d, B, Ci, D, H, W, Co);
+  make_wdims(d, B, Ci, D, H, W, Co, stride);
   return (size_t)d.S * d.MTo * d.MTc * 27 * 1024 * sizeof(float);
 }
 
 extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
                                       int W, int Co, int stride, int accumulate, mode_stream_t stream) {
-  int rc = check_conv_args(gy, x, gw, workspace, B, Ci, D, H, W, Co, stride, "mode_conv3d_bwd_weight");
+  int rc = check_conv_args(gy, x, gw, workspace, B, Ci, D, H, W, Co, stride, "mode_conv3d_bwd_weight", true);
   if (rc != MODE_OK) return rc;
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
@@ -384,14 +555,33 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
     return MODE_OK;
   }
   WDims d;
-  make_wdims(d, B, Ci, D, H, W, Co);
-  const size_t lds = (size_t)(32 * XPLANE + 32 * GPLANE) * sizeof(float);
-  rc = mode::allow_lds(conv3d_bwd_weight_kernel, lds, "mode_conv3d_bwd_weight");
-  if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_bwd_weight_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+  make_wdims(d, B, Ci, D, H, W, Co, stride);
+  if (stride == 1) {
+    const size_t lds = WGeom<1, WTH1>::LDS;
+    rc = mode::allow_lds(conv3d_bwd_weight_kernel<1, WTH1>, lds, "mode_conv3d_bwd_weight");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv3d_bwd_weight_kernel<1, WTH1>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+  } else {
+    const size_t lds = WGeom<2, WTH2>::LDS;
+    rc = mode::allow_lds(conv3d_bwd_weight_kernel<2, WTH2>, lds, "mode_conv3d_bwd_weight");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv3d_bwd_weight_kernel<2, WTH2>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+  }
   rc = mode::check_launch("mode_conv3d_bwd_weight");
   if (rc != MODE_OK) return rc;
   const long long n = (long long)Co * Ci * 27;
   hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
+}
+
+// Transposed convolution k3 s2 p1 op1 (= backward-data of the stride-2 convolution).
+//   x (B, Cin, D, H, W), w: `w_is_conv` = 0 -> ConvTranspose3d weight (Cin, Cout, 3,3,3);
+//                          `w_is_conv` = 1 -> Conv3d weight (Cin_of_this_call = conv Co, Cout = conv Ci) i.e. (Co, Ci, 3,3,3)
+//   both index as w[cin][cout][tap], so one packing mode serves both.       y (B, Cout, 2D, 2H, 2W)
+extern "C" int mode_deconv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Cin, int D, int H, int W,
+                                 int Cout, mode_stream_t stream) {
+  int rc = check_conv_args(x, w, y, wpack, B, Cin, D, H, W, Cout, 1, "mode_deconv3d_fwd");
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE((long long)Cout * D * H * W * 8 < (1ll << 31), MODE_ERR_UNSUPPORTED, "mode_deconv3d_fwd: output sample too large");
+  return deconv3d(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), "mode_deconv3d_fwd");
 }

@@ -17,6 +17,8 @@
 //
 // MFMA operand maps (32x32x2 f32): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; it receives
 // D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31] in accumulator register r (r = 0..15).
+#include <cstring>
+
 #include "common.h"
 
 namespace {
@@ -228,7 +230,134 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Backward w.r.t. the input.  grid = (B*tps, 1, G); LDS = KK*P*20 + KSQ*8*P*4 bytes.
+// Backward w.r.t. the input, gather form (deterministic, no atomics).
+//   gx[c, q] = sum_{k, o} W[o, c, k] * colT[(o,k), q],     colT[(o,k), q] = sum_{e in L(k,q)} wt_e * gy[o, p_e]
+// where L(k, q) lists the output pixels p whose tap k touches input pixel q with bilinear weight wt (the transpose of the
+// sampling table, built once per table by mode_sphere_adjoint_build).  Same structure as the forward kernel: the producer
+// fills a column tile in LDS (8 output channels x KK taps x 64 input pixels), the contraction runs on MFMA with
+// D[i = c][j = q].  grid = (B*tiles(H*W), ceil(MTc/4), G).  ACCUMULATES into gx (each element is owned by one lane).
+//
+// wp[((g*MTc + mt)*NCHo + ch)*KK + quad][lane][j] = W[g*Cog + ch*8 + kl/KK][mt*32 + (lane&31)][kl%KK], kl = 2*(quad*4+j) + (lane>>5)
+__global__ void pack_w_adj(const float* __restrict__ w, float* __restrict__ wp, Dims d, int MTc, int NCHo) {
+  const long long total = (long long)d.G * MTc * NCHo * d.KK * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int quad = (int)(r % d.KK);
+    r /= d.KK;
+    const int ch = (int)(r % NCHo);
+    r /= NCHo;
+    const int mt = (int)(r % MTc);
+    const int g = (int)(r / MTc);
+    const int kl = 2 * (quad * 4 + j) + (lane >> 5);
+    const int o = ch * CCH + kl / d.KK;
+    const int tap = kl % d.KK;
+    const int c = mt * 32 + (lane & 31);
+    float v = 0.f;
+    if (o < d.Cog && c < d.Cig) v = w[((long long)(g * d.Cog + o) * d.Cig + c) * d.KK + tap];
+    wp[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj_kernel(const float* __restrict__ gy, const int* __restrict__ rowptr,
+                                                                        const int2* __restrict__ entries,
+                                                                        const float4* __restrict__ wp, float* __restrict__ gx, Dims d,
+                                                                        int MTc, int NCHo, int qtiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int2* span = reinterpret_cast<int2*>(smem);  // [KK][P]: (first entry, count) of L(k, q)
+  float* colbuf = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 8);
+  const int rows = CCH * d.KK;
+  const int HWin = d.H * d.W;
+
+  const int tile = blockIdx.x;
+  const int b = tile / qtiles;
+  const int q0 = (tile - b * qtiles) * P;
+  const int g = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int mt = blockIdx.y * 4 + wave;
+  const bool active = mt < MTc;
+
+  for (int item = tid; item < d.KK * P; item += NTHREADS) {
+    const int k = item / P, pp = item % P;
+    const int qq = q0 + pp;
+    int2 s = make_int2(0, 0);
+    if (qq < HWin) {
+      const int beg = rowptr[(long long)k * HWin + qq];
+      s = make_int2(beg, rowptr[(long long)k * HWin + qq + 1] - beg);
+    }
+    span[item] = s;
+  }
+  __syncthreads();
+
+  const int p = tid & (P - 1);
+  const int qd = tid / P;  // 0..3 -> output channels 2qd, 2qd+1 of the chunk
+  const float* gyg = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+
+  auto produce = [&](int ch, float* buf) {
+    const int o0 = ch * CCH + qd * 2;
+    const bool ok0 = o0 < d.Cog, ok1 = o0 + 1 < d.Cog;
+    const float* g0 = gyg + (long long)(ok0 ? o0 : 0) * d.npix;
+    const float* g1 = gyg + (long long)(ok1 ? o0 + 1 : 0) * d.npix;
+    for (int k = 0; k < d.KK; ++k) {
+      const int2 s = span[k * P + p];
+      float v0 = 0.f, v1 = 0.f;
+      for (int e = 0; e < s.y; ++e) {
+        const int2 ent = entries[s.x + e];
+        const float wt = __int_as_float(ent.y);
+        v0 += wt * g0[ent.x];
+        v1 += wt * g1[ent.x];
+      }
+      buf[((qd * 2) * d.KK + k) * P + p] = ok0 ? v0 : 0.f;
+      buf[((qd * 2 + 1) * d.KK + k) * P + p] = ok1 ? v1 : 0.f;
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const float4* wpa = wp + ((long long)(g * MTc + (active ? mt : 0)) * NCHo) * d.KK * 64 + lane;
+
+  produce(0, colbuf);
+  __syncthreads();
+  for (int ch = 0; ch < NCHo; ++ch) {
+    float* cur = colbuf + (ch & 1) * rows * P;
+    if (ch + 1 < NCHo) produce(ch + 1, colbuf + ((ch + 1) & 1) * rows * P);
+    if (active) {
+      const float4* wq = wpa + (long long)ch * d.KK * 64;
+      const float* bp = cur + (lane >> 5) * P + (lane & 31);
+      for (int quad = 0; quad < d.KK; ++quad) {
+        const float4 a4 = wq[quad * 64];
+        const float* bq = bp + quad * 8 * P;
+        acc0 = mfma32(a4.x, bq[0], acc0);
+        acc1 = mfma32(a4.x, bq[32], acc1);
+        acc0 = mfma32(a4.y, bq[2 * P], acc0);
+        acc1 = mfma32(a4.y, bq[2 * P + 32], acc1);
+        acc0 = mfma32(a4.z, bq[4 * P], acc0);
+        acc1 = mfma32(a4.z, bq[4 * P + 32], acc1);
+        acc0 = mfma32(a4.w, bq[6 * P], acc0);
+        acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+    float* gxb = gx + ((long long)b * d.Ci + (long long)g * d.Cig) * HWin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (c < d.Cig) {
+        const int qq = q0 + (lane & 31);
+        if (qq < HWin) gxb[(long long)c * HWin + qq] += acc0[r];
+        if (qq + 32 < HWin) gxb[(long long)c * HWin + qq + 32] += acc1[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward w.r.t. the input, scatter form (needs no adjoint table).  grid = (B*tps, 1, G); LDS = KK*P*20 + KSQ*8*P*4 bytes.
 // gcol rows come out of the MFMA in 128-row blocks (CB channels x KK taps) and are scattered with the same
 // bilinear weights as the forward gather (the transpose of cu:83-113, i.e. what cu:293-356 computes).
 __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ pos,
@@ -423,7 +552,8 @@ int make_dims(Dims& d, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int 
 size_t wpack_floats(const Dims& d) {
   const size_t f = (size_t)d.G * d.MT * d.NCHUNK * d.KK * 256;
   const size_t bw = (size_t)d.G * d.NB * 4 * d.KSQ * 256;
-  return f > bw ? f : bw;
+  const size_t adj = (size_t)d.G * mode::cdiv(d.Cig, 32) * mode::cdiv(d.Cog, CCH) * d.KK * 256;
+  return std::max(f, std::max(bw, adj));
 }
 
 int bww_splits(const Dims& d, int MG) {
@@ -512,4 +642,98 @@ extern "C" int mode_sphere_conv_bwd_weight(const float* gy, const float* pos, co
   const long long n = (long long)d.Co * d.Cig * d.KK;
   hipLaunchKernelGGL(reduce_gw, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, MG);
   return mode::check_launch("mode_sphere_conv_bwd_weight(reduce)");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adjoint (transposed) sampling table, built on the HOST once per position table (the table is a constant of the
+// module: sphere_conv.py:150, 156-157).  For tap k and input pixel q it lists every (output pixel p, weight) with
+// S_k[p, q] != 0, using exactly the arithmetic of compute_tapinfo above.  CSR layout:
+//   rowptr[k*H*W + q] .. rowptr[k*H*W + q + 1]  index into entries[] = (p, float bits of the weight) pairs.
+extern "C" size_t mode_sphere_adjoint_max_entries(int Kh, int Kw, int Ho, int Wo) {
+  if (Kh <= 0 || Kw <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  return (size_t)Kh * Kw * Ho * Wo * 4;
+}
+
+extern "C" int mode_sphere_adjoint_build(const float* pos_host, int H, int W, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
+                                         int32_t* rowptr_host, int32_t* entries_host, int64_t* n_entries) {
+  MODE_REQUIRE(pos_host && rowptr_host && entries_host && n_entries, MODE_ERR_BAD_ARG, "mode_sphere_adjoint_build: null pointer");
+  MODE_REQUIRE(H > 0 && W > 0 && Kh > 0 && Kw > 0 && sH > 0 && sW > 0 && Ho > 0 && Wo > 0, MODE_ERR_BAD_ARG,
+               "mode_sphere_adjoint_build: non-positive size");
+  MODE_REQUIRE((long long)(Ho - 1) * sH < H && (long long)(Wo - 1) * sW < W, MODE_ERR_BAD_ARG,
+               "mode_sphere_adjoint_build: output %dx%d with stride %dx%d reads the position table outside %dx%d", Ho, Wo, sH, sW, H,
+               W);
+  const int KK = Kh * Kw;
+  const long long HW = (long long)H * W;
+  MODE_REQUIRE((long long)KK * HW < (1ll << 31) && (long long)KK * Ho * Wo * 4 < (1ll << 31), MODE_ERR_UNSUPPORTED,
+               "mode_sphere_adjoint_build: table too large for 32-bit indices");
+  const long long nrows = (long long)KK * HW;
+  // corner records of one (k, p): up to 4 (q, weight)
+  auto corners = [&](int k, int p, int qs[4], float ws[4]) -> int {
+    const int ho = p / Wo, wo = p - ho * Wo;
+    const long long idx = (long long)(ho * sH) * W + wo * sW;
+    const float h = pos_host[(long long)(2 * k) * HW + idx];
+    const float w = pos_host[(long long)(2 * k + 1) * HW + idx];
+    if (!(h > -1.f && w > -1.f && h < (float)H && w < (float)W)) return 0;
+    const float hf = floorf(h), wf = floorf(w);
+    const int hl = (int)hf, wl = (int)wf, hh = hl + 1, wh = wl + 1;
+    const float lh = h - hf, lw = w - wf, uh = 1.f - lh, uw = 1.f - lw;
+    const float wt[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+    const int hc[4] = {hl, hl, hh, hh}, wc[4] = {wl, wh, wl, wh};
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+      if (hc[i] >= 0 && hc[i] <= H - 1 && wc[i] >= 0 && wc[i] <= W - 1 && wt[i] != 0.f) {
+        qs[n] = hc[i] * W + wc[i];
+        ws[n] = wt[i];
+        ++n;
+      }
+    return n;
+  };
+  for (long long i = 0; i <= nrows; ++i) rowptr_host[i] = 0;
+  const int npix = Ho * Wo;
+  int qs[4];
+  float ws[4];
+  for (int k = 0; k < KK; ++k)
+    for (int p = 0; p < npix; ++p) {
+      const int n = corners(k, p, qs, ws);
+      for (int i = 0; i < n; ++i) rowptr_host[(long long)k * HW + qs[i] + 1]++;
+    }
+  for (long long i = 0; i < nrows; ++i) rowptr_host[i + 1] += rowptr_host[i];
+  *n_entries = rowptr_host[nrows];
+  // fill (rows are filled in ascending p: deterministic summation order); use the row starts as moving cursors
+  for (int k = 0; k < KK; ++k)
+    for (int p = 0; p < npix; ++p) {
+      const int n = corners(k, p, qs, ws);
+      for (int i = 0; i < n; ++i) {
+        const int32_t at = rowptr_host[(long long)k * HW + qs[i]]++;
+        entries_host[2 * (long long)at] = p;
+        int32_t bits;
+        memcpy(&bits, &ws[i], 4);
+        entries_host[2 * (long long)at + 1] = bits;
+      }
+    }
+  for (long long i = nrows; i > 0; --i) rowptr_host[i] = rowptr_host[i - 1];  // undo the cursor shift
+  rowptr_host[0] = 0;
+  return MODE_OK;
+}
+
+extern "C" int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                                             const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                                             int Ho, int Wo, int groups, mode_stream_t stream) {
+  Dims d;
+  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, 1, 1, Ho, Wo, groups, "mode_sphere_conv_bwd_data_adj");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(gy && w && gx && wpack && adj_rowptr && adj_entries, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_data_adj: null pointer");
+  hipStream_t st = mode::as_stream(stream);
+  const int MTc = mode::cdiv(d.Cig, 32);
+  const int NCHo = mode::cdiv(d.Cog, CCH);
+  const long long npack = (long long)d.G * MTc * NCHo * d.KK * 256;
+  hipLaunchKernelGGL(pack_w_adj, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, MTc, NCHo);
+  const size_t lds = (size_t)d.KK * P * 8 + 2 * (size_t)CCH * d.KK * P * 4;
+  rc = mode::allow_lds(sphere_bwd_data_adj_kernel, lds, "mode_sphere_conv_bwd_data_adj");
+  if (rc != MODE_OK) return rc;
+  const int qtiles = mode::cdiv((long long)H * W, P);
+  hipLaunchKernelGGL(sphere_bwd_data_adj_kernel, dim3(B * qtiles, mode::cdiv(MTc, 4), d.G), dim3(NTHREADS), lds, st, gy, adj_rowptr,
+                     reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles);
+  return mode::check_launch("mode_sphere_conv_bwd_data_adj");
 }

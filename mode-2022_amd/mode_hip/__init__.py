@@ -24,6 +24,9 @@ SIGNATURES = {
     'mode_sphere_conv_wpack_bytes': (_c_size, [_c_int] * 5),
     'mode_sphere_conv_fwd': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_bwd_data': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_adjoint_max_entries': (_c_size, [_c_int] * 4),
+    'mode_sphere_adjoint_build': (_c_int, [_c_ptr] + [_c_int] * 8 + [_c_ptr] * 3),
+    'mode_sphere_conv_bwd_data_adj': (_c_int, [_c_ptr] * 6 + [_c_int] * 10 + [_c_ptr]),
     'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
@@ -31,7 +34,8 @@ SIGNATURES = {
     'mode_conv3d_wpack_bytes': (_c_size, [_c_int] * 2),
     'mode_conv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
-    'mode_conv3d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 6),
+    'mode_conv3d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 7),
+    'mode_deconv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 8 + [_c_ptr]),
     'mode_head_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr]),
     'mode_head_bwd_workspace_bytes': (_c_size, [_c_int] * 4),

@@ -1,4 +1,8 @@
 """torch.autograd wrappers over the C-ABI kernels (host-side glue only; no arithmetic here)."""
+import ctypes
+import os
+import threading
+
 import torch
 
 from . import check, lib, profiling, ptr, require_f32c, require_gpu, stream_of
@@ -90,6 +94,33 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
   return out
 
 
+_adjoint_cache = {}
+_adjoint_lock = threading.Lock()
+SPHERE_BWD_DATA = os.environ.get('MODE_SPHERE_BWD_DATA', 'gather')  # 'gather' (adjoint table) | 'scatter' (atomics)
+
+
+def sphere_adjoint(pos, kh, kw, stride, out_hw):
+  """Device copies (rowptr int32, entries int32 pairs) of the transposed sampling table of `pos`; built on the host by
+  mode_sphere_adjoint_build once per (table, stride, output size, device) and cached -- the table is a constant of the
+  module (sphere_conv.py:150)."""
+  key = (pos.data_ptr(), pos._version, tuple(pos.shape), kh, kw, tuple(stride), tuple(out_hw), str(pos.device))
+  with _adjoint_lock:
+    hit = _adjoint_cache.get(key)
+    if hit is not None:
+      return hit
+    H, W = pos.shape[2:]
+    host = pos.detach().to('cpu', torch.float32).contiguous()
+    nmax = lib().mode_sphere_adjoint_max_entries(kh, kw, out_hw[0], out_hw[1])
+    rowptr = torch.empty(kh * kw * H * W + 1, dtype=torch.int32)
+    entries = torch.empty(2 * nmax, dtype=torch.int32)
+    n = ctypes.c_int64(0)
+    check(lib().mode_sphere_adjoint_build(ptr(host), H, W, kh, kw, stride[0], stride[1], out_hw[0], out_hw[1], ptr(rowptr),
+                                          ptr(entries), ctypes.cast(ctypes.pointer(n), ctypes.c_void_p)), 'mode_sphere_adjoint_build')
+    hit = (rowptr.to(pos.device), entries[:2 * max(n.value, 1)].contiguous().to(pos.device), pos)  # keep `pos` alive: key uses its address
+    _adjoint_cache[key] = hit
+    return hit
+
+
 def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups):
   """Accumulates into `gx` (B,Ci,H,W) (caller zero-fills, sphere_conv.py:62)."""
   require_gpu(gy, pos, w, gx)
@@ -97,6 +128,14 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups):
   dims = _sc_dims(gx.shape, w.shape, gy.shape[2:], stride, groups)
   flops = 2 * gy.numel() * w[0].numel()
   nbytes = 4 * (gx.numel() + gy.numel() + pos.numel() + w.numel())
+  if SPHERE_BWD_DATA == 'gather':
+    rowptr, entries, _ = sphere_adjoint(pos, w.shape[2], w.shape[3], stride, gy.shape[2:])
+    B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
+    with torch.cuda.device_of(gy), profiling.region('sphere_conv_bwd_data', nbytes, flops, gy.device):
+      wp = _wpack(w, groups)
+      check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
+                                                Kw, Ho, Wo, G, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
+    return gx
   with torch.cuda.device_of(gy), profiling.region('sphere_conv_bwd_data', nbytes, flops, gy.device):
     wp = _wpack(w, groups)
     check(lib().mode_sphere_conv_bwd_data(ptr(gy), ptr(pos), ptr(w), ptr(gx), ptr(wp), *dims, stream_of(gy)),
@@ -120,14 +159,18 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
   return gw
 
 
-# ------------------------------------------------------------------------------------ 3x3x3 convolution (stride 1)
-def _wpack3d(w):
-  n = lib().mode_conv3d_wpack_bytes(w.shape[1], w.shape[0])
-  return torch.empty(n // 4, dtype=torch.float32, device=w.device)
+# ------------------------------------------------------------------------------------ 3x3x3 convolution / transposed conv
+def _wpack3d(ci, co, device):
+  n = lib().mode_conv3d_wpack_bytes(ci, co)
+  return torch.empty(n // 4, dtype=torch.float32, device=device)
 
 
-def conv3d_fwd(x, w):
-  """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,D,H,W); k3 p1 s1, no bias (convbn_3d, submodule.py:20-22)."""
+def _out3(n, stride):
+  return (n - 1) // stride + 1
+
+
+def conv3d_fwd(x, w, stride=1):
+  """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,Do,Ho,Wo); k3 p1, stride 1|2, no bias (convbn_3d, submodule.py:20-22)."""
   require_gpu(x, w)
   x, w = x.contiguous(), w.contiguous()
   require_f32c(x, w)
@@ -135,63 +178,104 @@ def conv3d_fwd(x, w):
   Co = w.shape[0]
   if tuple(w.shape[1:]) != (Ci, 3, 3, 3):
     raise RuntimeError('conv3d: weight %s does not match input channels %d / kernel 3' % (tuple(w.shape), Ci))
-  y = torch.empty((B, Co, D, H, W), dtype=x.dtype, device=x.device)
+  y = torch.empty((B, Co, _out3(D, stride), _out3(H, stride), _out3(W, stride)), dtype=x.dtype, device=x.device)
   flops = 2 * y.numel() * Ci * 27
   with torch.cuda.device_of(x), profiling.region('conv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    wp = _wpack3d(w)
-    check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, 1, stream_of(x)), 'mode_conv3d_fwd')
+    wp = _wpack3d(Ci, Co, x.device)
+    check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)), 'mode_conv3d_fwd')
   return y
 
 
-def conv3d_bwd_data(gy, w):
+def conv3d_bwd_data(gy, w, in_shape, stride=1):
+  """gradient w.r.t. the input of conv3d_fwd; in_shape = x.shape."""
   require_gpu(gy, w)
   gy, w = gy.contiguous(), w.contiguous()
   require_f32c(gy, w)
-  B, Co, D, H, W = gy.shape
-  Ci = w.shape[1]
+  B, Ci, D, H, W = in_shape
+  Co = w.shape[0]
   gx = torch.empty((B, Ci, D, H, W), dtype=gy.dtype, device=gy.device)
   flops = 2 * gy.numel() * Ci * 27
   with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_data', 4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
-    wp = _wpack3d(w)
-    check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, 1, stream_of(gy)),
+    wp = _wpack3d(Ci, Co, gy.device)
+    check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
           'mode_conv3d_bwd_data')
   return gx
 
 
-def conv3d_bwd_weight(gy, x):
+def conv3d_bwd_weight(gy, x, stride=1):
+  """gW (Co,Ci,3,3,3) = sum gy[o, q] * x[c, stride*q + k - 1]."""
   require_gpu(gy, x)
   gy, x = gy.contiguous(), x.contiguous()
   require_f32c(gy, x)
-  B, Co, D, H, W = gy.shape
-  Ci = x.shape[1]
+  B, Ci, D, H, W = x.shape
+  Co = gy.shape[1]
   gw = torch.empty((Co, Ci, 3, 3, 3), dtype=gy.dtype, device=gy.device)
   flops = 2 * gy.numel() * Ci * 27
   with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_weight', 4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
-    n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co)
+    n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, stride)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, 1, 0, stream_of(gy)),
+    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, 0, stream_of(gy)),
           'mode_conv3d_bwd_weight')
   return gw
 
 
+def deconv3d_fwd(x, w):
+  """ConvTranspose3d k3 s2 p1 op1: x (B,Cin,D,H,W), w (Cin,Cout,3,3,3) -> (B,Cout,2D,2H,2W) (mode_disparity.py:23, 25)."""
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.contiguous()
+  require_f32c(x, w)
+  B, Cin, D, H, W = x.shape
+  Cout = w.shape[1]
+  if w.shape[0] != Cin or tuple(w.shape[2:]) != (3, 3, 3):
+    raise RuntimeError('deconv3d: weight %s does not match input channels %d / kernel 3' % (tuple(w.shape), Cin))
+  y = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+  flops = 2 * x.numel() * Cout * 27
+  with torch.cuda.device_of(x), profiling.region('deconv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+    wp = _wpack3d(Cin, Cout, x.device)
+    check(lib().mode_deconv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd')
+  return y
+
+
 class Conv3dFunction(torch.autograd.Function):
-  """k3 p1 s1 convolution on the HIP kernels; autograd of F.conv3d(x, w, None, 1, 1)."""
+  """k3 p1 convolution (stride 1|2) on the HIP kernels; autograd of F.conv3d(x, w, None, stride, 1)."""
 
   @staticmethod
-  def forward(ctx, x, w):
+  def forward(ctx, x, w, stride):
     ctx.save_for_backward(x, w)
-    return conv3d_fwd(x, w)
+    ctx.stride = stride
+    return conv3d_fwd(x, w, stride)
 
   @staticmethod
   def backward(ctx, gy):
     x, w = ctx.saved_tensors
-    gx = conv3d_bwd_data(gy, w) if ctx.needs_input_grad[0] else None
-    gw = conv3d_bwd_weight(gy, x) if ctx.needs_input_grad[1] else None
+    gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
+    gw = conv3d_bwd_weight(gy, x, ctx.stride) if ctx.needs_input_grad[1] else None
+    return gx, gw, None
+
+
+class Deconv3dFunction(torch.autograd.Function):
+  """ConvTranspose3d k3 s2 p1 op1; its input gradient is a stride-2 convolution with the same weights and its weight
+  gradient the stride-2 weight-gradient kernel with the roles of input and output gradient exchanged."""
+
+  @staticmethod
+  def forward(ctx, x, w):
+    ctx.save_for_backward(x, w)
+    return deconv3d_fwd(x, w)
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    gx = conv3d_fwd(gy, w, 2) if ctx.needs_input_grad[0] else None  # w (Cin,Cout,27) read as (Co=Cin, Ci=Cout)
+    gw = conv3d_bwd_weight(x, gy, 2) if ctx.needs_input_grad[1] else None  # -> (Cin, Cout, 3,3,3)
     return gx, gw
 
 
-def conv3d(x, w):
-  return Conv3dFunction.apply(x, w)
+def conv3d(x, w, stride=1):
+  return Conv3dFunction.apply(x, w, stride)
+
+
+def deconv3d(x, w):
+  return Deconv3dFunction.apply(x, w)
 
 
 # ------------------------------------------------------------------------------------ fused soft-argmin head

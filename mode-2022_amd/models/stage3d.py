@@ -2,9 +2,8 @@
 
 Each helper takes the nn.Module that owns the parameters (so the state_dict layout stays the reference's) and
 runs the layer.  ``BACKEND`` selects who does the arithmetic of the 3x3x3 convolutions:
-  'hip'    -- libmode_hip.so fp32-MFMA kernels for every stride-1 Conv3d with <= 64 channels (dres0, dres1, hourglass
-              conv2/conv4, classifier bodies = 82 % of the 3D FLOPs); the stride-2 / transposed / 32->1 layers run on the
-              vendor library until their kernels land (DESIGN.md tracks the coverage);
+  'hip'    -- libmode_hip.so fp32-MFMA kernels for every 3x3x3 layer of the regulariser: stride-1 and stride-2 Conv3d,
+              ConvTranspose3d (k3 s2 p1 op1) and the 32->1 classifier convolutions, forward and both gradients;
   'vendor' -- torch.nn.functional on the GPU (MIOpen) for everything; used for A/B measurements.
 Neither is a CPU path; BatchNorm / ReLU / residual adds are torch GPU ops for now.
 """
@@ -20,18 +19,32 @@ BACKEND = os.environ.get('MODE_STAGE3D', 'hip')
 HEAD_BACKEND = os.environ.get('MODE_HEAD', 'hip')  # 'hip' = fused kernel (mode_head_fwd/bwd), 'vendor' = torch ops
 
 
-def _hip_conv_ok(conv):
-  return (BACKEND == 'hip' and type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and
-          conv.padding == (1, 1, 1) and conv.dilation == (1, 1, 1) and conv.groups == 1 and conv.bias is None and
-          conv.in_channels <= 64 and 8 <= conv.out_channels <= 64)
+def _hip_kind(conv, x):
+  """'conv1' / 'conv2' / 'deconv' if libmode_hip implements this layer, else None (vendor library)."""
+  if BACKEND != 'hip' or conv.kernel_size != (3, 3, 3) or conv.padding != (1, 1, 1) or conv.dilation != (1, 1, 1) or \
+      conv.groups != 1 or conv.bias is not None or conv.in_channels > 64 or conv.out_channels > 64:
+    return None
+  if type(conv) is nn.Conv3d:
+    if conv.stride == (1, 1, 1):
+      return 'conv1'
+    if conv.stride == (2, 2, 2) and all(s % 2 == 0 for s in x.shape[2:]):
+      return 'conv2'
+  if type(conv) is nn.ConvTranspose3d and conv.stride == (2, 2, 2) and conv.output_padding == (1, 1, 1):
+    return 'deconv'
+  return None
 
 
 def conv3(conv, x):
   """One Conv3d / ConvTranspose3d layer."""
   if not x.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')  # same refusal as the reference's native op
-  if _hip_conv_ok(conv):
-    return HF.conv3d(x, conv.weight)
+  kind = _hip_kind(conv, x)
+  if kind == 'conv1':
+    return HF.conv3d(x, conv.weight, 1)
+  if kind == 'conv2':
+    return HF.conv3d(x, conv.weight, 2)
+  if kind == 'deconv':
+    return HF.deconv3d(x, conv.weight)
   return conv(x)
 
 

@@ -224,6 +224,25 @@ def run_model(models, maxdisp, H, W, B, seed, tag, full_outputs, with_grad=True)
   out['eval/logits3'] = taps['classif3'].numpy() if full_outputs else taps['classif3'][:, :, ::2, ::4, ::4].numpy()
   for h in hooks:
     h.remove()
+  # ---- fp64 evaluation of the same network by the (pinned) oracle: the reference's own fp32 run is only reproducible
+  # to E_ref = max|ref32 - truth64| (1e-3 .. 1e-2 here), which is what an independent fp32 implementation can be held to.
+  from oracle import mode_ref
+  P64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in recipe.recipe_state(manifest, seed).items()}
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+  with torch.no_grad():
+    t64 = mode_ref.mode_disparity(P64, left.double(), right.double(), maxdisp, pos, True)
+  for i, p in enumerate(t64):
+    out['truth64/train_pred%d' % (i + 1)] = p[sub].numpy()
+  out['truth64/train_E_ref'] = np.array(max(float((torch.from_numpy(out['train/pred%d' % (i + 1)]).double() - t64[i][sub]).abs().max())
+                                            for i in range(3)))
+  for k, v in out.items():
+    if k.startswith('bn/'):
+      P64[k[3:]] = torch.from_numpy(v).double()
+  with torch.no_grad():
+    e64 = mode_ref.mode_disparity(P64, left.double(), right.double(), maxdisp, pos, False)
+  out['truth64/eval_pred3'] = e64[sub].numpy()
+  out['truth64/eval_E_ref'] = np.array(float((torch.from_numpy(out['eval/pred3']).double() - e64[sub]).abs().max()))
+  print('  E_ref (reference fp32 vs fp64): train %.3e eval %.3e' % (float(out['truth64/train_E_ref']), float(out['truth64/eval_E_ref'])))
   np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % tag), **out)
   print('model', tag, 'loss', float(loss), 'eval mean', float(pred.mean()),
         'frac integer', float((pred == pred.round()).float().mean()))

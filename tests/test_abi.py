@@ -52,6 +52,42 @@ def test_argument_validation_without_gpu():
     mode_hip.check(-1, 'x')
 
 
+@pytest.mark.parametrize('typ,ih,iw,stride', [('ERP', 8, 16, 1), ('Cassini', 16, 8, 1), ('ERP', 8, 16, 2)])
+def test_adjoint_table_is_the_transpose_of_the_gather(typ, ih, iw, stride):
+  """mode_sphere_adjoint_build is host code: check it against the oracle's col2im (cu:293-356 restated)."""
+  import numpy as np
+  import torch
+  from oracle import mode_ref, sphere_conv_ref
+  pos = mode_ref.sphere_position(ih, iw, typ)
+  H, W = pos.shape[2:]
+  Ho, Wo = sphere_conv_ref.out_size(H, 3, stride, 1, 1), sphere_conv_ref.out_size(W, 3, stride, 1, 1)
+  lib = mode_hip.lib()
+  nmax = lib.mode_sphere_adjoint_max_entries(3, 3, Ho, Wo)
+  rowptr = torch.empty(9 * H * W + 1, dtype=torch.int32)
+  entries = torch.empty(2 * nmax, dtype=torch.int32)
+  n = ctypes.c_int64(0)
+  rc = lib.mode_sphere_adjoint_build(ctypes.c_void_p(pos.data_ptr()), H, W, 3, 3, stride, stride, Ho, Wo,
+                                     ctypes.c_void_p(rowptr.data_ptr()), ctypes.c_void_p(entries.data_ptr()),
+                                     ctypes.cast(ctypes.pointer(n), ctypes.c_void_p))
+  assert rc == 0 and 0 < n.value <= nmax and int(rowptr[-1]) == n.value
+  assert bool((rowptr[1:] >= rowptr[:-1]).all())
+  ent = entries[:2 * n.value].view(-1, 2)
+  p_idx = ent[:, 0].long()
+  wts = ent[:, 1].contiguous().view(torch.float32).double()
+  g = torch.Generator().manual_seed(0)
+  gcol = torch.randn(1, 2, 9, Ho, Wo, generator=g, dtype=torch.float64)
+  want = sphere_conv_ref.col2im_scatter(gcol, pos, H, W, 3, 3, stride, stride)  # (1,2,H,W)
+  rows = torch.repeat_interleave(torch.arange(9 * H * W), (rowptr[1:] - rowptr[:-1]).long())
+  k_idx, q_idx = rows // (H * W), rows % (H * W)
+  got = torch.zeros(2, H * W, dtype=torch.float64)
+  got.index_add_(1, q_idx, gcol[0].reshape(2, 9, Ho * Wo)[:, k_idx, p_idx] * wts)
+  assert (got.view(2, H, W) - want[0]).abs().max() < 2e-6  # the table's weights are fp32 (kernel arithmetic), the oracle's fp64
+  # rows are filled in ascending output-pixel order (deterministic summation)
+  for r in (0, 5 * H * W + 3, 9 * H * W - 1):
+    seg = p_idx[int(rowptr[r]):int(rowptr[r + 1])]
+    assert bool((seg[1:] >= seg[:-1]).all())
+
+
 def test_workspace_queries_are_host_only():
   lib = mode_hip.lib()
   n = lib.mode_sphere_conv_wpack_bytes(128, 128, 3, 3, 1)

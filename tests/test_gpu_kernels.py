@@ -217,6 +217,61 @@ def test_conv3d_fwd_bwd(B, Ci, Co, D, H, W):
   assert torch.equal(g2, wd.grad)
 
 
+@pytest.mark.parametrize('B,Ci,Co,D,H,W', [(2, 8, 16, 8, 8, 8), (1, 32, 64, 4, 8, 64), (1, 64, 64, 6, 12, 40), (2, 20, 40, 4, 6, 70)])
+def test_conv3d_stride2(B, Ci, Co, D, H, W):
+  """hourglass conv1 / conv3 (mode_disparity.py:15, 19): k3 s2 p1."""
+  import torch.nn.functional as F
+  x = _rand((B, Ci, D, H, W), 44)
+  w = _rand((Co, Ci, 3, 3, 3), 45, (2.0 / (27 * Co))**0.5)
+  xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+  y_ref = F.conv3d(xa, wa, None, 2, 1)
+  gy = _rand(tuple(y_ref.shape), 46)
+  y_ref.backward(gy.double())
+  xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+  y = HF.conv3d(xd, wd, 2)
+  assert y.shape == y_ref.shape
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 2e-6 * Ci * 27 * max(1.0, float(y_ref.abs().max()))
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 2e-6 * Co * 27 * max(1.0, float(xa.grad.abs().max()))
+  assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+
+
+@pytest.mark.parametrize('B,Ci,Co,D,H,W', [(2, 8, 16, 4, 4, 4), (1, 64, 64, 3, 8, 32), (1, 64, 32, 6, 16, 32), (2, 24, 40, 2, 5, 35)])
+def test_deconv3d(B, Ci, Co, D, H, W):
+  """hourglass conv5 / conv6 (mode_disparity.py:23, 25): ConvTranspose3d k3 s2 p1 op1, weight (Cin, Cout, 3,3,3)."""
+  import torch.nn.functional as F
+  x = _rand((B, Ci, D, H, W), 47)
+  w = _rand((Ci, Co, 3, 3, 3), 48, 0.1)
+  xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+  y_ref = F.conv_transpose3d(xa, wa, None, 2, 1, 1)
+  gy = _rand(tuple(y_ref.shape), 49)
+  y_ref.backward(gy.double())
+  xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+  y = HF.deconv3d(xd, wd)
+  assert y.shape == y_ref.shape == (B, Co, 2 * D, 2 * H, 2 * W)
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 2e-6 * Ci * 27 * max(1.0, float(y_ref.abs().max()))
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 2e-6 * Co * 27 * max(1.0, float(xa.grad.abs().max()))
+  assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+
+
+def test_conv3d_single_output_channel():
+  """classifN[2]: Conv3d(32 -> 1) (mode_disparity.py:76-80)."""
+  import torch.nn.functional as F
+  x = _rand((2, 32, 6, 12, 40), 54)
+  w = _rand((1, 32, 3, 3, 3), 55, 0.05)
+  xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+  y_ref = F.conv3d(xa, wa, None, 1, 1)
+  gy = _rand(tuple(y_ref.shape), 56)
+  y_ref.backward(gy.double())
+  xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+  y = HF.conv3d(xd, wd, 1)
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 1e-4
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 1e-4
+  assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+
+
 # ------------------------------------------------------------------ fused head (a13/a14)
 @pytest.mark.parametrize('B,D4,H4,W4,scale', [(2, 4, 6, 8, 4), (1, 12, 5, 7, 4), (1, 3, 4, 4, 3), (2, 48, 8, 16, 4)])
 def test_head_fwd_bwd_conf(B, D4, H4, W4, scale):

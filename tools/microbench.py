@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timings at the benchmark shapes (GPU box).  Prints one line per kernel: avg ms, GB/s, TFLOP/s.
 
-  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,vendor3d,stages]
+  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,conv3d,head,vendor,stages]
 """
 import argparse
 import os
@@ -32,14 +32,14 @@ def timeit(fn, iters, warm=2):
 
 
 def report(name, ms, nbytes=0, flops=0):
-  print('%-38s %9.3f ms  %8.1f GB/s  %8.2f TFLOP/s' % (name, ms, nbytes / ms / 1e6, flops / ms / 1e9), flush=True)
+  print('%-46s %9.3f ms  %8.1f GB/s  %8.2f TFLOP/s' % (name, ms, nbytes / ms / 1e6, flops / ms / 1e9), flush=True)
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--batch', type=int, default=2)
   ap.add_argument('--iters', type=int, default=10)
-  ap.add_argument('--only', default='cost,sphere,vendor3d,stages')
+  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages')
   a = ap.parse_args()
   only = a.only.split(',')
   dev = 'cuda:0'
@@ -76,40 +76,58 @@ def main():
       wr = torch.randn(co, ci, 3, 3, device=dev)
       report('  (vendor conv2d 3x3 same shape)', timeit(lambda: F.conv2d(x, wr, None, 1, 1), a.iters), nb, fl)
 
-  if 'vendor3d' in only:
-    for (ci, co, d, h, w_, s) in ((64, 32, 48, 256, 128, 1), (32, 32, 48, 256, 128, 1), (32, 64, 48, 256, 128, 2), (64, 64, 24, 128, 64, 1),
-                                  (64, 64, 24, 128, 64, 2), (64, 64, 12, 64, 32, 1), (32, 1, 48, 256, 128, 1)):
-      x = torch.randn(B, ci, d, h, w_, device=dev, requires_grad=True)
-      wt = torch.randn(co, ci, 3, 3, 3, device=dev, requires_grad=True)
-      y = F.conv3d(x, wt, None, s, 1)
+  if 'conv3d' in only:
+    shapes = ((64, 32, 48, 256, 128, 1), (32, 32, 48, 256, 128, 1), (32, 64, 48, 256, 128, 2), (64, 64, 24, 128, 64, 1),
+              (64, 64, 24, 128, 64, 2), (64, 64, 12, 64, 32, 1), (32, 1, 48, 256, 128, 1))
+    for (ci, co, d, h, w_, s) in shapes:
+      x = torch.randn(B, ci, d, h, w_, device=dev)
+      wt = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05
+      y = HF.conv3d_fwd(x, wt, s)
       fl = 2 * y.numel() * ci * 27
       nb = 4 * (x.numel() + y.numel())
-      report('vendor conv3d %d->%d s%d @%dx%dx%d fwd' % (ci, co, s, d, h, w_), timeit(lambda: F.conv3d(x, wt, None, s, 1), a.iters), nb, fl)
+      tag = '%d->%d s%d @%dx%dx%d' % (ci, co, s, d, h, w_)
+      report('conv3d_fwd ' + tag, timeit(lambda: HF.conv3d_fwd(x, wt, s), a.iters), nb, fl)
+      report('  (vendor conv3d fwd)', timeit(lambda: F.conv3d(x, wt, None, s, 1), max(2, a.iters // 3)), nb, fl)
       gy = torch.randn_like(y)
-
-      def bwd():
-        x.grad = wt.grad = None
-        F.conv3d(x, wt, None, s, 1).backward(gy)
-
-      report('   fwd+bwd', timeit(bwd, max(2, a.iters // 2)), 3 * nb, 3 * fl)
+      report('conv3d_bwd_data ' + tag, timeit(lambda: HF.conv3d_bwd_data(gy, wt, x.shape, s), a.iters), nb, fl)
+      report('conv3d_bwd_weight ' + tag, timeit(lambda: HF.conv3d_bwd_weight(gy, x, s), a.iters), nb, fl)
       del x, wt, y, gy
-    x = torch.randn(B, 64, 12, 64, 32, device=dev)
-    wt = torch.randn(64, 64, 3, 3, 3, device=dev)
-    y = F.conv_transpose3d(x, wt, None, 2, 1, 1)
-    report('vendor deconv3d 64->64 @12x64x32', timeit(lambda: F.conv_transpose3d(x, wt, None, 2, 1, 1), a.iters), 4 * (x.numel() + y.numel()),
-           2 * x.numel() * 64 * 27)
+    for (ci, co, d, h, w_) in ((64, 64, 12, 64, 32), (64, 32, 24, 128, 64)):
+      x = torch.randn(B, ci, d, h, w_, device=dev)
+      wt = torch.randn(ci, co, 3, 3, 3, device=dev) * 0.05
+      y = HF.deconv3d_fwd(x, wt)
+      fl = 2 * x.numel() * co * 27
+      nb = 4 * (x.numel() + y.numel())
+      report('deconv3d_fwd %d->%d @%dx%dx%d' % (ci, co, d, h, w_), timeit(lambda: HF.deconv3d_fwd(x, wt), a.iters), nb, fl)
+      report('  (vendor conv_transpose3d fwd)', timeit(lambda: F.conv_transpose3d(x, wt, None, 2, 1, 1), max(2, a.iters // 3)), nb, fl)
+      del x, wt, y
+
+  if 'head' in only:
+    lg = torch.randn(B, 1, 48, 256, 128, device=dev)
+    nb = 4 * (lg.numel() + B * 1024 * 512)
+    report('head_fwd', timeit(lambda: HF.head_fwd(lg, (192, 1024, 512)), a.iters), nb)
+    report('head_fwd + confidence', timeit(lambda: HF.head_fwd(lg, (192, 1024, 512), True), a.iters), nb)
+    g = torch.randn(B, 1, 1024, 512, device=dev)
+    report('head_bwd', timeit(lambda: HF.head_bwd(lg, g, (192, 1024, 512)), a.iters), nb + 4 * lg.numel())
+    from models import stage3d
+    report('  (vendor upsample+softmax+regress fwd)', timeit(lambda: stage3d.head_vendor(lg, (192, 1024, 512)), 3), nb)
+
+  if 'vendor' in only:
     x = torch.randn(B, 32, 48, 256, 128, device=dev)
     bn = torch.nn.BatchNorm3d(32).to(dev)
-    report('vendor BatchNorm3d train 32ch', timeit(lambda: bn(x), a.iters), 2 * 4 * x.numel())
+    report('vendor BatchNorm3d train 32ch fwd', timeit(lambda: bn(x), a.iters), 2 * 4 * x.numel())
+    xr = x.clone().requires_grad_(True)
+
+    def bnb():
+      xr.grad = None
+      bn(xr).sum().backward()
+
+    report('vendor BatchNorm3d fwd+bwd', timeit(bnb, 3), 5 * 4 * x.numel())
     report('vendor relu', timeit(lambda: F.relu(x), a.iters), 2 * 4 * x.numel())
-    lg = torch.randn(B, 1, 48, 256, 128, device=dev)
-
-    def head():
-      up = F.interpolate(lg, [192, 1024, 512], mode='trilinear', align_corners=True).squeeze(1)
-      p = F.softmax(up, 1)
-      return (p * torch.arange(192, device=dev, dtype=p.dtype).view(1, 192, 1, 1)).sum(1, keepdim=True)
-
-    report('vendor head (upsample+softmax+regress)', timeit(head, a.iters), 4 * (lg.numel() + B * 1024 * 512))
+    report('vendor add', timeit(lambda: x + x, a.iters), 3 * 4 * x.numel())
+    x2 = torch.randn(B, 64, 512, 256, device=dev)
+    bn2 = torch.nn.BatchNorm2d(64).to(dev)
+    report('vendor BatchNorm2d train 64ch @512x256', timeit(lambda: bn2(x2), a.iters), 2 * 4 * x2.numel())
 
   if 'stages' in only:
     import models
@@ -121,10 +139,17 @@ def main():
       fea = net.feature_extraction(left)
       cost = HF.cost_volume_fwd(fea, fea, 48)
       report('stage: dres0 fwd', timeit(lambda: net.dres0(cost), 3, 1))
-      c0 = net.dres0(cost)
+      from models import stage3d
+      c0 = stage3d.conv_bn(net.dres0[0], cost, relu=True)
       report('stage: hourglass fwd', timeit(lambda: net.dres2(c0, None, None), 3, 1))
-      report('stage: classif fwd', timeit(lambda: net.classif1(c0), 3, 1))
+      report('stage: classif fwd', timeit(lambda: stage3d.classify(net.classif1, c0), 3, 1))
       report('stage: full forward (train mode, 3 heads)', timeit(lambda: net(left, right), 3, 1))
+
+    def fe():
+      net.zero_grad()
+      net.feature_extraction(left).sum().backward()
+
+    report('stage: feature_extraction fwd+bwd', timeit(fe, 3, 1))
 
     def full():
       net.zero_grad()
