@@ -165,6 +165,31 @@ size_t mode_head_bwd_workspace_bytes(int B, int D4, int H, int W);
 int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float* workspace, int B, int D4, int H4,
                   int W4, int D, int H, int W, mode_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm (+ residual add) (+ ReLU) over (B, C, S) tensors, S = D*H*W or H*W, S % 4 == 0.
+ * Replaces nn.BatchNorm3d/2d of convbn_3d / convbn (models/submodule.py:15-22) fused with the adds and ReLUs that
+ * follow it in hourglass.forward / ModeDisparity.forward (models/mode_disparity.py:27-46, 115-129):
+ *      out = relu?( gamma * (y - mean) / sqrt(var + eps) + beta  [+ add] )
+ * train: batch statistics over (B, S) per channel (biased variance for normalisation); running_mean / running_var are
+ *        updated in place with `momentum` (unbiased variance), as torch does; save_mean / save_invstd feed the backward.
+ * eval : running statistics.
+ * bwd  : g = relu ? gout * (out > 0) : gout;  gy = dL/dy, ggamma, gbeta written; gadd (optional, = g) written if non-NULL.
+ * `workspace` >= mode_bn_workspace_bytes(C) for every call.
+ */
+size_t mode_bn_workspace_bytes(int C);
+
+int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int relu, float* out, float* save_mean,
+                      float* save_invstd, float* workspace, int B, int C, long long S, mode_stream_t stream);
+
+int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, int relu, float* out, float* workspace, int B, int C,
+                     long long S, mode_stream_t stream);
+
+int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
+                      const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
+                      float* workspace, int B, int C, long long S, mode_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

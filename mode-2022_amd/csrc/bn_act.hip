@@ -1,0 +1,361 @@
+// BatchNorm (+ residual add) (+ ReLU) for (B, C, S) fp32 tensors (S = D*H*W or H*W), gfx950.
+//
+// Reference: nn.BatchNorm3d / nn.BatchNorm2d inside convbn_3d / convbn (models/submodule.py:15-22, torch defaults eps 1e-5,
+// momentum 0.1, affine, running statistics, per-replica batch statistics) followed by the residual adds and ReLUs of
+// hourglass.forward / ModeDisparity.forward (models/mode_disparity.py:27-46, 115-129).  The reference runs these as separate
+// kernels (BN: read, read, write; add: read, read, write; ReLU: read, write); here a layer is two HBM passes in training
+// (statistics, then normalise + add + ReLU in one pass) and one pass in eval mode.  Pure HBM roofline kernels:
+//   train fwd  : (2 reads [+1 read of the skip tensor] + 1 write) * 4 B per element
+//   train bwd  : reduce pass (reads gout, y [, out]) + apply pass (reads gout, y [, out], writes gy [, gadd])
+// Statistics are reduced per thread / per block in fp32 over short runs and combined across blocks in fp64.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [8] */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sh[wave] = a;
+    sh[4 + wave] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sh[0] + sh[1] + sh[2] + sh[3];
+    b = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
+
+// grid = (nsplit, C).  partial[(c*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int B, int C,
+                                                      long long S, int nsplit) {
+  __shared__ float sh[8];
+  const int c = blockIdx.y, split = blockIdx.x;
+  const long long S4 = S >> 2;
+  const long long per_b = (S4 + nsplit - 1) / nsplit;
+  const long long lo = split * per_b, hi = min(S4, lo + per_b);
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float4* p = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * S);
+    for (long long i = lo + threadIdx.x; i < hi; i += NT) {
+      const float4 v = p[i];
+      s0 += (v.x + v.y) + (v.z + v.w);
+      s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (split == 0) {  // ragged tail (S % 4)
+      const float* q = y + ((long long)b * C + c) * S;
+      for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+        s0 += q[i];
+        s1 += q[i] * q[i];
+      }
+    }
+  }
+  block_sum2(s0, s1, sh);
+  if (threadIdx.x == 0) {
+    partial[((long long)c * nsplit + split) * 2] = s0;
+    partial[((long long)c * nsplit + split) * 2 + 1] = s1;
+  }
+}
+
+// one thread per channel: batch mean / biased variance, running-stat update (unbiased variance), affine coefficients
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C, int nsplit, double count) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nsplit; ++i) {
+    s0 += (double)partial[((long long)c * nsplit + i) * 2];
+    s1 += (double)partial[((long long)c * nsplit + i) * 2 + 1];
+  }
+  const double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)invstd;
+  const double sc = (double)gamma[c] * invstd;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - mean * sc);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(running_var[c] + eps);  // same arithmetic order as torch's eval-mode batch_norm
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
+template <bool RELU, bool ADD>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ out, int C, long long S) {
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const float sc = scale[c], sh = shift[c];
+  const long long base = (long long)bc * S;
+  const long long S4 = S >> 2;
+  const float4* yp = reinterpret_cast<const float4*>(y + base);
+  const float4* ap = reinterpret_cast<const float4*>(add + base);
+  float4* op = reinterpret_cast<float4*>(out + base);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
+    float4 v = yp[i];
+    v.x = v.x * sc + sh;
+    v.y = v.y * sc + sh;
+    v.z = v.z * sc + sh;
+    v.w = v.w * sc + sh;
+    if (ADD) {
+      const float4 a = ap[i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    op[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+      float v = y[base + i] * sc + sh;
+      if (ADD) v += add[base + i];
+      if (RELU) v = fmaxf(v, 0.f);
+      out[base + i] = v;
+    }
+}
+
+// Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y)
+template <bool RELU>
+__global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ gout, const float* __restrict__ y,
+                                                          const float* __restrict__ out, float* __restrict__ partial, int B, int C,
+                                                          long long S, int nsplit) {
+  __shared__ float sh[8];
+  const int c = blockIdx.y, split = blockIdx.x;
+  const long long S4 = S >> 2;
+  const long long per_b = (S4 + nsplit - 1) / nsplit;
+  const long long lo = split * per_b, hi = min(S4, lo + per_b);
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const long long base = ((long long)b * C + c) * S;
+    const float4* gp = reinterpret_cast<const float4*>(gout + base);
+    const float4* yp = reinterpret_cast<const float4*>(y + base);
+    const float4* op = reinterpret_cast<const float4*>(out + base);
+    for (long long i = lo + threadIdx.x; i < hi; i += NT) {
+      float4 g = gp[i];
+      const float4 v = yp[i];
+      if (RELU) {
+        const float4 o = op[i];
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      s0 += (g.x + g.y) + (g.z + g.w);
+      s1 += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+    }
+    if (split == 0)
+      for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+        float g = gout[base + i];
+        if (RELU) g = out[base + i] > 0.f ? g : 0.f;
+        s0 += g;
+        s1 += g * y[base + i];
+      }
+  }
+  block_sum2(s0, s1, sh);
+  if (threadIdx.x == 0) {
+    partial[((long long)c * nsplit + split) * 2] = s0;
+    partial[((long long)c * nsplit + split) * 2 + 1] = s1;
+  }
+}
+
+// ggamma = invstd * (sum(g*y) - mean*sum(g)), gbeta = sum(g); gy = A*g + Bc*y + Cc
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                       float* __restrict__ ggamma, float* __restrict__ gbeta, float* __restrict__ coef /* [3][C] */,
+                                       int C, int nsplit, double count) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgy = 0.0;
+  for (int i = 0; i < nsplit; ++i) {
+    sg += (double)partial[((long long)c * nsplit + i) * 2];
+    sgy += (double)partial[((long long)c * nsplit + i) * 2 + 1];
+  }
+  const double mean = save_mean[c], invstd = save_invstd[c], gm = gamma[c];
+  const double dgamma = invstd * (sgy - mean * sg);
+  ggamma[c] = (float)dgamma;
+  gbeta[c] = (float)sg;
+  const double A = gm * invstd;
+  coef[c] = (float)A;
+  coef[C + c] = (float)(-A * invstd * dgamma / count);
+  coef[2 * C + c] = (float)(A * (mean * invstd * dgamma - sg) / count);
+}
+
+// grid = (chunks, B*C): g = masked gout; gy = A*g + Bc*y + Cc; optionally gadd = g
+template <bool RELU, bool GADD>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ gout, const float* __restrict__ y,
+                                                          const float* __restrict__ out, const float* __restrict__ coef,
+                                                          float* __restrict__ gy, float* __restrict__ gadd, int C, long long S) {
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const float A = coef[c], Bc = coef[C + c], Cc = coef[2 * C + c];
+  const long long base = (long long)bc * S;
+  const long long S4 = S >> 2;
+  const float4* gp = reinterpret_cast<const float4*>(gout + base);
+  const float4* yp = reinterpret_cast<const float4*>(y + base);
+  const float4* op = reinterpret_cast<const float4*>(out + base);
+  float4* gyp = reinterpret_cast<float4*>(gy + base);
+  float4* gap = reinterpret_cast<float4*>(gadd + base);
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
+    float4 g = gp[i];
+    const float4 v = yp[i];
+    if (RELU) {
+      const float4 o = op[i];
+      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    if (GADD) gap[i] = g;
+    float4 r;
+    r.x = A * g.x + Bc * v.x + Cc;
+    r.y = A * g.y + Bc * v.y + Cc;
+    r.z = A * g.z + Bc * v.z + Cc;
+    r.w = A * g.w + Bc * v.w + Cc;
+    gyp[i] = r;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+      float g = gout[base + i];
+      if (RELU) g = out[base + i] > 0.f ? g : 0.f;
+      if (GADD) gadd[base + i] = g;
+      gy[base + i] = A * g + Bc * y[base + i] + Cc;
+    }
+}
+
+int pick_nsplit(int C, long long S) {
+  // ~8 blocks per CU in total, each with at least 4096 elements per image
+  long long n = (8LL * kNumCU + C - 1) / C;
+  const long long maxn = std::max<long long>(1, (S / 4) / 1024);
+  if (n > maxn) n = maxn;
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+
+int apply_chunks(int BC, long long S) {
+  long long n = (8LL * kNumCU + BC - 1) / BC;
+  const long long maxn = std::max<long long>(1, ((S / 4) + NT - 1) / NT);
+  if (n > maxn) n = maxn;
+  return (int)std::max<long long>(1, n);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_bn(int B, int C, long long S, const char* who) {
+  MODE_REQUIRE(B >= 0 && C > 0 && S > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE((long long)B * C < 65536, MODE_ERR_UNSUPPORTED, "%s: B*C = %lld exceeds the grid limit", who, (long long)B * C);
+  MODE_REQUIRE(S % 4 == 0, MODE_ERR_UNSUPPORTED, "%s: spatial size %lld not a multiple of 4 (vector path needs 16-byte rows)", who, S);
+  return MODE_OK;
+}
+
+template <typename K, typename... Args>
+int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who, Args... args) {
+  hipLaunchKernelGGL(kernel, dim3(apply_chunks(BC, S), BC), dim3(NT), 0, st, args...);
+  return mode::check_launch(who);
+}
+
+}  // namespace
+
+// workspace (floats): partial sums C*1024*2 + scale C + shift C (+ 3C coefficients for the backward)
+extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * (2048 + 5) * sizeof(float) : 0; }
+
+extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, int relu, float* out, float* save_mean,
+                                 float* save_invstd, float* workspace, int B, int C, long long S, mode_stream_t stream) {
+  int rc = check_bn(B, C, S, "mode_bn_train_fwd");
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
+  MODE_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && workspace, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: null pointer");
+  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_train_fwd: unaligned buffer");
+  MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
+  hipStream_t st = mode::as_stream(stream);
+  const int nsplit = pick_nsplit(C, S);
+  float* partial = workspace;
+  float* scale = workspace + (size_t)C * 2048;
+  float* shift = scale + C;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NT), 0, st, y, partial, B, C, S, nsplit);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, partial, gamma, beta, running_mean, running_var,
+                     momentum, eps, save_mean, save_invstd, scale, shift, C, nsplit, (double)B * (double)S);
+  const int BC = B * C;
+  if (relu) {
+    if (add) return launch_apply(bn_apply_kernel<true, true>, BC, S, st, "mode_bn_train_fwd", y, add, scale, shift, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false>, BC, S, st, "mode_bn_train_fwd", y, y, scale, shift, out, C, S);
+  }
+  if (add) return launch_apply(bn_apply_kernel<false, true>, BC, S, st, "mode_bn_train_fwd", y, add, scale, shift, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false>, BC, S, st, "mode_bn_train_fwd", y, y, scale, shift, out, C, S);
+}
+
+extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, int relu, float* out, float* workspace, int B, int C,
+                                long long S, mode_stream_t stream) {
+  int rc = check_bn(B, C, S, "mode_bn_eval_fwd");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(y && gamma && beta && running_mean && running_var && out && workspace, MODE_ERR_BAD_ARG, "mode_bn_eval_fwd: null pointer");
+  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_eval_fwd: unaligned buffer");
+  hipStream_t st = mode::as_stream(stream);
+  float* scale = workspace + (size_t)C * 2048;
+  float* shift = scale + C;
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, gamma, beta, running_mean, running_var, eps, scale,
+                     shift, C);
+  const int BC = B * C;
+  if (relu) {
+    if (add) return launch_apply(bn_apply_kernel<true, true>, BC, S, st, "mode_bn_eval_fwd", y, add, scale, shift, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false>, BC, S, st, "mode_bn_eval_fwd", y, y, scale, shift, out, C, S);
+  }
+  if (add) return launch_apply(bn_apply_kernel<false, true>, BC, S, st, "mode_bn_eval_fwd", y, add, scale, shift, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false>, BC, S, st, "mode_bn_eval_fwd", y, y, scale, shift, out, C, S);
+}
+
+extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
+                                 float* workspace, int B, int C, long long S, mode_stream_t stream) {
+  int rc = check_bn(B, C, S, "mode_bn_train_bwd");
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");
+  MODE_REQUIRE(gout && y && gamma && save_mean && save_invstd && gy && ggamma && gbeta && workspace, MODE_ERR_BAD_ARG,
+               "mode_bn_train_bwd: null pointer");
+  MODE_REQUIRE(!relu || out, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: the ReLU mask needs the forward output");
+  MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)),
+               MODE_ERR_UNSUPPORTED, "mode_bn_train_bwd: unaligned buffer");
+  hipStream_t st = mode::as_stream(stream);
+  const int nsplit = pick_nsplit(C, S);
+  float* partial = workspace;
+  float* coef = workspace + (size_t)C * 2048 + 2 * C;
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, out, partial, B, C, S, nsplit);
+  else
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, y, partial, B, C, S, nsplit);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, partial, gamma, save_mean, save_invstd, ggamma,
+                     gbeta, coef, C, nsplit, (double)B * (double)S);
+  const int BC = B * C;
+  const char* who = "mode_bn_train_bwd";
+  if (relu) {
+    if (gadd) return launch_apply(bn_bwd_apply_kernel<true, true>, BC, S, st, who, gout, y, out, coef, gy, gadd, C, S);
+    return launch_apply(bn_bwd_apply_kernel<true, false>, BC, S, st, who, gout, y, out, coef, gy, gy, C, S);
+  }
+  if (gadd) return launch_apply(bn_bwd_apply_kernel<false, true>, BC, S, st, who, gout, y, y, coef, gy, gadd, C, S);
+  return launch_apply(bn_bwd_apply_kernel<false, false>, BC, S, st, who, gout, y, y, coef, gy, gy, C, S);
+}

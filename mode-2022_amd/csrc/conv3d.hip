@@ -503,6 +503,109 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
   }
 }
 
+// Stride-1 variant with a rolling depth window: a work unit is a (b, h-tile, w-tile) column times a run of DC consecutive
+// depths; the three x planes d-1, d, d+1 live in an LDS ring and only plane d+1 is staged per step (the halo re-read per
+// 64 output voxels drops from 408 to 136 floats per channel).  Same fragment maps and partial layout as the kernel above.
+constexpr int RING_DC = 12;
+
+__global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                    float* __restrict__ part, WDims d, int nDc, int units) {
+  constexpr int WTH = 2, XR = WTH + 2, XW = 34, PS = XR * XW;  // plane = 136 floats
+  constexpr int XPLANE = 3 * PS + 1;                           // 409 (odd)
+  constexpr int GPLANE = WTH * 32 + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xl = lds;                 // [32][3 ring slots][XR][XW]
+  float* gl = lds + 32 * XPLANE;   // [32][GPLANE]
+  const int s = blockIdx.x, ob = blockIdx.y, cb = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long long HW = (long long)d.H * d.W;
+  const long long DHW = (long long)d.D * HW;
+
+  f32x16 acc[7];
+  int kd[7], khw[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    acc[t] = (f32x16){0};
+    const int tap = wave + 4 * t;
+    kd[t] = tap / 9;
+    khw[t] = ((tap / 3) % 3) * XW + (tap % 3);
+  }
+  const bool last_valid = (wave + 24) < 27;
+
+  for (int u = s; u < units; u += d.S) {
+    int t = u;
+    const int dc = t % nDc;
+    t /= nDc;
+    const int wt = t % d.nWt;
+    t /= d.nWt;
+    const int ht = t % d.nHt;
+    const int b = t / d.nHt;
+    const int w0 = wt * 32, h0 = ht * WTH;
+    const int dlo = dc * RING_DC, dhi = min(d.D, dlo + RING_DC);
+    const float* xb = x + ((long long)b * d.Ci + cb * 32) * DHW;
+    const float* gb = gy + ((long long)b * d.Co + ob * 32) * DHW;
+
+    for (int dd = dlo; dd < dhi; ++dd) {
+      // stage x planes: all three at the start of a unit, then only plane dd+1 (ring slot (z+3) % 3 for depth z)
+      const int zfirst = (dd == dlo) ? dd - 1 : dd + 1;
+      const int nplanes = (dd == dlo) ? 3 : 1;
+      for (int idx = tid; idx < 32 * nplanes * PS; idx += NT) {
+        const int c = idx / (nplanes * PS);
+        int rem = idx - c * (nplanes * PS);
+        const int pz = rem / PS;
+        rem -= pz * PS;
+        const int hy = rem / XW;
+        const int wx = rem - hy * XW;
+        const int gd = zfirst + pz, gh = h0 + hy - 1, gw = w0 + wx - 1;
+        float v = 0.f;
+        if (cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
+          v = xb[c * DHW + gd * HW + gh * d.W + gw];
+        xl[c * XPLANE + ((gd + 3) % 3) * PS + rem] = v;
+      }
+      for (int idx = tid; idx < 32 * WTH * 32; idx += NT) {
+        const int o = idx / (WTH * 32);
+        const int rem = idx - o * (WTH * 32);
+        const int hy = rem / 32, wx = rem % 32;
+        const int gh = h0 + hy, gw = w0 + wx;
+        float v = 0.f;
+        if (ob * 32 + o < d.Co && gh < d.H && gw < d.W) v = gb[o * DHW + dd * HW + gh * d.W + gw];
+        gl[o * GPLANE + rem] = v;
+      }
+      __syncthreads();
+      int toff[7];
+#pragma unroll
+      for (int t7 = 0; t7 < 7; ++t7) toff[t7] = ((dd + kd[t7] + 2) % 3) * PS + khw[t7];  // depth dd + kd - 1
+      const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);
+      const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5);
+#pragma unroll
+      for (int row = 0; row < WTH; ++row) {
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = ap[row * 32 + 2 * ks];
+          const float* bq = bp + row * XW + 2 * ks;
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
+          if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  float* pb = part + (((long long)s * d.MTo + ob) * d.MTc + cb) * (27 * 1024);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < 27) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        pb[tap * 1024 + i * 32 + (lane & 31)] = acc[t][q];
+      }
+    }
+  }
+}
+
 // gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32]
 __global__ void reduce_gw3d(const float* __restrict__ part, float* __restrict__ gw, WDims d, int accumulate) {
   const long long total = (long long)d.Co * d.Ci * 27;
@@ -557,10 +660,13 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   WDims d;
   make_wdims(d, B, Ci, D, H, W, Co, stride);
   if (stride == 1) {
-    const size_t lds = WGeom<1, WTH1>::LDS;
-    rc = mode::allow_lds(conv3d_bwd_weight_kernel<1, WTH1>, lds, "mode_conv3d_bwd_weight");
+    const size_t lds = WGeom<1, WTH1>::LDS;  // same footprint: 3 planes of (WTH+2) x 34 per channel + the gy tile
+    rc = mode::allow_lds(conv3d_bwd_weight_ring_kernel, lds, "mode_conv3d_bwd_weight");
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_bwd_weight_kernel<1, WTH1>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+    const int nDc = mode::cdiv(D, RING_DC);
+    const int units = B * d.nHt * d.nWt * nDc;
+    if (d.S > units) d.S = units;  // never more than the workspace query assumed
+    hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units);
   } else {
     const size_t lds = WGeom<2, WTH2>::LDS;
     rc = mode::allow_lds(conv3d_bwd_weight_kernel<2, WTH2>, lds, "mode_conv3d_bwd_weight");

@@ -330,3 +330,101 @@ class HeadFunction(torch.autograd.Function):
 
 def head(logits, size):
   return HeadFunction.apply(logits, size)
+
+
+# ------------------------------------------------------------------------------------ BatchNorm (+ add) (+ ReLU)
+def _bn_ws(C, device):
+  return torch.empty(lib().mode_bn_workspace_bytes(C) // 4, dtype=torch.float32, device=device)
+
+
+def _bcs(t):
+  B, C = t.shape[:2]
+  S = t.numel() // max(B * C, 1)
+  return B, C, S
+
+
+def bn_supported(y):
+  B, C, S = _bcs(y)
+  return y.is_cuda and y.dtype == torch.float32 and S % 4 == 0 and B * C < 65536 and B > 0
+
+
+class BnActFunction(torch.autograd.Function):
+  """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
+
+  @staticmethod
+  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    require_gpu(y, add, gamma, beta)
+    y = y.contiguous()
+    add = add.contiguous() if add is not None else None
+    require_f32c(y, gamma, beta)
+    B, C, S = _bcs(y)
+    out = torch.empty_like(y)
+    mean = torch.empty(C, dtype=torch.float32, device=y.device)
+    invstd = torch.empty_like(mean)
+    nbytes = 4 * y.numel() * (3 + (1 if add is not None else 0))
+    with torch.cuda.device_of(y), profiling.region('bn_train_fwd', nbytes, 0, y.device):
+      ws = _bn_ws(C, y.device)
+      check(lib().mode_bn_train_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta),
+                                    ptr(running_mean) if running_mean is not None else None,
+                                    ptr(running_var) if running_var is not None else None, float(momentum), float(eps), int(relu),
+                                    ptr(out), ptr(mean), ptr(invstd), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_fwd')
+    ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+    ctx.relu, ctx.has_add = bool(relu), add is not None
+    return out
+
+  @staticmethod
+  def backward(ctx, gout):
+    y, out, gamma, mean, invstd = ctx.saved_tensors
+    gout = gout.contiguous()
+    B, C, S = _bcs(y)
+    gy = torch.empty_like(y)
+    need_gadd = ctx.has_add and ctx.relu and ctx.needs_input_grad[1]
+    gadd = torch.empty_like(y) if need_gadd else None
+    ggamma = torch.empty_like(gamma)
+    gbeta = torch.empty_like(gamma)
+    nbytes = 4 * y.numel() * (2 * (2 + (1 if ctx.relu else 0)) + 1 + (1 if need_gadd else 0))
+    with torch.cuda.device_of(y), profiling.region('bn_train_bwd', nbytes, 0, y.device):
+      ws = _bn_ws(C, y.device)
+      check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
+                                    int(ctx.relu), ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta), ptr(ws),
+                                    B, C, S, stream_of(y)), 'mode_bn_train_bwd')
+    if ctx.has_add and not ctx.relu:
+      gadd = gout  # the add passes the gradient through unchanged
+    return gy, gadd, ggamma, gbeta, None, None, None, None, None
+
+
+def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
+  require_gpu(y, add, gamma, beta, running_mean, running_var)
+  y = y.contiguous()
+  add = add.contiguous() if add is not None else None
+  require_f32c(y, gamma, beta, running_mean, running_var)
+  B, C, S = _bcs(y)
+  out = torch.empty_like(y)
+  nbytes = 4 * y.numel() * (2 + (1 if add is not None else 0))
+  with torch.cuda.device_of(y), profiling.region('bn_eval_fwd', nbytes, 0, y.device):
+    ws = _bn_ws(C, y.device)
+    check(lib().mode_bn_eval_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta), ptr(running_mean),
+                                 ptr(running_var), float(eps), int(relu), ptr(out), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_eval_fwd')
+  return out
+
+
+def bn_act(bn, y, add=None, relu=False):
+  """nn.BatchNorm2d/3d `bn` applied to y, then the optional residual add and ReLU, in one fused pass (two in training).
+  Same state handling as nn.BatchNorm: train mode uses batch statistics and updates running_mean / running_var /
+  num_batches_tracked; eval mode uses the running statistics."""
+  use_batch_stats = bn.training or bn.running_mean is None
+  if use_batch_stats:
+    momentum = bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+      bn.num_batches_tracked.add_(1)
+      if momentum is None:
+        momentum = 1.0 / float(bn.num_batches_tracked)
+    update = bn.training and bn.track_running_stats
+    return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
+                               momentum if momentum is not None else 0.0, bn.eps, relu)
+  if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
+    # eval-mode BN inside a graph that needs gradients: rare (the reference never does it); vendor ops keep autograd correct
+    out = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    out = out + add if add is not None else out
+    return torch.relu(out) if relu else out
+  return bn_eval(y, add, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)

@@ -36,13 +36,15 @@ class hourglass(nn.Module):
     self.conv6 = nn.Sequential(nn.ConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
                                nn.BatchNorm3d(inplanes))
 
-  def forward(self, x, presqu, postsqu):
+  def forward(self, x, presqu, postsqu, residual=None):
+    """`residual` (not in the reference signature) is added to the output inside the last fused BatchNorm pass; the
+    reference adds cost0 right after the call (mode_disparity.py:119, 122, 125)."""
     out = stage3d.conv_bn(self.conv1[0], x, relu=True)  # 1/4 -> 1/8
     pre = stage3d.conv_bn(self.conv2, out, relu=True, add=postsqu)  # relu(bn(conv) [+ postsqu])
     out = stage3d.conv_bn(self.conv3[0], pre, relu=True)  # 1/8 -> 1/16
     out = stage3d.conv_bn(self.conv4[0], out, relu=True)
     post = stage3d.conv_bn(self.conv5, out, relu=True, add=presqu if presqu is not None else pre)  # 1/16 -> 1/8
-    out = stage3d.conv_bn(self.conv6, post)  # 1/8 -> 1/4
+    out = stage3d.conv_bn(self.conv6, post, add=residual)  # 1/8 -> 1/4
     return out, pre, post
 
 
@@ -100,12 +102,9 @@ class ModeDisparity(nn.Module):
     t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
     cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
 
-    out1, pre1, post1 = self.dres2(cost0, None, None)
-    out1 = out1 + cost0
-    out2, pre2, post2 = self.dres3(out1, pre1, post1)
-    out2 = out2 + cost0
-    out3, pre3, post3 = self.dres4(out2, pre1, post2)  # pre1 (not pre2), as in the reference (:124)
-    out3 = out3 + cost0
+    out1, pre1, post1 = self.dres2(cost0, None, None, cost0)  # out1 = hourglass(...) + cost0
+    out2, pre2, post2 = self.dres3(out1, pre1, post1, cost0)
+    out3, pre3, post3 = self.dres4(out2, pre1, post2, cost0)  # pre1 (not pre2), as in the reference (:124)
 
     cost1 = stage3d.classify(self.classif1, out1)
     cost2 = stage3d.classify(self.classif2, out2) + cost1

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from mode_hip import functional as HF
 
 BACKEND = os.environ.get('MODE_STAGE3D', 'hip')
+BN_BACKEND = os.environ.get('MODE_BN', 'hip')  # 'hip' = fused BatchNorm+add+ReLU kernels (mode_bn_*), 'vendor' = torch ops
 HEAD_BACKEND = os.environ.get('MODE_HEAD', 'hip')  # 'hip' = fused kernel (mode_head_fwd/bwd), 'vendor' = torch ops
 
 
@@ -51,7 +52,20 @@ def conv3(conv, x):
 def conv_bn(seq, x, relu=False, add=None):
   """seq = Sequential(Conv3d | ConvTranspose3d, BatchNorm3d): y = bn(conv(x)) [+ add] [relu]
   (convbn_3d submodule.py:20-22; transposed form mode_disparity.py:23, 25)."""
-  y = seq[1](conv3(seq[0], x))
+  return bn_act(seq[1], conv3(seq[0], x), add, relu)
+
+
+def bn_act(bn, y, add=None, relu=False):
+  """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training), or vendor ops."""
+  if not y.is_cuda:
+    raise NotImplementedError('Only support cuda tensor!')
+  if BN_BACKEND == 'hip' and HF.bn_supported(y):
+    return HF.bn_act(bn, y, add, relu)
+  return bn_act_vendor(bn, y, add, relu)
+
+
+def bn_act_vendor(bn, y, add=None, relu=False):
+  y = bn(y)
   if add is not None:
     y = y + add
   return F.relu(y, inplace=True) if relu else y

@@ -272,6 +272,58 @@ def test_conv3d_single_output_channel():
   assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
 
 
+# ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
+@pytest.mark.parametrize('shape', [(2, 8, 4, 6, 8), (1, 32, 6, 16, 32), (2, 64, 24, 32), (3, 5, 2, 2, 4)])
+@pytest.mark.parametrize('relu,with_add', [(False, False), (True, False), (True, True), (False, True)])
+def test_bn_act_train_and_eval(shape, relu, with_add):
+  import torch.nn as nn
+  C = shape[1]
+  BN = nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d
+  ref_bn, dev_bn = BN(C).double(), BN(C).to(DEV)
+  g = torch.Generator().manual_seed(7)
+  gamma = 1 + 0.2 * torch.randn(C, generator=g)
+  beta = 0.3 * torch.randn(C, generator=g)
+  with torch.no_grad():
+    for bn in (ref_bn, dev_bn):
+      bn.weight.copy_(gamma)
+      bn.bias.copy_(beta)
+  y = _rand(shape, 71, 2.0) + 1.5  # non-zero mean: exercises the variance cancellation
+  add = _rand(shape, 72) if with_add else None
+  gout = _rand(shape, 73)
+  ya = y.double().requires_grad_(True)
+  aa = add.double().requires_grad_(True) if with_add else None
+  o_ref = ref_bn(ya)
+  if with_add:
+    o_ref = o_ref + aa
+  if relu:
+    o_ref = torch.relu(o_ref)
+  o_ref.backward(gout.double())
+  yd = y.to(DEV).requires_grad_(True)
+  ad = add.to(DEV).requires_grad_(True) if with_add else None
+  out = HF.bn_act(dev_bn, yd, ad, relu)
+  out.backward(gout.to(DEV))
+  assert (out.detach().cpu().double() - o_ref.detach()).abs().max() < 2e-5
+  assert (yd.grad.cpu().double() - ya.grad).abs().max() < 5e-5 * max(1.0, float(ya.grad.abs().max()))
+  if with_add:
+    assert (ad.grad.cpu().double() - aa.grad).abs().max() < 1e-6
+  assert (dev_bn.weight.grad.cpu().double() - ref_bn.weight.grad).abs().max() < 1e-4 * max(1.0, float(ref_bn.weight.grad.abs().max()))
+  assert (dev_bn.bias.grad.cpu().double() - ref_bn.bias.grad).abs().max() < 1e-4 * max(1.0, float(ref_bn.bias.grad.abs().max()))
+  assert (dev_bn.running_mean.cpu().double() - ref_bn.running_mean).abs().max() < 1e-5
+  assert (dev_bn.running_var.cpu().double() - ref_bn.running_var).abs().max() < 1e-4
+  assert int(dev_bn.num_batches_tracked) == 1
+  # eval mode uses the running statistics just updated
+  ref_bn.eval()
+  dev_bn.eval()
+  with torch.no_grad():
+    e_ref = ref_bn(y.double())
+    if with_add:
+      e_ref = e_ref + add.double()
+    if relu:
+      e_ref = torch.relu(e_ref)
+    e = HF.bn_act(dev_bn, y.to(DEV), add.to(DEV) if with_add else None, relu)
+  assert (e.cpu().double() - e_ref).abs().max() < 2e-5
+
+
 # ------------------------------------------------------------------ fused head (a13/a14)
 @pytest.mark.parametrize('B,D4,H4,W4,scale', [(2, 4, 6, 8, 4), (1, 12, 5, 7, 4), (1, 3, 4, 4, 3), (2, 48, 8, 16, 4)])
 def test_head_fwd_bwd_conf(B, D4, H4, W4, scale):

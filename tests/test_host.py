@@ -28,6 +28,7 @@ def oracle_ops(monkeypatch):
   monkeypatch.setattr(md_mod.HF, 'cost_volume', mode_ref.cost_volume)
   monkeypatch.setattr(md_mod.stage3d, 'conv3', lambda conv, x: conv(x))  # torch CPU conv = what oracle/mode_ref.py uses
   monkeypatch.setattr(md_mod.stage3d, 'head', md_mod.stage3d.head_vendor)
+  monkeypatch.setattr(md_mod.stage3d, 'bn_act', md_mod.stage3d.bn_act_vendor)
 
 
 @pytest.fixture(scope='module')
