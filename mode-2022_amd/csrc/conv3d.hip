@@ -112,24 +112,131 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
   const float* bbase = tile + (lane >> 5) * PLANE + (lane & 31);
   const float* xb = x + (long long)b * d.Ci * DHW;
 
-  for (int ch = 0; ch < d.NCHUNK; ++ch) {
-    // ---- stage 8 input channels of the haloed tile (zero padding outside the volume)
-    for (int idx = tid; idx < CCH * PLANE; idx += NT) {
-      const int c = idx / PLANE;
-      int rem = idx - c * PLANE;
-      const int dz = rem / (IH * IW);
-      rem -= dz * (IH * IW);
-      const int hy = rem / IW;
-      const int wx = rem - hy * IW;
-      const int gd = d0 * S + dz - 1, gh = h0 * S + hy - 1, gw = w0 * S + wx - 1;
-      const int cin = ch * CCH + c;
-      float v = 0.f;
-      if (cin < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
-        v = xb[cin * DHW + gd * HW + gh * d.W + gw];
-      const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
-      tile[idx - wx + lw] = v;
+  // ---- staging of the haloed input tile, one 8-channel chunk at a time.
+  // The tile is NROWS = 8*ID*IH rows of IW floats.  A half-wave loads 32 consecutive columns of one row with one coalesced
+  // instruction ("main" items); the 1-2 remaining halo columns of every row are "halo" items.  All loads of a chunk are
+  // issued branch-free into registers (out-of-volume elements read a safe address and are zeroed by a select), so they are
+  // in flight together; with OVERLAP they are issued before the MFMA phase of the previous chunk and written to LDS after it.
+  constexpr int NROWS = CCH * ID * IH;
+  constexpr int NG = (S == 1) ? 1 : 2;      // 32-column groups per row
+  constexpr int GO = (S == 1) ? 1 : 0;      // first column of group 0
+  constexpr int NHALO = (S == 1) ? 2 : 1;   // leftover columns per row: {0, 33} or {64}
+  constexpr int NPM = (NROWS * NG + 7) / 8;
+  constexpr int NPH = (NROWS * NHALO + NT - 1) / NT;
+  constexpr bool OVERLAP = (MT == 1 && S == 1);
+  int* rowtab = reinterpret_cast<int*>(tile + CCH * PLANE);  // per row: element offset of (c, gd, gh, 0) or -1
+  for (int r = tid; r < NROWS; r += NT) {
+    const int c = r / (ID * IH);
+    const int rem = r - c * (ID * IH);
+    const int dz = rem / IH;
+    const int hy = rem - dz * IH;
+    const int gd = d0 * S + dz - 1, gh = h0 * S + hy - 1;
+    rowtab[r] = (gd >= 0 && gd < d.D && gh >= 0 && gh < d.H) ? (int)(c * DHW + gd * HW + gh * d.W) : -1;
+  }
+  __syncthreads();
+  const int hwv = tid >> 5, l32 = tid & 31;
+  // passes are processed in batches of NBM (all of them when overlapping with the MFMA phase; 16 otherwise, to bound the
+  // number of live registers next to the accumulators)
+  constexpr int NBM = OVERLAP ? NPM : 1;  // the register-resident whole-chunk form is only used when overlapping
+  float vm[NBM], vh[NPH];
+
+  auto issue = [&](int ch, int kb) {
+    const float* xc = xb + (long long)ch * CCH * DHW;
+#pragma unroll
+    for (int j = 0; j < NBM; ++j) {
+      const int item = (kb + j) * 8 + hwv;
+      const int r = item / NG, g = item - r * NG;
+      const int gw = w0 * S + GO + 32 * g + l32 - 1;
+      const int off = (kb + j < NPM && item < NROWS * NG) ? rowtab[r] : -1;
+      const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
+      const float v = xc[ok ? off + gw : 0];
+      vm[j] = ok ? v : 0.f;
     }
-    __syncthreads();
+    if (kb == 0) {
+#pragma unroll
+      for (int k = 0; k < NPH; ++k) {
+        const int item = k * NT + tid;
+        const int r = item / NHALO, side = item - r * NHALO;
+        const int wx = (S == 1) ? (side ? 33 : 0) : 64;
+        const int gw = w0 * S + wx - 1;
+        const int off = (item < NROWS * NHALO) ? rowtab[r] : -1;
+        const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
+        const float v = xc[ok ? off + gw : 0];
+        vh[k] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto commit = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < NBM; ++j) {
+      const int item = (kb + j) * 8 + hwv;
+      const int r = item / NG, g = item - r * NG;
+      const int wx = GO + 32 * g + l32;
+      const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
+      if (kb + j < NPM && item < NROWS * NG) tile[r * IW + lw] = vm[j];
+    }
+    if (kb == 0) {
+#pragma unroll
+      for (int k = 0; k < NPH; ++k) {
+        const int item = k * NT + tid;
+        const int r = item / NHALO, side = item - r * NHALO;
+        const int wx = (S == 1) ? (side ? 33 : 0) : 64;
+        const int lw = (S == 1) ? wx : 32;  // column 64 = odd-phase entry O[32] of the [O | E] split
+        if (item < NROWS * NHALO) tile[r * IW + lw] = vh[k];
+      }
+    }
+  };
+  // non-overlapped staging: 8 passes (= 8 loads per thread) in flight at a time, registers local to the loop body
+  auto stage_now = [&](int ch) {
+    const float* xc = xb + (long long)ch * CCH * DHW;
+#pragma unroll 1
+    for (int kb = 0; kb < NPM; kb += 8) {
+      float t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = (kb + j) * 8 + hwv;
+        const int r = item / NG, g = item - r * NG;
+        const int gw = w0 * S + GO + 32 * g + l32 - 1;
+        const int off = (item < NROWS * NG) ? rowtab[r] : -1;
+        const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
+        const float v = xc[ok ? off + gw : 0];
+        t8[j] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = (kb + j) * 8 + hwv;
+        const int r = item / NG, g = item - r * NG;
+        const int wx = GO + 32 * g + l32;
+        const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
+        if (item < NROWS * NG) tile[r * IW + lw] = t8[j];
+      }
+    }
+    float th[NPH];
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) {
+      const int item = k * NT + tid;
+      const int r = item / NHALO, side = item - r * NHALO;
+      const int wx = (S == 1) ? (side ? 33 : 0) : 64;
+      const int gw = w0 * S + wx - 1;
+      const int off = (item < NROWS * NHALO) ? rowtab[r] : -1;
+      const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
+      const float v = xc[ok ? off + gw : 0];
+      th[k] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) {
+      const int item = k * NT + tid;
+      const int r = item / NHALO, side = item - r * NHALO;
+      const int wx = (S == 1) ? (side ? 33 : 0) : 64;
+      const int lw = (S == 1) ? wx : 32;
+      if (item < NROWS * NHALO) tile[r * IW + lw] = th[k];
+    }
+  };
+
+  stage_now(0);
+  __syncthreads();
+  for (int ch = 0; ch < d.NCHUNK; ++ch) {
+    if (OVERLAP && ch + 1 < d.NCHUNK) issue(ch + 1, 0);  // in flight during the MFMA phase below
     // ---- 27 taps x 4 channel pairs x R rows x MT tiles of MFMA
     const float4* wq = wp + ((long long)ch * 27) * 64 + lane;
 #pragma unroll
@@ -151,7 +258,14 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
         }
       }
     }
-    __syncthreads();
+    __syncthreads();  // every wave is done reading this chunk
+    if (ch + 1 < d.NCHUNK) {
+      if (OVERLAP)
+        commit(0);
+      else
+        stage_now(ch + 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: D[i = o][j = w]
@@ -180,7 +294,8 @@ int launch_conv(const float* x, const float* wpack, float* y, CDims d, hipStream
   d.nHt = mode::cdiv(d.Ho, TH);
   d.nDt = mode::cdiv(d.Do, TD);
   d.ntiles = d.B * d.nDt * d.nHt * d.nWt;
-  const size_t lds = (size_t)CCH * ((TD - 1) * S + 3) * ((TH - 1) * S + 3) * (S == 1 ? 34 : 65) * sizeof(float);
+  constexpr int kRows = CCH * ((TD - 1) * S + 3) * ((TH - 1) * S + 3);
+  const size_t lds = (size_t)kRows * (S == 1 ? 34 : 65) * sizeof(float) + (size_t)kRows * sizeof(int);  // tile + row table
   int rc = mode::allow_lds(conv3d_kernel<MT, TD, TH, S>, lds, who);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL((conv3d_kernel<MT, TD, TH, S>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
@@ -207,7 +322,7 @@ int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int
     if (mid >= 2 * kNumCU) return launch_conv<1, 2, 4, 1>(x, wpack, y, d, st, who);
     return launch_conv<1, 1, 4, 1>(x, wpack, y, d, st, who);
   }
-  if (big >= 2 * kNumCU) return launch_conv<2, 2, 8, 1>(x, wpack, y, d, st, who);
+  // (the 2x8 tile with two output-channel tiles needs 268 registers -> one wave per SIMD; 2x4 keeps two)
   if (mid >= 2 * kNumCU) return launch_conv<2, 2, 4, 1>(x, wpack, y, d, st, who);
   return launch_conv<2, 1, 4, 1>(x, wpack, y, d, st, who);
 }
@@ -349,8 +464,8 @@ int check_conv_args(const void* a, const void* b, const void* c, const void* wp,
                     int stride, const char* who, bool allow_s2 = false) {
   MODE_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
   MODE_REQUIRE(stride == 1 || (stride == 2 && allow_s2), MODE_ERR_UNSUPPORTED, "%s: stride %d not implemented", who, stride);
-  MODE_REQUIRE((long long)Ci * D * H * W < (1ll << 31) && (long long)Co * D * H * W < (1ll << 31), MODE_ERR_UNSUPPORTED,
-               "%s: a sample larger than 2^31 elements", who);
+  MODE_REQUIRE((long long)std::max(Ci, 8) * D * H * W < (1ll << 31) && (long long)std::max(Co, 8) * D * H * W < (1ll << 31),
+               MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^31 elements", who);
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(a && b && c && wp, MODE_ERR_BAD_ARG, "%s: null pointer", who);
   return MODE_OK;
@@ -546,30 +661,56 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
     const float* gb = gy + ((long long)b * d.Co + ob * 32) * DHW;
 
     for (int dd = dlo; dd < dhi; ++dd) {
-      // stage x planes: all three at the start of a unit, then only plane dd+1 (ring slot (z+3) % 3 for depth z)
+      // stage x planes: all three at the start of a unit, then only plane dd+1 (ring slot (z+3) % 3 for depth z).
+      // Branch-free: a half-wave loads the 32 interior columns of one (channel, row) with one coalesced instruction, 8 such
+      // loads per thread are in flight together; the two halo columns of every row are one more load per thread.
+      const int hwv = tid >> 5, l32 = tid & 31;
       const int zfirst = (dd == dlo) ? dd - 1 : dd + 1;
-      const int nplanes = (dd == dlo) ? 3 : 1;
-      for (int idx = tid; idx < 32 * nplanes * PS; idx += NT) {
-        const int c = idx / (nplanes * PS);
-        int rem = idx - c * (nplanes * PS);
-        const int pz = rem / PS;
-        rem -= pz * PS;
-        const int hy = rem / XW;
-        const int wx = rem - hy * XW;
-        const int gd = zfirst + pz, gh = h0 + hy - 1, gw = w0 + wx - 1;
-        float v = 0.f;
-        if (cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
-          v = xb[c * DHW + gd * HW + gh * d.W + gw];
-        xl[c * XPLANE + ((gd + 3) % 3) * PS + rem] = v;
+      const int zlast = dd + 1;
+      for (int z = zfirst; z <= zlast; ++z) {
+        const int slot = (z + 3) % 3;
+        const bool zok = z >= 0 && z < d.D;
+        const long long zoff = (long long)(zok ? z : 0) * HW;
+#pragma unroll 1
+        for (int kb = 0; kb < 16; kb += 8) {
+          float t8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = (kb + j) * 8 + hwv;  // (channel, row) = (r >> 2, r & 3)
+            const int c = r >> 2, gh = h0 + (r & 3) - 1, gw = w0 + l32;
+            const bool ok = zok && cb * 32 + c < d.Ci && gh >= 0 && gh < d.H && gw < d.W;
+            const float v = xb[ok ? c * DHW + zoff + gh * d.W + gw : 0];
+            t8[j] = ok ? v : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = (kb + j) * 8 + hwv;
+            xl[(r >> 2) * XPLANE + slot * PS + (r & 3) * XW + 1 + l32] = t8[j];
+          }
+        }
+        {
+          const int r = tid >> 1, side = tid & 1;
+          const int c = r >> 2, gh = h0 + (r & 3) - 1, gw = side ? w0 + 32 : w0 - 1;
+          const bool ok = zok && cb * 32 + c < d.Ci && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
+          const float v = xb[ok ? c * DHW + zoff + gh * d.W + gw : 0];
+          xl[c * XPLANE + slot * PS + (r & 3) * XW + (side ? 33 : 0)] = ok ? v : 0.f;
+        }
       }
-      for (int idx = tid; idx < 32 * WTH * 32; idx += NT) {
-        const int o = idx / (WTH * 32);
-        const int rem = idx - o * (WTH * 32);
-        const int hy = rem / 32, wx = rem % 32;
-        const int gh = h0 + hy, gw = w0 + wx;
-        float v = 0.f;
-        if (ob * 32 + o < d.Co && gh < d.H && gw < d.W) v = gb[o * DHW + dd * HW + gh * d.W + gw];
-        gl[o * GPLANE + rem] = v;
+      {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = j * 8 + hwv;  // (output channel, row) = (r >> 1, r & 1)
+          const int o = r >> 1, gh = h0 + (r & 1), gw = w0 + l32;
+          const bool ok = ob * 32 + o < d.Co && gh < d.H && gw < d.W;
+          const float v = gb[ok ? o * DHW + dd * HW + gh * d.W + gw : 0];
+          t8[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = j * 8 + hwv;
+          gl[(r >> 1) * GPLANE + (r & 1) * 32 + l32] = t8[j];
+        }
       }
       __syncthreads();
       int toff[7];
