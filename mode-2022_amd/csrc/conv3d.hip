@@ -382,18 +382,37 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
   const float* xb = x + (long long)b * d.Ci * DHW;
 
   for (int ch = 0; ch < d.NCHUNK; ++ch) {
-    for (int idx = tid; idx < CCH * PLANE; idx += NT) {
-      const int c = idx / PLANE;
-      int rem = idx - c * PLANE;
-      const int z = rem / (IH * IW);
-      rem -= z * (IH * IW);
-      const int yy = rem / IW;
-      const int xx = rem - yy * IW;
-      const int gd = d0 + z, gh = h0 + yy, gw = w0 + xx;
-      const int cin = ch * CCH + c;
-      float v = 0.f;
-      if (cin < d.Ci && gd < d.D && gh < d.H && gw < d.W) v = xb[cin * DHW + gd * HW + gh * d.W + gw];
-      tile[idx] = v;
+    {
+      // branch-free row staging: CCH*ID*IH rows of 33 floats = 32 coalesced columns per half-wave + one leftover column
+      constexpr int NROWS = CCH * ID * IH;
+      const int hwv = tid >> 5, l32 = tid & 31;
+      const float* xc = xb + (long long)ch * CCH * DHW;
+#pragma unroll 1
+      for (int kb = 0; kb < NROWS; kb += 64) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = kb + j * 8 + hwv;
+          const int c = r / (ID * IH), rem = r - c * (ID * IH);
+          const int gd = d0 + rem / IH, gh = h0 + rem % IH, gw = w0 + l32;
+          const bool ok = r < NROWS && ch * CCH + c < d.Ci && gd < d.D && gh < d.H && gw < d.W;
+          const float v = xc[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
+          t8[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = kb + j * 8 + hwv;
+          if (r < NROWS) tile[r * IW + l32] = t8[j];
+        }
+      }
+      if (tid < NROWS) {
+        const int r = tid;
+        const int c = r / (ID * IH), rem = r - c * (ID * IH);
+        const int gd = d0 + rem / IH, gh = h0 + rem % IH, gw = w0 + 32;
+        const bool ok = ch * CCH + c < d.Ci && gd < d.D && gh < d.H && gw < d.W;
+        const float v = xc[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
+        tile[r * IW + 32] = ok ? v : 0.f;
+      }
     }
     __syncthreads();
     const float4* wq = wp + (((long long)mt * d.NCHUNK + ch) * 27) * 64 + lane;
@@ -565,27 +584,66 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
     const int w0 = wt * 32, h0 = ht * WTH;  // output (gy) coordinates
     const float* xb = x + ((long long)b * d.Ci + cb * 32) * DHW;
     const float* gb = gy + ((long long)b * d.Co + ob * 32) * oDHW;
-    for (int idx = tid; idx < 32 * XP0; idx += NT) {
-      const int c = idx / XP0;
-      int rem = idx - c * XP0;
-      const int dz = rem / (XR * XW);
-      rem -= dz * (XR * XW);
-      const int hy = rem / XW;
-      const int wx = rem - hy * XW;
-      const int gd = qd * S + dz - 1, gh = h0 * S + hy - 1, gw = w0 * S + wx - 1;
-      float v = 0.f;
-      if (cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W)
-        v = xb[c * DHW + gd * HW + gh * d.W + gw];
-      xl[c * XPLANE + (idx - c * XP0)] = v;
-    }
-    for (int idx = tid; idx < 32 * WTH * 32; idx += NT) {
-      const int o = idx / (WTH * 32);
-      const int rem = idx - o * (WTH * 32);
-      const int hy = rem / 32, wx = rem % 32;
-      const int gh = h0 + hy, gw = w0 + wx;
-      float v = 0.f;
-      if (ob * 32 + o < d.Co && gh < d.Ho && gw < d.Wo) v = gb[o * oDHW + qd * oHW + gh * d.Wo + gw];
-      gl[o * GPLANE + rem] = v;
+    {
+      // Branch-free row staging (see conv3d_kernel): the x tile is 32*3*XR rows of XW floats; a half-wave loads 32
+      // consecutive columns of a row per instruction, 8 loads per thread in flight; leftover columns one per thread.
+      constexpr int NROWS = 32 * 3 * XR;
+      constexpr int NG = (XW - 1) / 32;          // full 32-column groups per row: 1 (34 cols) or 2 (65 cols)
+      constexpr int NLEFT = XW - 32 * NG;        // 2 or 1 leftover columns
+      const int hwv = tid >> 5, l32 = tid & 31;
+#pragma unroll 1
+      for (int kb = 0; kb < NROWS * NG; kb += 64) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int item = kb + j * 8 + hwv;
+          const int r = item / NG, g = item - r * NG;
+          const int c = r / (3 * XR), rem = r - c * (3 * XR);
+          const int gd = qd * S + rem / XR - 1, gh = h0 * S + rem % XR - 1;
+          const int wx = (NLEFT == 2 ? 1 : 0) + 32 * g + l32;
+          const int gw = w0 * S + wx - 1;
+          const bool ok = item < NROWS * NG && cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
+          const float v = xb[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
+          t8[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int item = kb + j * 8 + hwv;
+          const int r = item / NG, g = item - r * NG;
+          const int c = r / (3 * XR), rem = r - c * (3 * XR);
+          const int wx = (NLEFT == 2 ? 1 : 0) + 32 * g + l32;
+          if (item < NROWS * NG) xl[c * XPLANE + rem * XW + wx] = t8[j];
+        }
+      }
+#pragma unroll 1
+      for (int item = tid; item < NROWS * NLEFT; item += NT) {
+        const int r = item / NLEFT, side = item - r * NLEFT;
+        const int c = r / (3 * XR), rem = r - c * (3 * XR);
+        const int gd = qd * S + rem / XR - 1, gh = h0 * S + rem % XR - 1;
+        const int wx = (NLEFT == 2) ? (side ? XW - 1 : 0) : XW - 1;
+        const int gw = w0 * S + wx - 1;
+        const bool ok = cb * 32 + c < d.Ci && gd >= 0 && gd < d.D && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
+        const float v = xb[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
+        xl[c * XPLANE + rem * XW + wx] = ok ? v : 0.f;
+      }
+      constexpr int GROWS = 32 * WTH;  // (output channel, row) pairs of the gy tile
+#pragma unroll 1
+      for (int kb = 0; kb < GROWS; kb += 64) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = kb + j * 8 + hwv;
+          const int o = r / WTH, gh = h0 + r % WTH, gw = w0 + l32;
+          const bool ok = r < GROWS && ob * 32 + o < d.Co && gh < d.Ho && gw < d.Wo;
+          const float v = gb[ok ? o * oDHW + qd * oHW + gh * d.Wo + gw : 0];
+          t8[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = kb + j * 8 + hwv;
+          if (r < GROWS) gl[(r / WTH) * GPLANE + (r % WTH) * 32 + l32] = t8[j];
+        }
+      }
     }
     __syncthreads();
     const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);

@@ -147,9 +147,15 @@ __global__ void pack_w_bwd(const float* __restrict__ w, float* __restrict__ wp, 
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward.  grid = (B*tps, ceil(MT/4), G); LDS = KK*P*(16+4) + 2 * CCH*KK*P*4 bytes.
+// KT = compile-time tap count (9 for the 3x3 kernels of the network) enables the software pipeline: the 4*2*KT corner
+// loads of the NEXT chunk are issued into registers before the MFMA phase of the current chunk and combined / written to
+// the other LDS buffer after it, so the gather latency hides under the MFMAs.  KT = 0: generic tap count, no pipelining.
+template <int KT>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                const float4* __restrict__ wp, float* __restrict__ y,
-                                                               Dims d) {
+                                                               Dims dd) {
+  Dims d = dd;
+  if (KT > 0) d.KK = KT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* tap_w = reinterpret_cast<float4*>(smem);
   unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
@@ -188,14 +194,60 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
     }
   };
 
+  // pipelined form (KT > 0): registers for the 2 channels x KT taps x 4 corners of the next chunk
+  constexpr int NLV = KT > 0 ? KT * 8 : 1;
+  float lv[NLV];
+  auto issue = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < (KT > 0 ? KT : 0); ++k) {
+      const unsigned po = tap_off[k * P + p];
+      const int off = (int)(po & 0x3fffffffu);
+      const int dw = (int)((po >> 30) & 1u);
+      const int dh = (po >> 31) ? d.W : 0;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = ch * CCH + q * 2 + cc;
+        const float* xc = xg + (c < d.Cig ? c : 0) * HW;
+        lv[(k * 2 + cc) * 4 + 0] = xc[off];
+        lv[(k * 2 + cc) * 4 + 1] = xc[off + dw];
+        lv[(k * 2 + cc) * 4 + 2] = xc[off + dh];
+        lv[(k * 2 + cc) * 4 + 3] = xc[off + dh + dw];
+      }
+    }
+  };
+  auto finish = [&](int ch, float* buf) {
+#pragma unroll
+    for (int k = 0; k < (KT > 0 ? KT : 0); ++k) {
+      const float4 tw = tap_w[k * P + p];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int cl = q * 2 + cc;
+        const float* l4 = lv + (k * 2 + cc) * 4;
+        const float v = tw.x * l4[0] + tw.y * l4[1] + tw.z * l4[2] + tw.w * l4[3];
+        buf[(cl * KT + k) * P + p] = (ch * CCH + cl < d.Cig) ? v : 0.f;
+      }
+    }
+  };
+
   f32x16 acc0 = {0}, acc1 = {0};
   const float4* wpa = wp + ((long long)(g * d.MT + (active ? mt : 0)) * d.NCHUNK) * d.KK * 64 + lane;
 
-  produce(0, colbuf);
+  if (KT > 0) {
+    issue(0);
+    finish(0, colbuf);
+  } else {
+    produce(0, colbuf);
+  }
   __syncthreads();
   for (int ch = 0; ch < d.NCHUNK; ++ch) {
     float* cur = colbuf + (ch & 1) * rows * P;
-    if (ch + 1 < d.NCHUNK) produce(ch + 1, colbuf + ((ch + 1) & 1) * rows * P);
+    float* nxt = colbuf + ((ch + 1) & 1) * rows * P;
+    if (ch + 1 < d.NCHUNK) {
+      if (KT > 0)
+        issue(ch + 1);  // loads fly during the MFMA phase below
+      else
+        produce(ch + 1, nxt);
+    }
     if (active) {
       const float4* wq = wpa + (long long)ch * d.KK * 64;
       const float* bp = cur + (lane >> 5) * P + (lane & 31);
@@ -212,6 +264,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
         acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
       }
     }
+    if (KT > 0 && ch + 1 < d.NCHUNK) finish(ch + 1, nxt);  // the other buffer: no barrier needed before writing it
     __syncthreads();
   }
 
@@ -356,6 +409,137 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj_kernel(const flo
   }
 }
 
+// Software-pipelined variant of the kernel above for 3x3 kernels (KK = 9).  The first EC = 4 adjoint entries of every
+// (tap, input pixel) of the tile -- all of them for the tables of the network away from the poles -- are cached in LDS once
+// per tile; the gy loads of the next chunk (2 channels x 9 taps x 4 entries per thread) are issued before the MFMA phase of
+// the current chunk and combined after it.  Entries beyond the fourth are added by a (rare) synchronous tail loop.
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const float* __restrict__ gy, const int* __restrict__ rowptr,
+                                                                         const int2* __restrict__ entries,
+                                                                         const float4* __restrict__ wp, float* __restrict__ gx, Dims d,
+                                                                         int MTc, int NCHo, int qtiles) {
+  constexpr int KT = 9, EC = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int4* ent_p = reinterpret_cast<int4*>(smem);                          // [KT][P] output pixels of the first 4 entries
+  float4* ent_w = reinterpret_cast<float4*>(smem + KT * P * 16);        // [KT][P] their weights (0 beyond the list)
+  int2* span = reinterpret_cast<int2*>(smem + KT * P * 32);             // [KT][P] (first entry, count)
+  float* colbuf = reinterpret_cast<float*>(smem + KT * P * 40);         // [2][CCH*KT][P]
+  constexpr int rows = CCH * KT;
+  const int HWin = d.H * d.W;
+
+  const int tile = blockIdx.x;
+  const int b = tile / qtiles;
+  const int q0 = (tile - b * qtiles) * P;
+  const int g = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int mt = blockIdx.y * 4 + wave;
+  const bool active = mt < MTc;
+
+  for (int item = tid; item < KT * P; item += NTHREADS) {
+    const int k = item / P, pp = item % P;
+    const int qq = q0 + pp;
+    int beg = 0, cnt = 0;
+    if (qq < HWin) {
+      beg = rowptr[(long long)k * HWin + qq];
+      cnt = rowptr[(long long)k * HWin + qq + 1] - beg;
+    }
+    int pe[EC];
+    float we[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) {
+      const int2 ent = entries[e < cnt ? beg + e : 0];  // entries[] always holds at least one element
+      pe[e] = e < cnt ? ent.x : 0;
+      we[e] = e < cnt ? __int_as_float(ent.y) : 0.f;
+    }
+    ent_p[item] = make_int4(pe[0], pe[1], pe[2], pe[3]);
+    ent_w[item] = make_float4(we[0], we[1], we[2], we[3]);
+    span[item] = make_int2(beg, cnt);
+  }
+  __syncthreads();
+
+  const int p = tid & (P - 1);
+  const int qd = tid / P;  // output channels 2qd, 2qd+1 of the chunk
+  const float* gyg = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+  float lv[KT * 2 * EC];
+
+  auto issue = [&](int ch) {
+    const int o0 = ch * CCH + qd * 2;
+    const float* g0 = gyg + (long long)(o0 < d.Cog ? o0 : 0) * d.npix;
+    const float* g1 = gyg + (long long)(o0 + 1 < d.Cog ? o0 + 1 : 0) * d.npix;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int4 pe = ent_p[k * P + p];
+      lv[k * 8 + 0] = g0[pe.x]; lv[k * 8 + 1] = g0[pe.y]; lv[k * 8 + 2] = g0[pe.z]; lv[k * 8 + 3] = g0[pe.w];
+      lv[k * 8 + 4] = g1[pe.x]; lv[k * 8 + 5] = g1[pe.y]; lv[k * 8 + 6] = g1[pe.z]; lv[k * 8 + 7] = g1[pe.w];
+    }
+  };
+  auto finish = [&](int ch, float* buf) {
+    const int o0 = ch * CCH + qd * 2;
+    const bool ok0 = o0 < d.Cog, ok1 = o0 + 1 < d.Cog;
+    const float* g0 = gyg + (long long)(ok0 ? o0 : 0) * d.npix;
+    const float* g1 = gyg + (long long)(ok1 ? o0 + 1 : 0) * d.npix;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const float4 we = ent_w[k * P + p];
+      float v0 = we.x * lv[k * 8 + 0] + we.y * lv[k * 8 + 1] + we.z * lv[k * 8 + 2] + we.w * lv[k * 8 + 3];
+      float v1 = we.x * lv[k * 8 + 4] + we.y * lv[k * 8 + 5] + we.z * lv[k * 8 + 6] + we.w * lv[k * 8 + 7];
+      const int2 s = span[k * P + p];
+      for (int e = EC; e < s.y; ++e) {  // long lists (near the poles)
+        const int2 ent = entries[s.x + e];
+        const float wt = __int_as_float(ent.y);
+        v0 += wt * g0[ent.x];
+        v1 += wt * g1[ent.x];
+      }
+      buf[((qd * 2) * KT + k) * P + p] = ok0 ? v0 : 0.f;
+      buf[((qd * 2 + 1) * KT + k) * P + p] = ok1 ? v1 : 0.f;
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const float4* wpa = wp + ((long long)(g * MTc + (active ? mt : 0)) * NCHo) * KT * 64 + lane;
+
+  issue(0);
+  finish(0, colbuf);
+  __syncthreads();
+  for (int ch = 0; ch < NCHo; ++ch) {
+    float* cur = colbuf + (ch & 1) * rows * P;
+    float* nxt = colbuf + ((ch + 1) & 1) * rows * P;
+    if (ch + 1 < NCHo) issue(ch + 1);
+    if (active) {
+      const float4* wq = wpa + (long long)ch * KT * 64;
+      const float* bp = cur + (lane >> 5) * P + (lane & 31);
+#pragma unroll
+      for (int quad = 0; quad < KT; ++quad) {
+        const float4 a4 = wq[quad * 64];
+        const float* bq = bp + quad * 8 * P;
+        acc0 = mfma32(a4.x, bq[0], acc0);
+        acc1 = mfma32(a4.x, bq[32], acc1);
+        acc0 = mfma32(a4.y, bq[2 * P], acc0);
+        acc1 = mfma32(a4.y, bq[2 * P + 32], acc1);
+        acc0 = mfma32(a4.z, bq[4 * P], acc0);
+        acc1 = mfma32(a4.z, bq[4 * P + 32], acc1);
+        acc0 = mfma32(a4.w, bq[6 * P], acc0);
+        acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
+      }
+    }
+    if (ch + 1 < NCHo) finish(ch + 1, nxt);
+    __syncthreads();
+  }
+
+  if (active) {
+    float* gxb = gx + ((long long)b * d.Ci + (long long)g * d.Cig) * HWin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (c < d.Cig) {
+        const int qq = q0 + (lane & 31);
+        if (qq < HWin) gxb[(long long)c * HWin + qq] += acc0[r];
+        if (qq + 32 < HWin) gxb[(long long)c * HWin + qq + 32] += acc1[r];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Backward w.r.t. the input, scatter form (needs no adjoint table).  grid = (B*tps, 1, G); LDS = KK*P*20 + KSQ*8*P*4 bytes.
 // gcol rows come out of the MFMA in 128-row blocks (CB channels x KK taps) and are scattered with the same
@@ -465,23 +649,53 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float
     const int pix0 = (t - b * d.tps) * P;
     compute_tapinfo(pos, d, pix0, tap_off, tap_w);
     const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
-    for (int idx = tid; idx < 128 * P; idx += NTHREADS) {
-      const int row = idx / P, pp = idx % P;
-      const int co = mg * 128 + row;
-      float v = 0.f;
-      if (co < d.Cog && pix0 + pp < d.npix) v = gyb[(long long)co * d.npix + pix0 + pp];
-      gyl[row * PS + pp] = v;
+    // gy tile: a wave loads 64 consecutive pixels of one output-channel row per instruction; 8 loads in flight per thread
+#pragma unroll 1
+    for (int r0 = 0; r0 < 128; r0 += 32) {
+      float t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = r0 + j * 4 + q;
+        const bool ok = mg * 128 + row < d.Cog && pix0 + p < d.npix;
+        const float v = gyb[ok ? (long long)(mg * 128 + row) * d.npix + pix0 + p : 0];
+        t8[j] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gyl[(r0 + j * 4 + q) * PS + p] = t8[j];
     }
     __syncthreads();
+    // column tile: 32 samples per thread, issued 8 at a time (32 corner loads in flight), branch-free
     const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
-    for (int i = 0; i < 32; ++i) {
-      const int rr = q * 32 + i;
-      const int cl = rr / d.KK;
-      const int k = rr - cl * d.KK;
-      const int c = nb * d.CB + cl;
-      float v = 0.f;
-      if (rr < nrows && c < d.Cig) v = sample(xg + c * HW, tap_off[k * P + p], tap_w[k * P + p], d.W);
-      col[rr * PS + p] = v;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+      float l[8][4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rr = q * 32 + i0 + j;
+        const int cl = rr / d.KK;
+        const int k = rr - cl * d.KK;
+        const int c = nb * d.CB + cl;
+        const bool ok = rr < nrows && c < d.Cig;
+        const unsigned po = tap_off[(ok ? k : 0) * P + p];
+        const int off = (int)(po & 0x3fffffffu);
+        const int dw = (int)((po >> 30) & 1u);
+        const int dh = (po >> 31) ? d.W : 0;
+        const float* xc = xg + (ok ? c : 0) * HW;
+        l[j][0] = xc[off];
+        l[j][1] = xc[off + dw];
+        l[j][2] = xc[off + dh];
+        l[j][3] = xc[off + dh + dw];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rr = q * 32 + i0 + j;
+        const int cl = rr / d.KK;
+        const int k = rr - cl * d.KK;
+        const bool ok = rr < nrows && nb * d.CB + cl < d.Cig;
+        const float4 tw = tap_w[(ok ? k : 0) * P + p];
+        const float v = tw.x * l[j][0] + tw.y * l[j][1] + tw.z * l[j][2] + tw.w * l[j][3];
+        col[rr * PS + p] = ok ? v : 0.f;
+      }
     }
     __syncthreads();
     const float* ap = gyl + (wave * 32 + (lane & 31)) * PS + (lane >> 5);
@@ -584,10 +798,16 @@ extern "C" int mode_sphere_conv_fwd(const float* x, const float* pos, const floa
   const long long npack = (long long)d.G * d.MT * d.NCHUNK * d.KK * 256;
   hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
   const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)CCH * d.KK * P * 4;
-  rc = mode::allow_lds(sphere_fwd_kernel, lds, "mode_sphere_conv_fwd");
-  if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(sphere_fwd_kernel, dim3(B * d.tps, mode::cdiv(d.MT, 4), d.G), dim3(NTHREADS), lds, st, x, pos,
-                     reinterpret_cast<const float4*>(wpack), y, d);
+  const dim3 grid(B * d.tps, mode::cdiv(d.MT, 4), d.G);
+  if (d.KK == 9) {  // the 3x3 kernels of the network: software-pipelined gather
+    rc = mode::allow_lds(sphere_fwd_kernel<9>, lds, "mode_sphere_conv_fwd");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_fwd_kernel<9>, grid, dim3(NTHREADS), lds, st, x, pos, reinterpret_cast<const float4*>(wpack), y, d);
+  } else {
+    rc = mode::allow_lds(sphere_fwd_kernel<0>, lds, "mode_sphere_conv_fwd");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_fwd_kernel<0>, grid, dim3(NTHREADS), lds, st, x, pos, reinterpret_cast<const float4*>(wpack), y, d);
+  }
   return mode::check_launch("mode_sphere_conv_fwd");
 }
 
@@ -729,11 +949,20 @@ extern "C" int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, fl
   const int NCHo = mode::cdiv(d.Cog, CCH);
   const long long npack = (long long)d.G * MTc * NCHo * d.KK * 256;
   hipLaunchKernelGGL(pack_w_adj, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, MTc, NCHo);
-  const size_t lds = (size_t)d.KK * P * 8 + 2 * (size_t)CCH * d.KK * P * 4;
-  rc = mode::allow_lds(sphere_bwd_data_adj_kernel, lds, "mode_sphere_conv_bwd_data_adj");
-  if (rc != MODE_OK) return rc;
   const int qtiles = mode::cdiv((long long)H * W, P);
-  hipLaunchKernelGGL(sphere_bwd_data_adj_kernel, dim3(B * qtiles, mode::cdiv(MTc, 4), d.G), dim3(NTHREADS), lds, st, gy, adj_rowptr,
-                     reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles);
+  const dim3 grid(B * qtiles, mode::cdiv(MTc, 4), d.G);
+  if (d.KK == 9) {
+    const size_t lds = (size_t)9 * P * 40 + 2 * (size_t)CCH * 9 * P * 4;
+    rc = mode::allow_lds(sphere_bwd_data_adj9_kernel, lds, "mode_sphere_conv_bwd_data_adj");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_bwd_data_adj9_kernel, grid, dim3(NTHREADS), lds, st, gy, adj_rowptr,
+                       reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles);
+  } else {
+    const size_t lds = (size_t)d.KK * P * 8 + 2 * (size_t)CCH * d.KK * P * 4;
+    rc = mode::allow_lds(sphere_bwd_data_adj_kernel, lds, "mode_sphere_conv_bwd_data_adj");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_bwd_data_adj_kernel, grid, dim3(NTHREADS), lds, st, gy, adj_rowptr,
+                       reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles);
+  }
   return mode::check_launch("mode_sphere_conv_bwd_data_adj");
 }

@@ -125,6 +125,47 @@ def test_sphere_conv_fwd_bwd(typ, ih, iw, B, ci, co, stride, groups):
   assert torch.equal(gw2, gw3)
 
 
+@pytest.mark.parametrize('kh,kw', [(1, 3), (5, 5), (2, 2)])
+def test_sphere_conv_other_kernel_sizes(kh, kw):
+  """Tap counts other than 9 take the generic (non-pipelined) kernels; even sizes use the reference's centre-less tap set."""
+  pos = mode_ref.sphere_position(16, 32, 'ERP', (kh, kw))
+  H, W = pos.shape[2:]
+  ci, co = 6, 10
+  x, w = _rand((2, ci, H, W), 81), _rand((co, ci, kh, kw), 82, 0.2)
+  ph, pw = (kh - 1) // 2, (kw - 1) // 2
+  Ho = sphere_conv_ref.out_size(H, kh, 1, ph, 1)
+  Wo = sphere_conv_ref.out_size(W, kw, 1, pw, 1)
+  gy = _rand((2, co, Ho, Wo), 83)
+  cfg = ((1, 1), (ph, pw), (1, 1), 1)
+  y_ref = sphere_conv_ref.forward(x.double(), pos, w.double(), *cfg)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x.double(), pos, w.double(), gy.double(), *cfg)
+  xd, wd, pd, gyd = x.to(DEV), w.to(DEV), pos.to(DEV), gy.to(DEV)
+  y = torch.empty(tuple(y_ref.shape), device=DEV)
+  HF.sphere_conv_fwd(xd, pd, wd, y, (1, 1), 1)
+  assert (y.cpu().double() - y_ref).abs().max() < 1e-4
+  gx = torch.zeros_like(xd)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, gx, (1, 1), 1)
+  assert (gx.cpu().double() - gx_ref).abs().max() < 1e-4
+  gw = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (1, 1), 1)
+  assert (gw.cpu().double() - gw_ref).abs().max() < 1e-3
+
+
+def test_sphere_conv_bwd_data_scatter_form_matches_gather_form():
+  """The atomic scatter kernel (mode_sphere_conv_bwd_data, the reference's col2im structure) is kept next to the default
+  gather form; both must give the same gradient."""
+  pos, x, w, gy = _sphere_case('Cassini', 64, 32, 2, 24, 40, 1, 1, 91)
+  xd, wd, pd, gyd = x.to(DEV), w.to(DEV), pos.to(DEV), gy.to(DEV)
+  g_gather = torch.zeros_like(xd)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, g_gather, (1, 1), 1)
+  g_scatter = torch.zeros_like(xd)
+  wp = HF._wpack(wd, 1)
+  dims = HF._sc_dims(xd.shape, wd.shape, gyd.shape[2:], (1, 1), 1)
+  mode_hip.check(mode_hip.lib().mode_sphere_conv_bwd_data(mode_hip.ptr(gyd), mode_hip.ptr(pd), mode_hip.ptr(wd), mode_hip.ptr(g_scatter),
+                                                           mode_hip.ptr(wp), *dims, mode_hip.stream_of(gyd)), 'mode_sphere_conv_bwd_data')
+  assert (g_gather - g_scatter).abs().max() < 1e-4 * max(1.0, float(g_gather.abs().max()))
+
+
 @pytest.mark.parametrize('name', ['erp_s1', 'cas_s1', 'erp_s2', 'cas_g2'])
 def test_sphere_conv_golden(golden, name):
   from models.basic.spherical_conv.sphere_conv import SphereConv
