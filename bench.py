@@ -229,15 +229,31 @@ def main():
         },
     }
     if kern:
+      # dominant hand-written kernel = the (kernel, layer shape) label with the largest total time in the timed region
       dom = max(kern, key=lambda k: kern[k]['total_ms'])
       a = kern[dom]
-      bound = KERNEL_BOUND.get(dom, 'mfma')
+      bound = KERNEL_BOUND.get(dom.split('[')[0], 'mfma')
       if bound == 'hbm':
-        achieved, peak, unit = a['GBps'], HBM_PEAK_GBPS, 'GB/s'
+        achieved, peak, unit, per_launch = a['GBps'], HBM_PEAK_GBPS, 'GB/s', a['bytes_per_call']
       else:
-        achieved, peak, unit = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+        achieved, peak, unit, per_launch = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', a['flops_per_call']
+      traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
+      try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+          traffic = json.load(f).get('%s B=%d' % (dom, args.batch), {}).get('hbm_bytes_per_launch')
+      except (OSError, ValueError):
+        pass
       out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
-                         'frac': achieved / peak, 'traffic': None, 'avg_ms': a['avg_ms'], 'calls': a['calls']}
+                         'frac': achieved / peak, 'traffic': traffic, 'algorithmic_per_launch': per_launch,
+                         'avg_ms': a['avg_ms'], 'calls': a['calls']}
+      # north_star targets: HBM fraction of the cost-volume build, MFMA fraction of the whole 3D regulariser
+      cv = kern.get('cost_volume_fwd')
+      k3 = [v for k, v in kern.items() if k.startswith(('conv3d_', 'deconv3d_'))]
+      out['targets'] = {
+          'cost_volume_fwd_hbm_frac': round(cv['GBps'] / HBM_PEAK_GBPS, 4) if cv else None,
+          'regulariser3d_mfma_frac': round(sum(v['flops'] for v in k3) / (sum(v['total_ms'] for v in k3) * 1e9) / MFMA_F32_PEAK_TFLOPS, 4)
+          if k3 else None,
+      }
       out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
                             'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}
     else:

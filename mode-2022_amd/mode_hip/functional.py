@@ -169,6 +169,11 @@ def _out3(n, stride):
   return (n - 1) // stride + 1
 
 
+def _tag3(name, ci, co, stride, d, h, w):
+  """Profiling label carrying the layer shape (input volume of the convolution), e.g. conv3d_fwd[32->32 s1 48x256x128]."""
+  return '%s[%d->%d s%d %dx%dx%d]' % (name, ci, co, stride, d, h, w) if profiling.ENABLED else name
+
+
 def conv3d_fwd(x, w, stride=1):
   """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,Do,Ho,Wo); k3 p1, stride 1|2, no bias (convbn_3d, submodule.py:20-22)."""
   require_gpu(x, w)
@@ -180,7 +185,8 @@ def conv3d_fwd(x, w, stride=1):
     raise RuntimeError('conv3d: weight %s does not match input channels %d / kernel 3' % (tuple(w.shape), Ci))
   y = torch.empty((B, Co, _out3(D, stride), _out3(H, stride), _out3(W, stride)), dtype=x.dtype, device=x.device)
   flops = 2 * y.numel() * Ci * 27
-  with torch.cuda.device_of(x), profiling.region('conv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+  with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
+                                                 flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
     check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)), 'mode_conv3d_fwd')
   return y
@@ -195,7 +201,8 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   Co = w.shape[0]
   gx = torch.empty((B, Ci, D, H, W), dtype=gy.dtype, device=gy.device)
   flops = 2 * gy.numel() * Ci * 27
-  with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_data', 4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
+  with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
+                                                  4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
     check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
           'mode_conv3d_bwd_data')
@@ -211,7 +218,8 @@ def conv3d_bwd_weight(gy, x, stride=1):
   Co = gy.shape[1]
   gw = torch.empty((Co, Ci, 3, 3, 3), dtype=gy.dtype, device=gy.device)
   flops = 2 * gy.numel() * Ci * 27
-  with torch.cuda.device_of(gy), profiling.region('conv3d_bwd_weight', 4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
+  with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_weight', Ci, Co, stride, D, H, W),
+                                                  4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
     n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, stride)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
     check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, 0, stream_of(gy)),

@@ -76,9 +76,11 @@ def main():
       wr = torch.randn(co, ci, 3, 3, device=dev)
       report('  (vendor conv2d 3x3 same shape)', timeit(lambda: F.conv2d(x, wr, None, 1, 1), a.iters), nb, fl)
 
-  if 'conv3d' in only:
+  if 'conv3d' in only or 'conv3d_main' in only:
     shapes = ((64, 32, 48, 256, 128, 1), (32, 32, 48, 256, 128, 1), (32, 64, 48, 256, 128, 2), (64, 64, 24, 128, 64, 1),
               (64, 64, 24, 128, 64, 2), (64, 64, 12, 64, 32, 1), (32, 1, 48, 256, 128, 1))
+    if 'conv3d_main' in only:  # the single dominant layer shape (used for the PMC traffic passes)
+      shapes = ((32, 32, 48, 256, 128, 1),)
     for (ci, co, d, h, w_, s) in shapes:
       x = torch.randn(B, ci, d, h, w_, device=dev)
       wt = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05
