@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import stage3d
 from .basic import SphereConv
 
 
@@ -45,15 +46,30 @@ class disparityregression(nn.Module):
     return torch.sum(x * disp, 1, keepdim=True)
 
 
+def _run_convbn_relu_chain(seq, x):
+  """Sequential(convbn, ReLU, convbn, ReLU, ...) with every BatchNorm+ReLU as one fused pass."""
+  mods = list(seq)
+  i = 0
+  while i < len(mods):
+    relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+    if isinstance(mods[i], nn.Sequential) and len(mods[i]) == 2 and isinstance(mods[i][1], nn.BatchNorm2d):
+      x = stage3d.conv_bn(mods[i], x, relu=relu)
+      i += 2 if relu else 1
+    else:  # anything else (a bare Conv2d, pooling, ...) runs as is
+      x = mods[i](x)
+      i += 1
+  return x
+
+
 class _ResidualBlock(nn.Module):
   expansion = 1
 
-  def _residual(self, x):
-    out = self.conv2(self.conv1(x))
-    if self.downsample is not None:
-      x = self.downsample(x)
-    out += x
-    return out
+  def _residual(self, x, final_relu):
+    """conv-bn-relu, conv-bn, + shortcut [, relu]: the second BatchNorm, the add and the ReLU are one fused pass
+    (the reference runs bn, `out += x` and relu as three kernels)."""
+    out = stage3d.conv_bn(self.conv1[0], x, relu=True)
+    shortcut = x if self.downsample is None else stage3d.conv_bn(self.downsample, x)
+    return stage3d.conv_bn(self.conv2, out, relu=final_relu, add=shortcut)
 
 
 class BasicBlock(_ResidualBlock):
@@ -67,7 +83,7 @@ class BasicBlock(_ResidualBlock):
     self.stride = stride
 
   def forward(self, x):
-    return self._residual(x)
+    return self._residual(x, False)
 
 
 class RegularBasicBlock(_ResidualBlock):
@@ -82,7 +98,7 @@ class RegularBasicBlock(_ResidualBlock):
     self.stride = stride
 
   def forward(self, x):
-    return self.relu(self._residual(x))
+    return self._residual(x, True)
 
 
 class SphereBasicBlock(_ResidualBlock):
@@ -98,7 +114,7 @@ class SphereBasicBlock(_ResidualBlock):
     self.stride = stride
 
   def forward(self, x):
-    return self.relu(self._residual(x))
+    return self._residual(x, True)
 
 
 def _downsample(inplanes, planes, stride):
@@ -137,10 +153,10 @@ class sphere_feature_extraction(nn.Module):
     return nn.Sequential(*layers)
 
   def forward(self, x):
-    raw = self.layer2(self.layer1(self.firstconv(x)))
+    raw = self.layer2(self.layer1(_run_convbn_relu_chain(self.firstconv, x)))
     regular = self.layer3(raw)
     sphere = self.layer4(regular)
-    return self.lastconv(torch.cat((raw, regular, sphere), 1))
+    return _run_convbn_relu_chain(self.lastconv, torch.cat((raw, regular, sphere), 1))
 
 
 class feature_extraction(nn.Module):
@@ -170,8 +186,8 @@ class feature_extraction(nn.Module):
     return nn.Sequential(*layers)
 
   def forward(self, x):
-    raw = self.layer2(self.layer1(self.firstconv(x)))
+    raw = self.layer2(self.layer1(_run_convbn_relu_chain(self.firstconv, x)))
     skip = self.layer4(self.layer3(raw))
     size = skip.shape[2:]
     pooled = [F.interpolate(getattr(self, 'branch%d' % i)(skip), size, mode='bilinear', align_corners=True) for i in (4, 3, 2, 1)]
-    return self.lastconv(torch.cat([raw, skip] + pooled, 1))
+    return _run_convbn_relu_chain(self.lastconv, torch.cat([raw, skip] + pooled, 1))
