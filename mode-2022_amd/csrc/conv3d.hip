@@ -14,6 +14,7 @@
 // Input channels are streamed through LDS in chunks of 8.  Backward-data of a stride-1 convolution is the same kernel
 // on gy with the weights transposed and flipped (done by the packing kernel).
 #include "common.h"
+#include "conv3d_internal.h"
 
 namespace {
 
@@ -504,6 +505,7 @@ extern "C" int mode_conv3d_fwd(const float* x, const float* w, float* y, float* 
   int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, stride, "mode_conv3d_fwd", true);
   if (rc != MODE_OK || B == 0) return rc;
   if (stride == 2) return conv3d_s2(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), "mode_conv3d_fwd");
+  if (Co == 1) return mode::conv3d_co1_fwd(x, w, y, B, Ci, D, H, W, mode::as_stream(stream), "mode_conv3d_fwd");
   return conv3d_s1(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), "mode_conv3d_fwd");
 }
 
@@ -844,7 +846,9 @@ extern "C" size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, i
   if (B <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
   WDims d;
   make_wdims(d, B, Ci, D, H, W, Co, stride);
-  return (size_t)d.S * d.MTo * d.MTc * 27 * 1024 * sizeof(float);
+  const size_t generic = (size_t)d.S * d.MTo * d.MTc * 27 * 1024;
+  const size_t co1 = (Co == 1 && stride == 1) ? mode::conv3d_co1_bwd_weight_workspace_floats(B, Ci, D, H, W) : 0;
+  return std::max(generic, co1) * sizeof(float);
 }
 
 extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
@@ -856,6 +860,8 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
     if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
     return MODE_OK;
   }
+  if (Co == 1 && stride == 1)
+    return mode::conv3d_co1_bwd_weight(gy, x, gw, workspace, B, Ci, D, H, W, accumulate, st, "mode_conv3d_bwd_weight");
   WDims d;
   make_wdims(d, B, Ci, D, H, W, Co, stride);
   if (stride == 1) {

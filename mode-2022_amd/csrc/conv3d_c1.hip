@@ -1,0 +1,246 @@
+// Single-output-channel 3x3x3 convolution: the last layer of classif1-3, Conv3d(32 -> 1) (models/mode_disparity.py:76-80).
+//
+// With one output channel the implicit-GEMM tile of conv3d.hip is 31/32 padding (1.47 ms forward, 1.71 ms weight gradient at
+// the benchmark volume).  The layer is really a memory-bound stencil: 201 MB of input per sample for 6.3 MB of output.
+//   forward        : vector-ALU stencil; a thread owns 4 outputs along h so that one LDS read feeds up to 3 FMAs
+//   weight gradient: gW[c][tap] = sum_q x[c,q] * gy[q + 1 - k]  as an MFMA GEMM with  D[i = c][j = tap]  (27 of 32 columns
+//                    used): A[i = c][k = voxel] = x tile, B[k = voxel][j = tap] = the gy halo tile read at a per-lane tap
+//                    offset; split-K over voxel tiles with a fixed-order reduction
+// (the input gradient stays on the generic MFMA kernel: K = 1 is cheap there.)
+#include "conv3d_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------------------------- forward
+constexpr int FTD = 2, FTH = 16, FCC = 4;                 // tile 2 x 16 x 32 outputs, 4 input channels per LDS chunk
+constexpr int FID = FTD + 2, FIH = FTH + 2, FIW = 34;
+constexpr int FPLANE = FID * FIH * FIW;                   // 2448 floats per channel
+constexpr int FROWS = FCC * FID * FIH;                    // 288 rows of 34
+
+__global__ __launch_bounds__(NT) void conv3d_co1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, int B, int Ci, int D, int H, int W, int nDt,
+                                                            int nHt, int nWt) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [FCC][FID][FIH][FIW]
+  int* rowtab = reinterpret_cast<int*>(tile + FCC * FPLANE);
+  int t = blockIdx.x;
+  const int wt = t % nWt;
+  t /= nWt;
+  const int ht = t % nHt;
+  t /= nHt;
+  const int dt = t % nDt;
+  const int b = t / nDt;
+  const int w0 = wt * 32, h0 = ht * FTH, d0 = dt * FTD;
+  const int tid = threadIdx.x;
+  const int dz = tid >> 7, hq = (tid >> 5) & 3, wx = tid & 31;
+  const long long HW = (long long)H * W, DHW = (long long)D * HW;
+  const float* xb = x + (long long)b * Ci * DHW;
+
+  for (int r = tid; r < FROWS; r += NT) {
+    const int c = r / (FID * FIH), rem = r - c * (FID * FIH);
+    const int gd = d0 + rem / FIH - 1, gh = h0 + rem % FIH - 1;
+    rowtab[r] = (gd >= 0 && gd < D && gh >= 0 && gh < H) ? (int)(c * DHW + gd * HW + gh * W) : -1;
+  }
+  __syncthreads();
+
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hwv = tid >> 5, l32 = tid & 31;
+  const int nchunk = (Ci + FCC - 1) / FCC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const float* xc = xb + (long long)ch * FCC * DHW;
+#pragma unroll 1
+    for (int kb = 0; kb < FROWS; kb += 64) {
+      float t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = kb + j * 8 + hwv;
+        const int off = r < FROWS ? rowtab[r] : -1;
+        const int gw = w0 + l32;
+        const bool ok = off >= 0 && gw < W && ch * FCC + r / (FID * FIH) < Ci;
+        const float v = xc[ok ? off + gw : 0];
+        t8[j] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = kb + j * 8 + hwv;
+        if (r < FROWS) tile[r * FIW + 1 + l32] = t8[j];
+      }
+    }
+#pragma unroll 1
+    for (int item = tid; item < FROWS * 2; item += NT) {
+      const int r = item >> 1, side = item & 1;
+      const int off = rowtab[r];
+      const int gw = side ? w0 + 32 : w0 - 1;
+      const bool ok = off >= 0 && gw >= 0 && gw < W && ch * FCC + r / (FID * FIH) < Ci;
+      const float v = xc[ok ? off + gw : 0];
+      tile[r * FIW + (side ? 33 : 0)] = ok ? v : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < FCC; ++c) {
+      const int cin = min(ch * FCC + c, Ci - 1);  // out-of-range channels were staged as zeros; keep the weight read valid
+      const float* wc = w + cin * 27;             // wave-uniform: scalar loads
+      const float* tp = tile + c * FPLANE + dz * (FIH * FIW) + (hq * 4) * FIW + wx;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float v = tp[kd * (FIH * FIW) + r * FIW + kw];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int o = r - kh;
+              if (o >= 0 && o < 4) acc[o] += wc[kd * 9 + kh * 3 + kw] * v;
+            }
+          }
+    }
+    __syncthreads();
+  }
+  const int gd = d0 + dz, gw = w0 + wx;
+  if (gd < D && gw < W) {
+    float* yb = y + (long long)b * DHW + gd * HW + gw;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gh = h0 + hq * 4 + o;
+      if (gh < H) yb[(long long)gh * W] = acc[o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- weight gradient
+constexpr int GTH = 8;                      // tile 1 x 8 x 32 input voxels = 128 k-steps, 32 per wave
+constexpr int XS = GTH * 32 + 1;            // 257: odd channel stride -> conflict-free A fragments
+constexpr int GH = GTH + 2, GW = 34, GPL = GH * GW;  // gy halo tile [3][10][34]
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// grid = (S, ceil(Ci/32)); part[(s*MTc + cb)*1024 + c*32 + tap]
+__global__ __launch_bounds__(NT) void conv3d_co1_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                   float* __restrict__ part, int B, int Ci, int D, int H, int W,
+                                                                   int nHt, int nWt, int T, int S) {
+  __shared__ float xl[32 * XS];
+  __shared__ float gl[3 * GPL];
+  __shared__ float red[4 * 1024];
+  const int s = blockIdx.x, cb = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hwv = tid >> 5, l32 = tid & 31;
+  const long long HW = (long long)H * W, DHW = (long long)D * HW;
+  const int j = lane & 31;                     // this lane's tap column
+  const int tap = j < 27 ? j : 0;
+  const int toff = (2 - tap / 9) * GPL + (2 - (tap / 3) % 3) * GW + (2 - tap % 3);
+  f32x16 acc = {0};
+
+  for (int tt = s; tt < T; tt += S) {
+    int t = tt;
+    const int wt = t % nWt;
+    t /= nWt;
+    const int ht = t % nHt;
+    t /= nHt;
+    const int d0 = t % D;
+    const int b = t / D;
+    const int w0 = wt * 32, h0 = ht * GTH;
+    const float* xb = x + ((long long)b * Ci + cb * 32) * DHW + d0 * HW;
+    const float* gb = gy + (long long)b * DHW;
+    // x tile: 32 channels x 8 rows x 32 voxels, one coalesced half-wave load per (channel, row)
+#pragma unroll 1
+    for (int kb = 0; kb < 256; kb += 64) {
+      float t8[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int r = kb + jj * 8 + hwv;  // (channel, row) = (r >> 3, r & 7)
+        const int c = r >> 3, gh = h0 + (r & 7), gw = w0 + l32;
+        const bool ok = cb * 32 + c < Ci && gh < H && gw < W;
+        const float v = xb[ok ? c * DHW + (long long)gh * W + gw : 0];
+        t8[jj] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int r = kb + jj * 8 + hwv;
+        xl[(r >> 3) * XS + (r & 7) * 32 + l32] = t8[jj];
+      }
+    }
+    // gy halo tile G[zz][yy][xx] = gy[d0-1+zz][h0-1+yy][w0-1+xx]
+    for (int idx = tid; idx < 3 * GPL; idx += NT) {
+      const int zz = idx / GPL, rem = idx - zz * GPL;
+      const int yy = rem / GW, xx = rem - yy * GW;
+      const int gd = d0 - 1 + zz, gh = h0 - 1 + yy, gw = w0 - 1 + xx;
+      const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      const float v = gb[ok ? gd * HW + (long long)gh * W + gw : 0];
+      gl[idx] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    // wave v: rows 2v, 2v+1; A[i = c][k] = x[c][row][2ks + (lane>>5)], B[k][j = tap] = G[toff_j + row*34 + 2ks + (lane>>5)]
+    const float* ap = xl + (lane & 31) * XS + (lane >> 5);
+    const float* bp = gl + toff + (lane >> 5);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr;
+#pragma unroll 8
+      for (int ks = 0; ks < 16; ++ks) acc = mfma32(ap[row * 32 + 2 * ks], bp[row * GW + 2 * ks], acc);
+    }
+    __syncthreads();
+  }
+  // cross-wave reduction in a fixed order, then one 32x32 partial per workgroup
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    red[wave * 1024 + i * 32 + (lane & 31)] = acc[q];
+  }
+  __syncthreads();
+  float* pb = part + ((long long)s * gridDim.y + cb) * 1024;
+  for (int idx = tid; idx < 1024; idx += NT) pb[idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+}
+
+__global__ void conv3d_co1_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int Ci, int S, int MTc,
+                                         int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // c*27 + tap
+  if (idx >= Ci * 27) return;
+  const int c = idx / 27, tap = idx - c * 27;
+  const float* p = part + (long long)(c / 32) * 1024 + (c % 32) * 32 + tap;
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += p[(long long)s * MTc * 1024];
+  gw[idx] = accumulate ? gw[idx] + sum : sum;
+}
+
+int co1_splits(int T, int MTc) {
+  int S = mode::cdiv(4 * kNumCU, MTc);
+  if (S > T) S = T;
+  return S < 1 ? 1 : S;
+}
+
+}  // namespace
+
+namespace mode {
+
+int conv3d_co1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who) {
+  const int nDt = cdiv(D, FTD), nHt = cdiv(H, FTH), nWt = cdiv(W, 32);
+  const size_t lds = (size_t)FCC * FPLANE * sizeof(float) + (size_t)FROWS * sizeof(int);
+  hipLaunchKernelGGL(conv3d_co1_fwd_kernel, dim3(B * nDt * nHt * nWt), dim3(NT), lds, st, x, w, y, B, Ci, D, H, W, nDt, nHt, nWt);
+  return check_launch(who);
+}
+
+size_t conv3d_co1_bwd_weight_workspace_floats(int B, int Ci, int D, int H, int W) {
+  const int MTc = cdiv(Ci, 32);
+  const int T = B * D * cdiv(H, GTH) * cdiv(W, 32);
+  return (size_t)co1_splits(T, MTc) * MTc * 1024;
+}
+
+int conv3d_co1_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,
+                          int accumulate, hipStream_t st, const char* who) {
+  const int MTc = cdiv(Ci, 32);
+  const int nHt = cdiv(H, GTH), nWt = cdiv(W, 32);
+  const int T = B * D * nHt * nWt;
+  const int S = co1_splits(T, MTc);
+  hipLaunchKernelGGL(conv3d_co1_bwd_weight_kernel, dim3(S, MTc), dim3(NT), 0, st, gy, x, workspace, B, Ci, D, H, W, nHt, nWt, T, S);
+  int rc = check_launch(who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(conv3d_co1_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, gw, Ci, S, MTc, accumulate);
+  return check_launch(who);
+}
+
+}  // namespace mode
