@@ -719,167 +719,6 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float
     }
 }
 
-// Wave-specialised variant for 3x3 kernels: 8 waves, waves 0-3 consume (MFMA, one 32-row output-channel tile each), waves
-// 4-7 produce (sampling records, gy tile, gathered column tile) for the NEXT 32-pixel tile into the other LDS buffer, so
-// the gather latency is hidden behind the matrix pipe instead of alternating with it.  Two barriers per tile:
-//   phase A: producers write records + gy tile of tile t+1          | consumers run the first half of tile t's MFMAs
-//   phase B: producers gather the column tile of t+1 (needs A)      | consumers run the second half
-// Same partial layout / reduction as sphere_bwd_weight_kernel.
-constexpr int WP = 32;        // pixels per tile
-constexpr int WPS = WP + 1;   // padded row stride (bank = row + k)
-
-__global__ __launch_bounds__(512) void sphere_bwd_weight_ws_kernel(const float* __restrict__ gy, const float* __restrict__ pos,
-                                                                   const float* __restrict__ x, float* __restrict__ part, Dims d,
-                                                                   int S, int MG, int tps32) {
-  constexpr int KT = 9;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (records 16 B + 4 B, gy tile, column tile) = 79.1 KB
-  typedef float4 tapw_row[KT * WP];
-  typedef unsigned tapo_row[KT * WP];
-  typedef float tile_row[128 * WPS];
-  tapw_row* tapw_s = reinterpret_cast<tapw_row*>(smem);
-  tapo_row* tapo_s = reinterpret_cast<tapo_row*>(smem + 2 * sizeof(tapw_row));
-  tile_row* gyl_s = reinterpret_cast<tile_row*>(smem + 2 * sizeof(tapw_row) + 2 * sizeof(tapo_row));
-  tile_row* col_s = gyl_s + 2;
-
-  const int s = blockIdx.x, nb = blockIdx.y;
-  const int g = blockIdx.z / MG, mg = blockIdx.z % MG;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const bool producer = wave >= 4;
-  const int pt = tid & 255;            // producer-local thread id
-  const int pp = pt & 31, q8 = pt >> 5;  // producer: pixel, row group
-  const long long HW = (long long)d.H * d.W;
-  const int nrows = d.CB * KT;
-  const int T = d.B * tps32;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x16){0};
-
-  auto phase_a = [&](int t, int buf) {  // producers: sampling records + gy tile of tile t
-    const int b = t / tps32;
-    const int pix0 = (t - b * tps32) * WP;
-    for (int item = pt; item < KT * WP; item += 256) {
-      const int k = item / WP, p = item % WP;
-      const int pix = pix0 + p;
-      unsigned off = 0;
-      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < d.npix) {
-        const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
-        const int idx = (ho * d.sH) * d.W + wo * d.sW;
-        const float h = pos[(2 * k) * HW + idx];
-        const float w = pos[(2 * k + 1) * HW + idx];
-        if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
-          const float hf = floorf(h), wf = floorf(w);
-          const int hl = (int)hf, wl = (int)wf, hh = hl + 1, wh = wl + 1;
-          const float lh = h - hf, lw = w - wf, uh = 1.f - lh, uw = 1.f - lw;
-          wt.x = (hl >= 0 && wl >= 0) ? uh * uw : 0.f;
-          wt.y = (hl >= 0 && wh <= d.W - 1) ? uh * lw : 0.f;
-          wt.z = (hh <= d.H - 1 && wl >= 0) ? lh * uw : 0.f;
-          wt.w = (hh <= d.H - 1 && wh <= d.W - 1) ? lh * lw : 0.f;
-          const int hlc = max(hl, 0), hhc = min(hh, d.H - 1), wlc = max(wl, 0), whc = min(wh, d.W - 1);
-          off = (unsigned)(hlc * d.W + wlc) | ((unsigned)(whc - wlc) << 30) | ((unsigned)(hhc - hlc) << 31);
-        }
-      }
-      tapo_s[buf][item] = off;
-      tapw_s[buf][item] = wt;
-    }
-    const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
-#pragma unroll 1
-    for (int j0 = 0; j0 < 16; j0 += 8) {
-      float t8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int row = (j0 + j) * 8 + q8;
-        const bool ok = mg * 128 + row < d.Cog && pix0 + pp < d.npix;
-        const float v = gyb[ok ? (long long)(mg * 128 + row) * d.npix + pix0 + pp : 0];
-        t8[j] = ok ? v : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gyl_s[buf][((j0 + j) * 8 + q8) * WPS + pp] = t8[j];
-    }
-  };
-  auto phase_b = [&](int t, int buf) {  // producers: gathered column tile of tile t (16 samples per thread)
-    const int b = t / tps32;
-    const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
-#pragma unroll 1
-    for (int j0 = 0; j0 < 16; j0 += 8) {  // two batches of 8 samples = 32 corner loads in flight
-      float l[8][4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int rr = q8 * 16 + j0 + j;
-        const int cl = rr / KT, k = rr - cl * KT;
-        const int c = nb * d.CB + cl;
-        const bool ok = rr < nrows && c < d.Cig;
-        const unsigned po = tapo_s[buf][(ok ? k : 0) * WP + pp];
-        const int off = (int)(po & 0x3fffffffu);
-        const int dw = (int)((po >> 30) & 1u);
-        const int dh = (po >> 31) ? d.W : 0;
-        const float* xc = xg + (ok ? c : 0) * HW;
-        l[j][0] = xc[off];
-        l[j][1] = xc[off + dw];
-        l[j][2] = xc[off + dh];
-        l[j][3] = xc[off + dh + dw];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int rr = q8 * 16 + j0 + j;
-        const int cl = rr / KT, k = rr - cl * KT;
-        const bool ok = rr < nrows && nb * d.CB + cl < d.Cig;
-        const float4 tw = tapw_s[buf][(ok ? k : 0) * WP + pp];
-        const float v = tw.x * l[j][0] + tw.y * l[j][1] + tw.z * l[j][2] + tw.w * l[j][3];
-        col_s[buf][rr * WPS + pp] = ok ? v : 0.f;
-      }
-    }
-  };
-  auto mma_half = [&](int buf, int half) {  // consumers: k-steps [8*half, 8*half + 8) of the 16 in a 32-pixel tile
-    const float* ap = gyl_s[buf] + (wave * 32 + (lane & 31)) * WPS + (lane >> 5);
-    const float* bp = col_s[buf] + (lane & 31) * WPS + (lane >> 5);
-#pragma unroll
-    for (int ks = half * 8; ks < half * 8 + 8; ++ks) {
-      const float a = ap[2 * ks];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma32(a, bp[nt * 32 * WPS + 2 * ks], acc[nt]);
-    }
-  };
-
-  // prologue: tile s into buffer 0
-  if (s < T) {
-    if (producer) phase_a(s, 0);
-    __syncthreads();
-    if (producer) phase_b(s, 0);
-    __syncthreads();
-  }
-  int buf = 0;
-  for (int t = s; t < T; t += S) {
-    const int tn = t + S;
-    if (producer) {
-      if (tn < T) phase_a(tn, buf ^ 1);
-    } else {
-      mma_half(buf, 0);
-    }
-    __syncthreads();
-    if (producer) {
-      if (tn < T) phase_b(tn, buf ^ 1);
-    } else {
-      mma_half(buf, 1);
-    }
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  if (!producer) {
-    float* pb = part + ((((long long)s * d.G + g) * MG + mg) * d.NB + nb) * (128 * 128);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        pb[i * 128 + nt * 32 + (lane & 31)] = acc[nt][r];
-      }
-  }
-}
-
 __global__ void reduce_gw(const float* __restrict__ part, float* __restrict__ gw, Dims d, int S, int MG) {
   const long long total = (long long)d.Co * d.Cig * d.KK;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1013,19 +852,11 @@ extern "C" int mode_sphere_conv_bwd_weight(const float* gy, const float* pos, co
   hipStream_t st = mode::as_stream(stream);
   const int MG = mode::cdiv(d.Cog, 128);
   const int S = bww_splits(d, MG);
-  if (d.KK == 9) {  // wave-specialised producer/consumer kernel (32-pixel tiles; S <= B*ceil(npix/64) <= its tile count)
-    const size_t lds = 2 * ((size_t)9 * WP * 20 + 2 * (size_t)128 * WPS * 4);
-    rc = mode::allow_lds(sphere_bwd_weight_ws_kernel, lds, "mode_sphere_conv_bwd_weight");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_bwd_weight_ws_kernel, dim3(S, d.NB, d.G * MG), dim3(512), lds, st, gy, pos, x, workspace, d, S, MG,
-                       mode::cdiv(d.npix, WP));
-  } else {
-    const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)128 * PS * 4;
-    rc = mode::allow_lds(sphere_bwd_weight_kernel, lds, "mode_sphere_conv_bwd_weight");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_bwd_weight_kernel, dim3(S, d.NB, d.G * MG), dim3(NTHREADS), lds, st, gy, pos, x, workspace, d, S,
-                       MG);
-  }
+  const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)128 * PS * 4;
+  rc = mode::allow_lds(sphere_bwd_weight_kernel, lds, "mode_sphere_conv_bwd_weight");
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_bwd_weight_kernel, dim3(S, d.NB, d.G * MG), dim3(NTHREADS), lds, st, gy, pos, x, workspace, d, S,
+                     MG);
   rc = mode::check_launch("mode_sphere_conv_bwd_weight");
   if (rc != MODE_OK) return rc;
   const long long n = (long long)d.Co * d.Cig * d.KK;
