@@ -219,6 +219,7 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
+        'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'config': {
             'workload': 'ModeDisparity(%d,Sphere,%dx%d Cassini) %s step, batch %d/GPU (BASELINE configs[%d])' %
                         (args.maxdisp, args.height, args.width, 'fwd+bwd+Adam' if args.mode == 'train' else 'eval fwd',
