@@ -155,7 +155,10 @@ def main():
   net = models.ModeDisparity(args.maxdisp, 'Sphere', args.height, args.width, 'Cassini').to(dev)
   reducer = data_parallel.GradAllReducer(net)
   reducer.broadcast_parameters(net)
-  opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
+  try:  # same update rule as train_disparity.py:287 (Adam, lr 1e-3, betas (0.9, 0.999)); single-kernel implementation
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), fused=True)
+  except (TypeError, RuntimeError):
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
   left, right, gt = synthetic_batch(args.batch, args.height, args.width, args.maxdisp, dev, seed=1234 + rank)
   mask = ~torch.isnan(gt)
   gt0 = torch.nan_to_num(gt)

@@ -64,6 +64,11 @@ def _sc_dims(x_shape, w_shape, out_hw, stride, groups):
   return [B, Ci, H, W, Co, Kh, Kw, stride[0], stride[1], out_hw[0], out_hw[1], groups]
 
 
+def _tag2(name, w, x):
+  """Profiling label with the layer shape, e.g. sphere_conv_fwd[128->128 256x128]."""
+  return '%s[%d->%d %dx%d]' % (name, x.shape[1], w.shape[0], x.shape[2], x.shape[3]) if profiling.ENABLED else name
+
+
 def _wpack(w, groups):
   Co, Cig, Kh, Kw = w.shape
   n = lib().mode_sphere_conv_wpack_bytes(Cig * groups, Co, Kh, Kw, groups)
@@ -88,7 +93,7 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
   dims = _sc_dims(x.shape, w.shape, out.shape[2:], stride, groups)
   flops = 2 * out.numel() * w[0].numel()
   nbytes = 4 * (x.numel() + out.numel() + pos.numel() + w.numel())
-  with torch.cuda.device_of(x), profiling.region('sphere_conv_fwd', nbytes, flops, x.device):
+  with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
     wp = _wpack(w, groups)
     check(lib().mode_sphere_conv_fwd(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), *dims, stream_of(x)), 'mode_sphere_conv_fwd')
   return out
@@ -131,12 +136,12 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups):
   if SPHERE_BWD_DATA == 'gather':
     rowptr, entries, _ = sphere_adjoint(pos, w.shape[2], w.shape[3], stride, gy.shape[2:])
     B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
-    with torch.cuda.device_of(gy), profiling.region('sphere_conv_bwd_data', nbytes, flops, gy.device):
+    with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
       wp = _wpack(w, groups)
       check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
                                                 Kw, Ho, Wo, G, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
     return gx
-  with torch.cuda.device_of(gy), profiling.region('sphere_conv_bwd_data', nbytes, flops, gy.device):
+  with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
     wp = _wpack(w, groups)
     check(lib().mode_sphere_conv_bwd_data(ptr(gy), ptr(pos), ptr(w), ptr(gx), ptr(wp), *dims, stream_of(gy)),
           'mode_sphere_conv_bwd_data')
@@ -151,7 +156,7 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
   B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
   flops = 2 * gy.numel() * gw[0].numel()
   nbytes = 4 * (x.numel() + gy.numel() + pos.numel() + gw.numel())
-  with torch.cuda.device_of(gy), profiling.region('sphere_conv_bwd_weight', nbytes, flops, gy.device):
+  with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_weight', gw, x), nbytes, flops, gy.device):
     n = lib().mode_sphere_conv_bwd_weight_workspace_bytes(B, Ci, Co, Kh, Kw, Ho, Wo, G)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
     check(lib().mode_sphere_conv_bwd_weight(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), *dims, stream_of(gy)),
