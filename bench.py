@@ -141,8 +141,11 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+    # 'nccl' is RCCL on ROCm (xGMI inside the node).  MODE_DIST_BACKEND=gloo only exists to exercise this code path with
+    # several ranks on ONE GPU in tests (RCCL refuses two ranks on the same device).
+    dist.init_process_group(os.environ.get('MODE_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
   assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
+  local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
 

@@ -23,6 +23,14 @@ def pytest_collection_modifyitems(config, items):
   pass
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _native_library():
+  """The .so is a build artefact (git-ignored): build it in-tree if it is missing or stale (hipcc cross-compiles
+  gfx950 without a GPU; a no-op when up to date).  Tests never run against anything but this library."""
+  from mode_hip import build as hip_build
+  hip_build.build(force=False, verbose=False)
+
+
 @pytest.fixture(scope='session')
 def golden():
   def load(name):

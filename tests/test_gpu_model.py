@@ -133,6 +133,31 @@ def test_hourglass_golden(golden, tag):
     assert np.abs(p.grad.cpu().numpy() - g).max() < 1e-3 * max(1.0, np.abs(g).max()), k
 
 
+def test_bench_two_ranks_share_one_gpu():
+  """The N > 1 launch path of bench.py (torch.distributed.run, one process per rank, flat-gradient all-reduce, barrier +
+  max-over-ranks timing) end to end.  Two ranks on ONE GPU need the gloo backend (RCCL refuses duplicate devices); on an
+  8-GPU node the driver runs the same path over RCCL."""
+  import json
+  import os
+  import socket
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MODE_DIST_BACKEND='gloo')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '256',
+         '--width', '128', '--maxdisp', '64', '--batch', '1', '--no-cpu-baseline']
+  r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
+
+
 def test_smoke_entry():
   import __graft_entry__
   __graft_entry__.smoke()
