@@ -7,8 +7,10 @@
 
 Rank 0 prints ONE JSON line.  A "step" is one training iteration of ModeDisparity over one synthetic batch that is already
 resident in HBM: zero-grad, forward (3 heads), masked smooth-L1 loss 0.5/0.7/1.0, backward, gradient all-reduce (N > 1),
-Adam step.  `roofline` describes the dominant hand-written kernel, timed with HIP events on its launch stream inside the
-timed region; `cpu_baseline` times the CPU oracle (a port, not the product) on this host's cores.
+Adam step.  By default zero-grad + forward + loss + backward are replayed as one hipGraph (--launch graph).  `roofline`
+describes the dominant hand-written kernel, timed with HIP events on its launch stream (inside the timed region with
+--launch eager; over --profile-steps eager steps right after it with --launch graph, where events cannot sit inside the
+replayed graph); `cpu_baseline` times the CPU oracle (a port, not the product) on this host's cores.
 """
 import argparse
 import json
@@ -45,6 +47,9 @@ def parse():
   ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) run the CPU oracle timing and print its JSON')
   ap.add_argument('--cpu-baseline-timeout', type=int, default=420)
   ap.add_argument('--no-kernel-timing', action='store_true')
+  ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
+                  help="graph: forward+loss+backward replayed as one hipGraph (default); eager: one launch per kernel")
+  ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
   return ap.parse_args()
 
 
@@ -166,27 +171,36 @@ def main():
   mask = ~torch.isnan(gt)
   gt0 = torch.nan_to_num(gt)
 
-  def train_step():
+  count = data_parallel.global_valid_count(mask)  # a property of the batch, not of the step: computed when it is loaded
+
+  def fwd_bwd():
     reducer.zero_grad()
     o1, o2, o3 = net(left, right)
     loss = 0
     for wgt, o in ((0.5, o1), (0.7, o2), (1.0, o3)):
-      loss = loss + wgt * data_parallel.global_masked_mean(F.smooth_l1_loss(o, gt0, reduction='none'), mask)
+      loss = loss + wgt * data_parallel.global_masked_mean(F.smooth_l1_loss(o, gt0, reduction='none'), mask, count=count)
     loss.backward()
-    reducer.all_reduce()
-    opt.step()
     return loss
 
-  def eval_step():
+  def eval_fwd():
     with torch.no_grad():
       return net(left, right)
 
   if args.mode == 'train':
     net.train()
-    step = train_step
+    body = fwd_bwd
   else:
     net.eval()
-    step = eval_step
+    body = eval_fwd
+
+  def finish():
+    if args.mode == 'train':
+      reducer.all_reduce()
+      opt.step()
+
+  def eager_step():
+    body()
+    finish()
 
   def fence():
     torch.cuda.synchronize()
@@ -195,14 +209,34 @@ def main():
     torch.cuda.synchronize()
 
   for _ in range(args.warmup):
-    step()
+    eager_step()
   fence()
-  profiling.enable(not args.no_kernel_timing)
+  step = eager_step
+  if args.launch == 'graph':
+    from mode_hip.graph_step import GraphedStep
+    graphed = GraphedStep(body, (left, right, gt0), warmup=1)
+
+    def step():
+      graphed.replay()
+      finish()
+
+    step()  # first replay uploads the graph; not timed
+    fence()
+
+  # Timed region: exactly K steps.  With --launch graph the per-kernel events cannot sit inside the replayed graph, so the
+  # per-kernel (roofline) timing is taken over --profile-steps eager steps of the same workload right after the timed
+  # region; with --launch eager the events are recorded inside the timed region itself.
+  profiling.enable(args.launch == 'eager' and not args.no_kernel_timing)
   t0 = time.time()
   for _ in range(args.steps):
     step()
   fence()
   elapsed = time.time() - t0
+  if args.launch == 'graph' and not args.no_kernel_timing:
+    profiling.enable(True)
+    for _ in range(args.profile_steps):
+      eager_step()
+    fence()
   kern = profiling.summary()
   profiling.enable(False)
   if world > 1:
@@ -233,6 +267,8 @@ def main():
             'global_batch': args.batch * world,
             'parallelism': 'dp%d' % world,
             'stage3d_backend': models.stage3d.BACKEND,
+            'launch': 'hipGraph replay of zero-grad+forward+loss+backward, then all-reduce and fused Adam' if args.launch == 'graph'
+                      else 'eager (one launch per kernel)',
         },
     }
     if kern:
@@ -252,7 +288,9 @@ def main():
         pass
       out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
                          'frac': achieved / peak, 'traffic': traffic, 'algorithmic_per_launch': per_launch,
-                         'avg_ms': a['avg_ms'], 'calls': a['calls']}
+                         'avg_ms': a['avg_ms'], 'calls': a['calls'],
+                         'timed_over': ('%d eager steps after the timed region (the timed steps replay a hipGraph)' % args.profile_steps)
+                                       if args.launch == 'graph' else 'the timed region'}
       # north_star targets: HBM fraction of the cost-volume build, MFMA fraction of the whole 3D regulariser
       cv = kern.get('cost_volume_fwd')
       k3 = [v for k, v in kern.items() if k.startswith(('conv3d_', 'deconv3d_'))]

@@ -42,6 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
+#define MODE_HIP_ABI_VERSION 2 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -78,7 +79,8 @@ int mode_sphere_conv_bwd_data(const float* gy, const float* pos, const float* w,
  *   mode_sphere_adjoint_build(pos_host, ...) fills rowptr_host[Kh*Kw*H*W + 1] and entries_host[2 * n] (n <=
  *   mode_sphere_adjoint_max_entries()) -- for tap k and input pixel q, entries rowptr[k*H*W+q] .. rowptr[k*H*W+q+1] are
  *   (output pixel p, float bits of the bilinear weight) pairs.  The caller uploads both arrays and passes the device
- *   copies to mode_sphere_conv_bwd_data_adj, which ACCUMULATES into gx like the scatter form. */
+ *   copies to mode_sphere_conv_bwd_data_adj, which adds to gx like the scatter form (accumulate = 1) or overwrites it
+ *   (accumulate = 0: no zero-fill and no read of gx needed). */
 size_t mode_sphere_adjoint_max_entries(int Kh, int Kw, int Ho, int Wo);
 
 int mode_sphere_adjoint_build(const float* pos_host, int H, int W, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
@@ -86,7 +88,54 @@ int mode_sphere_adjoint_build(const float* pos_host, int H, int W, int Kh, int K
 
 int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
                                   const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
-                                  int Ho, int Wo, int groups, mode_stream_t stream);
+                                  int Ho, int Wo, int groups, int accumulate, mode_stream_t stream);
+
+/* Windowed forward (csrc/sphere_conv_win.hip): same result as mode_sphere_conv_fwd for stride 1 and 3x3 taps, ~2x faster on
+ * tables whose samples are spatially compact (the gnomonic tables of the network).  The caller plans the table once on the HOST:
+ *   mode_sphere_plan_build(pos_host, ...) fills tiles_host[4 * mode_sphere_plan_max_tiles(H, W)] with (h0, w0, rbase, cbase)
+ *   per 64x4 tile of output pixels (the window class is packed into bits 16.. of the 4th word) and counts[4] = tiles per
+ *   class (81-row window, 145-row window, whole-axis window, does-not-fit).  If counts[3] != 0 the table is not compact: use mode_sphere_conv_fwd.
+ * Otherwise upload the tile list and pass it with counts[0..2]; `wpack` >= mode_sphere_conv_win_wpack_bytes(). */
+size_t mode_sphere_plan_max_tiles(int H, int W);
+
+int mode_sphere_plan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* tiles_host, int32_t* counts);
+
+size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups);
+
+int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, float* y, float* wpack, const int32_t* tiles,
+                             int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                             int groups, int transposed, mode_stream_t stream);
+
+/* `transposed` != 0: x and y are stored plane-transposed, (B, C, W, H) contiguous, i.e. with the h axis contiguous
+ * (mode_transpose_planes converts).  For the Cassini tables of the network h is the shift-invariant longitude axis, and in
+ * this storage every global access of the windowed kernels is a full contiguous segment.  H, W, the table and the plan
+ * always refer to the logical (untransposed) image. */
+int mode_transpose_planes(const float* in, float* out, long long planes, int H, int W, mode_stream_t stream);
+
+/* Windowed weight gradient: the 81-row-window tiles of the plan run on the LDS-window kernel, the pixels of all other tiles
+ * (mode_sphere_plan_rest_pixels: their linear indices h*W + w, sorted; at most H*W) on the general kernels.  ADDS to gw like
+ * mode_sphere_conv_bwd_weight; deterministic.  `workspace` >= mode_sphere_conv_bwd_weight_win_workspace_bytes().
+ * gy_t / x_t (both or neither): plane-transposed copies of gy / x for the windowed kernel (see mode_transpose_planes); the
+ * general kernels always read gy / x. */
+int mode_sphere_plan_rest_pixels(const int32_t* tiles_host, const int32_t* counts, int H, int W, int32_t* pix_host,
+                                 int32_t* n_pix);
+
+/* Sampling records of the 81-row-window tiles (window offset + 4 corner weights per tap and pixel), which the windowed
+ * weight-gradient kernel reads instead of re-deriving them from the table: rec_w_host[4 * n], rec_off_host[n],
+ * n = mode_sphere_plan_records_count(counts[0]).  Built once per table on the host, uploaded by the caller. */
+size_t mode_sphere_plan_records_count(int n_small);
+
+int mode_sphere_plan_records(const float* pos_host, const int32_t* tiles_host, const int32_t* counts, int H, int W,
+                             float* rec_w_host, int32_t* rec_off_host);
+
+size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                                       int n_small, int n_rest_pixels);
+
+int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                    const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
+                                    const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, int B, int Ci, int H,
+                                    int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
+                                    mode_stream_t stream);
 
 /* Replaces the grad_weight half (sphere_conv_cuda.cpp:296-315: second im2col + addmm_(gO, col^T),
  * summed over the batch).  ACCUMULATES into gw (caller zero-fills, sphere_conv.py:63).  `workspace`
@@ -171,24 +220,28 @@ int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float
  * follow it in hourglass.forward / ModeDisparity.forward (models/mode_disparity.py:27-46, 115-129):
  *      out = relu?( gamma * (y - mean) / sqrt(var + eps) + beta  [+ add] )
  * train: batch statistics over (B, S) per channel (biased variance for normalisation); running_mean / running_var are
- *        updated in place with `momentum` (unbiased variance), as torch does; save_mean / save_invstd feed the backward.
- * eval : running statistics.
- * bwd  : g = relu ? gout * (out > 0) : gout;  gy = dL/dy, ggamma, gbeta written; gadd (optional, = g) written if non-NULL.
- * `workspace` >= mode_bn_workspace_bytes(C) for every call.
+ *        updated in place with `momentum` (unbiased variance) and *num_batches_tracked is incremented (either may be
+ *        NULL), as nn.BatchNorm does; save_mean / save_invstd feed the backward.  Two launches.
+ * eval : running statistics.  One launch.
+ * bwd  : g = relu ? gout * (out > 0) : gout;  gy = dL/dy written; gadd (optional, = g) written if non-NULL;
+ *        ggamma / gbeta written (accumulate = 0) or added to (accumulate = 1: the caller's gradient buffer, which saves
+ *        the separate accumulation kernels of autograd).  Two launches.
+ * `workspace` >= mode_bn_workspace_bytes(C) for the training calls.
  */
 size_t mode_bn_workspace_bytes(int C);
 
 int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
-                      float* running_var, float momentum, float eps, int relu, float* out, float* save_mean,
-                      float* save_invstd, float* workspace, int B, int C, long long S, mode_stream_t stream);
+                      float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
+                      float* out, float* save_mean, float* save_invstd, float* workspace, int B, int C, long long S,
+                      mode_stream_t stream);
 
 int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
-                     const float* running_var, float eps, int relu, float* out, float* workspace, int B, int C,
-                     long long S, mode_stream_t stream);
+                     const float* running_var, float eps, int relu, float* out, int B, int C, long long S,
+                     mode_stream_t stream);
 
 int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
                       const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
-                      float* workspace, int B, int C, long long S, mode_stream_t stream);
+                      int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -3,8 +3,9 @@
 // Reference: nn.BatchNorm3d / nn.BatchNorm2d inside convbn_3d / convbn (models/submodule.py:15-22, torch defaults eps 1e-5,
 // momentum 0.1, affine, running statistics, per-replica batch statistics) followed by the residual adds and ReLUs of
 // hourglass.forward / ModeDisparity.forward (models/mode_disparity.py:27-46, 115-129).  The reference runs these as separate
-// kernels (BN: read, read, write; add: read, read, write; ReLU: read, write); here a layer is two HBM passes in training
-// (statistics, then normalise + add + ReLU in one pass) and one pass in eval mode.  Pure HBM roofline kernels:
+// kernels (BN: read, read, write; add: read, read, write; ReLU: read, write); here a layer is two launches / two HBM passes
+// in training (statistics, then normalise + add + ReLU with the per-channel finalisation folded into the prologue of every
+// block) and one launch / one pass in eval mode.  Pure HBM roofline kernels:
 //   train fwd  : (2 reads [+1 read of the skip tensor] + 1 write) * 4 B per element
 //   train bwd  : reduce pass (reads gout, y [, out]) + apply pass (reads gout, y [, out], writes gy [, gadd])
 // Statistics are reduced per thread / per block in fp32 over short runs and combined across blocks in fp64.
@@ -67,52 +68,87 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   }
 }
 
-// one thread per channel: batch mean / biased variance, running-stat update (unbiased variance), affine coefficients
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift, int C, int nsplit, double count) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nsplit; ++i) {
-    s0 += (double)partial[((long long)c * nsplit + i) * 2];
-    s1 += (double)partial[((long long)c * nsplit + i) * 2 + 1];
+// Block-wide fp64 sum of this channel's per-block partials (pairs); every block of a channel walks them in the same
+// order, so all blocks derive bit-identical coefficients.  Result valid in thread 0.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int c, int nsplit, double& s0, double& s1,
+                                                double* shd /* [8] */) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nsplit; i += NT) {
+    const float2 v = reinterpret_cast<const float2*>(partial)[(long long)c * nsplit + i];
+    a += (double)v.x;
+    b += (double)v.y;
   }
-  const double mean = s0 / count;
-  double var = s1 / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)invstd;
-  const double sc = (double)gamma[c] * invstd;
-  scale[c] = (float)sc;
-  shift[c] = (float)((double)beta[c] - mean * sc);
-  if (running_mean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    shd[wave] = a;
+    shd[4 + wave] = b;
+  }
+  __syncthreads();
+  s0 = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+  s1 = (shd[4] + shd[5]) + (shd[6] + shd[7]);
 }
 
-__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
-                                     float* __restrict__ scale, float* __restrict__ shift, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float sc = gamma[c] / sqrtf(running_var[c] + eps);  // same arithmetic order as torch's eval-mode batch_norm
-  scale[c] = sc;
-  shift[c] = beta[c] - running_mean[c] * sc;
-}
+// Where the affine coefficients of the apply pass come from.
+//   TRAIN: batch statistics from the per-block partial sums of bn_stats_kernel; the block (chunk 0, sample 0) of each channel
+//          also stores mean / invstd for the backward pass and updates the running statistics (unbiased variance), and the
+//          one of channel 0 counts the batch in num_batches_tracked.
+//   EVAL : running statistics, same arithmetic order as torch's eval-mode batch_norm.
+struct BnCoefArgs {
+  const float* partial;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  float* save_mean;
+  float* save_invstd;
+  float momentum, eps;
+  int nsplit;
+  double count;
+};
 
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
-template <bool RELU, bool ADD>
-__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+template <bool RELU, bool ADD, bool TRAIN>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add, BnCoefArgs k,
                                                       float* __restrict__ out, int C, long long S) {
+  __shared__ double shd[8];
+  __shared__ float coef[2];
   const int bc = blockIdx.y;
   const int c = bc % C;
-  const float sc = scale[c], sh = shift[c];
+  if (TRAIN) {
+    double s0, s1;
+    reduce_partials(k.partial, c, k.nsplit, s0, s1, shd);
+    if (threadIdx.x == 0) {
+      const double mean = s0 / k.count;
+      double var = s1 / k.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)k.eps);
+      const double sc = (double)k.gamma[c] * invstd;
+      coef[0] = (float)sc;
+      coef[1] = (float)((double)k.beta[c] - mean * sc);
+      if (blockIdx.x == 0 && bc < C) {
+        k.save_mean[c] = (float)mean;
+        k.save_invstd[c] = (float)invstd;
+        if (k.running_mean) {
+          const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
+          k.running_mean[c] = (float)((1.0 - k.momentum) * (double)k.running_mean[c] + k.momentum * mean);
+          k.running_var[c] = (float)((1.0 - k.momentum) * (double)k.running_var[c] + k.momentum * unbiased);
+        }
+        if (c == 0 && k.num_batches_tracked) *k.num_batches_tracked += 1;
+      }
+    }
+  } else if (threadIdx.x == 0) {
+    const float sc = k.gamma[c] / sqrtf(k.running_var[c] + k.eps);
+    coef[0] = sc;
+    coef[1] = k.beta[c] - k.running_mean[c] * sc;
+  }
+  __syncthreads();
+  const float sc = coef[0], sh = coef[1];
   const long long base = (long long)bc * S;
   const long long S4 = S >> 2;
   const float4* yp = reinterpret_cast<const float4*>(y + base);
@@ -183,36 +219,45 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
   }
 }
 
-// ggamma = invstd * (sum(g*y) - mean*sum(g)), gbeta = sum(g); gy = A*g + Bc*y + Cc
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                       float* __restrict__ ggamma, float* __restrict__ gbeta, float* __restrict__ coef /* [3][C] */,
-                                       int C, int nsplit, double count) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgy = 0.0;
-  for (int i = 0; i < nsplit; ++i) {
-    sg += (double)partial[((long long)c * nsplit + i) * 2];
-    sgy += (double)partial[((long long)c * nsplit + i) * 2 + 1];
-  }
-  const double mean = save_mean[c], invstd = save_invstd[c], gm = gamma[c];
-  const double dgamma = invstd * (sgy - mean * sg);
-  ggamma[c] = (float)dgamma;
-  gbeta[c] = (float)sg;
-  const double A = gm * invstd;
-  coef[c] = (float)A;
-  coef[C + c] = (float)(-A * invstd * dgamma / count);
-  coef[2 * C + c] = (float)(A * (mean * invstd * dgamma - sg) / count);
-}
-
-// grid = (chunks, B*C): g = masked gout; gy = A*g + Bc*y + Cc; optionally gadd = g
+// grid = (chunks, B*C): g = masked gout; gy = A*g + Bc*y + Cc; optionally gadd = g, with
+//   dgamma = invstd * (sum(g*y) - mean*sum(g)), dbeta = sum(g), A = gamma*invstd, Bc = -A*invstd*dgamma/count,
+//   Cc = A*(mean*invstd*dgamma - sum(g))/count
+// derived by every block from the partial sums; the block (chunk 0, sample 0) of each channel stores (or, with
+// `accumulate`, adds into) ggamma / gbeta.
 template <bool RELU, bool GADD>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ gout, const float* __restrict__ y,
-                                                          const float* __restrict__ out, const float* __restrict__ coef,
+                                                          const float* __restrict__ out, const float* __restrict__ partial,
+                                                          const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, float* __restrict__ ggamma,
+                                                          float* __restrict__ gbeta, int accumulate, int nsplit, double count,
                                                           float* __restrict__ gy, float* __restrict__ gadd, int C, long long S) {
+  __shared__ double shd[8];
+  __shared__ float coef[3];
   const int bc = blockIdx.y;
   const int c = bc % C;
-  const float A = coef[c], Bc = coef[C + c], Cc = coef[2 * C + c];
+  {
+    double sg, sgy;
+    reduce_partials(partial, c, nsplit, sg, sgy, shd);
+    if (threadIdx.x == 0) {
+      const double mean = save_mean[c], invstd = save_invstd[c], gm = gamma[c];
+      const double dgamma = invstd * (sgy - mean * sg);
+      const double A = gm * invstd;
+      coef[0] = (float)A;
+      coef[1] = (float)(-A * invstd * dgamma / count);
+      coef[2] = (float)(A * (mean * invstd * dgamma - sg) / count);
+      if (blockIdx.x == 0 && bc < C) {
+        if (accumulate) {
+          ggamma[c] += (float)dgamma;
+          gbeta[c] += (float)sg;
+        } else {
+          ggamma[c] = (float)dgamma;
+          gbeta[c] = (float)sg;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const float A = coef[0], Bc = coef[1], Cc = coef[2];
   const long long base = (long long)bc * S;
   const long long S4 = S >> 2;
   const float4* gp = reinterpret_cast<const float4*>(gout + base);
@@ -278,84 +323,88 @@ int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who,
 
 }  // namespace
 
-// workspace (floats): partial sums C*1024*2 + scale C + shift C (+ 3C coefficients for the backward)
-extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * (2048 + 5) * sizeof(float) : 0; }
+// workspace (floats): per-block partial sums, C * 1024 pairs
+extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 2048 * sizeof(float) : 0; }
 
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
-                                 float* running_var, float momentum, float eps, int relu, float* out, float* save_mean,
-                                 float* save_invstd, float* workspace, int B, int C, long long S, mode_stream_t stream) {
+                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                                 float* save_mean, float* save_invstd, float* workspace, int B, int C, long long S,
+                                 mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
   MODE_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && workspace, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: null pointer");
-  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_train_fwd: unaligned buffer");
+  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)) && aligned16(workspace), MODE_ERR_UNSUPPORTED,
+               "mode_bn_train_fwd: unaligned buffer");
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = pick_nsplit(C, S);
-  float* partial = workspace;
-  float* scale = workspace + (size_t)C * 2048;
-  float* shift = scale + C;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NT), 0, st, y, partial, B, C, S, nsplit);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, partial, gamma, beta, running_mean, running_var,
-                     momentum, eps, save_mean, save_invstd, scale, shift, C, nsplit, (double)B * (double)S);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, momentum, eps, nsplit,
+               (double)B * (double)S};
   const int BC = B * C;
+  const char* who = "mode_bn_train_fwd";
   if (relu) {
-    if (add) return launch_apply(bn_apply_kernel<true, true>, BC, S, st, "mode_bn_train_fwd", y, add, scale, shift, out, C, S);
-    return launch_apply(bn_apply_kernel<true, false>, BC, S, st, "mode_bn_train_fwd", y, y, scale, shift, out, C, S);
+    if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false, true>, BC, S, st, who, y, y, k, out, C, S);
   }
-  if (add) return launch_apply(bn_apply_kernel<false, true>, BC, S, st, "mode_bn_train_fwd", y, add, scale, shift, out, C, S);
-  return launch_apply(bn_apply_kernel<false, false>, BC, S, st, "mode_bn_train_fwd", y, y, scale, shift, out, C, S);
+  if (add) return launch_apply(bn_apply_kernel<false, true, true>, BC, S, st, who, y, add, k, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false, true>, BC, S, st, who, y, y, k, out, C, S);
 }
 
 extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
-                                const float* running_var, float eps, int relu, float* out, float* workspace, int B, int C,
-                                long long S, mode_stream_t stream) {
+                                const float* running_var, float eps, int relu, float* out, int B, int C, long long S,
+                                mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_eval_fwd");
   if (rc != MODE_OK) return rc;
   if (B == 0) return MODE_OK;
-  MODE_REQUIRE(y && gamma && beta && running_mean && running_var && out && workspace, MODE_ERR_BAD_ARG, "mode_bn_eval_fwd: null pointer");
+  MODE_REQUIRE(y && gamma && beta && running_mean && running_var && out, MODE_ERR_BAD_ARG, "mode_bn_eval_fwd: null pointer");
   MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_eval_fwd: unaligned buffer");
   hipStream_t st = mode::as_stream(stream);
-  float* scale = workspace + (size_t)C * 2048;
-  float* shift = scale + C;
-  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, gamma, beta, running_mean, running_var, eps, scale,
-                     shift, C);
+  BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, 0.f,
+               eps, 0, 0.0};
   const int BC = B * C;
+  const char* who = "mode_bn_eval_fwd";
   if (relu) {
-    if (add) return launch_apply(bn_apply_kernel<true, true>, BC, S, st, "mode_bn_eval_fwd", y, add, scale, shift, out, C, S);
-    return launch_apply(bn_apply_kernel<true, false>, BC, S, st, "mode_bn_eval_fwd", y, y, scale, shift, out, C, S);
+    if (add) return launch_apply(bn_apply_kernel<true, true, false>, BC, S, st, who, y, add, k, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false, false>, BC, S, st, who, y, y, k, out, C, S);
   }
-  if (add) return launch_apply(bn_apply_kernel<false, true>, BC, S, st, "mode_bn_eval_fwd", y, add, scale, shift, out, C, S);
-  return launch_apply(bn_apply_kernel<false, false>, BC, S, st, "mode_bn_eval_fwd", y, y, scale, shift, out, C, S);
+  if (add) return launch_apply(bn_apply_kernel<false, true, false>, BC, S, st, who, y, add, k, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false, false>, BC, S, st, who, y, y, k, out, C, S);
 }
 
 extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
                                  const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
-                                 float* workspace, int B, int C, long long S, mode_stream_t stream) {
+                                 int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_bwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");
   MODE_REQUIRE(gout && y && gamma && save_mean && save_invstd && gy && ggamma && gbeta && workspace, MODE_ERR_BAD_ARG,
                "mode_bn_train_bwd: null pointer");
   MODE_REQUIRE(!relu || out, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: the ReLU mask needs the forward output");
-  MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)),
+  MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)) &&
+                   aligned16(workspace),
                MODE_ERR_UNSUPPORTED, "mode_bn_train_bwd: unaligned buffer");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = pick_nsplit(C, S);
   float* partial = workspace;
-  float* coef = workspace + (size_t)C * 2048 + 2 * C;
   if (relu)
     hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, out, partial, B, C, S, nsplit);
   else
     hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, y, partial, B, C, S, nsplit);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mode::cdiv(C, 64)), dim3(64), 0, st, partial, gamma, save_mean, save_invstd, ggamma,
-                     gbeta, coef, C, nsplit, (double)B * (double)S);
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
+  const double count = (double)B * (double)S;
   if (relu) {
-    if (gadd) return launch_apply(bn_bwd_apply_kernel<true, true>, BC, S, st, who, gout, y, out, coef, gy, gadd, C, S);
-    return launch_apply(bn_bwd_apply_kernel<true, false>, BC, S, st, who, gout, y, out, coef, gy, gy, C, S);
+    if (gadd)
+      return launch_apply(bn_bwd_apply_kernel<true, true>, BC, S, st, who, gout, y, out, partial, gamma, save_mean, save_invstd, ggamma,
+                          gbeta, accumulate, nsplit, count, gy, gadd, C, S);
+    return launch_apply(bn_bwd_apply_kernel<true, false>, BC, S, st, who, gout, y, out, partial, gamma, save_mean, save_invstd, ggamma,
+                        gbeta, accumulate, nsplit, count, gy, gy, C, S);
   }
-  if (gadd) return launch_apply(bn_bwd_apply_kernel<false, true>, BC, S, st, who, gout, y, y, coef, gy, gadd, C, S);
-  return launch_apply(bn_bwd_apply_kernel<false, false>, BC, S, st, who, gout, y, y, coef, gy, gy, C, S);
+  if (gadd)
+    return launch_apply(bn_bwd_apply_kernel<false, true>, BC, S, st, who, gout, y, y, partial, gamma, save_mean, save_invstd, ggamma, gbeta,
+                        accumulate, nsplit, count, gy, gadd, C, S);
+  return launch_apply(bn_bwd_apply_kernel<false, false>, BC, S, st, who, gout, y, y, partial, gamma, save_mean, save_invstd, ggamma, gbeta,
+                      accumulate, nsplit, count, gy, gy, C, S);
 }

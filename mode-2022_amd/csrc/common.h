@@ -4,6 +4,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "mode_hip.h"
 
@@ -30,7 +33,23 @@ inline int allow_lds(K kernel, size_t bytes, const char* what) {
     set_error("%s: needs %zu B of LDS (> 160 KiB)", what, bytes);
     return MODE_ERR_UNSUPPORTED;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // once per (kernel, size): keeps the call out of the steady state (and out of hipGraph captures)
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const std::pair<const void*, int> key(fn, device);
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return MODE_OK;
+  }
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> g(mu);
+    granted[key] = bytes;
+  }
   if (e != hipSuccess) {
     set_error("%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
     return (int)e;

@@ -14,6 +14,6 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace mode
 
-extern "C" int mode_hip_abi_version(void) { return 1; }
+extern "C" int mode_hip_abi_version(void) { return MODE_HIP_ABI_VERSION; }
 
 extern "C" const char* mode_last_error(void) { return mode::g_err; }

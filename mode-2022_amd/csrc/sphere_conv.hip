@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "sphere_internal.h"
 
 namespace {
 
@@ -39,6 +40,7 @@ struct Dims {
   int CB;         // channels per 128-row block (bwd): floor(128 / KK)
   int NB;         // such blocks over Cig
   int KSQ;        // k-step quads over Cog (bwd-data): ceil(Cog / 8)
+  int accumulate; // gather-form bwd-data: add to gx (1, the reference op's contract) or overwrite it (0)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -49,13 +51,17 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // Sampling records.  tap_off: bits 0-29 offset of the (clamped) top-left corner, bit 30 = step to the right
 // corner (0/1), bit 31 = step to the lower row (0/1).  tap_w = weights of (top-left, top-right, bottom-left,
 // bottom-right) with invalid corners zeroed (cu:96-107) and the whole tap zeroed outside (-1,H)x(-1,W) (cu:246).
+// With a pixel selection (pixmap, nsel) the tile holds the listed output pixels pixmap[pix0 .. pix0+P) instead of the
+// consecutive ones.
 __device__ __forceinline__ void compute_tapinfo(const float* __restrict__ pos, const Dims& d, int pix0,
-                                                unsigned* tap_off, float4* tap_w) {
+                                                unsigned* tap_off, float4* tap_w, const int* __restrict__ pixmap = nullptr,
+                                                int nsel = 0) {
   const int HW = d.H * d.W;
   for (int item = threadIdx.x; item < d.KK * P; item += NTHREADS) {
     const int k = item / P;
     const int p = item % P;
-    const int pix = pix0 + p;
+    int pix = pix0 + p;
+    if (pixmap) pix = pix < nsel ? pixmap[pix] : d.npix;
     unsigned off = 0;
     float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pix < d.npix) {
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
 // where L(k, q) lists the output pixels p whose tap k touches input pixel q with bilinear weight wt (the transpose of the
 // sampling table, built once per table by mode_sphere_adjoint_build).  Same structure as the forward kernel: the producer
 // fills a column tile in LDS (8 output channels x KK taps x 64 input pixels), the contraction runs on MFMA with
-// D[i = c][j = q].  grid = (B*tiles(H*W), ceil(MTc/4), G).  ACCUMULATES into gx (each element is owned by one lane).
+// D[i = c][j = q].  grid = (B*tiles(H*W), ceil(MTc/4), G).  Adds to (d.accumulate) or overwrites gx; each element is owned by one lane.
 //
 // wp[((g*MTc + mt)*NCHo + ch)*KK + quad][lane][j] = W[g*Cog + ch*8 + kl/KK][mt*32 + (lane&31)][kl%KK], kl = 2*(quad*4+j) + (lane>>5)
 __global__ void pack_w_adj(const float* __restrict__ w, float* __restrict__ wp, Dims d, int MTc, int NCHo) {
@@ -402,8 +408,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj_kernel(const flo
       const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (c < d.Cig) {
         const int qq = q0 + (lane & 31);
-        if (qq < HWin) gxb[(long long)c * HWin + qq] += acc0[r];
-        if (qq + 32 < HWin) gxb[(long long)c * HWin + qq + 32] += acc1[r];
+        float* o0 = gxb + (long long)c * HWin + qq;
+        if (qq < HWin) o0[0] = d.accumulate ? o0[0] + acc0[r] : acc0[r];
+        if (qq + 32 < HWin) o0[32] = d.accumulate ? o0[32] + acc1[r] : acc1[r];
       }
     }
   }
@@ -533,8 +540,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
       const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (c < d.Cig) {
         const int qq = q0 + (lane & 31);
-        if (qq < HWin) gxb[(long long)c * HWin + qq] += acc0[r];
-        if (qq + 32 < HWin) gxb[(long long)c * HWin + qq + 32] += acc1[r];
+        float* o0 = gxb + (long long)c * HWin + qq;
+        if (qq < HWin) o0[0] = d.accumulate ? o0[0] + acc0[r] : acc0[r];
+        if (qq + 32 < HWin) o0[32] = d.accumulate ? o0[32] + acc1[r] : acc1[r];
       }
     }
   }
@@ -624,7 +632,8 @@ constexpr int PS = P + 1;  // padded row stride: bank = (row*65 + k) % 32 -> con
 
 __global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ pos,
                                                                       const float* __restrict__ x, float* __restrict__ part,
-                                                                      Dims d, int S, int MG) {
+                                                                      Dims d, int S, int MG, const int* __restrict__ pixmap,
+                                                                      int nsel) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* tap_w = reinterpret_cast<float4*>(smem);
   unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
@@ -647,8 +656,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float
   for (int t = s; t < T; t += S) {
     const int b = t / d.tps;
     const int pix0 = (t - b * d.tps) * P;
-    compute_tapinfo(pos, d, pix0, tap_off, tap_w);
+    compute_tapinfo(pos, d, pix0, tap_off, tap_w, pixmap, nsel);
     const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
+    int mypix = pix0 + p;  // this thread's output pixel of the tile (d.npix = none)
+    if (pixmap) mypix = mypix < nsel ? pixmap[mypix] : d.npix;
     // gy tile: a wave loads 64 consecutive pixels of one output-channel row per instruction; 8 loads in flight per thread
 #pragma unroll 1
     for (int r0 = 0; r0 < 128; r0 += 32) {
@@ -656,8 +667,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_weight_kernel(const float
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int row = r0 + j * 4 + q;
-        const bool ok = mg * 128 + row < d.Cog && pix0 + p < d.npix;
-        const float v = gyb[ok ? (long long)(mg * 128 + row) * d.npix + pix0 + p : 0];
+        const bool ok = mg * 128 + row < d.Cog && mypix < d.npix;
+        const float v = gyb[ok ? (long long)(mg * 128 + row) * d.npix + mypix : 0];
         t8[j] = ok ? v : 0.f;
       }
 #pragma unroll
@@ -840,28 +851,49 @@ extern "C" size_t mode_sphere_conv_bwd_weight_workspace_bytes(int B, int Ci, int
   return (size_t)bww_splits(d, MG) * d.G * MG * d.NB * 128 * 128 * sizeof(float);
 }
 
+namespace mode {
+// General (gather) weight-gradient kernels over all output pixels (pixmap == nullptr) or over the listed ones only; ADDS the
+// result to gw.  Used by mode_sphere_conv_bwd_weight and, for the tiles the windowed kernel leaves out, by
+// mode_sphere_conv_bwd_weight_win (sphere_conv_win.hip).
+size_t sphere_bwd_weight_general_workspace(int B, int Ci, int Co, int Kh, int Kw, int Ho, int Wo, int groups, int nsel) {
+  Dims d;
+  if (make_dims(d, B, Ci, 1 << 14, 1 << 14, Co, Kh, Kw, 1, 1, Ho, Wo, groups, "mode_sphere_conv_bwd_weight_workspace_bytes") != MODE_OK)
+    return 0;
+  if (nsel > 0) d.tps = mode::cdiv(nsel, P);
+  const int MG = mode::cdiv(d.Cog, 128);
+  return (size_t)bww_splits(d, MG) * d.G * MG * d.NB * 128 * 128 * sizeof(float);
+}
+
+int sphere_bwd_weight_general(const float* gy, const float* pos, const float* x, float* gw, float* workspace, int B, int Ci, int H,
+                              int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups, const int* pixmap, int nsel,
+                              hipStream_t st, const char* who) {
+  Dims d;
+  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, who);
+  if (rc != MODE_OK) return rc;
+  if (B == 0 || (pixmap && nsel == 0)) return MODE_OK;
+  if (pixmap) d.tps = mode::cdiv(nsel, P);
+  const int MG = mode::cdiv(d.Cog, 128);
+  const int S = bww_splits(d, MG);
+  const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)128 * PS * 4;
+  rc = mode::allow_lds(sphere_bwd_weight_kernel, lds, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_bwd_weight_kernel, dim3(S, d.NB, d.G * MG), dim3(NTHREADS), lds, st, gy, pos, x, workspace, d, S, MG,
+                     pixmap, nsel);
+  rc = mode::check_launch(who);
+  if (rc != MODE_OK) return rc;
+  const long long n = (long long)d.Co * d.Cig * d.KK;
+  hipLaunchKernelGGL(reduce_gw, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, MG);
+  return mode::check_launch(who);
+}
+}  // namespace mode
+
 extern "C" int mode_sphere_conv_bwd_weight(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                            int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo,
                                            int groups, mode_stream_t stream) {
   MODE_REQUIRE(gy && pos && x && gw, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight: null pointer");
   MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_sphere_conv_bwd_weight: workspace required");
-  Dims d;
-  int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, "mode_sphere_conv_bwd_weight");
-  if (rc != MODE_OK) return rc;
-  if (B == 0) return MODE_OK;
-  hipStream_t st = mode::as_stream(stream);
-  const int MG = mode::cdiv(d.Cog, 128);
-  const int S = bww_splits(d, MG);
-  const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)128 * PS * 4;
-  rc = mode::allow_lds(sphere_bwd_weight_kernel, lds, "mode_sphere_conv_bwd_weight");
-  if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(sphere_bwd_weight_kernel, dim3(S, d.NB, d.G * MG), dim3(NTHREADS), lds, st, gy, pos, x, workspace, d, S,
-                     MG);
-  rc = mode::check_launch("mode_sphere_conv_bwd_weight");
-  if (rc != MODE_OK) return rc;
-  const long long n = (long long)d.Co * d.Cig * d.KK;
-  hipLaunchKernelGGL(reduce_gw, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, MG);
-  return mode::check_launch("mode_sphere_conv_bwd_weight(reduce)");
+  return mode::sphere_bwd_weight_general(gy, pos, x, gw, workspace, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, nullptr, 0,
+                                         mode::as_stream(stream), "mode_sphere_conv_bwd_weight");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -938,10 +970,11 @@ extern "C" int mode_sphere_adjoint_build(const float* pos_host, int H, int W, in
 
 extern "C" int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
                                              const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
-                                             int Ho, int Wo, int groups, mode_stream_t stream) {
+                                             int Ho, int Wo, int groups, int accumulate, mode_stream_t stream) {
   Dims d;
   int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, 1, 1, Ho, Wo, groups, "mode_sphere_conv_bwd_data_adj");
   if (rc != MODE_OK) return rc;
+  d.accumulate = accumulate ? 1 : 0;
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(gy && w && gx && wpack && adj_rowptr && adj_entries, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_data_adj: null pointer");
   hipStream_t st = mode::as_stream(stream);

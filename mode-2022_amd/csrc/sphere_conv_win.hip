@@ -1,0 +1,908 @@
+// Spherical convolution, "windowed" kernels for gfx950 (MI355X).
+//
+// The general kernels of sphere_conv.hip gather the four bilinear corners of every (channel, tap, pixel) sample straight from
+// global memory: 4 dependent loads and ~50 VALU instructions per sample, which bound them at 22-44 % of the fp32 MFMA peak.
+// The sampling tables of the network are not arbitrary, though: a gnomonic kernel on an equirectangular grid is
+// shift-invariant along the longitude axis, so all samples of a small block of output pixels fall into a compact window of
+// the input (a few columns wide; a few rows taller than the block, except next to the poles where it wraps around the whole
+// longitude axis).  These kernels stage that window of the input ONCE per channel chunk in LDS with plain row loads and
+// build the MFMA B operand on the fly from it: 4 LDS reads + 4 FMAs per sample, no column buffer at all.
+//
+// Nothing is assumed about the table: the host plans every tile from the actual table values (mode_sphere_plan_build,
+// same record arithmetic as the kernel, sphere_tap.h) and classifies it by the window it needs.  A table whose tiles do not
+// fit any window class is reported as such and the caller uses the general kernels.
+//
+// Tile = 32 rows x 4 columns of output pixels (stride 1): wave v owns column w0 + v and the 32 rows h0 .. h0+31 as the N
+// dimension of v_mfma_f32_32x32x2_f32 (lanes run along h: for the Cassini layout of the network that is the longitude axis,
+// so the 32 lanes of a half-wave read 32 consecutive LDS words), and all (<= 128) output channels of its z-slice as 4 M-tiles.
+// K is ordered chunk (8 input channels) > tap > channel pair; the two half-waves supply the two channels of a pair.
+//
+// Reference: sphere_conv_cuda_kernel.cu:83-113, 195-262 (im2col gather) + sphere_conv_cuda.cpp:177-205 (addmm_).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "sphere_internal.h"
+#include "sphere_tap.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RB = 2;      // MFMA N-tiles (32 rows) per tile column
+constexpr int TH = 32 * RB;  // tile rows
+constexpr int TW = 4;      // tile columns
+constexpr int WC = 8;      // window columns
+constexpr int CCH = 8;     // input channels per chunk
+constexpr int KT = 9;      // taps (3x3 kernels)
+constexpr int MTW = 4;     // M-tiles (32 output channels each) per wave
+constexpr int NTHREADS = 64 * TW * RB;  // one wave per (column, 32-row block)
+constexpr int SROWS = NTHREADS / WC;    // window rows staged per pass
+constexpr int WR_SMALL = TH + 17, WR_MID = TH + 81;  // window rows of the two compact classes (odd: conflict-free column pitch)
+constexpr int WR_PIPE_MAX = 5 * SROWS;  // tallest window whose next chunk still fits in registers while the current one computes
+
+struct WinDims {
+  int B, Ci, H, W, Co, G;
+  int Cig, Cog;
+  int NCH;  // channel chunks
+  int MG;   // 128-channel output slices per group
+  int wr;   // window rows of the wrap-around class (H + 1)
+  int wrap_pipe;  // wrap-around class double-buffered (fits LDS and registers) or staged in place
+  int sh, sw;     // element strides of h and w in the activation tensors: (W, 1) = NCHW; (1, H) = planes stored transposed
+  int accumulate;
+};
+
+__host__ __device__ constexpr int chan_pitch(int wr) {
+  // 8 columns of wr rows, padded so that consecutive channels are 32 banks apart (the two half-waves of a B read)
+  return WC * wr + ((32 - (WC * wr) % 64) + 64) % 64;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// wp[(((g*MG + mg)*NCH + ch)*KT + tap)*MTW + m][lane] (float4 = 4 k-steps) = W[g*Cog + mg*128 + m*32 + (lane&31)][ch*8 + 2*s + (lane>>5)][tap]
+__global__ void pack_w_win(const float* __restrict__ w, float* __restrict__ wp, WinDims d) {
+  const long long total = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int m = (int)(r % MTW);
+    r /= MTW;
+    const int tap = (int)(r % KT);
+    r /= KT;
+    const int ch = (int)(r % d.NCH);
+    r /= d.NCH;
+    const int mg = (int)(r % d.MG);
+    const int g = (int)(r / d.MG);
+    const int co = mg * 128 + m * 32 + (lane & 31);
+    const int c = ch * CCH + 2 * s + (lane >> 5);
+    float v = 0.f;
+    if (co < d.Cog && c < d.Cig) v = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
+    wp[idx] = v;
+  }
+}
+
+// One tile.  WR_T > 0: compile-time window rows; WR_T == 0: window rows = d.wr (wrap-around class).  PIPE: double-buffered,
+// the next chunk's rows are prefetched into registers under the MFMA phase, in NPH phases of CCH/NPH channels each (a tall
+// window has too many rows to hold a whole chunk in registers); otherwise single buffer, staged in place.
+template <int WR_T, bool PIPE, int NRB, int NPH>
+__device__ __forceinline__ void fwd_tile(const float* __restrict__ x, const float* __restrict__ pos, const float4* __restrict__ wp,
+                                         float* __restrict__ y, const WinDims& d, int h0, int w0, int rbase, int cbase, float* smem) {
+  const int WRP = WR_T > 0 ? WR_T : d.wr;
+  const int CP = chan_pitch(WRP);
+  const int bufsz = CCH * CP;
+
+  const int b = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5;
+  const int h = h0 + (wave / TW) * 32 + (lane & 31), w = w0 + (wave % TW);
+  const bool pix_ok = h < d.H && w < d.W;
+  const long long HW = (long long)d.H * d.W;
+
+  // sampling records of this lane's pixel: window offset of the first corner + 4 weights per tap, kept in registers
+  int roff[KT];
+  float4 rw[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    int r0 = 0, c0 = 0;
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix_ok) {
+      const long long idx = (long long)h * d.W + w;
+      mode::tap_record_fixed(pos[(2 * k) * HW + idx], pos[(2 * k + 1) * HW + idx], d.H, d.W, r0, c0, wt);
+    }
+    int lr = r0 - rbase;
+    if (lr < 0) lr += d.H;
+    const int lc = c0 - cbase;
+    const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
+    roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
+    rw[k] = wt;
+  }
+
+  // every LDS word that can be read must be finite: zero everything once (corners with weight 0 may point anywhere inside)
+  const int lds_floats = (PIPE ? 2 : 1) * bufsz + WRP + 8;
+  for (int i = tid; i < lds_floats; i += NTHREADS) smem[i] = 0.f;
+  __syncthreads();
+
+  // staging: thread -> (window column, row within a pass of SROWS rows)
+  // lanes run along the contiguous axis of the planes: columns for NCHW, rows when the planes are stored transposed
+  const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
+  const int gcol = cbase + scol;
+  const bool col_ok = gcol < d.W;
+  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW + (col_ok ? gcol * d.sw : 0);
+  int rowoff[NRB];  // global offset of the source row of each pass (rows wrap around the axis; H*W < 2^30)
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int r = rb * SROWS + srow;
+    rowoff[rb] = ((rbase + (r < WRP ? r : 0)) % d.H) * d.sh;
+  }
+  constexpr int CPH = CCH / NPH;  // channels per staging phase
+  float lv[PIPE ? CPH * NRB : 1];
+
+  auto issue = [&](int ch, int ph) {
+#pragma unroll
+    for (int cc = 0; cc < CPH; ++cc) {
+      const int chan = ch * CCH + ph * CPH + cc;
+      const float* xc = xg + (long long)(chan < d.Cig ? chan : 0) * HW;
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) lv[cc * NRB + rb] = xc[rowoff[rb]];
+    }
+  };
+  auto commit = [&](int ch, int ph, float* buf) {
+#pragma unroll
+    for (int cc = 0; cc < CPH; ++cc) {
+      const int c = ph * CPH + cc;
+      const bool ok = col_ok && (ch * CCH + c < d.Cig);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const int r = rb * SROWS + srow;
+        if (r < WRP) buf[c * CP + scol * WRP + r] = ok ? lv[cc * NRB + rb] : 0.f;
+      }
+    }
+  };
+  auto stage_now = [&](int ch, float* buf) {  // tall windows: plain loop, 4 loads in flight per thread
+    for (int r = srow; r < WRP; r += SROWS) {
+      const int ro = ((rbase + r) % d.H) * d.sh;
+#pragma unroll
+      for (int c4 = 0; c4 < CCH; c4 += 4) {
+        float t4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int chan = ch * CCH + c4 + c;
+          t4[c] = xg[(long long)(chan < d.Cig ? chan : 0) * HW + ro];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) buf[(c4 + c) * CP + scol * WRP + r] = (col_ok && ch * CCH + c4 + c < d.Cig) ? t4[c] : 0.f;
+      }
+    }
+  };
+
+  f32x16 acc[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  const float4* wpa = wp + ((long long)(g * d.MG + mg) * d.NCH) * KT * MTW * 64 + lane;
+  const int nsteps = d.NCH * KT;
+  float4 a_cur[MTW], a_nxt[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) a_cur[m] = wpa[m * 64];
+
+  // B operand of tap k for the 4 channel pairs of the chunk in `buf`: 4 LDS reads (load_raw) + 4 FMAs (combine, operand
+  // order of cu:111) each.  The two halves are separate so that the reads of the NEXT tap can be issued before the MFMAs of
+  // the current one and combined after them; the scheduling barriers keep the compiler from sinking the prefetches (weights
+  // from L2, window words from LDS) down to their first use, which would expose their latency on every tap.
+  auto load_raw = [&](const float* buf, int k, float (&raw)[16]) {
+    const float* p = buf + half * CP + roff[k];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float* q = p + 2 * s * CP;
+      raw[s * 4 + 0] = q[0];
+      raw[s * 4 + 1] = q[WRP];
+      raw[s * 4 + 2] = q[1];
+      raw[s * 4 + 3] = q[WRP + 1];
+    }
+  };
+  auto combine = [&](const float (&raw)[16], int k, float (&v)[4]) {
+    const float4 tw = rw[k];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = tw.x * raw[s * 4] + tw.y * raw[s * 4 + 1] + tw.z * raw[s * 4 + 2] + tw.w * raw[s * 4 + 3];
+  };
+
+  if (PIPE) {
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      issue(0, ph);
+      commit(0, ph, smem);
+    }
+    __syncthreads();
+  }
+  constexpr int TPP = KT / NPH;  // taps per staging phase (the last phase also takes the remainder)
+  for (int ch = 0; ch < d.NCH; ++ch) {
+    float* cur = smem + (PIPE ? (ch & 1) * bufsz : 0);
+    float* nxt = smem + (PIPE ? ((ch + 1) & 1) * bufsz : 0);
+    const bool more = ch + 1 < d.NCH;
+    if (!PIPE) {
+      if (ch > 0) __syncthreads();  // everyone is done reading the previous chunk
+      stage_now(ch, cur);
+      __syncthreads();
+    }
+    float vb[4], raw[16];
+    load_raw(cur, 0, raw);
+    combine(raw, 0, vb);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int step = ch * KT + k;
+      const int nstep = step + 1 < nsteps ? step + 1 : step;
+      if (PIPE && k % TPP == 0 && k / TPP < NPH && more) issue(ch + 1, k / TPP);  // rows of the next chunk fly under the MFMAs below
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) a_nxt[m] = wpa[((long long)nstep * MTW + m) * 64];
+      if (k + 1 < KT) load_raw(cur, k + 1, raw);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a0 = s == 0 ? a_cur[0].x : s == 1 ? a_cur[0].y : s == 2 ? a_cur[0].z : a_cur[0].w;
+        const float a1 = s == 0 ? a_cur[1].x : s == 1 ? a_cur[1].y : s == 2 ? a_cur[1].z : a_cur[1].w;
+        const float a2 = s == 0 ? a_cur[2].x : s == 1 ? a_cur[2].y : s == 2 ? a_cur[2].z : a_cur[2].w;
+        const float a3 = s == 0 ? a_cur[3].x : s == 1 ? a_cur[3].y : s == 2 ? a_cur[3].z : a_cur[3].w;
+        acc[0] = mfma32(a0, vb[s], acc[0]);
+        acc[1] = mfma32(a1, vb[s], acc[1]);
+        acc[2] = mfma32(a2, vb[s], acc[2]);
+        acc[3] = mfma32(a3, vb[s], acc[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < KT) combine(raw, k + 1, vb);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) a_cur[m] = a_nxt[m];
+      if (PIPE && more && (k == KT - 1 || (k % TPP == TPP - 1 && k / TPP < NPH - 1)))
+        commit(ch + 1, k == KT - 1 ? NPH - 1 : k / TPP, nxt);  // the other buffer: nobody reads it now
+    }
+    if (PIPE) __syncthreads();
+  }
+
+  if (pix_ok) {
+    float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)h * d.sh + (long long)w * d.sw;
+    const int cmax = d.Cog - mg * 128;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < cmax) yb[(long long)co * HW] = acc[m][r];
+      }
+  }
+}
+
+// grid = (tiles, B, G*MG); tiles[i] = (h0, w0, rbase, cbase | class << 16).  All window classes run in ONE launch so that
+// the few tall-window tiles next to the poles overlap with the rest instead of forming an under-filled tail of their own.
+__global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                                   const float4* __restrict__ wp, float* __restrict__ y, WinDims d,
+                                                                   const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int4 t = tiles[blockIdx.x];
+  const int cls = t.w >> 16, cbase = t.w & 0xffff;
+  if (cls == 0)
+    fwd_tile<WR_SMALL, true, (WR_SMALL + SROWS - 1) / SROWS, 1>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+  else if (cls == 1)
+    fwd_tile<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+  else
+    fwd_tile<0, true, WR_PIPE_MAX / SROWS, 4>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+}
+
+// Wrap-around tiles of images too tall for the double-buffered form (H + 1 > 320 rows, or more LDS than there is): single
+// buffer, staged in place.  A kernel of its own so that its register needs do not weigh on the main one.
+__global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_tall_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                                        const float4* __restrict__ wp, float* __restrict__ y,
+                                                                        WinDims d, const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int4 t = tiles[blockIdx.x];
+  fwd_tile<0, false, 1, 1>(x, pos, wp, y, d, t.x, t.y, t.z, t.w & 0xffff, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward w.r.t. the weight on the compact-window tiles:  gW[o][c][k] = sum_p gy[o][p] * col[c][k][p]
+//   D[i = o][j = c] per tap, K = the pixels of the tile; A = gy (LDS, [o][pixel]), B = col built on the fly from the x window
+//   of 32 input channels (LDS, [c][col][row], odd channel pitch: the 32 lanes of a half-wave read 32 channels).
+// Work item = half a plan tile (32 rows x 4 columns) of one sample, processed column by column (32 pixels = 16 k-steps).
+// grid = (S, ceil(Cig/32), G*MG); split-K slice s owns the items s, s+S, ...; 8 waves: wave v owns tap v for all 4 o-tiles,
+// tap 8 is shared: o-tile v&3, first (v < 4) or second half of every column's pixels.  Partial sums go to
+// part[s][z][cg][slot 0..9][128 o][32 c] (slots 8, 9 = the two halves of tap 8), summed in fixed order by reduce_gw_win.
+// The sampling records (window offset + 4 weights per tap and pixel) come from a table the host builds with the plan
+// (mode_sphere_plan_records): they depend on the table and the tile only, not on the sample, layer or channel group.
+// Everything the next column needs (gy, records; the x window before a new item) is fetched into registers before the MFMAs
+// of the current column and written to the other LDS buffer after them.
+constexpr int BW_CG = 32;
+constexpr int BW_TH = 32;                  // rows per work item
+constexpr int BW_WR = BW_TH + 17;          // its window rows (49)
+constexpr int BW_CP = WC * BW_WR + 1;      // odd channel pitch of the x window
+constexpr int BW_GP = BW_TH + 1;           // gy row pitch
+constexpr int BW_SLOTS = KT + 1;
+constexpr int BW_XW = BW_CG * BW_CP + BW_WR + 8;  // + slack: zero-weight corners may point just past the last window
+constexpr int BW_COLBUF = 128 * BW_GP;  // gy column
+constexpr int BW_LDS_FLOATS = BW_XW + 2 * BW_COLBUF;
+constexpr int BW_NXW = BW_CG;  // x-window words per thread: one per channel
+constexpr int BW_NREC = KT * BW_TH;                                      // records per column (288)
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                   float* __restrict__ part, WinDims d, const int4* __restrict__ tiles,
+                                                                   const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
+                                                                   int ntiles, int S) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xw = smem;  // [32][BW_CP]
+  constexpr int WRP = BW_WR;
+  const int s = blockIdx.x, cg = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, half = lane >> 5;
+  const long long HW = (long long)d.H * d.W;
+  const int T = ntiles * 2 * d.B;  // (sample, tile, half) items
+  const int NCG = gridDim.y;
+
+  f32x16 acc[MTW], acc8;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc8[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[m][r] = 0.f;
+  }
+  for (int i = tid; i < BW_LDS_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every word that may be read is finite
+
+  // prefetch registers
+  float pxw[BW_NXW];  // x window of the next item
+  float pgy[8];       // gy of the next column: o = (tid >> 5) + 16 u, pixel tid & 31
+
+  const int omax = d.Cog - mg * 128;
+  const int cmax = d.Cig - cg * BW_CG;
+  const int gpx = tid & (BW_TH - 1), go0 = tid >> 5;
+
+  auto item_geom = [&](int t, int& b, int& ti, int& hf) {
+    b = t / (ntiles * 2);
+    const int r = t - b * ntiles * 2;
+    ti = r >> 1;
+    hf = r & 1;
+  };
+  // x window: thread -> (column tid & 7, row tid >> 3 < 49), one word per channel; addresses are base + channel * stride
+  const int xcol = d.sh == 1 ? tid >> 6 : tid & (WC - 1), xrow = d.sh == 1 ? tid & 63 : tid >> 3;
+  const bool xrow_ok = xrow < WRP;
+  auto issue_xw = [&](int t) {
+    int b, ti, hf;
+    item_geom(t, b, ti, hf);
+    const int4 tl = tiles[ti];
+    const int rbase = (tl.z + hf * BW_TH) % d.H, cbase = tl.w & 0xffff;
+    const bool ok0 = xrow_ok && cbase + xcol < d.W;
+    const int grow = (rbase + (xrow_ok ? xrow : 0)) % d.H;
+    const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
+                      (ok0 ? (long long)grow * d.sh + (long long)(cbase + xcol) * d.sw : 0);
+#pragma unroll
+    for (int c = 0; c < BW_CG; ++c) {
+      const bool ok = ok0 && c < cmax;
+      const float v = xg[ok ? (long long)c * HW : 0];
+      pxw[c] = ok ? v : 0.f;
+    }
+  };
+  auto commit_xw = [&]() {
+    if (xrow_ok) {
+      float* dst = xw + xcol * WRP + xrow;
+#pragma unroll
+      for (int c = 0; c < BW_CG; ++c) dst[c * BW_CP] = pxw[c];
+    }
+  };
+  auto issue_col = [&](int t, int wc) {
+    int b, ti, hf;
+    item_geom(t, b, ti, hf);
+    const int4 tl = tiles[ti];
+    const int h = tl.x + hf * BW_TH + gpx, w = tl.y + wc;
+    const bool pok = h < d.H && w < d.W;
+    const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
+                       (pok ? (long long)h * d.sh + (long long)w * d.sw : 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int o = go0 + 16 * u;
+      const bool ok = pok && o < omax;
+      const float v = gyb[ok ? (long long)o * HW : 0];
+      pgy[u] = ok ? v : 0.f;
+    }
+  };
+  auto commit_col = [&](float* cb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cb[(go0 + 16 * u) * BW_GP + gpx] = pgy[u];
+  };
+
+  // first item: window and first column
+  issue_xw(s);
+  issue_col(s, 0);
+  __syncthreads();  // zero fill done
+  commit_xw();
+  commit_col(smem + BW_XW);
+  __syncthreads();
+
+  int buf = 0;
+  for (int t = s; t < T; t += S) {
+    const bool more_items = t + S < T;
+    for (int wc = 0; wc < TW; ++wc) {
+      const float* cb = smem + BW_XW + buf * BW_COLBUF;
+      const bool last_col = wc == TW - 1;
+      const bool have_next = !last_col || more_items;
+      if (have_next) issue_col(last_col ? t + S : t, last_col ? 0 : wc + 1);
+      if (last_col && more_items) issue_xw(t + S);
+
+      const float* ap = cb + j * BW_GP + half;
+      const float* xb = xw + j * BW_CP;
+      // The records of a k-step (two pixels: even for lanes 0-31, odd for lanes 32-63) are the same for every lane of a
+      // half-wave: they are fetched with scalar loads straight from the record table (wave-uniform addresses) and selected
+      // per half, so they cost no LDS traffic at all.
+      int bq, tiq, hfq;
+      item_geom(t, bq, tiq, hfq);
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      const long long rcol = (((long long)tiq * 2 + hfq) * TW + wc) * BW_NREC;
+      const float4* rw_own = rec_w + rcol + wave_u * BW_TH;
+      const int* ro_own = rec_off + rcol + wave_u * BW_TH;
+      const float4* rw_t8 = rec_w + rcol + 8 * BW_TH;
+      const int* ro_t8 = rec_off + rcol + 8 * BW_TH;
+      const int m8 = wave_u & 3;
+      const int q8lo = (wave_u >> 2) * (BW_TH / 4);  // this wave's k-steps of tap 8: [q8lo, q8lo + 8)
+
+      struct Rec {
+        float4 w;
+        int o;
+      };
+      auto load_rec = [&](const float4* rwp, const int* rop, int q) {
+        const float4 we = rwp[2 * q], wo = rwp[2 * q + 1];
+        const int oe = rop[2 * q], oo = rop[2 * q + 1];
+        Rec r;
+        r.w.x = half ? wo.x : we.x;
+        r.w.y = half ? wo.y : we.y;
+        r.w.z = half ? wo.z : we.z;
+        r.w.w = half ? wo.w : we.w;
+        r.o = half ? oo : oe;
+        return r;
+      };
+      auto load_x = [&](int o, float (&raw)[4]) {
+        const float* p = xb + o;
+        raw[0] = p[0];
+        raw[1] = p[WRP];
+        raw[2] = p[1];
+        raw[3] = p[WRP + 1];
+      };
+      auto load_a = [&](int q, float (&a)[4]) {
+        a[0] = ap[2 * q];
+        a[1] = ap[32 * BW_GP + 2 * q];
+        a[2] = ap[64 * BW_GP + 2 * q];
+        a[3] = ap[96 * BW_GP + 2 * q];
+      };
+      // software pipeline over the 16 k-steps: records two steps ahead (scalar), LDS operands one step ahead
+      Rec r_c = load_rec(rw_own, ro_own, 0), r_n = load_rec(rw_own, ro_own, 1);
+      Rec r8_c = load_rec(rw_t8, ro_t8, q8lo), r8_n = load_rec(rw_t8, ro_t8, q8lo + 1);
+      float raw_c[4], raw8_c[4], a_c[4];
+      load_x(r_c.o, raw_c);
+      load_a(0, a_c);
+      if (q8lo == 0) load_x(r8_c.o, raw8_c);
+#pragma unroll 4
+      for (int q = 0; q < BW_TH / 2; ++q) {
+        const bool do8 = q >= q8lo && q < q8lo + BW_TH / 4;         // tap 8 in this step
+        const bool nx8 = q + 1 >= q8lo && q + 1 < q8lo + BW_TH / 4;  // ... and in the next one
+        float raw_n[4], raw8_n[4], a_n[4];
+        Rec r_nn = r_n, r8_nn = r8_n;
+        if (q + 1 < BW_TH / 2) {
+          load_x(r_n.o, raw_n);
+          load_a(q + 1, a_n);
+          if (nx8) load_x(do8 ? r8_n.o : r8_c.o, raw8_n);
+        }
+        if (q + 2 < BW_TH / 2) r_nn = load_rec(rw_own, ro_own, q + 2);
+        if (do8 && q + 2 < q8lo + BW_TH / 4) r8_nn = load_rec(rw_t8, ro_t8, q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const float bv = r_c.w.x * raw_c[0] + r_c.w.y * raw_c[1] + r_c.w.z * raw_c[2] + r_c.w.w * raw_c[3];
+        acc[0] = mfma32(a_c[0], bv, acc[0]);
+        acc[1] = mfma32(a_c[1], bv, acc[1]);
+        acc[2] = mfma32(a_c[2], bv, acc[2]);
+        acc[3] = mfma32(a_c[3], bv, acc[3]);
+        if (do8) {
+          const float b8 = r8_c.w.x * raw8_c[0] + r8_c.w.y * raw8_c[1] + r8_c.w.z * raw8_c[2] + r8_c.w.w * raw8_c[3];
+          const float a8 = m8 == 0 ? a_c[0] : m8 == 1 ? a_c[1] : m8 == 2 ? a_c[2] : a_c[3];
+          acc8 = mfma32(a8, b8, acc8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        r_c = r_n;
+        r_n = r_nn;
+        if (do8) {
+          r8_c = r8_n;
+          r8_n = r8_nn;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          raw_c[i] = raw_n[i];
+          raw8_c[i] = raw8_n[i];
+          a_c[i] = a_n[i];
+        }
+      }
+
+      if (have_next) commit_col(smem + BW_XW + (buf ^ 1) * BW_COLBUF);  // the other buffer: nobody reads it now
+      if (last_col && more_items) {
+        __syncthreads();  // everyone is done with the x window of this item
+        commit_xw();
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      pb[((long long)wave * 128 + o) * BW_CG + j] = acc[m][r];
+    }
+  {
+    const int slot = 8 + (wave >> 2), m = wave & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      pb[((long long)slot * 128 + o) * BW_CG + j] = acc8[r];
+    }
+  }
+}
+
+// gw[o][c][k] += sum over slices (fixed order) of slot k (+ slot 9 for tap 8); one thread per (z, cg, k, o, c), c fastest:
+// coalesced reads of the partials
+__global__ void reduce_gw_win(const float* __restrict__ part, float* __restrict__ gw, WinDims d, int S, int NCG) {
+  const int GZ = d.G * d.MG;
+  const long long total = (long long)GZ * NCG * KT * 128 * BW_CG;
+  const long long stride = (long long)GZ * NCG * BW_SLOTS * 128 * BW_CG;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int cl = (int)(idx % BW_CG);
+    long long r = idx / BW_CG;
+    const int row = (int)(r % 128);
+    r /= 128;
+    const int k = (int)(r % KT);
+    r /= KT;
+    const int cg = (int)(r % NCG);
+    const int z = (int)(r / NCG);
+    const int g = z / d.MG, mg = z % d.MG;
+    const int ol = mg * 128 + row, c = cg * BW_CG + cl;
+    if (ol >= d.Cog || c >= d.Cig) continue;
+    const float* pp = part + ((((long long)z * NCG + cg) * BW_SLOTS + k) * 128 + row) * BW_CG + cl;
+    float sum = 0.f;  // fixed order: slice by slice, slot 8 before slot 9
+    const long long second = k == KT - 1 ? 128 * BW_CG : 0;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+      float v[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = s0 + u < S;
+        v[u] = ok ? pp[(s0 + u) * stride] : 0.f;
+        v2[u] = ok && second ? pp[(s0 + u) * stride + second] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u] + v2[u];
+    }
+    gw[((long long)(g * d.Cog + ol) * d.Cig + c) * KT + k] += sum;
+  }
+}
+
+// Class 0 also promises the weight-gradient kernel that each 32-row half of the tile fits a 49-row window starting at
+// rbase (+32 for the second half): true for shift-invariant tables, checked for all.
+bool halves_fit(const float* pos_host, int H, int W, int KK, int h0, int w0, int rbase, int cbase) {
+  const long long HW = (long long)H * W;
+  for (int hf = 0; hf < 2; ++hf) {
+    const int rb = (rbase + hf * BW_TH) % H;
+    for (int k = 0; k < KK; ++k)
+      for (int h = h0 + hf * BW_TH; h < std::min(h0 + (hf + 1) * BW_TH, H); ++h)
+        for (int w = w0; w < std::min(w0 + TW, W); ++w) {
+          int r0, c0;
+          float4 wt;
+          const long long idx = (long long)h * W + w;
+          if (!mode::tap_record_fixed(pos_host[(2 * k) * HW + idx], pos_host[(2 * k + 1) * HW + idx], H, W, r0, c0, wt)) continue;
+          if (wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f) continue;
+          const int lr = ((r0 - rb) % H + H) % H;
+          if (lr + 1 >= BW_WR || c0 - cbase < 0 || c0 - cbase + 1 >= WC) return false;
+        }
+  }
+  return true;
+}
+
+int bww_win_splits(const WinDims& d, int ntiles) {
+  const int T = ntiles * 2 * d.B;
+  const int wgs_per_slice = mode::cdiv(d.Cig, BW_CG) * d.G * d.MG;
+  const int per = std::max(1, mode::cdiv((long long)T * wgs_per_slice, kNumCU));  // items per workgroup for ~one workgroup per CU
+  return std::max(1, mode::cdiv(T, per));
+}
+
+size_t win_lds_bytes(int wr, bool pipe) { return ((size_t)(pipe ? 2 : 1) * CCH * chan_pitch(wr) + wr + 8) * sizeof(float); }
+bool wrap_is_pipelined(int H) { return H + 1 <= WR_PIPE_MAX && win_lds_bytes(H + 1, true) <= 160 * 1024; }
+
+// out[p][w][h] = in[p][h][w] for P planes of H x W: 32x32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+  __shared__ float tile[32][33];
+  const long long plane = (long long)blockIdx.z * H * W;
+  const int w0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int h = h0 + ty + i, w = w0 + tx;
+    if (h < H && w < W) tile[ty + i][tx] = in[plane + (long long)h * W + w];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int w = w0 + ty + i, h = h0 + tx;
+    if (h < H && w < W) out[plane + (long long)w * H + h] = tile[tx][ty + i];
+  }
+}
+
+int make_win_dims(WinDims& d, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const char* who) {
+  MODE_REQUIRE(B >= 0 && Ci > 0 && H > 0 && W > 0 && Co > 0 && groups > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(Kh * Kw == KT, MODE_ERR_UNSUPPORTED, "%s: the windowed kernels are built for %d taps (got %dx%d)", who, KT, Kh, Kw);
+  MODE_REQUIRE(Ci % groups == 0 && Co % groups == 0, MODE_ERR_BAD_ARG, "%s: channels not divisible by groups", who);
+  MODE_REQUIRE((long long)H * W < (1LL << 30), MODE_ERR_UNSUPPORTED, "%s: image too large", who);
+  d.B = B; d.Ci = Ci; d.H = H; d.W = W; d.Co = Co; d.G = groups;
+  d.Cig = Ci / groups;
+  d.Cog = Co / groups;
+  d.NCH = mode::cdiv(d.Cig, CCH);
+  d.MG = mode::cdiv(d.Cog, 128);
+  d.wr = H + 1;
+  d.sh = W;
+  d.sw = 1;
+  d.wrap_pipe = wrap_is_pipelined(H) ? 1 : 0;
+  d.accumulate = 0;
+  return MODE_OK;
+}
+
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-side tile plan.  tiles_host[4*i .. 4*i+3] = (h0, w0, rbase, cbase) ordered by class; counts[c] = tiles of class c:
+//   0: window of 81 rows   1: 145 rows   2: all H rows + 1 (wraps around)   3: does not fit (caller must use the general path)
+// and the class is also stored in bits 16.. of the 4th word (cbase | class << 16).
+// Inside a class the tiles are ordered so that, with the round-robin workgroup -> XCD assignment, the tiles that share rows of
+// the output (and cache lines of the input window) run on the same XCD and meet in its L2.
+extern "C" size_t mode_sphere_plan_max_tiles(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  return (size_t)mode::cdiv(H, TH) * mode::cdiv(W, TW);
+}
+
+extern "C" int mode_sphere_plan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* tiles_host, int32_t* counts) {
+  MODE_REQUIRE(pos_host && tiles_host && counts, MODE_ERR_BAD_ARG, "mode_sphere_plan_build: null pointer");
+  MODE_REQUIRE(H > 0 && W > 0 && Kh > 0 && Kw > 0, MODE_ERR_BAD_ARG, "mode_sphere_plan_build: non-positive size");
+  const int KK = Kh * Kw;
+  const long long HW = (long long)H * W;
+  const int nth = mode::cdiv(H, TH), ntw = mode::cdiv(W, TW);
+  std::vector<int32_t> cls[4];
+  // order: groups of 8 row-blocks; inside a group all column blocks; inside a column block the 8 row-blocks -> index % 8
+  // (the XCD) is the row-block, for every column block
+  for (int hg = 0; hg < nth; hg += kNumXCD)
+    for (int tw = 0; tw < ntw; ++tw)
+      for (int hs = 0; hs < kNumXCD && hg + hs < nth; ++hs) {
+        const int h0 = (hg + hs) * TH, w0 = tw * TW;
+        int dmin = 1 << 30, dmax = -(1 << 30), cmin = 1 << 30, cmax = -(1 << 30);
+        bool any = false;
+        for (int k = 0; k < KK; ++k)
+          for (int h = h0; h < std::min(h0 + TH, H); ++h)
+            for (int w = w0; w < std::min(w0 + TW, W); ++w) {
+              int r0, c0;
+              float4 wt;
+              const long long idx = (long long)h * W + w;
+              if (!mode::tap_record_fixed(pos_host[(2 * k) * HW + idx], pos_host[(2 * k + 1) * HW + idx], H, W, r0, c0, wt)) continue;
+              if (wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f) continue;
+              int dr = r0 - h0;  // wrapped into (-H/2, H/2]
+              dr %= H;
+              if (dr > H / 2) dr -= H;
+              if (dr <= -(H + 1) / 2) dr += H;
+              dmin = std::min(dmin, dr);
+              dmax = std::max(dmax, dr);
+              cmin = std::min(cmin, c0);
+              cmax = std::max(cmax, c0);
+              any = true;
+            }
+        int c = 0, rbase = h0, cbase = std::min(w0, std::max(W - WC, 0));
+        if (any) {
+          const int rows = dmax - dmin + 2;  // + the second corner row
+          const int cols = cmax - cmin + 2;
+          cbase = cmin;
+          rbase = ((h0 + dmin) % H + H) % H;
+          if (cols > WC) {
+            c = 3;
+          } else if (rows <= WR_SMALL && halves_fit(pos_host, H, W, KK, h0, w0, rbase, cbase)) {
+            c = 0;
+          } else if (rows <= WR_MID) {
+            c = 1;
+          } else {
+            c = 2;  // whole axis: any start works, take 0 so that no row index wraps twice
+            rbase = 0;
+            if (win_lds_bytes(H + 1, false) > 160 * 1024) c = 3;
+          }
+        }
+        if (cbase >= (1 << 16)) c = 3;
+        cls[c].insert(cls[c].end(), {h0, w0, rbase, cbase | (c << 16)});
+      }
+  size_t o = 0;
+  for (int c = 0; c < 4; ++c) counts[c] = (int32_t)(cls[c].size() / 4);
+  for (int c : {2, 1, 0, 3}) {  // tall windows first: they are the slowest tiles of the launch
+    if (!cls[c].empty()) std::memcpy(tiles_host + o, cls[c].data(), cls[c].size() * sizeof(int32_t));
+    o += cls[c].size();
+  }
+  return MODE_OK;
+}
+
+extern "C" size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups) {
+  if (Ci <= 0 || Co <= 0 || groups <= 0 || Kh * Kw != KT || Ci % groups || Co % groups) return 0;
+  const int Cig = Ci / groups, Cog = Co / groups;
+  return (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 * sizeof(float);
+}
+
+extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, float* y, float* wpack,
+                                        const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co,
+                                        int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  WinDims d;
+  int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_fwd_win");
+  if (rc != MODE_OK) return rc;
+  if (transposed) {
+    d.sh = 1;
+    d.sw = H;
+  }
+  MODE_REQUIRE(n_small >= 0 && n_mid >= 0 && n_wrap >= 0 && (size_t)n_small + n_mid + n_wrap == mode_sphere_plan_max_tiles(H, W),
+               MODE_ERR_BAD_ARG, "mode_sphere_conv_fwd_win: the plan must cover every tile (%d + %d + %d given, %zu tiles)", n_small, n_mid,
+               n_wrap, mode_sphere_plan_max_tiles(H, W));
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(x && pos && w && y && wpack && tiles, MODE_ERR_BAD_ARG, "mode_sphere_conv_fwd_win: null pointer");
+  MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "mode_sphere_conv_fwd_win: grid limit");
+  hipStream_t st = mode::as_stream(stream);
+  const long long npack = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
+  hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  // tile list order: wrap-around tiles, then mid, then small
+  const float4* wp4 = reinterpret_cast<const float4*>(wpack);
+  const int4* tl = reinterpret_cast<const int4*>(tiles);
+  int n_main = n_small + n_mid + n_wrap;
+  if (n_wrap > 0 && !d.wrap_pipe) {
+    const size_t lds = win_lds_bytes(d.wr, false);
+    rc = mode::allow_lds(sphere_fwd_win_tall_kernel, lds, "mode_sphere_conv_fwd_win");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_fwd_win_tall_kernel, dim3(n_wrap, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl);
+    tl += n_wrap;
+    n_main -= n_wrap;
+    n_wrap = 0;
+  }
+  if (n_main > 0) {
+    size_t lds = 0;
+    if (n_small > 0) lds = std::max(lds, win_lds_bytes(WR_SMALL, true));
+    if (n_mid > 0) lds = std::max(lds, win_lds_bytes(WR_MID, true));
+    if (n_wrap > 0) lds = std::max(lds, win_lds_bytes(d.wr, true));
+    rc = mode::allow_lds(sphere_fwd_win_kernel, lds, "mode_sphere_conv_fwd_win");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_fwd_win_kernel, dim3(n_main, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl);
+  }
+  return mode::check_launch("mode_sphere_conv_fwd_win");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pixels of the tiles that are NOT of the small-window class, sorted by linear index (they go to the general kernels).
+extern "C" int mode_sphere_plan_rest_pixels(const int32_t* tiles_host, const int32_t* counts, int H, int W, int32_t* pix_host,
+                                            int32_t* n_pix) {
+  MODE_REQUIRE(tiles_host && counts && pix_host && n_pix, MODE_ERR_BAD_ARG, "mode_sphere_plan_rest_pixels: null pointer");
+  const int n = counts[0] + counts[1] + counts[2] + counts[3];
+  std::vector<int32_t> v;
+  for (int i = 0; i < n; ++i) {
+    const int32_t* t = tiles_host + 4 * i;
+    if ((t[3] >> 16) == 0) continue;
+    for (int h = t[0]; h < std::min(t[0] + TH, H); ++h)
+      for (int w = t[1]; w < std::min(t[1] + TW, W); ++w) v.push_back(h * W + w);
+  }
+  std::sort(v.begin(), v.end());
+  if (!v.empty()) std::memcpy(pix_host, v.data(), v.size() * sizeof(int32_t));
+  *n_pix = (int32_t)v.size();
+  return MODE_OK;
+}
+
+// Sampling records of the small-window tiles for the weight-gradient kernel, in tile-list order:
+//   index (((ti*2 + half)*4 + column)*9 + tap)*32 + row -> window offset (rec_off) and the 4 corner weights (rec_w, 4 floats)
+extern "C" size_t mode_sphere_plan_records_count(int n_small) { return n_small > 0 ? (size_t)n_small * 2 * TW * BW_NREC : 0; }
+
+extern "C" int mode_sphere_plan_records(const float* pos_host, const int32_t* tiles_host, const int32_t* counts, int H, int W,
+                                        float* rec_w_host, int32_t* rec_off_host) {
+  MODE_REQUIRE(pos_host && tiles_host && counts && rec_w_host && rec_off_host, MODE_ERR_BAD_ARG, "mode_sphere_plan_records: null pointer");
+  const long long HW = (long long)H * W;
+  const int32_t* small = tiles_host + 4 * (size_t)(counts[2] + counts[1]);  // list order: wrap-around, mid, small
+  for (int ti = 0; ti < counts[0]; ++ti) {
+    const int h0 = small[4 * ti], w0 = small[4 * ti + 1], rbase = small[4 * ti + 2], cbase = small[4 * ti + 3] & 0xffff;
+    for (int hf = 0; hf < 2; ++hf) {
+      const int rb = (rbase + hf * BW_TH) % H;
+      for (int wc = 0; wc < TW; ++wc)
+        for (int k = 0; k < KT; ++k)
+          for (int px = 0; px < BW_TH; ++px) {
+            const size_t o = ((((size_t)ti * 2 + hf) * TW + wc) * KT + k) * BW_TH + px;
+            const int h = h0 + hf * BW_TH + px, w = w0 + wc;
+            int r0 = 0, c0 = 0;
+            float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool live = false;
+            if (h < H && w < W) {
+              const long long idx = (long long)h * W + w;
+              live = mode::tap_record_fixed(pos_host[(2 * k) * HW + idx], pos_host[(2 * k + 1) * HW + idx], H, W, r0, c0, wt);
+            }
+            live = live && !(wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f);
+            rec_off_host[o] = live ? (c0 - cbase) * BW_WR + ((r0 - rb) % H + H) % H : 0;
+            rec_w_host[4 * o + 0] = live ? wt.x : 0.f;
+            rec_w_host[4 * o + 1] = live ? wt.y : 0.f;
+            rec_w_host[4 * o + 2] = live ? wt.z : 0.f;
+            rec_w_host[4 * o + 3] = live ? wt.w : 0.f;
+          }
+    }
+  }
+  return MODE_OK;
+}
+
+extern "C" size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                                                  int n_small, int n_rest_pixels) {
+  WinDims d;
+  if (make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win_workspace_bytes") != MODE_OK) return 0;
+  const size_t win = (size_t)bww_win_splits(d, std::max(n_small, 1)) * d.G * d.MG * mode::cdiv(d.Cig, BW_CG) * BW_SLOTS * 128 * BW_CG *
+                     sizeof(float);
+  return win + mode::sphere_bwd_weight_general_workspace(B, Ci, Co, Kh, Kw, H, W, groups, std::max(n_rest_pixels, 1));
+}
+
+// Weight gradient, ADDED to gw like mode_sphere_conv_bwd_weight: windowed kernel on the n_small compact tiles of the plan
+// (tile list order: wrap-around, mid, small), general kernels on the n_rest_pixels pixels of the other tiles.
+extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                               const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
+                                               const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, int B, int Ci,
+                                               int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
+                                               mode_stream_t stream) {
+  WinDims d;
+  int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win");
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE((gy_t == nullptr) == (x_t == nullptr), MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: gy_t and x_t come together");
+  if (gy_t) {
+    d.sh = 1;
+    d.sw = H;
+  }
+  MODE_REQUIRE(n_small >= 0 && n_mid >= 0 && n_wrap >= 0 && n_rest_pixels >= 0 &&
+                   (size_t)n_small + n_mid + n_wrap == mode_sphere_plan_max_tiles(H, W),
+               MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: the plan must cover every tile");
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(gy && pos && x && gw && workspace && tiles && (n_rest_pixels == 0 || rest_pixels) && (n_small == 0 || (rec_w && rec_off)),
+               MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: null pointer");
+  hipStream_t st = mode::as_stream(stream);
+  size_t win_bytes = 0;
+  if (n_small > 0) {
+    const int NCG = mode::cdiv(d.Cig, BW_CG);
+    const int S = bww_win_splits(d, n_small);
+    win_bytes = (size_t)S * d.G * d.MG * NCG * BW_SLOTS * 128 * BW_CG * sizeof(float);
+    const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
+    rc = mode::allow_lds(sphere_bww_win_kernel, lds, "mode_sphere_conv_bwd_weight_win");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_bww_win_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gy_t ? gy_t : gy, x_t ? x_t : x, workspace, d,
+                       reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
+    rc = mode::check_launch("mode_sphere_conv_bwd_weight_win");
+    if (rc != MODE_OK) return rc;
+    const long long n = (long long)d.G * d.MG * NCG * KT * 128 * BW_CG;
+    hipLaunchKernelGGL(reduce_gw_win, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, NCG);
+    rc = mode::check_launch("mode_sphere_conv_bwd_weight_win(reduce)");
+    if (rc != MODE_OK) return rc;
+  }
+  if (n_rest_pixels > 0)
+    return mode::sphere_bwd_weight_general(gy, pos, x, gw, reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + win_bytes), B, Ci,
+                                           H, W, Co, Kh, Kw, 1, 1, H, W, groups, rest_pixels, n_rest_pixels, st,
+                                           "mode_sphere_conv_bwd_weight_win(rest)");
+  return MODE_OK;
+}
+
+// out (P, W, H) = in (P, H, W) transposed plane by plane (P = B*C).  The windowed kernels run with every access coalesced when
+// the planes are stored with the shift-invariant (longitude) axis contiguous, which for the Cassini layout is the transpose.
+extern "C" int mode_transpose_planes(const float* in, float* out, long long planes, int H, int W, mode_stream_t stream) {
+  MODE_REQUIRE(planes >= 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "mode_transpose_planes: bad size");
+  if (planes == 0) return MODE_OK;
+  MODE_REQUIRE(in && out, MODE_ERR_BAD_ARG, "mode_transpose_planes: null pointer");
+  hipStream_t st = mode::as_stream(stream);
+  for (long long p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)std::min<long long>(65535, planes - p0);
+    hipLaunchKernelGGL(transpose_planes_kernel, dim3(mode::cdiv(W, 32), mode::cdiv(H, 32), np), dim3(256), 0, st,
+                       in + p0 * (long long)H * W, out + p0 * (long long)H * W, H, W);
+  }
+  return mode::check_launch("mode_transpose_planes");
+}

@@ -26,7 +26,17 @@ SIGNATURES = {
     'mode_sphere_conv_bwd_data': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_adjoint_max_entries': (_c_size, [_c_int] * 4),
     'mode_sphere_adjoint_build': (_c_int, [_c_ptr] + [_c_int] * 8 + [_c_ptr] * 3),
-    'mode_sphere_conv_bwd_data_adj': (_c_int, [_c_ptr] * 6 + [_c_int] * 10 + [_c_ptr]),
+    'mode_sphere_conv_bwd_data_adj': (_c_int, [_c_ptr] * 6 + [_c_int] * 11 + [_c_ptr]),
+    'mode_sphere_plan_max_tiles': (_c_size, [_c_int] * 2),
+    'mode_sphere_plan_build': (_c_int, [_c_ptr] + [_c_int] * 4 + [_c_ptr] * 2),
+    'mode_sphere_conv_win_wpack_bytes': (_c_size, [_c_int] * 5),
+    'mode_sphere_conv_fwd_win': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),
+    'mode_transpose_planes': (_c_int, [_c_ptr] * 2 + [ctypes.c_longlong] + [_c_int] * 2 + [_c_ptr]),
+    'mode_sphere_plan_rest_pixels': (_c_int, [_c_ptr] * 2 + [_c_int] * 2 + [_c_ptr] * 2),
+    'mode_sphere_conv_bwd_weight_win_workspace_bytes': (_c_size, [_c_int] * 10),
+    'mode_sphere_plan_records_count': (_c_size, [_c_int]),
+    'mode_sphere_plan_records': (_c_int, [_c_ptr] * 3 + [_c_int] * 2 + [_c_ptr] * 2),
+    'mode_sphere_conv_bwd_weight_win': (_c_int, [_c_ptr] * 6 + [_c_int] * 3 + [_c_ptr] * 3 + [_c_int] * 9 + [_c_ptr] * 3),
     'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
@@ -41,12 +51,14 @@ SIGNATURES = {
     'mode_head_bwd_workspace_bytes': (_c_size, [_c_int] * 4),
     'mode_head_bwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_bn_workspace_bytes': (_c_size, [_c_int]),
-    'mode_bn_train_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 4 + [_c_int] * 2 +
+    'mode_bn_train_fwd': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 4 + [_c_int] * 2 +
                           [ctypes.c_longlong, _c_ptr]),
-    'mode_bn_eval_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float, _c_int] + [_c_ptr] * 2 + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
-    'mode_bn_train_bwd': (_c_int, [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 5 + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
+    'mode_bn_eval_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float, _c_int] + [_c_ptr] + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
+    'mode_bn_train_bwd': (_c_int, [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] + [_c_int] * 2 +
+                          [ctypes.c_longlong, _c_ptr]),
 }
 
+ABI_VERSION = 2  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 
@@ -65,6 +77,10 @@ def lib():
           fn = getattr(handle, name)
           fn.restype = res
           fn.argtypes = args
+        have = handle.mode_hip_abi_version()
+        if have != ABI_VERSION:
+          raise RuntimeError('libmode_hip.so has ABI version %d, this binding needs %d: rebuild it (python '
+                             'mode-2022_amd/mode_hip/build.py)' % (have, ABI_VERSION))
         _lib = handle
   return _lib
 

@@ -17,8 +17,12 @@ import torch.distributed as dist
 
 class GradAllReducer(object):
 
-  def __init__(self, module, process_group=None):
+  def __init__(self, module, process_group=None, fuse_accumulation=True):
+    """fuse_accumulation: let the native backward kernels add parameter gradients straight into the flat buffer
+    (functional.grad_sink) instead of handing them to autograd's per-parameter accumulation kernels.  Needs zero_grad()
+    of THIS object before every backward (optimizer.zero_grad(set_to_none=True) would detach the views; see rebind())."""
     self.group = process_group
+    self.fuse_accumulation = fuse_accumulation
     self.params = [p for p in module.parameters() if p.requires_grad]
     n = sum(p.numel() for p in self.params)
     ref = self.params[0]
@@ -26,6 +30,8 @@ class GradAllReducer(object):
     off = 0
     for p in self.params:
       p.grad = self.flat[off:off + p.numel()].view_as(p)
+      if fuse_accumulation:
+        p._mode_grad_sink = p.grad
       off += p.numel()
     self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
 
@@ -45,7 +51,15 @@ class GradAllReducer(object):
     for p in self.params:
       if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
         p.grad = self.flat[off:off + p.numel()].view_as(p)
+      if self.fuse_accumulation:
+        p._mode_grad_sink = p.grad
       off += p.numel()
+
+  def detach(self):
+    """Give the parameters back to plain autograd accumulation."""
+    for p in self.params:
+      if hasattr(p, '_mode_grad_sink'):
+        del p._mode_grad_sink
 
   def all_reduce(self):
     """SUM over ranks (see module docstring for why not the mean)."""
@@ -53,9 +67,18 @@ class GradAllReducer(object):
       dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def global_masked_mean(per_pixel, mask, group=None):
-  """sum(per_pixel[mask]) / (number of valid pixels over ALL ranks); differentiable w.r.t. per_pixel."""
+def global_valid_count(mask, group=None):
+  """Number of valid pixels over ALL ranks as a 0-d fp32 device tensor (one small all-reduce when world > 1)."""
   count = mask.sum().to(torch.float32)
   if dist.is_initialized() and dist.get_world_size(group) > 1:
     dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
-  return torch.where(mask, per_pixel, torch.zeros((), dtype=per_pixel.dtype, device=per_pixel.device)).sum() / count.clamp(min=1)
+  return count.clamp(min=1)
+
+
+def global_masked_mean(per_pixel, mask, group=None, count=None):
+  """sum(per_pixel[mask]) / (number of valid pixels over ALL ranks); differentiable w.r.t. per_pixel.  Pass ``count``
+  (from global_valid_count, computed once per batch) to keep the collective out of the step -- required when the step is
+  captured into a hipGraph."""
+  if count is None:
+    count = global_valid_count(mask, group)
+  return torch.where(mask, per_pixel, torch.zeros((), dtype=per_pixel.dtype, device=per_pixel.device)).sum() / count

@@ -85,6 +85,57 @@ def _check_pos(pos, x, Kh, Kw):
                        (x.shape[2], x.shape[3], pos.shape[2], pos.shape[3]))
 
 
+_plan_cache = {}
+_plan_lock = threading.Lock()
+SPHERE_LAYOUT = os.environ.get('MODE_SPHERE_LAYOUT', 'transposed')  # windowed kernels on plane-transposed copies | 'nchw'
+SPHERE_FWD = os.environ.get('MODE_SPHERE_FWD', 'window')  # 'window' (LDS-window kernels where the table allows) | 'gather'
+
+
+def transpose_planes(t, out=None):
+  """(B, C, H, W) -> (B, C, W, H) contiguous (or the inverse into `out`, whose last two sizes are swapped)."""
+  require_gpu(t)
+  require_f32c(t)
+  B, C, H, W = t.shape
+  if out is None:
+    out = torch.empty((B, C, W, H), dtype=t.dtype, device=t.device)
+  with torch.cuda.device_of(t):
+    check(lib().mode_transpose_planes(ptr(t), ptr(out), B * C, H, W, stream_of(t)), 'mode_transpose_planes')
+  return out
+
+
+def sphere_plan(pos, kh, kw):
+  """Tile plan of the windowed kernels for the sampling table `pos`: (tiles int32 device tensor, (n_small, n_mid, n_wrap),
+  pixels of the non-small tiles int32 device tensor, their number, record weights, record offsets) or None when the table is not spatially compact (the
+  general gather kernels are used then).  Built on the host by
+  mode_sphere_plan_build once per (table, device) and cached, like the adjoint table."""
+  key = (pos.data_ptr(), pos._version, tuple(pos.shape), kh, kw, str(pos.device))
+  with _plan_lock:
+    if key in _plan_cache:
+      return _plan_cache[key][0]
+    H, W = pos.shape[2:]
+    host = pos.detach().to('cpu', torch.float32).contiguous()
+    n = lib().mode_sphere_plan_max_tiles(H, W)
+    tiles = torch.empty(4 * n, dtype=torch.int32)
+    counts = torch.zeros(4, dtype=torch.int32)
+    check(lib().mode_sphere_plan_build(ptr(host), H, W, kh, kw, ptr(tiles), ptr(counts)), 'mode_sphere_plan_build')
+    c = [int(v) for v in counts]
+    plan = None
+    if not c[3]:
+      rest = torch.empty(H * W, dtype=torch.int32)
+      nrest = torch.zeros(1, dtype=torch.int32)
+      check(lib().mode_sphere_plan_rest_pixels(ptr(tiles), ptr(counts), H, W, ptr(rest), ptr(nrest)), 'mode_sphere_plan_rest_pixels')
+      nrest = int(nrest)
+      nrec = max(lib().mode_sphere_plan_records_count(c[0]), 1)
+      rec_w = torch.zeros(4 * nrec, dtype=torch.float32)
+      rec_off = torch.zeros(nrec, dtype=torch.int32)
+      if c[0]:
+        check(lib().mode_sphere_plan_records(ptr(host), ptr(tiles), ptr(counts), H, W, ptr(rec_w), ptr(rec_off)), 'mode_sphere_plan_records')
+      plan = (tiles.to(pos.device), (c[0], c[1], c[2]), rest[:max(nrest, 1)].contiguous().to(pos.device), nrest, rec_w.to(pos.device),
+              rec_off.to(pos.device))
+    _plan_cache[key] = (plan, pos)  # keep `pos` alive: the key uses its address
+    return plan
+
+
 def sphere_conv_fwd(x, pos, w, out, stride, groups):
   """Writes `out` (B,Co,Ho,Wo) in place.  Replaces sphere_conv_forward_cuda (sphere_conv_cuda.cpp:129-210)."""
   require_gpu(x, pos, w, out)
@@ -93,9 +144,25 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
   dims = _sc_dims(x.shape, w.shape, out.shape[2:], stride, groups)
   flops = 2 * out.numel() * w[0].numel()
   nbytes = 4 * (x.numel() + out.numel() + pos.numel() + w.numel())
+  plan = None
+  if SPHERE_FWD == 'window' and tuple(stride) == (1, 1) and w.shape[2] * w.shape[3] == 9 and tuple(out.shape[2:]) == tuple(x.shape[2:]):
+    plan = sphere_plan(pos, w.shape[2], w.shape[3])
   with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
-    wp = _wpack(w, groups)
-    check(lib().mode_sphere_conv_fwd(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), *dims, stream_of(x)), 'mode_sphere_conv_fwd')
+    if plan is not None:
+      B, Ci, H, W, Co, Kh, Kw = dims[:7]
+      tiles, (n0, n1, n2) = plan[:2]
+      wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+      if SPHERE_LAYOUT == 'transposed':
+        xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
+        check(lib().mode_sphere_conv_fwd_win(ptr(xt), ptr(pos), ptr(w), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
+                                             Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win')
+        transpose_planes(yt, out)
+      else:
+        check(lib().mode_sphere_conv_fwd_win(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
+                                             Kw, groups, 0, stream_of(x)), 'mode_sphere_conv_fwd_win')
+    else:
+      wp = _wpack(w, groups)
+      check(lib().mode_sphere_conv_fwd(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), *dims, stream_of(x)), 'mode_sphere_conv_fwd')
   return out
 
 
@@ -126,8 +193,9 @@ def sphere_adjoint(pos, kh, kw, stride, out_hw):
     return hit
 
 
-def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups):
-  """Accumulates into `gx` (B,Ci,H,W) (caller zero-fills, sphere_conv.py:62)."""
+def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False):
+  """Accumulates into `gx` (B,Ci,H,W) (caller zero-fills, sphere_conv.py:62); with overwrite=True `gx` may hold anything and
+  is overwritten."""
   require_gpu(gy, pos, w, gx)
   require_f32c(gy, pos, w, gx)
   dims = _sc_dims(gx.shape, w.shape, gy.shape[2:], stride, groups)
@@ -139,13 +207,18 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups):
     with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
       wp = _wpack(w, groups)
       check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
-                                                Kw, Ho, Wo, G, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
+                                                Kw, Ho, Wo, G, 0 if overwrite else 1, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
     return gx
+  if overwrite:
+    gx.zero_()  # the scatter form adds with atomics
   with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
     wp = _wpack(w, groups)
     check(lib().mode_sphere_conv_bwd_data(ptr(gy), ptr(pos), ptr(w), ptr(gx), ptr(wp), *dims, stream_of(gy)),
           'mode_sphere_conv_bwd_data')
   return gx
+
+
+SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'gather')  # 'gather' | 'window' (not faster yet: DESIGN.md)
 
 
 def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
@@ -156,12 +229,44 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
   B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
   flops = 2 * gy.numel() * gw[0].numel()
   nbytes = 4 * (x.numel() + gy.numel() + pos.numel() + gw.numel())
+  plan = None
+  if SPHERE_BWD_WEIGHT == 'window' and (sH, sW) == (1, 1) and Kh * Kw == 9 and (Ho, Wo) == (H, W):
+    plan = sphere_plan(pos, Kh, Kw)
+    if plan is not None and plan[1][0] == 0:
+      plan = None  # no compact tile at all: nothing to gain
   with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_weight', gw, x), nbytes, flops, gy.device):
-    n = lib().mode_sphere_conv_bwd_weight_workspace_bytes(B, Ci, Co, Kh, Kw, Ho, Wo, G)
-    ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-    check(lib().mode_sphere_conv_bwd_weight(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), *dims, stream_of(gy)),
-          'mode_sphere_conv_bwd_weight')
+    if plan is not None:
+      tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off = plan
+      n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, G, n0, nrest)
+      ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
+      gyt, xt = (transpose_planes(gy), transpose_planes(x)) if SPHERE_LAYOUT == 'transposed' else (None, None)
+      check(lib().mode_sphere_conv_bwd_weight_win(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
+                                                  ptr(rec_off), ptr(rest), nrest, B, Ci, H, W, Co, Kh, Kw, G,
+                                                  ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,
+                                                  stream_of(gy)), 'mode_sphere_conv_bwd_weight_win')
+    else:
+      n = lib().mode_sphere_conv_bwd_weight_workspace_bytes(B, Ci, Co, Kh, Kw, Ho, Wo, G)
+      ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
+      check(lib().mode_sphere_conv_bwd_weight(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), *dims, stream_of(gy)),
+            'mode_sphere_conv_bwd_weight')
   return gw
+
+
+# ------------------------------------------------------------------------------------ gradient sinks
+def grad_sink(param):
+  """The buffer parameter gradients are accumulated into directly by the native backward kernels, or None.
+
+  autograd's AccumulateGrad costs one extra elementwise kernel per parameter and step (243 launches for ModeDisparity).
+  When a parameter carries `_mode_grad_sink` (set by data_parallel.GradAllReducer: a view into its flat gradient buffer,
+  which is also `param.grad`), the weight-gradient kernels add into that view themselves and the autograd Function
+  returns None for the parameter, so nothing is left for autograd to accumulate.  Parameters without the attribute get
+  ordinary autograd gradients."""
+  sink = getattr(param, '_mode_grad_sink', None)
+  if sink is None:
+    return None
+  if not (sink.is_cuda and sink.dtype == torch.float32 and sink.is_contiguous() and sink.shape == param.shape):
+    raise RuntimeError('gradient sink of a %s parameter must be a contiguous fp32 device tensor of the same shape' % (tuple(param.shape),))
+  return sink
 
 
 # ------------------------------------------------------------------------------------ 3x3x3 convolution / transposed conv
@@ -214,20 +319,22 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   return gx
 
 
-def conv3d_bwd_weight(gy, x, stride=1):
-  """gW (Co,Ci,3,3,3) = sum gy[o, q] * x[c, stride*q + k - 1]."""
+def conv3d_bwd_weight(gy, x, stride=1, into=None):
+  """gW (Co,Ci,3,3,3) = sum gy[o, q] * x[c, stride*q + k - 1]; returned, or ADDED to `into` when given."""
   require_gpu(gy, x)
   gy, x = gy.contiguous(), x.contiguous()
   require_f32c(gy, x)
   B, Ci, D, H, W = x.shape
   Co = gy.shape[1]
-  gw = torch.empty((Co, Ci, 3, 3, 3), dtype=gy.dtype, device=gy.device)
+  gw = into if into is not None else torch.empty((Co, Ci, 3, 3, 3), dtype=gy.dtype, device=gy.device)
+  if gw.numel() != Co * Ci * 27:
+    raise RuntimeError('conv3d_bwd_weight: gradient buffer %s does not hold %dx%dx27 values' % (tuple(gw.shape), Co, Ci))
   flops = 2 * gy.numel() * Ci * 27
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_weight', Ci, Co, stride, D, H, W),
                                                   4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
     n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, stride)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, 0, stream_of(gy)),
+    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, int(into is not None), stream_of(gy)),
           'mode_conv3d_bwd_weight')
   return gw
 
@@ -262,7 +369,12 @@ class Conv3dFunction(torch.autograd.Function):
   def backward(ctx, gy):
     x, w = ctx.saved_tensors
     gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
-    gw = conv3d_bwd_weight(gy, x, ctx.stride) if ctx.needs_input_grad[1] else None
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = conv3d_bwd_weight(gy, x, ctx.stride, into=sink)
+      if sink is not None:
+        gw = None
     return gx, gw, None
 
 
@@ -279,7 +391,12 @@ class Deconv3dFunction(torch.autograd.Function):
   def backward(ctx, gy):
     x, w = ctx.saved_tensors
     gx = conv3d_fwd(gy, w, 2) if ctx.needs_input_grad[0] else None  # w (Cin,Cout,27) read as (Co=Cin, Ci=Cout)
-    gw = conv3d_bwd_weight(x, gy, 2) if ctx.needs_input_grad[1] else None  # -> (Cin, Cout, 3,3,3)
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = conv3d_bwd_weight(x, gy, 2, into=sink)  # -> (Cin, Cout, 3,3,3)
+      if sink is not None:
+        gw = None
     return gx, gw
 
 
@@ -365,7 +482,7 @@ class BnActFunction(torch.autograd.Function):
   """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
 
   @staticmethod
-  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu):
+  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
     require_gpu(y, add, gamma, beta)
     y = y.contiguous()
     add = add.contiguous() if add is not None else None
@@ -379,31 +496,36 @@ class BnActFunction(torch.autograd.Function):
       ws = _bn_ws(C, y.device)
       check(lib().mode_bn_train_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta),
                                     ptr(running_mean) if running_mean is not None else None,
-                                    ptr(running_var) if running_var is not None else None, float(momentum), float(eps), int(relu),
+                                    ptr(running_var) if running_var is not None else None,
+                                    ptr(num_batches_tracked) if num_batches_tracked is not None else None, float(momentum), float(eps), int(relu),
                                     ptr(out), ptr(mean), ptr(invstd), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_fwd')
-    ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+    ctx.save_for_backward(y, out if relu else None, gamma, beta, mean, invstd)
     ctx.relu, ctx.has_add = bool(relu), add is not None
     return out
 
   @staticmethod
   def backward(ctx, gout):
-    y, out, gamma, mean, invstd = ctx.saved_tensors
+    y, out, gamma, beta, mean, invstd = ctx.saved_tensors
     gout = gout.contiguous()
     B, C, S = _bcs(y)
     gy = torch.empty_like(y)
     need_gadd = ctx.has_add and ctx.relu and ctx.needs_input_grad[1]
     gadd = torch.empty_like(y) if need_gadd else None
-    ggamma = torch.empty_like(gamma)
-    gbeta = torch.empty_like(gamma)
+    sink_g, sink_b = grad_sink(gamma), grad_sink(beta)
+    fused = sink_g is not None and sink_b is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+    ggamma = sink_g if fused else torch.empty_like(gamma)
+    gbeta = sink_b if fused else torch.empty_like(gamma)
     nbytes = 4 * y.numel() * (2 * (2 + (1 if ctx.relu else 0)) + 1 + (1 if need_gadd else 0))
     with torch.cuda.device_of(y), profiling.region('bn_train_bwd', nbytes, 0, y.device):
       ws = _bn_ws(C, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
-                                    int(ctx.relu), ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta), ptr(ws),
-                                    B, C, S, stream_of(y)), 'mode_bn_train_bwd')
+                                    int(ctx.relu), ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
+                                    int(fused), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_bwd')
+    if fused:
+      ggamma = gbeta = None
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
-    return gy, gadd, ggamma, gbeta, None, None, None, None, None
+    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None
 
 
 def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
@@ -415,9 +537,8 @@ def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
   out = torch.empty_like(y)
   nbytes = 4 * y.numel() * (2 + (1 if add is not None else 0))
   with torch.cuda.device_of(y), profiling.region('bn_eval_fwd', nbytes, 0, y.device):
-    ws = _bn_ws(C, y.device)
     check(lib().mode_bn_eval_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta), ptr(running_mean),
-                                 ptr(running_var), float(eps), int(relu), ptr(out), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_eval_fwd')
+                                 ptr(running_var), float(eps), int(relu), ptr(out), B, C, S, stream_of(y)), 'mode_bn_eval_fwd')
   return out
 
 
@@ -428,13 +549,15 @@ def bn_act(bn, y, add=None, relu=False):
   use_batch_stats = bn.training or bn.running_mean is None
   if use_batch_stats:
     momentum = bn.momentum
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-      bn.num_batches_tracked.add_(1)
-      if momentum is None:
-        momentum = 1.0 / float(bn.num_batches_tracked)
     update = bn.training and bn.track_running_stats
+    nbt = bn.num_batches_tracked if update else None
+    if nbt is not None and (momentum is None or not (nbt.is_cuda and nbt.dtype == torch.int64)):
+      nbt.add_(1)  # cumulative moving average needs the count on the host; otherwise the kernel counts the batch
+      if momentum is None:
+        momentum = 1.0 / float(nbt)
+      nbt = None
     return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
-                               momentum if momentum is not None else 0.0, bn.eps, relu)
+                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt)
   if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
     # eval-mode BN inside a graph that needs gradients: rare (the reference never does it); vendor ops keep autograd correct
     out = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)

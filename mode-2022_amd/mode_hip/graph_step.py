@@ -1,0 +1,46 @@
+"""Replay a whole training (or inference) step as ONE hipGraph.
+
+A ModeDisparity training step is ~2 200 kernel launches of 3 us .. 3 ms; launched one by one from Python the GPU idles for
+about a quarter of the step.  The step has static shapes and no host-side data dependence (the sampling and adjoint tables
+are constants of the geometry, the loss mask is applied arithmetically), so it is captured once -- forward, loss, backward
+into the flat gradient buffer -- and replayed with a single launch.  The native library only ever enqueues on the stream it
+is handed and never allocates, so capture needs nothing special from it.
+
+The gradient exchange and the optimizer stay outside the graph: the exchange because a collective is only capturable with
+RCCL (not with the gloo backend the CPU tests use), the optimizer so that its hyper-parameters stay ordinary Python state.
+
+  gs = GraphedStep(fn, static_inputs)      # fn() reads the static input tensors and returns a tensor / tuple of tensors
+  gs.load(left, right, gt, ...)            # copy_ new data into the static inputs (optional)
+  out = gs.replay()                        # static output tensors, overwritten by every replay
+"""
+import torch
+
+
+class GraphedStep(object):
+
+  def __init__(self, fn, static_inputs=(), warmup=2, pool=None):
+    self.static_inputs = list(static_inputs)
+    dev = self.static_inputs[0].device if self.static_inputs else torch.device('cuda', torch.cuda.current_device())
+    assert dev.type == 'cuda', 'hipGraph capture needs device tensors'
+    # Warm up on a side stream: vendor find-phases, table/adjoint uploads, LDS attribute calls and allocator growth all
+    # happen here, not during capture.
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      for _ in range(warmup):
+        fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph, pool=pool):
+      self.outputs = fn()
+    torch.cuda.synchronize(dev)
+
+  def load(self, *tensors):
+    assert len(tensors) == len(self.static_inputs)
+    for dst, src in zip(self.static_inputs, tensors):
+      dst.copy_(src, non_blocking=True)
+
+  def replay(self):
+    self.graph.replay()
+    return self.outputs

@@ -16,6 +16,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _single
 
 from . import sphere_conv_cuda
+from mode_hip import functional as _F
 
 
 def _conv_out(size, k, stride, pad, dil):
@@ -52,14 +53,18 @@ class SphereConvFunction(Function):
     input, position, weight, bias = ctx.saved_tensors
     if not grad_output.is_cuda:
       raise NotImplementedError
-    grad_input = torch.zeros_like(input)
-    grad_weight = torch.zeros_like(weight)
+    grad_input = torch.empty_like(input)  # written, not added to (overwrite_grad_input)
+    # The op ADDS the weight gradient to the tensor it is given (reference contract).  When the parameter has a gradient
+    # sink (mode_hip.functional.grad_sink) that tensor is the optimizer's gradient buffer itself and autograd gets None.
+    sink = _F.grad_sink(weight) if ctx.needs_input_grad[2] else None
+    grad_weight = sink if sink is not None else torch.zeros_like(weight)
     grad_bias = torch.zeros_like(bias)
     kh, kw = weight.shape[2:]
     sphere_conv_cuda.sphere_conv_backward_cuda(input, weight, bias, None, position, None, grad_input, grad_weight, grad_bias,
                                                grad_output, kh, kw, ctx.stride[0], ctx.stride[1], ctx.padding[0], ctx.padding[1],
-                                               ctx.dilation[0], ctx.dilation[1], ctx.groups, ctx.has_bias)
-    return grad_input, None, grad_weight, (grad_bias if ctx.has_bias else None), None, None, None, None
+                                               ctx.dilation[0], ctx.dilation[1], ctx.groups, ctx.has_bias,
+                                               overwrite_grad_input=True)
+    return grad_input, None, (None if sink is not None else grad_weight), (grad_bias if ctx.has_bias else None), None, None, None, None
 
   @staticmethod
   def _output_size(input, weight, padding, dilation, stride):

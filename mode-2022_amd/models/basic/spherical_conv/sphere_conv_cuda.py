@@ -77,12 +77,15 @@ def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, column
 
 
 def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad_input, grad_weight, grad_bias, grad_output,
-                              kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, has_bias):
+                              kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *,
+                              overwrite_grad_input=False):
+  """The 20 positional arguments of the reference op.  Keyword-only extension: overwrite_grad_input=True lets the caller
+  pass an uninitialised grad_input (it is written, not added to), which saves the zero-fill and one read of the tensor."""
   _shape_check(input, position, grad_output, grad_weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
                dilation_w, group)
   gy = grad_output.contiguous()
   pos = position.contiguous()
-  _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group)
+  _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group, overwrite=overwrite_grad_input)
   _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group)
   if has_bias:
     grad_bias += gy.sum((0, 2, 3))  # cpp:316-322

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == 1
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu():
@@ -95,3 +95,51 @@ def test_workspace_queries_are_host_only():
   assert lib.mode_sphere_conv_wpack_bytes(3, 4, 3, 3, 1) > 0
   ws = lib.mode_sphere_conv_bwd_weight_workspace_bytes(2, 128, 128, 3, 3, 256, 128, 1)
   assert ws > 0 and ws % (128 * 128 * 4) == 0
+
+
+def test_sphere_window_plan_covers_every_sample():
+  """mode_sphere_plan_build (host code, no GPU): every tile of the gnomonic Cassini table gets a window class, the classes
+  partition the tiles, and every live sample of a tile lies inside the window the plan gives it."""
+  import numpy as np
+  import torch
+  from oracle import mode_ref
+  lib = mode_hip.lib()
+  for ih, iw in ((128, 256), (10, 20), (33, 66)):
+    pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+    H, W = pos.shape[2:]
+    n = lib.mode_sphere_plan_max_tiles(H, W)
+    assert n == -(-H // 64) * -(-W // 4)
+    tiles = torch.full((4 * n,), -1, dtype=torch.int32)
+    counts = torch.zeros(4, dtype=torch.int32)
+    assert lib.mode_sphere_plan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(tiles), mode_hip.ptr(counts)) == 0
+    c = counts.tolist()
+    assert sum(c) == n and c[3] == 0, c
+    t = tiles.view(n, 4).numpy()
+    assert len({(a, b) for a, b, _, _ in t}) == n  # every tile exactly once
+    p = pos[0].numpy()
+    assert [int((t[:, 3] >> 16 == k).sum()) for k in range(4)] == c
+    for h0, w0, rbase, packed in t:
+      cbase, wr = packed & 0xffff, {0: 81, 1: 145, 2: H + 1}[packed >> 16]
+      hh, ww = np.meshgrid(np.arange(h0, min(h0 + 64, H)), np.arange(w0, min(w0 + 4, W)), indexing='ij')
+      for k in range(9):
+        y, x = p[2 * k][hh, ww], p[2 * k + 1][hh, ww]
+        live = (y > -1) & (x > -1) & (y < H) & (x < W)
+        r0 = np.maximum(np.floor(y).astype(int), 0)[live]
+        c0 = np.maximum(np.floor(x).astype(int), 0)[live]
+        lr = (r0 - rbase) % H
+        assert (lr + 1 < wr).all() and (c0 - cbase >= 0).all() and (c0 - cbase + 1 < 8).all()
+    if (ih, iw) == (128, 256):
+      assert c[0] == 7 * (c[1] + c[2])  # 28 of the 32 column blocks are far enough from the poles for the small window
+
+
+def test_sphere_window_plan_rejects_unstructured_table():
+  import torch
+  lib = mode_hip.lib()
+  g = torch.Generator().manual_seed(3)
+  H, W = 24, 20
+  pos = torch.stack([torch.rand(9, H, W, generator=g) * (H + 1) - 1, torch.rand(9, H, W, generator=g) * (W + 1) - 1], 1).reshape(1, 18, H, W).contiguous()
+  n = lib.mode_sphere_plan_max_tiles(H, W)
+  tiles = torch.zeros(4 * n, dtype=torch.int32)
+  counts = torch.zeros(4, dtype=torch.int32)
+  assert lib.mode_sphere_plan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(tiles), mode_hip.ptr(counts)) == 0
+  assert counts[3] > 0 and int(counts.sum()) == n

@@ -125,6 +125,60 @@ def test_sphere_conv_fwd_bwd(typ, ih, iw, B, ci, co, stride, groups):
   assert torch.equal(gw2, gw3)
 
 
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(64, 128, 1, 16, 32, 1), (128, 256, 1, 8, 32, 1), (10, 20, 2, 5, 7, 1), (33, 66, 1, 12, 40, 2),
+                                                   (16, 32, 1, 40, 160, 1)])
+def test_sphere_conv_window_kernels_match_gather_kernels(ih, iw, B, ci, co, groups, monkeypatch):
+  """The LDS-window forward (csrc/sphere_conv_win.hip) against the general gather forward on Cassini tables: all three
+  window classes (equator, near-pole, wrap-around) appear at 128x256; ragged tiles (H % 32, W % 4 != 0), groups and
+  Co > 128.  Same products, different summation order: fp32 round-off only."""
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').to(DEV)
+  H, W = pos.shape[2:]
+  plan = HF.sphere_plan(pos, 3, 3)
+  assert plan is not None, 'the gnomonic Cassini table must be plannable'
+  x = _rand((B, ci, H, W), 5).to(DEV)
+  w = _rand((co, ci // groups, 3, 3), 6, 0.2).to(DEV)
+  out = {}
+  for mode in ('window', 'gather'):
+    monkeypatch.setattr(HF, 'SPHERE_FWD', mode)
+    y = torch.full((B, co, H, W), float('nan'), device=DEV)
+    HF.sphere_conv_fwd(x, pos, w, y, (1, 1), groups)
+    out[mode] = y
+  assert torch.isfinite(out['window']).all()
+  assert (out['window'] - out['gather']).abs().max() < 2e-6 * (ci // groups * 9) * max(1.0, float(out['gather'].abs().max()))
+  y_ref = sphere_conv_ref.forward(x.cpu().double(), pos.cpu(), w.cpu().double(), (1, 1), (1, 1), (1, 1), groups)
+  assert (out['window'].cpu().double() - y_ref).abs().max() < 2e-6 * (ci // groups * 9) * max(1.0, float(y_ref.abs().max()))
+  # weight gradient: windowed kernel on the compact tiles + general kernel on the listed polar pixels == general kernel on all
+  gy = _rand((B, co, H, W), 9).to(DEV)
+  gws = {}
+  for mode in ('window', 'gather'):
+    monkeypatch.setattr(HF, 'SPHERE_BWD_WEIGHT', mode)
+    gw = torch.zeros_like(w)
+    HF.sphere_conv_bwd_weight(gy, pos, x, gw, (1, 1), groups)
+    gws[mode] = gw
+  scale = max(1.0, float(gws['gather'].abs().max()))
+  assert (gws['window'] - gws['gather']).abs().max() < 2e-5 * scale
+  _, gw_ref = sphere_conv_ref.backward(x.cpu().double(), pos.cpu(), w.cpu().double(), gy.cpu().double(), (1, 1), (1, 1), (1, 1), groups)
+  assert (gws['window'].cpu().double() - gw_ref).abs().max() < 1e-5 * max(1.0, float(gw_ref.abs().max()))
+  monkeypatch.setattr(HF, 'SPHERE_BWD_WEIGHT', 'window')
+  gw2 = torch.zeros_like(w)
+  HF.sphere_conv_bwd_weight(gy, pos, x, gw2, (1, 1), groups)
+  assert torch.equal(gw2, gws['window'])  # deterministic
+
+
+def test_sphere_conv_unplannable_table_takes_the_gather_kernels():
+  """A table without spatial structure cannot be windowed: the plan says so and the general kernels run."""
+  g = torch.Generator().manual_seed(3)
+  H, W = 24, 20
+  pos = torch.stack([torch.rand(9, H, W, generator=g) * (H + 1) - 1, torch.rand(9, H, W, generator=g) * (W + 1) - 1], 1).reshape(1, 18, H, W)
+  pd = pos.to(DEV)
+  assert HF.sphere_plan(pd, 3, 3) is None
+  x, w = _rand((1, 6, H, W), 7), _rand((8, 6, 3, 3), 8, 0.2)
+  y = torch.empty((1, 8, H, W), device=DEV)
+  HF.sphere_conv_fwd(x.to(DEV), pd, w.to(DEV), y, (1, 1), 1)
+  y_ref = sphere_conv_ref.forward(x.double(), pos, w.double(), (1, 1), (1, 1), (1, 1), 1)
+  assert (y.cpu().double() - y_ref).abs().max() < 1e-4
+
+
 @pytest.mark.parametrize('kh,kw', [(1, 3), (5, 5), (2, 2)])
 def test_sphere_conv_other_kernel_sizes(kh, kw):
   """Tap counts other than 9 take the generic (non-pipelined) kernels; even sizes use the reference's centre-less tap set."""
