@@ -29,6 +29,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 constexpr int RB = 2;      // MFMA N-tiles (32 rows) per tile column
 constexpr int TH = 32 * RB;  // tile rows
@@ -310,8 +311,12 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_tall_kernel(const flo
 //   of 32 input channels (LDS, [c][col][row], odd channel pitch: the 32 lanes of a half-wave read 32 channels).
 // Work item = half a plan tile (32 rows x 4 columns) of one sample, processed column by column (32 pixels = 16 k-steps).
 // grid = (S, ceil(Cig/32), G*MG); split-K slice s owns the items s, s+S, ...; 8 waves: wave v owns tap v for all 4 o-tiles,
-// tap 8 is shared: o-tile v&3, first (v < 4) or second half of every column's pixels.  Partial sums go to
-// part[s][z][cg][slot 0..9][128 o][32 c] (slots 8, 9 = the two halves of tap 8), summed in fixed order by reduce_gw_win.
+// tap 8 is shared: wave v takes the pixels p = v (mod 8) of every column.  Partial sums go to
+// part[s][z][cg][slot 0..15][128 o][32 c] (slots 8..15 = the waves' shares of tap 8), summed in fixed order by reduce_gw_win.
+// The contraction runs on v_mfma_f32_32x32x1_2b_f32: ONE pixel per instruction, two o-tiles (the two 32x32 blocks) at a time.
+// With one pixel per step the sampling record is the same for the whole wave, so it lives in SGPRs (scalar loads from the
+// record table) and the bilinear combine is 4 VALU instructions with scalar weights -- the 32x32x2 form (two pixels per step,
+// one per half-wave) needed ~14 VALU + 7 SALU instructions per MFMA for the per-half selects and measured 30 % MFMA busy.
 // The sampling records (window offset + 4 weights per tap and pixel) come from a table the host builds with the plan
 // (mode_sphere_plan_records): they depend on the table and the tile only, not on the sample, layer or channel group.
 // Everything the next column needs (gy, records; the x window before a new item) is fetched into registers before the MFMAs
@@ -321,7 +326,7 @@ constexpr int BW_TH = 32;                  // rows per work item
 constexpr int BW_WR = BW_TH + 17;          // its window rows (49)
 constexpr int BW_CP = WC * BW_WR + 1;      // odd channel pitch of the x window
 constexpr int BW_GP = BW_TH + 1;           // gy row pitch
-constexpr int BW_SLOTS = KT + 1;
+constexpr int BW_SLOTS = 16;                // 8 own taps + 8 per-wave shares of tap 8
 constexpr int BW_XW = BW_CG * BW_CP + BW_WR + 8;  // + slack: zero-weight corners may point just past the last window
 constexpr int BW_COLBUF = 128 * BW_GP;  // gy column
 constexpr int BW_LDS_FLOATS = BW_XW + 2 * BW_COLBUF;
@@ -344,41 +349,49 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
   const int T = ntiles * 2 * d.B;  // (sample, tile, half) items
   const int NCG = gridDim.y;
 
-  f32x16 acc[MTW], acc8;
+  f32x32 accp[2], acc8p[2];  // [o-tile pair]: elements 0-15 = first tile of the pair, 16-31 = second
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc8[r] = 0.f;
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) acc[m][r] = 0.f;
+  for (int r = 0; r < 32; ++r) {
+    accp[0][r] = accp[1][r] = 0.f;
+    acc8p[0][r] = acc8p[1][r] = 0.f;
   }
   for (int i = tid; i < BW_LDS_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every word that may be read is finite
 
   // prefetch registers
   float pxw[BW_NXW];  // x window of the next item
   float pgy[8];       // gy of the next column: o = (tid >> 5) + 16 u, pixel tid & 31
+  float4 prw, prw8;   // records of the next column: lane l holds pixel l & 31 of this wave's tap and of tap 8
+  int pro, pro8;
 
   const int omax = d.Cog - mg * 128;
   const int cmax = d.Cig - cg * BW_CG;
   const int gpx = tid & (BW_TH - 1), go0 = tid >> 5;
 
-  auto item_geom = [&](int t, int& b, int& ti, int& hf) {
-    b = t / (ntiles * 2);
-    const int r = t - b * ntiles * 2;
-    ti = r >> 1;
-    hf = r & 1;
+  struct Item {  // geometry of a work item, wave-uniform
+    int b, ti, hf, h0, w0, rbase, cbase;
   };
-  // x window: thread -> (column tid & 7, row tid >> 3 < 49), one word per channel; addresses are base + channel * stride
+  auto item_of = [&](int t) {
+    Item it;
+    it.b = t / (ntiles * 2);
+    const int r = t - it.b * ntiles * 2;
+    it.ti = r >> 1;
+    it.hf = r & 1;
+    const int4 tl = tiles[it.ti];
+    it.h0 = tl.x + it.hf * BW_TH;
+    it.w0 = tl.y;
+    it.rbase = (tl.z + it.hf * BW_TH) % d.H;
+    it.cbase = tl.w & 0xffff;
+    return it;
+  };
+  // x window: thread -> (column, row < 49), one word per channel; addresses are base + channel * stride.  Lanes run along the
+  // contiguous axis of the planes (columns for NCHW, rows for transposed planes).
   const int xcol = d.sh == 1 ? tid >> 6 : tid & (WC - 1), xrow = d.sh == 1 ? tid & 63 : tid >> 3;
   const bool xrow_ok = xrow < WRP;
-  auto issue_xw = [&](int t) {
-    int b, ti, hf;
-    item_geom(t, b, ti, hf);
-    const int4 tl = tiles[ti];
-    const int rbase = (tl.z + hf * BW_TH) % d.H, cbase = tl.w & 0xffff;
-    const bool ok0 = xrow_ok && cbase + xcol < d.W;
-    const int grow = (rbase + (xrow_ok ? xrow : 0)) % d.H;
-    const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
-                      (ok0 ? (long long)grow * d.sh + (long long)(cbase + xcol) * d.sw : 0);
+  auto issue_xw = [&](const Item& it) {
+    const bool ok0 = xrow_ok && it.cbase + xcol < d.W;
+    const int grow = (it.rbase + (xrow_ok ? xrow : 0)) % d.H;
+    const float* xg = x + ((long long)it.b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
+                      (ok0 ? (long long)grow * d.sh + (long long)(it.cbase + xcol) * d.sw : 0);
 #pragma unroll
     for (int c = 0; c < BW_CG; ++c) {
       const bool ok = ok0 && c < cmax;
@@ -393,13 +406,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
       for (int c = 0; c < BW_CG; ++c) dst[c * BW_CP] = pxw[c];
     }
   };
-  auto issue_col = [&](int t, int wc) {
-    int b, ti, hf;
-    item_geom(t, b, ti, hf);
-    const int4 tl = tiles[ti];
-    const int h = tl.x + hf * BW_TH + gpx, w = tl.y + wc;
+  auto issue_col = [&](const Item& it, int wc) {
+    const int h = it.h0 + gpx, w = it.w0 + wc;
     const bool pok = h < d.H && w < d.W;
-    const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
+    const float* gyb = gy + ((long long)it.b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
                        (pok ? (long long)h * d.sh + (long long)w * d.sw : 0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -408,6 +418,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
       const float v = gyb[ok ? (long long)o * HW : 0];
       pgy[u] = ok ? v : 0.f;
     }
+    const long long rcol = (((long long)it.ti * 2 + it.hf) * TW + wc) * BW_NREC;
+    prw = rec_w[rcol + wave * BW_TH + j];
+    pro = rec_off[rcol + wave * BW_TH + j];
+    prw8 = rec_w[rcol + 8 * BW_TH + j];
+    pro8 = rec_off[rcol + 8 * BW_TH + j];
   };
   auto commit_col = [&](float* cb) {
 #pragma unroll
@@ -415,110 +430,85 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
   };
 
   // first item: window and first column
-  issue_xw(s);
-  issue_col(s, 0);
+  Item cur = item_of(s);
+  issue_xw(cur);
+  issue_col(cur, 0);
   __syncthreads();  // zero fill done
   commit_xw();
   commit_col(smem + BW_XW);
   __syncthreads();
 
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   int buf = 0;
   for (int t = s; t < T; t += S) {
     const bool more_items = t + S < T;
+    const Item nxt = item_of(more_items ? t + S : t);
     for (int wc = 0; wc < TW; ++wc) {
       const float* cb = smem + BW_XW + buf * BW_COLBUF;
       const bool last_col = wc == TW - 1;
       const bool have_next = !last_col || more_items;
-      if (have_next) issue_col(last_col ? t + S : t, last_col ? 0 : wc + 1);
-      if (last_col && more_items) issue_xw(t + S);
+      // The sampling record of a pixel is the same for every lane: lane l holds the record of pixel l & 31 (vector loads,
+      // prefetched with the column) and each step broadcasts its pixel's record with v_readlane -- no scalar-memory loads
+      // in the loop, whose out-of-order return would force a full LDS drain on every use.
+      const float4 rw = prw, rw8 = prw8;
+      const int ro = pro, ro8 = pro8;
+      if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
+      if (last_col && more_items) issue_xw(nxt);
 
-      const float* ap = cb + j * BW_GP + half;
+      // A operand: block 0 (lanes 0-31) = o-tile 0 / 2, block 1 (lanes 32-63) = o-tile 1 / 3
+      const float* ap = cb + (half * 32 + j) * BW_GP;
       const float* xb = xw + j * BW_CP;
-      // The records of a k-step (two pixels: even for lanes 0-31, odd for lanes 32-63) are the same for every lane of a
-      // half-wave: they are fetched with scalar loads straight from the record table (wave-uniform addresses) and selected
-      // per half, so they cost no LDS traffic at all.
-      int bq, tiq, hfq;
-      item_geom(t, bq, tiq, hfq);
-      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-      const long long rcol = (((long long)tiq * 2 + hfq) * TW + wc) * BW_NREC;
-      const float4* rw_own = rec_w + rcol + wave_u * BW_TH;
-      const int* ro_own = rec_off + rcol + wave_u * BW_TH;
-      const float4* rw_t8 = rec_w + rcol + 8 * BW_TH;
-      const int* ro_t8 = rec_off + rcol + 8 * BW_TH;
-      const int m8 = wave_u & 3;
-      const int q8lo = (wave_u >> 2) * (BW_TH / 4);  // this wave's k-steps of tap 8: [q8lo, q8lo + 8)
-
-      struct Rec {
-        float4 w;
-        int o;
-      };
-      auto load_rec = [&](const float4* rwp, const int* rop, int q) {
-        const float4 we = rwp[2 * q], wo = rwp[2 * q + 1];
-        const int oe = rop[2 * q], oo = rop[2 * q + 1];
-        Rec r;
-        r.w.x = half ? wo.x : we.x;
-        r.w.y = half ? wo.y : we.y;
-        r.w.z = half ? wo.z : we.z;
-        r.w.w = half ? wo.w : we.w;
-        r.o = half ? oo : oe;
-        return r;
-      };
-      auto load_x = [&](int o, float (&raw)[4]) {
+      auto load_x = [&](int o, float (&raw)[4]) {  // o is wave-uniform
         const float* p = xb + o;
         raw[0] = p[0];
         raw[1] = p[WRP];
         raw[2] = p[1];
         raw[3] = p[WRP + 1];
       };
-      auto load_a = [&](int q, float (&a)[4]) {
-        a[0] = ap[2 * q];
-        a[1] = ap[32 * BW_GP + 2 * q];
-        a[2] = ap[64 * BW_GP + 2 * q];
-        a[3] = ap[96 * BW_GP + 2 * q];
+      auto bcast = [&](float v, int px) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), px)); };
+      auto combine = [&](const float4& w, int px, const float (&raw)[4]) {  // one fma chain: keeps the compiler from SLP-packing
+        return __builtin_fmaf(bcast(w.w, px), raw[3],
+                              __builtin_fmaf(bcast(w.z, px), raw[2], __builtin_fmaf(bcast(w.y, px), raw[1], bcast(w.x, px) * raw[0])));
       };
-      // software pipeline over the 16 k-steps: records two steps ahead (scalar), LDS operands one step ahead
-      Rec r_c = load_rec(rw_own, ro_own, 0), r_n = load_rec(rw_own, ro_own, 1);
-      Rec r8_c = load_rec(rw_t8, ro_t8, q8lo), r8_n = load_rec(rw_t8, ro_t8, q8lo + 1);
-      float raw_c[4], raw8_c[4], a_c[4];
-      load_x(r_c.o, raw_c);
-      load_a(0, a_c);
-      if (q8lo == 0) load_x(r8_c.o, raw8_c);
-#pragma unroll 4
-      for (int q = 0; q < BW_TH / 2; ++q) {
-        const bool do8 = q >= q8lo && q < q8lo + BW_TH / 4;         // tap 8 in this step
-        const bool nx8 = q + 1 >= q8lo && q + 1 < q8lo + BW_TH / 4;  // ... and in the next one
-        float raw_n[4], raw8_n[4], a_n[4];
-        Rec r_nn = r_n, r8_nn = r8_n;
-        if (q + 1 < BW_TH / 2) {
-          load_x(r_n.o, raw_n);
-          load_a(q + 1, a_n);
-          if (nx8) load_x(do8 ? r8_n.o : r8_c.o, raw8_n);
-        }
-        if (q + 2 < BW_TH / 2) r_nn = load_rec(rw_own, ro_own, q + 2);
-        if (do8 && q + 2 < q8lo + BW_TH / 4) r8_nn = load_rec(rw_t8, ro_t8, q + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        const float bv = r_c.w.x * raw_c[0] + r_c.w.y * raw_c[1] + r_c.w.z * raw_c[2] + r_c.w.w * raw_c[3];
-        acc[0] = mfma32(a_c[0], bv, acc[0]);
-        acc[1] = mfma32(a_c[1], bv, acc[1]);
-        acc[2] = mfma32(a_c[2], bv, acc[2]);
-        acc[3] = mfma32(a_c[3], bv, acc[3]);
-        if (do8) {
-          const float b8 = r8_c.w.x * raw8_c[0] + r8_c.w.y * raw8_c[1] + r8_c.w.z * raw8_c[2] + r8_c.w.w * raw8_c[3];
-          const float a8 = m8 == 0 ? a_c[0] : m8 == 1 ? a_c[1] : m8 == 2 ? a_c[2] : a_c[3];
-          acc8 = mfma32(a8, b8, acc8);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        r_c = r_n;
-        r_n = r_nn;
-        if (do8) {
-          r8_c = r8_n;
-          r8_n = r8_nn;
+      // own tap: all 32 pixels; the operands of pixel px+2 are read while the MFMAs of pixel px run
+      {
+        float raw[3][4], a[3][2];
+#pragma unroll
+        for (int p0 = 0; p0 < 2; ++p0) {
+          load_x(__builtin_amdgcn_readlane(ro, p0), raw[p0]);
+          a[p0][0] = ap[p0];
+          a[p0][1] = ap[64 * BW_GP + p0];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          raw_c[i] = raw_n[i];
-          raw8_c[i] = raw8_n[i];
-          a_c[i] = a_n[i];
+        for (int px = 0; px < BW_TH; ++px) {
+          const int c3 = px % 3, n3 = (px + 2) % 3;
+          if (px + 2 < BW_TH) {
+            load_x(__builtin_amdgcn_readlane(ro, px + 2), raw[n3]);
+            a[n3][0] = ap[px + 2];
+            a[n3][1] = ap[64 * BW_GP + px + 2];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const float bv = combine(rw, px, raw[c3]);
+          accp[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][0], bv, accp[0], 0, 0, 0);
+          accp[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][1], bv, accp[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // this wave's share of tap 8: pixels wave, wave + 8, wave + 16, wave + 24
+      {
+        float raw[4][4], a[4][2];
+#pragma unroll
+        for (int i = 0; i < BW_TH / 8; ++i) {
+          const int px = wave_u + 8 * i;
+          load_x(__builtin_amdgcn_readlane(ro8, px), raw[i]);
+          a[i][0] = ap[px];
+          a[i][1] = ap[64 * BW_GP + px];
+        }
+#pragma unroll
+        for (int i = 0; i < BW_TH / 8; ++i) {
+          const float b8 = combine(rw8, wave_u + 8 * i, raw[i]);
+          acc8p[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][0], b8, acc8p[0], 0, 0, 0);
+          acc8p[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][1], b8, acc8p[1], 0, 0, 0);
         }
       }
 
@@ -530,27 +520,21 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
       __syncthreads();
       buf ^= 1;
     }
+    cur = nxt;
   }
 
   float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
+  for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      pb[((long long)wave * 128 + o) * BW_CG + j] = acc[m][r];
+    for (int r = 0; r < 32; ++r) {
+      const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
+      pb[((long long)wave * 128 + o) * BW_CG + j] = accp[pr][r];
+      pb[((long long)(8 + wave) * 128 + o) * BW_CG + j] = acc8p[pr][r];
     }
-  {
-    const int slot = 8 + (wave >> 2), m = wave & 3;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      pb[((long long)slot * 128 + o) * BW_CG + j] = acc8[r];
-    }
-  }
 }
 
-// gw[o][c][k] += sum over slices (fixed order) of slot k (+ slot 9 for tap 8); one thread per (z, cg, k, o, c), c fastest:
+// gw[o][c][k] += sum over slices (fixed order) of slot k (slots 8..15 for tap 8); one thread per (z, cg, k, o, c), c fastest:
 // coalesced reads of the partials
 __global__ void reduce_gw_win(const float* __restrict__ part, float* __restrict__ gw, WinDims d, int S, int NCG) {
   const int GZ = d.G * d.MG;
@@ -569,18 +553,14 @@ __global__ void reduce_gw_win(const float* __restrict__ part, float* __restrict_
     const int ol = mg * 128 + row, c = cg * BW_CG + cl;
     if (ol >= d.Cog || c >= d.Cig) continue;
     const float* pp = part + ((((long long)z * NCG + cg) * BW_SLOTS + k) * 128 + row) * BW_CG + cl;
-    float sum = 0.f;  // fixed order: slice by slice, slot 8 before slot 9
-    const long long second = k == KT - 1 ? 128 * BW_CG : 0;
-    for (int s0 = 0; s0 < S; s0 += 8) {
-      float v[8], v2[8];
+    float sum = 0.f;  // fixed order: slice by slice, tap 8: wave share by wave share
+    const int nshare = k == KT - 1 ? 8 : 1;
+    for (int s0 = 0; s0 < S; ++s0) {
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = s0 + u < S;
-        v[u] = ok ? pp[(s0 + u) * stride] : 0.f;
-        v2[u] = ok && second ? pp[(s0 + u) * stride + second] : 0.f;
-      }
+      for (int u = 0; u < 8; ++u) v[u] = u < nshare ? pp[s0 * stride + (long long)u * 128 * BW_CG] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sum += v[u] + v2[u];
+      for (int u = 0; u < 8; ++u) sum += v[u];
     }
     gw[((long long)(g * d.Cog + ol) * d.Cig + c) * KT + k] += sum;
   }
