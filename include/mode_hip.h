@@ -243,6 +243,41 @@ int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const
                       const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
                       int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Export-stage geometry: what happens between the disparity network and the fusion network.
+ *
+ * mode_disp2depth: sine-rule depth of save_output_disparity_stage.py:105-135 for a Cassini disparity map (H, W);
+ *   disp == 0 -> 1000, clamp to [0, 1000]; `baseline` = the camera-pair baseline.
+ * mode_grid_sample_border: F.grid_sample(bilinear, align_corners=True, padding_mode='border') as used by cassini2Equirec /
+ *   rotateCassini / erp2rect_cassini (utils/geometry.py:38, 92, 188); src (N,C,Hs,Ws), grid (grids,Ho,Wo,2) with grids = 1
+ *   (shared) or N, dst (N,C,Ho,Wo).
+ * mode_depth_view_trans: depthViewTransWithConf (utils/geometry.py:99-145) including the sequential z-buffer of
+ *   __iterPixels_with_conf (:148-156), reproduced bit-for-bit with a 64-bit atomic min.  view1/conf1/view2/conf2 (H, W);
+ *   trig = the float32 values the reference computes with numpy, concatenated: sin phi[W], cos phi[W], sin theta[H],
+ *   cos theta[H] (device array of 2W + 2H floats; the products r*sin(phi), (r*cos(phi))*sin(theta), (r*cos(phi))*cos(theta) are
+ *   formed in that order like numpy's); R (9 doubles, row-major) and t (3 doubles) on the HOST;
+ *   workspace >= mode_depth_view_trans_workspace_bytes.
+ */
+int mode_disp2depth(const float* disp, float* depth, int H, int W, float baseline, mode_stream_t stream);
+
+int mode_grid_sample_border(const float* src, const float* grid, float* dst, int N, int C, int Hs, int Ws, int Ho, int Wo,
+                            int grids, mode_stream_t stream);
+
+size_t mode_depth_view_trans_workspace_bytes(int H, int W);
+
+int mode_depth_view_trans(const float* view1, const float* conf1, const float* trig, const double* R, const double* t,
+                          float* view2, float* conf2, void* workspace, int H, int W, mode_stream_t stream);
+
+/* The two halves of mode_depth_view_trans on their own: the projection of every source pixel (r2 in float64, target index
+ * i*W + j or -1), and the z-buffer over n given (r2, target) pairs (workspace >= 8 n bytes).  The z-buffer is exact; the
+ * projection rounds angles to pixel indices, and the reference's maps put whole families of points exactly on the rounding
+ * boundary, where the last bit of atan2 / asin decides -- parity of the projection is therefore tested off those boundaries. */
+int mode_depth_view_project(const float* view1, const float* trig, const double* R, const double* t, double* r2, int32_t* target,
+                            int H, int W, mode_stream_t stream);
+
+int mode_zbuffer(const double* r2, const int32_t* target, const float* conf1, float* view2, float* conf2, void* workspace,
+                 long long n, mode_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timings at the benchmark shapes (GPU box).  Prints one line per kernel: avg ms, GB/s, TFLOP/s.
 
-  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,conv3d,head,vendor,stages]
+  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,conv3d,head,vendor,stages,export]
 """
 import argparse
 import os
@@ -39,12 +39,41 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--batch', type=int, default=2)
   ap.add_argument('--iters', type=int, default=10)
-  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages')
+  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages,export')
   a = ap.parse_args()
   only = a.only.split(',')
   dev = 'cuda:0'
   B = a.batch
   torch.manual_seed(0)
+
+  if 'export' in only:  # disparity -> depth -> other camera's view, 1024x512
+    import math
+    import time
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import geometry_ref as G
+    from utils import geometry as HG
+    H, W = 1024, 512
+    disp = torch.rand(H, W, device=dev) * 40
+    disp[torch.rand(H, W, device=dev) < 0.05] = 0
+    conf = torch.rand(H, W, device=dev)
+    n = H * W
+    report('disp2depth 1024x512', timeit(lambda: HG.disp2depth_gpu(disp, conf, '12'), a.iters), 8 * n)
+    depth = HG.disp2depth_gpu(disp, conf, '12')[0]
+    report('depthViewTransWithConf (project + z-buffer)', timeit(lambda: HG.depthViewTransWithConf_gpu(depth, conf, 0, -1, 0, 0.5 * math.pi, 0, 0),
+                                                              a.iters), (4 + 8 + 8 + 4 + 8) * n)
+    img = torch.rand(1, 2, H, W, device=dev)
+    report('rotateCassini 2 channels', timeit(lambda: HG.rotateCassini_gpu(img, 0.5 * math.pi, 0, 0), a.iters), (8 + 2 * 4 * 2) * n)
+    report('disp2depth pair 24 (depth + view transform)', timeit(lambda: HG.disp2depth_gpu(disp, conf, '24'), a.iters), 0)
+    dn, cn = disp.cpu().numpy(), conf.cpu().numpy()
+    t0 = time.time()
+    G.disp2depth(dn, cn, '24')
+    print('  (CPU oracle, same call: %.0f ms; numpy maps + interpreted sequential z-buffer -- the reference jit-compiles that loop)' %
+          (1e3 * (time.time() - t0)), flush=True)
+    t0 = time.time()
+    G.project(depth.cpu().numpy(), 0, -1, 0, 0.5 * math.pi, 0, 0)
+    print('  (CPU oracle, numpy projection alone, what the reference runs on the host before its jitted loop: %.0f ms)' %
+          (1e3 * (time.time() - t0)), flush=True)
 
   if 'cost' in only:
     C, D4, H, W = 32, 48, 256, 128
