@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 2 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 3 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -226,22 +226,26 @@ int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float
  * bwd  : g = relu ? gout * (out > 0) : gout;  gy = dL/dy written; gadd (optional, = g) written if non-NULL;
  *        ggamma / gbeta written (accumulate = 0) or added to (accumulate = 1: the caller's gradient buffer, which saves
  *        the separate accumulation kernels of autograd).  Two launches.
+ *        The ReLU mask comes from `out`; when no residual was added, `out` may be NULL and the mask is rebuilt bit-exactly
+ *        from y with the float32 save_scale / save_shift (C floats each, optional outputs of the forward): one tensor less
+ *        to read in both backward passes.
  * `workspace` >= mode_bn_workspace_bytes(C) for the training calls.
  */
 size_t mode_bn_workspace_bytes(int C);
 
 int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
-                      float* out, float* save_mean, float* save_invstd, float* workspace, int B, int C, long long S,
-                      mode_stream_t stream);
+                      float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                      float* workspace, int B, int C, long long S, mode_stream_t stream);
 
 int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int relu, float* out, int B, int C, long long S,
                      mode_stream_t stream);
 
 int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
-                      const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
-                      int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream);
+                      const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
+                      float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
+                      long long S, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Export-stage geometry: what happens between the disparity network and the fusion network.

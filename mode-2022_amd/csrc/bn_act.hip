@@ -107,6 +107,8 @@ struct BnCoefArgs {
   long long* num_batches_tracked;
   float* save_mean;
   float* save_invstd;
+  float* save_scale;  // the float32 affine coefficients of the apply pass (optional): the backward pass re-derives the ReLU
+  float* save_shift;  // mask from y with exactly these instead of reading `out`
   float momentum, eps;
   int nsplit;
   double count;
@@ -134,6 +136,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       if (blockIdx.x == 0 && bc < C) {
         k.save_mean[c] = (float)mean;
         k.save_invstd[c] = (float)invstd;
+        if (k.save_scale) {
+          k.save_scale[c] = coef[0];
+          k.save_shift[c] = coef[1];
+        }
         if (k.running_mean) {
           const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
           k.running_mean[c] = (float)((1.0 - k.momentum) * (double)k.running_mean[c] + k.momentum * mean);
@@ -156,10 +162,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   float4* op = reinterpret_cast<float4*>(out + base);
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
     float4 v = yp[i];
-    v.x = v.x * sc + sh;
-    v.y = v.y * sc + sh;
-    v.z = v.z * sc + sh;
-    v.w = v.w * sc + sh;
+    v.x = __builtin_fmaf(v.x, sc, sh);  // one rounding: the backward pass repeats exactly this to rebuild the ReLU mask
+    v.y = __builtin_fmaf(v.y, sc, sh);
+    v.z = __builtin_fmaf(v.z, sc, sh);
+    v.w = __builtin_fmaf(v.w, sc, sh);
     if (ADD) {
       const float4 a = ap[i];
       v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
@@ -171,20 +177,24 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   }
   if (blockIdx.x == 0)
     for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
-      float v = y[base + i] * sc + sh;
+      float v = __builtin_fmaf(y[base + i], sc, sh);
       if (ADD) v += add[base + i];
       if (RELU) v = fmaxf(v, 0.f);
       out[base + i] = v;
     }
 }
 
-// Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y)
-template <bool RELU>
+// Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y).
+// RELU = 1: the mask is read from the forward output; RELU = 2 (no residual add): it is rebuilt from y with the forward's own
+// float32 coefficients, out = fma(y, scale, shift) -- bit-identical, and one tensor less to read in both backward passes.
+template <int RELU>
 __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ gout, const float* __restrict__ y,
-                                                          const float* __restrict__ out, float* __restrict__ partial, int B, int C,
+                                                          const float* __restrict__ out, const float* __restrict__ mscale,
+                                                          const float* __restrict__ mshift, float* __restrict__ partial, int B, int C,
                                                           long long S, int nsplit) {
   __shared__ float sh[8];
   const int c = blockIdx.y, split = blockIdx.x;
+  const float msc = RELU == 2 ? mscale[c] : 0.f, msh = RELU == 2 ? mshift[c] : 0.f;
   const long long S4 = S >> 2;
   const long long per_b = (S4 + nsplit - 1) / nsplit;
   const long long lo = split * per_b, hi = min(S4, lo + per_b);
@@ -197,9 +207,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
     for (long long i = lo + threadIdx.x; i < hi; i += NT) {
       float4 g = gp[i];
       const float4 v = yp[i];
-      if (RELU) {
+      if (RELU == 1) {
         const float4 o = op[i];
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      } else if (RELU == 2) {
+        g.x = __builtin_fmaf(v.x, msc, msh) > 0.f ? g.x : 0.f;
+        g.y = __builtin_fmaf(v.y, msc, msh) > 0.f ? g.y : 0.f;
+        g.z = __builtin_fmaf(v.z, msc, msh) > 0.f ? g.z : 0.f;
+        g.w = __builtin_fmaf(v.w, msc, msh) > 0.f ? g.w : 0.f;
       }
       s0 += (g.x + g.y) + (g.z + g.w);
       s1 += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
@@ -207,7 +222,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
     if (split == 0)
       for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
         float g = gout[base + i];
-        if (RELU) g = out[base + i] > 0.f ? g : 0.f;
+        if (RELU == 1) g = out[base + i] > 0.f ? g : 0.f;
+        if (RELU == 2) g = __builtin_fmaf(y[base + i], msc, msh) > 0.f ? g : 0.f;
         s0 += g;
         s1 += g * y[base + i];
       }
@@ -224,9 +240,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
 //   Cc = A*(mean*invstd*dgamma - sum(g))/count
 // derived by every block from the partial sums; the block (chunk 0, sample 0) of each channel stores (or, with
 // `accumulate`, adds into) ggamma / gbeta.
-template <bool RELU, bool GADD>
+template <int RELU, bool GADD>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ gout, const float* __restrict__ y,
-                                                          const float* __restrict__ out, const float* __restrict__ partial,
+                                                          const float* __restrict__ out, const float* __restrict__ mscale,
+                                                          const float* __restrict__ mshift, const float* __restrict__ partial,
                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int accumulate, int nsplit, double count,
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     __syncthreads();
   }
   const float A = coef[0], Bc = coef[1], Cc = coef[2];
+  const float msc = RELU == 2 ? mscale[c] : 0.f, msh = RELU == 2 ? mshift[c] : 0.f;
   const long long base = (long long)bc * S;
   const long long S4 = S >> 2;
   const float4* gp = reinterpret_cast<const float4*>(gout + base);
@@ -268,9 +286,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
     float4 g = gp[i];
     const float4 v = yp[i];
-    if (RELU) {
+    if (RELU == 1) {
       const float4 o = op[i];
       g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    } else if (RELU == 2) {
+      g.x = __builtin_fmaf(v.x, msc, msh) > 0.f ? g.x : 0.f;
+      g.y = __builtin_fmaf(v.y, msc, msh) > 0.f ? g.y : 0.f;
+      g.z = __builtin_fmaf(v.z, msc, msh) > 0.f ? g.z : 0.f;
+      g.w = __builtin_fmaf(v.w, msc, msh) > 0.f ? g.w : 0.f;
     }
     if (GADD) gap[i] = g;
     float4 r;
@@ -283,7 +306,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
   if (blockIdx.x == 0)
     for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
       float g = gout[base + i];
-      if (RELU) g = out[base + i] > 0.f ? g : 0.f;
+      if (RELU == 1) g = out[base + i] > 0.f ? g : 0.f;
+      if (RELU == 2) g = __builtin_fmaf(y[base + i], msc, msh) > 0.f ? g : 0.f;
       if (GADD) gadd[base + i] = g;
       gy[base + i] = A * g + Bc * y[base + i] + Cc;
     }
@@ -328,8 +352,8 @@ extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 20
 
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
-                                 float* save_mean, float* save_invstd, float* workspace, int B, int C, long long S,
-                                 mode_stream_t stream) {
+                                 float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
+                                 int C, long long S, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
@@ -337,10 +361,12 @@ extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* 
   MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)) && aligned16(workspace), MODE_ERR_UNSUPPORTED,
                "mode_bn_train_fwd: unaligned buffer");
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
+  MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: save_scale / save_shift come in pairs");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = pick_nsplit(C, S);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
-  BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, momentum, eps, nsplit,
+  BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
+               momentum, eps, nsplit,
                (double)B * (double)S};
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
@@ -361,7 +387,8 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
   MODE_REQUIRE(y && gamma && beta && running_mean && running_var && out, MODE_ERR_BAD_ARG, "mode_bn_eval_fwd: null pointer");
   MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_eval_fwd: unaligned buffer");
   hipStream_t st = mode::as_stream(stream);
-  BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, 0.f,
+  BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, nullptr,
+               nullptr, 0.f,
                eps, 0, 0.0};
   const int BC = B * C;
   const char* who = "mode_bn_eval_fwd";
@@ -374,37 +401,40 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
 }
 
 extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, int relu, float* gy, float* gadd, float* ggamma, float* gbeta,
-                                 int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream) {
+                                 const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
+                                 float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, long long S,
+                                 mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_bwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");
   MODE_REQUIRE(gout && y && gamma && save_mean && save_invstd && gy && ggamma && gbeta && workspace, MODE_ERR_BAD_ARG,
                "mode_bn_train_bwd: null pointer");
-  MODE_REQUIRE(!relu || out, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: the ReLU mask needs the forward output");
+  MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_bwd: save_scale / save_shift come in pairs");
+  MODE_REQUIRE(!relu || out || save_scale, MODE_ERR_BAD_ARG,
+               "mode_bn_train_bwd: the ReLU mask needs the forward output, or (no residual add) the forward's scale / shift");
   MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)) &&
                    aligned16(workspace),
                MODE_ERR_UNSUPPORTED, "mode_bn_train_bwd: unaligned buffer");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = pick_nsplit(C, S);
   float* partial = workspace;
-  if (relu)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, out, partial, B, C, S, nsplit);
+  // mask source: the forward output when given (mandatory if a residual was added before the ReLU), else y and the coefficients
+  const int mode = !relu ? 0 : (out ? 1 : 2);
+  const float* o = out ? out : y;
+  if (mode == 0)
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+  else if (mode == 1)
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   else
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, y, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
   const double count = (double)B * (double)S;
-  if (relu) {
-    if (gadd)
-      return launch_apply(bn_bwd_apply_kernel<true, true>, BC, S, st, who, gout, y, out, partial, gamma, save_mean, save_invstd, ggamma,
-                          gbeta, accumulate, nsplit, count, gy, gadd, C, S);
-    return launch_apply(bn_bwd_apply_kernel<true, false>, BC, S, st, who, gout, y, out, partial, gamma, save_mean, save_invstd, ggamma,
-                        gbeta, accumulate, nsplit, count, gy, gy, C, S);
-  }
-  if (gadd)
-    return launch_apply(bn_bwd_apply_kernel<false, true>, BC, S, st, who, gout, y, y, partial, gamma, save_mean, save_invstd, ggamma, gbeta,
-                        accumulate, nsplit, count, gy, gadd, C, S);
-  return launch_apply(bn_bwd_apply_kernel<false, false>, BC, S, st, who, gout, y, y, partial, gamma, save_mean, save_invstd, ggamma, gbeta,
-                      accumulate, nsplit, count, gy, gy, C, S);
+#define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
+  launch_apply(bn_bwd_apply_kernel<M, G>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean, save_invstd, ggamma, \
+               gbeta, accumulate, nsplit, count, gy, (G) ? gadd : gy, C, S)
+  if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
+  if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
+  return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);
+#undef MODE_BN_BWD_APPLY
 }

@@ -147,6 +147,12 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
   plan = None
   if SPHERE_FWD == 'window' and tuple(stride) == (1, 1) and w.shape[2] * w.shape[3] == 9 and tuple(out.shape[2:]) == tuple(x.shape[2:]):
     plan = sphere_plan(pos, w.shape[2], w.shape[3])
+    if plan is not None:
+      # one workgroup per 64x4 tile, sample and 128-channel slice: below ~one workgroup per CU the general kernel (64-pixel
+      # tiles) fills the chip better (measured at B = 1, 256x128: 22.9 vs 20.3 ms for the whole eval forward)
+      n_wg = sum(plan[1]) * x.shape[0] * groups * (-(-(w.shape[0] // groups) // 128))
+      if n_wg < 200:
+        plan = None
   with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
     if plan is not None:
       B, Ci, H, W, Co, Kh, Kw = dims[:7]
@@ -491,6 +497,9 @@ class BnActFunction(torch.autograd.Function):
     out = torch.empty_like(y)
     mean = torch.empty(C, dtype=torch.float32, device=y.device)
     invstd = torch.empty_like(mean)
+    # ReLU without a residual: the backward rebuilds the mask from y and these coefficients instead of reading `out`
+    from_y = bool(relu) and add is None
+    coef = torch.empty((2, C), dtype=torch.float32, device=y.device) if from_y else None
     nbytes = 4 * y.numel() * (3 + (1 if add is not None else 0))
     with torch.cuda.device_of(y), profiling.region('bn_train_fwd', nbytes, 0, y.device):
       ws = _bn_ws(C, y.device)
@@ -498,14 +507,15 @@ class BnActFunction(torch.autograd.Function):
                                     ptr(running_mean) if running_mean is not None else None,
                                     ptr(running_var) if running_var is not None else None,
                                     ptr(num_batches_tracked) if num_batches_tracked is not None else None, float(momentum), float(eps), int(relu),
-                                    ptr(out), ptr(mean), ptr(invstd), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_fwd')
-    ctx.save_for_backward(y, out if relu else None, gamma, beta, mean, invstd)
+                                    ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None, ptr(coef[1]) if from_y else None,
+                                    ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_fwd')
+    ctx.save_for_backward(y, out if (relu and not from_y) else None, gamma, beta, mean, invstd, coef)
     ctx.relu, ctx.has_add = bool(relu), add is not None
     return out
 
   @staticmethod
   def backward(ctx, gout):
-    y, out, gamma, beta, mean, invstd = ctx.saved_tensors
+    y, out, gamma, beta, mean, invstd, coef = ctx.saved_tensors
     gout = gout.contiguous()
     B, C, S = _bcs(y)
     gy = torch.empty_like(y)
@@ -515,11 +525,12 @@ class BnActFunction(torch.autograd.Function):
     fused = sink_g is not None and sink_b is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
     ggamma = sink_g if fused else torch.empty_like(gamma)
     gbeta = sink_b if fused else torch.empty_like(gamma)
-    nbytes = 4 * y.numel() * (2 * (2 + (1 if ctx.relu else 0)) + 1 + (1 if need_gadd else 0))
+    nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
     with torch.cuda.device_of(y), profiling.region('bn_train_bwd', nbytes, 0, y.device):
       ws = _bn_ws(C, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
-                                    int(ctx.relu), ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
+                                    ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
+                                    ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
                                     int(fused), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_bwd')
     if fused:
       ggamma = gbeta = None
