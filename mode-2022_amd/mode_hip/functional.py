@@ -88,6 +88,7 @@ def _check_pos(pos, x, Kh, Kw):
 _plan_cache = {}
 _plan_lock = threading.Lock()
 SPHERE_LAYOUT = os.environ.get('MODE_SPHERE_LAYOUT', 'transposed')  # windowed kernels on plane-transposed copies | 'nchw'
+SPHERE_FWD_MIN_WG = 200  # fewer workgroups than this: the windowed forward under-fills the chip, use the general kernel
 SPHERE_FWD = os.environ.get('MODE_SPHERE_FWD', 'window')  # 'window' (LDS-window kernels where the table allows) | 'gather'
 
 
@@ -151,7 +152,7 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
       # one workgroup per 64x4 tile, sample and 128-channel slice: below ~one workgroup per CU the general kernel (64-pixel
       # tiles) fills the chip better (measured at B = 1, 256x128: 22.9 vs 20.3 ms for the whole eval forward)
       n_wg = sum(plan[1]) * x.shape[0] * groups * (-(-(w.shape[0] // groups) // 128))
-      if n_wg < 200:
+      if n_wg < SPHERE_FWD_MIN_WG:
         plan = None
   with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
     if plan is not None:
