@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NT) void head_fwd_kernel(const float* __restrict__ 
 // Backward kernel 1: G[b][d4][h][w] = sum_d (lerp weight of d4 at d) * gpred * p_d * (d - pred)
 __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restrict__ L, const float* __restrict__ gpred,
                                                           float* __restrict__ G, HDims d) {
-  extern __shared__ __attribute__((aligned(16))) float u[];  // [2][D4][NT]: logits column, then its gradient
+  extern __shared__ __attribute__((aligned(16))) float u[];  // [D4][NT]: logits column
   const long long npix = (long long)d.B * d.H * d.W;
   const long long pix = (long long)blockIdx.x * NT + threadIdx.x;
   if (pix >= npix) return;
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restric
   const int h = (int)((pix / d.W) % d.H);
   const int b = (int)(pix / ((long long)d.W * d.H));
   float* ucol = u + threadIdx.x;
-  float* gcol = u + d.D4 * NT + threadIdx.x;
   const float m = fill_column(L + (long long)b * d.D4 * d.H4 * d.W4, d, h, w, ucol);
   float s0 = 0.f, s1 = 0.f;
   for (int dd = 0; dd < d.D; ++dd) {
@@ -109,19 +108,36 @@ __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restric
   }
   const float p = s1 / s0;
   const float g = gpred[pix] / s0;
-  for (int k = 0; k < d.D4; ++k) gcol[k * NT] = 0.f;
+  // The source node d0 of disparity dd grows monotonically with dd (d1 = d0 + 1, or d0 at the last node): the gradient of a
+  // node is complete once d0 has moved past it, so two running sums replace the read-modify-write column in LDS (half the LDS:
+  // three workgroups per CU instead of one) and every node is written exactly once, straight to G, in a fixed order.
+  const long long hw = (long long)d.H * d.W;
+  float* Gb = G + (long long)b * d.D4 * hw + (long long)h * d.W + w;
+  int cur = 0;            // node held in a0; a1 holds node cur + 1
+  float a0 = 0.f, a1 = 0.f;
   for (int dd = 0; dd < d.D; ++dd) {
     int d0, d1;
     float ld;
     src_index(dd, d.sd, d.D4, d0, d1, ld);
+    while (cur < d0) {  // flush finished nodes (nodes skipped by a coarse disparity axis get their zero)
+      Gb[(long long)cur * hw] = a0;
+      a0 = a1;
+      a1 = 0.f;
+      ++cur;
+    }
     const float v = (1.f - ld) * ucol[d0 * NT] + ld * ucol[d1 * NT];
     const float gv = g * __expf(v - m) * ((float)dd - p);
-    gcol[d0 * NT] += (1.f - ld) * gv;
-    gcol[d1 * NT] += ld * gv;
+    a0 += (1.f - ld) * gv;
+    if (d1 != d0)
+      a1 += ld * gv;
+    else
+      a0 += ld * gv;
   }
-  const long long hw = (long long)d.H * d.W;
-  float* Gb = G + (long long)b * d.D4 * hw + (long long)h * d.W + w;
-  for (int k = 0; k < d.D4; ++k) Gb[k * hw] = gcol[k * NT];
+  for (; cur < d.D4; ++cur) {
+    Gb[(long long)cur * hw] = a0;
+    a0 = a1;
+    a1 = 0.f;
+  }
 }
 
 // Backward kernel 2: gL[b][d4][h4][w4] = sum_{h,w} wh(h,h4) * ww(w,w4) * G[b][d4][h][w]
@@ -140,6 +156,17 @@ __global__ __launch_bounds__(NT) void head_bwd_gather_kernel(const float* __rest
   const int whi = d.sw > 0.f ? min(d.W - 1, (int)ceilf((float)(w4 + 1) / d.sw) + 1) : d.W - 1;
   const float* Gp = G + bd * (long long)d.H * d.W;
   float sum = 0.f;
+  constexpr int MAXW = 16;
+  const bool small = whi - wlo + 1 <= MAXW;  // x4 upsampling: 10-12 columns; weights of the columns computed once, not per row
+  float wwv[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int w = wlo + i;
+    int w0, w1;
+    float lw;
+    src_index(min(w, d.W - 1), d.sw, d.W4, w0, w1, lw);
+    wwv[i] = (small && w <= whi) ? (w0 == w4 ? 1.f - lw : 0.f) + (w1 == w4 ? lw : 0.f) : 0.f;
+  }
   for (int h = hlo; h <= hhi; ++h) {
     int h0, h1;
     float lh;
@@ -147,12 +174,19 @@ __global__ __launch_bounds__(NT) void head_bwd_gather_kernel(const float* __rest
     const float wh = (h0 == h4 ? 1.f - lh : 0.f) + (h1 == h4 ? lh : 0.f);
     if (wh == 0.f) continue;
     float rs = 0.f;
-    for (int w = wlo; w <= whi; ++w) {
-      int w0, w1;
-      float lw;
-      src_index(w, d.sw, d.W4, w0, w1, lw);
-      const float ww = (w0 == w4 ? 1.f - lw : 0.f) + (w1 == w4 ? lw : 0.f);
-      if (ww != 0.f) rs += ww * Gp[(long long)h * d.W + w];
+    if (small) {
+      const float* row = Gp + (long long)h * d.W + wlo;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i)
+        if (wwv[i] != 0.f) rs += wwv[i] * row[i];
+    } else {
+      for (int w = wlo; w <= whi; ++w) {
+        int w0, w1;
+        float lw;
+        src_index(w, d.sw, d.W4, w0, w1, lw);
+        const float ww = (w0 == w4 ? 1.f - lw : 0.f) + (w1 == w4 ? lw : 0.f);
+        if (ww != 0.f) rs += ww * Gp[(long long)h * d.W + w];
+      }
     }
     sum += wh * rs;
   }
@@ -161,7 +195,7 @@ __global__ __launch_bounds__(NT) void head_bwd_gather_kernel(const float* __rest
 
 int make_hdims(HDims& d, int B, int D4, int H4, int W4, int D, int H, int W, const char* who) {
   MODE_REQUIRE(B >= 0 && D4 > 0 && H4 > 0 && W4 > 0 && D > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
-  MODE_REQUIRE((size_t)2 * D4 * NT * sizeof(float) <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D4 = %d too large for LDS", who, D4);
+  MODE_REQUIRE((size_t)D4 * NT * sizeof(float) <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D4 = %d too large for LDS", who, D4);
   d.B = B; d.D4 = D4; d.H4 = H4; d.W4 = W4; d.D = D; d.H = H; d.W = W;
   d.sd = D > 1 ? (float)(D4 - 1) / (float)(D - 1) : 0.f;
   d.sh = H > 1 ? (float)(H4 - 1) / (float)(H - 1) : 0.f;
@@ -199,7 +233,7 @@ extern "C" int mode_head_bwd(const float* logits, const float* gpred, float* glo
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(logits && gpred && glogits, MODE_ERR_BAD_ARG, "mode_head_bwd: null pointer");
   MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_head_bwd: workspace required");
-  const size_t lds = (size_t)2 * D4 * NT * sizeof(float);
+  const size_t lds = (size_t)D4 * NT * sizeof(float);
   rc = mode::allow_lds(head_bwd_pix_kernel, lds, "mode_head_bwd");
   if (rc != MODE_OK) return rc;
   hipStream_t st = mode::as_stream(stream);
