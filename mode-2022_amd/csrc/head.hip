@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT) void head_bwd_gather_kernel(const float* __rest
       const float* row = Gp + (long long)h * d.W + wlo;
 #pragma unroll
       for (int i = 0; i < MAXW; ++i)
-        if (wwv[i] != 0.f) rs += wwv[i] * row[i];
+        if (wwv[i] != 0.f) rs += wwv[i] * row[i];  // (unconditional loads of all 16 columns measured slower: 0.63 vs 0.50 ms)
     } else {
       for (int w = wlo; w <= whi; ++w) {
         int w0, w1;

@@ -454,7 +454,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
     float we[EC];
 #pragma unroll
     for (int e = 0; e < EC; ++e) {
-      const int2 ent = entries[e < cnt ? beg + e : 0];  // entries[] always holds at least one element
+      // always a valid element of this row's list (or element 0): the load stays unconditional, the selects come after
+      const int2 ent = entries[beg + min(e, max(cnt - 1, 0))];
       pe[e] = e < cnt ? ent.x : 0;
       we[e] = e < cnt ? __int_as_float(ent.y) : 0.f;
     }

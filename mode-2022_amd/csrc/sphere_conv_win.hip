@@ -311,8 +311,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_tall_kernel(const flo
 //   of 32 input channels (LDS, [c][col][row], odd channel pitch: the 32 lanes of a half-wave read 32 channels).
 // Work item = half a plan tile (32 rows x 4 columns) of one sample, processed column by column (32 pixels = 16 k-steps).
 // grid = (S, ceil(Cig/32), G*MG); split-K slice s owns the items s, s+S, ...; 8 waves: wave v owns tap v for all 4 o-tiles,
-// tap 8 is shared: wave v takes the pixels p = v (mod 8) of every column.  Partial sums go to
-// part[s][z][cg][slot 0..15][128 o][32 c] (slots 8..15 = the waves' shares of tap 8), summed in fixed order by reduce_gw_win.
+// tap 8 is shared: wave v takes the pixels p = v (mod 8) of every column (the 8 shares are summed through LDS in wave order
+// at the end).  Partial sums go to part[s][z][cg][tap][128 o][32 c], summed in fixed order by reduce_gw_win.
 // The contraction runs on v_mfma_f32_32x32x1_2b_f32: ONE pixel per instruction, two o-tiles (the two 32x32 blocks) at a time.
 // With one pixel per step the sampling record is the same for the whole wave, so it lives in SGPRs (scalar loads from the
 // record table) and the bilinear combine is 4 VALU instructions with scalar weights -- the 32x32x2 form (two pixels per step,
@@ -326,11 +326,11 @@ constexpr int BW_TH = 32;                  // rows per work item
 constexpr int BW_WR = BW_TH + 17;          // its window rows (49)
 constexpr int BW_CP = WC * BW_WR + 1;      // odd channel pitch of the x window
 constexpr int BW_GP = BW_TH + 1;           // gy row pitch
-constexpr int BW_SLOTS = 16;                // 8 own taps + 8 per-wave shares of tap 8
+constexpr int BW_SLOTS = KT;                // one partial per tap (the waves' shares of tap 8 are summed in the kernel)
 constexpr int BW_XW = BW_CG * BW_CP + BW_WR + 8;  // + slack: zero-weight corners may point just past the last window
 constexpr int BW_COLBUF = 128 * BW_GP;  // gy column
-constexpr int BW_LDS_FLOATS = BW_XW + 2 * BW_COLBUF;
-constexpr int BW_NXW = BW_CG;  // x-window words per thread: one per channel
+constexpr int BW_LDS_FLOATS = 2 * BW_XW + 2 * BW_COLBUF;  // x window and gy column, both double-buffered
+constexpr int BW_NXW = BW_CG / TW;  // x-window words per thread and column step: the next item's window arrives in 4 parts
 constexpr int BW_NREC = KT * BW_TH;                                      // records per column (288)
 
 __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* __restrict__ gy, const float* __restrict__ x,
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
                                                                    const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
                                                                    int ntiles, int S) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xw = smem;  // [32][BW_CP]
+  float* colbuf = smem + 2 * BW_XW;  // smem: [2][x window 32 x BW_CP] [2][gy column]
   constexpr int WRP = BW_WR;
   const int s = blockIdx.x, cg = blockIdx.y;
   const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
@@ -387,23 +387,24 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
   // contiguous axis of the planes (columns for NCHW, rows for transposed planes).
   const int xcol = d.sh == 1 ? tid >> 6 : tid & (WC - 1), xrow = d.sh == 1 ? tid & 63 : tid >> 3;
   const bool xrow_ok = xrow < WRP;
-  auto issue_xw = [&](const Item& it) {
-    const bool ok0 = xrow_ok && it.cbase + xcol < d.W;
+  // Loads are issued unconditionally from clamped addresses and masked when they are written to LDS: a load whose only
+  // consumer is a select on the same condition gets sunk into a branch by the compiler, with a full vmcnt(0) wait per load
+  // (measured: 7.6k cycles per column spent "issuing" 12 loads).
+  bool pxw_ok = false;   // row / column of this thread's window words inside the image (next item)
+  unsigned pgy_ok = 0;   // bit u: pgy[u] is a real value (next column)
+  auto issue_xw = [&](const Item& it, int part) {  // channels part*8 .. part*8+7 of the window of item `it`
+    pxw_ok = xrow_ok && it.cbase + xcol < d.W;
     const int grow = (it.rbase + (xrow_ok ? xrow : 0)) % d.H;
     const float* xg = x + ((long long)it.b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
-                      (ok0 ? (long long)grow * d.sh + (long long)(it.cbase + xcol) * d.sw : 0);
+                      (pxw_ok ? (long long)grow * d.sh + (long long)(it.cbase + xcol) * d.sw : 0);
 #pragma unroll
-    for (int c = 0; c < BW_CG; ++c) {
-      const bool ok = ok0 && c < cmax;
-      const float v = xg[ok ? (long long)c * HW : 0];
-      pxw[c] = ok ? v : 0.f;
-    }
+    for (int c = 0; c < BW_NXW; ++c) pxw[c] = xg[(long long)min(part * BW_NXW + c, cmax - 1) * HW];
   };
-  auto commit_xw = [&]() {
+  auto commit_xw = [&](float* xwdst, int part) {
     if (xrow_ok) {
-      float* dst = xw + xcol * WRP + xrow;
+      float* dst = xwdst + xcol * WRP + xrow;
 #pragma unroll
-      for (int c = 0; c < BW_CG; ++c) dst[c * BW_CP] = pxw[c];
+      for (int c = 0; c < BW_NXW; ++c) dst[(part * BW_NXW + c) * BW_CP] = (pxw_ok && part * BW_NXW + c < cmax) ? pxw[c] : 0.f;
     }
   };
   auto issue_col = [&](const Item& it, int wc) {
@@ -411,12 +412,12 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
     const bool pok = h < d.H && w < d.W;
     const float* gyb = gy + ((long long)it.b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
                        (pok ? (long long)h * d.sh + (long long)w * d.sw : 0);
+    pgy_ok = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int o = go0 + 16 * u;
-      const bool ok = pok && o < omax;
-      const float v = gyb[ok ? (long long)o * HW : 0];
-      pgy[u] = ok ? v : 0.f;
+      pgy[u] = gyb[(long long)min(o, omax - 1) * HW];
+      pgy_ok |= (pok && o < omax) ? (1u << u) : 0u;
     }
     const long long rcol = (((long long)it.ti * 2 + it.hf) * TW + wc) * BW_NREC;
     prw = rec_w[rcol + wave * BW_TH + j];
@@ -426,25 +427,28 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
   };
   auto commit_col = [&](float* cb) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cb[(go0 + 16 * u) * BW_GP + gpx] = pgy[u];
+    for (int u = 0; u < 8; ++u) cb[(go0 + 16 * u) * BW_GP + gpx] = (pgy_ok >> u & 1u) ? pgy[u] : 0.f;
   };
 
   // first item: window and first column
   Item cur = item_of(s);
-  issue_xw(cur);
-  issue_col(cur, 0);
   __syncthreads();  // zero fill done
-  commit_xw();
-  commit_col(smem + BW_XW);
+  for (int part = 0; part < TW; ++part) {
+    issue_xw(cur, part);
+    commit_xw(smem, part);
+  }
+  issue_col(cur, 0);
+  commit_col(colbuf);
   __syncthreads();
 
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  int buf = 0;
+  int buf = 0, xbuf = 0;
   for (int t = s; t < T; t += S) {
     const bool more_items = t + S < T;
     const Item nxt = item_of(more_items ? t + S : t);
+    const float* xw = smem + xbuf * BW_XW;
     for (int wc = 0; wc < TW; ++wc) {
-      const float* cb = smem + BW_XW + buf * BW_COLBUF;
+      const float* cb = colbuf + buf * BW_COLBUF;
       const bool last_col = wc == TW - 1;
       const bool have_next = !last_col || more_items;
       // The sampling record of a pixel is the same for every lane: lane l holds the record of pixel l & 31 (vector loads,
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
       const float4 rw = prw, rw8 = prw8;
       const int ro = pro, ro8 = pro8;
       if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
-      if (last_col && more_items) issue_xw(nxt);
+      if (more_items) issue_xw(nxt, wc);  // a quarter of the next item's window per column, into the other window buffer
 
       // A operand: block 0 (lanes 0-31) = o-tile 0 / 2, block 1 (lanes 32-63) = o-tile 1 / 3
       const float* ap = cb + (half * 32 + j) * BW_GP;
@@ -512,15 +516,14 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
         }
       }
 
-      if (have_next) commit_col(smem + BW_XW + (buf ^ 1) * BW_COLBUF);  // the other buffer: nobody reads it now
-      if (last_col && more_items) {
-        __syncthreads();  // everyone is done with the x window of this item
-        commit_xw();
-      }
+      // the other buffers: nobody reads them now
+      if (have_next) commit_col(colbuf + (buf ^ 1) * BW_COLBUF);
+      if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);
       __syncthreads();
       buf ^= 1;
     }
     cur = nxt;
+    xbuf ^= 1;
   }
 
   float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
@@ -530,11 +533,26 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
     for (int r = 0; r < 32; ++r) {
       const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
       pb[((long long)wave * 128 + o) * BW_CG + j] = accp[pr][r];
-      pb[((long long)(8 + wave) * 128 + o) * BW_CG + j] = acc8p[pr][r];
     }
+  // tap 8: the 8 waves' shares, added in wave order through LDS (deterministic), then written as one partial
+  float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier, nobody reads the windows any more
+  for (int v = 0; v < 8; ++v) {
+    if (wave == v) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
+          float* q = red + o * BW_CG + j;
+          *q = v == 0 ? acc8p[pr][r] : *q + acc8p[pr][r];
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
 }
 
-// gw[o][c][k] += sum over slices (fixed order) of slot k (slots 8..15 for tap 8); one thread per (z, cg, k, o, c), c fastest:
+// gw[o][c][k] += sum over slices (fixed order) of the tap's partial; one thread per (z, cg, k, o, c), c fastest:
 // coalesced reads of the partials
 __global__ void reduce_gw_win(const float* __restrict__ part, float* __restrict__ gw, WinDims d, int S, int NCG) {
   const int GZ = d.G * d.MG;
@@ -553,15 +571,17 @@ __global__ void reduce_gw_win(const float* __restrict__ part, float* __restrict_
     const int ol = mg * 128 + row, c = cg * BW_CG + cl;
     if (ol >= d.Cog || c >= d.Cig) continue;
     const float* pp = part + ((((long long)z * NCG + cg) * BW_SLOTS + k) * 128 + row) * BW_CG + cl;
-    float sum = 0.f;  // fixed order: slice by slice, tap 8: wave share by wave share
-    const int nshare = k == KT - 1 ? 8 : 1;
-    for (int s0 = 0; s0 < S; ++s0) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = u < nshare ? pp[s0 * stride + (long long)u * 128 * BW_CG] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) sum += v[u];
+    // fixed association (4 interleaved running sums over the slices): deterministic, 4 independent loads in flight
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int e = 0;
+    for (; e + 3 < S; e += 4) {
+      a0 += pp[(long long)e * stride];
+      a1 += pp[(long long)(e + 1) * stride];
+      a2 += pp[(long long)(e + 2) * stride];
+      a3 += pp[(long long)(e + 3) * stride];
     }
+    for (; e < S; ++e) a0 += pp[(long long)e * stride];
+    const float sum = (a0 + a1) + (a2 + a3);
     gw[((long long)(g * d.Cog + ol) * d.Cig + c) * KT + k] += sum;
   }
 }

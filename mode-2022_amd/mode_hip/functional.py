@@ -137,8 +137,9 @@ def sphere_plan(pos, kh, kw):
     return plan
 
 
-def sphere_conv_fwd(x, pos, w, out, stride, groups):
-  """Writes `out` (B,Co,Ho,Wo) in place.  Replaces sphere_conv_forward_cuda (sphere_conv_cuda.cpp:129-210)."""
+def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
+  """Writes `out` (B,Co,Ho,Wo) in place.  Replaces sphere_conv_forward_cuda (sphere_conv_cuda.cpp:129-210).
+  return_transposed: return the plane-transposed copy of x the windowed kernel used (None if it did not run) instead of out."""
   require_gpu(x, pos, w, out)
   require_f32c(x, pos, w, out)
   _check_pos(pos, x, w.shape[2], w.shape[3])
@@ -159,6 +160,7 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
       B, Ci, H, W, Co, Kh, Kw = dims[:7]
       tiles, (n0, n1, n2) = plan[:2]
       wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+      xt = None
       if SPHERE_LAYOUT == 'transposed':
         xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
         check(lib().mode_sphere_conv_fwd_win(ptr(xt), ptr(pos), ptr(w), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
@@ -168,9 +170,10 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups):
         check(lib().mode_sphere_conv_fwd_win(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
                                              Kw, groups, 0, stream_of(x)), 'mode_sphere_conv_fwd_win')
     else:
+      xt = None
       wp = _wpack(w, groups)
       check(lib().mode_sphere_conv_fwd(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), *dims, stream_of(x)), 'mode_sphere_conv_fwd')
-  return out
+  return xt if return_transposed else out
 
 
 _adjoint_cache = {}
@@ -225,11 +228,12 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False):
   return gx
 
 
-SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'gather')  # 'gather' | 'window' (not faster yet: DESIGN.md)
+SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'window')  # 'window' (where the table allows) | 'gather'
 
 
-def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
-  """Accumulates into `gw` (Co,Ci/g,Kh,Kw) (caller zero-fills, sphere_conv.py:63)."""
+def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None):
+  """Accumulates into `gw` (Co,Ci/g,Kh,Kw) (caller zero-fills, sphere_conv.py:63).  x_transposed: the plane-transposed copy
+  of x kept from the forward, if any (saves rebuilding it for the windowed kernel)."""
   require_gpu(gy, pos, x, gw)
   require_f32c(gy, pos, x, gw)
   dims = _sc_dims(x.shape, gw.shape, gy.shape[2:], stride, groups)
@@ -246,7 +250,10 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups):
       tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off = plan
       n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, G, n0, nrest)
       ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-      gyt, xt = (transpose_planes(gy), transpose_planes(x)) if SPHERE_LAYOUT == 'transposed' else (None, None)
+      gyt = xt = None
+      if SPHERE_LAYOUT == 'transposed':
+        gyt = transpose_planes(gy)
+        xt = x_transposed if x_transposed is not None and tuple(x_transposed.shape) == (B, Ci, W, H) else transpose_planes(x)
       check(lib().mode_sphere_conv_bwd_weight_win(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
                                                   ptr(rec_off), ptr(rest), nrest, B, Ci, H, W, Co, Kh, Kw, G,
                                                   ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,

@@ -66,26 +66,32 @@ def _shape_check(input, position, grad_output, weight, kH, kW, sH, sW, pH, pW, d
 
 
 def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, columns, kernel_h, kernel_w, stride_h, stride_w,
-                             pad_h, pad_w, dilation_h, dilation_w, group, has_bias):
+                             pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *, keep_transposed=None):
+  """The 17 positional arguments of the reference op.  Keyword-only extension: pass a list as keep_transposed and the
+  plane-transposed copy of `input` that the windowed kernel made (if it ran) is appended to it, for
+  sphere_conv_backward_cuda(input_transposed=...)."""
   Ho, Wo = _shape_check(input, position, None, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
                         dilation_w, group)
   if tuple(output.shape) != (input.size(0), weight.size(0), Ho, Wo):
     raise RuntimeError('output has shape %s, expected %s' % (tuple(output.shape), (input.size(0), weight.size(0), Ho, Wo)))
-  _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group)
+  xt = _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group, return_transposed=True)
+  if keep_transposed is not None and xt is not None:
+    keep_transposed.append(xt)
   if has_bias:
     output += bias.view(1, -1, 1, 1)  # cpp:207-209
 
 
 def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad_input, grad_weight, grad_bias, grad_output,
                               kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *,
-                              overwrite_grad_input=False):
-  """The 20 positional arguments of the reference op.  Keyword-only extension: overwrite_grad_input=True lets the caller
-  pass an uninitialised grad_input (it is written, not added to), which saves the zero-fill and one read of the tensor."""
+                              overwrite_grad_input=False, input_transposed=None):
+  """The 20 positional arguments of the reference op.  Keyword-only extensions: overwrite_grad_input=True lets the caller
+  pass an uninitialised grad_input (it is written, not added to), which saves the zero-fill and one read of the tensor;
+  input_transposed = the plane-transposed copy of `input` kept from the forward (see sphere_conv_forward_cuda)."""
   _shape_check(input, position, grad_output, grad_weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
                dilation_w, group)
   gy = grad_output.contiguous()
   pos = position.contiguous()
   _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group, overwrite=overwrite_grad_input)
-  _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group)
+  _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group, x_transposed=input_transposed)
   if has_bias:
     grad_bias += gy.sum((0, 2, 3))  # cpp:316-322
