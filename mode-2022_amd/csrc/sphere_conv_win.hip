@@ -474,28 +474,32 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
         return __builtin_fmaf(bcast(w.w, px), raw[3],
                               __builtin_fmaf(bcast(w.z, px), raw[2], __builtin_fmaf(bcast(w.y, px), raw[1], bcast(w.x, px) * raw[0])));
       };
-      // own tap: all 32 pixels; the operands of pixel px+2 are read while the MFMAs of pixel px run
+      // own tap: all 32 pixels, software-pipelined three deep: while the MFMAs of pixel px run, the B value of pixel px+1 is
+      // combined (4 FMAs on words read one step earlier) and the LDS words of pixel px+2 are requested
       {
-        float raw[3][4], a[3][2];
+        float raw[2][4], a[3][2];
 #pragma unroll
         for (int p0 = 0; p0 < 2; ++p0) {
           load_x(__builtin_amdgcn_readlane(ro, p0), raw[p0]);
           a[p0][0] = ap[p0];
           a[p0][1] = ap[64 * BW_GP + p0];
         }
+        float bv = combine(rw, 0, raw[0]);
 #pragma unroll
         for (int px = 0; px < BW_TH; ++px) {
           const int c3 = px % 3, n3 = (px + 2) % 3;
+          float bv_next = 0.f;
+          if (px + 1 < BW_TH) bv_next = combine(rw, px + 1, raw[(px + 1) & 1]);
           if (px + 2 < BW_TH) {
-            load_x(__builtin_amdgcn_readlane(ro, px + 2), raw[n3]);
+            load_x(__builtin_amdgcn_readlane(ro, px + 2), raw[px & 1]);  // the slot of pixel px is free again
             a[n3][0] = ap[px + 2];
             a[n3][1] = ap[64 * BW_GP + px + 2];
           }
           __builtin_amdgcn_sched_barrier(0);
-          const float bv = combine(rw, px, raw[c3]);
           accp[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][0], bv, accp[0], 0, 0, 0);
           accp[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][1], bv, accp[1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          bv = bv_next;
         }
       }
       // this wave's share of tap 8: pixels wave, wave + 8, wave + 16, wave + 24
