@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timings at the benchmark shapes (GPU box).  Prints one line per kernel: avg ms, GB/s, TFLOP/s.
 
-  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,conv3d,head,vendor,stages,export]
+  python tools/microbench.py [--batch 2] [--iters 10] [--only cost,sphere,conv3d,head,vendor,stages,export,fusion]
 """
 import argparse
 import os
@@ -39,12 +39,42 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--batch', type=int, default=2)
   ap.add_argument('--iters', type=int, default=10)
-  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages,export')
+  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages,export,fusion')
   a = ap.parse_args()
   only = a.only.split(',')
   dev = 'cuda:0'
   B = a.batch
   torch.manual_seed(0)
+
+  if 'fusion' in only:  # ModeFusion(1000, [32, 64, 128, 256], {'depth': 12, 'rgb': 12}) at 1024x512
+    import models
+    from models import stage3d
+    sys.path.insert(0, ROOT)
+    from oracle import fusion_ref
+    net = models.ModeFusion(1000, [32, 64, 128, 256], {'depth': 12, 'rgb': 12}).to(dev).train()
+    depthes = [torch.rand(B, 1, 1024, 512, device=dev) * 50 for _ in range(6)]
+    confs = [torch.rand(B, 1, 1024, 512, device=dev) for _ in range(6)]
+    rgbs = [torch.rand(B, 3, 1024, 512, device=dev) for _ in range(4)]
+    gt = torch.rand(B, 1024, 512, device=dev) * 60
+
+    def fusion_step():
+      net.zero_grad(set_to_none=True)
+      fusion_ref.training_loss(net(depthes, confs, rgbs), gt, 1000).backward()
+
+    def fusion_eval():
+      with torch.no_grad():
+        net(depthes, confs, rgbs)
+
+    report('ModeFusion fwd+bwd B=%d (fused BatchNorm kernels)' % B, timeit(fusion_step, max(3, a.iters // 2)))
+    net.eval()
+    report('ModeFusion eval fwd B=%d' % B, timeit(fusion_eval, max(3, a.iters // 2)))
+    net.train()
+    prev = stage3d.BN_BACKEND
+    stage3d.BN_BACKEND = 'vendor'
+    report('  (same step with torch BatchNorm + ReLU)', timeit(fusion_step, max(3, a.iters // 2)))
+    stage3d.BN_BACKEND = prev
+    del net, depthes, confs, rgbs, gt
+    torch.cuda.empty_cache()
 
   if 'export' in only:  # disparity -> depth -> other camera's view, 1024x512
     import math
