@@ -160,8 +160,9 @@ class sphere_feature_extraction(nn.Module):
 
 
 class feature_extraction(nn.Module):
-  """PSMNet SPP feature extractor, used only by ModeDisparity(conv='Regular') (submodule.py:205-268).
-  Stock layers only; kept so that the constructor contract is complete."""
+  """PSMNet SPP feature extractor of ModeDisparity(conv='Regular') (submodule.py:205-268).  Vendor 2D
+  convolutions, poolings and bilinear upsampling; every BatchNorm (+ residual add) (+ ReLU) on the fused HIP kernels, like the
+  spherical extractor."""
 
   def __init__(self):
     super(feature_extraction, self).__init__()
@@ -189,5 +190,6 @@ class feature_extraction(nn.Module):
     raw = self.layer2(self.layer1(_run_convbn_relu_chain(self.firstconv, x)))
     skip = self.layer4(self.layer3(raw))
     size = skip.shape[2:]
-    pooled = [F.interpolate(getattr(self, 'branch%d' % i)(skip), size, mode='bilinear', align_corners=True) for i in (4, 3, 2, 1)]
+    pooled = [F.interpolate(_run_convbn_relu_chain(getattr(self, 'branch%d' % i), skip), size, mode='bilinear', align_corners=True)
+              for i in (4, 3, 2, 1)]
     return _run_convbn_relu_chain(self.lastconv, torch.cat([raw, skip] + pooled, 1))
