@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 3 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 4 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -229,14 +229,17 @@ int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float
  *        The ReLU mask comes from `out`; when no residual was added, `out` may be NULL and the mask is rebuilt bit-exactly
  *        from y with the float32 save_scale / save_shift (C floats each, optional outputs of the forward): one tensor less
  *        to read in both backward passes.
- * `workspace` >= mode_bn_workspace_bytes(C) for the training calls.
+ * groups: statistics over `groups` consecutive sub-batches of B / groups samples each (1 = the whole batch) -- what `groups`
+ *        consecutive calls of the module on the sub-batches would compute, including the order of the running-statistics
+ *        updates; save_* hold groups * C values.  Used to run the left and right images through the shared extractor as one batch.
+ * `workspace` >= mode_bn_workspace_bytes(C * groups) for the training calls.
  */
 size_t mode_bn_workspace_bytes(int C);
 
 int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
                       float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
-                      float* workspace, int B, int C, long long S, mode_stream_t stream);
+                      float* workspace, int B, int C, long long S, int groups, mode_stream_t stream);
 
 int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int relu, float* out, int B, int C, long long S,
@@ -245,7 +248,7 @@ int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const
 int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
                       const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                       float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
-                      long long S, mode_stream_t stream);
+                      long long S, int groups, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Export-stage geometry: what happens between the disparity network and the fusion network.

@@ -37,16 +37,21 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [8] 
   }
 }
 
-// grid = (nsplit, C).  partial[(c*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
+// Statistics can be taken over GROUPS of samples: group g = samples [g*B/G, (g+1)*B/G) (G = 1: the whole batch).  The paired
+// feature extractor pushes the left and the right images through the network as one batch while keeping the reference's
+// per-call BatchNorm statistics: two groups.
+// grid = (nsplit, C, G).  partial[((g*C + c)*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
 __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int B, int C,
                                                       long long S, int nsplit) {
   __shared__ float sh[8];
   const int c = blockIdx.y, split = blockIdx.x;
+  const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
+  const long long prow = (long long)blockIdx.z * C + c;
   const long long S4 = S >> 2;
   const long long per_b = (S4 + nsplit - 1) / nsplit;
   const long long lo = split * per_b, hi = min(S4, lo + per_b);
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b0 + Bg; ++b) {
     const float4* p = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * S);
     for (long long i = lo + threadIdx.x; i < hi; i += NT) {
       const float4 v = p[i];
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   }
   block_sum2(s0, s1, sh);
   if (threadIdx.x == 0) {
-    partial[((long long)c * nsplit + split) * 2] = s0;
-    partial[((long long)c * nsplit + split) * 2 + 1] = s1;
+    partial[(prow * nsplit + split) * 2] = s0;
+    partial[(prow * nsplit + split) * 2 + 1] = s1;
   }
 }
 
@@ -91,6 +96,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
   __syncthreads();
   s0 = (shd[0] + shd[1]) + (shd[2] + shd[3]);
   s1 = (shd[4] + shd[5]) + (shd[6] + shd[7]);
+  __syncthreads();  // shd may be reused by the next call
 }
 
 // Where the affine coefficients of the apply pass come from.
@@ -111,7 +117,9 @@ struct BnCoefArgs {
   float* save_shift;  // mask from y with exactly these instead of reading `out`
   float momentum, eps;
   int nsplit;
-  double count;
+  double count;  // elements per (group, channel)
+  int groups;    // statistics groups (TRAIN)
+  int Bg;        // samples per group
 };
 
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
@@ -123,8 +131,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   const int bc = blockIdx.y;
   const int c = bc % C;
   if (TRAIN) {
+    const int b = bc / C, g = b / k.Bg;
     double s0, s1;
-    reduce_partials(k.partial, c, k.nsplit, s0, s1, shd);
+    reduce_partials(k.partial, g * C + c, k.nsplit, s0, s1, shd);
     if (threadIdx.x == 0) {
       const double mean = s0 / k.count;
       double var = s1 / k.count - mean * mean;
@@ -133,21 +142,32 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       const double sc = (double)k.gamma[c] * invstd;
       coef[0] = (float)sc;
       coef[1] = (float)((double)k.beta[c] - mean * sc);
-      if (blockIdx.x == 0 && bc < C) {
-        k.save_mean[c] = (float)mean;
-        k.save_invstd[c] = (float)invstd;
+      if (blockIdx.x == 0 && b == g * k.Bg) {  // first sample of the group: its saved statistics
+        k.save_mean[g * C + c] = (float)mean;
+        k.save_invstd[g * C + c] = (float)invstd;
         if (k.save_scale) {
-          k.save_scale[c] = coef[0];
-          k.save_shift[c] = coef[1];
+          k.save_scale[g * C + c] = coef[0];
+          k.save_shift[g * C + c] = coef[1];
         }
-        if (k.running_mean) {
+      }
+    }
+    // running statistics: one block per channel applies the groups' updates IN ORDER (what consecutive calls of the module
+    // would do), each rounded to float like a separate call
+    if (blockIdx.x == 0 && bc < C && k.running_mean) {
+      for (int gg = 0; gg < k.groups; ++gg) {
+        double t0, t1;
+        reduce_partials(k.partial, gg * C + c, k.nsplit, t0, t1, shd);
+        if (threadIdx.x == 0) {
+          const double mean = t0 / k.count;
+          double var = t1 / k.count - mean * mean;
+          if (var < 0.0) var = 0.0;
           const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
           k.running_mean[c] = (float)((1.0 - k.momentum) * (double)k.running_mean[c] + k.momentum * mean);
           k.running_var[c] = (float)((1.0 - k.momentum) * (double)k.running_var[c] + k.momentum * unbiased);
         }
-        if (c == 0 && k.num_batches_tracked) *k.num_batches_tracked += 1;
       }
     }
+    if (blockIdx.x == 0 && bc == 0 && threadIdx.x == 0 && k.num_batches_tracked) *k.num_batches_tracked += k.groups;
   } else if (threadIdx.x == 0) {
     const float sc = k.gamma[c] / sqrtf(k.running_var[c] + k.eps);
     coef[0] = sc;
@@ -194,12 +214,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
                                                           long long S, int nsplit) {
   __shared__ float sh[8];
   const int c = blockIdx.y, split = blockIdx.x;
-  const float msc = RELU == 2 ? mscale[c] : 0.f, msh = RELU == 2 ? mshift[c] : 0.f;
+  const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
+  const long long prow = (long long)blockIdx.z * C + c;
+  const float msc = RELU == 2 ? mscale[prow] : 0.f, msh = RELU == 2 ? mshift[prow] : 0.f;
   const long long S4 = S >> 2;
   const long long per_b = (S4 + nsplit - 1) / nsplit;
   const long long lo = split * per_b, hi = min(S4, lo + per_b);
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b0 + Bg; ++b) {
     const long long base = ((long long)b * C + c) * S;
     const float4* gp = reinterpret_cast<const float4*>(gout + base);
     const float4* yp = reinterpret_cast<const float4*>(y + base);
@@ -230,8 +252,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
   }
   block_sum2(s0, s1, sh);
   if (threadIdx.x == 0) {
-    partial[((long long)c * nsplit + split) * 2] = s0;
-    partial[((long long)c * nsplit + split) * 2 + 1] = s1;
+    partial[(prow * nsplit + split) * 2] = s0;
+    partial[(prow * nsplit + split) * 2 + 1] = s1;
   }
 }
 
@@ -247,35 +269,47 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int accumulate, int nsplit, double count,
-                                                          float* __restrict__ gy, float* __restrict__ gadd, int C, long long S) {
+                                                          int groups, int Bg, float* __restrict__ gy, float* __restrict__ gadd, int C,
+                                                          long long S) {
   __shared__ double shd[8];
   __shared__ float coef[3];
   const int bc = blockIdx.y;
   const int c = bc % C;
+  const int grp = (bc / C) / Bg;
   {
     double sg, sgy;
-    reduce_partials(partial, c, nsplit, sg, sgy, shd);
+    reduce_partials(partial, grp * C + c, nsplit, sg, sgy, shd);
     if (threadIdx.x == 0) {
-      const double mean = save_mean[c], invstd = save_invstd[c], gm = gamma[c];
+      const double mean = save_mean[grp * C + c], invstd = save_invstd[grp * C + c], gm = gamma[c];
       const double dgamma = invstd * (sgy - mean * sg);
       const double A = gm * invstd;
       coef[0] = (float)A;
       coef[1] = (float)(-A * invstd * dgamma / count);
       coef[2] = (float)(A * (mean * invstd * dgamma - sg) / count);
-      if (blockIdx.x == 0 && bc < C) {
+    }
+    // affine gradients: one block per channel sums the groups in order
+    if (blockIdx.x == 0 && bc < C) {
+      double dg = 0.0, db = 0.0;
+      for (int gg = 0; gg < groups; ++gg) {
+        double tg, tgy;
+        reduce_partials(partial, gg * C + c, nsplit, tg, tgy, shd);
+        dg += (double)save_invstd[gg * C + c] * (tgy - (double)save_mean[gg * C + c] * tg);
+        db += tg;
+      }
+      if (threadIdx.x == 0) {
         if (accumulate) {
-          ggamma[c] += (float)dgamma;
-          gbeta[c] += (float)sg;
+          ggamma[c] += (float)dg;
+          gbeta[c] += (float)db;
         } else {
-          ggamma[c] = (float)dgamma;
-          gbeta[c] = (float)sg;
+          ggamma[c] = (float)dg;
+          gbeta[c] = (float)db;
         }
       }
     }
     __syncthreads();
   }
   const float A = coef[0], Bc = coef[1], Cc = coef[2];
-  const float msc = RELU == 2 ? mscale[c] : 0.f, msh = RELU == 2 ? mshift[c] : 0.f;
+  const float msc = RELU == 2 ? mscale[grp * C + c] : 0.f, msh = RELU == 2 ? mshift[grp * C + c] : 0.f;
   const long long base = (long long)bc * S;
   const long long S4 = S >> 2;
   const float4* gp = reinterpret_cast<const float4*>(gout + base);
@@ -347,13 +381,13 @@ int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who,
 
 }  // namespace
 
-// workspace (floats): per-block partial sums, C * 1024 pairs
+// workspace (floats): per-block partial sums, up to 1024 pairs per (group, channel); C = channels x groups
 extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 2048 * sizeof(float) : 0; }
 
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                  float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
-                                 int C, long long S, mode_stream_t stream) {
+                                 int C, long long S, int groups, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
@@ -362,12 +396,13 @@ extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* 
                "mode_bn_train_fwd: unaligned buffer");
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
   MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: save_scale / save_shift come in pairs");
+  MODE_REQUIRE(groups >= 1 && B % groups == 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: batch %d not divisible into %d groups", B, groups);
   hipStream_t st = mode::as_stream(stream);
-  const int nsplit = pick_nsplit(C, S);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  const int nsplit = pick_nsplit(C * groups, S);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit,
-               (double)B * (double)S};
+               (double)(B / groups) * (double)S, groups, B / groups};
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
   if (relu) {
@@ -389,7 +424,7 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
   hipStream_t st = mode::as_stream(stream);
   BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, nullptr,
                nullptr, 0.f,
-               eps, 0, 0.0};
+               eps, 0, 0.0, 1, 1};
   const int BC = B * C;
   const char* who = "mode_bn_eval_fwd";
   if (relu) {
@@ -403,7 +438,7 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
 extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
                                  const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                                  float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, long long S,
-                                 mode_stream_t stream) {
+                                 int groups, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_bwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");
@@ -415,24 +450,25 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)) &&
                    aligned16(workspace),
                MODE_ERR_UNSUPPORTED, "mode_bn_train_bwd: unaligned buffer");
+  MODE_REQUIRE(groups >= 1 && B % groups == 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: batch %d not divisible into %d groups", B, groups);
   hipStream_t st = mode::as_stream(stream);
-  const int nsplit = pick_nsplit(C, S);
+  const int nsplit = pick_nsplit(C * groups, S);
   float* partial = workspace;
   // mask source: the forward output when given (mandatory if a residual was added before the ReLU), else y and the coefficients
   const int mode = !relu ? 0 : (out ? 1 : 2);
   const float* o = out ? out : y;
   if (mode == 0)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   else if (mode == 1)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   else
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
-  const double count = (double)B * (double)S;
+  const double count = (double)(B / groups) * (double)S;
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
   launch_apply(bn_bwd_apply_kernel<M, G>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean, save_invstd, ggamma, \
-               gbeta, accumulate, nsplit, count, gy, (G) ? gadd : gy, C, S)
+               gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S)
   if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
   if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
   return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);

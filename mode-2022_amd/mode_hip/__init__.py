@@ -58,13 +58,13 @@ SIGNATURES = {
     'mode_zbuffer': (_c_int, [_c_ptr] * 6 + [ctypes.c_longlong, _c_ptr]),
     'mode_bn_workspace_bytes': (_c_size, [_c_int]),
     'mode_bn_train_fwd': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 6 + [_c_int] * 2 +
-                          [ctypes.c_longlong, _c_ptr]),
+                          [ctypes.c_longlong, _c_int, _c_ptr]),
     'mode_bn_eval_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float, _c_int] + [_c_ptr] + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
     'mode_bn_train_bwd': (_c_int, [_c_ptr] * 8 + [_c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] + [_c_int] * 2 +
-                          [ctypes.c_longlong, _c_ptr]),
+                          [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 3  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 4  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

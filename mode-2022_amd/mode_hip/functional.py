@@ -496,29 +496,31 @@ class BnActFunction(torch.autograd.Function):
   """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
 
   @staticmethod
-  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
+  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1):
     require_gpu(y, add, gamma, beta)
     y = y.contiguous()
     add = add.contiguous() if add is not None else None
     require_f32c(y, gamma, beta)
     B, C, S = _bcs(y)
     out = torch.empty_like(y)
-    mean = torch.empty(C, dtype=torch.float32, device=y.device)
+    if B % groups:
+      raise RuntimeError('BatchNorm statistics groups: batch %d is not divisible by %d' % (B, groups))
+    mean = torch.empty(groups * C, dtype=torch.float32, device=y.device)
     invstd = torch.empty_like(mean)
     # ReLU without a residual: the backward rebuilds the mask from y and these coefficients instead of reading `out`
     from_y = bool(relu) and add is None
-    coef = torch.empty((2, C), dtype=torch.float32, device=y.device) if from_y else None
+    coef = torch.empty((2, groups * C), dtype=torch.float32, device=y.device) if from_y else None
     nbytes = 4 * y.numel() * (3 + (1 if add is not None else 0))
     with torch.cuda.device_of(y), profiling.region('bn_train_fwd', nbytes, 0, y.device):
-      ws = _bn_ws(C, y.device)
+      ws = _bn_ws(C * groups, y.device)
       check(lib().mode_bn_train_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta),
                                     ptr(running_mean) if running_mean is not None else None,
                                     ptr(running_var) if running_var is not None else None,
                                     ptr(num_batches_tracked) if num_batches_tracked is not None else None, float(momentum), float(eps), int(relu),
                                     ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None, ptr(coef[1]) if from_y else None,
-                                    ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_fwd')
+                                    ptr(ws), B, C, S, groups, stream_of(y)), 'mode_bn_train_fwd')
     ctx.save_for_backward(y, out if (relu and not from_y) else None, gamma, beta, mean, invstd, coef)
-    ctx.relu, ctx.has_add = bool(relu), add is not None
+    ctx.relu, ctx.has_add, ctx.groups = bool(relu), add is not None, groups
     return out
 
   @staticmethod
@@ -535,16 +537,16 @@ class BnActFunction(torch.autograd.Function):
     gbeta = sink_b if fused else torch.empty_like(gamma)
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
     with torch.cuda.device_of(y), profiling.region('bn_train_bwd', nbytes, 0, y.device):
-      ws = _bn_ws(C, y.device)
+      ws = _bn_ws(C * ctx.groups, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
                                     ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
                                     ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
-                                    int(fused), ptr(ws), B, C, S, stream_of(y)), 'mode_bn_train_bwd')
+                                    int(fused), ptr(ws), B, C, S, ctx.groups, stream_of(y)), 'mode_bn_train_bwd')
     if fused:
       ggamma = gbeta = None
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
-    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None
+    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None
 
 
 def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
@@ -561,8 +563,9 @@ def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
   return out
 
 
-def bn_act(bn, y, add=None, relu=False):
-  """nn.BatchNorm2d/3d `bn` applied to y, then the optional residual add and ReLU, in one fused pass (two in training).
+def bn_act(bn, y, add=None, relu=False, groups=1):
+  """groups > 1: batch statistics per group of B / groups consecutive samples, as `groups` consecutive calls would take them.
+  nn.BatchNorm2d/3d `bn` applied to y, then the optional residual add and ReLU, in one fused pass (two in training).
   Same state handling as nn.BatchNorm: train mode uses batch statistics and updates running_mean / running_var /
   num_batches_tracked; eval mode uses the running statistics."""
   use_batch_stats = bn.training or bn.running_mean is None
@@ -570,13 +573,15 @@ def bn_act(bn, y, add=None, relu=False):
     momentum = bn.momentum
     update = bn.training and bn.track_running_stats
     nbt = bn.num_batches_tracked if update else None
+    if groups > 1 and momentum is None:
+      raise NotImplementedError('grouped BatchNorm statistics need a fixed momentum')
     if nbt is not None and (momentum is None or not (nbt.is_cuda and nbt.dtype == torch.int64)):
-      nbt.add_(1)  # cumulative moving average needs the count on the host; otherwise the kernel counts the batch
+      nbt.add_(groups)  # cumulative moving average needs the count on the host; otherwise the kernel counts the batches
       if momentum is None:
         momentum = 1.0 / float(nbt)
       nbt = None
     return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
-                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt)
+                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt, groups)
   if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
     # eval-mode BN inside a graph that needs gradients: rare (the reference never does it); vendor ops keep autograd correct
     out = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)

@@ -10,6 +10,8 @@ from __future__ import print_function
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -46,6 +48,14 @@ class hourglass(nn.Module):
     post = stage3d.conv_bn(self.conv5, out, relu=True, add=presqu if presqu is not None else pre)  # 1/16 -> 1/8
     out = stage3d.conv_bn(self.conv6, post, add=residual)  # 1/8 -> 1/4
     return out, pre, post
+
+
+PAIR_EXTRACTOR = os.environ.get('MODE_PAIR_EXTRACTOR', '1') == '1'
+
+
+def _cumulative_bn(module):
+  """True if some BatchNorm of `module` uses the cumulative moving average (momentum=None), which the grouped kernels do not do."""
+  return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.momentum is None for m in module.modules())
 
 
 class ModeDisparity(nn.Module):
@@ -92,8 +102,16 @@ class ModeDisparity(nn.Module):
         m.bias.data.zero_()
 
   def forward(self, left, right):
-    ref_fea = self.feature_extraction(left)
-    tgt_fea = self.feature_extraction(right)
+    if PAIR_EXTRACTOR and left.shape == right.shape and not _cumulative_bn(self.feature_extraction):
+      # One pass of the shared extractor over [left; right] instead of two: same arithmetic per sample, BatchNorm statistics
+      # still per image set (stage3d.bn_groups), twice the work per kernel launch -- the extractor's kernels are small at the
+      # benchmark batch (2 x 256x128 at quarter resolution) and fill the chip better at 4.
+      with stage3d.bn_groups(2):
+        fea = self.feature_extraction(torch.cat((left, right), 0))
+      ref_fea, tgt_fea = fea[:left.shape[0]], fea[left.shape[0]:]
+    else:
+      ref_fea = self.feature_extraction(left)
+      tgt_fea = self.feature_extraction(right)
 
     cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
 

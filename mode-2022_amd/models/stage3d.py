@@ -7,6 +7,7 @@ runs the layer.  ``BACKEND`` selects who does the arithmetic of the 3x3x3 convol
   'vendor' -- torch.nn.functional on the GPU (MIOpen) for everything; used for A/B measurements.
 Neither is a CPU path; BatchNorm / ReLU / residual adds are torch GPU ops for now.
 """
+import contextlib
 import os
 
 import torch
@@ -55,17 +56,36 @@ def conv_bn(seq, x, relu=False, add=None):
   return bn_act(seq[1], conv3(seq[0], x), add, relu)
 
 
+_bn_groups = 1
+
+
+@contextlib.contextmanager
+def bn_groups(n):
+  """Inside this context every training-mode BatchNorm takes its batch statistics per group of B / n consecutive samples and
+  updates its running statistics group after group -- exactly what n consecutive calls of the network on the n sub-batches do.
+  ModeDisparity pushes the left and the right images through the shared extractor as one batch this way."""
+  global _bn_groups
+  prev, _bn_groups = _bn_groups, n
+  try:
+    yield
+  finally:
+    _bn_groups = prev
+
+
 def bn_act(bn, y, add=None, relu=False):
   """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training), or vendor ops."""
   if not y.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')
   if BN_BACKEND == 'hip' and HF.bn_supported(y):
-    return HF.bn_act(bn, y, add, relu)
+    return HF.bn_act(bn, y, add, relu, groups=_bn_groups if bn.training else 1)
   return bn_act_vendor(bn, y, add, relu)
 
 
 def bn_act_vendor(bn, y, add=None, relu=False):
-  y = bn(y)
+  if _bn_groups > 1 and bn.training:  # group after group, like consecutive calls
+    y = torch.cat([bn(part) for part in y.chunk(_bn_groups, 0)], 0)
+  else:
+    y = bn(y)
   if add is not None:
     y = y + add
   return F.relu(y, inplace=True) if relu else y

@@ -420,6 +420,48 @@ def test_bn_act_train_and_eval(shape, relu, with_add):
   assert (e.cpu().double() - e_ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize('shape,groups', [((4, 8, 12, 16), 2), ((6, 5, 4, 6, 8), 3), ((2, 64, 32, 64), 2)])
+@pytest.mark.parametrize('relu,with_add', [(True, False), (True, True), (False, False)])
+def test_bn_act_grouped_statistics(shape, groups, relu, with_add):
+  """groups = n: exactly what n consecutive calls of the module on the n sub-batches compute -- outputs, gradients (affine
+  gradients summed over the calls), running statistics updated call after call, num_batches_tracked += n."""
+  import torch.nn as nn
+  C = shape[1]
+  BN = nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d
+  ref_bn, dev_bn = BN(C).double(), BN(C).to(DEV)
+  g = torch.Generator().manual_seed(9)
+  with torch.no_grad():
+    for bn in (ref_bn, dev_bn):
+      bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(1)))
+      bn.bias.copy_(0.3 * torch.randn(C, generator=torch.Generator().manual_seed(2)))
+  y = torch.randn(shape, generator=g) * 2 + torch.arange(shape[0]).view(-1, *([1] * (len(shape) - 1))).float()  # groups differ in mean
+  add = _rand(shape, 72) if with_add else None
+  gout = _rand(shape, 73)
+  ya = y.double().requires_grad_(True)
+  aa = add.double().requires_grad_(True) if with_add else None
+  outs = []
+  for part, apart in zip(ya.chunk(groups, 0), aa.chunk(groups, 0) if with_add else [None] * groups):
+    o = ref_bn(part)
+    if with_add:
+      o = o + apart
+    outs.append(torch.relu(o) if relu else o)
+  o_ref = torch.cat(outs, 0)
+  o_ref.backward(gout.double())
+  yd = y.to(DEV).requires_grad_(True)
+  ad = add.to(DEV).requires_grad_(True) if with_add else None
+  out = HF.bn_act(dev_bn, yd, ad, relu, groups=groups)
+  out.backward(gout.to(DEV))
+  assert (out.detach().cpu().double() - o_ref.detach()).abs().max() < 2e-5
+  assert (yd.grad.cpu().double() - ya.grad).abs().max() < 5e-5 * max(1.0, float(ya.grad.abs().max()))
+  if with_add:
+    assert (ad.grad.cpu().double() - aa.grad).abs().max() < 1e-6
+  for a, b in ((dev_bn.weight.grad, ref_bn.weight.grad), (dev_bn.bias.grad, ref_bn.bias.grad)):
+    assert (a.cpu().double() - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max()))
+  assert (dev_bn.running_mean.cpu().double() - ref_bn.running_mean).abs().max() < 1e-5
+  assert (dev_bn.running_var.cpu().double() - ref_bn.running_var).abs().max() < 1e-4
+  assert int(dev_bn.num_batches_tracked) == groups == int(ref_bn.num_batches_tracked)
+
+
 # ------------------------------------------------------------------ fused head (a13/a14)
 @pytest.mark.parametrize('B,D4,H4,W4,scale', [(2, 4, 6, 8, 4), (1, 12, 5, 7, 4), (1, 3, 4, 4, 3), (2, 48, 8, 16, 4)])
 def test_head_fwd_bwd_conf(B, D4, H4, W4, scale):
