@@ -813,18 +813,30 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
 
 // gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32]
 __global__ void reduce_gw3d(const float* __restrict__ part, float* __restrict__ gw, WDims d, int accumulate) {
-  const long long total = (long long)d.Co * d.Ci * 27;
+  // one thread per element of the partial layout (tap, o % 32, c % 32 fastest): coalesced reads of every slice; the slices
+  // are summed with 4 interleaved running sums in a fixed association -- deterministic, 4 independent loads in flight
   const long long stride = (long long)d.MTo * d.MTc * 27 * 1024;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int tap = (int)(idx % 27);
-    long long r = idx / 27;
-    const int c = (int)(r % d.Ci);
-    const int o = (int)(r / d.Ci);
-    const float* p = part + (((long long)(o / 32) * d.MTc + c / 32) * 27 + tap) * 1024 + (o % 32) * 32 + (c % 32);
-    float sum = 0.f;
-    for (int s = 0; s < d.S; ++s) sum += p[s * stride];
-    gw[idx] = accumulate ? gw[idx] + sum : sum;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < stride; e += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 31), i = (int)((e >> 5) & 31);
+    long long r = e >> 10;
+    const int tap = (int)(r % 27);
+    r /= 27;
+    const int cb = (int)(r % d.MTc), ob = (int)(r / d.MTc);
+    const int o = ob * 32 + i, c = cb * 32 + j;
+    if (o >= d.Co || c >= d.Ci) continue;
+    const float* p = part + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < d.S; s += 4) {
+      a0 += p[(long long)s * stride];
+      a1 += p[(long long)(s + 1) * stride];
+      a2 += p[(long long)(s + 2) * stride];
+      a3 += p[(long long)(s + 3) * stride];
+    }
+    for (; s < d.S; ++s) a0 += p[(long long)s * stride];
+    const float sum = (a0 + a1) + (a2 + a3);
+    float* q = gw + ((long long)o * d.Ci + c) * 27 + tap;
+    *q = accumulate ? *q + sum : sum;
   }
 }
 
@@ -885,7 +897,7 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   rc = mode::check_launch("mode_conv3d_bwd_weight");
   if (rc != MODE_OK) return rc;
   const long long n = (long long)Co * Ci * 27;
-  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 256)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
 }
 
