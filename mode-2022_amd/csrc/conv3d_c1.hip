@@ -198,13 +198,18 @@ __global__ __launch_bounds__(NT) void conv3d_co1_bwd_weight_kernel(const float* 
 
 __global__ void conv3d_co1_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int Ci, int S, int MTc,
                                          int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // c*27 + tap
+  // one wave per output element (c, tap): lane l sums slices l, l + 64, ... in order, then a fixed shuffle tree combines the 64
+  // lane sums -- deterministic, and 64-way parallel instead of one thread walking ~1000 slices
+  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // c*27 + tap
+  const int lane = threadIdx.x & 63;
   if (idx >= Ci * 27) return;
   const int c = idx / 27, tap = idx - c * 27;
   const float* p = part + (long long)(c / 32) * 1024 + (c % 32) * 32 + tap;
   float sum = 0.f;
-  for (int s = 0; s < S; ++s) sum += p[(long long)s * MTc * 1024];
-  gw[idx] = accumulate ? gw[idx] + sum : sum;
+  for (int s = lane; s < S; s += 64) sum += p[(long long)s * MTc * 1024];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) gw[idx] = accumulate ? gw[idx] + sum : sum;
 }
 
 int co1_splits(int T, int MTc) {
@@ -239,7 +244,7 @@ int conv3d_co1_bwd_weight(const float* gy, const float* x, float* gw, float* wor
   hipLaunchKernelGGL(conv3d_co1_bwd_weight_kernel, dim3(S, MTc), dim3(NT), 0, st, gy, x, workspace, B, Ci, D, H, W, nHt, nWt, T, S);
   int rc = check_launch(who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_co1_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, gw, Ci, S, MTc, accumulate);
+  hipLaunchKernelGGL(conv3d_co1_reduce_kernel, dim3(cdiv(Ci * 27, 4)), dim3(256), 0, st, workspace, gw, Ci, S, MTc, accumulate);
   return check_launch(who);
 }
 

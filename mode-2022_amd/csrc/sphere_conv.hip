@@ -744,9 +744,16 @@ __global__ void reduce_gw(const float* __restrict__ part, float* __restrict__ gw
     const int nb = c / d.CB, colr = (c % d.CB) * d.KK + k;
     const long long stride = (long long)d.G * MG * d.NB * (128 * 128);
     const float* pp = part + (((long long)g * MG + mg) * d.NB + nb) * (128 * 128) + row * 128 + colr;
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += pp[s * stride];
-    gw[idx] += sum;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // fixed association, 4 independent loads in flight
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+      a0 += pp[s * stride];
+      a1 += pp[(s + 1) * stride];
+      a2 += pp[(s + 2) * stride];
+      a3 += pp[(s + 3) * stride];
+    }
+    for (; s < S; ++s) a0 += pp[s * stride];
+    gw[idx] += (a0 + a1) + (a2 + a3);
   }
 }
 
