@@ -690,6 +690,7 @@ constexpr int RING_DC = 12;
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                     float* __restrict__ part, WDims d, int nDc, int units) {
   constexpr int WTH = 2, XR = WTH + 2, XW = 34, PS = XR * XW;  // plane = 136 floats
+  constexpr int RNF = 8;                                       // plane loads in flight per thread (16 costs the second wave per SIMD: 1.58 -> 1.90 ms)
   constexpr int XPLANE = 3 * PS + 1;                           // 409 (odd)
   constexpr int GPLANE = WTH * 32 + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -736,10 +737,10 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
         const bool zok = z >= 0 && z < d.D;
         const long long zoff = (long long)(zok ? z : 0) * HW;
 #pragma unroll 1
-        for (int kb = 0; kb < 16; kb += 8) {
-          float t8[8];
+        for (int kb = 0; kb < 16; kb += RNF) {
+          float t8[RNF];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < RNF; ++j) {
             const int r = (kb + j) * 8 + hwv;  // (channel, row) = (r >> 2, r & 3)
             const int c = r >> 2, gh = h0 + (r & 3) - 1, gw = w0 + l32;
             const bool ok = zok && cb * 32 + c < d.Ci && gh >= 0 && gh < d.H && gw < d.W;
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
             t8[j] = ok ? v : 0.f;
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < RNF; ++j) {
             const int r = (kb + j) * 8 + hwv;
             xl[(r >> 2) * XPLANE + slot * PS + (r & 3) * XW + 1 + l32] = t8[j];
           }
