@@ -233,6 +233,8 @@ def main():
   fence()
   elapsed = time.time() - t0
   if args.launch == 'graph' and not args.no_kernel_timing:
+    eager_step()  # re-warm the eager allocator pool (the replayed steps lived in the graph's private pool): an allocation
+    fence()       # that falls through to hipMalloc stalls the stream between the two events of a region
     profiling.enable(True)
     for _ in range(args.profile_steps):
       eager_step()
