@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 4 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 5 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -112,8 +112,9 @@ int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, f
  * always refer to the logical (untransposed) image. */
 int mode_transpose_planes(const float* in, float* out, long long planes, int H, int W, mode_stream_t stream);
 
-/* Windowed weight gradient: the 81-row-window tiles of the plan run on the LDS-window kernel, the pixels of all other tiles
- * (mode_sphere_plan_rest_pixels: their linear indices h*W + w, sorted; at most H*W) on the general kernels.  ADDS to gw like
+/* Windowed weight gradient: the 81-row-window tiles of the plan run on the LDS-window kernel; the other tiles on the polar
+ * kernel (mode_sphere_plan_polar; pass n_rest_pixels = 0 then) or, if they could not be planned, their pixels
+ * (mode_sphere_plan_rest_pixels: linear indices h*W + w, sorted; at most H*W; n_polar_items = 0 then) on the general kernels.  ADDS to gw like
  * mode_sphere_conv_bwd_weight; deterministic.  `workspace` >= mode_sphere_conv_bwd_weight_win_workspace_bytes().
  * gy_t / x_t (both or neither): plane-transposed copies of gy / x for the windowed kernel (see mode_transpose_planes); the
  * general kernels always read gy / x. */
@@ -128,14 +129,22 @@ size_t mode_sphere_plan_records_count(int n_small);
 int mode_sphere_plan_records(const float* pos_host, const int32_t* tiles_host, const int32_t* counts, int H, int W,
                              float* rec_w_host, int32_t* rec_off_host);
 
+/* Column items of the tiles that are not of the 81-row class, for the polar weight-gradient kernel (one output column of 32 pixels
+ * per item, nine per-tap windows of 34 rows x 2 columns): pitems_host[20 * n], rec_w_host[4 * 288 * n], rec_off_host[288 * n],
+ * n <= mode_sphere_plan_polar_max_items(counts); *n_items = -1 when some column does not fit (use the pixel list instead). */
+size_t mode_sphere_plan_polar_max_items(const int32_t* counts);
+
+int mode_sphere_plan_polar(const float* pos_host, const int32_t* tiles_host, const int32_t* counts, int H, int W,
+                           int32_t* pitems_host, float* rec_w_host, int32_t* rec_off_host, int32_t* n_items);
+
 size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
-                                                       int n_small, int n_rest_pixels);
+                                                       int n_small, int n_rest_pixels, int n_polar_items);
 
 int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                     const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
-                                    const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, int B, int Ci, int H,
-                                    int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
-                                    mode_stream_t stream);
+                                    const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, const int32_t* pitems,
+                                    const float* prec_w, const int32_t* prec_off, int n_polar_items, int B, int Ci, int H, int W,
+                                    int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t, mode_stream_t stream);
 
 /* Replaces the grad_weight half (sphere_conv_cuda.cpp:296-315: second im2col + addmm_(gO, col^T),
  * summed over the batch).  ACCUMULATES into gw (caller zero-fills, sphere_conv.py:63).  `workspace`

@@ -333,6 +333,105 @@ constexpr int BW_LDS_FLOATS = 2 * BW_XW + 2 * BW_COLBUF;  // x window and gy col
 constexpr int BW_NXW = BW_CG / TW;  // x-window words per thread and column step: the next item's window arrives in 4 parts
 constexpr int BW_NREC = KT * BW_TH;                                      // records per column (288)
 
+// The 72 MFMAs of one column (32 pixels) of a work item for this wave: own tap (all 32 pixels, software-pipelined: while the
+// MFMAs of pixel px run, the B value of pixel px+1 is combined and the LDS words of pixel px+2 are requested), then this wave's
+// share of tap 8.  cb = gy column [128][BW_GP], xw = x window(s) [32][CP], rw/ro (rw8/ro8) = lane l holds the record of pixel
+// l & 31 of this wave's tap (of tap 8); WRP = distance between the two window columns of a record.
+template <int WRP, int CP>
+__device__ __forceinline__ void bww_column(const float* cb, const float* xw, const float4 rw, const int ro, const float4 rw8,
+                                           const int ro8, f32x32 (&accp)[2], f32x32 (&acc8p)[2], int wave_u, int j, int half) {
+  // A operand: block 0 (lanes 0-31) = o-tile 0 / 2, block 1 (lanes 32-63) = o-tile 1 / 3
+  const float* ap = cb + (half * 32 + j) * BW_GP;
+  const float* xb = xw + j * CP;
+  auto load_x = [&](int o, float (&raw)[4]) {  // o is wave-uniform
+    const float* p = xb + o;
+    raw[0] = p[0];
+    raw[1] = p[WRP];
+    raw[2] = p[1];
+    raw[3] = p[WRP + 1];
+  };
+  auto bcast = [&](float v, int px) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), px)); };
+  auto combine = [&](const float4& w, int px, const float (&raw)[4]) {  // one fma chain: keeps the compiler from SLP-packing
+    return __builtin_fmaf(bcast(w.w, px), raw[3],
+                          __builtin_fmaf(bcast(w.z, px), raw[2], __builtin_fmaf(bcast(w.y, px), raw[1], bcast(w.x, px) * raw[0])));
+  };
+  // own tap: all 32 pixels, software-pipelined three deep: while the MFMAs of pixel px run, the B value of pixel px+1 is
+  // combined (4 FMAs on words read one step earlier) and the LDS words of pixel px+2 are requested
+  {
+    float raw[2][4], a[3][2];
+#pragma unroll
+    for (int p0 = 0; p0 < 2; ++p0) {
+      load_x(__builtin_amdgcn_readlane(ro, p0), raw[p0]);
+      a[p0][0] = ap[p0];
+      a[p0][1] = ap[64 * BW_GP + p0];
+    }
+    float bv = combine(rw, 0, raw[0]);
+#pragma unroll
+    for (int px = 0; px < BW_TH; ++px) {
+      const int c3 = px % 3, n3 = (px + 2) % 3;
+      float bv_next = 0.f;
+      if (px + 1 < BW_TH) bv_next = combine(rw, px + 1, raw[(px + 1) & 1]);
+      if (px + 2 < BW_TH) {
+        load_x(__builtin_amdgcn_readlane(ro, px + 2), raw[px & 1]);  // the slot of pixel px is free again
+        a[n3][0] = ap[px + 2];
+        a[n3][1] = ap[64 * BW_GP + px + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      accp[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][0], bv, accp[0], 0, 0, 0);
+      accp[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][1], bv, accp[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bv = bv_next;
+    }
+  }
+  // this wave's share of tap 8: pixels wave, wave + 8, wave + 16, wave + 24
+  {
+    float raw[4][4], a[4][2];
+#pragma unroll
+    for (int i = 0; i < BW_TH / 8; ++i) {
+      const int px = wave_u + 8 * i;
+      load_x(__builtin_amdgcn_readlane(ro8, px), raw[i]);
+      a[i][0] = ap[px];
+      a[i][1] = ap[64 * BW_GP + px];
+    }
+#pragma unroll
+    for (int i = 0; i < BW_TH / 8; ++i) {
+      const float b8 = combine(rw8, wave_u + 8 * i, raw[i]);
+      acc8p[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][0], b8, acc8p[0], 0, 0, 0);
+      acc8p[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][1], b8, acc8p[1], 0, 0, 0);
+    }
+  }
+
+}
+
+// Partials of one workgroup: tap `wave` from its wave, tap 8 = the 8 waves' shares added in wave order through LDS (deterministic).
+// Must be called after a barrier that ends all reads of `smem`.
+__device__ __forceinline__ void bww_write_partials(float* pb, float* smem, f32x32 (&accp)[2], f32x32 (&acc8p)[2], int wave, int half,
+                                                   int j, int tid) {
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
+      pb[((long long)wave * 128 + o) * BW_CG + j] = accp[pr][r];
+    }
+  // tap 8: the 8 waves' shares, added in wave order through LDS (deterministic), then written as one partial
+  float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier, nobody reads the windows any more
+  for (int v = 0; v < 8; ++v) {
+    if (wave == v) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
+          float* q = red + o * BW_CG + j;
+          *q = v == 0 ? acc8p[pr][r] : *q + acc8p[pr][r];
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
+}
+
 __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                    float* __restrict__ part, WinDims d, const int4* __restrict__ tiles,
                                                                    const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
@@ -459,66 +558,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
       if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
       if (more_items) issue_xw(nxt, wc);  // a quarter of the next item's window per column, into the other window buffer
 
-      // A operand: block 0 (lanes 0-31) = o-tile 0 / 2, block 1 (lanes 32-63) = o-tile 1 / 3
-      const float* ap = cb + (half * 32 + j) * BW_GP;
-      const float* xb = xw + j * BW_CP;
-      auto load_x = [&](int o, float (&raw)[4]) {  // o is wave-uniform
-        const float* p = xb + o;
-        raw[0] = p[0];
-        raw[1] = p[WRP];
-        raw[2] = p[1];
-        raw[3] = p[WRP + 1];
-      };
-      auto bcast = [&](float v, int px) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), px)); };
-      auto combine = [&](const float4& w, int px, const float (&raw)[4]) {  // one fma chain: keeps the compiler from SLP-packing
-        return __builtin_fmaf(bcast(w.w, px), raw[3],
-                              __builtin_fmaf(bcast(w.z, px), raw[2], __builtin_fmaf(bcast(w.y, px), raw[1], bcast(w.x, px) * raw[0])));
-      };
-      // own tap: all 32 pixels, software-pipelined three deep: while the MFMAs of pixel px run, the B value of pixel px+1 is
-      // combined (4 FMAs on words read one step earlier) and the LDS words of pixel px+2 are requested
-      {
-        float raw[2][4], a[3][2];
-#pragma unroll
-        for (int p0 = 0; p0 < 2; ++p0) {
-          load_x(__builtin_amdgcn_readlane(ro, p0), raw[p0]);
-          a[p0][0] = ap[p0];
-          a[p0][1] = ap[64 * BW_GP + p0];
-        }
-        float bv = combine(rw, 0, raw[0]);
-#pragma unroll
-        for (int px = 0; px < BW_TH; ++px) {
-          const int c3 = px % 3, n3 = (px + 2) % 3;
-          float bv_next = 0.f;
-          if (px + 1 < BW_TH) bv_next = combine(rw, px + 1, raw[(px + 1) & 1]);
-          if (px + 2 < BW_TH) {
-            load_x(__builtin_amdgcn_readlane(ro, px + 2), raw[px & 1]);  // the slot of pixel px is free again
-            a[n3][0] = ap[px + 2];
-            a[n3][1] = ap[64 * BW_GP + px + 2];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          accp[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][0], bv, accp[0], 0, 0, 0);
-          accp[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[c3][1], bv, accp[1], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          bv = bv_next;
-        }
-      }
-      // this wave's share of tap 8: pixels wave, wave + 8, wave + 16, wave + 24
-      {
-        float raw[4][4], a[4][2];
-#pragma unroll
-        for (int i = 0; i < BW_TH / 8; ++i) {
-          const int px = wave_u + 8 * i;
-          load_x(__builtin_amdgcn_readlane(ro8, px), raw[i]);
-          a[i][0] = ap[px];
-          a[i][1] = ap[64 * BW_GP + px];
-        }
-#pragma unroll
-        for (int i = 0; i < BW_TH / 8; ++i) {
-          const float b8 = combine(rw8, wave_u + 8 * i, raw[i]);
-          acc8p[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][0], b8, acc8p[0], 0, 0, 0);
-          acc8p[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(a[i][1], b8, acc8p[1], 0, 0, 0);
-        }
-      }
+      bww_column<BW_WR, BW_CP>(cb, xw, rw, ro, rw8, ro8, accp, acc8p, wave_u, j, half);
 
       // the other buffers: nobody reads them now
       if (have_next) commit_col(colbuf + (buf ^ 1) * BW_COLBUF);
@@ -530,30 +570,104 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_win_kernel(const float* _
     xbuf ^= 1;
   }
 
-  float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
+  bww_write_partials(part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG), smem, accp, acc8p, wave,
+                     half, j, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same contraction for the tiles next to the poles, where the nine taps of one output column sample row ranges that lie far
+// apart (so no single compact window exists): a work item is ONE column of 32 pixels, and the x window is nine small windows,
+// one per tap: [32 ch][9 taps][2 columns][34 rows] (78 KB).  Everything of an item is staged in place (no cross-item prefetch:
+// these items are 12.5 % of the pixels), then the k-loop of the compact-window kernel runs unchanged on it.
+// pitems[i] = (h0, w, rbase[9], cbase[9]); records [item][tap][32] hold offsets into the per-tap layout.
+constexpr int BP_WR = BW_TH + 2;         // rows per tap window
+constexpr int BP_TAPW = 2 * BP_WR;       // floats per tap window: [2 cols][34 rows]
+constexpr int BP_CP = KT * BP_TAPW + 1;  // odd channel pitch (613)
+constexpr int BP_XW = BW_CG * BP_CP + BP_WR + 8;
+constexpr int BP_LDS_FLOATS = BP_XW + BW_COLBUF;
+constexpr int BP_ITEM_INTS = 2 + 2 * KT;
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bww_polar_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                     float* __restrict__ part, WinDims d, const int* __restrict__ pitems,
+                                                                     const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
+                                                                     int nitems, int S, int s_base) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xw = smem;
+  float* cb = smem + BP_XW;
+  const int s = blockIdx.x, cg = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, half = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const long long HW = (long long)d.H * d.W;
+  const int T = nitems * d.B;
+  const int omax = d.Cog - mg * 128, cmax = d.Cig - cg * BW_CG;
+  const int gpx = tid & (BW_TH - 1), go0 = tid >> 5;
+
+  f32x32 accp[2], acc8p[2];
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
-      pb[((long long)wave * 128 + o) * BW_CG + j] = accp[pr][r];
-    }
-  // tap 8: the 8 waves' shares, added in wave order through LDS (deterministic), then written as one partial
-  float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier, nobody reads the windows any more
-  for (int v = 0; v < 8; ++v) {
-    if (wave == v) {
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          const int o = (2 * pr + (r >> 4)) * 32 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;
-          float* q = red + o * BW_CG + j;
-          *q = v == 0 ? acc8p[pr][r] : *q + acc8p[pr][r];
-        }
-    }
-    __syncthreads();
+  for (int r = 0; r < 32; ++r) {
+    accp[0][r] = accp[1][r] = 0.f;
+    acc8p[0][r] = acc8p[1][r] = 0.f;
   }
-  for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
+  for (int i = tid; i < BP_LDS_FLOATS; i += NTHREADS) smem[i] = 0.f;
+
+  // this thread's window words: element e = tid (and tid + 512 < 612) of the [9][2][34] per-channel layout
+  constexpr int NE = KT * BP_TAPW;  // 612
+  const int e0 = tid, e1 = tid + NTHREADS;
+  const bool has1 = e1 < NE;
+  const int k0 = e0 / BP_TAPW, k1 = (has1 ? e1 : 0) / BP_TAPW;
+  const int col0 = (e0 % BP_TAPW) / BP_WR, r0 = e0 % BP_WR;
+  const int col1 = ((has1 ? e1 : 0) % BP_TAPW) / BP_WR, r1 = (has1 ? e1 : 0) % BP_WR;
+
+  for (int t = s; t < T; t += S) {
+    const int b = t / nitems, it = t - b * nitems;
+    const int* pi = pitems + (long long)it * BP_ITEM_INTS;
+    const int h0 = pi[0], w = pi[1];
+    __syncthreads();  // previous item consumed (first pass: zero fill done)
+    {
+      const int rb0 = pi[2 + k0], cb0 = pi[2 + KT + k0], rb1 = pi[2 + k1], cb1 = pi[2 + KT + k1];
+      const bool ok0 = cb0 + col0 < d.W, ok1 = has1 && cb1 + col1 < d.W;
+      const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW;
+      const long long a0 = ok0 ? (long long)((rb0 + r0) % d.H) * d.sh + (long long)(cb0 + col0) * d.sw : 0;
+      const long long a1 = ok1 ? (long long)((rb1 + r1) % d.H) * d.sh + (long long)(cb1 + col1) * d.sw : 0;
+#pragma unroll 1
+      for (int c8 = 0; c8 < BW_CG; c8 += 8) {  // 16 unconditional loads in flight, masked at the store
+        float v0[8], v1[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const long long co = (long long)min(c8 + c, cmax - 1) * HW;
+          v0[c] = xg[co + a0];
+          v1[c] = xg[co + a1];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          xw[(c8 + c) * BP_CP + e0] = (ok0 && c8 + c < cmax) ? v0[c] : 0.f;
+          if (has1) xw[(c8 + c) * BP_CP + e1] = (ok1 && c8 + c < cmax) ? v1[c] : 0.f;
+        }
+      }
+    }
+    {
+      const int h = h0 + gpx;
+      const bool pok = h < d.H && w < d.W;
+      const float* gyb = gy + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
+                         (pok ? (long long)h * d.sh + (long long)w * d.sw : 0);
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = gyb[(long long)min(go0 + 16 * u, omax - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cb[(go0 + 16 * u) * BW_GP + gpx] = (pok && go0 + 16 * u < omax) ? v[u] : 0.f;
+    }
+    const long long rbase = (long long)it * BW_NREC;
+    const float4 rw = rec_w[rbase + wave * BW_TH + j], rw8 = rec_w[rbase + 8 * BW_TH + j];
+    const int ro = rec_off[rbase + wave * BW_TH + j], ro8 = rec_off[rbase + 8 * BW_TH + j];
+    __syncthreads();
+    bww_column<BP_WR, BP_CP>(cb, xw, rw, ro, rw8, ro8, accp, acc8p, wave_u, j, half);
+  }
+  __syncthreads();
+  bww_write_partials(part + ((((long long)(s_base + s) * gridDim.z + blockIdx.z) * gridDim.y + cg) * BW_SLOTS) * (128 * BW_CG), smem, accp,
+                     acc8p, wave, half, j, tid);
 }
 
 // gw[o][c][k] += sum over slices (fixed order) of the tap's partial; one thread per (z, cg, k, o, c), c fastest:
@@ -841,22 +955,113 @@ extern "C" int mode_sphere_plan_records(const float* pos_host, const int32_t* ti
   return MODE_OK;
 }
 
+// Work items of the polar weight-gradient kernel: every tile that is NOT of the small-window class, split into 2 halves x 4
+// columns.  pitems_host[20 * i ..] = (h0, w, rbase[9], cbase[9]); rec_w_host[4 * (i*288 + tap*32 + row)], rec_off_host[...] = the
+// sampling records in the per-tap window layout.  Returns the number of items, or -1 (in *n_items) if some column does not fit
+// its per-tap windows (34 rows x 2 columns per tap) -- the caller then keeps those pixels on the general kernel.
+extern "C" size_t mode_sphere_plan_polar_max_items(const int32_t* counts) {
+  return counts ? (size_t)(counts[1] + counts[2]) * 2 * TW : 0;
+}
+
+extern "C" int mode_sphere_plan_polar(const float* pos_host, const int32_t* tiles_host, const int32_t* counts, int H, int W,
+                                      int32_t* pitems_host, float* rec_w_host, int32_t* rec_off_host, int32_t* n_items) {
+  MODE_REQUIRE(pos_host && tiles_host && counts && pitems_host && rec_w_host && rec_off_host && n_items, MODE_ERR_BAD_ARG,
+               "mode_sphere_plan_polar: null pointer");
+  const long long HW = (long long)H * W;
+  const int ntall = counts[2] + counts[1];  // list order: wrap-around, mid, small
+  int ni = 0;
+  for (int ti = 0; ti < ntall; ++ti) {
+    const int th0 = tiles_host[4 * ti], tw0 = tiles_host[4 * ti + 1];
+    for (int hf = 0; hf < 2; ++hf)
+      for (int wc = 0; wc < TW; ++wc) {
+        const int h0 = th0 + hf * BW_TH, w = tw0 + wc;
+        if (h0 >= H || w >= W) continue;
+        int32_t* pi = pitems_host + (size_t)ni * BP_ITEM_INTS;
+        pi[0] = h0;
+        pi[1] = w;
+        for (int k = 0; k < KT; ++k) {
+          // row SHIFT of every live pixel, n = r0 - (h0 + px) modulo H, taken relative to the first one so that a shift of about
+          // half the axis (the far side of the sphere) does not straddle the wrap-around cut
+          int nfirst = 0, nmin = 1 << 30, nmax = -(1 << 30), cmin = 1 << 30, cmax = -(1 << 30);
+          bool have = false;
+          for (int px = 0; px < BW_TH && h0 + px < H; ++px) {
+            int r0, c0;
+            float4 wt;
+            const long long idx = (long long)(h0 + px) * W + w;
+            if (!mode::tap_record_fixed(pos_host[(2 * k) * HW + idx], pos_host[(2 * k + 1) * HW + idx], H, W, r0, c0, wt)) continue;
+            if (wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f) continue;
+            int n = ((r0 - h0 - px) % H + H) % H;
+            if (!have) {
+              nfirst = n;
+              have = true;
+            }
+            n = ((n - nfirst + H / 2) % H + H) % H - H / 2 + nfirst;  // within H/2 of the first shift
+            nmin = std::min(nmin, n);
+            nmax = std::max(nmax, n);
+            cmin = std::min(cmin, c0);
+            cmax = std::max(cmax, c0);
+          }
+          int rb = 0, cbs = 0;
+          if (have) {
+            // rows h0 + nmin .. h0 + 31 + nmax (+1 for the second corner) must fit the 34-row window, the columns its 2
+            if (BW_TH - 1 + (nmax - nmin) + 2 > BP_WR || cmax - cmin + 2 > 2) {
+              *n_items = -1;
+              return MODE_OK;
+            }
+            rb = ((h0 + nmin) % H + H) % H;
+            cbs = cmin;
+          }
+          pi[2 + k] = rb;
+          pi[2 + KT + k] = cbs;
+          for (int px = 0; px < BW_TH; ++px) {
+            const size_t o = ((size_t)ni * KT + k) * BW_TH + px;
+            int r0 = 0, c0 = 0;
+            float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool live = false;
+            if (h0 + px < H) {
+              const long long idx = (long long)(h0 + px) * W + w;
+              live = mode::tap_record_fixed(pos_host[(2 * k) * HW + idx], pos_host[(2 * k + 1) * HW + idx], H, W, r0, c0, wt);
+            }
+            live = live && !(wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f);
+            rec_off_host[o] = live ? k * BP_TAPW + (c0 - cbs) * BP_WR + ((r0 - rb) % H + H) % H : 0;
+            rec_w_host[4 * o + 0] = live ? wt.x : 0.f;
+            rec_w_host[4 * o + 1] = live ? wt.y : 0.f;
+            rec_w_host[4 * o + 2] = live ? wt.z : 0.f;
+            rec_w_host[4 * o + 3] = live ? wt.w : 0.f;
+          }
+        }
+        ++ni;
+      }
+  }
+  *n_items = ni;
+  return MODE_OK;
+}
+
+int bww_polar_splits(const WinDims& d, int n_items) {
+  const int T = n_items * d.B;
+  const int wgs_per_slice = mode::cdiv(d.Cig, BW_CG) * d.G * d.MG;
+  const int per = std::max(1, mode::cdiv((long long)T * wgs_per_slice, kNumCU));
+  return std::max(1, mode::cdiv(T, per));
+}
+
 extern "C" size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
-                                                                  int n_small, int n_rest_pixels) {
+                                                                  int n_small, int n_rest_pixels, int n_polar_items) {
   WinDims d;
   if (make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win_workspace_bytes") != MODE_OK) return 0;
-  const size_t win = (size_t)bww_win_splits(d, std::max(n_small, 1)) * d.G * d.MG * mode::cdiv(d.Cig, BW_CG) * BW_SLOTS * 128 * BW_CG *
-                     sizeof(float);
+  const size_t slice = (size_t)d.G * d.MG * mode::cdiv(d.Cig, BW_CG) * BW_SLOTS * 128 * BW_CG * sizeof(float);
+  const size_t win = slice * (bww_win_splits(d, std::max(n_small, 1)) + bww_polar_splits(d, std::max(n_polar_items, 1)));
   return win + mode::sphere_bwd_weight_general_workspace(B, Ci, Co, Kh, Kw, H, W, groups, std::max(n_rest_pixels, 1));
 }
 
 // Weight gradient, ADDED to gw like mode_sphere_conv_bwd_weight: windowed kernel on the n_small compact tiles of the plan
-// (tile list order: wrap-around, mid, small), general kernels on the n_rest_pixels pixels of the other tiles.
+// (tile list order: wrap-around, mid, small), the polar kernel on the n_polar_items column items of the other tiles
+// (mode_sphere_plan_polar), or -- when those could not be planned -- the general kernels on their n_rest_pixels pixels.
 extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                                const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
-                                               const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, int B, int Ci,
-                                               int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
-                                               mode_stream_t stream) {
+                                               const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels,
+                                               const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
+                                               int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t,
+                                               const float* x_t, mode_stream_t stream) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win");
   if (rc != MODE_OK) return rc;
@@ -865,33 +1070,49 @@ extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos
     d.sh = 1;
     d.sw = H;
   }
-  MODE_REQUIRE(n_small >= 0 && n_mid >= 0 && n_wrap >= 0 && n_rest_pixels >= 0 &&
+  MODE_REQUIRE(n_small >= 0 && n_mid >= 0 && n_wrap >= 0 && n_rest_pixels >= 0 && n_polar_items >= 0 &&
                    (size_t)n_small + n_mid + n_wrap == mode_sphere_plan_max_tiles(H, W),
                MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: the plan must cover every tile");
   if (B == 0) return MODE_OK;
-  MODE_REQUIRE(gy && pos && x && gw && workspace && tiles && (n_rest_pixels == 0 || rest_pixels) && (n_small == 0 || (rec_w && rec_off)),
+  MODE_REQUIRE(gy && pos && x && gw && workspace && tiles && (n_rest_pixels == 0 || rest_pixels) && (n_small == 0 || (rec_w && rec_off)) &&
+                   (n_polar_items == 0 || (pitems && prec_w && prec_off)),
                MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: null pointer");
   hipStream_t st = mode::as_stream(stream);
-  size_t win_bytes = 0;
+  const int NCG = mode::cdiv(d.Cig, BW_CG);
+  const size_t slice = (size_t)d.G * d.MG * NCG * BW_SLOTS * 128 * BW_CG * sizeof(float);
+  const float* gys = gy_t ? gy_t : gy;
+  const float* xs = x_t ? x_t : x;
+  int S = 0;
   if (n_small > 0) {
-    const int NCG = mode::cdiv(d.Cig, BW_CG);
-    const int S = bww_win_splits(d, n_small);
-    win_bytes = (size_t)S * d.G * d.MG * NCG * BW_SLOTS * 128 * BW_CG * sizeof(float);
+    S = bww_win_splits(d, n_small);
     const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
     rc = mode::allow_lds(sphere_bww_win_kernel, lds, "mode_sphere_conv_bwd_weight_win");
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_bww_win_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gy_t ? gy_t : gy, x_t ? x_t : x, workspace, d,
+    hipLaunchKernelGGL(sphere_bww_win_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
                        reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
     rc = mode::check_launch("mode_sphere_conv_bwd_weight_win");
     if (rc != MODE_OK) return rc;
+  }
+  int Sp = 0;
+  if (n_polar_items > 0) {
+    Sp = bww_polar_splits(d, n_polar_items);
+    const size_t lds = (size_t)BP_LDS_FLOATS * sizeof(float);
+    rc = mode::allow_lds(sphere_bww_polar_kernel, lds, "mode_sphere_conv_bwd_weight_win");
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_bww_polar_kernel, dim3(Sp, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d, pitems,
+                       reinterpret_cast<const float4*>(prec_w), prec_off, n_polar_items, Sp, S);
+    rc = mode::check_launch("mode_sphere_conv_bwd_weight_win(polar)");
+    if (rc != MODE_OK) return rc;
+  }
+  if (S + Sp > 0) {
     const long long n = (long long)d.G * d.MG * NCG * KT * 128 * BW_CG;
-    hipLaunchKernelGGL(reduce_gw_win, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S, NCG);
+    hipLaunchKernelGGL(reduce_gw_win, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, d, S + Sp, NCG);
     rc = mode::check_launch("mode_sphere_conv_bwd_weight_win(reduce)");
     if (rc != MODE_OK) return rc;
   }
   if (n_rest_pixels > 0)
-    return mode::sphere_bwd_weight_general(gy, pos, x, gw, reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + win_bytes), B, Ci,
-                                           H, W, Co, Kh, Kw, 1, 1, H, W, groups, rest_pixels, n_rest_pixels, st,
+    return mode::sphere_bwd_weight_general(gy, pos, x, gw, reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + slice * (S + Sp)), B,
+                                           Ci, H, W, Co, Kh, Kw, 1, 1, H, W, groups, rest_pixels, n_rest_pixels, st,
                                            "mode_sphere_conv_bwd_weight_win(rest)");
   return MODE_OK;
 }

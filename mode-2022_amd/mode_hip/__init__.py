@@ -33,10 +33,13 @@ SIGNATURES = {
     'mode_sphere_conv_fwd_win': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),
     'mode_transpose_planes': (_c_int, [_c_ptr] * 2 + [ctypes.c_longlong] + [_c_int] * 2 + [_c_ptr]),
     'mode_sphere_plan_rest_pixels': (_c_int, [_c_ptr] * 2 + [_c_int] * 2 + [_c_ptr] * 2),
-    'mode_sphere_conv_bwd_weight_win_workspace_bytes': (_c_size, [_c_int] * 10),
+    'mode_sphere_plan_polar_max_items': (_c_size, [_c_ptr]),
+    'mode_sphere_plan_polar': (_c_int, [_c_ptr] * 3 + [_c_int] * 2 + [_c_ptr] * 4),
+    'mode_sphere_conv_bwd_weight_win_workspace_bytes': (_c_size, [_c_int] * 11),
     'mode_sphere_plan_records_count': (_c_size, [_c_int]),
     'mode_sphere_plan_records': (_c_int, [_c_ptr] * 3 + [_c_int] * 2 + [_c_ptr] * 2),
-    'mode_sphere_conv_bwd_weight_win': (_c_int, [_c_ptr] * 6 + [_c_int] * 3 + [_c_ptr] * 3 + [_c_int] * 9 + [_c_ptr] * 3),
+    'mode_sphere_conv_bwd_weight_win': (_c_int, [_c_ptr] * 6 + [_c_int] * 3 + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 9 +
+                                        [_c_ptr] * 3),
     'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
@@ -64,7 +67,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 4  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 5  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

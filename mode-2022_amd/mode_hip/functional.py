@@ -106,7 +106,7 @@ def transpose_planes(t, out=None):
 
 def sphere_plan(pos, kh, kw):
   """Tile plan of the windowed kernels for the sampling table `pos`: (tiles int32 device tensor, (n_small, n_mid, n_wrap),
-  pixels of the non-small tiles int32 device tensor, their number, record weights, record offsets) or None when the table is not spatially compact (the
+  pixels of the non-small tiles int32 device tensor, their number, record weights, record offsets, polar items or None) or None when the table is not spatially compact (the
   general gather kernels are used then).  Built on the host by
   mode_sphere_plan_build once per (table, device) and cached, like the adjoint table."""
   key = (pos.data_ptr(), pos._version, tuple(pos.shape), kh, kw, str(pos.device))
@@ -131,8 +131,21 @@ def sphere_plan(pos, kh, kw):
       rec_off = torch.zeros(nrec, dtype=torch.int32)
       if c[0]:
         check(lib().mode_sphere_plan_records(ptr(host), ptr(tiles), ptr(counts), H, W, ptr(rec_w), ptr(rec_off)), 'mode_sphere_plan_records')
+      polar = None
+      npmax = lib().mode_sphere_plan_polar_max_items(ptr(counts))
+      if npmax and c[0]:
+        pitems = torch.zeros(20 * npmax, dtype=torch.int32)
+        prw = torch.zeros(4 * 288 * npmax, dtype=torch.float32)
+        pro = torch.zeros(288 * npmax, dtype=torch.int32)
+        npol = torch.zeros(1, dtype=torch.int32)
+        check(lib().mode_sphere_plan_polar(ptr(host), ptr(tiles), ptr(counts), H, W, ptr(pitems), ptr(prw), ptr(pro), ptr(npol)),
+              'mode_sphere_plan_polar')
+        if int(npol) > 0:
+          n = int(npol)
+          polar = (pitems[:20 * n].contiguous().to(pos.device), prw[:4 * 288 * n].contiguous().to(pos.device),
+                   pro[:288 * n].contiguous().to(pos.device), n)
       plan = (tiles.to(pos.device), (c[0], c[1], c[2]), rest[:max(nrest, 1)].contiguous().to(pos.device), nrest, rec_w.to(pos.device),
-              rec_off.to(pos.device))
+              rec_off.to(pos.device), polar)
     _plan_cache[key] = (plan, pos)  # keep `pos` alive: the key uses its address
     return plan
 
@@ -228,6 +241,7 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False):
   return gx
 
 
+SPHERE_POLAR = os.environ.get('MODE_SPHERE_POLAR', '1') == '1'  # polar kernel for the tall-window tiles (else: pixel list + general kernel)
 SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'window')  # 'window' (where the table allows) | 'gather'
 
 
@@ -247,15 +261,22 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None):
       plan = None  # no compact tile at all: nothing to gain
   with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_weight', gw, x), nbytes, flops, gy.device):
     if plan is not None:
-      tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off = plan
-      n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, G, n0, nrest)
+      tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off, polar = plan
+      if polar is not None and SPHERE_POLAR:  # the tall-window tiles on the polar kernel instead of the pixel list
+        pitems, prw, pro, npol = polar
+        nrest = 0
+      else:
+        pitems = prw = pro = None
+        npol = 0
+      n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, G, n0, nrest, npol)
       ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
       gyt = xt = None
       if SPHERE_LAYOUT == 'transposed':
         gyt = transpose_planes(gy)
         xt = x_transposed if x_transposed is not None and tuple(x_transposed.shape) == (B, Ci, W, H) else transpose_planes(x)
       check(lib().mode_sphere_conv_bwd_weight_win(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
-                                                  ptr(rec_off), ptr(rest), nrest, B, Ci, H, W, Co, Kh, Kw, G,
+                                                  ptr(rec_off), ptr(rest), nrest, ptr(pitems) if npol else None, ptr(prw) if npol else None,
+                                                  ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, G,
                                                   ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,
                                                   stream_of(gy)), 'mode_sphere_conv_bwd_weight_win')
     else:

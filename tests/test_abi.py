@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 4
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 5
 
 
 def test_argument_validation_without_gpu():
@@ -143,3 +143,43 @@ def test_sphere_window_plan_rejects_unstructured_table():
   counts = torch.zeros(4, dtype=torch.int32)
   assert lib.mode_sphere_plan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(tiles), mode_hip.ptr(counts)) == 0
   assert counts[3] > 0 and int(counts.sum()) == n
+
+
+def test_sphere_polar_plan_items():
+  """mode_sphere_plan_polar (host code): the tiles outside the small-window class become column items whose nine per-tap
+  windows (34 rows x 2 columns) hold every live sample, and the records point inside them."""
+  import numpy as np
+  import torch
+  from oracle import mode_ref
+  lib = mode_hip.lib()
+  pos = mode_ref.sphere_position(128, 256, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  n = lib.mode_sphere_plan_max_tiles(H, W)
+  tiles = torch.zeros(4 * n, dtype=torch.int32)
+  counts = torch.zeros(4, dtype=torch.int32)
+  assert lib.mode_sphere_plan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(tiles), mode_hip.ptr(counts)) == 0
+  npmax = lib.mode_sphere_plan_polar_max_items(mode_hip.ptr(counts))
+  assert npmax == (int(counts[1]) + int(counts[2])) * 8
+  items = torch.zeros(20 * npmax, dtype=torch.int32)
+  rw = torch.zeros(4 * 288 * npmax, dtype=torch.float32)
+  ro = torch.zeros(288 * npmax, dtype=torch.int32)
+  ni = torch.zeros(1, dtype=torch.int32)
+  assert lib.mode_sphere_plan_polar(mode_hip.ptr(pos), mode_hip.ptr(tiles), mode_hip.ptr(counts), H, W, mode_hip.ptr(items), mode_hip.ptr(rw),
+                                    mode_hip.ptr(ro), mode_hip.ptr(ni)) == 0
+  ni = int(ni)
+  assert ni == npmax  # 16 columns x 8 row blocks, all plannable
+  it = items.view(-1, 20)[:ni].numpy()
+  cols = sorted(set(it[:, 1].tolist()))
+  assert cols == list(range(0, 8)) + list(range(W - 8, W))
+  off = ro.view(-1, 9, 32)[:ni].numpy()
+  wts = rw.view(-1, 9, 32, 4)[:ni].numpy()
+  assert (off >= 0).all() and (off + 34 + 1 < 9 * 68 + 1).all()
+  assert ((off // 68) == np.arange(9)[None, :, None])[wts.any(-1)].all()  # a live record points into its own tap's window
+  p = pos[0].numpy()
+  for i in (0, ni // 2, ni - 1):  # spot-check the window bases against the table
+    h0, w = it[i, 0], it[i, 1]
+    for k in range(9):
+      y = p[2 * k][h0:h0 + 32, w]
+      r0 = np.maximum(np.floor(y).astype(int), 0)
+      lr = (r0 - it[i, 2 + k]) % H
+      assert (lr + 1 < 34).all()

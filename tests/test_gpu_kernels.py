@@ -164,6 +164,12 @@ def test_sphere_conv_window_kernels_match_gather_kernels(ih, iw, B, ci, co, grou
   gw2 = torch.zeros_like(w)
   HF.sphere_conv_bwd_weight(gy, pos, x, gw2, (1, 1), groups)
   assert torch.equal(gw2, gws['window'])  # deterministic
+  # the tall-window tiles: polar kernel (default) vs the pixel-list fallback on the general kernel
+  monkeypatch.setattr(HF, 'SPHERE_POLAR', False)
+  gw3 = torch.zeros_like(w)
+  HF.sphere_conv_bwd_weight(gy, pos, x, gw3, (1, 1), groups)
+  assert (gw3 - gws['window']).abs().max() < 2e-5 * scale
+  assert (gw3.cpu().double() - gw_ref).abs().max() < 1e-5 * max(1.0, float(gw_ref.abs().max()))
 
 
 def test_sphere_conv_unplannable_table_takes_the_gather_kernels():
