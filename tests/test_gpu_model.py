@@ -267,7 +267,8 @@ def test_regular_extractor_variant(golden):
   loss.backward()
   grads = dict(net.named_parameters())
   for n, s in zip(z['train/grad_names'], z['train/grad_abs_sum']):
-    assert abs(float(grads[str(n)].grad.double().abs().sum()) - s) <= 5e-2 * s + 1e-6, str(n)
+    # (tensors whose true gradient is zero -- e.g. a convolution bias in front of a BatchNorm -- hold round-off only)
+    assert abs(float(grads[str(n)].grad.double().abs().sum()) - s) <= 5e-2 * s + 1e-4, str(n)
   sd = net.state_dict()
   for k in z.files:
     if k.startswith('bn/'):
