@@ -216,21 +216,51 @@ def sphere_adjoint(pos, kh, kw, stride, out_hw):
     return hit
 
 
-def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False):
+SPHERE_BWD_DATA_T = os.environ.get('MODE_SPHERE_BWD_DATA_T', '1') == '1'  # adjoint gather on plane-transposed storage
+_pos_t_cache = {}
+
+
+def _transposed_table(pos):
+  """The sampling table of the plane-transposed problem: image (W rows, H columns), row coordinate = the original column
+  coordinate and vice versa.  Cached per table like the adjoint."""
+  key = (pos.data_ptr(), pos._version, tuple(pos.shape), str(pos.device))
+  with _adjoint_lock:
+    hit = _pos_t_cache.get(key)
+    if hit is None:
+      K2, H, W = pos.shape[1:]
+      p = pos[0].view(K2 // 2, 2, H, W)
+      t = torch.stack((p[:, 1].transpose(1, 2), p[:, 0].transpose(1, 2)), 1).reshape(1, K2, W, H).contiguous()
+      hit = _pos_t_cache[key] = (t, pos)
+    return hit[0]
+
+
+def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_transposed=None):
   """Accumulates into `gx` (B,Ci,H,W) (caller zero-fills, sphere_conv.py:62); with overwrite=True `gx` may hold anything and
-  is overwritten."""
+  is overwritten.  gy_transposed: the plane-transposed copy of gy, if the caller has one (the weight gradient needs it too):
+  with overwrite=True the gather then runs on the transposed problem, where the 64 lanes of a wave are 64 consecutive rows
+  of one column and the source pixels of a tap are runs of consecutive addresses -- on NCHW storage they are one address
+  per image row (0.50 vs 0.66 ms per 128->128 layer and 4 images, including the transpose of the result)."""
   require_gpu(gy, pos, w, gx)
   require_f32c(gy, pos, w, gx)
   dims = _sc_dims(gx.shape, w.shape, gy.shape[2:], stride, groups)
   flops = 2 * gy.numel() * w[0].numel()
   nbytes = 4 * (gx.numel() + gy.numel() + pos.numel() + w.numel())
   if SPHERE_BWD_DATA == 'gather':
-    rowptr, entries, _ = sphere_adjoint(pos, w.shape[2], w.shape[3], stride, gy.shape[2:])
     B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
+    use_t = (SPHERE_BWD_DATA_T and overwrite and gy_transposed is not None and (sH, sW) == (1, 1) and (Ho, Wo) == (H, W) and
+             tuple(gy_transposed.shape) == (B, Co, Wo, Ho))
     with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
       wp = _wpack(w, groups)
-      check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
-                                                Kw, Ho, Wo, G, 0 if overwrite else 1, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
+      if use_t:
+        rowptr, entries, _ = sphere_adjoint(_transposed_table(pos), Kh, Kw, stride, (Wo, Ho))
+        gxt = torch.empty((B, Ci, W, H), dtype=gx.dtype, device=gx.device)
+        check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy_transposed), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W,
+                                                  H, Co, Kh, Kw, Wo, Ho, G, 0, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
+        transpose_planes(gxt, gx)
+      else:
+        rowptr, entries, _ = sphere_adjoint(pos, Kh, Kw, stride, gy.shape[2:])
+        check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
+                                                  Kw, Ho, Wo, G, 0 if overwrite else 1, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
     return gx
   if overwrite:
     gx.zero_()  # the scatter form adds with atomics
@@ -245,9 +275,9 @@ SPHERE_POLAR = os.environ.get('MODE_SPHERE_POLAR', '1') == '1'  # polar kernel f
 SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'window')  # 'window' (where the table allows) | 'gather'
 
 
-def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None):
+def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy_transposed=None):
   """Accumulates into `gw` (Co,Ci/g,Kh,Kw) (caller zero-fills, sphere_conv.py:63).  x_transposed: the plane-transposed copy
-  of x kept from the forward, if any (saves rebuilding it for the windowed kernel)."""
+  of x kept from the forward, if any (saves rebuilding it for the windowed kernel); gy_transposed: the same for gy."""
   require_gpu(gy, pos, x, gw)
   require_f32c(gy, pos, x, gw)
   dims = _sc_dims(x.shape, gw.shape, gy.shape[2:], stride, groups)
@@ -272,7 +302,7 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None):
       ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
       gyt = xt = None
       if SPHERE_LAYOUT == 'transposed':
-        gyt = transpose_planes(gy)
+        gyt = gy_transposed if gy_transposed is not None and tuple(gy_transposed.shape) == (B, Co, Wo, Ho) else transpose_planes(gy)
         xt = x_transposed if x_transposed is not None and tuple(x_transposed.shape) == (B, Ci, W, H) else transpose_planes(x)
       check(lib().mode_sphere_conv_bwd_weight_win(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
                                                   ptr(rec_off), ptr(rest), nrest, ptr(pitems) if npol else None, ptr(prw) if npol else None,

@@ -91,7 +91,13 @@ def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad
                dilation_w, group)
   gy = grad_output.contiguous()
   pos = position.contiguous()
-  _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group, overwrite=overwrite_grad_input)
-  _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group, x_transposed=input_transposed)
+  # one plane-transposed copy of grad_output serves both gradients (windowed weight gradient, transposed adjoint gather)
+  gyt = None
+  if _F.SPHERE_LAYOUT == 'transposed' and (stride_h, stride_w) == (1, 1) and kernel_h * kernel_w == 9 and gy.shape[2:] == input.shape[2:]:
+    gyt = _F.transpose_planes(gy)
+  _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group, overwrite=overwrite_grad_input,
+                          gy_transposed=gyt)
+  _F.sphere_conv_bwd_weight(gy, pos, input.contiguous(), grad_weight, (stride_h, stride_w), group, x_transposed=input_transposed,
+                            gy_transposed=gyt)
   if has_bias:
     grad_bias += gy.sum((0, 2, 3))  # cpp:316-322

@@ -172,6 +172,25 @@ def test_sphere_conv_window_kernels_match_gather_kernels(ih, iw, B, ci, co, grou
   assert (gw3.cpu().double() - gw_ref).abs().max() < 1e-5 * max(1.0, float(gw_ref.abs().max()))
 
 
+@pytest.mark.parametrize('typ,ih,iw,B,ci,co,groups', [('Cassini', 64, 128, 2, 24, 40, 1), ('Cassini', 36, 72, 1, 8, 12, 2), ('ERP', 32, 64, 2, 16, 16, 1)])
+def test_sphere_conv_bwd_data_on_transposed_storage(typ, ih, iw, B, ci, co, groups):
+  """The adjoint gather run on the plane-transposed problem (transposed table, gy and gx) gives the input gradient of the
+  NCHW run: same (pixel, tap, corner) products, only the order of the entries within a row of the adjoint table can differ."""
+  pos = mode_ref.sphere_position(ih, iw, typ).to(DEV)
+  H, W = pos.shape[2:]
+  gy = _rand((B, co, H, W), 21).to(DEV)
+  w = _rand((co, ci // groups, 3, 3), 22, 0.2).to(DEV)
+  g_nchw = torch.full((B, ci, H, W), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data(gy, pos, w, g_nchw, (1, 1), groups, overwrite=True)
+  g_t = torch.full((B, ci, H, W), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data(gy, pos, w, g_t, (1, 1), groups, overwrite=True, gy_transposed=HF.transpose_planes(gy))
+  assert torch.isfinite(g_t).all()
+  assert (g_t - g_nchw).abs().max() < 1e-5 * max(1.0, float(g_nchw.abs().max()))
+  x = _rand((B, ci, H, W), 23)
+  gx_ref, _ = sphere_conv_ref.backward(x.double(), pos.cpu(), w.cpu().double(), gy.cpu().double(), (1, 1), (1, 1), (1, 1), groups)
+  assert (g_t.cpu().double() - gx_ref).abs().max() < 1e-5 * max(1.0, float(gx_ref.abs().max()))
+
+
 def test_sphere_conv_unplannable_table_takes_the_gather_kernels():
   """A table without spatial structure cannot be windowed: the plan says so and the general kernels run."""
   g = torch.Generator().manual_seed(3)
