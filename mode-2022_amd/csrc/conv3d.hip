@@ -682,6 +682,153 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
   }
 }
 
+// Stride-2 variant, software pipelined.  The generic kernel above alternates "stage a tile" and "27 x 16 MFMAs on it" with a
+// barrier in between, and at two workgroups per CU (75 KB of LDS each) there is nothing else to hide the staging behind:
+// 37 TFLOP/s.  Here the NEXT tile travels global -> registers while the MFMAs of the current one run (78 loads per thread in
+// flight, issued before the k-loop, consumed after it), so a step costs max(load, MFMA) + the LDS stores.  The item -> (channel,
+// row, column group) map is chosen so that everything but the half-wave's channel is a compile-time constant: a tile needs 9
+// row offsets, 2 column offsets and an 11-bit validity mask, the 72 addresses are sums of those.
+__global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                     float* __restrict__ part, WDims d) {
+  using G = WGeom<2, 1>;
+  constexpr int XR = G::XR, XW = G::XW, XPLANE = G::XPLANE, GPLANE = G::GPLANE;
+  static_assert(XR == 3 && XW == 65, "item map below assumes the 3 x 3 x 65 tile");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xl = lds;                 // [32][XPLANE]
+  float* gl = lds + 32 * XPLANE;   // [32][GPLANE]
+  const int s = blockIdx.x, ob = blockIdx.y, cb = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hwv = tid >> 5, l32 = tid & 31;
+  const int HW = d.H * d.W, DHW = d.D * HW;          // (host guarantees Ci * DHW < 2^29)
+  const int oHW = d.Ho * d.Wo, oDHW = d.Do * oHW;
+
+  f32x16 acc[7];
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    acc[t] = (f32x16){0};
+    const int tap = wave + 4 * t;  // < 27 except wave 3, t = 6
+    toff[t] = (tap / 9) * (XR * XW) + ((tap / 3) % 3) * XW + (tap % 3);
+  }
+  const bool last_valid = (wave + 24) < 27;
+
+  // x tile = 288 (channel, depth, row) rows of 65 columns.  Columns 0..63: item jj of half-wave hwv is channel hwv + 8 * (jj / 18),
+  // row (jj % 18) / 2, column group jj & 1.  Column 64: one item per thread (+ 32 threads a second one).  gy tile: 32 x 32.
+  float px[72], pe[2], pg[4];
+  unsigned chan_ok = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) chan_ok |= (cb * 32 + hwv + 8 * q < d.Ci ? 1u : 0u) << q;
+  const int e_r0 = tid, e_r1 = tid + 256;  // rows of the column-64 items
+  const int e_c0 = e_r0 / 9, e_m0 = e_r0 - 9 * e_c0, e_c1 = e_r1 / 9, e_m1 = e_r1 - 9 * e_c1;
+
+  // issues the loads of tile tt, returns its validity mask (bits 0..8 rows, 9..10 column groups, 11 column 64, 12 gy column)
+  auto prefetch = [&](int tt) -> unsigned {
+    int t = tt;
+    const int wt = t % d.nWt;
+    t /= d.nWt;
+    const int ht = t % d.nHt;
+    t /= d.nHt;
+    const int qd = t % d.Do;
+    const int b = t / d.Do;
+    const int w0 = wt * 32, h0 = ht;
+    const float* xb = x + ((long long)b * d.Ci + cb * 32) * (long long)DHW;
+    const float* gb = gy + ((long long)b * d.Co + ob * 32) * (long long)oDHW;
+    unsigned m = 0;
+    int rowoff[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int gd = 2 * qd + r / 3 - 1, gh = 2 * h0 + r % 3 - 1;
+      const bool ok = gd >= 0 && gd < d.D && gh >= 0 && gh < d.H;
+      rowoff[r] = ok ? gd * HW + gh * d.W : 0;
+      m |= (ok ? 1u : 0u) << r;
+    }
+    const int gw0 = 2 * w0 + l32 - 1, gw1 = gw0 + 32, gw2 = 2 * w0 + 63;
+    m |= (gw0 >= 0 && gw0 < d.W ? 1u : 0u) << 9;
+    m |= (gw1 < d.W ? 1u : 0u) << 10;
+    m |= (gw2 < d.W ? 1u : 0u) << 11;
+    m |= (w0 + l32 < d.Wo ? 1u : 0u) << 12;
+    const int cbase = hwv * DHW;
+#pragma unroll
+    for (int jj = 0; jj < 72; ++jj) {
+      const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+      const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
+      const int off = cbase + q * 8 * DHW + rowoff[r] + (g ? gw1 : gw0);
+      px[jj] = xb[ok ? off : 0];
+    }
+    {
+      const int gd0 = 2 * qd + e_m0 / 3 - 1, gh0 = 2 * h0 + e_m0 % 3 - 1;
+      const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
+      pe[0] = xb[ok0 ? e_c0 * DHW + gd0 * HW + gh0 * d.W + gw2 : 0];
+      const int gd1 = 2 * qd + e_m1 / 3 - 1, gh1 = 2 * h0 + e_m1 % 3 - 1;
+      const bool ok1 = e_r1 < 288 && ((m >> e_m1) & 1) && ((m >> 11) & 1) && cb * 32 + e_c1 < d.Ci;
+      pe[1] = xb[ok1 ? e_c1 * DHW + gd1 * HW + gh1 * d.W + gw2 : 0];
+    }
+    const int gbase = qd * oHW + h0 * d.Wo + w0 + l32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 8 * j + hwv;
+      const bool ok = ((m >> 12) & 1) && ob * 32 + o < d.Co;
+      pg[j] = gb[ok ? o * oDHW + gbase : 0];
+    }
+    return m;
+  };
+  // registers -> LDS for the tile whose mask is m (masked elements become zeros)
+  auto store = [&](unsigned m) {
+    float* xrow = xl + hwv * XPLANE + l32;
+#pragma unroll
+    for (int jj = 0; jj < 72; ++jj) {
+      const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+      const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
+      xrow[q * 8 * XPLANE + r * XW + 32 * g] = ok ? px[jj] : 0.f;
+    }
+    const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
+    xl[e_c0 * XPLANE + e_m0 * XW + 64] = ok0 ? pe[0] : 0.f;
+    if (e_r1 < 288) {
+      const bool ok1 = ((m >> e_m1) & 1) && ((m >> 11) & 1) && cb * 32 + e_c1 < d.Ci;
+      xl[e_c1 * XPLANE + e_m1 * XW + 64] = ok1 ? pe[1] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 8 * j + hwv;
+      const bool ok = ((m >> 12) & 1) && ob * 32 + o < d.Co;
+      gl[o * GPLANE + l32] = ok ? pg[j] : 0.f;
+    }
+  };
+
+  unsigned mask = 0;
+  if (s < d.T) mask = prefetch(s);
+  const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);
+  const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5) * 2;
+  for (int tt = s; tt < d.T; tt += d.S) {
+    store(mask);
+    __syncthreads();
+    if (tt + d.S < d.T) mask = prefetch(tt + d.S);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a = ap[2 * ks];
+      const float* bq = bp + 4 * ks;
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
+      if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
+    }
+    __syncthreads();
+  }
+
+  float* pb = part + (((long long)s * d.MTo + ob) * d.MTc + cb) * (27 * 1024);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < 27) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        pb[tap * 1024 + i * 32 + (lane & 31)] = acc[t][q];
+      }
+    }
+  }
+}
+
 // Stride-1 variant with a rolling depth window: a work unit is a (b, h-tile, w-tile) column times a run of DC consecutive
 // depths; the three x planes d-1, d, d+1 live in an LDS ring and only plane d+1 is staged per step (the halo re-read per
 // 64 output voxels drops from 408 to 136 floats per channel).  Same fragment maps and partial layout as the kernel above.
@@ -891,9 +1038,15 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
     hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units);
   } else {
     const size_t lds = WGeom<2, WTH2>::LDS;
-    rc = mode::allow_lds(conv3d_bwd_weight_kernel<2, WTH2>, lds, "mode_conv3d_bwd_weight");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_bwd_weight_kernel<2, WTH2>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+    if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
+      rc = mode::allow_lds(conv3d_bwd_weight_s2_kernel, lds, "mode_conv3d_bwd_weight");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(conv3d_bwd_weight_s2_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+    } else {
+      rc = mode::allow_lds(conv3d_bwd_weight_kernel<2, WTH2>, lds, "mode_conv3d_bwd_weight");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL((conv3d_bwd_weight_kernel<2, WTH2>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+    }
   }
   rc = mode::check_launch("mode_conv3d_bwd_weight");
   if (rc != MODE_OK) return rc;
