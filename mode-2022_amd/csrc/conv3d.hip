@@ -837,8 +837,7 @@ constexpr int RING_DC = 12;
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                     float* __restrict__ part, WDims d, int nDc, int units) {
   constexpr int WTH = 2, XR = WTH + 2, XW = 34, PS = XR * XW;  // plane = 136 floats
-  constexpr int RNF = 8;                                       // plane loads in flight per thread (16 costs the second wave per SIMD: 1.58 -> 1.90 ms)
-  constexpr int XPLANE = 3 * PS + 1;                           // 409 (odd)
+    constexpr int XPLANE = 3 * PS + 1;                           // 409 (odd)
   constexpr int GPLANE = WTH * 32 + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xl = lds;                 // [32][3 ring slots][XR][XW]
@@ -858,6 +857,13 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
     khw[t] = ((tap / 3) % 3) * XW + (tap % 3);
   }
   const bool last_valid = (wave + 24) < 27;
+  const int hwv = tid >> 5, l32 = tid & 31;
+  const int HWi = d.H * d.W, DHWi = d.D * HWi;  // (host guarantees 32-bit element offsets within a sample)
+  unsigned chan_ok = 0, gchan_ok = 0;           // x item j is channel 2 * j + (hwv >> 2), gy item j is channel 4 * j + (hwv >> 1)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) chan_ok |= (cb * 32 + 2 * j + (hwv >> 2) < d.Ci ? 1u : 0u) << j;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gchan_ok |= (ob * 32 + 4 * j + (hwv >> 1) < d.Co ? 1u : 0u) << j;
 
   for (int u = s; u < units; u += d.S) {
     int t = u;
@@ -872,59 +878,61 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
     const float* xb = x + ((long long)b * d.Ci + cb * 32) * DHW;
     const float* gb = gy + ((long long)b * d.Co + ob * 32) * DHW;
 
+    // Software pipeline over the depths of the unit: while the MFMAs of depth dd run, plane dd+2 and the gy rows of depth
+    // dd+1 travel global -> registers (25 loads per thread); they are written to LDS (ring slot of plane dd-1, which is dead
+    // by then) after the k-loop.  Loads are unconditional from clamped addresses, the masks are applied at the LDS store.
+    const int gh_x = h0 + (hwv & 3) - 1;      // every item of a thread is the same tile row ...
+    const int gw_x = w0 + l32;                // ... and column
+    const bool rc_ok = gh_x >= 0 && gh_x < d.H && gw_x < d.W;
+    const int xoff = (hwv >> 2) * DHWi + (rc_ok ? gh_x * d.W + gw_x : 0);  // + 2 * item * DHW + z * HW
+    const int hr = tid >> 1, hside = tid & 1;  // halo item: (channel, row) = (hr >> 2, hr & 3), left / right column
+    const int gh_h = h0 + (hr & 3) - 1, gw_h = hside ? w0 + 32 : w0 - 1;
+    const bool h_ok = cb * 32 + (hr >> 2) < d.Ci && gh_h >= 0 && gh_h < d.H && gw_h >= 0 && gw_h < d.W;
+    const int hoff = h_ok ? (hr >> 2) * DHWi + gh_h * d.W + gw_h : 0;
+    const int gh_g = h0 + (hwv & 1);           // gy item j: output channel 4 * j + (hwv >> 1), row hwv & 1
+    const bool g_ok = gh_g < d.H && gw_x < d.W;
+    const int goff = (hwv >> 1) * DHWi + (g_ok ? gh_g * d.W + gw_x : 0);
+    float px[16], ph, pg[8];
+    auto load_plane = [&](int z) {
+      const int zo = (z >= 0 && z < d.D ? z : 0) * HWi;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) px[j] = xb[((chan_ok >> j) & 1) && rc_ok ? xoff + 2 * j * DHWi + zo : 0];
+      ph = xb[hoff + (h_ok ? zo : 0)];
+    };
+    auto store_plane = [&](int z) {
+      const bool zok = z >= 0 && z < d.D;
+      float* dst = xl + (hwv >> 2) * XPLANE + ((z + 3) % 3) * PS + (hwv & 3) * XW + 1 + l32;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dst[2 * j * XPLANE] = (zok && rc_ok && ((chan_ok >> j) & 1)) ? px[j] : 0.f;
+      xl[(hr >> 2) * XPLANE + ((z + 3) % 3) * PS + (hr & 3) * XW + (hside ? 33 : 0)] = (zok && h_ok) ? ph : 0.f;
+    };
+    auto load_gy = [&](int z) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pg[j] = gb[((gchan_ok >> j) & 1) && g_ok ? goff + 4 * j * DHWi + z * HWi : 0];
+    };
+    auto store_gy = [&]() {
+      float* dst = gl + (hwv >> 1) * GPLANE + (hwv & 1) * 32 + l32;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[4 * j * GPLANE] = (g_ok && ((gchan_ok >> j) & 1)) ? pg[j] : 0.f;
+    };
+    // prologue: planes dlo-1, dlo, dlo+1 and the gy rows of depth dlo
+    load_plane(dlo - 1);
+    load_gy(dlo);
+    store_plane(dlo - 1);
+    store_gy();
+    load_plane(dlo);
+    store_plane(dlo);
+    load_plane(dlo + 1);
+    store_plane(dlo + 1);
+    __syncthreads();
+
     for (int dd = dlo; dd < dhi; ++dd) {
-      // stage x planes: all three at the start of a unit, then only plane dd+1 (ring slot (z+3) % 3 for depth z).
-      // Branch-free: a half-wave loads the 32 interior columns of one (channel, row) with one coalesced instruction, 8 such
-      // loads per thread are in flight together; the two halo columns of every row are one more load per thread.
-      const int hwv = tid >> 5, l32 = tid & 31;
-      const int zfirst = (dd == dlo) ? dd - 1 : dd + 1;
-      const int zlast = dd + 1;
-      for (int z = zfirst; z <= zlast; ++z) {
-        const int slot = (z + 3) % 3;
-        const bool zok = z >= 0 && z < d.D;
-        const long long zoff = (long long)(zok ? z : 0) * HW;
-#pragma unroll 1
-        for (int kb = 0; kb < 16; kb += RNF) {
-          float t8[RNF];
-#pragma unroll
-          for (int j = 0; j < RNF; ++j) {
-            const int r = (kb + j) * 8 + hwv;  // (channel, row) = (r >> 2, r & 3)
-            const int c = r >> 2, gh = h0 + (r & 3) - 1, gw = w0 + l32;
-            const bool ok = zok && cb * 32 + c < d.Ci && gh >= 0 && gh < d.H && gw < d.W;
-            const float v = xb[ok ? c * DHW + zoff + gh * d.W + gw : 0];
-            t8[j] = ok ? v : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < RNF; ++j) {
-            const int r = (kb + j) * 8 + hwv;
-            xl[(r >> 2) * XPLANE + slot * PS + (r & 3) * XW + 1 + l32] = t8[j];
-          }
-        }
-        {
-          const int r = tid >> 1, side = tid & 1;
-          const int c = r >> 2, gh = h0 + (r & 3) - 1, gw = side ? w0 + 32 : w0 - 1;
-          const bool ok = zok && cb * 32 + c < d.Ci && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
-          const float v = xb[ok ? c * DHW + zoff + gh * d.W + gw : 0];
-          xl[c * XPLANE + slot * PS + (r & 3) * XW + (side ? 33 : 0)] = ok ? v : 0.f;
-        }
+      const bool more = dd + 1 < dhi;
+      if (more) {
+        load_plane(dd + 2);
+        load_gy(dd + 1);
       }
-      {
-        float t8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = j * 8 + hwv;  // (output channel, row) = (r >> 1, r & 1)
-          const int o = r >> 1, gh = h0 + (r & 1), gw = w0 + l32;
-          const bool ok = ob * 32 + o < d.Co && gh < d.H && gw < d.W;
-          const float v = gb[ok ? o * DHW + dd * HW + gh * d.W + gw : 0];
-          t8[j] = ok ? v : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = j * 8 + hwv;
-          gl[(r >> 1) * GPLANE + (r & 1) * 32 + l32] = t8[j];
-        }
-      }
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
       int toff[7];
 #pragma unroll
       for (int t7 = 0; t7 < 7; ++t7) toff[t7] = ((dd + kd[t7] + 2) % 3) * PS + khw[t7];  // depth dd + kd - 1
@@ -940,6 +948,11 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
           for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
           if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
         }
+      }
+      __syncthreads();
+      if (more) {
+        store_plane(dd + 2);
+        store_gy();
       }
       __syncthreads();
     }
@@ -1030,12 +1043,18 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   make_wdims(d, B, Ci, D, H, W, Co, stride);
   if (stride == 1) {
     const size_t lds = WGeom<1, WTH1>::LDS;  // same footprint: 3 planes of (WTH+2) x 34 per channel + the gy tile
-    rc = mode::allow_lds(conv3d_bwd_weight_ring_kernel, lds, "mode_conv3d_bwd_weight");
-    if (rc != MODE_OK) return rc;
-    const int nDc = mode::cdiv(D, RING_DC);
-    const int units = B * d.nHt * d.nWt * nDc;
-    if (d.S > units) d.S = units;  // never more than the workspace query assumed
-    hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units);
+    if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
+      rc = mode::allow_lds(conv3d_bwd_weight_ring_kernel, lds, "mode_conv3d_bwd_weight");
+      if (rc != MODE_OK) return rc;
+      const int nDc = mode::cdiv(D, RING_DC);
+      const int units = B * d.nHt * d.nWt * nDc;
+      if (d.S > units) d.S = units;  // never more than the workspace query assumed
+      hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units);
+    } else {
+      rc = mode::allow_lds(conv3d_bwd_weight_kernel<1, WTH1>, lds, "mode_conv3d_bwd_weight");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL((conv3d_bwd_weight_kernel<1, WTH1>), dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+    }
   } else {
     const size_t lds = WGeom<2, WTH2>::LDS;
     if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
