@@ -113,22 +113,24 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
   const float* bbase = tile + (lane >> 5) * PLANE + (lane & 31);
   const float* xb = x + (long long)b * d.Ci * DHW;
 
-  // ---- staging of the haloed input tile, one 8-channel chunk at a time.
-  // The tile is NROWS = 8*ID*IH rows of IW floats.  A half-wave loads 32 consecutive columns of one row with one coalesced
-  // instruction ("main" items); the 1-2 remaining halo columns of every row are "halo" items.  All loads of a chunk are
-  // issued branch-free into registers (out-of-volume elements read a safe address and are zeroed by a select), so they are
-  // in flight together; with OVERLAP they are issued before the MFMA phase of the previous chunk and written to LDS after it.
-  constexpr int NROWS = CCH * ID * IH;
+  // ---- staging of the haloed input tile, one 8-channel chunk at a time, software pipelined: the loads of chunk ch+1 are
+  // issued before the MFMA phase of chunk ch and written to LDS after it.  The tile is 8 channels x RPC = ID*IH rows of IW
+  // floats.  Half-wave hwv owns channel hwv of the chunk: its item j is row j / NG, 32-column group j % NG -- one coalesced
+  // 128-byte load per half-wave, and (row, group) are compile-time constants, so an address is rowtab[row] + column.  The 1-2
+  // remaining halo columns of every row are spread over the threads.  Loads are unconditional from clamped addresses; the
+  // validity is recomputed at the LDS store (a select at the load would wait for it, or keep the masks alive across the MFMAs).
+  constexpr int RPC = ID * IH;
+  constexpr int NROWS = CCH * RPC;
   constexpr int NG = (S == 1) ? 1 : 2;      // 32-column groups per row
   constexpr int GO = (S == 1) ? 1 : 0;      // first column of group 0
   constexpr int NHALO = (S == 1) ? 2 : 1;   // leftover columns per row: {0, 33} or {64}
-  constexpr int NPM = (NROWS * NG + 7) / 8;
+  constexpr int NIT = RPC * NG;
   constexpr int NPH = (NROWS * NHALO + NT - 1) / NT;
-  constexpr bool OVERLAP = (MT == 1 && S == 1);
+  static_assert(NT == 32 * CCH, "one half-wave per channel of the chunk");
   int* rowtab = reinterpret_cast<int*>(tile + CCH * PLANE);  // per row: element offset of (c, gd, gh, 0) or -1
   for (int r = tid; r < NROWS; r += NT) {
-    const int c = r / (ID * IH);
-    const int rem = r - c * (ID * IH);
+    const int c = r / RPC;
+    const int rem = r - c * RPC;
     const int dz = rem / IH;
     const int hy = rem - dz * IH;
     const int gd = d0 * S + dz - 1, gh = h0 * S + hy - 1;
@@ -136,85 +138,21 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
   }
   __syncthreads();
   const int hwv = tid >> 5, l32 = tid & 31;
-  // passes are processed in batches of NBM (all of them when overlapping with the MFMA phase; 16 otherwise, to bound the
-  // number of live registers next to the accumulators)
-  constexpr int NBM = OVERLAP ? NPM : 1;  // the register-resident whole-chunk form is only used when overlapping
-  float vm[NBM], vh[NPH];
+  const int* myrows = rowtab + hwv * RPC;
+  float* mytile = tile + hwv * PLANE;
+  float vm[NIT], vh[NPH];
 
-  auto issue = [&](int ch, int kb) {
+  auto issue = [&](int ch) {
     const float* xc = xb + (long long)ch * CCH * DHW;
+    const bool cok = ch * CCH + hwv < d.Ci;
 #pragma unroll
-    for (int j = 0; j < NBM; ++j) {
-      const int item = (kb + j) * 8 + hwv;
-      const int r = item / NG, g = item - r * NG;
+    for (int j = 0; j < NIT; ++j) {
+      const int rem = j / NG, g = j % NG;
       const int gw = w0 * S + GO + 32 * g + l32 - 1;
-      const int off = (kb + j < NPM && item < NROWS * NG) ? rowtab[r] : -1;
-      const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
-      const float v = xc[ok ? off + gw : 0];
-      vm[j] = ok ? v : 0.f;
+      const int off = myrows[rem];
+      const bool ok = cok && off >= 0 && gw >= 0 && gw < d.W;
+      vm[j] = xc[(unsigned)(ok ? off + gw : 0)];
     }
-    if (kb == 0) {
-#pragma unroll
-      for (int k = 0; k < NPH; ++k) {
-        const int item = k * NT + tid;
-        const int r = item / NHALO, side = item - r * NHALO;
-        const int wx = (S == 1) ? (side ? 33 : 0) : 64;
-        const int gw = w0 * S + wx - 1;
-        const int off = (item < NROWS * NHALO) ? rowtab[r] : -1;
-        const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
-        const float v = xc[ok ? off + gw : 0];
-        vh[k] = ok ? v : 0.f;
-      }
-    }
-  };
-  auto commit = [&](int kb) {
-#pragma unroll
-    for (int j = 0; j < NBM; ++j) {
-      const int item = (kb + j) * 8 + hwv;
-      const int r = item / NG, g = item - r * NG;
-      const int wx = GO + 32 * g + l32;
-      const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
-      if (kb + j < NPM && item < NROWS * NG) tile[r * IW + lw] = vm[j];
-    }
-    if (kb == 0) {
-#pragma unroll
-      for (int k = 0; k < NPH; ++k) {
-        const int item = k * NT + tid;
-        const int r = item / NHALO, side = item - r * NHALO;
-        const int wx = (S == 1) ? (side ? 33 : 0) : 64;
-        const int lw = (S == 1) ? wx : 32;  // column 64 = odd-phase entry O[32] of the [O | E] split
-        if (item < NROWS * NHALO) tile[r * IW + lw] = vh[k];
-      }
-    }
-  };
-  // non-overlapped staging: NF passes (= NF loads per thread) in flight at a time, registers local to the loop body.  The
-  // phase is latency-bound (every batch waits a full memory round trip): as many loads per batch as the registers allow.
-  constexpr int NF = 8;  // (16 / 24 measured slower here: the extra registers cost more than the shorter latency chain)
-  auto stage_now = [&](int ch) {
-    const float* xc = xb + (long long)ch * CCH * DHW;
-#pragma unroll 1
-    for (int kb = 0; kb < NPM; kb += NF) {
-      float t8[NF];
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int item = (kb + j) * 8 + hwv;
-        const int r = item / NG, g = item - r * NG;
-        const int gw = w0 * S + GO + 32 * g + l32 - 1;
-        const int off = (item < NROWS * NG) ? rowtab[r] : -1;
-        const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
-        const float v = xc[ok ? off + gw : 0];
-        t8[j] = ok ? v : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int item = (kb + j) * 8 + hwv;
-        const int r = item / NG, g = item - r * NG;
-        const int wx = GO + 32 * g + l32;
-        const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
-        if (item < NROWS * NG) tile[r * IW + lw] = t8[j];
-      }
-    }
-    float th[NPH];
 #pragma unroll
     for (int k = 0; k < NPH; ++k) {
       const int item = k * NT + tid;
@@ -222,24 +160,43 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
       const int wx = (S == 1) ? (side ? 33 : 0) : 64;
       const int gw = w0 * S + wx - 1;
       const int off = (item < NROWS * NHALO) ? rowtab[r] : -1;
-      const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / (ID * IH) < d.Ci;
-      const float v = xc[ok ? off + gw : 0];
-      th[k] = ok ? v : 0.f;
+      const bool ok = off >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / RPC < d.Ci;
+      vh[k] = xc[(unsigned)(ok ? off + gw : 0)];
+    }
+  };
+  auto commit = [&](int ch) {
+    const bool cok = ch * CCH + hwv < d.Ci;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int rem = j / NG, g = j % NG;
+      const int wx = GO + 32 * g + l32;
+      const int gw = w0 * S + wx - 1;
+      const int lw = (S == 1) ? wx : ((wx & 1) ? 33 + (wx >> 1) : (wx >> 1));
+      const bool ok = cok && myrows[rem] >= 0 && gw >= 0 && gw < d.W;
+      mytile[rem * IW + lw] = ok ? vm[j] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NPH; ++k) {
       const int item = k * NT + tid;
       const int r = item / NHALO, side = item - r * NHALO;
       const int wx = (S == 1) ? (side ? 33 : 0) : 64;
-      const int lw = (S == 1) ? wx : 32;
-      if (item < NROWS * NHALO) tile[r * IW + lw] = th[k];
+      const int gw = w0 * S + wx - 1;
+      const int lw = (S == 1) ? wx : 32;  // column 64 = odd-phase entry O[32] of the [O | E] split
+      if (item < NROWS * NHALO) {
+        const bool ok = rowtab[r] >= 0 && gw >= 0 && gw < d.W && ch * CCH + r / RPC < d.Ci;
+        tile[r * IW + lw] = ok ? vh[k] : 0.f;
+      }
     }
   };
 
-  stage_now(0);
+  issue(0);
+  commit(0);
   __syncthreads();
   for (int ch = 0; ch < d.NCHUNK; ++ch) {
-    if (OVERLAP && ch + 1 < d.NCHUNK) issue(ch + 1, 0);  // in flight during the MFMA phase below
+    if (ch + 1 < d.NCHUNK) {
+      issue(ch + 1);  // in flight during the MFMA phase below
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- 27 taps x 4 channel pairs x R rows x MT tiles of MFMA
     const float4* wq = wp + ((long long)ch * 27) * 64 + lane;
 #pragma unroll
@@ -263,10 +220,7 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
     }
     __syncthreads();  // every wave is done reading this chunk
     if (ch + 1 < d.NCHUNK) {
-      if (OVERLAP)
-        commit(0);
-      else
-        stage_now(ch + 1);
+      commit(ch + 1);
       __syncthreads();
     }
   }
