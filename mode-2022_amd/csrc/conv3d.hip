@@ -338,41 +338,50 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
   const float* bbase = tile + (lane >> 5) * PLANE + dz * (IH * IW) + hy * IW + (lane & 31);
   const float* xb = x + (long long)b * d.Ci * DHW;
 
+  // Staging, software pipelined like conv3d_kernel: half-wave hwv owns channel hwv of the 8-channel chunk; its item j is tile
+  // row j (RPC = ID*IH rows of 32 coalesced columns), the 33rd column of every row is one more load for the first 72 threads.
+  // The loads of chunk ch+1 are issued before the MFMAs of chunk ch and written to LDS after them.
+  constexpr int RPC = ID * IH, NROWS = CCH * RPC;
+  static_assert(NROWS <= NT, "one thread per row for the leftover column");
+  const int hwv = tid >> 5, l32 = tid & 31;
+  int rowoff[RPC];
+  unsigned rowok = 0;
+#pragma unroll
+  for (int j = 0; j < RPC; ++j) {
+    const int gd = d0 + j / IH, gh = h0 + j % IH;
+    const bool ok = gd < d.D && gh < d.H && w0 + l32 < d.W;
+    rowoff[j] = ok ? (int)(gd * HW + gh * d.W) + w0 + l32 : 0;
+    rowok |= (ok ? 1u : 0u) << j;
+  }
+  const int e_c = tid / RPC, e_rem = tid - e_c * RPC;  // leftover-column item of thread tid < NROWS
+  const int e_gd = d0 + e_rem / IH, e_gh = h0 + e_rem % IH;
+  const bool e_in = tid < NROWS && e_gd < d.D && e_gh < d.H && w0 + 32 < d.W;
+  const int e_off = e_in ? (int)(e_gd * HW + e_gh * d.W) + w0 + 32 : 0;
+  float vm[RPC], ve;
+  auto issue = [&](int ch) {
+    const float* xc = xb + ((long long)ch * CCH + hwv) * DHW;
+    const bool cok = ch * CCH + hwv < d.Ci;
+#pragma unroll
+    for (int j = 0; j < RPC; ++j) vm[j] = xc[(unsigned)(cok ? rowoff[j] : 0)];
+    const bool eok = e_in && ch * CCH + e_c < d.Ci;
+    ve = xb[eok ? ((long long)ch * CCH + e_c) * DHW + e_off : 0];
+  };
+  auto commit = [&](int ch) {
+    const bool cok = ch * CCH + hwv < d.Ci;
+    float* dst = tile + hwv * PLANE + l32;
+#pragma unroll
+    for (int j = 0; j < RPC; ++j) dst[j * IW] = (cok && ((rowok >> j) & 1)) ? vm[j] : 0.f;
+    if (tid < NROWS) tile[tid * IW + 32] = (e_in && ch * CCH + e_c < d.Ci) ? ve : 0.f;
+  };
+
+  issue(0);
+  commit(0);
+  __syncthreads();
   for (int ch = 0; ch < d.NCHUNK; ++ch) {
-    {
-      // branch-free row staging: CCH*ID*IH rows of 33 floats = 32 coalesced columns per half-wave + one leftover column
-      constexpr int NROWS = CCH * ID * IH;
-      constexpr int DNF = 16;  // loads in flight per thread and batch (the phase is latency-bound)
-      const int hwv = tid >> 5, l32 = tid & 31;
-      const float* xc = xb + (long long)ch * CCH * DHW;
-#pragma unroll 1
-      for (int kb = 0; kb < NROWS; kb += 8 * DNF) {
-        float t8[DNF];
-#pragma unroll
-        for (int j = 0; j < DNF; ++j) {
-          const int r = kb + j * 8 + hwv;
-          const int c = r / (ID * IH), rem = r - c * (ID * IH);
-          const int gd = d0 + rem / IH, gh = h0 + rem % IH, gw = w0 + l32;
-          const bool ok = r < NROWS && ch * CCH + c < d.Ci && gd < d.D && gh < d.H && gw < d.W;
-          const float v = xc[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
-          t8[j] = ok ? v : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < DNF; ++j) {
-          const int r = kb + j * 8 + hwv;
-          if (r < NROWS) tile[r * IW + l32] = t8[j];
-        }
-      }
-      if (tid < NROWS) {
-        const int r = tid;
-        const int c = r / (ID * IH), rem = r - c * (ID * IH);
-        const int gd = d0 + rem / IH, gh = h0 + rem % IH, gw = w0 + 32;
-        const bool ok = ch * CCH + c < d.Ci && gd < d.D && gh < d.H && gw < d.W;
-        const float v = xc[ok ? c * DHW + gd * HW + gh * d.W + gw : 0];
-        tile[r * IW + 32] = ok ? v : 0.f;
-      }
+    if (ch + 1 < d.NCHUNK) {
+      issue(ch + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
     const float4* wq = wp + (((long long)mt * d.NCHUNK + ch) * 27) * 64 + lane;
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
@@ -396,6 +405,10 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
                 acc[pd][ph][pw] = mfma32(a4.w, bbase[6 * PLANE + off], acc[pd][ph][pw]);
               }
     __syncthreads();
+    if (ch + 1 < d.NCHUNK) {
+      commit(ch + 1);
+      __syncthreads();
+    }
   }
 
   float* yb = y + (long long)b * d.Co * oDHW;
