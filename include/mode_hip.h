@@ -117,7 +117,7 @@ int mode_transpose_planes(const float* in, float* out, long long planes, int H, 
  * (mode_sphere_plan_rest_pixels: linear indices h*W + w, sorted; at most H*W; n_polar_items = 0 then) on the general kernels.  ADDS to gw like
  * mode_sphere_conv_bwd_weight; deterministic.  `workspace` >= mode_sphere_conv_bwd_weight_win_workspace_bytes().
  * gy_t / x_t (both or neither): plane-transposed copies of gy / x for the windowed kernel (see mode_transpose_planes); the
- * general kernels always read gy / x. */
+ * general kernels always read gy / x (which may be null when gy_t / x_t are given and n_rest_pixels = 0). */
 int mode_sphere_plan_rest_pixels(const int32_t* tiles_host, const int32_t* counts, int H, int W, int32_t* pix_host,
                                  int32_t* n_pix);
 

@@ -1074,7 +1074,9 @@ extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos
                    (size_t)n_small + n_mid + n_wrap == mode_sphere_plan_max_tiles(H, W),
                MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: the plan must cover every tile");
   if (B == 0) return MODE_OK;
-  MODE_REQUIRE(gy && pos && x && gw && workspace && tiles && (n_rest_pixels == 0 || rest_pixels) && (n_small == 0 || (rec_w && rec_off)) &&
+  // (the NCHW tensors are only read by the pixel-list fallback: with the transposed copies and no listed pixel they may be null)
+  MODE_REQUIRE(((gy && x) || (gy_t && n_rest_pixels == 0)) && pos && gw && workspace && tiles && (n_rest_pixels == 0 || rest_pixels) &&
+                   (n_small == 0 || (rec_w && rec_off)) &&
                    (n_polar_items == 0 || (pitems && prec_w && prec_off)),
                MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: null pointer");
   hipStream_t st = mode::as_stream(stream);

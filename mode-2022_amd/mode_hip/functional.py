@@ -317,6 +317,77 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy
   return gw
 
 
+# ------------------------------------------------------------------------------------ plane-transposed operator
+# A run of stride-1 3x3 spherical layers (layer4 of the extractor: 16 of them, with BatchNorm / ReLU / residual adds in
+# between, all of which are indifferent to the order of the two spatial axes) can stay in the (B, C, W, H) storage the
+# windowed kernels work on: the three functions below are the operator on that storage, without any transpose.
+def sphere_t_supported(pos, w, B, groups):
+  """True when the windowed forward would run for this table / weight / batch (else callers use the NCHW operator)."""
+  if SPHERE_LAYOUT != 'transposed' or SPHERE_FWD != 'window' or SPHERE_BWD_WEIGHT != 'window' or SPHERE_BWD_DATA != 'gather':
+    return False
+  if w.shape[2] * w.shape[3] != 9:
+    return False
+  plan = sphere_plan(pos, w.shape[2], w.shape[3])
+  if plan is None or plan[1][0] == 0 or (plan[3] and not (plan[6] is not None and SPHERE_POLAR)):
+    return False
+  return sum(plan[1]) * B * groups * (-(-(w.shape[0] // groups) // 128)) >= SPHERE_FWD_MIN_WG
+
+
+def sphere_conv_fwd_t(xt, pos, w, yt, groups):
+  """yt (B,Co,W,H) = spherical convolution of xt (B,Ci,W,H), both plane-transposed; stride 1, 3x3 taps."""
+  require_gpu(xt, pos, w, yt)
+  require_f32c(xt, pos, w, yt)
+  B, Ci, W, H = xt.shape
+  Co, _, Kh, Kw = w.shape
+  assert tuple(pos.shape[2:]) == (H, W) and tuple(yt.shape) == (B, Co, W, H)
+  tiles, (n0, n1, n2) = sphere_plan(pos, Kh, Kw)[:2]
+  flops = 2 * yt.numel() * w[0].numel()
+  nbytes = 4 * (xt.numel() + yt.numel() + pos.numel() + w.numel())
+  with torch.cuda.device_of(xt), profiling.region('sphere_conv_fwd[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, xt.device):
+    wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+    check(lib().mode_sphere_conv_fwd_win(ptr(xt), ptr(pos), ptr(w), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh, Kw,
+                                         groups, 1, stream_of(xt)), 'mode_sphere_conv_fwd_win')
+  return yt
+
+
+def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
+  """gxt (B,Ci,W,H) = input gradient for gyt (B,Co,W,H), both plane-transposed (written, not added to)."""
+  require_gpu(gyt, pos, w, gxt)
+  require_f32c(gyt, pos, w, gxt)
+  B, Co, W, H = gyt.shape
+  Ci, Kh, Kw = gxt.shape[1], w.shape[2], w.shape[3]
+  flops = 2 * gyt.numel() * w[0].numel()
+  nbytes = 4 * (gxt.numel() + gyt.numel() + pos.numel() + w.numel())
+  rowptr, entries, _ = sphere_adjoint(_transposed_table(pos), Kh, Kw, (1, 1), (W, H))
+  with torch.cuda.device_of(gyt), profiling.region('sphere_conv_bwd_data[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, gyt.device):
+    wp = _wpack(w, groups)
+    check(lib().mode_sphere_conv_bwd_data_adj(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co, Kh, Kw,
+                                              W, H, groups, 0, stream_of(gyt)), 'mode_sphere_conv_bwd_data_adj')
+  return gxt
+
+
+def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
+  """Adds the weight gradient for plane-transposed gyt (B,Co,W,H) and xt (B,Ci,W,H) to gw."""
+  require_gpu(gyt, pos, xt, gw)
+  require_f32c(gyt, pos, xt, gw)
+  B, Co, W, H = gyt.shape
+  Ci, Kh, Kw = xt.shape[1], gw.shape[2], gw.shape[3]
+  tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off, polar = sphere_plan(pos, Kh, Kw)
+  if nrest and polar is None:
+    raise RuntimeError('sphere_conv_bwd_weight_t: the table needs the pixel-list fallback, which reads NCHW tensors')
+  pitems, prw, pro, npol = polar if polar is not None else (None, None, None, 0)
+  flops = 2 * gyt.numel() * gw[0].numel()
+  nbytes = 4 * (xt.numel() + gyt.numel() + pos.numel() + gw.numel())
+  with torch.cuda.device_of(gyt), profiling.region('sphere_conv_bwd_weight[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, gyt.device):
+    n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, groups, n0, 0, npol)
+    ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gyt.device)
+    check(lib().mode_sphere_conv_bwd_weight_win(None, ptr(pos), None, ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w), ptr(rec_off),
+                                                ptr(rest), 0, ptr(pitems) if npol else None, ptr(prw) if npol else None,
+                                                ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, groups, ptr(gyt), ptr(xt),
+                                                stream_of(gyt)), 'mode_sphere_conv_bwd_weight_win')
+  return gw
+
+
 # ------------------------------------------------------------------------------------ gradient sinks
 def grad_sink(param):
   """The buffer parameter gradients are accumulated into directly by the native backward kernels, or None.

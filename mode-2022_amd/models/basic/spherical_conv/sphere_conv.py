@@ -88,6 +88,69 @@ class SphereConvFunction(Function):
 
 sphere_conv = SphereConvFunction.apply
 
+
+# ---- operator on plane-transposed storage (an extension; the reference has no counterpart) ----------------------------
+# The windowed kernels work on (B, C, W, H) storage.  A run of stride-1 spherical layers separated only by layout-agnostic ops
+# (BatchNorm, ReLU, residual add, 1x1 convolution) can stay in that storage: one transpose in, one out, instead of four per
+# layer and step.  `transposed_io()` switches SphereConv.forward to this form for the modules called inside the block.
+_tls = threading.local()
+
+
+class transposed_io(object):
+  """with transposed_io(): SphereConv.forward takes and returns plane-transposed tensors (B, C, W, H)."""
+
+  def __enter__(self):
+    self._prev = getattr(_tls, 'transposed', False)
+    _tls.transposed = True
+
+  def __exit__(self, *exc):
+    _tls.transposed = self._prev
+
+
+class TransposePlanes(Function):
+  """(B, C, H, W) <-> (B, C, W, H) contiguous; its own adjoint."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return _F.transpose_planes(x.contiguous())
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, g):
+    return _F.transpose_planes(g.contiguous())
+
+
+class SphereConvTransposedFunction(Function):
+  """SphereConvFunction for stride 1, 3x3 taps, no bias, on plane-transposed input and output."""
+
+  @staticmethod
+  def forward(ctx, input_t, position, weight, groups):
+    input_t = input_t.contiguous()
+    weight = weight.contiguous()
+    B, _, W, H = input_t.shape
+    output_t = input_t.new_empty((B, weight.size(0), W, H))
+    _F.sphere_conv_fwd_t(input_t, position, weight, output_t, groups)
+    ctx.save_for_backward(input_t, position, weight)
+    ctx.groups = groups
+    return output_t
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, grad_output_t):
+    input_t, position, weight = ctx.saved_tensors
+    gyt = grad_output_t.contiguous()
+    grad_input_t = None
+    if ctx.needs_input_grad[0]:
+      grad_input_t = torch.empty_like(input_t)
+      _F.sphere_conv_bwd_data_t(gyt, position, weight, grad_input_t, ctx.groups)
+    grad_weight = None
+    if ctx.needs_input_grad[2]:
+      sink = _F.grad_sink(weight)
+      gw = sink if sink is not None else torch.zeros_like(weight)
+      _F.sphere_conv_bwd_weight_t(gyt, position, input_t, gw, ctx.groups)
+      grad_weight = None if sink is not None else gw
+    return grad_input_t, None, grad_weight, None
+
 # All layers of one network share a handful of geometries (16 identical tables in ModeDisparity): build each
 # table once per process and upload it once per device, instead of per layer (reference) and per call (:240).
 _table_lock = threading.Lock()
@@ -204,8 +267,19 @@ class SphereConv(nn.Module):
     return t
 
   def forward(self, x):
+    if getattr(_tls, 'transposed', False):
+      if not self.supports_transposed_io(x.shape[0], x.device):
+        raise RuntimeError('SphereConv: this layer cannot run on plane-transposed storage (see supports_transposed_io)')
+      return SphereConvTransposedFunction.apply(x, self.position_on(x.device), self.weight, self.groups)
     return sphere_conv(x, self.position_on(x.device), self.weight, self.bias, self.stride, self.padding, self.dilation,
                        self.groups)
+
+  def supports_transposed_io(self, batch, device):
+    """Whether forward() can run inside `with transposed_io()` for this batch size: stride 1, 3x3, no bias, a sampling table
+    the windowed kernels can plan, and enough tiles to fill the chip."""
+    if self.stride != (1, 1) or self.kernel_size != (3, 3) or self.bias is not None or device.type != 'cuda':
+      return False
+    return _F.sphere_t_supported(self.position_on(device), self.weight, batch, self.groups)
 
   def getPosition(self):
     return self.position

@@ -1,11 +1,16 @@
 """Sub-networks of the disparity stage (module tree and state_dict names of the reference's
 models/submodule.py; regular 2D convolutions run on the vendor library, spherical ones on libmode_hip)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import stage3d
 from .basic import SphereConv
+from .basic.spherical_conv import sphere_conv as sphere_conv_mod
+
+SPHERE_CHAIN = os.environ.get('MODE_SPHERE_CHAIN', '1') == '1'  # layer4 on plane-transposed storage end to end
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
@@ -155,8 +160,19 @@ class sphere_feature_extraction(nn.Module):
   def forward(self, x):
     raw = self.layer2(self.layer1(_run_convbn_relu_chain(self.firstconv, x)))
     regular = self.layer3(raw)
-    sphere = self.layer4(regular)
+    sphere = self._layer4(regular)
     return _run_convbn_relu_chain(self.lastconv, torch.cat((raw, regular, sphere), 1))
+
+  def _layer4(self, x):
+    """The 16 spherical layers.  Between them sit only BatchNorm, ReLU, the residual add and one 1x1 convolution, none of
+    which cares about the order of the two spatial axes, so the whole run stays in the plane-transposed storage of the
+    windowed kernels (one transpose in, one out) when every layer supports it."""
+    convs = [m for m in self.layer4.modules() if isinstance(m, SphereConv)]
+    if SPHERE_CHAIN and x.is_cuda and all(m.supports_transposed_io(x.shape[0], x.device) for m in convs):
+      with sphere_conv_mod.transposed_io():
+        yt = self.layer4(sphere_conv_mod.TransposePlanes.apply(x))
+      return sphere_conv_mod.TransposePlanes.apply(yt)
+    return self.layer4(x)
 
 
 class feature_extraction(nn.Module):

@@ -284,6 +284,37 @@ def test_regular_extractor_variant(golden):
               np.abs(z['eval/pred3'] - z['truth64/eval_pred3']).max(), mean_floor=DISP_TOL / 5)
 
 
+def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch):
+  """layer4 of the spherical extractor (16 SphereConv + BatchNorm/ReLU/add/1x1 conv) end to end on plane-transposed storage
+  (SphereConv inside transposed_io()) against the same modules on the NCHW operator: outputs, input and parameter
+  gradients, BatchNorm state."""
+  import models.submodule as sm
+  from mode_hip import functional as HF
+  monkeypatch.setattr(HF, 'SPHERE_FWD_MIN_WG', 0)  # the small test geometry too
+  res = {}
+  for chain in (True, False):
+    monkeypatch.setattr(sm, 'SPHERE_CHAIN', chain)
+    torch.manual_seed(11)
+    fe = sm.sphere_feature_extraction(512, 256, 'Cassini').to(DEV).train()  # layer4 at 128 x 64: all window classes
+    x = torch.randn(2, 3, 512, 256, device=DEV, requires_grad=True)
+    if chain:
+      convs = [m for m in fe.layer4.modules() if isinstance(m, sm.SphereConv)]
+      assert len(convs) == 16 and all(m.supports_transposed_io(2, x.device) for m in convs)
+    y = fe(x)
+    (y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+    res[chain] = (y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in fe.named_parameters()},
+                  {k: v.clone() for k, v in fe.state_dict().items() if 'running' in k})
+  a, b = res[True], res[False]
+  assert (a[0] - b[0]).abs().max() <= 1e-4 * max(1.0, float(b[0].abs().max()))
+  # gradients through ~50 random train-mode BatchNorm layers: round-off of the two summation orders is amplified to ~5e-3
+  # (measured); a wrong axis order anywhere would be an O(1) difference
+  assert float((a[1] - b[1]).norm()) <= 2e-2 * float(b[1].norm())
+  for k in a[2]:
+    assert float((a[2][k] - b[2][k]).norm()) <= 2e-2 * float(b[2][k].norm()) + 1e-4, k
+  for k in a[3]:
+    assert (a[3][k] - b[3][k]).abs().max() <= 1e-5 * max(1.0, float(b[3][k].abs().max())), k
+
+
 def test_paired_extractor_pass_equals_two_passes(monkeypatch):
   """ModeDisparity runs the shared extractor once over [left; right] with per-image-set BatchNorm statistics
   (stage3d.bn_groups): same outputs, gradients and BatchNorm state as the reference's two passes."""
