@@ -489,6 +489,7 @@ extern "C" int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, 
                  "mode_conv3d_bwd_data: stride 2 needs even input sizes (got %dx%dx%d)", D, H, W);
     return deconv3d(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), "mode_conv3d_bwd_data");
   }
+  if (Co == 1) return mode::conv3d_co1_bwd_data(gy, w, gx, B, Ci, D, H, W, mode::as_stream(stream), "mode_conv3d_bwd_data");
   return conv3d_s1(gy, w, gx, wpack, B, Co, Ci, D, H, W, 1, mode::as_stream(stream), "mode_conv3d_bwd_data");
 }
 

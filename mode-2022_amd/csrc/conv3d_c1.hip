@@ -6,7 +6,7 @@
 //   weight gradient: gW[c][tap] = sum_q x[c,q] * gy[q + 1 - k]  as an MFMA GEMM with  D[i = c][j = tap]  (27 of 32 columns
 //                    used): A[i = c][k = voxel] = x tile, B[k = voxel][j = tap] = the gy halo tile read at a per-lane tap
 //                    offset; split-K over voxel tiles with a fixed-order reduction
-// (the input gradient stays on the generic MFMA kernel: K = 1 is cheap there.)
+//   input gradient : gx[c][u] = sum_t w[c][t] * gy[u - off(t)]  as an MFMA GEMM with  D[i = c][j = voxel]  and the 27 taps as K
 #include "conv3d_internal.h"
 
 namespace {
@@ -106,6 +106,86 @@ __global__ __launch_bounds__(NT) void conv3d_co1_fwd_kernel(const float* __restr
     for (int o = 0; o < 4; ++o) {
       const int gh = h0 + hq * 4 + o;
       if (gh < H) yb[(long long)gh * W] = acc[o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- input gradient
+// gx[c][u] = sum_t w[c][t] * gy[u - off(t)] = sum_k w[c][26 - k] * gy[u + off(k)]   (off(k) = (kd-1, kh-1, kw-1)):
+// D[i = c][j = 32 voxels along w], K = the 27 taps (28 with a zero column): A[i = c][k] = w[c][26 - k] lives in 14 registers,
+// B[k][j] = the single-channel gy halo tile (5.4 KB of LDS) read at the per-lane offset of tap k.  14 MFMAs per 32 voxels x
+// 32 channels -- the generic kernel spends 108 on its zero-padded 8-channel chunk -- so the kernel is bound by the
+// 201 MB per sample of gx it writes.
+constexpr int BTD = 2, BTH = 8;                           // tile 2 x 8 x 32 voxels, 4 rows per wave
+constexpr int BID = BTD + 2, BIH = BTH + 2, BIW = 34;     // gy halo tile [4][10][34]
+
+__device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// grid = (tiles, ceil(Ci/32))
+__global__ __launch_bounds__(NT) void conv3d_co1_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                 float* __restrict__ gx, int B, int Ci, int D, int H, int W, int nDt,
+                                                                 int nHt, int nWt) {
+  __shared__ float tile[BID * BIH * BIW];
+  int t = blockIdx.x;
+  const int wt = t % nWt;
+  t /= nWt;
+  const int ht = t % nHt;
+  t /= nHt;
+  const int dt = t % nDt;
+  const int b = t / nDt;
+  const int cb = blockIdx.y;
+  const int w0 = wt * 32, h0 = ht * BTH, d0 = dt * BTD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long long HW = (long long)H * W, DHW = (long long)D * HW;
+  const float* gb = gy + (long long)b * DHW;
+
+  for (int idx = tid; idx < BID * BIH * BIW; idx += NT) {
+    const int dz = idx / (BIH * BIW), rem = idx - dz * (BIH * BIW);
+    const int hy = rem / BIW, wx = rem - hy * BIW;
+    const int gd = d0 + dz - 1, gh = h0 + hy - 1, gw = w0 + wx - 1;
+    const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    const float v = gb[ok ? gd * HW + gh * W + gw : 0];
+    tile[idx] = ok ? v : 0.f;
+  }
+  float a[14];
+  int toff[14];
+  const int c = cb * 32 + (lane & 31);
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks) {
+    const int k = 2 * ks + (lane >> 5);
+    a[ks] = (k < 27 && c < Ci) ? w[c * 27 + 26 - k] : 0.f;
+    const int kk = k < 27 ? k : 26;
+    toff[ks] = (kk / 9) * (BIH * BIW) + ((kk / 3) % 3) * BIW + kk % 3;
+  }
+  __syncthreads();
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (f32x16){0};
+  const float* tp = tile + (lane & 31);
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 4 + r;  // (dz, hy) = (row / BTH, row % BTH)
+      acc[r] = mfma32b(a[ks], tp[(row / BTH) * (BIH * BIW) + (row % BTH) * BIW + toff[ks]], acc[r]);
+    }
+
+  float* gxb = gx + ((long long)b * Ci + cb * 32) * DHW;
+  const int gw = w0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = wave * 4 + r;
+    const int gd = d0 + row / BTH, gh = h0 + row % BTH;
+    if (gd < D && gh < H && gw < W) {
+      const long long sp = gd * HW + (long long)gh * W + gw;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (cb * 32 + i < Ci) gxb[i * DHW + sp] = acc[r][q];
+      }
     }
   }
 }
@@ -226,6 +306,14 @@ int conv3d_co1_fwd(const float* x, const float* w, float* y, int B, int Ci, int 
   const int nDt = cdiv(D, FTD), nHt = cdiv(H, FTH), nWt = cdiv(W, 32);
   const size_t lds = (size_t)FCC * FPLANE * sizeof(float) + (size_t)FROWS * sizeof(int);
   hipLaunchKernelGGL(conv3d_co1_fwd_kernel, dim3(B * nDt * nHt * nWt), dim3(NT), lds, st, x, w, y, B, Ci, D, H, W, nDt, nHt, nWt);
+  return check_launch(who);
+}
+
+int conv3d_co1_bwd_data(const float* gy, const float* w, float* gx, int B, int Ci, int D, int H, int W, hipStream_t st,
+                        const char* who) {
+  const int nDt = cdiv(D, BTD), nHt = cdiv(H, BTH), nWt = cdiv(W, 32);
+  hipLaunchKernelGGL(conv3d_co1_bwd_data_kernel, dim3(B * nDt * nHt * nWt, cdiv(Ci, 32)), dim3(NT), 0, st, gy, w, gx, B, Ci, D, H, W,
+                     nDt, nHt, nWt);
   return check_launch(who);
 }
 

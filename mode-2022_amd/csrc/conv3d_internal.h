@@ -6,8 +6,11 @@ namespace mode {
 
 // 3x3x3, pad 1, stride 1 convolution with a SINGLE output channel (the classifier heads, mode_disparity.py:76-80).
 // The MFMA tile would be 31/32 padding for Co = 1; these use the vector ALU (forward) and an MFMA formulation with the 27
-// taps as the GEMM-N dimension (weight gradient).
+// taps as the GEMM-N dimension (weight gradient) or the GEMM-K dimension (input gradient).
 int conv3d_co1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who);
+
+// gx (B,Ci,D,H,W) = input gradient for gy (B,1,D,H,W); overwrites gx.
+int conv3d_co1_bwd_data(const float* gy, const float* w, float* gx, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who);
 
 size_t conv3d_co1_bwd_weight_workspace_floats(int B, int Ci, int D, int H, int W);
 int conv3d_co1_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,

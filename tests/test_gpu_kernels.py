@@ -376,11 +376,13 @@ def test_deconv3d(B, Ci, Co, D, H, W):
   assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
 
 
-def test_conv3d_single_output_channel():
-  """classifN[2]: Conv3d(32 -> 1) (mode_disparity.py:76-80)."""
+@pytest.mark.parametrize('B,Ci,D,H,W', [(2, 32, 6, 12, 40), (1, 20, 3, 5, 33), (1, 40, 2, 9, 64), (2, 32, 1, 1, 7)])
+def test_conv3d_single_output_channel(B, Ci, D, H, W):
+  """classifN[2]: Conv3d(32 -> 1) (mode_disparity.py:76-80): stencil forward, MFMA input / weight gradients with the taps
+  as a GEMM dimension; ragged tiles, channel counts off the 32-wide tile, volumes thinner than the halo."""
   import torch.nn.functional as F
-  x = _rand((2, 32, 6, 12, 40), 54)
-  w = _rand((1, 32, 3, 3, 3), 55, 0.05)
+  x = _rand((B, Ci, D, H, W), 54)
+  w = _rand((1, Ci, 3, 3, 3), 55, 0.05)
   xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
   y_ref = F.conv3d(xa, wa, None, 1, 1)
   gy = _rand(tuple(y_ref.shape), 56)
