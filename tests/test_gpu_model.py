@@ -44,7 +44,7 @@ def _setup(z, bn_from_fixture=False):
   return net, left.to(DEV), right.to(DEV), gt.to(DEV), maxdisp
 
 
-def _check_disp(name, got, ref32, truth64, e_ref, mean_floor=DISP_TOL / 10):
+def _check_disp(name, got, ref32, truth64, e_ref, mean_floor=DISP_TOL / 10, max_factor=3.0):
   """got: HIP path; ref32: the reference's own fp32 run; truth64: fp64 evaluation of the same network.
   The error of any fp32 evaluation against truth64 is amplified round-off: its MEAN over the pixels is a stable statistic,
   its MAX is a single draw that moves by a factor of ~2 with any change of summation order (measured: 7.1e-3 and 1.65e-2
@@ -53,7 +53,7 @@ def _check_disp(name, got, ref32, truth64, e_ref, mean_floor=DISP_TOL / 10):
   got = got.detach().cpu().numpy().astype(np.float64)
   err = np.abs(got - truth64)
   ref_err = np.abs(np.asarray(ref32, dtype=np.float64) - truth64)
-  bound_max = max(DISP_TOL, 3.0 * float(e_ref))
+  bound_max = max(DISP_TOL, max_factor * float(e_ref))
   bound_mean = max(mean_floor, 2.0 * float(ref_err.mean()))  # (a mean error below 1e-4 px is a tenth of the north_star's bound)
   print('%s: |gpu-truth64| max %.3e mean %.3e   reference itself: max %.3e mean %.3e   |gpu-ref32| max %.3e' %
         (name, err.max(), err.mean(), ref_err.max(), ref_err.mean(), np.abs(got - ref32).max()))
@@ -262,9 +262,11 @@ def test_regular_extractor_variant(golden):
   e_ref = max(np.abs(z['train/pred%d' % i] - z['truth64/train_pred%d' % i]).max() for i in (1, 2, 3))
   for i, p in enumerate(preds):
     # This variant's 2-D convolutions run in the vendor library, whose solver choice differs from process to process
-    # (measured mean error over six runs: 4.5e-5 ... 1.3e-4 px, the reference's own fp32 run: 2.9e-5): floor at DISP_TOL/5.
+    # (measured mean error over six runs: 4.5e-5 ... 1.3e-4 px, the reference's own fp32 run: 2.9e-5; max error 0.8 ... 4.0 x
+    # E_ref, the largest on a box where MIOpen's find picked other solvers): floor at DISP_TOL/5, max at 8 x E_ref -- a wrong
+    # layer is an O(0.1 .. 1) px difference.
     _check_disp('regular train pred%d' % (i + 1), p[:, :, ::4, ::4], z['train/pred%d' % (i + 1)], z['truth64/train_pred%d' % (i + 1)], e_ref,
-                mean_floor=DISP_TOL / 5)
+                mean_floor=DISP_TOL / 5, max_factor=8.0)
   loss = mode_ref.training_loss(preds, gt, ~torch.isnan(gt))
   assert abs(float(loss.detach()) - float(z['train/loss'])) < 2e-4 * float(z['train/loss'])
   loss.backward()
@@ -281,7 +283,7 @@ def test_regular_extractor_variant(golden):
   with torch.no_grad():
     pred = net(left, right)
   _check_disp('regular eval pred3', pred[:, :, ::4, ::4], z['eval/pred3'], z['truth64/eval_pred3'],
-              np.abs(z['eval/pred3'] - z['truth64/eval_pred3']).max(), mean_floor=DISP_TOL / 5)
+              np.abs(z['eval/pred3'] - z['truth64/eval_pred3']).max(), mean_floor=DISP_TOL / 5, max_factor=8.0)
 
 
 def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch):
