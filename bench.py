@@ -49,6 +49,8 @@ def parse():
   ap.add_argument('--no-kernel-timing', action='store_true')
   ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
                   help="graph: forward+loss+backward replayed as one hipGraph (default); eager: one launch per kernel")
+  ap.add_argument('--vendor-autotune', type=int, default=int(os.environ.get('MODE_VENDOR_AUTOTUNE', '0')),
+                  help='1: torch.backends.cudnn.benchmark = True (MIOpen times its solvers for the regular 2-D convolutions)')
   ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
   return ap.parse_args()
 
@@ -159,6 +161,7 @@ def main():
   import mode_hip
   mode_hip.lib()  # fail loudly if the native library is missing
 
+  torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)
   net = models.ModeDisparity(args.maxdisp, 'Sphere', args.height, args.width, 'Cassini').to(dev)
   reducer = data_parallel.GradAllReducer(net)
@@ -239,6 +242,18 @@ def main():
     for _ in range(args.profile_steps):
       eager_step()
     fence()
+    if models.mode_disparity.FUSED_COST_CONV and args.profile_steps:
+      # the step no longer builds the cost volume (HF.cost_conv); the a9 kernel remains part of the operator API and its
+      # north_star target is measured on the step's shapes, standalone
+      from mode_hip import functional as HF
+      fr = torch.randn(args.batch, 32, args.height // 4, args.width // 4, device=dev)
+      ft = torch.randn_like(fr)
+      HF.cost_volume_fwd(fr, ft, args.maxdisp // 4)  # (allocator warm-up for the 400 MB/sample result)
+      fence()
+      for _ in range(3):
+        HF.cost_volume_fwd(fr, ft, args.maxdisp // 4)
+      fence()
+      del fr, ft
   kern = profiling.summary()
   profiling.enable(False)
   if world > 1:
@@ -269,6 +284,9 @@ def main():
             'global_batch': args.batch * world,
             'parallelism': 'dp%d' % world,
             'stage3d_backend': models.stage3d.BACKEND,
+            'cost_volume': ('folded into dres0[0][0] (cost_conv: 18 partial 2-D products + assembly kernel); the volume is not built, '
+                            'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if models.mode_disparity.FUSED_COST_CONV
+                           else 'built (mode_cost_volume_fwd)',
             'launch': 'hipGraph replay of zero-grad+forward+loss+backward, then all-reduce and fused Adam' if args.launch == 'graph'
                       else 'eager (one launch per kernel)',
         },

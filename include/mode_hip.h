@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 5 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 6 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -171,6 +171,16 @@ int mode_cost_volume_fwd(const float* ref, const float* tgt, float* cost, int B,
  * g_tgt[b,c,h,w] = sum_{i<W-w} g[b,C+c,i,h,w+i].  Writes (does not accumulate). */
 int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, int C, int D4, int H, int W,
                          mode_stream_t stream);
+
+/* Cost volume + first 3-D convolution without the volume (models/mode_disparity.py:104-116: the concatenation volume followed
+ * by dres0[0][0] = Conv3d(2C -> Co, k3 s1 p1, no bias)).  The host forms the 18 partial products over (channel, kh)
+ *   R[b, t*Co + o, h, w] = sum_{c,kh} W[o, c,   kd, kh, kw] * ref[b, c, h+kh-1, w],   t = kd*3 + kw,
+ *   T[b, t*Co + o, h, u] = sum_{c,kh} W[o, C+c, kd, kh, kw] * tgt[b, c, h+kh-1, u]     (two GEMMs with K = 3C), and
+ *   out[b,o,d,h,w] = sum_t [0 <= d' < D][d' <= w' < W] (R_t[b,o,h,w'] + T_t[b,o,h,w'-d']),  d' = d+kd-1, w' = w+kw-1
+ * is the layer's output exactly (csrc/cost_conv.hip).  _bwd is the adjoint: gR, gT (B, 9*Co, H, W) from gout (B,Co,D,H,W);
+ * both write (do not accumulate) and are deterministic. */
+int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W, mode_stream_t stream);
+int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3x3 convolution, padding 1, no bias -- replaces the cuDNN nn.Conv3d inside convbn_3d

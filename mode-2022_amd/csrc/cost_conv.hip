@@ -1,0 +1,133 @@
+// First layer of the 3-D regulariser WITHOUT the cost volume (reference: models/mode_disparity.py:104-116 -- the concatenation
+// volume followed by dres0[0] = Conv3d(64 -> 32, k3 s1 p1)).
+//
+// cost[c][d'][h][w'] is ref[c][h][w'] (c < C) or tgt[c-C][h][w'-d'] for w' >= d', else 0: the reference half does not depend on
+// d' at all and the target half only on w'-d'.  So with the per-(kd,kw) partial convolutions over (channel, kh)
+//     R_t[o][h][w'] = sum_{c,kh} W[o][c  ][kd][kh][kw] * ref[c][h+kh-1][w']          t = kd*3 + kw
+//     T_t[o][h][u ] = sum_{c,kh} W[o][C+c][kd][kh][kw] * tgt[c][h+kh-1][u ]
+// (18 small 2-D products, a GEMM of K = 3C over the feature maps -- 7 GFLOP instead of the layer's 261) the layer is
+//     out[o][d][h][w] = sum_t [0 <= d' < D][d' <= w' < W] ( R_t[o][h][w'] + T_t[o][h][w'-d'] ),   d' = d+kd-1, w' = w+kw-1,
+// exactly (the masks are the volume's zero triangle and the convolution's zero padding in d and w; the padding in h is inside
+// R_t / T_t).  These two kernels do that assembly and its adjoint; the 402.7 MB volume per sample never exists.
+// HBM-bound: the forward writes B*Co*D*H*W floats once (9 LDS reads per element), the adjoint reads them once.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 128;
+
+// grid = B*Co*H blocks; LDS = 9*(W+2) + 9*W floats.  R, T: (B, 9*Co, H, W) with channel = t*Co + o.
+__global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float* __restrict__ R, const float* __restrict__ T,
+                                                                    float* __restrict__ out, int B, int Co, int D, int H, int W) {
+  extern __shared__ float sm[];
+  float* Rl = sm;                  // [9][W+2], columns -1 and W are zeros
+  float* Tl = sm + 9 * (W + 2);    // [9][W]
+  int t0 = blockIdx.x;
+  const int h = t0 % H;
+  t0 /= H;
+  const int o = t0 % Co;
+  const int b = t0 / Co;
+  const long long HW = (long long)H * W;
+  for (int idx = threadIdx.x; idx < 9 * W; idx += NT) {
+    const int t = idx / W, w = idx - t * W;
+    const long long src = (((long long)b * 9 + t) * Co + o) * HW + (long long)h * W + w;
+    Rl[t * (W + 2) + 1 + w] = R[src];
+    Tl[idx] = T[src];
+  }
+  if (threadIdx.x < 18) Rl[(threadIdx.x >> 1) * (W + 2) + ((threadIdx.x & 1) ? W + 1 : 0)] = 0.f;
+  __syncthreads();
+  float* ob = out + (((long long)b * Co + o) * D) * HW + (long long)h * W;
+  for (int w = threadIdx.x; w < W; w += NT) {
+    float r[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) r[t] = Rl[t * (W + 2) + w + (t % 3)];  // column w' = w + kw - 1, stored at index w' + 1
+    for (int d = 0; d < D; ++d) {
+      float acc = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int dp = d + kd - 1;
+        if (dp < 0 || dp >= D) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wp = w + kw - 1;
+          if (wp >= dp && wp < W) acc += r[kd * 3 + kw] + Tl[(kd * 3 + kw) * W + wp - dp];
+        }
+      }
+      ob[(long long)d * HW + w] = acc;
+    }
+  }
+}
+
+// Adjoint: gR_t[o][h][w'] = sum_d [0 <= d' < D][d' <= w'] gout[o][d][h][w'-kw+1],
+//          gT_t[o][h][u ] = sum_d [0 <= d' < D][u+d' < W] gout[o][d][h][u+d'-kw+1]      (terms with a column outside [0, W) vanish).
+// grid = B*Co*H blocks; LDS = D*(W+2) floats (the gout rows of this (b, o, h), zero columns at -1 and W).  Sums over d ascending.
+__global__ __launch_bounds__(NT) void cost_conv_assemble_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gR,
+                                                                    float* __restrict__ gT, int B, int Co, int D, int H, int W) {
+  extern __shared__ float gl[];  // [D][W+2]
+  int t0 = blockIdx.x;
+  const int h = t0 % H;
+  t0 /= H;
+  const int o = t0 % Co;
+  const int b = t0 / Co;
+  const long long HW = (long long)H * W;
+  const float* gb = gout + (((long long)b * Co + o) * D) * HW + (long long)h * W;
+  for (int idx = threadIdx.x; idx < D * W; idx += NT) {
+    const int d = idx / W, w = idx - d * W;
+    gl[d * (W + 2) + 1 + w] = gb[(long long)d * HW + w];
+  }
+  for (int d = threadIdx.x; d < D; d += NT) gl[d * (W + 2)] = gl[d * (W + 2) + W + 1] = 0.f;
+  __syncthreads();
+  for (int wp = threadIdx.x; wp < W; wp += NT) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int kd = t / 3, kw = t % 3;
+      const int dlo = max(0, 1 - kd), dhi = min(D, D + 1 - kd);  // 0 <= d' = d + kd - 1 < D
+      float sr = 0.f, st = 0.f;
+      const float* col = gl + (wp - kw + 2);  // column w = w' - kw + 1, stored at index w + 1
+      for (int d = dlo; d < dhi; ++d) {
+        const int dp = d + kd - 1;
+        if (dp <= wp) sr += col[d * (W + 2)];
+        if (wp + dp < W) st += col[d * (W + 2) + dp];  // u = wp: column u + d' - kw + 1
+      }
+      const long long dst = (((long long)b * 9 + t) * Co + o) * HW + (long long)h * W + wp;
+      gR[dst] = sr;
+      gT[dst] = st;
+    }
+  }
+}
+
+int check_args(const void* a, const void* b, const void* c, int B, int Co, int D, int H, int W, const char* who) {
+  MODE_REQUIRE(B >= 0 && Co > 0 && D > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE((long long)B * Co * H < (1ll << 31), MODE_ERR_UNSUPPORTED, "%s: too many rows", who);
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(a && b && c, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  return MODE_OK;
+}
+
+}  // namespace
+
+extern "C" int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W,
+                                           mode_stream_t stream) {
+  const char* who = "mode_cost_conv_assemble_fwd";
+  int rc = check_args(R, T, out, B, Co, D, H, W, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  const size_t lds = (size_t)(9 * (W + 2) + 9 * W) * sizeof(float);
+  MODE_REQUIRE(lds <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: W = %d too wide for the row buffers", who, W);
+  rc = mode::allow_lds(cost_conv_assemble_fwd_kernel, lds, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(cost_conv_assemble_fwd_kernel, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), R, T, out, B, Co, D, H, W);
+  return mode::check_launch(who);
+}
+
+extern "C" int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W,
+                                           mode_stream_t stream) {
+  const char* who = "mode_cost_conv_assemble_bwd";
+  int rc = check_args(gout, gR, gT, B, Co, D, H, W, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  const size_t lds = (size_t)D * (W + 2) * sizeof(float);
+  MODE_REQUIRE(lds <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D x W = %d x %d too large for the row buffer", who, D, W);
+  rc = mode::allow_lds(cost_conv_assemble_bwd_kernel, lds, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(cost_conv_assemble_bwd_kernel, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), gout, gR, gT, B, Co, D, H, W);
+  return mode::check_launch(who);
+}

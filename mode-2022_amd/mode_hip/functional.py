@@ -56,6 +56,56 @@ def cost_volume(ref, tgt, d4):
 
 
 # ------------------------------------------------------------------------------------ sphere conv
+# ------------------------------------------------------------------------------------ cost volume + dres0[0][0], fused
+class CostConvAssemble(torch.autograd.Function):
+  """out (B,Co,D,H,W) from the partial products R, T (B, 9*Co, H, W) -- see cost_conv() and csrc/cost_conv.hip."""
+
+  @staticmethod
+  def forward(ctx, R, T, D):
+    require_gpu(R, T)
+    require_f32c(R, T)
+    B, C9, H, W = R.shape
+    Co = C9 // 9
+    out = torch.empty((B, Co, D, H, W), dtype=R.dtype, device=R.device)
+    nbytes = 4 * (R.numel() + T.numel() + out.numel())
+    with torch.cuda.device_of(R), profiling.region('cost_conv_assemble_fwd', nbytes, 0, R.device):
+      check(lib().mode_cost_conv_assemble_fwd(ptr(R), ptr(T), ptr(out), B, Co, D, H, W, stream_of(R)), 'mode_cost_conv_assemble_fwd')
+    ctx.D = D
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gout):
+    gout = gout.contiguous()
+    B, Co, D, H, W = gout.shape
+    gR = torch.empty((B, 9 * Co, H, W), dtype=gout.dtype, device=gout.device)
+    gT = torch.empty_like(gR)
+    nbytes = 4 * (gR.numel() + gT.numel() + gout.numel())
+    with torch.cuda.device_of(gout), profiling.region('cost_conv_assemble_bwd', nbytes, 0, gout.device):
+      check(lib().mode_cost_conv_assemble_bwd(ptr(gout), ptr(gR), ptr(gT), B, Co, D, H, W, stream_of(gout)), 'mode_cost_conv_assemble_bwd')
+    return gR, gT, None
+
+
+def _tap_products(fea, wpart):
+  """(B, 9*Co, H, W): channel (kd*3+kw)*Co + o = sum_{c,kh} wpart[o,c,kd,kh,kw] * fea[b,c,h+kh-1,w] (zero padding in h): one
+  GEMM with K = 3C over the feature map (rocBLAS fp32)."""
+  B, C, H, W = fea.shape
+  Co = wpart.shape[0]
+  wr = wpart.permute(2, 4, 0, 1, 3).reshape(9 * Co, C * 3)            # rows (kd, kw, o), columns (c, kh)
+  x = torch.nn.functional.pad(fea, (0, 0, 1, 1))                       # rows -1 and H
+  xs = torch.stack([x[:, :, kh:kh + H] for kh in range(3)], 2).reshape(B, C * 3, H * W)
+  return torch.matmul(wr, xs).view(B, 9 * Co, H, W)
+
+
+def cost_conv(ref, tgt, weight, d4):
+  """conv3d(cost_volume(ref, tgt, d4), weight, stride 1, padding 1) for a (Co, 2C, 3, 3, 3) weight, without the volume:
+  models/mode_disparity.py:104-116.  261 GFLOP per sample of the reference layer become 7 GFLOP of GEMM plus one HBM-bound
+  assembly pass; differentiable in ref, tgt and weight (the GEMMs through autograd, the assembly through its adjoint kernel)."""
+  C = ref.shape[1]
+  assert tuple(weight.shape[1:]) == (2 * C, 3, 3, 3) and ref.shape == tgt.shape
+  return CostConvAssemble.apply(_tap_products(ref, weight[:, :C]), _tap_products(tgt, weight[:, C:]), d4)
+
+
 def _sc_dims(x_shape, w_shape, out_hw, stride, groups):
   B, Ci, H, W = x_shape
   Co, Cig, Kh, Kw = w_shape

@@ -51,6 +51,7 @@ class hourglass(nn.Module):
 
 
 PAIR_EXTRACTOR = os.environ.get('MODE_PAIR_EXTRACTOR', '1') == '1'
+FUSED_COST_CONV = os.environ.get('MODE_FUSED_COST_CONV', '1') == '1'  # cost volume + dres0[0][0] without the volume
 
 
 def _cumulative_bn(module):
@@ -113,9 +114,16 @@ class ModeDisparity(nn.Module):
       ref_fea = self.feature_extraction(left)
       tgt_fea = self.feature_extraction(right)
 
-    cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
-
-    cost0 = stage3d.conv_bn(self.dres0[0], cost, relu=True)
+    conv0 = self.dres0[0][0]
+    if (FUSED_COST_CONV and stage3d.BACKEND == 'hip' and ref_fea.is_cuda and conv0.bias is None and tuple(conv0.kernel_size) == (3, 3, 3) and
+        tuple(conv0.stride) == (1, 1, 1) and tuple(conv0.padding) == (1, 1, 1) and conv0.in_channels == 2 * ref_fea.shape[1]):
+      # the volume is constant along d in its reference half and a function of w-d in its target half: its first convolution
+      # collapses to 18 small 2-D products and one assembly pass (HF.cost_conv), and the 402.7 MB volume is never built
+      y0 = HF.cost_conv(ref_fea, tgt_fea, conv0.weight, self.maxdisp // 4)
+      cost0 = stage3d.bn_act(self.dres0[0][1], y0, None, True)
+    else:
+      cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
+      cost0 = stage3d.conv_bn(self.dres0[0], cost, relu=True)
     cost0 = stage3d.conv_bn(self.dres0[2], cost0, relu=True)
     t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
     cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)

@@ -72,6 +72,71 @@ def test_cost_volume_full_size_properties():
   assert torch.equal(c2[:, :C], 2 * cost[:, :C]) and torch.equal(c2[:, C:], cost[:, C:])
 
 
+# ------------------------------------------------------------------ cost volume + dres0[0][0] without the volume (a9 + a10)
+@pytest.mark.parametrize('B,C,Co,D4,H,W', [(2, 4, 6, 6, 5, 16), (1, 3, 5, 7, 4, 5), (1, 8, 8, 1, 3, 9), (2, 32, 32, 12, 8, 40), (1, 2, 3, 4, 1, 130)])
+def test_cost_conv_equals_conv3d_of_the_cost_volume(B, C, Co, D4, H, W):
+  """HF.cost_conv (18 partial 2-D products + the assembly kernel and its adjoint) against conv3d(cost_volume(...)) in fp64 on
+  the CPU oracle: output and the gradients of both feature maps and of the weight; more disparities than columns, D4 = 1,
+  H = 1, widths beyond one block."""
+  import torch.nn.functional as F
+  ref, tgt = _rand((B, C, H, W), 31), _rand((B, C, H, W), 32)
+  w = _rand((Co, 2 * C, 3, 3, 3), 33, 0.2)
+  ra, ta, wa = ref.double().requires_grad_(True), tgt.double().requires_grad_(True), w.double().requires_grad_(True)
+  y_ref = F.conv3d(mode_ref.cost_volume(ra, ta, D4), wa, None, 1, 1)
+  gy = _rand(tuple(y_ref.shape), 34)
+  y_ref.backward(gy.double())
+  rd, td, wd = ref.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+  y = HF.cost_conv(rd, td, wd, D4)
+  assert tuple(y.shape) == tuple(y_ref.shape)
+  y.backward(gy.to(DEV))
+  tol = 2e-6 * (2 * C * 27)
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < tol * max(1.0, float(y_ref.abs().max()))
+  for got, want in ((rd.grad, ra.grad), (td.grad, ta.grad), (wd.grad, wa.grad)):
+    assert (got.cpu().double() - want).abs().max() < 1e-5 * max(1.0, float(want.abs().max()))
+  # deterministic
+  y2 = HF.cost_conv(rd, td, wd, D4)
+  assert torch.equal(y2, y)
+
+
+def test_cost_conv_assembly_is_exact_on_integers():
+  """With integer-valued partial products every sum is exact in fp32: the assembly kernel and its adjoint must then agree
+  bit for bit with a direct evaluation of the masked sums (masks = the volume's zero triangle and the zero padding)."""
+  B, Co, D, H, W = 1, 2, 5, 2, 7
+  R = _rand((B, 9 * Co, H, W), 41, integer=True)
+  T = _rand((B, 9 * Co, H, W), 42, integer=True)
+  Rd, Td = R.to(DEV).requires_grad_(True), T.to(DEV).requires_grad_(True)
+  out = HF.CostConvAssemble.apply(Rd, Td, D)
+  want = torch.zeros(B, Co, D, H, W)
+  for kd in range(3):
+    for kw in range(3):
+      t = kd * 3 + kw
+      for d in range(D):
+        dp = d + kd - 1
+        if not 0 <= dp < D:
+          continue
+        for w in range(W):
+          wp = w + kw - 1
+          if dp <= wp < W:
+            want[:, :, d, :, w] += R[:, t * Co:(t + 1) * Co, :, wp] + T[:, t * Co:(t + 1) * Co, :, wp - dp]
+  assert torch.equal(out.detach().cpu(), want)
+  g = _rand(tuple(want.shape), 43, integer=True)
+  gR, gT = torch.zeros_like(R), torch.zeros_like(T)  # the adjoint of the loop above, term by term
+  for kd in range(3):
+    for kw in range(3):
+      t = kd * 3 + kw
+      for d in range(D):
+        dp = d + kd - 1
+        if not 0 <= dp < D:
+          continue
+        for w in range(W):
+          wp = w + kw - 1
+          if dp <= wp < W:
+            gR[:, t * Co:(t + 1) * Co, :, wp] += g[:, :, d, :, w]
+            gT[:, t * Co:(t + 1) * Co, :, wp - dp] += g[:, :, d, :, w]
+  out.backward(g.to(DEV))
+  assert torch.equal(Rd.grad.cpu(), gR) and torch.equal(Td.grad.cpu(), gT)
+
+
 # ------------------------------------------------------------------ sphere conv (a7/a8)
 def _sphere_case(typ, ih, iw, B, ci, co, stride, groups, seed):
   pos = mode_ref.sphere_position(ih, iw, typ)
