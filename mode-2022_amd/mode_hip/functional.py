@@ -1,4 +1,5 @@
-"""torch.autograd wrappers over the C-ABI kernels (host-side glue only; no arithmetic here)."""
+"""torch.autograd wrappers over the C-ABI kernels (host-side glue; the only arithmetic left to torch is the pair of small GEMMs
+of cost_conv, which run on rocBLAS)."""
 import ctypes
 import os
 import threading
