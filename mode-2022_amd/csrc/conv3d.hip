@@ -14,6 +14,8 @@
 // Input channels are streamed through LDS in chunks of 8.  Backward-data of a stride-1 convolution is the same kernel
 // on gy with the weights transposed and flipped (done by the packing kernel).
 #include "common.h"
+#include <cstdlib>
+
 #include "conv3d_internal.h"
 
 namespace {
@@ -800,10 +802,9 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
 // Stride-1 variant with a rolling depth window: a work unit is a (b, h-tile, w-tile) column times a run of DC consecutive
 // depths; the three x planes d-1, d, d+1 live in an LDS ring and only plane d+1 is staged per step (the halo re-read per
 // 64 output voxels drops from 408 to 136 floats per channel).  Same fragment maps and partial layout as the kernel above.
-constexpr int RING_DC = 12;
 
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                                    float* __restrict__ part, WDims d, int nDc, int units) {
+                                                                    float* __restrict__ part, WDims d, int nDc, int units, int ring_dc) {
   constexpr int WTH = 2, XR = WTH + 2, XW = 34, PS = XR * XW;  // plane = 136 floats
     constexpr int XPLANE = 3 * PS + 1;                           // 409 (odd)
   constexpr int GPLANE = WTH * 32 + 1;
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
     const int ht = t % d.nHt;
     const int b = t / d.nHt;
     const int w0 = wt * 32, h0 = ht * WTH;
-    const int dlo = dc * RING_DC, dhi = min(d.D, dlo + RING_DC);
+    const int dlo = dc * ring_dc, dhi = min(d.D, dlo + ring_dc);
     const float* xb = x + ((long long)b * d.Ci + cb * 32) * DHW;
     const float* gb = gy + ((long long)b * d.Co + ob * 32) * DHW;
 
@@ -1014,10 +1015,17 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
     if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
       rc = mode::allow_lds(conv3d_bwd_weight_ring_kernel, lds, "mode_conv3d_bwd_weight");
       if (rc != MODE_OK) return rc;
-      const int nDc = mode::cdiv(D, RING_DC);
+      // depths per work unit: every unit starts with three un-pipelined plane loads, so as deep as the volume allows while
+      // every workgroup still gets >= 2 units
+      int ring_dc = D;
+      while (ring_dc > 6 && (long long)B * d.nHt * d.nWt * mode::cdiv(D, ring_dc) < 2ll * d.S) ring_dc = mode::cdiv(ring_dc, 2);
+      static const char* dc_env = getenv("MODE_RING_DC");  // (tuning override)
+      if (dc_env && atoi(dc_env) > 0) ring_dc = atoi(dc_env);
+      const int nDc = mode::cdiv(D, ring_dc);
       const int units = B * d.nHt * d.nWt * nDc;
       if (d.S > units) d.S = units;  // never more than the workspace query assumed
-      hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units);
+      hipLaunchKernelGGL(conv3d_bwd_weight_ring_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d, nDc, units,
+                         ring_dc);
     } else {
       rc = mode::allow_lds(conv3d_bwd_weight_kernel<1, WTH1>, lds, "mode_conv3d_bwd_weight");
       if (rc != MODE_OK) return rc;
