@@ -658,16 +658,24 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __re
 // flight, issued before the k-loop, consumed after it), so a step costs max(load, MFMA) + the LDS stores.  The item -> (channel,
 // row, column group) map is chosen so that everything but the half-wave's channel is a compile-time constant: a tile needs 9
 // row offsets, 2 column offsets and an 11-bit validity mask, the 72 addresses are sums of those.
-__global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+// OB = output-channel blocks per workgroup (256 threads each): with OB = 2 the two blocks of a 64-channel gy share one staged x
+// tile -- half the loads, LDS stores and prefetch registers per thread for the same MFMAs.
+template <int OB>
+__global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                      float* __restrict__ part, WDims d) {
   using G = WGeom<2, 1>;
   constexpr int XR = G::XR, XW = G::XW, XPLANE = G::XPLANE, GPLANE = G::GPLANE;
   static_assert(XR == 3 && XW == 65, "item map below assumes the 3 x 3 x 65 tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xl = lds;                 // [32][XPLANE]
-  float* gl = lds + 32 * XPLANE;   // [32][GPLANE]
-  const int s = blockIdx.x, ob = blockIdx.y, cb = blockIdx.z;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* gl = lds + 32 * XPLANE;   // [32 * OB][GPLANE]
+  constexpr int NTH = NT * OB, HWV = 8 * OB;                 // threads, half-waves
+  constexpr int NQ = 4 / OB, NX = 18 * NQ;                   // channels per half-wave, x items per thread
+  constexpr int NE = (288 + NTH - 1) / NTH;                  // column-64 items per thread
+  const int s = blockIdx.x, cb = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, oh = tid >> 8;            // tap group, output-channel block of this wave
+  const int ob0 = blockIdx.y * OB, ob = ob0 + oh;
   const int hwv = tid >> 5, l32 = tid & 31;
   const int HW = d.H * d.W, DHW = d.D * HW;          // (host guarantees Ci * DHW < 2^29)
   const int oHW = d.Ho * d.Wo, oDHW = d.Do * oHW;
@@ -684,12 +692,12 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
 
   // x tile = 288 (channel, depth, row) rows of 65 columns.  Columns 0..63: item jj of half-wave hwv is channel hwv + 8 * (jj / 18),
   // row (jj % 18) / 2, column group jj & 1.  Column 64: one item per thread (+ 32 threads a second one).  gy tile: 32 x 32.
-  float px[72], pe[2], pg[4];
+  float px[NX], pe[NE], pg[4];
   unsigned chan_ok = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) chan_ok |= (cb * 32 + hwv + 8 * q < d.Ci ? 1u : 0u) << q;
-  const int e_r0 = tid, e_r1 = tid + 256;  // rows of the column-64 items
-  const int e_c0 = e_r0 / 9, e_m0 = e_r0 - 9 * e_c0, e_c1 = e_r1 / 9, e_m1 = e_r1 - 9 * e_c1;
+  for (int q = 0; q < NQ; ++q) chan_ok |= (cb * 32 + hwv + HWV * q < d.Ci ? 1u : 0u) << q;
+  const int e_r0 = tid, e_r1 = tid + NTH;  // rows of the column-64 items (the second one only with OB = 1)
+  const int e_c0 = min(e_r0, 287) / 9, e_m0 = min(e_r0, 287) - 9 * e_c0, e_c1 = min(e_r1, 287) / 9, e_m1 = min(e_r1, 287) - 9 * e_c1;
 
   // issues the loads of tile tt, returns its validity mask (bits 0..8 rows, 9..10 column groups, 11 column 64, 12 gy column)
   auto prefetch = [&](int tt) -> unsigned {
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
     const int b = t / d.Do;
     const int w0 = wt * 32, h0 = ht;
     const float* xb = x + ((long long)b * d.Ci + cb * 32) * (long long)DHW;
-    const float* gb = gy + ((long long)b * d.Co + ob * 32) * (long long)oDHW;
+    const float* gb = gy + ((long long)b * d.Co + ob0 * 32) * (long long)oDHW;
     unsigned m = 0;
     int rowoff[9];
 #pragma unroll
@@ -719,25 +727,27 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
     m |= (w0 + l32 < d.Wo ? 1u : 0u) << 12;
     const int cbase = hwv * DHW;
 #pragma unroll
-    for (int jj = 0; jj < 72; ++jj) {
+    for (int jj = 0; jj < NX; ++jj) {
       const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
       const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
-      const int off = cbase + q * 8 * DHW + rowoff[r] + (g ? gw1 : gw0);
+      const int off = cbase + q * HWV * DHW + rowoff[r] + (g ? gw1 : gw0);
       px[jj] = xb[ok ? off : 0];
     }
     {
       const int gd0 = 2 * qd + e_m0 / 3 - 1, gh0 = 2 * h0 + e_m0 % 3 - 1;
-      const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
+      const bool ok0 = e_r0 < 288 && ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
       pe[0] = xb[ok0 ? e_c0 * DHW + gd0 * HW + gh0 * d.W + gw2 : 0];
-      const int gd1 = 2 * qd + e_m1 / 3 - 1, gh1 = 2 * h0 + e_m1 % 3 - 1;
-      const bool ok1 = e_r1 < 288 && ((m >> e_m1) & 1) && ((m >> 11) & 1) && cb * 32 + e_c1 < d.Ci;
-      pe[1] = xb[ok1 ? e_c1 * DHW + gd1 * HW + gh1 * d.W + gw2 : 0];
+      if (NE > 1) {
+        const int gd1 = 2 * qd + e_m1 / 3 - 1, gh1 = 2 * h0 + e_m1 % 3 - 1;
+        const bool ok1 = e_r1 < 288 && ((m >> e_m1) & 1) && ((m >> 11) & 1) && cb * 32 + e_c1 < d.Ci;
+        pe[NE - 1] = xb[ok1 ? e_c1 * DHW + gd1 * HW + gh1 * d.W + gw2 : 0];
+      }
     }
     const int gbase = qd * oHW + h0 * d.Wo + w0 + l32;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int o = 8 * j + hwv;
-      const bool ok = ((m >> 12) & 1) && ob * 32 + o < d.Co;
+      const int o = HWV * j + hwv;  // row of the 32 * OB gy tile
+      const bool ok = ((m >> 12) & 1) && ob0 * 32 + o < d.Co;
       pg[j] = gb[ok ? o * oDHW + gbase : 0];
     }
     return m;
@@ -746,28 +756,30 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
   auto store = [&](unsigned m) {
     float* xrow = xl + hwv * XPLANE + l32;
 #pragma unroll
-    for (int jj = 0; jj < 72; ++jj) {
+    for (int jj = 0; jj < NX; ++jj) {
       const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
       const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
-      xrow[q * 8 * XPLANE + r * XW + 32 * g] = ok ? px[jj] : 0.f;
+      xrow[q * HWV * XPLANE + r * XW + 32 * g] = ok ? px[jj] : 0.f;
     }
-    const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
-    xl[e_c0 * XPLANE + e_m0 * XW + 64] = ok0 ? pe[0] : 0.f;
-    if (e_r1 < 288) {
+    if (e_r0 < 288) {
+      const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
+      xl[e_c0 * XPLANE + e_m0 * XW + 64] = ok0 ? pe[0] : 0.f;
+    }
+    if (NE > 1 && e_r1 < 288) {
       const bool ok1 = ((m >> e_m1) & 1) && ((m >> 11) & 1) && cb * 32 + e_c1 < d.Ci;
-      xl[e_c1 * XPLANE + e_m1 * XW + 64] = ok1 ? pe[1] : 0.f;
+      xl[e_c1 * XPLANE + e_m1 * XW + 64] = ok1 ? pe[NE - 1] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int o = 8 * j + hwv;
-      const bool ok = ((m >> 12) & 1) && ob * 32 + o < d.Co;
+      const int o = HWV * j + hwv;
+      const bool ok = ((m >> 12) & 1) && ob0 * 32 + o < d.Co;
       gl[o * GPLANE + l32] = ok ? pg[j] : 0.f;
     }
   };
 
   unsigned mask = 0;
   if (s < d.T) mask = prefetch(s);
-  const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);
+  const float* ap = gl + (oh * 32 + (lane & 31)) * GPLANE + (lane >> 5);
   const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5) * 2;
   for (int tt = s; tt < d.T; tt += d.S) {
     store(mask);
@@ -785,11 +797,11 @@ __global__ __launch_bounds__(NT, 2) void conv3d_bwd_weight_s2_kernel(const float
     __syncthreads();
   }
 
-  float* pb = part + (((long long)s * d.MTo + ob) * d.MTc + cb) * (27 * 1024);
+  float* pb = part + (((long long)s * d.MTo + (ob < d.MTo ? ob : 0)) * d.MTc + cb) * (27 * 1024);
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = wave + 4 * t;
-    if (tap < 27) {
+    if (tap < 27 && ob < d.MTo) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -1034,9 +1046,16 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   } else {
     const size_t lds = WGeom<2, WTH2>::LDS;
     if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
-      rc = mode::allow_lds(conv3d_bwd_weight_s2_kernel, lds, "mode_conv3d_bwd_weight");
-      if (rc != MODE_OK) return rc;
-      hipLaunchKernelGGL(conv3d_bwd_weight_s2_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+      if (d.MTo >= 2) {  // two output-channel blocks per workgroup share the staged x tile
+        const size_t lds2 = lds + (size_t)32 * WGeom<2, WTH2>::GPLANE * sizeof(float);
+        rc = mode::allow_lds(conv3d_bwd_weight_s2_kernel<2>, lds2, "mode_conv3d_bwd_weight");
+        if (rc != MODE_OK) return rc;
+        hipLaunchKernelGGL(conv3d_bwd_weight_s2_kernel<2>, dim3(d.S, mode::cdiv(d.MTo, 2), d.MTc), dim3(2 * NT), lds2, st, gy, x, workspace, d);
+      } else {
+        rc = mode::allow_lds(conv3d_bwd_weight_s2_kernel<1>, lds, "mode_conv3d_bwd_weight");
+        if (rc != MODE_OK) return rc;
+        hipLaunchKernelGGL(conv3d_bwd_weight_s2_kernel<1>, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
+      }
     } else {
       rc = mode::allow_lds(conv3d_bwd_weight_kernel<2, WTH2>, lds, "mode_conv3d_bwd_weight");
       if (rc != MODE_OK) return rc;
