@@ -696,6 +696,7 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
   unsigned chan_ok = 0;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) chan_ok |= (cb * 32 + hwv + HWV * q < d.Ci ? 1u : 0u) << q;
+  const bool all_chan = cb * 32 + 32 <= d.Ci;  // (block-uniform)
   const int e_r0 = tid, e_r1 = tid + NTH;  // rows of the column-64 items (the second one only with OB = 1)
   const int e_c0 = min(e_r0, 287) / 9, e_m0 = min(e_r0, 287) - 9 * e_c0, e_c1 = min(e_r1, 287) / 9, e_m1 = min(e_r1, 287) - 9 * e_c1;
 
@@ -726,12 +727,25 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
     m |= (gw2 < d.W ? 1u : 0u) << 11;
     m |= (w0 + l32 < d.Wo ? 1u : 0u) << 12;
     const int cbase = hwv * DHW;
+    if (all_chan && (m & 0x1ffu) == 0x1ffu) {
+      // interior tile (every row and channel exists -- all but the first depth / row of a sample): no per-item masks, the two
+      // column groups read a clamped column and are masked by one select each at the LDS store (PMC: the general form below
+      // costs 4.9 VALU + 3.4 SALU instructions per MFMA)
+      m |= 1u << 13;
+      const int c0 = cbase + ((m >> 9) & 1 ? gw0 : 0), c1 = cbase + ((m >> 10) & 1 ? gw1 : 0);
 #pragma unroll
-    for (int jj = 0; jj < NX; ++jj) {
-      const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
-      const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
-      const int off = cbase + q * HWV * DHW + rowoff[r] + (g ? gw1 : gw0);
-      px[jj] = xb[ok ? off : 0];
+      for (int jj = 0; jj < NX; ++jj) {
+        const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+        px[jj] = xb[(g ? c1 : c0) + q * HWV * DHW + rowoff[r]];
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NX; ++jj) {
+        const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+        const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
+        const int off = cbase + q * HWV * DHW + rowoff[r] + (g ? gw1 : gw0);
+        px[jj] = xb[ok ? off : 0];
+      }
     }
     {
       const int gd0 = 2 * qd + e_m0 / 3 - 1, gh0 = 2 * h0 + e_m0 % 3 - 1;
@@ -755,11 +769,20 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
   // registers -> LDS for the tile whose mask is m (masked elements become zeros)
   auto store = [&](unsigned m) {
     float* xrow = xl + hwv * XPLANE + l32;
+    if ((m >> 13) & 1) {  // interior tile: only the column masks
+      const bool ok0 = (m >> 9) & 1, ok1 = (m >> 10) & 1;
 #pragma unroll
-    for (int jj = 0; jj < NX; ++jj) {
-      const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
-      const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
-      xrow[q * HWV * XPLANE + r * XW + 32 * g] = ok ? px[jj] : 0.f;
+      for (int jj = 0; jj < NX; ++jj) {
+        const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+        xrow[q * HWV * XPLANE + r * XW + 32 * g] = (g ? ok1 : ok0) ? px[jj] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NX; ++jj) {
+        const int q = jj / 18, r = (jj % 18) / 2, g = jj & 1;
+        const bool ok = ((chan_ok >> q) & 1) && ((m >> r) & 1) && ((m >> (9 + g)) & 1);
+        xrow[q * HWV * XPLANE + r * XW + 32 * g] = ok ? px[jj] : 0.f;
+      }
     }
     if (e_r0 < 288) {
       const bool ok0 = ((m >> e_m0) & 1) && ((m >> 11) & 1) && cb * 32 + e_c0 < d.Ci;
