@@ -685,10 +685,9 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     acc[t] = (f32x16){0};
-    const int tap = wave + 4 * t;  // < 27 except wave 3, t = 6
+    const int tap = min(wave + 4 * t, 26);  // wave 3, t = 6 would be tap 27: it repeats tap 26 and drops the result
     toff[t] = (tap / 9) * (XR * XW) + ((tap / 3) % 3) * XW + (tap % 3);
   }
-  const bool last_valid = (wave + 24) < 27;
 
   // x tile = 288 (channel, depth, row) rows of 65 columns.  Columns 0..63: item jj of half-wave hwv is channel hwv + 8 * (jj / 18),
   // row (jj % 18) / 2, column group jj & 1.  Column 64: one item per thread (+ 32 threads a second one).  gy tile: 32 x 32.
@@ -809,13 +808,26 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
     __syncthreads();
     if (tt + d.S < d.T) mask = prefetch(tt + d.S);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-      const float a = ap[2 * ks];
-      const float* bq = bp + 4 * ks;
+    // operands of k-step ks+1 are read from LDS before the 7 MFMAs of k-step ks are issued (the straightforward loop waited
+    // for an LDS round trip at the head of every k-step, and once more inside the branch around the 7th tap: all four waves
+    // now run 7 taps -- wave 3's last one is a duplicate whose result is dropped -- and there is no branch)
+    float a_n = ap[0], b_n[7];
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
-      if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
+    for (int t7 = 0; t7 < 7; ++t7) b_n[t7] = bp[toff[t7]];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a = a_n;
+      float bb[7];
+#pragma unroll
+      for (int t7 = 0; t7 < 7; ++t7) bb[t7] = b_n[t7];
+      if (ks + 1 < 16) {
+        a_n = ap[2 * (ks + 1)];
+#pragma unroll
+        for (int t7 = 0; t7 < 7; ++t7) b_n[t7] = bp[4 * (ks + 1) + toff[t7]];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink these reads to their first use)
+#pragma unroll
+      for (int t7 = 0; t7 < 7; ++t7) acc[t7] = mfma32(a, bb[t7], acc[t7]);
     }
     __syncthreads();
   }
@@ -856,11 +868,10 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     acc[t] = (f32x16){0};
-    const int tap = wave + 4 * t;
+    const int tap = min(wave + 4 * t, 26);  // wave 3, t = 6 would be tap 27: it repeats tap 26 and drops the result (no branch)
     kd[t] = tap / 9;
     khw[t] = ((tap / 3) % 3) * XW + (tap % 3);
   }
-  const bool last_valid = (wave + 24) < 27;
   const int hwv = tid >> 5, l32 = tid & 31;
   const int HWi = d.H * d.W, DHWi = d.D * HWi;  // (host guarantees 32-bit element offsets within a sample)
   unsigned chan_ok = 0, gchan_ok = 0;           // x item j is channel 2 * j + (hwv >> 2), gy item j is channel 4 * j + (hwv >> 1)
@@ -942,16 +953,25 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
       for (int t7 = 0; t7 < 7; ++t7) toff[t7] = ((dd + kd[t7] + 2) % 3) * PS + khw[t7];  // depth dd + kd - 1
       const float* ap = gl + (lane & 31) * GPLANE + (lane >> 5);
       const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5);
+      // 32 k-steps (2 rows x 16 voxel pairs); the operands of step i+1 are read from LDS before the 7 MFMAs of step i are issued
+      float a_n = ap[0], b_n[7];
 #pragma unroll
-      for (int row = 0; row < WTH; ++row) {
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-          const float a = ap[row * 32 + 2 * ks];
-          const float* bq = bp + row * XW + 2 * ks;
+      for (int t7 = 0; t7 < 7; ++t7) b_n[t7] = bp[toff[t7]];
 #pragma unroll
-          for (int t6 = 0; t6 < 6; ++t6) acc[t6] = mfma32(a, bq[toff[t6]], acc[t6]);
-          if (last_valid) acc[6] = mfma32(a, bq[toff[6]], acc[6]);
+      for (int i = 0; i < WTH * 16; ++i) {
+        const float a = a_n;
+        float bb[7];
+#pragma unroll
+        for (int t7 = 0; t7 < 7; ++t7) bb[t7] = b_n[t7];
+        if (i + 1 < WTH * 16) {
+          const int row = (i + 1) / 16, ks = (i + 1) % 16;
+          a_n = ap[row * 32 + 2 * ks];
+#pragma unroll
+          for (int t7 = 0; t7 < 7; ++t7) b_n[t7] = bp[row * XW + 2 * ks + toff[t7]];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink these reads to their first use)
+#pragma unroll
+        for (int t7 = 0; t7 < 7; ++t7) acc[t7] = mfma32(a, bb[t7], acc[t7]);
       }
       __syncthreads();
       if (more) {
