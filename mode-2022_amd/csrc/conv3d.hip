@@ -200,15 +200,27 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- 27 taps x 4 channel pairs x R rows x MT tiles of MFMA
+    // weights one tap ahead: the fragment of tap t+1 is requested half-way through the MFMAs of tap t (the compiler on its
+    // own requested it right before its first use and waited a full L1/L2 round trip every other tap)
     const float4* wq = wp + ((long long)ch * 27) * 64 + lane;
+    float4 a_nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_nxt[m] = wq[((long long)m * d.NCHUNK * 27) * 64];
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int toff = (tap / 9) * (IH * IW) + ((tap / 3) % 3) * IW + tap_woff<S>(tap % 3);
       float4 a4[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a4[m] = wq[((long long)m * d.NCHUNK * 27 + tap) * 64];
+      for (int m = 0; m < MT; ++m) a4[m] = a_nxt[m];
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) {
+        if (cp == 2) {
+          if (tap + 1 < 27) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_nxt[m] = wq[((long long)m * d.NCHUNK * 27 + tap + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float bv = bbase[2 * cp * PLANE + toff + rowoff[r]];
