@@ -320,6 +320,21 @@ int conv3d_s2(const float* x, const float* w, float* y, float* wpack, int B, int
 // k = 2 (q = q') and k = 0 (q = q'+1).  The 8 parity classes of one low-resolution voxel carry 1+2+2+2+4+4+4+8 = 27
 // taps, so no MFMA is spent on structural zeros.  D[i = o][j = 32 low-res w]; a wave owns one low-res row and keeps the
 // 8 class accumulators live; the two w-parities of a row are stored interleaved as one float2 per lane (coalesced).
+// Weight tap (kd*9 + kh*3 + kw) of the n-th MFMA group of deconv3d_kernel, in the order its parity-class loops run.
+__host__ __device__ constexpr int deconv_wtap(int n) {
+  int i = 0;
+  for (int pd = 0; pd < 2; ++pd)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw)
+        for (int td = 0; td <= pd; ++td)
+          for (int th = 0; th <= ph; ++th)
+            for (int tw = 0; tw <= pw; ++tw) {
+              if (i == n) return (pd ? (td ? 0 : 2) : 1) * 9 + (ph ? (th ? 0 : 2) : 1) * 3 + (pw ? (tw ? 0 : 2) : 1);
+              ++i;
+            }
+  return 0;
+}
+
 template <int TD, int TH>
 __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
                                                       float* __restrict__ y, CDims d) {
@@ -396,7 +411,17 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
       issue(ch + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // The 27 taps touch only 8 distinct input voxels per channel pair ((dq_d, dq_h, dq_w) in {0,1}^3): the 32 B operands of the
+    // chunk are read from LDS once, up front.  The weight fragment of tap n+2 is requested while tap n runs (the compiler on
+    // its own requested every fragment right before its first use and waited for the L1/L2 round trip).
     const float4* wq = wp + (((long long)mt * d.NCHUNK + ch) * 27) * 64 + lane;
+    float bop[4][8];
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+      for (int v = 0; v < 8; ++v) bop[cp][v] = bbase[2 * cp * PLANE + (v >> 2) * (IH * IW) + ((v >> 1) & 1) * IW + (v & 1)];
+    float4 w_a = wq[deconv_wtap(0) * 64], w_b = wq[deconv_wtap(1) * 64];
+    int n = 0;
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
@@ -410,13 +435,16 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
 #pragma unroll
               for (int tw = 0; tw <= pw; ++tw) {
                 // parity 0: (k = 1, dq = 0); parity 1: t = 0 -> (k = 2, dq = 0), t = 1 -> (k = 0, dq = 1)
-                const int kd = pd ? (td ? 0 : 2) : 1, kh = ph ? (th ? 0 : 2) : 1, kw = pw ? (tw ? 0 : 2) : 1;
-                const int off = (pd ? td : 0) * (IH * IW) + (ph ? th : 0) * IW + (pw ? tw : 0);
-                const float4 a4 = wq[(kd * 9 + kh * 3 + kw) * 64];
-                acc[pd][ph][pw] = mfma32(a4.x, bbase[0 * PLANE + off], acc[pd][ph][pw]);
-                acc[pd][ph][pw] = mfma32(a4.y, bbase[2 * PLANE + off], acc[pd][ph][pw]);
-                acc[pd][ph][pw] = mfma32(a4.z, bbase[4 * PLANE + off], acc[pd][ph][pw]);
-                acc[pd][ph][pw] = mfma32(a4.w, bbase[6 * PLANE + off], acc[pd][ph][pw]);
+                const int v = ((pd ? td : 0) << 2) | ((ph ? th : 0) << 1) | (pw ? tw : 0);
+                const float4 a4 = w_a;
+                w_a = w_b;
+                if (n + 2 < 27) w_b = wq[deconv_wtap(n + 2) * 64];
+                ++n;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pd][ph][pw] = mfma32(a4.x, bop[0][v], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.y, bop[1][v], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.z, bop[2][v], acc[pd][ph][pw]);
+                acc[pd][ph][pw] = mfma32(a4.w, bop[3][v], acc[pd][ph][pw]);
               }
     __syncthreads();
     if (ch + 1 < d.NCHUNK) {
