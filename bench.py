@@ -30,7 +30,8 @@ import torch.nn.functional as F  # noqa: E402
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
-KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm'}
+KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
+                'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm'}
 
 
 def parse():

@@ -506,31 +506,57 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
   f32x16 acc0 = {0}, acc1 = {0};
   const float4* wpa = wp + ((long long)(g * MTc + (active ? mt : 0)) * NCHo) * KT * 64 + lane;
 
+  // Weight fragments of chunk ch+1 (9 x float4) are requested BEFORE the gathers of chunk ch+1, so that by the time the MFMAs
+  // of chunk ch+1 run they are long complete and nothing in the MFMA phase waits on the (in-order) vector-memory counter;
+  // the 8 LDS operands of quad q+1 are read before the 16 MFMAs of quad q are issued.  (The straightforward loop waited for an
+  // LDS round trip every two MFMAs and for an L1/L2 round trip -- and with it for all 72 gathers in flight -- every quad.)
+  float4 wcur[KT], wnxt[KT];
+#pragma unroll
+  for (int quad = 0; quad < KT; ++quad) wcur[quad] = wpa[quad * 64];
   issue(0);
   finish(0, colbuf);
   __syncthreads();
   for (int ch = 0; ch < NCHo; ++ch) {
     float* cur = colbuf + (ch & 1) * rows * P;
     float* nxt = colbuf + ((ch + 1) & 1) * rows * P;
-    if (ch + 1 < NCHo) issue(ch + 1);
+    if (ch + 1 < NCHo) {
+      const float4* wq = wpa + (long long)(ch + 1) * KT * 64;
+#pragma unroll
+      for (int quad = 0; quad < KT; ++quad) wnxt[quad] = wq[quad * 64];
+      issue(ch + 1);
+    }
     if (active) {
-      const float4* wq = wpa + (long long)ch * KT * 64;
       const float* bp = cur + (lane >> 5) * P + (lane & 31);
+      float bn[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bn[i] = bp[(i >> 1) * 2 * P + (i & 1) * 32];
 #pragma unroll
       for (int quad = 0; quad < KT; ++quad) {
-        const float4 a4 = wq[quad * 64];
-        const float* bq = bp + quad * 8 * P;
-        acc0 = mfma32(a4.x, bq[0], acc0);
-        acc1 = mfma32(a4.x, bq[32], acc1);
-        acc0 = mfma32(a4.y, bq[2 * P], acc0);
-        acc1 = mfma32(a4.y, bq[2 * P + 32], acc1);
-        acc0 = mfma32(a4.z, bq[4 * P], acc0);
-        acc1 = mfma32(a4.z, bq[4 * P + 32], acc1);
-        acc0 = mfma32(a4.w, bq[6 * P], acc0);
-        acc1 = mfma32(a4.w, bq[6 * P + 32], acc1);
+        const float4 a4 = wcur[quad];
+        float bc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bc[i] = bn[i];
+        if (quad + 1 < KT) {
+          const float* bq = bp + (quad + 1) * 8 * P;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bn[i] = bq[(i >> 1) * 2 * P + (i & 1) * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma32(a4.x, bc[0], acc0);
+        acc1 = mfma32(a4.x, bc[1], acc1);
+        acc0 = mfma32(a4.y, bc[2], acc0);
+        acc1 = mfma32(a4.y, bc[3], acc1);
+        acc0 = mfma32(a4.z, bc[4], acc0);
+        acc1 = mfma32(a4.z, bc[5], acc1);
+        acc0 = mfma32(a4.w, bc[6], acc0);
+        acc1 = mfma32(a4.w, bc[7], acc1);
       }
     }
-    if (ch + 1 < NCHo) finish(ch + 1, nxt);
+    if (ch + 1 < NCHo) {
+      finish(ch + 1, nxt);
+#pragma unroll
+      for (int quad = 0; quad < KT; ++quad) wcur[quad] = wnxt[quad];
+    }
     __syncthreads();
   }
 

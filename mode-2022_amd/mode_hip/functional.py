@@ -650,6 +650,11 @@ def head(logits, size):
 
 
 # ------------------------------------------------------------------------------------ BatchNorm (+ add) (+ ReLU)
+def _tag_bn(name, y):
+  """Profiling label with the tensor shape (like the convolution labels), e.g. bn_train_fwd[2x32 48x256x128]."""
+  return '%s[%dx%d %s]' % (name, y.shape[0], y.shape[1], 'x'.join(str(int(v)) for v in y.shape[2:])) if profiling.ENABLED else name
+
+
 def _bn_ws(C, device):
   return torch.empty(lib().mode_bn_workspace_bytes(C) // 4, dtype=torch.float32, device=device)
 
@@ -684,7 +689,7 @@ class BnActFunction(torch.autograd.Function):
     from_y = bool(relu) and add is None
     coef = torch.empty((2, groups * C), dtype=torch.float32, device=y.device) if from_y else None
     nbytes = 4 * y.numel() * (3 + (1 if add is not None else 0))
-    with torch.cuda.device_of(y), profiling.region('bn_train_fwd', nbytes, 0, y.device):
+    with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_fwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * groups, y.device)
       check(lib().mode_bn_train_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta),
                                     ptr(running_mean) if running_mean is not None else None,
@@ -709,7 +714,7 @@ class BnActFunction(torch.autograd.Function):
     ggamma = sink_g if fused else torch.empty_like(gamma)
     gbeta = sink_b if fused else torch.empty_like(gamma)
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
-    with torch.cuda.device_of(y), profiling.region('bn_train_bwd', nbytes, 0, y.device):
+    with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * ctx.groups, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
                                     ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
