@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 6 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 7 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -181,6 +181,14 @@ int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, 
  * both write (do not accumulate) and are deterministic. */
 int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W, mode_stream_t stream);
 int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W, mode_stream_t stream);
+
+/* Weight gradient of the regular 3x3 Conv2d layers of the extractor (nn.Conv2d inside convbn, models/submodule.py:15-17):
+ * stride 1, padding = dilation in {1, 2}, no bias, groups 1.  gw (Co, Ci, 3, 3) (+)= sum_{b,h,w} gy[b,o,h,w] * x[b,c,h+(kh-1)*dil,
+ * w+(kw-1)*dil]; gy (B,Co,H,W), x (B,Ci,H,W).  Deterministic.  `workspace` >= mode_conv2d_bwd_weight_workspace_bytes().
+ * (Forward and input gradient of these layers stay on the vendor library's fp32 Winograd kernels.) */
+size_t mode_conv2d_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co);
+int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
+                           int dilation, int accumulate, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3x3 convolution, padding 1, no bias -- replaces the cuDNN nn.Conv3d inside convbn_3d

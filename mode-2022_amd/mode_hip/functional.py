@@ -57,6 +57,58 @@ def cost_volume(ref, tgt, d4):
 
 
 # ------------------------------------------------------------------------------------ sphere conv
+# ------------------------------------------------------------------------------------ regular 3x3 Conv2d: own weight gradient
+def conv2d_bwd_weight(gy, x, dilation=1, into=None):
+  """Weight gradient (Co, Ci, 3, 3) of a stride-1 3x3 convolution with padding = dilation (1 or 2): mode_conv2d_bwd_weight.
+  `into`: add to this tensor (a gradient sink) instead of returning a new one."""
+  require_gpu(gy, x)
+  require_f32c(gy, x)
+  B, Ci, H, W = x.shape
+  Co = gy.shape[1]
+  assert tuple(gy.shape) == (B, Co, H, W)
+  gw = into if into is not None else torch.empty((Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+  flops = 2 * gy.numel() * Ci * 9
+  nbytes = 4 * (gy.numel() + x.numel() + gw.numel())
+  with torch.cuda.device_of(x), profiling.region('conv2d_bwd_weight[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
+                                                 else 'conv2d_bwd_weight', nbytes, flops, x.device):
+    ws = torch.empty(max(lib().mode_conv2d_bwd_weight_workspace_bytes(B, Ci, H, W, Co) // 4, 1), dtype=torch.float32, device=x.device)
+    check(lib().mode_conv2d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, dilation, 1 if into is not None else 0,
+                                       stream_of(x)), 'mode_conv2d_bwd_weight')
+  return gw
+
+
+class Conv2d3x3Function(torch.autograd.Function):
+  """y = conv2d(x, w, stride 1, padding = dilation): forward and input gradient on the vendor library (fp32 Winograd), weight
+  gradient on mode_conv2d_bwd_weight (the vendor's runs as an NHWC implicit GEMM between two layout transposes)."""
+
+  @staticmethod
+  def forward(ctx, x, w, dilation):
+    ctx.save_for_backward(x, w)
+    ctx.dilation = dilation
+    return torch.nn.functional.conv2d(x, w, None, 1, dilation, dilation)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    dil = ctx.dilation
+    gy = gy.contiguous()
+    gx = None
+    if ctx.needs_input_grad[0]:
+      gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = conv2d_bwd_weight(gy, x.contiguous(), dil, into=sink)
+      if sink is not None:
+        gw = None
+    return gx, gw, None
+
+
+def conv2d_3x3(x, w, dilation=1):
+  return Conv2d3x3Function.apply(x, w, dilation)
+
+
 # ------------------------------------------------------------------------------------ cost volume + dres0[0][0], fused
 class CostConvAssemble(torch.autograd.Function):
   """out (B,Co,D,H,W) from the partial products R, T (B, 9*Co, H, W) -- see cost_conv() and csrc/cost_conv.hip."""

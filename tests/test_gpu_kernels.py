@@ -460,6 +460,35 @@ def test_conv3d_single_output_channel(B, Ci, D, H, W):
   assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
 
 
+# ------------------------------------------------------------------ regular 3x3 Conv2d: weight gradient (a3)
+@pytest.mark.parametrize('B,Ci,Co,H,W,dil', [(2, 32, 32, 16, 64, 1), (1, 64, 64, 9, 40, 1), (2, 20, 40, 7, 33, 1), (1, 64, 64, 12, 32, 2),
+                                             (2, 3, 5, 5, 70, 2), (1, 128, 128, 8, 32, 1), (1, 8, 8, 2, 3, 2)])
+def test_conv2d_3x3_weight_gradient(B, Ci, Co, H, W, dil):
+  """mode_conv2d_bwd_weight against torch's fp64 conv2d autograd: ragged tiles, channel counts off the 32-wide block, dilation 2,
+  images smaller than the halo; accumulate semantics; the autograd Function (vendor forward / input gradient + own weight
+  gradient) end to end."""
+  import torch.nn.functional as F
+  x, w = _rand((B, Ci, H, W), 61), _rand((Co, Ci, 3, 3), 62, 0.2)
+  xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+  y_ref = F.conv2d(xa, wa, None, 1, dil, dil)
+  gy = _rand(tuple(y_ref.shape), 63)
+  y_ref.backward(gy.double())
+  scale = max(1.0, float(wa.grad.abs().max()))
+  gw = HF.conv2d_bwd_weight(gy.to(DEV), x.to(DEV), dil)
+  assert (gw.cpu().double() - wa.grad).abs().max() < 2e-5 * scale
+  gw2 = HF.conv2d_bwd_weight(gy.to(DEV), x.to(DEV), dil)
+  assert torch.equal(gw, gw2)  # deterministic
+  acc = gw.clone()
+  HF.conv2d_bwd_weight(gy.to(DEV), x.to(DEV), dil, into=acc)
+  assert (acc.cpu().double() - 2 * wa.grad).abs().max() < 4e-5 * scale
+  xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+  y = HF.conv2d_3x3(xd, wd, dil)
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().max()))  # (vendor Winograd forward)
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 1e-3 * max(1.0, float(xa.grad.abs().max()))
+  assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * scale
+
+
 # ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
 @pytest.mark.parametrize('shape', [(2, 8, 4, 6, 8), (1, 32, 6, 16, 32), (2, 64, 24, 32), (3, 5, 2, 2, 4)])
 @pytest.mark.parametrize('relu,with_add', [(False, False), (True, False), (True, True), (False, True)])
