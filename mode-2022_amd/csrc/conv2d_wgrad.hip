@@ -167,47 +167,61 @@ __global__ __launch_bounds__(NT, 2) void conv2d_bwd_weight_kernel(const float* _
     __syncthreads();
   }
 
-  // combine the four waves (rows of the tile) through LDS, tap by tap, then one partial per workgroup
-  float* red = lds;  // [4][1024]
+  // combine the four waves (rows of the tile) through LDS, three taps per round (48 KB), then one partial per workgroup
+  float* red = lds;  // [3 taps][4 waves][1024]
   float* pb = part + (((long long)s * d.MTo + ob) * d.MTc + cb) * (9 * 1024);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+  for (int t3 = 0; t3 < 3; ++t3) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-      red[wave * 1024 + i * 32 + (lane & 31)] = acc[t][q];
-    }
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        red[(u * 4 + wave) * 1024 + i * 32 + (lane & 31)] = acc[t3 * 3 + u][q];
+      }
     __syncthreads();
-    for (int idx = tid; idx < 1024; idx += NT) pb[t * 1024 + idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+    for (int idx = tid; idx < 3 * 1024; idx += NT) {
+      const int u = idx >> 10, e = idx & 1023;
+      const float* r4 = red + u * 4096 + e;
+      pb[(t3 * 3 + u) * 1024 + e] = (r4[0] + r4[1024]) + (r4[2048] + r4[3072]);
+    }
     __syncthreads();
   }
 }
 
-// gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32]: one thread per element of the partial layout (coalesced reads of
-// every slice), 4 interleaved running sums in a fixed association
-__global__ void reduce_gw2d(const float* __restrict__ part, float* __restrict__ gw, W2Dims d, int accumulate) {
+// gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32].  A block of 256 threads handles 32 consecutive elements of the
+// partial layout: thread (e, g) sums the slices s = g, g+8, ... in order (coalesced 128-byte reads per slice), the 8 group sums
+// are combined through LDS in a fixed association -- deterministic, and 8x the parallelism of one thread per element (the split
+// count is 128-512 and an element per thread walked them as one dependent chain).
+__global__ __launch_bounds__(256) void reduce_gw2d(const float* __restrict__ part, float* __restrict__ gw, W2Dims d, int accumulate) {
+  __shared__ float sh[8][33];
   const long long stride = (long long)d.MTo * d.MTc * 9 * 1024;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < stride; e += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + el;
+  float a0 = 0.f, a1 = 0.f;
+  if (e < stride) {
+    const float* p = part + e;
+    int s = g;
+    for (; s + 8 < d.S; s += 16) {
+      a0 += p[(long long)s * stride];
+      a1 += p[(long long)(s + 8) * stride];
+    }
+    if (s < d.S) a0 += p[(long long)s * stride];
+  }
+  sh[g][el] = a0 + a1;
+  __syncthreads();
+  if (g == 0 && e < stride) {
+    const float sum = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
     const int j = (int)(e & 31), i = (int)((e >> 5) & 31);
     long long r = e >> 10;
     const int tap = (int)(r % 9);
     r /= 9;
     const int cb = (int)(r % d.MTc), ob = (int)(r / d.MTc);
     const int o = ob * 32 + i, c = cb * 32 + j;
-    if (o >= d.Co || c >= d.Ci) continue;
-    const float* p = part + e;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < d.S; s += 4) {
-      a0 += p[(long long)s * stride];
-      a1 += p[(long long)(s + 1) * stride];
-      a2 += p[(long long)(s + 2) * stride];
-      a3 += p[(long long)(s + 3) * stride];
+    if (o < d.Co && c < d.Ci) {
+      float* q = gw + ((long long)o * d.Ci + c) * 9 + tap;
+      *q = accumulate ? *q + sum : sum;
     }
-    for (; s < d.S; ++s) a0 += p[(long long)s * stride];
-    const float sum = (a0 + a1) + (a2 + a3);
-    float* q = gw + ((long long)o * d.Ci + c) * 9 + tap;
-    *q = accumulate ? *q + sum : sum;
   }
 }
 
@@ -225,7 +239,7 @@ void make_dims(W2Dims& d, int B, int Ci, int H, int W, int Co) {
 
 template <int DIL>
 int launch(const float* gy, const float* x, float* workspace, const W2Dims& d, hipStream_t st, const char* who) {
-  const size_t lds = Geo<DIL>::LDS;
+  const size_t lds = std::max(Geo<DIL>::LDS, (size_t)3 * 4 * 1024 * sizeof(float));  // tile buffers, reused by the final cross-wave sum
   int rc = mode::allow_lds(conv2d_bwd_weight_kernel<DIL>, lds, who);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(conv2d_bwd_weight_kernel<DIL>, dim3(d.S, d.MTo, d.MTc), dim3(NT), lds, st, gy, x, workspace, d);
@@ -257,6 +271,6 @@ extern "C" int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw
   make_dims(d, B, Ci, H, W, Co);
   int rc = dilation == 1 ? launch<1>(gy, x, workspace, d, st, who) : launch<2>(gy, x, workspace, d, st, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(reduce_gw2d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 9 * 1024, 256)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  hipLaunchKernelGGL(reduce_gw2d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 9 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv2d_bwd_weight(reduce)");
 }
