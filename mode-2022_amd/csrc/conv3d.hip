@@ -1036,32 +1036,38 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
   }
 }
 
-// gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32]
-__global__ void reduce_gw3d(const float* __restrict__ part, float* __restrict__ gw, WDims d, int accumulate) {
-  // one thread per element of the partial layout (tap, o % 32, c % 32 fastest): coalesced reads of every slice; the slices
-  // are summed with 4 interleaved running sums in a fixed association -- deterministic, 4 independent loads in flight
+// gw[o][c][tap] (+)= sum_s part[s][o/32][c/32][tap][o%32][c%32].  A block of 256 threads handles 32 consecutive elements of the
+// partial layout: thread (e, g) sums the slices s = g, g+8, ... in order (coalesced 128-byte reads per slice), the 8 group sums
+// are combined through LDS in a fixed association -- deterministic, and 8x the parallelism of one thread per element.
+__global__ __launch_bounds__(256) void reduce_gw3d(const float* __restrict__ part, float* __restrict__ gw, WDims d, int accumulate) {
+  __shared__ float sh[8][33];
   const long long stride = (long long)d.MTo * d.MTc * 27 * 1024;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < stride; e += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + el;
+  float a0 = 0.f, a1 = 0.f;
+  if (e < stride) {
+    const float* p = part + e;
+    int s = g;
+    for (; s + 8 < d.S; s += 16) {
+      a0 += p[(long long)s * stride];
+      a1 += p[(long long)(s + 8) * stride];
+    }
+    if (s < d.S) a0 += p[(long long)s * stride];
+  }
+  sh[g][el] = a0 + a1;
+  __syncthreads();
+  if (g == 0 && e < stride) {
+    const float sum = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
     const int j = (int)(e & 31), i = (int)((e >> 5) & 31);
     long long r = e >> 10;
     const int tap = (int)(r % 27);
     r /= 27;
     const int cb = (int)(r % d.MTc), ob = (int)(r / d.MTc);
     const int o = ob * 32 + i, c = cb * 32 + j;
-    if (o >= d.Co || c >= d.Ci) continue;
-    const float* p = part + e;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < d.S; s += 4) {
-      a0 += p[(long long)s * stride];
-      a1 += p[(long long)(s + 1) * stride];
-      a2 += p[(long long)(s + 2) * stride];
-      a3 += p[(long long)(s + 3) * stride];
+    if (o < d.Co && c < d.Ci) {
+      float* q = gw + ((long long)o * d.Ci + c) * 27 + tap;
+      *q = accumulate ? *q + sum : sum;
     }
-    for (; s < d.S; ++s) a0 += p[(long long)s * stride];
-    const float sum = (a0 + a1) + (a2 + a3);
-    float* q = gw + ((long long)o * d.Ci + c) * 27 + tap;
-    *q = accumulate ? *q + sum : sum;
   }
 }
 
@@ -1148,7 +1154,7 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   rc = mode::check_launch("mode_conv3d_bwd_weight");
   if (rc != MODE_OK) return rc;
   const long long n = (long long)Co * Ci * 27;
-  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 256)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
 }
 
