@@ -567,7 +567,7 @@ template <int S, int WTH>
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                float* __restrict__ part, WDims d) {
   using G = WGeom<S, WTH>;
-  constexpr int XR = G::XR, XW = G::XW, XP0 = G::XP0, XPLANE = G::XPLANE, GPLANE = G::GPLANE;
+  constexpr int XR = G::XR, XW = G::XW, XPLANE = G::XPLANE, GPLANE = G::GPLANE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xl = lds;                 // [32][XPLANE]
   float* gl = lds + 32 * XPLANE;   // [32][GPLANE]
@@ -1153,7 +1153,6 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   }
   rc = mode::check_launch("mode_conv3d_bwd_weight");
   if (rc != MODE_OK) return rc;
-  const long long n = (long long)Co * Ci * 27;
   hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
 }

@@ -123,7 +123,7 @@ __device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) {
 
 constexpr int ZTH = 16, ZIH = ZTH + 2, ZIW = 34, ZPL = ZIH * ZIW;  // 16 x 32 outputs per plane; Z tile [27][18][34] = 66 KB
 constexpr int ZDC = 12;                                            // output depths per work unit (2 halo planes on top)
-constexpr int ZGROUPS = ZIH + 2;                                   // 18 row groups + 36 halo-column positions in 2 groups
+static_assert(ZIH + 2 == 4 * 5, "18 row groups + 36 halo-column positions in 2 groups = 5 groups per wave");
 
 template <bool ONE>
 __global__ __launch_bounds__(NT, 2) void conv3d_co1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
