@@ -42,7 +42,7 @@ enum {
 };
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 7 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 8 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -186,6 +186,14 @@ int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, 
  * stride 1, padding = dilation in {1, 2}, no bias, groups 1.  gw (Co, Ci, 3, 3) (+)= sum_{b,h,w} gy[b,o,h,w] * x[b,c,h+(kh-1)*dil,
  * w+(kw-1)*dil]; gy (B,Co,H,W), x (B,Ci,H,W).  Deterministic.  `workspace` >= mode_conv2d_bwd_weight_workspace_bytes().
  * (Forward and input gradient of these layers stay on the vendor library's fp32 Winograd kernels.) */
+/* Forward and input gradient of the same layers (used where they beat the vendor's Winograd: quarter resolution and dilation 2).
+ * x (B,Ci,H,W), w (Co,Ci,3,3), y (B,Co,H,W); Co <= 128 (Ci <= 128 for _bwd_data).  Both overwrite their output.
+ * `wpack` >= mode_conv2d_wpack_bytes(Ci, Co) bytes of scratch (fragment-ordered weights, rebuilt on every call). */
+size_t mode_conv2d_wpack_bytes(int Ci, int Co);
+int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                    mode_stream_t stream);
+int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                         mode_stream_t stream);
 size_t mode_conv2d_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co);
 int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                            int dilation, int accumulate, mode_stream_t stream);

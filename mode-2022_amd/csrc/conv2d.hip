@@ -1,0 +1,246 @@
+// Regular 3x3 convolution (stride 1, padding = dilation in {1, 2}, no bias) of the 2-D feature extractor at quarter resolution
+// (reference: nn.Conv2d inside convbn, models/submodule.py:15-17; layer2/layer3/lastconv, 23 layers of 64 -> 64 and one of
+// 128 -> 128 at 256 x 128).  At these sizes the vendor's fp32 Winograd runs at ~83 TFLOP/s effective and its dilated layers go
+// through an NHWC implicit GEMM between layout transposes (~74 effective); at half resolution its Winograd reaches ~190 and
+// stays in use (the host picks per layer).
+//
+// Same structure as conv3d.hip, one dimension down: implicit GEMM on v_mfma_f32_32x32x2_f32, D[i = o][j = 32 pixels along w];
+// haloed input tile [8 channels][TH + 2 dil][32 + 2 dil] in LDS, input channels streamed in chunks of 8 with the next chunk
+// travelling global -> registers under the MFMAs (half-wave = channel, item = tile row; unconditional loads from clamped
+// addresses, masks at the LDS store); weights pre-packed in fragment order and requested one tap ahead.  The input gradient is the
+// same kernel on gy with the weights transposed and flipped by the packing kernel.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 256;
+constexpr int CCH = 8;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct C2Dims {
+  int B, Ci, Co, H, W;
+  int nHt, nWt, ntiles, NCHUNK;
+};
+
+// wp[((mt*NCHUNK + ch)*9 + tap)*64 + lane][cp] = Wsrc(o = mt*32 + (lane&31), c = ch*8 + 2*cp + (lane>>5), tap)
+//   flip == 0: Wsrc(o,c,tap) = w[o][c][tap]      (forward; w is (Co,Ci,3,3), rows = Co, K = Ci)
+//   flip == 1: Wsrc(o,c,tap) = w[c][o][8 - tap]  (input gradient: rows = Ci of the convolution, K = Co)
+__global__ void pack_w2d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip) {
+  const long long total = (long long)MT * NCHUNK * 9 * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int ch = (int)(r % NCHUNK);
+    const int mt = (int)(r / NCHUNK);
+    const int o = mt * 32 + (lane & 31);
+    const int c = ch * CCH + 2 * cp + (lane >> 5);
+    float v = 0.f;
+    if (o < rows && c < K) v = flip ? w[((long long)c * rows + o) * 9 + 8 - tap] : w[((long long)o * K + c) * 9 + tap];
+    wp[idx] = v;
+  }
+}
+
+template <int MT, int TH, int DIL>
+__global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x, const float4* __restrict__ wp, float* __restrict__ y,
+                                                    C2Dims d) {
+  constexpr int R = TH / 4;  // output rows per wave
+  constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
+  constexpr int PLANE = (IH * IW) | 1;
+  constexpr int NHALO = CCH * IH * 2 * DIL, NPH = (NHALO + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [CCH][PLANE]
+
+  int t = blockIdx.x;
+  const int wt = t % d.nWt;
+  t /= d.nWt;
+  const int ht = t % d.nHt;
+  const int b = t / d.nHt;
+  const int w0 = wt * 32, h0 = ht * TH;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hwv = tid >> 5, l32 = tid & 31;
+  const int HW = d.H * d.W;  // (host guarantees max(Ci, Co) * H * W < 2^29)
+
+  f32x16 acc[MT][R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[m][r] = (f32x16){0};
+
+  const float* xb = x + (long long)b * d.Ci * HW;
+  // row offsets / validity of the tile rows (chunk-invariant); column validity of the interior group
+  int rowoff[IH];
+  unsigned rowok = 0;
+#pragma unroll
+  for (int r = 0; r < IH; ++r) {
+    const int gh = h0 + r - DIL;
+    const bool ok = gh >= 0 && gh < d.H && w0 + l32 < d.W;
+    rowoff[r] = ok ? gh * d.W + w0 + l32 : 0;
+    rowok |= (ok ? 1u : 0u) << r;
+  }
+  float vm[IH], vh[NPH];
+  auto halo_geom = [&](int k, int& c, int& r, int& col) {
+    const int e = k * NT + tid;
+    const int cr = e / (2 * DIL), j = e - cr * (2 * DIL);
+    c = cr / IH;
+    r = cr - c * IH;
+    col = j < DIL ? j : 32 + j;
+    return e < NHALO;
+  };
+  auto issue = [&](int ch) {
+    const float* xc = xb + (long long)(ch * CCH) * HW;
+    const bool cok = ch * CCH + hwv < d.Ci;
+#pragma unroll
+    for (int r = 0; r < IH; ++r) vm[r] = xc[(unsigned)(cok ? hwv * HW + rowoff[r] : 0)];
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) {
+      int c, r, col;
+      const bool in = halo_geom(k, c, r, col);
+      const int gh = h0 + r - DIL, gw = w0 + col - DIL;
+      const bool ok = in && ch * CCH + c < d.Ci && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
+      vh[k] = xc[(unsigned)(ok ? c * HW + gh * d.W + gw : 0)];
+    }
+  };
+  auto commit = [&](int ch) {
+    const bool cok = ch * CCH + hwv < d.Ci;
+    float* dst = tile + hwv * PLANE + DIL + l32;
+#pragma unroll
+    for (int r = 0; r < IH; ++r) dst[r * IW] = (cok && ((rowok >> r) & 1)) ? vm[r] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) {
+      int c, r, col;
+      const bool in = halo_geom(k, c, r, col);
+      const int gh = h0 + r - DIL, gw = w0 + col - DIL;
+      const bool ok = ch * CCH + c < d.Ci && gh >= 0 && gh < d.H && gw >= 0 && gw < d.W;
+      if (in) tile[c * PLANE + r * IW + col] = ok ? vh[k] : 0.f;
+    }
+  };
+
+  const float* bbase = tile + (lane >> 5) * PLANE + (wave * R) * IW + (lane & 31);
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int ch = 0; ch < d.NCHUNK; ++ch) {
+    if (ch + 1 < d.NCHUNK) {
+      issue(ch + 1);  // in flight during the MFMA phase below
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float4* wq = wp + ((long long)ch * 9) * 64 + lane;
+    float4 a_nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_nxt[m] = wq[((long long)m * d.NCHUNK * 9) * 64];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * DIL * IW + (tap % 3) * DIL;
+      float4 a4[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a4[m] = a_nxt[m];
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        if (cp == 2) {
+          if (tap + 1 < 9) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_nxt[m] = wq[((long long)m * d.NCHUNK * 9 + tap + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float bv = bbase[2 * cp * PLANE + toff + r * IW];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float av = cp == 0 ? a4[m].x : cp == 1 ? a4[m].y : cp == 2 ? a4[m].z : a4[m].w;
+            acc[m][r] = mfma32(av, bv, acc[m][r]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading this chunk
+    if (ch + 1 < d.NCHUNK) {
+      commit(ch + 1);
+      __syncthreads();
+    }
+  }
+
+  float* yb = y + (long long)b * d.Co * HW;
+  const int gw = w0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int gh = h0 + wave * R + r;
+    if (gh < d.H && gw < d.W) {
+      const int sp = gh * d.W + gw;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          if (o < d.Co) yb[(long long)o * HW + sp] = acc[m][r][q];
+        }
+    }
+  }
+}
+
+template <int MT, int TH, int DIL>
+int launch(const float* x, const float* wpack, float* y, C2Dims d, hipStream_t st, const char* who) {
+  d.nHt = mode::cdiv(d.H, TH);
+  d.nWt = mode::cdiv(d.W, 32);
+  d.ntiles = d.B * d.nHt * d.nWt;
+  constexpr int PLANE = ((TH + 2 * DIL) * (32 + 2 * DIL)) | 1;
+  const size_t lds = (size_t)CCH * PLANE * sizeof(float);
+  hipLaunchKernelGGL((conv2d_kernel<MT, TH, DIL>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack), y, d);
+  return mode::check_launch(who);
+}
+
+template <int DIL>
+int dispatch(const float* x, const float* wpack, float* y, const C2Dims& d, int MT, hipStream_t st, const char* who) {
+  // 8 rows per tile (two per wave) when that still gives every CU two workgroups, else 4
+  const bool big = (long long)d.B * mode::cdiv(d.H, 8) * mode::cdiv(d.W, 32) >= 2 * kNumCU;
+  switch (MT) {
+    case 1: return big ? launch<1, 8, DIL>(x, wpack, y, d, st, who) : launch<1, 4, DIL>(x, wpack, y, d, st, who);
+    case 2: return big ? launch<2, 8, DIL>(x, wpack, y, d, st, who) : launch<2, 4, DIL>(x, wpack, y, d, st, who);
+    case 3: return big ? launch<3, 8, DIL>(x, wpack, y, d, st, who) : launch<3, 4, DIL>(x, wpack, y, d, st, who);
+    default: return big ? launch<4, 8, DIL>(x, wpack, y, d, st, who) : launch<4, 4, DIL>(x, wpack, y, d, st, who);
+  }
+}
+
+// rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels
+int run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip, hipStream_t st,
+        const char* who) {
+  MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(dilation == 1 || dilation == 2, MODE_ERR_UNSUPPORTED, "%s: dilation %d not implemented (1 or 2)", who, dilation);
+  MODE_REQUIRE(rows <= 128, MODE_ERR_UNSUPPORTED, "%s: more than 128 output channels (%d) not supported", who, rows);
+  MODE_REQUIRE((long long)std::max(K, rows) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(x && w && y && wpack, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  C2Dims d;
+  d.B = B; d.Ci = K; d.Co = rows; d.H = H; d.W = W;
+  d.NCHUNK = mode::cdiv(K, CCH);
+  const int MT = mode::cdiv(rows, 32);
+  const long long npack = (long long)MT * d.NCHUNK * 9 * 256;
+  hipLaunchKernelGGL(pack_w2d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, MT, d.NCHUNK, flip);
+  return dilation == 1 ? dispatch<1>(x, wpack, y, d, MT, st, who) : dispatch<2>(x, wpack, y, d, MT, st, who);
+}
+
+}  // namespace
+
+extern "C" size_t mode_conv2d_wpack_bytes(int Ci, int Co) {
+  if (Ci <= 0 || Co <= 0) return 0;
+  const size_t f = (size_t)mode::cdiv(Co, 32) * mode::cdiv(Ci, CCH) * 9 * 256;
+  const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 9 * 256;
+  return (f > b ? f : b) * sizeof(float);
+}
+
+extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                               mode_stream_t stream) {
+  return run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd");
+}
+
+extern "C" int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co,
+                                    int dilation, mode_stream_t stream) {
+  return run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data");
+}

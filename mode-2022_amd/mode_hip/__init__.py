@@ -44,6 +44,9 @@ SIGNATURES = {
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_volume_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
+    'mode_conv2d_wpack_bytes': (_c_size, [_c_int] * 2),
+    'mode_conv2d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv2d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 5),
     'mode_conv2d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
@@ -71,7 +74,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 7  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 8  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

@@ -77,14 +77,50 @@ def conv2d_bwd_weight(gy, x, dilation=1, into=None):
   return gw
 
 
+CONV2D_OWN_MAX_PIXELS = int(os.environ.get('MODE_CONV2D_OWN_MAX_PIXELS', 256 * 128))  # own forward / input gradient up to this H*W
+
+
+def _conv2d_own(x, w):
+  """Whether forward / input gradient of this layer run on mode_conv2d_fwd / _bwd_data: at quarter resolution (and for dilated
+  layers) they beat the vendor's Winograd / implicit GEMM, at half resolution the vendor's Winograd (~190 TFLOP/s effective) wins."""
+  return x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and w.shape[0] <= 128 and w.shape[1] <= 128
+
+
+def _conv2d_run(entry, name, src, w, out_channels, dilation):
+  require_gpu(src, w)
+  require_f32c(src, w)
+  B, _, H, W = src.shape
+  Co, Ci = w.shape[:2]
+  out = torch.empty((B, out_channels, H, W), dtype=src.dtype, device=src.device)
+  flops = 2 * B * H * W * Ci * Co * 9
+  nbytes = 4 * (src.numel() + out.numel() + w.numel())
+  with torch.cuda.device_of(src), profiling.region('%s[%d->%d d%d %dx%d]' % (name, Ci, Co, dilation, H, W) if profiling.ENABLED else name,
+                                                   nbytes, flops, src.device):
+    wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=src.device)
+    check(getattr(lib(), entry)(ptr(src), ptr(w), ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)), entry)
+  return out
+
+
+def conv2d_fwd(x, w, dilation=1):
+  return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation)
+
+
+def conv2d_bwd_data(gy, w, dilation=1):
+  return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation)
+
+
 class Conv2d3x3Function(torch.autograd.Function):
-  """y = conv2d(x, w, stride 1, padding = dilation): forward and input gradient on the vendor library (fp32 Winograd), weight
-  gradient on mode_conv2d_bwd_weight (the vendor's runs as an NHWC implicit GEMM between two layout transposes)."""
+  """y = conv2d(x, w, stride 1, padding = dilation).  Weight gradient always on mode_conv2d_bwd_weight (the vendor's runs as an
+  NHWC implicit GEMM between two layout transposes); forward and input gradient on mode_conv2d_fwd / _bwd_data where they are
+  faster (_conv2d_own), else on the vendor library's fp32 Winograd."""
 
   @staticmethod
   def forward(ctx, x, w, dilation):
     ctx.save_for_backward(x, w)
     ctx.dilation = dilation
+    ctx.own = _conv2d_own(x, w)
+    if ctx.own:
+      return conv2d_fwd(x, w.contiguous(), dilation)
     return torch.nn.functional.conv2d(x, w, None, 1, dilation, dilation)
 
   @staticmethod
@@ -95,7 +131,10 @@ class Conv2d3x3Function(torch.autograd.Function):
     gy = gy.contiguous()
     gx = None
     if ctx.needs_input_grad[0]:
-      gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
+      if ctx.own:
+        gx = conv2d_bwd_data(gy, w.contiguous(), dil)
+      else:
+        gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
     gw = None
     if ctx.needs_input_grad[1]:
       sink = grad_sink(w)

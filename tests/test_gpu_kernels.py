@@ -462,8 +462,8 @@ def test_conv3d_single_output_channel(B, Ci, D, H, W):
 
 # ------------------------------------------------------------------ regular 3x3 Conv2d: weight gradient (a3)
 @pytest.mark.parametrize('B,Ci,Co,H,W,dil', [(2, 32, 32, 16, 64, 1), (1, 64, 64, 9, 40, 1), (2, 20, 40, 7, 33, 1), (1, 64, 64, 12, 32, 2),
-                                             (2, 3, 5, 5, 70, 2), (1, 128, 128, 8, 32, 1), (1, 8, 8, 2, 3, 2)])
-def test_conv2d_3x3_weight_gradient(B, Ci, Co, H, W, dil):
+                                             (2, 3, 5, 5, 70, 2), (1, 128, 128, 8, 32, 1), (1, 8, 8, 2, 3, 2), (4, 64, 64, 64, 32, 1), (1, 96, 72, 10, 64, 2)])
+def test_conv2d_3x3_kernels(B, Ci, Co, H, W, dil, monkeypatch):
   """mode_conv2d_bwd_weight against torch's fp64 conv2d autograd: ragged tiles, channel counts off the 32-wide block, dilation 2,
   images smaller than the halo; accumulate semantics; the autograd Function (vendor forward / input gradient + own weight
   gradient) end to end."""
@@ -481,12 +481,21 @@ def test_conv2d_3x3_weight_gradient(B, Ci, Co, H, W, dil):
   acc = gw.clone()
   HF.conv2d_bwd_weight(gy.to(DEV), x.to(DEV), dil, into=acc)
   assert (acc.cpu().double() - 2 * wa.grad).abs().max() < 4e-5 * scale
-  xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-  y = HF.conv2d_3x3(xd, wd, dil)
-  y.backward(gy.to(DEV))
-  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().max()))  # (vendor Winograd forward)
-  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 1e-3 * max(1.0, float(xa.grad.abs().max()))
-  assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * scale
+  # own forward / input-gradient kernels (used at quarter resolution), directly
+  if Co <= 128 and Ci <= 128:
+    y = HF.conv2d_fwd(x.to(DEV), w.to(DEV), dil)
+    assert (y.cpu().double() - y_ref.detach()).abs().max() < 2e-6 * (Ci * 9) * max(1.0, float(y_ref.abs().max()))
+    gx = HF.conv2d_bwd_data(gy.to(DEV), w.to(DEV), dil)
+    assert (gx.cpu().double() - xa.grad).abs().max() < 2e-6 * (Co * 9) * max(1.0, float(xa.grad.abs().max()))
+  # the autograd Function end to end, on both routes (own kernels / vendor forward and input gradient)
+  for own_limit in (1 << 30, 0):
+    monkeypatch.setattr(HF, 'CONV2D_OWN_MAX_PIXELS', own_limit)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = HF.conv2d_3x3(xd, wd, dil)
+    y.backward(gy.to(DEV))
+    assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().max()))  # (vendor Winograd: looser)
+    assert (xd.grad.cpu().double() - xa.grad).abs().max() < 1e-3 * max(1.0, float(xa.grad.abs().max()))
+    assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * scale
 
 
 # ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
