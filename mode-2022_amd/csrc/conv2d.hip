@@ -1,8 +1,7 @@
-// Regular 3x3 convolution (stride 1, padding = dilation in {1, 2}, no bias) of the 2-D feature extractor at quarter resolution
-// (reference: nn.Conv2d inside convbn, models/submodule.py:15-17; layer2/layer3/lastconv, 23 layers of 64 -> 64 and one of
-// 128 -> 128 at 256 x 128).  At these sizes the vendor's fp32 Winograd runs at ~83 TFLOP/s effective and its dilated layers go
-// through an NHWC implicit GEMM between layout transposes (~74 effective); at half resolution its Winograd reaches ~190 and
-// stays in use (the host picks per layer).
+// Regular 3x3 convolution (stride 1, padding = dilation in {1, 2}, no bias) of the 2-D feature extractor (reference: nn.Conv2d
+// inside convbn, models/submodule.py:15-17: firstconv[1..2], layer1-3, lastconv[1] -- 31 of its 39 Conv2d layers).  Measured at
+// the step's 4 images: 90-130 TFLOP/s here against 80-112 for the vendor library (Winograd / NHWC implicit GEMM between layout
+// transposes for the dilated layers); the host picks per layer (functional._conv2d_own).
 //
 // Same structure as conv3d.hip, one dimension down: implicit GEMM on v_mfma_f32_32x32x2_f32, D[i = o][j = 32 pixels along w];
 // haloed input tile [8 channels][TH + 2 dil][32 + 2 dil] in LDS, input channels streamed in chunks of 8 with the next chunk

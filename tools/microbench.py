@@ -39,7 +39,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--batch', type=int, default=2)
   ap.add_argument('--iters', type=int, default=10)
-  ap.add_argument('--only', default='cost,sphere,conv3d,head,vendor,stages,export,fusion')
+  ap.add_argument('--only', default='cost,sphere,conv3d,conv2d,head,vendor,stages,export,fusion')
   a = ap.parse_args()
   only = a.only.split(',')
   dev = 'cuda:0'
@@ -162,6 +162,26 @@ def main():
       report('deconv3d_fwd %d->%d @%dx%dx%d' % (ci, co, d, h, w_), timeit(lambda: HF.deconv3d_fwd(x, wt), a.iters), nb, fl)
       report('  (vendor conv_transpose3d fwd)', timeit(lambda: F.conv_transpose3d(x, wt, None, 2, 1, 1), max(2, a.iters // 3)), nb, fl)
       del x, wt, y
+
+  if 'conv2d' in only:
+    # regular 3x3 layers of the extractor at the step's 4 images (paired pass): own kernels vs the vendor library
+    B4 = 2 * B
+    for (ci, co, h, w_, dil) in ((64, 64, 256, 128, 1), (64, 64, 256, 128, 2), (128, 128, 256, 128, 1), (64, 64, 512, 256, 1), (32, 32, 512, 256, 1)):
+      x = torch.randn(B4, ci, h, w_, device=dev)
+      wt = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+      gy = torch.randn(B4, co, h, w_, device=dev)
+      fl = 2 * gy.numel() * ci * 9
+      nb = 4 * (x.numel() + gy.numel())
+      tag = '%d->%d d%d @%dx%d B=%d' % (ci, co, dil, h, w_, B4)
+      report('conv2d_fwd ' + tag, timeit(lambda: HF.conv2d_fwd(x, wt, dil), a.iters), nb, fl)
+      report('  (vendor conv2d fwd)', timeit(lambda: F.conv2d(x, wt, None, 1, dil, dil), a.iters), nb, fl)
+      report('conv2d_bwd_data ' + tag, timeit(lambda: HF.conv2d_bwd_data(gy, wt, dil), a.iters), nb, fl)
+      report('  (vendor conv2d input gradient)', timeit(lambda: torch.ops.aten.convolution_backward(
+          gy, x, wt, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False]), a.iters), nb, fl)
+      report('conv2d_bwd_weight ' + tag, timeit(lambda: HF.conv2d_bwd_weight(gy, x, dil), a.iters), nb, fl)
+      report('  (vendor conv2d weight gradient)', timeit(lambda: torch.ops.aten.convolution_backward(
+          gy, x, wt, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [False, True, False]), a.iters), nb, fl)
+      del x, wt, gy
 
   if 'head' in only:
     lg = torch.randn(B, 1, 48, 256, 128, device=dev)
