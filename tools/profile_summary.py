@@ -18,8 +18,8 @@ def grp(n):
     return 'sphere'
   if 'cost_conv' in n:
     return 'cost_conv assembly'
-  if 'conv2d_bwd_weight' in n or 'reduce_gw2d' in n:
-    return 'conv2d weight gradient (own)'
+  if 'conv2d_' in n or 'reduce_gw2d' in n or 'pack_w2d' in n:
+    return 'conv2d (own)'
   if 'conv3d' in n or 'deconv3d' in n or 'reduce_gw3d' in n or 'pack_w3d' in n:
     return 'conv3d'
   if 'bn_' in n[:60]:
