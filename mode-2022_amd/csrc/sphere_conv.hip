@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
     for (int e = 0; e < EC; ++e) {
       // always a valid element of this row's list (or element 0): the load stays unconditional, the selects come after
       const int2 ent = entries[beg + min(e, max(cnt - 1, 0))];
-      pe[e] = e < cnt ? ent.x : 0;
+      pe[e] = e < cnt ? ent.x * 4 : 0;  // byte offset within a channel plane (32-bit: the gathers use a scalar base)
       we[e] = e < cnt ? __int_as_float(ent.y) : 0.f;
     }
     ent_p[item] = make_int4(pe[0], pe[1], pe[2], pe[3]);
@@ -466,9 +466,13 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
   __syncthreads();
 
   const int p = tid & (P - 1);
-  const int qd = tid / P;  // output channels 2qd, 2qd+1 of the chunk
+  static_assert(P == 64, "one wave per output-channel pair of the chunk");
+  const int qd = __builtin_amdgcn_readfirstlane(tid / P);  // output channels 2qd, 2qd+1 of the chunk (wave-uniform -> scalar bases)
   const float* gyg = gy + ((long long)b * d.Co + (long long)g * d.Cog) * d.npix;
   float lv[KT * 2 * EC];
+  bool has_tail = false;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) has_tail |= span[k * P + p].y > EC;
 
   auto issue = [&](int ch) {
     const int o0 = ch * CCH + qd * 2;
@@ -477,8 +481,12 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const int4 pe = ent_p[k * P + p];
-      lv[k * 8 + 0] = g0[pe.x]; lv[k * 8 + 1] = g0[pe.y]; lv[k * 8 + 2] = g0[pe.z]; lv[k * 8 + 3] = g0[pe.w];
-      lv[k * 8 + 4] = g1[pe.x]; lv[k * 8 + 5] = g1[pe.y]; lv[k * 8 + 6] = g1[pe.z]; lv[k * 8 + 7] = g1[pe.w];
+      const char* c0 = reinterpret_cast<const char*>(g0);
+      const char* c1 = reinterpret_cast<const char*>(g1);
+#define MODE_LD(base, off) (*reinterpret_cast<const float*>((base) + (unsigned)(off)))
+      lv[k * 8 + 0] = MODE_LD(c0, pe.x); lv[k * 8 + 1] = MODE_LD(c0, pe.y); lv[k * 8 + 2] = MODE_LD(c0, pe.z); lv[k * 8 + 3] = MODE_LD(c0, pe.w);
+      lv[k * 8 + 4] = MODE_LD(c1, pe.x); lv[k * 8 + 5] = MODE_LD(c1, pe.y); lv[k * 8 + 6] = MODE_LD(c1, pe.z); lv[k * 8 + 7] = MODE_LD(c1, pe.w);
+#undef MODE_LD
     }
   };
   auto finish = [&](int ch, float* buf) {
@@ -486,20 +494,29 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
     const bool ok0 = o0 < d.Cog, ok1 = o0 + 1 < d.Cog;
     const float* g0 = gyg + (long long)(ok0 ? o0 : 0) * d.npix;
     const float* g1 = gyg + (long long)(ok1 ? o0 + 1 : 0) * d.npix;
+    float v0[KT], v1[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const float4 we = ent_w[k * P + p];
-      float v0 = we.x * lv[k * 8 + 0] + we.y * lv[k * 8 + 1] + we.z * lv[k * 8 + 2] + we.w * lv[k * 8 + 3];
-      float v1 = we.x * lv[k * 8 + 4] + we.y * lv[k * 8 + 5] + we.z * lv[k * 8 + 6] + we.w * lv[k * 8 + 7];
-      const int2 s = span[k * P + p];
-      for (int e = EC; e < s.y; ++e) {  // long lists (near the poles)
-        const int2 ent = entries[s.x + e];
-        const float wt = __int_as_float(ent.y);
-        v0 += wt * g0[ent.x];
-        v1 += wt * g1[ent.x];
+      v0[k] = we.x * lv[k * 8 + 0] + we.y * lv[k * 8 + 1] + we.z * lv[k * 8 + 2] + we.w * lv[k * 8 + 3];
+      v1[k] = we.x * lv[k * 8 + 4] + we.y * lv[k * 8 + 5] + we.z * lv[k * 8 + 6] + we.w * lv[k * 8 + 7];
+    }
+    if (has_tail) {  // this pixel has a list longer than EC entries for some tap (near the poles): one branch per chunk
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int2 s = span[k * P + p];
+        for (int e = EC; e < s.y; ++e) {
+          const int2 ent = entries[s.x + e];
+          const float wt = __int_as_float(ent.y);
+          v0[k] += wt * g0[ent.x];
+          v1[k] += wt * g1[ent.x];
+        }
       }
-      buf[((qd * 2) * KT + k) * P + p] = ok0 ? v0 : 0.f;
-      buf[((qd * 2 + 1) * KT + k) * P + p] = ok1 ? v1 : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      buf[((qd * 2) * KT + k) * P + p] = ok0 ? v0[k] : 0.f;
+      buf[((qd * 2 + 1) * KT + k) * P + p] = ok1 ? v1[k] : 0.f;
     }
   };
 

@@ -14,7 +14,7 @@ for PASS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $PASS | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --pmc $PASS --output-format csv -d $OUT/$N -o pmc -- python3 $R/tools/microbench.py --only $ONLY --iters 2 > $OUT/$N.log 2>&1
+  timeout 600 rocprofv3 --pmc $PASS --output-format csv -d $OUT/$N -o pmc -- python3 $R/tools/microbench.py --only $ONLY --iters 2 $MB_EXTRA > $OUT/$N.log 2>&1
   echo "pass $N rc=$?"
 done
 cd $R
