@@ -18,7 +18,7 @@ from mode_hip import functional as HF
 
 BACKEND = os.environ.get('MODE_STAGE3D', 'hip')
 BN_BACKEND = os.environ.get('MODE_BN', 'hip')  # 'hip' = fused BatchNorm+add+ReLU kernels (mode_bn_*), 'vendor' = torch ops
-CONV2D_WGRAD = os.environ.get('MODE_CONV2D_WGRAD', '1') == '1'  # own weight-gradient kernel for the regular 3x3 Conv2d layers
+CONV2D_WGRAD = os.environ.get('MODE_CONV2D_WGRAD', '1') == '1'  # own kernels for the regular stride-1 3x3 Conv2d layers
 HEAD_BACKEND = os.environ.get('MODE_HEAD', 'hip')  # 'hip' = fused kernel (mode_head_fwd/bwd), 'vendor' = torch ops
 
 
@@ -50,9 +50,12 @@ def conv3(conv, x):
     return HF.deconv3d(x, conv.weight)
   if CONV2D_WGRAD and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and \
       conv.bias is None and conv.padding == conv.dilation and conv.dilation in ((1, 1), (2, 2)) and conv.padding_mode == 'zeros' and \
-      x.dtype == torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad:
-    # regular 3x3 layer of the 2-D extractor: vendor forward / input gradient, own weight gradient
-    return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
+      x.dtype == torch.float32:
+    # regular stride-1 3x3 layer of the 2-D extractor: own kernels (csrc/conv2d.hip, conv2d_wgrad.hip)
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
+      return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
+    if HF._conv2d_own(x, conv.weight):
+      return HF.conv2d_fwd(x.contiguous(), conv.weight.detach().contiguous(), conv.dilation[0])
   return conv(x)
 
 
