@@ -137,6 +137,29 @@ def test_cost_conv_assembly_is_exact_on_integers():
   assert torch.equal(Rd.grad.cpu(), gR) and torch.equal(Td.grad.cpu(), gT)
 
 
+def test_cost_conv_full_size_equals_the_two_kernel_path():
+  """BASELINE configs 2-4 (C = 32, D4 = 48, 256 x 128): the folded layer against cost_volume + conv3d 64 -> 32 on the GPU (both
+  hand-written paths, each pinned to the fp64 oracle at small sizes above), forward and all three gradients."""
+  B, C, Co, D4, H, W = 1, 32, 32, 48, 256, 128
+  ref, tgt = _rand((B, C, H, W), 35).to(DEV), _rand((B, C, H, W), 36).to(DEV)
+  w = _rand((Co, 2 * C, 3, 3, 3), 37, 0.05).to(DEV)
+  gy = _rand((B, Co, D4, H, W), 38).to(DEV)
+  out = {}
+  for name in ('folded', 'two-kernel'):
+    r, t, ww = ref.clone().requires_grad_(True), tgt.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = HF.cost_conv(r, t, ww, D4) if name == 'folded' else HF.conv3d(HF.cost_volume(r, t, D4), ww, 1)
+    y.backward(gy)
+    out[name] = (y.detach(), r.grad, t.grad, ww.grad)
+  for a, b_ in zip(out['folded'], out['two-kernel']):
+    assert (a - b_).abs().max() <= 2e-5 * max(1.0, float(b_.abs().max()))
+  # the zero triangle of the volume: columns w < d see no target feature, so d(out)/d(tgt) vanishes there by construction --
+  # perturbing tgt at column W-1 must not change out[..., d, :, w] for w < W-1-... (locality check on one element)
+  t2 = tgt.clone()
+  t2[:, :, :, W - 1] += 1.0
+  y2 = HF.cost_conv(ref, t2, w, D4)
+  assert torch.equal(y2[..., : W - 2], out['folded'][0][..., : W - 2])  # tgt[W-1] reaches w' = W-1+d' >= W-1 only: outputs w >= W-2
+
+
 # ------------------------------------------------------------------ sphere conv (a7/a8)
 def _sphere_case(typ, ih, iw, B, ci, co, stride, groups, seed):
   pos = mode_ref.sphere_position(ih, iw, typ)
@@ -496,6 +519,26 @@ def test_conv2d_3x3_kernels(B, Ci, Co, H, W, dil, monkeypatch):
     assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().max()))  # (vendor Winograd: looser)
     assert (xd.grad.cpu().double() - xa.grad).abs().max() < 1e-3 * max(1.0, float(xa.grad.abs().max()))
     assert (wd.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * scale
+
+
+def test_conv2d_3x3_full_size_against_the_vendor_library():
+  """The extractor's largest regular layer (64 -> 64 at 512 x 256, 4 images) and its dilated quarter-resolution layer: own
+  forward / input gradient / weight gradient against the vendor library on the GPU (fp32 both sides; the vendor's Winograd
+  has the larger round-off, hence 1e-3)."""
+  import torch.nn.functional as F
+  for (ci, co, H, W, dil) in ((64, 64, 512, 256, 1), (64, 64, 256, 128, 2)):
+    x, w = _rand((4, ci, H, W), 71).to(DEV), _rand((co, ci, 3, 3), 72, 0.05).to(DEV)
+    gy = _rand((4, co, H, W), 73).to(DEV)
+    y = HF.conv2d_fwd(x, w, dil)
+    y_v = F.conv2d(x, w, None, 1, dil, dil)
+    assert (y - y_v).abs().max() <= 1e-3 * max(1.0, float(y_v.abs().max()))
+    gx_v, gw_v = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, True, False])[:2]
+    gx = HF.conv2d_bwd_data(gy, w, dil)
+    assert (gx - gx_v).abs().max() <= 1e-3 * max(1.0, float(gx_v.abs().max()))
+    gw = HF.conv2d_bwd_weight(gy, x, dil)
+    assert (gw - gw_v).abs().max() <= 1e-3 * max(1.0, float(gw_v.abs().max()))
+    # linearity in the input (exact for a power of two)
+    assert torch.equal(HF.conv2d_fwd(2 * x, w, dil), 2 * y)
 
 
 # ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
