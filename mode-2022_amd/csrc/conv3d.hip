@@ -839,11 +839,12 @@ __global__ __launch_bounds__(NT * OB, 2) void conv3d_bwd_weight_s2_kernel(const 
     }
   };
 
+  const int s_x = xcd_remap(s, d.S);  // XCD-aware tile order (neighbouring tiles share halos in one L2), see the ring kernel
   unsigned mask = 0;
-  if (s < d.T) mask = prefetch(s);
+  if (s_x < d.T) mask = prefetch(s_x);
   const float* ap = gl + (oh * 32 + (lane & 31)) * GPLANE + (lane >> 5);
   const float* bp = xl + (lane & 31) * XPLANE + (lane >> 5) * 2;
-  for (int tt = s; tt < d.T; tt += d.S) {
+  for (int tt = s_x; tt < d.T; tt += d.S) {
     store(mask);
     __syncthreads();
     if (tt + d.S < d.T) mask = prefetch(tt + d.S);
@@ -920,7 +921,10 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_ring_kernel(const float*
 #pragma unroll
   for (int j = 0; j < 8; ++j) gchan_ok |= (ob * 32 + 4 * j + (hwv >> 1) < d.Co ? 1u : 0u) << j;
 
-  for (int u = s; u < units; u += d.S) {
+  // XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so give every XCD a contiguous range of units --
+  // neighbouring tiles share halo rows, and they only meet in an L2 if they run on the same XCD (PMC: 1.20 GB fetched per launch
+  // with the plain mapping, for 0.81 GB of operands)
+  for (int u = xcd_remap(s, d.S); u < units; u += d.S) {
     int t = u;
     const int dc = t % nDc;
     t /= nDc;
