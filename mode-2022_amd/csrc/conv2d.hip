@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x,
   constexpr int NHALO = CCH * IH * 2 * DIL, NPH = (NHALO + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [CCH][PLANE]
 
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, d.ntiles);  // neighbouring tiles (shared halos) on one XCD
   const int wt = t % d.nWt;
   t /= d.nWt;
   const int ht = t % d.nHt;

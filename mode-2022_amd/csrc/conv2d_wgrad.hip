@@ -137,8 +137,7 @@ __global__ __launch_bounds__(NT, 2) void conv2d_bwd_weight_kernel(const float* _
 
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; a contiguous range of tiles per XCD lets
   // neighbouring tiles find their shared halo rows in that XCD's L2
-  const int nx = kNumXCD, qx = d.S / nx, rx = d.S % nx, xcd = s % nx, kx = s / nx;
-  const int s_x = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + kx;
+  const int s_x = xcd_remap(s, d.S);
   int h0 = 0, w0 = 0, nh0 = 0, nw0 = 0;
   if (s_x < d.T) prefetch(s_x, nh0, nw0);
   const float* ap = gl + (lane & 31) * GPLANE + wave * 32 + (lane >> 5);

@@ -61,14 +61,6 @@ __global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, in
   }
 }
 
-// XCD-aware bijective remap: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
-// range of tiles so that neighbouring tiles (shared halos) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-  const int q = n / kNumXCD, r = n % kNumXCD;
-  const int xcd = bid % kNumXCD, k = bid / kNumXCD;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 // Stride 2 (S = 2): the 65 input columns of a row are stored de-interleaved, [33 odd-phase | 32 even-phase], so that the
 // 32 lanes of a fragment still read consecutive LDS words: tap kw = 0 -> O[j], kw = 1 -> E[j], kw = 2 -> O[j+1].
 template <int S>

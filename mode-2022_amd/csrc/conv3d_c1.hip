@@ -25,7 +25,7 @@ __global__ __launch_bounds__(NT) void conv3d_co1_fwd_kernel(const float* __restr
                                                             int nHt, int nWt) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [FCC][FID][FIH][FIW]
   int* rowtab = reinterpret_cast<int*>(tile + FCC * FPLANE);
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halos) on one XCD
   const int wt = t % nWt;
   t /= nWt;
   const int ht = t % nHt;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_co1_fwd_mfma_kernel(const float*
                                                                  float* __restrict__ y, int B, int Ci, int D, int H, int W, int nDc,
                                                                  int nHt, int nWt) {
   extern __shared__ __attribute__((aligned(16))) float zl[];  // [27][ZIH][ZIW]
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halos) on one XCD
   const int wt = t % nWt;
   t /= nWt;
   const int ht = t % nHt;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NT) void conv3d_co1_bwd_data_kernel(const float* __
                                                                  float* __restrict__ gx, int B, int Ci, int D, int H, int W, int nDt,
                                                                  int nHt, int nWt) {
   __shared__ float tile[BID * BIH * BIW];
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halos) on one XCD
   const int wt = t % nWt;
   t /= nWt;
   const int ht = t % nHt;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
   float* colbuf = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 20);
   const int rows = CCH * d.KK;  // column-tile rows per chunk
 
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring pixel tiles (overlapping gather footprints) on one XCD
   const int b = tile / d.tps;
   const int pix0 = (tile - b * d.tps) * P;
   const int g = blockIdx.z;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj_kernel(const flo
   const int rows = CCH * d.KK;
   const int HWin = d.H * d.W;
 
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring pixel tiles (overlapping gather footprints) on one XCD
   const int b = tile / qtiles;
   const int q0 = (tile - b * qtiles) * P;
   const int g = blockIdx.z;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
   constexpr int rows = CCH * KT;
   const int HWin = d.H * d.W;
 
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring pixel tiles (overlapping gather footprints) on one XCD
   const int b = tile / qtiles;
   const int q0 = (tile - b * qtiles) * P;
   const int g = blockIdx.z;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_kernel(const float* 
   unsigned* tap_off = reinterpret_cast<unsigned*>(smem + (size_t)d.KK * P * 16);
   float* gyl = reinterpret_cast<float*>(smem + (size_t)d.KK * P * 20);  // [KSQ*8][P]
 
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring pixel tiles (overlapping gather footprints) on one XCD
   const int b = tile / d.tps;
   const int pix0 = (tile - b * d.tps) * P;
   const int g = blockIdx.z;

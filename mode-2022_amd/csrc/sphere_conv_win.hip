@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_kernel(const float* _
                                                                    const float4* __restrict__ wp, float* __restrict__ y, WinDims d,
                                                                    const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int4 t = tiles[blockIdx.x];
+  const int4 t = tiles[blockIdx.x];  // (list order = tall-window tiles first; an XCD-contiguous order would pile them on one XCD)
   const int cls = t.w >> 16, cbase = t.w & 0xffff;
   if (cls == 0)
     fwd_tile<WR_SMALL, true, (WR_SMALL + SROWS - 1) / SROWS, 1>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_tall_kernel(const flo
                                                                         const float4* __restrict__ wp, float* __restrict__ y,
                                                                         WinDims d, const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int4 t = tiles[blockIdx.x];
+  const int4 t = tiles[blockIdx.x];  // (list order = tall-window tiles first; an XCD-contiguous order would pile them on one XCD)
   fwd_tile<0, false, 1, 1>(x, pos, wp, y, d, t.x, t.y, t.z, t.w & 0xffff, smem);
 }
 
