@@ -77,13 +77,14 @@ def conv2d_bwd_weight(gy, x, dilation=1, into=None):
   return gw
 
 
-CONV2D_OWN_MAX_PIXELS = int(os.environ.get('MODE_CONV2D_OWN_MAX_PIXELS', 512 * 256))  # own forward / input gradient up to this H*W
+CONV2D_OWN_MAX_PIXELS = int(os.environ.get('MODE_CONV2D_OWN_MAX_PIXELS', 1024 * 512))  # own forward / input gradient up to this H*W
 
 
 def _conv2d_own(x, w):
   """Whether forward / input gradient of this layer run on mode_conv2d_fwd / _bwd_data.  Measured at the step's 4 images
   (tools/microbench.py --only conv2d): 90-130 TFLOP/s against the vendor's 80-112 at every shape of the extractor, half
-  resolution included; larger images than the benchmark's stay on the vendor library (untested territory for the tile choice)."""
+  resolution included, and the fusion network's full-resolution layers (1024 x 512: 32.2 -> 31.9 ms per training step); larger
+  images stay on the vendor library (untested territory for the tile choice)."""
   return x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and w.shape[0] <= 128 and w.shape[1] <= 128
 
 
