@@ -38,7 +38,8 @@ def _run(module, x):
     m = items[i]
     if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d):
       relu = i + 1 < len(items) and isinstance(items[i + 1], nn.ReLU)  # convbn (+ ReLU)
-      x = stage3d.bn_act(m[1], stage3d.conv3(m[0], x), None, relu)  # (stride-1 3x3 layers: own conv2d kernels, csrc/conv2d*.hip)
+      # (stride-1 3x3 layers: own conv2d kernels, csrc/conv2d*.hip; host tensors keep torch's convolution for the wiring tests)
+      x = stage3d.bn_act(m[1], stage3d.conv3(m[0], x) if x.is_cuda else m[0](x), None, relu)
       i += 2 if relu else 1
     elif isinstance(m, nn.BatchNorm2d):
       relu = i + 1 < len(items) and isinstance(items[i + 1], nn.ReLU)  # ConvTranspose2d -> BatchNorm2d -> ReLU
