@@ -317,6 +317,40 @@ def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch
     assert (a[3][k] - b[3][k]).abs().max() <= 1e-5 * max(1.0, float(b[3][k].abs().max())), k
 
 
+def test_fast_paths_together_match_the_plain_composition(monkeypatch):
+  """Every restructuring of the default path switched off at once -- two extractor passes, NCHW spherical operator, cost volume +
+  conv3d 64 -> 32, vendor forward / gradients for the regular convolutions -- against the default path, at BASELINE config 1
+  size (512 x 256, 64 disparities), batch 2: predictions, loss, gradients, BatchNorm state."""
+  import models.mode_disparity as md
+  import models.stage3d as st
+  import models.submodule as sm
+  res = {}
+  for fast in (True, False):
+    monkeypatch.setattr(md, 'PAIR_EXTRACTOR', fast)
+    monkeypatch.setattr(md, 'FUSED_COST_CONV', fast)
+    monkeypatch.setattr(sm, 'SPHERE_CHAIN', fast)
+    monkeypatch.setattr(st, 'CONV2D_WGRAD', fast)
+    torch.manual_seed(21)
+    net = models.ModeDisparity(64, 'Sphere', 512, 256, 'Cassini').to(DEV).train()
+    left = torch.randn(2, 3, 512, 256, device=DEV)
+    right = torch.roll(left, -3, 3) + 0.01 * torch.randn_like(left)
+    gt = torch.rand(2, 1, 512, 256, device=DEV) * 30
+    preds = net(left, right)
+    loss = sum(w * torch.nn.functional.smooth_l1_loss(o, gt) for w, o in zip((0.5, 0.7, 1.0), preds))
+    loss.backward()
+    res[fast] = (preds[2].detach(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters()},
+                 {k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+  a, b = res[True], res[False]
+  # same network, different association of the same fp32 sums (and the vendor's Winograd in the plain variant): round-off,
+  # amplified by ~80 random train-mode layers; a wrong fast path is an O(1) difference
+  assert (a[0] - b[0]).abs().mean() < 5e-3 and (a[0] - b[0]).abs().max() < 0.5
+  assert abs(a[1] - b[1]) < 1e-3 * abs(b[1])
+  bad = [k for k in a[2] if float((a[2][k] - b[2][k]).norm()) > 0.25 * float(b[2][k].norm()) + 1e-5]
+  assert not bad, bad[:5]
+  for k in a[3]:
+    assert (a[3][k] - b[3][k]).abs().max() <= 1e-3 * max(1.0, float(b[3][k].abs().max())), k
+
+
 def test_paired_extractor_pass_equals_two_passes(monkeypatch):
   """ModeDisparity runs the shared extractor once over [left; right] with per-image-set BatchNorm statistics
   (stage3d.bn_groups): same outputs, gradients and BatchNorm state as the reference's two passes."""
