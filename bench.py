@@ -266,6 +266,11 @@ def main():
       fence()
       del fr, ft
   kern = profiling.summary()
+  if args.mode == 'train':
+    # sanity of the steps just timed: every parameter still finite after the optimizer updates (one reduction, after the timing)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    if not bool(torch.isfinite(flat).all()):
+      raise RuntimeError('bench.py: non-finite parameters after %d training steps' % (args.warmup + args.steps))
   profiling.enable(False)
   if world > 1:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
