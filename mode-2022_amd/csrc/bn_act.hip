@@ -10,6 +10,7 @@
 //   train bwd  : reduce pass (reads gout, y [, out]) + apply pass (reads gout, y [, out], writes gy [, gadd])
 // Statistics are reduced per thread / per block in fp32 over short runs and combined across blocks in fp64.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,16 +49,27 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
   const long long S4 = S >> 2;
-  const long long per_b = (S4 + nsplit - 1) / nsplit;
-  const long long lo = split * per_b, hi = min(S4, lo + per_b);
   float s0 = 0.f, s1 = 0.f;
   for (int b = b0; b < b0 + Bg; ++b) {
     const float4* p = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * S);
-    for (long long i = lo + threadIdx.x; i < hi; i += NT) {
-      const float4 v = p[i];
+    // four independent loads per iteration (see bn_apply_kernel); the sums are taken in the same order as element by element
+    auto acc1 = [&](const float4& v) {
       s0 += (v.x + v.y) + (v.z + v.w);
       s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    };
+    // block `split` takes the 4 KB pieces split, split + nsplit, ... of the row (not one contiguous slice): concurrently running
+    // blocks then read neighbouring addresses instead of addresses a multiple of 96 KB apart (same access pattern as the apply
+    // kernels; measured neutral on the 403 MB tensors)
+    const long long st = (long long)nsplit * NT;
+    long long i = (long long)split * NT + threadIdx.x;
+    for (; i + 3 * st < S4; i += 4 * st) {
+      const float4 v0 = p[i], v1 = p[i + st], v2 = p[i + 2 * st], v3 = p[i + 3 * st];
+      acc1(v0);
+      acc1(v1);
+      acc1(v2);
+      acc1(v3);
     }
+    for (; i < S4; i += st) acc1(p[i]);
     if (split == 0) {  // ragged tail (S % 4)
       const float* q = y + ((long long)b * C + c) * S;
       for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
@@ -180,21 +192,35 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   const float4* yp = reinterpret_cast<const float4*>(y + base);
   const float4* ap = reinterpret_cast<const float4*>(add + base);
   float4* op = reinterpret_cast<float4*>(out + base);
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
-    float4 v = yp[i];
+  // four independent 16-byte loads per thread and iteration: the compiler emits the plain loop as load -> wait -> store, i.e.
+  // ONE load in flight per thread (32 KB per CU at full occupancy: Little's law caps that at ~5.3 TB/s on this chip)
+  auto one = [&](float4 v, const float4& a) {
     v.x = __builtin_fmaf(v.x, sc, sh);  // one rounding: the backward pass repeats exactly this to rebuild the ReLU mask
     v.y = __builtin_fmaf(v.y, sc, sh);
     v.z = __builtin_fmaf(v.z, sc, sh);
     v.w = __builtin_fmaf(v.w, sc, sh);
     if (ADD) {
-      const float4 a = ap[i];
       v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
     if (RELU) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    op[i] = v;
+    return v;
+  };
+  const long long st = (long long)gridDim.x * NT;
+  long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  for (; i + 3 * st < S4; i += 4 * st) {
+    const float4 v0 = yp[i], v1 = yp[i + st], v2 = yp[i + 2 * st], v3 = yp[i + 3 * st];
+    float4 a0 = v0, a1 = v1, a2 = v2, a3 = v3;
+    if (ADD) {
+      a0 = ap[i]; a1 = ap[i + st]; a2 = ap[i + 2 * st]; a3 = ap[i + 3 * st];
+    }
+    op[i] = one(v0, a0);
+    op[i + st] = one(v1, a1);
+    op[i + 2 * st] = one(v2, a2);
+    op[i + 3 * st] = one(v3, a3);
   }
+  for (; i < S4; i += st) op[i] = one(yp[i], ADD ? ap[i] : yp[i]);
   if (blockIdx.x == 0)
     for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
       float v = __builtin_fmaf(y[base + i], sc, sh);
@@ -218,19 +244,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
   const long long prow = (long long)blockIdx.z * C + c;
   const float msc = RELU == 2 ? mscale[prow] : 0.f, msh = RELU == 2 ? mshift[prow] : 0.f;
   const long long S4 = S >> 2;
-  const long long per_b = (S4 + nsplit - 1) / nsplit;
-  const long long lo = split * per_b, hi = min(S4, lo + per_b);
   float s0 = 0.f, s1 = 0.f;
   for (int b = b0; b < b0 + Bg; ++b) {
     const long long base = ((long long)b * C + c) * S;
     const float4* gp = reinterpret_cast<const float4*>(gout + base);
     const float4* yp = reinterpret_cast<const float4*>(y + base);
     const float4* op = reinterpret_cast<const float4*>(out + base);
-    for (long long i = lo + threadIdx.x; i < hi; i += NT) {
-      float4 g = gp[i];
-      const float4 v = yp[i];
+    // (four independent loads of every operand per iteration; sums in element order)
+    auto acc1 = [&](float4 g, const float4& v, const float4& o) {
       if (RELU == 1) {
-        const float4 o = op[i];
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       } else if (RELU == 2) {
         g.x = __builtin_fmaf(v.x, msc, msh) > 0.f ? g.x : 0.f;
@@ -240,7 +262,22 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
       }
       s0 += (g.x + g.y) + (g.z + g.w);
       s1 += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+    };
+    const long long st = (long long)nsplit * NT;  // interleaved 4 KB pieces per block, see bn_stats_kernel
+    long long i = (long long)split * NT + threadIdx.x;
+    for (; i + 3 * st < S4; i += 4 * st) {
+      const float4 g0 = gp[i], g1 = gp[i + st], g2 = gp[i + 2 * st], g3 = gp[i + 3 * st];
+      const float4 v0 = yp[i], v1 = yp[i + st], v2 = yp[i + 2 * st], v3 = yp[i + 3 * st];
+      float4 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
+      if (RELU == 1) {
+        o0 = op[i]; o1 = op[i + st]; o2 = op[i + 2 * st]; o3 = op[i + 3 * st];
+      }
+      acc1(g0, v0, o0);
+      acc1(g1, v1, o1);
+      acc1(g2, v2, o2);
+      acc1(g3, v3, o3);
     }
+    for (; i < S4; i += st) acc1(gp[i], yp[i], RELU == 1 ? op[i] : yp[i]);
     if (split == 0)
       for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
         float g = gout[base + i];
@@ -317,11 +354,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
   const float4* op = reinterpret_cast<const float4*>(out + base);
   float4* gyp = reinterpret_cast<float4*>(gy + base);
   float4* gap = reinterpret_cast<float4*>(gadd + base);
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < S4; i += (long long)gridDim.x * NT) {
-    float4 g = gp[i];
-    const float4 v = yp[i];
+  // (four independent loads of every operand per thread and iteration, see bn_apply_kernel)
+  auto one = [&](long long i, float4 g, const float4& v, const float4& o) {
     if (RELU == 1) {
-      const float4 o = op[i];
       g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
     } else if (RELU == 2) {
       g.x = __builtin_fmaf(v.x, msc, msh) > 0.f ? g.x : 0.f;
@@ -336,7 +371,22 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     r.z = A * g.z + Bc * v.z + Cc;
     r.w = A * g.w + Bc * v.w + Cc;
     gyp[i] = r;
+  };
+  const long long st = (long long)gridDim.x * NT;
+  long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  for (; i + 3 * st < S4; i += 4 * st) {
+    const float4 g0 = gp[i], g1 = gp[i + st], g2 = gp[i + 2 * st], g3 = gp[i + 3 * st];
+    const float4 v0 = yp[i], v1 = yp[i + st], v2 = yp[i + 2 * st], v3 = yp[i + 3 * st];
+    float4 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
+    if (RELU == 1) {
+      o0 = op[i]; o1 = op[i + st]; o2 = op[i + 2 * st]; o3 = op[i + 3 * st];
+    }
+    one(i, g0, v0, o0);
+    one(i + st, g1, v1, o1);
+    one(i + 2 * st, g2, v2, o2);
+    one(i + 3 * st, g3, v3, o3);
   }
+  for (; i < S4; i += st) one(i, gp[i], yp[i], RELU == 1 ? op[i] : yp[i]);
   if (blockIdx.x == 0)
     for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
       float g = gout[base + i];
@@ -348,8 +398,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
 }
 
 int pick_nsplit(int C, long long S) {
-  // ~8 blocks per CU in total, each with at least 4096 elements per image
-  long long n = (8LL * kNumCU + C - 1) / C;
+  // ~16 blocks per CU in total (measured on the 403 MB tensors: 4 -> 101 us, 8 -> 93, 16 -> 89, 32 -> 88 for this read-only pass,
+  // i.e. ~4.6 TB/s: a pure read stream tops out below the ~6.2 TB/s a copy reaches), each with at least 4096 elements per image
+  long long n = (16LL * kNumCU + C - 1) / C;
   const long long maxn = std::max<long long>(1, (S / 4) / 1024);
   if (n > maxn) n = maxn;
   if (n < 1) n = 1;
