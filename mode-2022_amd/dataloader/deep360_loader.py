@@ -1,6 +1,10 @@
-"""Deep360 datasets (reference dataloader/deep360_loader.py:60-167): same class names, constructor arguments and item
-formats.  PIL + numpy instead of cv2 / torchvision; **parity unpinned** (the reference file cannot be imported here: cv2 and
-torchvision are absent), the tests check the documented behaviour on a synthetic tree."""
+"""Deep360 datasets for the two stages (public surface of the reference's dataloader/deep360_loader.py:60-167: the class names,
+constructor arguments and item formats the training / test scripts rely on).
+
+Written against PIL + numpy (the reference needs cv2 and torchvision, neither present here), which also makes it **parity
+unpinned**: the reference module cannot be imported in this environment, so tests/test_dataloader.py checks the documented
+behaviour on a synthetic tree instead.
+"""
 import random
 
 import numpy as np
@@ -10,99 +14,116 @@ from torch.utils.data import Dataset
 
 from . import preprocess
 
+CROP_H, CROP_W = 512, 256  # training crop of the disparity stage (deep360_loader.py:103)
+
+
+# ---- file readers (same names as the reference's module-level loaders) -------------------------------------------------
+def _npz_float32(path):
+  with np.load(path) as z:
+    return z['arr_0'].astype(np.float32)
+
 
 def default_loader(path):
-  return Image.open(path).convert('RGB')
+  """RGB panorama as a PIL image."""
+  with Image.open(path) as im:
+    return im.convert('RGB')
 
 
 def disparity_loader(path):
-  return np.load(path)['arr_0'].astype(np.float32)
+  """(H, W) float32 disparity map stored as arr_0 of an .npz."""
+  return _npz_float32(path)
 
 
 def depth_loader(path):
-  return np.expand_dims(np.load(path)['arr_0'].astype(np.float32), axis=-1)
+  """(H, W, 1) float32 depth map."""
+  return _npz_float32(path)[..., None]
 
 
 def conf_loader(path):
-  """(1, H, W) float32 in [0, 1] from the first stored channel of an 8-bit image (deep360_loader.py:27-29 reads it with
-  cv2.imread, whose channel 0 is BLUE; the exported confidence maps are grey, all channels equal)."""
-  img = np.asarray(Image.open(path).convert('RGB'))
-  return np.expand_dims((img[:, :, 2] / 255.0).astype(np.float32), axis=0)
+  """(1, H, W) float32 confidence in [0, 1] from an 8-bit image.  The reference takes channel 0 of cv2.imread (blue); the
+  exported confidence maps are grey, so any channel carries the same value -- the blue one is used here as well."""
+  blue = np.asarray(default_loader(path))[:, :, 2]
+  return (blue / 255.0).astype(np.float32)[None]
 
 
 def resize_nearest(a, width, height):
-  """cv2.resize(a, (width, height), interpolation=cv2.INTER_NEAREST): source index = floor(dst * src / dst_size), clamped."""
-  h, w = a.shape[:2]
-  ys = np.minimum((np.arange(height) * (h / height)).astype(np.int64), h - 1)
-  xs = np.minimum((np.arange(width) * (w / width)).astype(np.int64), w - 1)
-  return a[ys][:, xs]
+  """What cv2.resize(a, (width, height), interpolation=cv2.INTER_NEAREST) returns: destination pixel (y, x) copies source
+  pixel (floor(y * H / height), floor(x * W / width)), clamped to the image."""
+  src_h, src_w = a.shape[:2]
+  rows = np.minimum(np.floor(np.arange(height) * (src_h / height)).astype(np.int64), src_h - 1)
+  cols = np.minimum(np.floor(np.arange(width) * (src_w / width)).astype(np.int64), src_w - 1)
+  return a[np.ix_(rows, cols)] if a.ndim == 2 else a[rows][:, cols]
 
 
 class Deep360DatasetDisparity(Dataset):
-  """Items: {'leftImg' (3,H,W), 'rightImg' (3,H,W), 'dispMap' (1,H,W), 'dispNames'} (deep360_loader.py:60-117).
-  Images of another width are resized to `shape` (disparities by nearest neighbour, scaled by the width ratio, :96-99).
-  crop=True takes a random 512x256 window; the reference's branch (:101-108) refers to undefined names and raises -- here it
-  crops left, right and disparity consistently."""
+  """One stereo pair per item: {'leftImg': (3,H,W), 'rightImg': (3,H,W), 'dispMap': (1,H,W), 'dispNames': path}.
+
+  Pairs stored at another width than `shape` are resized (images with PIL, the disparity map by nearest neighbour and multiplied
+  by the width ratio, deep360_loader.py:96-99).  crop=True cuts the same random 512 x 256 window out of all three; the
+  reference's own crop branch (:101-108) uses names it never defined and raises."""
 
   def __init__(self, leftImgs, rightImgs, disps, shape=(1024, 512), crop=False, disploader=disparity_loader, rgbloader=default_loader):
     super(Deep360DatasetDisparity, self).__init__()
-    self.crop = crop
-    self.height, self.width = shape
-    self.processed = preprocess.get_transform_stage1(augment=False)
     self.leftImgs, self.rightImgs, self.disps = leftImgs, rightImgs, disps
+    self.height, self.width = shape
+    self.crop = crop
     self.disp_loader, self.rgb_loader = disploader, rgbloader
-
-  def __getitem__(self, index):
-    disp_name = self.disps[index]
-    left = self.rgb_loader(self.leftImgs[index])
-    right = self.rgb_loader(self.rightImgs[index])
-    disp = self.disp_loader(disp_name)
-    w, h = left.size
-    if w != self.width:
-      left = left.resize((self.width, self.height))
-      right = right.resize((self.width, self.height))
-      disp = resize_nearest(disp, self.width, self.height) * (self.width / w)
-    if self.crop:
-      w, h = left.size
-      th, tw = 512, 256
-      x1, y1 = random.randint(0, w - tw), random.randint(0, h - th)
-      left = left.crop((x1, y1, x1 + tw, y1 + th))
-      right = right.crop((x1, y1, x1 + tw, y1 + th))
-      disp = disp[y1:y1 + th, x1:x1 + tw]
-    disp = np.ascontiguousarray(disp, dtype=np.float32)
-    return {'leftImg': self.processed(left), 'rightImg': self.processed(right), 'dispMap': torch.from_numpy(disp).unsqueeze_(0),
-            'dispNames': disp_name}
+    self.processed = preprocess.get_transform_stage1(augment=False)
 
   def __len__(self):
     return len(self.disps)
 
+  def _fit(self, views, disp):
+    """Bring a pair and its disparity map to the working size."""
+    stored_w = views[0].size[0]
+    if stored_w == self.width:
+      return views, disp
+    size = (self.width, self.height)
+    return [v.resize(size) for v in views], resize_nearest(disp, *size) * (self.width / stored_w)
+
+  @staticmethod
+  def _window(views, disp):
+    full_w, full_h = views[0].size
+    left, top = random.randint(0, full_w - CROP_W), random.randint(0, full_h - CROP_H)
+    box = (left, top, left + CROP_W, top + CROP_H)
+    return [v.crop(box) for v in views], disp[top:top + CROP_H, left:left + CROP_W]
+
+  def __getitem__(self, index):
+    name = self.disps[index]
+    views = [self.rgb_loader(self.leftImgs[index]), self.rgb_loader(self.rightImgs[index])]
+    views, disp = self._fit(views, self.disp_loader(name))
+    if self.crop:
+      views, disp = self._window(views, disp)
+    disp = torch.from_numpy(np.ascontiguousarray(disp, dtype=np.float32))[None]
+    return {'leftImg': self.processed(views[0]), 'rightImg': self.processed(views[1]), 'dispMap': disp, 'dispNames': name}
+
 
 class Deep360DatasetFusion(Dataset):
-  """Items: (gt name, 6 depth tensors (1,H,W), 6 confidence arrays (1,H,W), 4 rgb tensors (3,H,W), gt (H,W))
-  (deep360_loader.py:120-167); resize=True halves everything by striding (rgb by PIL resize), the ground truth only in
-  training."""
+  """One frame per item, as the fusion scripts unpack it: (ground-truth path, [6 depth tensors (1,H,W)], [6 confidence arrays
+  (1,H,W)], [4 rgb tensors (3,H,W)], ground truth (H,W)) (deep360_loader.py:120-167).  resize=True halves every input by
+  taking every second pixel (the panoramas through PIL); the ground truth is halved only when training."""
 
   def __init__(self, depthes, confs, rgbs, gt, resize, training, depthloader=depth_loader, rgbloader=default_loader):
     super(Deep360DatasetFusion, self).__init__()
     self.depthes, self.confs, self.rgbs, self.gt = depthes, confs, rgbs, gt
-    self.depthloader, self.rgbloader = depthloader, rgbloader
     self.resize, self.training = resize, training
-
-  def __getitem__(self, index):
-    depthes = [self.depthloader(d[index]) for d in self.depthes]
-    confs = [conf_loader(c[index]) for c in self.confs]
-    rgbs = [self.rgbloader(r[index]) for r in self.rgbs]
-    gt = np.ascontiguousarray(np.squeeze(self.depthloader(self.gt[index]), axis=-1), dtype=np.float32)
-    if self.resize:
-      depthes = [d[::2, ::2, :] for d in depthes]
-      confs = [c[:, ::2, ::2] for c in confs]
-      w, h = rgbs[0].size
-      rgbs = [r.resize((int(w / 2), int(h / 2))) for r in rgbs]
-      if self.training:
-        gt = gt[::2, ::2]
-    to_depth = preprocess.get_transform_stage2(augment=False)
-    to_rgb = preprocess.get_transform_stage1(augment=False)
-    return self.gt[index], [to_depth(d) for d in depthes], confs, [to_rgb(r) for r in rgbs], gt
+    self.depthloader, self.rgbloader = depthloader, rgbloader
 
   def __len__(self):
     return len(self.gt)
+
+  def __getitem__(self, index):
+    depth_maps = [self.depthloader(paths[index]) for paths in self.depthes]
+    conf_maps = [conf_loader(paths[index]) for paths in self.confs]
+    panoramas = [self.rgbloader(paths[index]) for paths in self.rgbs]
+    truth = np.ascontiguousarray(self.depthloader(self.gt[index])[..., 0], dtype=np.float32)
+    if self.resize:
+      depth_maps = [m[::2, ::2] for m in depth_maps]
+      conf_maps = [m[:, ::2, ::2] for m in conf_maps]
+      half = (panoramas[0].size[0] // 2, panoramas[0].size[1] // 2)
+      panoramas = [im.resize(half) for im in panoramas]
+      if self.training:
+        truth = truth[::2, ::2]
+    as_depth = preprocess.get_transform_stage2(augment=False)
+    as_rgb = preprocess.get_transform_stage1(augment=False)
+    return self.gt[index], [as_depth(m) for m in depth_maps], conf_maps, [as_rgb(im) for im in panoramas], truth

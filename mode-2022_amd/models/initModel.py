@@ -14,31 +14,39 @@ _WEIGHT_INIT = {
 }
 
 
+def _zero_bias(module):
+  if getattr(module, 'bias', None) is not None:
+    nn.init.constant_(module.bias, 0)
+
+
 def initModelPara(model, initType):
-  """initModel.py:9-32: no-op for None / 'default'; otherwise re-draws every conv-like weight."""
-  if initType is None or initType == 'default':
+  """Re-draws the weights of every convolution-like layer with the named scheme (unknown names leave them alone), sets
+  BatchNorm1d/2d to (1, 0) and Linear layers to N(0, 0.01); None / 'default' keeps the constructors' own initialisation
+  (reference behaviour: initModel.py:9-32)."""
+  if initType in (None, 'default'):
     return
-  for m in model.modules():
-    if isinstance(m, _CONV_TYPES):
-      if initType in _WEIGHT_INIT:
-        _WEIGHT_INIT[initType](m.weight)
-      if m.bias is not None:
-        nn.init.constant_(m.bias, 0)
-    elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
-      nn.init.constant_(m.weight, 1)
-      nn.init.constant_(m.bias, 0)
-    elif isinstance(m, nn.Linear):
-      nn.init.normal_(m.weight, 0, 0.01)
-      if m.bias is not None:
-        nn.init.constant_(m.bias, 0)
+  draw = _WEIGHT_INIT.get(initType)
+  for module in model.modules():
+    if isinstance(module, _CONV_TYPES):
+      if draw is not None:
+        draw(module.weight)
+      _zero_bias(module)
+    elif isinstance(module, (nn.BatchNorm1d, nn.BatchNorm2d)):
+      nn.init.constant_(module.weight, 1)
+      nn.init.constant_(module.bias, 0)
+    elif isinstance(module, nn.Linear):
+      nn.init.normal_(module.weight, 0, 0.01)
+      _zero_bias(module)
 
 
 def loadStackHourglassOnly(model, savedDictPath):
-  """initModel.py:35-42: take every entry of a (PSMNet) checkpoint that exists in `model` and does not belong
-  to the feature extractor; keep the rest of the current parameters."""
-  saved = torch.load(savedDictPath)['state_dict']
-  current = model.state_dict()
-  current.update({k: v for k, v in saved.items() if k in current and 'feature_extraction' not in k and 'forfilter1' not in k})
+  """Partial warm start from a (PSMNet) checkpoint: every saved entry that `model` also has is taken over, except the feature
+  extractor's ('feature_extraction' / 'forfilter1' in the key); everything else keeps its current value (initModel.py:35-42)."""
+  checkpoint = torch.load(savedDictPath)['state_dict']
+  merged = model.state_dict()
+  skip = ('feature_extraction', 'forfilter1')
+  taken = {key: value for key, value in checkpoint.items() if key in merged and not any(tag in key for tag in skip)}
+  merged.update(taken)
   print("load partial parameter: ")
-  model.load_state_dict(current)
+  model.load_state_dict(merged)
   print("loading done!")
