@@ -53,7 +53,25 @@ def parse():
   ap.add_argument('--vendor-autotune', type=int, default=int(os.environ.get('MODE_VENDOR_AUTOTUNE', '0')),
                   help='1: torch.backends.cudnn.benchmark = True (MIOpen times its solvers for the regular 2-D convolutions)')
   ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
+  ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                  help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
+                  '(RCCL refuses two ranks on the same device)')
   return ap.parse_args()
+
+
+def launch_ranks(args):
+  """`python bench.py --gpus N` without a launcher around it: start N ranks (one process per GPU) with torch.distributed.run as
+  a CHILD process and pass its output and exit code through.  Nothing in this parent has touched the GPU (no HIP call, not even
+  torch.cuda.is_available()), and the parent does not exec: it waits for the child."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  return subprocess.call(cmd, env=env)
 
 
 def synthetic_batch(B, H, W, maxdisp, device, seed):
@@ -144,14 +162,16 @@ def main():
   if args.cpu_baseline_only:
     print(json.dumps(cpu_baseline(args)))
     return
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(launch_ranks(args))  # before anything touches the GPU in this process
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)' % (args.gpus, world))
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    # 'nccl' is RCCL on ROCm (xGMI inside the node).  MODE_DIST_BACKEND=gloo only exists to exercise this code path with
-    # several ranks on ONE GPU in tests (RCCL refuses two ranks on the same device).
-    dist.init_process_group(os.environ.get('MODE_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+    dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
   assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
   local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
@@ -172,13 +192,16 @@ def main():
   except (TypeError, RuntimeError):
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
   left, right, gt = synthetic_batch(args.batch, args.height, args.width, args.maxdisp, dev, seed=1234 + rank)
-  mask = ~torch.isnan(gt)
-  gt0 = torch.nan_to_num(gt)
-
-  count = data_parallel.global_valid_count(mask)  # a property of the batch, not of the step: computed when it is loaded
+  # The static inputs of the (graph-replayed) step: images, ground truth WITH its NaNs (the mask is derived inside the step) and
+  # the global valid-pixel count -- a property of the batch that needs a collective, so it is computed when a batch is loaded
+  # into a buffer the captured step reads (GraphedStep.load(left, right, gt, count)); nothing about the batch is baked into the
+  # graph as a constant.
+  count = data_parallel.global_valid_count(~torch.isnan(gt))
 
   def fwd_bwd():
     reducer.zero_grad()
+    mask = ~torch.isnan(gt)
+    gt0 = torch.nan_to_num(gt)
     o1, o2, o3 = net(left, right)
     loss = 0
     for wgt, o in ((0.5, o1), (0.7, o2), (1.0, o3)):
@@ -197,9 +220,16 @@ def main():
     net.eval()
     body = eval_fwd
 
+  ar_events = []
+
   def finish():
     if args.mode == 'train':
-      reducer.all_reduce()
+      if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reducer.all_reduce()
+        e1.record()
+        ar_events.append((e0, e1))
       opt.step()
 
   def eager_step():
@@ -219,7 +249,7 @@ def main():
   if args.launch == 'graph':
     from mode_hip.graph_step import GraphedStep
     try:
-      graphed = GraphedStep(body, (left, right, gt0), warmup=1)
+      graphed = GraphedStep(body, (left, right, gt, count), warmup=1)
 
       def step():
         graphed.replay()
@@ -239,11 +269,13 @@ def main():
   # per-kernel (roofline) timing is taken over --profile-steps eager steps of the same workload right after the timed
   # region; with --launch eager the events are recorded inside the timed region itself.
   profiling.enable(args.launch == 'eager' and not args.no_kernel_timing)
+  del ar_events[:]
   t0 = time.time()
   for _ in range(args.steps):
     step()
   fence()
   elapsed = time.time() - t0
+  allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else None
   if args.launch == 'graph' and not args.no_kernel_timing:
     eager_step()  # re-warm the eager allocator pool (the replayed steps lived in the graph's private pool): an allocation
     fence()       # that falls through to hipMalloc stalls the stream between the two events of a region
@@ -251,7 +283,7 @@ def main():
     for _ in range(args.profile_steps):
       eager_step()
     fence()
-    if models.mode_disparity.FUSED_COST_CONV and args.profile_steps:
+    if net.fold_cost_volume and args.profile_steps:
       # the step no longer builds the cost volume (HF.cost_conv); the a9 kernel remains part of the operator API and its
       # north_star target is measured on the step's shapes, standalone
       from mode_hip import functional as HF
@@ -272,10 +304,13 @@ def main():
     if not bool(torch.isfinite(flat).all()):
       raise RuntimeError('bench.py: non-finite parameters after %d training steps' % (args.warmup + args.steps))
   profiling.enable(False)
+  rank_ms = [1e3 * elapsed / args.steps]
   if world > 1:
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t)
+    t = torch.zeros(world, device=dev, dtype=torch.float64)
+    t[rank] = elapsed
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    rank_ms = [1e3 * float(v) / args.steps for v in t]
+    elapsed = float(t.max())
 
   if rank == 0:
     pairs = args.batch * world * args.steps
@@ -293,15 +328,20 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
+        'per_gpu_value': pairs / elapsed / world,
+        'rank_ms_per_step': [round(v, 3) for v in rank_ms],
+        'collective': None if world == 1 else {'backend': 'rccl' if args.dist_backend == 'nccl' else args.dist_backend, 'ranks': world,
+                                               'op': 'all_reduce(sum) of the flat gradient buffer, once per step',
+                                               'bytes': reducer.flat.numel() * 4,
+                                               'avg_ms_rank0': None if allreduce_ms is None else round(allreduce_ms, 3)},
         'config': {
             'workload': 'ModeDisparity(%d,Sphere,%dx%d Cassini) %s step, batch %d/GPU (BASELINE configs[%d])' %
                         (args.maxdisp, args.height, args.width, 'fwd+bwd+Adam' if args.mode == 'train' else 'eval fwd',
                          args.batch, 2 if world == 1 else 3),
             'global_batch': args.batch * world,
             'parallelism': 'dp%d' % world,
-            'stage3d_backend': models.stage3d.BACKEND,
             'cost_volume': ('folded into dres0[0][0] (cost_conv: 18 partial 2-D products + assembly kernel); the volume is not built, '
-                            'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if models.mode_disparity.FUSED_COST_CONV
+                            'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if net.fold_cost_volume
                            else 'built (mode_cost_volume_fwd)',
             'launch': 'hipGraph replay of zero-grad+forward+loss+backward, then all-reduce and fused Adam' if args.launch == 'graph'
                       else 'eager (one launch per kernel)',

@@ -1,7 +1,6 @@
 """torch.autograd wrappers over the C-ABI kernels (host-side glue; the only arithmetic left to torch is the pair of small GEMMs
 of cost_conv, which run on rocBLAS)."""
 import ctypes
-import os
 import threading
 
 import torch
@@ -77,7 +76,7 @@ def conv2d_bwd_weight(gy, x, dilation=1, into=None):
   return gw
 
 
-CONV2D_OWN_MAX_PIXELS = int(os.environ.get('MODE_CONV2D_OWN_MAX_PIXELS', 1024 * 512))  # own forward / input gradient up to this H*W
+CONV2D_OWN_MAX_PIXELS = 1024 * 512  # own forward / input gradient up to this H*W
 
 
 def _conv2d_own(x, w):
@@ -85,7 +84,13 @@ def _conv2d_own(x, w):
   (tools/microbench.py --only conv2d): 90-130 TFLOP/s against the vendor's 80-112 at every shape of the extractor, half
   resolution included, and the fusion network's full-resolution layers (1024 x 512: 32.2 -> 31.9 ms per training step); larger
   images stay on the vendor library (untested territory for the tile choice)."""
-  return x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and w.shape[0] <= 128 and w.shape[1] <= 128
+  return (x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and w.shape[0] <= 128 and w.shape[1] <= 128 and
+          max(w.shape[0], w.shape[1]) * x.shape[2] * x.shape[3] < 2**29)
+
+
+def conv2d_wgrad_supported(x, w):
+  """mode_conv2d_bwd_weight addresses a sample with 32-bit lane offsets (csrc/conv2d_wgrad.hip: max(Ci, Co) * H * W < 2^29)."""
+  return max(w.shape[0], w.shape[1]) * x.shape[2] * x.shape[3] < 2**29
 
 
 def _conv2d_run(entry, name, src, w, out_channels, dilation):
@@ -147,6 +152,7 @@ class Conv2d3x3Function(torch.autograd.Function):
 
 
 def conv2d_3x3(x, w, dilation=1):
+  """Callers check conv2d_wgrad_supported(x, w) first (models/stage3d.conv3 does)."""
   return Conv2d3x3Function.apply(x, w, dilation)
 
 
@@ -191,6 +197,14 @@ def _tap_products(fea, wpart):
   return torch.matmul(wr, xs).view(B, 9 * Co, H, W)
 
 
+def cost_conv_supported(fea, d4, co):
+  """Limits of the two assembly kernels (csrc/cost_conv.hip): the adjoint keeps the D4 gradient rows of one (sample, channel,
+  image row) in LDS, the forward the 18 partial-product rows; beyond that the caller builds the volume (mode_cost_volume_fwd)
+  and runs the 64 -> 32 convolution on it."""
+  B, _, H, W = fea.shape
+  return 4 * (4 + d4 * (W + 4)) <= 160 * 1024 and 4 * (9 * (W + 2) + 9 * W) <= 160 * 1024 and B * co * H < 2**31
+
+
 def cost_conv(ref, tgt, weight, d4):
   """conv3d(cost_volume(ref, tgt, d4), weight, stride 1, padding 1) for a (Co, 2C, 3, 3, 3) weight, without the volume:
   models/mode_disparity.py:104-116.  261 GFLOP per sample of the reference layer become 7 GFLOP of GEMM plus one HBM-bound
@@ -231,9 +245,9 @@ def _check_pos(pos, x, Kh, Kw):
 
 _plan_cache = {}
 _plan_lock = threading.Lock()
-SPHERE_LAYOUT = os.environ.get('MODE_SPHERE_LAYOUT', 'transposed')  # windowed kernels on plane-transposed copies | 'nchw'
+SPHERE_LAYOUT = 'transposed'  # windowed kernels on plane-transposed copies | 'nchw'
 SPHERE_FWD_MIN_WG = 200  # fewer workgroups than this: the windowed forward under-fills the chip, use the general kernel
-SPHERE_FWD = os.environ.get('MODE_SPHERE_FWD', 'window')  # 'window' (LDS-window kernels where the table allows) | 'gather'
+SPHERE_FWD = 'window'  # 'window' (LDS-window kernels where the table allows) | 'gather'
 
 
 def transpose_planes(t, out=None):
@@ -335,7 +349,7 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
 
 _adjoint_cache = {}
 _adjoint_lock = threading.Lock()
-SPHERE_BWD_DATA = os.environ.get('MODE_SPHERE_BWD_DATA', 'gather')  # 'gather' (adjoint table) | 'scatter' (atomics)
+SPHERE_BWD_DATA = 'gather'  # 'gather' (adjoint table) | 'scatter' (atomics)
 
 
 def sphere_adjoint(pos, kh, kw, stride, out_hw):
@@ -360,7 +374,7 @@ def sphere_adjoint(pos, kh, kw, stride, out_hw):
     return hit
 
 
-SPHERE_BWD_DATA_T = os.environ.get('MODE_SPHERE_BWD_DATA_T', '1') == '1'  # adjoint gather on plane-transposed storage
+SPHERE_BWD_DATA_T = True  # adjoint gather on plane-transposed storage
 _pos_t_cache = {}
 
 
@@ -415,8 +429,8 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_tra
   return gx
 
 
-SPHERE_POLAR = os.environ.get('MODE_SPHERE_POLAR', '1') == '1'  # polar kernel for the tall-window tiles (else: pixel list + general kernel)
-SPHERE_BWD_WEIGHT = os.environ.get('MODE_SPHERE_BWD_WEIGHT', 'window')  # 'window' (where the table allows) | 'gather'
+SPHERE_POLAR = True  # polar kernel for the tall-window tiles (else: pixel list + general kernel)
+SPHERE_BWD_WEIGHT = 'window'  # 'window' (where the table allows) | 'gather'
 
 
 def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy_transposed=None):
@@ -532,6 +546,79 @@ def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
   return gw
 
 
+# ------------------------------------------------------------------------------------ any other Conv2d: gather-and-MAC on an integer table
+# The extractor's remaining regular convolutions -- 7x7 stride 2 (stem), 3x3 stride 2, 1x1 (stride 1 and 2); submodule.py:155,
+# 158, 162, 167-174 -- are the spherical operator with an INTEGER sampling table: tap (i, j) of output pixel (h, w) reads input
+# pixel (h*s + i*d - p, w*s + j*d - p), the bilinear weights are exactly (1, 0, 0, 0) and positions outside the image are dropped
+# by the operator's own guard (cu:246), which is zero padding.  Same kernels as SphereConv (general gather-and-MAC forward,
+# adjoint-gather input gradient, split-K weight gradient), bit-for-bit a plain convolution up to the order of the fp32 sums.
+_conv_tables = {}
+_conv_table_lock = threading.Lock()
+
+
+def conv2d_table(H, W, kh, kw, stride, pad, dil, device):
+  """(1, 2*kh*kw, H, W) float32 table on `device`: channel 2k = row, 2k+1 = column read by tap k at the output pixel whose
+  top-left input position is (h, w) (the operator samples it at (h_out*stride, w_out*stride), cu:206-261).  Cached."""
+  key = (H, W, kh, kw, tuple(stride), tuple(pad), tuple(dil), str(device))
+  with _conv_table_lock:
+    t = _conv_tables.get(key)
+    if t is None:
+      hh = torch.arange(H, dtype=torch.float32).view(H, 1).expand(H, W)
+      ww = torch.arange(W, dtype=torch.float32).view(1, W).expand(H, W)
+      planes = []
+      for i in range(kh):
+        for j in range(kw):
+          planes += [hh + float(i * dil[0] - pad[0]), ww + float(j * dil[1] - pad[1])]
+      t = _conv_tables[key] = torch.stack(planes, 0).unsqueeze(0).contiguous().to(device)
+    return t
+
+
+def conv2d_tabled_supported(x, conv):
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None and
+          conv.padding_mode == 'zeros' and not isinstance(conv.padding, str) and
+          x.shape[2] >= conv.kernel_size[0] and x.shape[3] >= conv.kernel_size[1])
+
+
+class Conv2dTabledFunction(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, w, stride, pad, dil):
+    x, w = x.contiguous(), w.contiguous()
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
+    pos = conv2d_table(H, W, kh, kw, stride, pad, dil, x.device)
+    y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
+    sphere_conv_fwd(x, pos, w, y, stride, 1)
+    ctx.save_for_backward(x, w, pos)
+    ctx.stride = tuple(stride)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w, pos = ctx.saved_tensors
+    gy = gy.contiguous()
+    gx = None
+    if ctx.needs_input_grad[0]:
+      gx = torch.empty_like(x)
+      sphere_conv_bwd_data(gy, pos, w, gx, ctx.stride, 1, overwrite=True)
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = sink if sink is not None else torch.zeros_like(w)
+      sphere_conv_bwd_weight(gy, pos, x, gw, ctx.stride, 1)
+      if sink is not None:
+        gw = None
+    return gx, gw, None, None, None
+
+
+def conv2d_tabled(x, conv):
+  """nn.Conv2d `conv` (any kernel size / stride / padding / dilation; groups 1, no bias) on the gather-and-MAC kernels."""
+  return Conv2dTabledFunction.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), tuple(conv.dilation))
+
+
 # ------------------------------------------------------------------------------------ gradient sinks
 def grad_sink(param):
   """The buffer parameter gradients are accumulated into directly by the native backward kernels, or None.
@@ -543,6 +630,11 @@ def grad_sink(param):
   ordinary autograd gradients."""
   sink = getattr(param, '_mode_grad_sink', None)
   if sink is None:
+    return None
+  if param.grad is None or param.grad.data_ptr() != sink.data_ptr():
+    # optimizer.zero_grad() (set_to_none=True by default; train_disparity.py:149) or anything else replaced .grad: adding into
+    # the detached buffer would silently drop this parameter's gradient, so autograd accumulates it the ordinary way
+    # (GradAllReducer.rebind() re-attaches the views)
     return None
   if not (sink.is_cuda and sink.dtype == torch.float32 and sink.is_contiguous() and sink.shape == param.shape):
     raise RuntimeError('gradient sink of a %s parameter must be a contiguous fp32 device tensor of the same shape' % (tuple(param.shape),))

@@ -10,7 +10,12 @@ The gradient exchange and the optimizer stay outside the graph: the exchange bec
 RCCL (not with the gloo backend the CPU tests use), the optimizer so that its hyper-parameters stay ordinary Python state.
 
   gs = GraphedStep(fn, static_inputs)      # fn() reads the static input tensors and returns a tensor / tuple of tensors
-  gs.load(left, right, gt, ...)            # copy_ new data into the static inputs (optional)
+  gs.load(left, right, gt, count)          # copy_ new data into the static inputs (optional)
+
+EVERYTHING about a batch that fn() reads must be one of the static inputs -- also derived quantities such as a loss mask or the
+global valid-pixel count: a tensor that fn() merely closes over is baked into the graph with the values (the address) it had at
+capture time, and a replay on new data would silently use the stale one.  bench.py therefore passes the ground truth with its
+NaNs (the mask is derived inside the step) and the valid-pixel count as static inputs.
   out = gs.replay()                        # static output tensors, overwritten by every replay
 """
 import torch

@@ -10,8 +10,6 @@ from __future__ import print_function
 
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -38,9 +36,9 @@ class hourglass(nn.Module):
     self.conv6 = nn.Sequential(nn.ConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
                                nn.BatchNorm3d(inplanes))
 
-  def forward(self, x, presqu, postsqu, residual=None):
-    """`residual` (not in the reference signature) is added to the output inside the last fused BatchNorm pass; the
-    reference adds cost0 right after the call (mode_disparity.py:119, 122, 125)."""
+  def forward(self, x, presqu, postsqu, *, residual=None):
+    """Reference signature (x, presqu, postsqu).  The keyword-only `residual` is added to the output inside the last fused
+    BatchNorm pass; the reference adds cost0 right after the call (mode_disparity.py:119, 122, 125)."""
     out = stage3d.conv_bn(self.conv1[0], x, relu=True)  # 1/4 -> 1/8
     pre = stage3d.conv_bn(self.conv2, out, relu=True, add=postsqu)  # relu(bn(conv) [+ postsqu])
     out = stage3d.conv_bn(self.conv3[0], pre, relu=True)  # 1/8 -> 1/16
@@ -50,17 +48,20 @@ class hourglass(nn.Module):
     return out, pre, post
 
 
-PAIR_EXTRACTOR = os.environ.get('MODE_PAIR_EXTRACTOR', '1') == '1'
-FUSED_COST_CONV = os.environ.get('MODE_FUSED_COST_CONV', '1') == '1'  # cost volume + dres0[0][0] without the volume
-
-
 def _cumulative_bn(module):
   """True if some BatchNorm of `module` uses the cumulative moving average (momentum=None), which the grouped kernels do not do."""
   return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.momentum is None for m in module.modules())
 
 
 class ModeDisparity(nn.Module):
-  """in_height, in_width: input image shape -- (1024,512) for Deep360, (640,320) fisheye, (512,256) 3D60."""
+  """in_height, in_width: input image shape -- (1024,512) for Deep360, (640,320) fisheye, (512,256) 3D60.
+
+  Two restructurings of forward() are plain attributes (defaults on; the parity tests switch them off per instance to compare
+  against the literal composition -- they are not configuration and read no environment):
+    pair_extractor     one pass of the shared extractor over [left; right] with per-image-set BatchNorm statistics;
+    fold_cost_volume   the concat volume folded into dres0[0][0] (functional.cost_conv), never materialised."""
+  pair_extractor = True
+  fold_cost_volume = True
 
   def __init__(self, maxdisp, conv='Sphere', in_height=1024, in_width=512, sphereType='Cassini', out_conf=False):
     super(ModeDisparity, self).__init__()
@@ -103,7 +104,7 @@ class ModeDisparity(nn.Module):
         m.bias.data.zero_()
 
   def forward(self, left, right):
-    if PAIR_EXTRACTOR and left.shape == right.shape and not _cumulative_bn(self.feature_extraction):
+    if self.pair_extractor and left.shape == right.shape and not _cumulative_bn(self.feature_extraction):
       # One pass of the shared extractor over [left; right] instead of two: same arithmetic per sample, BatchNorm statistics
       # still per image set (stage3d.bn_groups), twice the work per kernel launch -- the extractor's kernels are small at the
       # benchmark batch (2 x 256x128 at quarter resolution) and fill the chip better at 4.
@@ -115,8 +116,9 @@ class ModeDisparity(nn.Module):
       tgt_fea = self.feature_extraction(right)
 
     conv0 = self.dres0[0][0]
-    if (FUSED_COST_CONV and stage3d.BACKEND == 'hip' and ref_fea.is_cuda and conv0.bias is None and tuple(conv0.kernel_size) == (3, 3, 3) and
-        tuple(conv0.stride) == (1, 1, 1) and tuple(conv0.padding) == (1, 1, 1) and conv0.in_channels == 2 * ref_fea.shape[1]):
+    if (self.fold_cost_volume and ref_fea.is_cuda and conv0.bias is None and tuple(conv0.kernel_size) == (3, 3, 3) and
+        tuple(conv0.stride) == (1, 1, 1) and tuple(conv0.padding) == (1, 1, 1) and conv0.in_channels == 2 * ref_fea.shape[1] and
+        HF.cost_conv_supported(ref_fea, self.maxdisp // 4, conv0.out_channels)):
       # the volume is constant along d in its reference half and a function of w-d in its target half: its first convolution
       # collapses to 18 small 2-D products and one assembly pass (HF.cost_conv), and the 402.7 MB volume is never built
       y0 = HF.cost_conv(ref_fea, tgt_fea, conv0.weight, self.maxdisp // 4)
@@ -128,9 +130,9 @@ class ModeDisparity(nn.Module):
     t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
     cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
 
-    out1, pre1, post1 = self.dres2(cost0, None, None, cost0)  # out1 = hourglass(...) + cost0
-    out2, pre2, post2 = self.dres3(out1, pre1, post1, cost0)
-    out3, pre3, post3 = self.dres4(out2, pre1, post2, cost0)  # pre1 (not pre2), as in the reference (:124)
+    out1, pre1, post1 = self.dres2(cost0, None, None, residual=cost0)  # out1 = hourglass(...) + cost0
+    out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=cost0)
+    out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=cost0)  # pre1 (not pre2), as in the reference (:124)
 
     cost1 = stage3d.classify(self.classif1, out1)
     cost2 = stage3d.classify(self.classif2, out2) + cost1

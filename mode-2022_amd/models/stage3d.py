@@ -1,14 +1,14 @@
 """3D regulariser + soft-argmin head building blocks used by ModeDisparity.forward.
 
 Each helper takes the nn.Module that owns the parameters (so the state_dict layout stays the reference's) and
-runs the layer.  ``BACKEND`` selects who does the arithmetic of the 3x3x3 convolutions:
-  'hip'    -- libmode_hip.so fp32-MFMA kernels for every 3x3x3 layer of the regulariser: stride-1 and stride-2 Conv3d,
-              ConvTranspose3d (k3 s2 p1 op1) and the 32->1 classifier convolutions, forward and both gradients;
-  'vendor' -- torch.nn.functional on the GPU (MIOpen) for everything; used for A/B measurements.
-Neither is a CPU path; BatchNorm / ReLU / residual adds are torch GPU ops for now.
+runs the layer on libmode_hip.so: fp32-MFMA kernels for every 3x3x3 layer of the regulariser (stride-1 and stride-2 Conv3d,
+ConvTranspose3d k3 s2 p1 op1, the 32->1 classifier convolutions; forward and both gradients), the fused BatchNorm (+ residual
+add) (+ ReLU) kernels, and the fused soft-argmin head.  There is no CPU path and no backend switch: layers whose shape the
+kernels do not implement run as the torch module they are (vendor library), everything else always runs on the HIP kernels.
+The plain-torch composition of the head, for A/B measurements and the CPU wiring tests, lives in tests/plain_ops.py.
 """
 import contextlib
-import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -16,15 +16,11 @@ import torch.nn.functional as F
 
 from mode_hip import functional as HF
 
-BACKEND = os.environ.get('MODE_STAGE3D', 'hip')
-BN_BACKEND = os.environ.get('MODE_BN', 'hip')  # 'hip' = fused BatchNorm+add+ReLU kernels (mode_bn_*), 'vendor' = torch ops
-CONV2D_WGRAD = os.environ.get('MODE_CONV2D_WGRAD', '1') == '1'  # own kernels for the regular stride-1 3x3 Conv2d layers
-HEAD_BACKEND = os.environ.get('MODE_HEAD', 'hip')  # 'hip' = fused kernel (mode_head_fwd/bwd), 'vendor' = torch ops
 
 
 def _hip_kind(conv, x):
   """'conv1' / 'conv2' / 'deconv' if libmode_hip implements this layer, else None (vendor library)."""
-  if BACKEND != 'hip' or conv.kernel_size != (3, 3, 3) or conv.padding != (1, 1, 1) or conv.dilation != (1, 1, 1) or \
+  if conv.kernel_size != (3, 3, 3) or conv.padding != (1, 1, 1) or conv.dilation != (1, 1, 1) or \
       conv.groups != 1 or conv.bias is not None or conv.in_channels > 64 or conv.out_channels > 64:
     return None
   if type(conv) is nn.Conv3d:
@@ -48,14 +44,18 @@ def conv3(conv, x):
     return HF.conv3d(x, conv.weight, 2)
   if kind == 'deconv':
     return HF.deconv3d(x, conv.weight)
-  if CONV2D_WGRAD and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and \
+  if type(conv) is nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and \
       conv.bias is None and conv.padding == conv.dilation and conv.dilation in ((1, 1), (2, 2)) and conv.padding_mode == 'zeros' and \
-      x.dtype == torch.float32:
+      x.dtype == torch.float32 and x.is_cuda:
     # regular stride-1 3x3 layer of the 2-D extractor: own kernels (csrc/conv2d.hip, conv2d_wgrad.hip)
     if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
-      return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
-    if HF._conv2d_own(x, conv.weight):
+      if HF.conv2d_wgrad_supported(x, conv.weight):
+        return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
+    elif HF._conv2d_own(x, conv.weight):
       return HF.conv2d_fwd(x.contiguous(), conv.weight.detach().contiguous(), conv.dilation[0])
+  if type(conv) is nn.Conv2d and HF.conv2d_tabled_supported(x, conv):
+    # every other regular convolution (7x7 stride 2, 3x3 stride 2, 1x1): the gather-and-MAC kernels on an integer table
+    return HF.conv2d_tabled(x, conv)
   return conv(x)
 
 
@@ -65,34 +65,42 @@ def conv_bn(seq, x, relu=False, add=None):
   return bn_act(seq[1], conv3(seq[0], x), add, relu)
 
 
-_bn_groups = 1
+# nn.DataParallel (train_disparity.py:264-265 and the other reference call sites) runs forward() of one replica per GPU on
+# one Python thread each: the statistics grouping of the current extractor pass is per-thread state, never a module global.
+_tls = threading.local()
+
+
+def current_bn_groups():
+  return getattr(_tls, 'bn_groups', 1)
 
 
 @contextlib.contextmanager
 def bn_groups(n):
-  """Inside this context every training-mode BatchNorm takes its batch statistics per group of B / n consecutive samples and
-  updates its running statistics group after group -- exactly what n consecutive calls of the network on the n sub-batches do.
-  ModeDisparity pushes the left and the right images through the shared extractor as one batch this way."""
-  global _bn_groups
-  prev, _bn_groups = _bn_groups, n
+  """Inside this context every training-mode BatchNorm of THIS THREAD takes its batch statistics per group of B / n consecutive
+  samples and updates its running statistics group after group -- exactly what n consecutive calls of the network on the n
+  sub-batches do.  ModeDisparity pushes the left and the right images through the shared extractor as one batch this way."""
+  prev = current_bn_groups()
+  _tls.bn_groups = n
   try:
     yield
   finally:
-    _bn_groups = prev
+    _tls.bn_groups = prev
 
 
 def bn_act(bn, y, add=None, relu=False):
-  """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training), or vendor ops."""
+  """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training)."""
   if not y.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')
-  if BN_BACKEND == 'hip' and HF.bn_supported(y):
-    return HF.bn_act(bn, y, add, relu, groups=_bn_groups if bn.training else 1)
-  return bn_act_vendor(bn, y, add, relu)
+  if not HF.bn_supported(y):  # (spatial size not a multiple of 4, other dtypes): the torch module itself, on the GPU
+    return bn_act_torch(bn, y, add, relu)
+  return HF.bn_act(bn, y, add, relu, groups=current_bn_groups() if bn.training else 1)
 
 
-def bn_act_vendor(bn, y, add=None, relu=False):
-  if _bn_groups > 1 and bn.training:  # group after group, like consecutive calls
-    y = torch.cat([bn(part) for part in y.chunk(_bn_groups, 0)], 0)
+def bn_act_torch(bn, y, add=None, relu=False):
+  """The same layer as separate torch ops; only reached for tensor shapes the fused kernels do not take."""
+  groups = current_bn_groups()
+  if groups > 1 and bn.training:  # group after group, like consecutive calls
+    y = torch.cat([bn(part) for part in y.chunk(groups, 0)], 0)
   else:
     y = bn(y)
   if add is not None:
@@ -111,25 +119,6 @@ def head(cost, size, with_confidence=False):
   map of mode_disparity.py:157-183 = P(round(d)-1) + P(round(d)) + P(round(d)+1), indices clamped to [0, D-1]."""
   if not cost.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')
-  if HEAD_BACKEND == 'hip':
-    if with_confidence:
-      return HF.head_fwd(cost, size, with_confidence=True)
-    return HF.head(cost, size)
-  return head_vendor(cost, size, with_confidence)
-
-
-def head_vendor(cost, size, with_confidence=False):
-  """The same head as separate torch GPU ops (A/B measurements; also what the CPU wiring tests substitute)."""
-  D = size[0]
-  up = F.interpolate(cost, list(size), mode='trilinear', align_corners=True).squeeze(1)
-  prob = F.softmax(up, dim=1)
-  disp = torch.arange(D, dtype=prob.dtype, device=prob.device).view(1, D, 1, 1)
-  pred = torch.sum(prob * disp, 1, keepdim=True)
-  if not with_confidence:
-    return pred
-  r = torch.round(pred)
-  conf = 0
-  for off in (0.0, -1.0, 1.0):
-    idx = (r + off).clamp(0, D - 1).long()
-    conf = conf + torch.gather(prob, 1, idx)
-  return pred, conf  # (B,1,H,W) each, like the reference's prob_map.squeeze(1)
+  if with_confidence:
+    return HF.head_fwd(cost, size, with_confidence=True)
+  return HF.head(cost, size)

@@ -1,7 +1,5 @@
 """Sub-networks of the disparity stage (module tree and state_dict names of the reference's
 models/submodule.py; regular 2D convolutions run on the vendor library, spherical ones on libmode_hip)."""
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -9,8 +7,6 @@ import torch.nn.functional as F
 from . import stage3d
 from .basic import SphereConv
 from .basic.spherical_conv import sphere_conv as sphere_conv_mod
-
-SPHERE_CHAIN = os.environ.get('MODE_SPHERE_CHAIN', '1') == '1'  # layer4 on plane-transposed storage end to end
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
@@ -134,7 +130,11 @@ def _three_convs(cin, first_kernel, first_pad):
 class sphere_feature_extraction(nn.Module):
   """2D feature extractor with a spherical-convolution stage (submodule.py:151-201):
   firstconv (7x7 s2 + 2x 3x3) -> layer1 (3 blocks 32->64) -> layer2 (8 blocks, s2) -> layer3 (4 blocks, dil 2)
-  -> layer4 (8 sphere blocks 64->128) ; cat(layer2, layer3, layer4) -> lastconv -> 32 ch at 1/4 resolution."""
+  -> layer4 (8 sphere blocks 64->128) ; cat(layer2, layer3, layer4) -> lastconv -> 32 ch at 1/4 resolution.
+
+  `transposed_chain` (plain attribute, default on): layer4 runs end to end on the plane-transposed storage of the windowed
+  spherical kernels when every layer supports it; the parity tests switch it off per instance to compare with the NCHW operator."""
+  transposed_chain = True
 
   def __init__(self, in_height, in_width, sphereType):
     super(sphere_feature_extraction, self).__init__()
@@ -168,7 +168,7 @@ class sphere_feature_extraction(nn.Module):
     which cares about the order of the two spatial axes, so the whole run stays in the plane-transposed storage of the
     windowed kernels (one transpose in, one out) when every layer supports it."""
     convs = [m for m in self.layer4.modules() if isinstance(m, SphereConv)]
-    if SPHERE_CHAIN and x.is_cuda and all(m.supports_transposed_io(x.shape[0], x.device) for m in convs):
+    if self.transposed_chain and x.is_cuda and all(m.supports_transposed_io(x.shape[0], x.device) for m in convs):
       with sphere_conv_mod.transposed_io():
         yt = self.layer4(sphere_conv_mod.TransposePlanes.apply(x))
       return sphere_conv_mod.TransposePlanes.apply(yt)

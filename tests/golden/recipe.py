@@ -61,3 +61,64 @@ def recipe_disparity(B, H, W, seed, maxdisp):
   d = (rs.rand(B, 1, H, W).astype(np.float32)) * (maxdisp / 2.0)
   d[rs.rand(B, 1, H, W) < 0.05] = np.nan
   return torch.from_numpy(d)
+
+
+# ------------------------------------------------------------------------------------------------ well-conditioned recipe
+# A randomly initialised BatchNorm + ReLU network of this depth amplifies fp32 round-off by ~10^3 (the reference's own fp32 run
+# differs from an fp64 evaluation of the same network by 2e-3 .. 1.6e-2 px under `recipe_state`), so the north_star's 1e-3 bound
+# cannot be tested on it.  `recipe_state_wc` draws the SAME random tensors from the same stream and mixes every convolution weight
+# with a channel-cyclic identity at its centre tap (w = identity + WC_MIX * He-random), and scales the three 32 -> 1 classifier
+# convolutions by WC_LOGIT_SCALE so that the soft-argmin stays in its smooth regime.  Every tap and channel still contributes at
+# O(1) (a wrong kernel or index map moves the output by ~1 px) while round-off is amplified ~100x less: measured E_ref =
+# max|reference fp32 - fp64| = 9e-5 px at config 1 (512 x 256, 64 disparities), with a 1.3 .. 1.9 px spread of the predictions.
+WC_MIX = 0.5
+WC_LOGIT_SCALE = 0.1
+
+
+def _cyclic_identity(shape, transposed):
+  """(Co, Ci, k...) -- or (Ci, Co, k...) for a transposed convolution -- with 1 at the centre tap where the channels agree
+  cyclically (c mod Co == o, or o mod Ci == c), normalised so that every output channel sums its inputs with weight 1."""
+  co, ci = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
+  o, c = np.meshgrid(np.arange(co), np.arange(ci), indexing='ij')
+  hit = ((c % co) == o) | ((o % ci) == c)
+  m = hit.astype(np.float32) / float(max(1, ci // co))
+  d = np.zeros(shape, np.float32)
+  ctr = tuple(s // 2 for s in shape[2:])
+  d[(slice(None), slice(None)) + ctr] = m.T if transposed else m
+  return d
+
+
+def recipe_state_wc(manifest, seed, mix=WC_MIX, logit_scale=WC_LOGIT_SCALE, dtype=torch.float32):
+  rs = np.random.RandomState(seed)
+  out = {}
+  for key, shape in manifest:
+    t = recipe_tensor(rs, key, shape)
+    if len(shape) >= 4:
+      transposed = len(shape) == 5 and ('.conv5.0.' in key or '.conv6.0.' in key)  # ConvTranspose3d weights are (Ci, Co, ...)
+      t = (_cyclic_identity(shape, transposed) + np.float32(mix) * t).astype(np.float32)
+      if shape[0] == 1:  # classifN.2.weight
+        t = (t * np.float32(logit_scale)).astype(np.float32)
+    t = torch.from_numpy(t)
+    out[key] = t.to(dtype) if t.is_floating_point() else t
+  return out
+
+
+def projection_signs(seed, tensor_index, n, k):
+  """(k, n) matrix of +-1 (int8), reproducible: for a Rademacher vector v, E <e, v>^2 = |e|^2, so the mean over k projections
+  of (<g, v> - <g_ref, v>)^2 estimates the squared L2 distance of two gradient tensors without storing them."""
+  rs = np.random.RandomState((seed * 1000003 + tensor_index * 7919 + 17) % (2**31 - 1))
+  return (rs.randint(0, 2, size=(k, n), dtype=np.int8) * 2 - 1).astype(np.int8)
+
+
+def recipe_disparity_smooth(B, H, W, seed, maxdisp):
+  """Smooth synthetic ground truth in [maxdisp/8, 3 maxdisp/8] with 5 % NaN: the loss gradient is then coherent over
+  neighbouring pixels (a per-pixel random ground truth makes the back-propagated sums cancel, which amplifies their relative
+  round-off)."""
+  rs = np.random.RandomState(seed)
+  h = np.arange(H, dtype=np.float64).reshape(1, 1, H, 1) / H
+  w = np.arange(W, dtype=np.float64).reshape(1, 1, 1, W) / W
+  ph = rs.rand(B, 1, 1, 1)
+  d = (maxdisp / 4.0) * (1.0 + 0.5 * np.sin(2 * np.pi * (h + ph)) * np.cos(2 * np.pi * w))
+  d = d.astype(np.float32)
+  d[rs.rand(B, 1, H, W) < 0.05] = np.nan
+  return torch.from_numpy(d)

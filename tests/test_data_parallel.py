@@ -2,6 +2,7 @@
 nn.DataParallel semantics (masked mean over the GLOBAL batch, gradients summed over replicas)."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
@@ -101,3 +102,29 @@ def test_single_process_is_a_noop():
   net.zero_grad(set_to_none=True)
   red.rebind()
   assert all(p.grad is not None for p in net.parameters())
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+  """bench.py --gpus N either starts N ranks itself or runs inside a launcher that did; anything else is an error, never a
+  silent 1-GPU run labelled N (checked before the GPU is touched, so this runs on the CPU tier)."""
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True,
+                     text=True, timeout=300, env=env)
+  assert r.returncode != 0 and '--gpus 2' in (r.stderr + r.stdout)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+  """Without WORLD_SIZE in the environment `bench.py --gpus 2` launches two ranks (torch.distributed.run child).  On this
+  GPU-less host each rank stops at its "needs a GPU" assertion -- after the rendezvous, which is what is checked here."""
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--dist-backend', 'gloo',
+                      '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+  out = r.stderr + r.stdout
+  if torch.cuda.is_available():
+    assert r.returncode == 0, out[-2000:]
+  else:
+    assert r.returncode != 0 and 'bench.py needs a GPU' in out and 'local_rank: 1' in out, out[-3000:]

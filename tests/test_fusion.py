@@ -68,7 +68,7 @@ def test_no_cpu_path():
 
 def test_wiring_on_vendor_batchnorm(golden, monkeypatch):
   """The module tree evaluated with torch's own BatchNorm (the only native op of this stage swapped out) is the reference."""
-  monkeypatch.setattr(stage3d, 'bn_act', stage3d.bn_act_vendor)
+  monkeypatch.setattr(stage3d, 'bn_act', stage3d.bn_act_torch)
   z = golden('fusion_tiny.npz')
   maxdepth, channels, manifest, sd, depthes, confs, rgbs, gt = _case(z)
   net = mode_fusion.ModeFusion(maxdepth, channels, {'depth': 12, 'rgb': 12})

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 import torch
 
+import plain_ops
 import recipe
 from oracle import mode_ref, sphere_conv_ref
 
@@ -541,6 +542,47 @@ def test_conv2d_3x3_full_size_against_the_vendor_library():
     assert torch.equal(HF.conv2d_fwd(2 * x, w, dil), 2 * y)
 
 
+# ------------------------------------------------------------------ the other regular Conv2d layers: integer-table gather-and-MAC (a3)
+@pytest.mark.parametrize('B,Ci,Co,H,W,k,s,p,d', [
+    (2, 3, 32, 64, 32, 7, 2, 3, 1),      # firstconv.0 (submodule.py:155)
+    (2, 64, 64, 32, 16, 3, 2, 1, 1),     # layer2.0.conv1 (:158)
+    (2, 64, 64, 32, 16, 1, 2, 0, 1),     # layer2.0.downsample (:167-174)
+    (2, 32, 64, 16, 24, 1, 1, 0, 1),     # layer1.0.downsample
+    (1, 256, 128, 8, 16, 1, 1, 0, 1),    # lastconv.0 (:162)
+    (1, 128, 32, 8, 16, 1, 1, 0, 1),     # lastconv.4
+    (1, 5, 7, 9, 11, 3, 2, 1, 1),        # odd sizes: the last window hangs over the border
+    (1, 4, 6, 12, 10, 3, 1, 2, 2),       # dilation 2
+    (1, 6, 4, 10, 13, 5, 3, 2, 1),       # 5x5 stride 3
+])
+def test_conv2d_on_the_integer_table(B, Ci, Co, H, W, k, s, p, d):
+  """nn.Conv2d layers other than stride-1 3x3 run on the spherical operator's kernels with an integer sampling table
+  (functional.conv2d_tabled): forward, input gradient and weight gradient against torch's fp64 conv2d autograd."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  conv = nn.Conv2d(Ci, Co, k, s, p, d, bias=False)
+  x = _rand((B, Ci, H, W), 81)
+  with torch.no_grad():
+    conv.weight.copy_(_rand((Co, Ci, k, k), 82, (2.0 / (Ci * k * k))**0.5))
+  xa, wa = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+  y_ref = F.conv2d(xa, wa, None, s, p, d)
+  gy = _rand(tuple(y_ref.shape), 83)
+  y_ref.backward(gy.double())
+  conv = conv.to(DEV)
+  assert HF.conv2d_tabled_supported(x.to(DEV), conv)
+  xd = x.to(DEV).requires_grad_(True)
+  y = HF.conv2d_tabled(xd, conv)
+  assert tuple(y.shape) == tuple(y_ref.shape)
+  y.backward(gy.to(DEV))
+  tol = 2e-6 * (Ci * k * k)
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < tol * max(1.0, float(y_ref.abs().max()))
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 2e-6 * (Co * k * k) * max(1.0, float(xa.grad.abs().max()))
+  assert (conv.weight.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+  # the module route: stage3d.conv3 sends the layer here (no vendor kernel in the step)
+  from models import stage3d
+  with torch.no_grad():
+    assert torch.equal(stage3d.conv3(conv, x.to(DEV)), y.detach())
+
+
 # ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
 @pytest.mark.parametrize('shape', [(2, 8, 4, 6, 8), (1, 32, 6, 16, 32), (2, 64, 24, 32), (3, 5, 2, 2, 4)])
 @pytest.mark.parametrize('relu,with_add', [(False, False), (True, False), (True, True), (False, True)])
@@ -676,8 +718,7 @@ def test_head_full_size_properties():
   flat = HF.head_fwd(torch.zeros_like(lg), (192, 1024, 512))
   assert (flat - 95.5).abs().max() < 1e-3
   # same math as separate vendor ops on the GPU (the CPU oracle at this size needs ~1.6 GB and tens of seconds)
-  from models import stage3d
-  ref = stage3d.head_vendor(lg, (192, 1024, 512))
+  ref = plain_ops.head(lg, (192, 1024, 512))
   assert (ref - pred).abs().max() < 1e-3
 
 

@@ -142,28 +142,24 @@ def test_hourglass_golden(golden, tag):
 
 
 def test_bench_two_ranks_share_one_gpu():
-  """The N > 1 launch path of bench.py (torch.distributed.run, one process per rank, flat-gradient all-reduce, barrier +
-  max-over-ranks timing) end to end.  Two ranks on ONE GPU need the gloo backend (RCCL refuses duplicate devices); on an
-  8-GPU node the driver runs the same path over RCCL."""
+  """`python bench.py --gpus 2` with no launcher around it: bench.py itself starts one process per rank (torch.distributed.run
+  as a child), flat-gradient all-reduce, barrier + max-over-ranks timing, rank 0 prints the one JSON line.  Two ranks on ONE
+  GPU need the gloo backend (RCCL refuses duplicate devices); on an 8-GPU node the same path runs over RCCL."""
   import json
   import os
-  import socket
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  s = socket.socket()
-  s.bind(('127.0.0.1', 0))
-  port = s.getsockname()[1]
-  s.close()
-  env = dict(os.environ, MODE_DIST_BACKEND='gloo')
-  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-         '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '256',
-         '--width', '128', '--maxdisp', '64', '--batch', '1', '--no-cpu-baseline']
-  r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+  cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '256',
+         '--width', '128', '--maxdisp', '64', '--batch', '1', '--no-cpu-baseline', '--dist-backend', 'gloo']
+  r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
   lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
   assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
+  assert len(d['rank_ms_per_step']) == 2 and d['collective']['ranks'] == 2 and d['collective']['bytes'] == 4 * 5489280
+  assert abs(d['per_gpu_value'] * 2 - d['value']) < 1e-9 * d['value']
 
 
 def test_smoke_entry():
@@ -295,9 +291,9 @@ def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch
   monkeypatch.setattr(HF, 'SPHERE_FWD_MIN_WG', 0)  # the small test geometry too
   res = {}
   for chain in (True, False):
-    monkeypatch.setattr(sm, 'SPHERE_CHAIN', chain)
     torch.manual_seed(11)
     fe = sm.sphere_feature_extraction(512, 256, 'Cassini').to(DEV).train()  # layer4 at 128 x 64: all window classes
+    fe.transposed_chain = chain
     x = torch.randn(2, 3, 512, 256, device=DEV, requires_grad=True)
     if chain:
       convs = [m for m in fe.layer4.modules() if isinstance(m, sm.SphereConv)]
@@ -319,19 +315,19 @@ def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch
 
 def test_fast_paths_together_match_the_plain_composition(monkeypatch):
   """Every restructuring of the default path switched off at once -- two extractor passes, NCHW spherical operator, cost volume +
-  conv3d 64 -> 32, vendor forward / gradients for the regular convolutions -- against the default path, at BASELINE config 1
+  conv3d 64 -> 32, vendor forward / gradients for ALL regular 2-D convolutions -- against the default path, at BASELINE config 1
   size (512 x 256, 64 disparities), batch 2: predictions, loss, gradients, BatchNorm state."""
   import models.mode_disparity as md
   import models.stage3d as st
   import models.submodule as sm
   res = {}
   for fast in (True, False):
-    monkeypatch.setattr(md, 'PAIR_EXTRACTOR', fast)
-    monkeypatch.setattr(md, 'FUSED_COST_CONV', fast)
-    monkeypatch.setattr(sm, 'SPHERE_CHAIN', fast)
-    monkeypatch.setattr(st, 'CONV2D_WGRAD', fast)
     torch.manual_seed(21)
     net = models.ModeDisparity(64, 'Sphere', 512, 256, 'Cassini').to(DEV).train()
+    net.pair_extractor = net.fold_cost_volume = net.feature_extraction.transposed_chain = fast
+    if not fast:  # the regular 3x3 layers as the torch modules they are (vendor library)
+      own = st.conv3
+      monkeypatch.setattr(st, 'conv3', lambda conv, x: conv(x) if type(conv) is torch.nn.Conv2d else own(conv, x))
     left = torch.randn(2, 3, 512, 256, device=DEV)
     right = torch.roll(left, -3, 3) + 0.01 * torch.randn_like(left)
     gt = torch.rand(2, 1, 512, 256, device=DEV) * 30
@@ -357,8 +353,8 @@ def test_paired_extractor_pass_equals_two_passes(monkeypatch):
   import models.mode_disparity as md
   res = {}
   for paired in (True, False):
-    monkeypatch.setattr(md, 'PAIR_EXTRACTOR', paired)
     net, left, right, gt = _tiny_net(9)
+    net.pair_extractor = paired
     _loss(net, left, right, gt).backward()
     res[paired] = (net(left, right)[2].detach(), {k: p.grad.clone() for k, p in net.named_parameters()},
                    {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k})
@@ -373,3 +369,78 @@ def test_paired_extractor_pass_equals_two_passes(monkeypatch):
       assert int(a[2][k]) == int(b[2][k]), k
     else:
       assert (a[2][k] - b[2][k]).abs().max() <= 1e-4 * max(1.0, float(b[2][k].abs().max())), k
+
+
+# ------------------------------------------------------------------ nn.DataParallel: forward() from one thread per replica
+def _replica_pair(seed=13):
+  import copy
+  torch.manual_seed(seed)
+  net = models.ModeDisparity(32, 'Sphere', 128, 64, 'Cassini').to(DEV).train()
+  left = torch.randn(2, 3, 128, 64, device=DEV)
+  right = torch.roll(left, -3, 3) + 0.01 * torch.randn_like(left)
+  return net, copy.deepcopy, left, right
+
+
+def test_forward_from_two_threads_equals_sequential_runs():
+  """The reference's six call sites wrap the module in nn.DataParallel (train_disparity.py:264-265, test_disparity.py:160-161,
+  ...): one Python thread per replica calls forward() concurrently.  Two replicas, two threads, two streams of one GPU, train
+  mode (so the per-thread BatchNorm grouping of the paired extractor pass is live), many iterations with the threads released
+  together: every output and every BatchNorm buffer must equal, bit for bit, the sequential run of the same replica."""
+  import threading
+  net, clone, left, right = _replica_pair()
+  seq = []
+  for i in range(2):
+    r = clone(net)
+    outs = [r(left[i:i + 1] + 0.1 * k, right[i:i + 1] + 0.1 * k) for k in range(4)]
+    seq.append(([tuple(o.detach().clone() for o in out) for out in outs], {k: v.clone() for k, v in r.state_dict().items()}))
+  torch.cuda.synchronize()
+  replicas = [clone(net) for _ in range(2)]
+  streams = [torch.cuda.Stream(DEV) for _ in range(2)]
+  results, errors = [None, None], []
+  gate = threading.Barrier(2)
+
+  def work(i):
+    try:
+      with torch.cuda.stream(streams[i]):
+        outs = []
+        for k in range(4):
+          gate.wait()
+          outs.append(tuple(o.detach() for o in replicas[i](left[i:i + 1] + 0.1 * k, right[i:i + 1] + 0.1 * k)))
+        streams[i].synchronize()
+        results[i] = outs
+    except Exception as e:  # noqa: BLE001
+      errors.append(e)
+      gate.abort()
+
+  for s_ in streams:
+    s_.wait_stream(torch.cuda.current_stream())
+  threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors
+  for i in range(2):
+    for k in range(4):
+      for a, b in zip(results[i][k], seq[i][0][k]):
+        assert torch.equal(a, b), (i, k)
+    sd = replicas[i].state_dict()
+    for key, v in seq[i][1].items():
+      assert torch.equal(sd[key], v), (i, key)
+
+
+def test_under_nn_dataparallel_like_the_reference_call_sites():
+  """model = nn.DataParallel(model); model.cuda() -- train_disparity.py:264-265 -- here with both replicas on the one GPU of
+  the box (device_ids=[0, 0]): scatter along the batch, one thread per replica, gather.  Per-replica BatchNorm statistics
+  (DataParallel semantics), so each half of the batch must equal the module run on that half alone."""
+  import copy
+  net, clone, left, right = _replica_pair(17)
+  want = [clone(net)(left[i:i + 1], right[i:i + 1]) for i in range(2)]
+  dp = torch.nn.DataParallel(clone(net), device_ids=[0, 0])
+  got = dp(left, right)
+  for h in range(3):
+    for i in range(2):
+      assert torch.equal(got[h][i:i + 1], want[i][h]), (h, i)
+  assert [k for k in dp.state_dict()][0].startswith('module.')  # the prefix loadStackHourglassOnly / load_state_dict callers see
+  sd = copy.deepcopy(dp.state_dict())
+  models.ModeDisparity(32, 'Sphere', 128, 64, 'Cassini').load_state_dict({k[len('module.'):]: v for k, v in sd.items()})

@@ -181,3 +181,72 @@ def test_model_cfg1_eval(golden):
     pred = mode_ref.mode_disparity(P, left, right, maxdisp, pos, False)
   assert np.abs(pred[:, :, ::4, ::4].numpy() - z['eval/pred3']).max() < 1e-3
   assert abs(float(pred.double().mean()) - float(z['eval/pred3_mean'])) < 1e-4
+
+
+# ------------------------------------------------------------------ well-conditioned fixtures (the 1e-3 bar itself)
+@pytest.mark.parametrize('tag', ['tiny', 'cfg1'])
+def test_model_wellconditioned_matches_the_reference_to_1e4(golden, tag):
+  """The oracle on the fixtures tests/test_gpu_parity.py holds the HIP path to (made by the imported reference,
+  tests/golden/make_golden_wc.py): same torch CPU kernels in the same order, so the agreement is at round-off level --
+  outputs to 1e-4 px (a tenth of the north_star's bound), gradients to the reference's own fp32 reproducibility."""
+  z = golden('model_wc_%s.npz' % tag)
+  maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
+  mix, logit_scale = [float(v) for v in z['wc']]
+  sub = int(z['sub'])
+  assert float(z['truth64/train_E_ref']) <= 1.5e-4 and float(z['truth64/eval_E_ref']) <= 1.5e-4  # what "well conditioned" means
+  P = recipe.recipe_state_wc(recipe.load_manifest(), seed, mix, logit_scale)
+  left, right = recipe.recipe_images(B, H, W, seed + 1)
+  gt = recipe.recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+  params = [k for k, v in P.items() if v.is_floating_point() and 'running' not in k]
+  for k in params:
+    P[k].requires_grad_(True)
+  preds = mode_ref.mode_disparity(P, left, right, maxdisp, pos, True)
+  for i, p in enumerate(preds):
+    assert np.abs(p.detach()[:, :, ::sub, ::sub].numpy() - z['train/pred%d' % (i + 1)]).max() <= 1e-4
+    assert np.abs(torch.nn.functional.avg_pool2d(p.detach().double(), 8).numpy() - z['train/pred%d_block' % (i + 1)]).max() <= 1e-4
+  loss = mode_ref.training_loss(preds, gt, ~torch.isnan(gt))
+  assert abs(float(loss.detach()) - float(z['train/loss'])) <= 1e-5 * float(z['train/loss'])
+  loss.backward()
+  assert [str(n) for n in z['train/grad_names']] == params
+  for i, n in enumerate(params):
+    g = P[n].grad.reshape(-1).double().numpy()
+    proj = recipe.projection_signs(seed, i, g.size, z['train/grad_proj'].shape[1]).astype(np.float64) @ g
+    rel = float(np.sqrt(np.mean((proj - z['train/grad_proj'][i])**2))) / (float(z['train/grad_norm'][i]) + 1e-300)
+    assert rel <= max(1e-3, 5.0 * float(z['truth64/grad_rel_l2'][i])), (n, rel)
+  for k in z.files:
+    if k.startswith('bn/'):
+      P[k[3:]] = torch.from_numpy(z[k]).clone()
+  with torch.no_grad():
+    pred, conf = mode_ref.mode_disparity({k: v.detach() for k, v in P.items()}, left, right, maxdisp, pos, False, out_conf=True)
+  assert np.abs(pred[:, :, ::sub, ::sub].numpy() - z['eval/pred3']).max() <= 1e-4
+  assert np.abs(conf[:, :, ::sub, ::sub].numpy() - z['eval/conf']).max() <= 1e-4
+
+
+def test_wellconditioned_full_size_fixture_is_well_conditioned(golden):
+  """The benchmark-size fixture (1024 x 512, 192 disparities) is only evaluated on the GPU tier; here: its header."""
+  z = golden('model_wc_full.npz')
+  assert [int(v) for v in z['cfg'][:4]] == [192, 1024, 512, 1]
+  assert float(z['truth64/train_E_ref']) <= 1.5e-4 and float(z['truth64/eval_E_ref']) <= 1.5e-4
+  assert z['train/pred3'].shape == (1, 1, 128, 64) and z['train/pred3_block'].shape == (1, 1, 128, 64)
+  assert len(z['train/grad_names']) == 243
+
+
+# ------------------------------------------------------------------ tap-wise fp64 conv oracle (full-size GPU tests)
+@pytest.mark.parametrize('B,Ci,Co,D,H,W,stride', [(2, 3, 5, 4, 6, 8, 1), (1, 4, 2, 6, 4, 10, 2), (1, 2, 3, 1, 1, 2, 1), (2, 5, 4, 8, 2, 6, 2)])
+def test_tapwise_conv_oracle_equals_torch_conv3d(B, Ci, Co, D, H, W, stride):
+  """oracle/conv_ref.py (27 GEMMs on strided views) against torch's CPU conv3d / conv_transpose3d and their autograd -- the
+  kernels oracle/mode_ref.py and the imported reference itself compute with."""
+  import torch.nn.functional as F
+  from oracle import conv_ref
+  g = torch.Generator().manual_seed(7)
+  x = torch.randn(B, Ci, D, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+  w = torch.randn(Co, Ci, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+  y = F.conv3d(x, w, None, stride, 1)
+  gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+  y.backward(gy)
+  assert (conv_ref.conv3d_fwd(x.detach(), w.detach(), stride) - y.detach()).abs().max() < 1e-12
+  assert (conv_ref.conv3d_bwd_weight(gy, x.detach(), stride) - w.grad).abs().max() < 1e-11
+  assert (conv_ref.conv3d_bwd_data(gy, w.detach(), x.shape, stride) - x.grad).abs().max() < 1e-12
+  wt = torch.randn(Ci, Co, 3, 3, 3, generator=g, dtype=torch.float64)
+  assert (conv_ref.deconv3d_fwd(x.detach(), wt) - F.conv_transpose3d(x.detach(), wt, None, 2, 1, 1)).abs().max() < 1e-12

@@ -69,10 +69,10 @@ def main():
     net.eval()
     report('ModeFusion eval fwd B=%d' % B, timeit(fusion_eval, max(3, a.iters // 2)))
     net.train()
-    prev = stage3d.BN_BACKEND
-    stage3d.BN_BACKEND = 'vendor'
+    fused = stage3d.bn_act
+    stage3d.bn_act = stage3d.bn_act_torch  # A/B only: the same module tree on torch's BatchNorm + ReLU
     report('  (same step with torch BatchNorm + ReLU)', timeit(fusion_step, max(3, a.iters // 2)))
-    stage3d.BN_BACKEND = prev
+    stage3d.bn_act = fused
     del net, depthes, confs, rgbs, gt
     torch.cuda.empty_cache()
 
@@ -190,8 +190,9 @@ def main():
     report('head_fwd + confidence', timeit(lambda: HF.head_fwd(lg, (192, 1024, 512), True), a.iters), nb)
     g = torch.randn(B, 1, 1024, 512, device=dev)
     report('head_bwd', timeit(lambda: HF.head_bwd(lg, g, (192, 1024, 512)), a.iters), nb + 4 * lg.numel())
-    from models import stage3d
-    report('  (vendor upsample+softmax+regress fwd)', timeit(lambda: stage3d.head_vendor(lg, (192, 1024, 512)), 3), nb)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import plain_ops
+    report('  (vendor upsample+softmax+regress fwd)', timeit(lambda: plain_ops.head(lg, (192, 1024, 512)), 3), nb)
 
   if 'vendor' in only:
     x = torch.randn(B, 32, 48, 256, 128, device=dev)
