@@ -41,8 +41,24 @@ enum {
   MODE_ERR_WORKSPACE = -3     /* workspace missing or too small */
 };
 
+/* Eval-mode epilogue of the *_bn entry points: the BatchNorm that follows a convolution in every convbn / convbn_3d /
+ * sphereConvbn block (models/submodule.py:15-22, 61-74), in inference mode (running statistics), folded into the convolution:
+ *     out = relu?( conv(x, w)[o] * gamma[o] / sqrt(var[o] + eps) + beta[o] - mean[o] * gamma[o] / sqrt(var[o] + eps) [+ add] )
+ * The scale goes into the packed weights, the shift / residual add / ReLU into the store of the convolution kernel: the layer
+ * is one launch and the un-normalised convolution result never reaches HBM.  All pointers are device pointers; `add` (same
+ * shape as the output) may be NULL.  The struct itself lives in host memory and is read during the call. */
+typedef struct mode_bn_epilogue {
+  const float* gamma; /* (Co) BatchNorm weight */
+  const float* beta;  /* (Co) BatchNorm bias */
+  const float* mean;  /* (Co) running_mean */
+  const float* var;   /* (Co) running_var */
+  float eps;
+  const float* add; /* residual added before the ReLU, or NULL */
+  int relu;
+} mode_bn_epilogue;
+
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 8 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 9 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -66,6 +82,12 @@ size_t mode_sphere_conv_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups);
 int mode_sphere_conv_fwd(const float* x, const float* pos, const float* w, float* y, float* wpack,
                          int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW,
                          int Ho, int Wo, int groups, mode_stream_t stream);
+
+/* sphereConvbn (models/submodule.py:61-74) -- and, through an integer table, any other convbn -- in eval mode as one launch:
+ * mode_sphere_conv_fwd with the folded-BatchNorm epilogue (mode_bn_epilogue above). */
+int mode_sphere_conv_fwd_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack,
+                            int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups,
+                            mode_stream_t stream);
 
 /* Replaces the grad_input half of sphere_conv_backward_cuda (sphere_conv_cuda.cpp:275-294:
  * addmm_(W^T, gO) + col2im kernel sphere_conv_cuda_kernel.cu:293-356).  ACCUMULATES into gx, which
@@ -105,6 +127,10 @@ size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int grou
 int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, float* y, float* wpack, const int32_t* tiles,
                              int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
                              int groups, int transposed, mode_stream_t stream);
+
+int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack,
+                                const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh,
+                                int Kw, int groups, int transposed, mode_stream_t stream);
 
 /* `transposed` != 0: x and y are stored plane-transposed, (B, C, W, H) contiguous, i.e. with the h axis contiguous
  * (mode_transpose_planes converts).  For the Cassini tables of the network h is the shift-invariant longitude axis, and in
@@ -182,6 +208,11 @@ int mode_cost_volume_bwd(const float* gcost, float* g_ref, float* g_tgt, int B, 
 int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W, mode_stream_t stream);
 int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W, mode_stream_t stream);
 
+/* dres0[0] = convbn_3d(64, 32) + ReLU on the cost volume in eval mode: the assembly with the BatchNorm scale / shift (+ ReLU)
+ * applied on the way out (bn->add must be NULL). */
+int mode_cost_conv_assemble_fwd_bn(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, int B, int Co, int D,
+                                   int H, int W, mode_stream_t stream);
+
 /* Weight gradient of the regular 3x3 Conv2d layers of the extractor (nn.Conv2d inside convbn, models/submodule.py:15-17):
  * stride 1, padding = dilation in {1, 2}, no bias, groups 1.  gw (Co, Ci, 3, 3) (+)= sum_{b,h,w} gy[b,o,h,w] * x[b,c,h+(kh-1)*dil,
  * w+(kw-1)*dil]; gy (B,Co,H,W), x (B,Ci,H,W).  Deterministic.  `workspace` >= mode_conv2d_bwd_weight_workspace_bytes().
@@ -194,6 +225,10 @@ int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int 
                     mode_stream_t stream);
 int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
                          mode_stream_t stream);
+
+/* convbn (models/submodule.py:15-17) in eval mode as one launch: mode_conv2d_fwd with the folded-BatchNorm epilogue. */
+int mode_conv2d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
+                       int W, int Co, int dilation, mode_stream_t stream);
 size_t mode_conv2d_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co);
 int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                            int dilation, int accumulate, mode_stream_t stream);
@@ -221,6 +256,14 @@ int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int 
 
 int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
                          int Co, int stride, mode_stream_t stream);
+
+/* convbn_3d in eval mode as ONE launch (+ the weight packing): mode_conv3d_fwd / mode_deconv3d_fwd with the folded-BatchNorm
+ * epilogue above (Co > 1). */
+int mode_conv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int D,
+                       int H, int W, int Co, int stride, mode_stream_t stream);
+
+int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin, int D,
+                         int H, int W, int Cout, mode_stream_t stream);
 
 size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride);
 

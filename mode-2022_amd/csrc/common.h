@@ -69,11 +69,45 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
     }                                  \
   } while (0)
 
+namespace mode {
+inline int check_bn(const mode_bn_epilogue* bn, const char* who) {
+  MODE_REQUIRE(bn && bn->gamma && bn->beta && bn->mean && bn->var, MODE_ERR_BAD_ARG, "%s: null BatchNorm epilogue / vector", who);
+  return MODE_OK;
+}
+}  // namespace mode
+
 // MI355X: 256 CUs in 8 XCDs; block b is dispatched to XCD b % 8 (performance hint only).
 constexpr int kNumCU = 256;
 constexpr int kNumXCD = 8;
 
+// Device-side view of mode_bn_epilogue (include/mode_hip.h): out = relu?(acc + shift[o] [+ add]); the BatchNorm scale is folded
+// into the packed weights by the packing kernel, which also writes `shift` (fold_scale / fold_shift below).  shift == nullptr:
+// plain store.
+struct Epi {
+  const float* shift;
+  const float* add;
+  int relu;
+};
+
+inline Epi make_epi(const mode_bn_epilogue* e, const float* shift) {
+  Epi r;
+  r.shift = e ? shift : nullptr;
+  r.add = e ? e->add : nullptr;
+  r.relu = e ? e->relu : 0;
+  return r;
+}
+
 #ifdef __HIPCC__
+// Eval-mode BatchNorm folded into the convolution in front of it (torch semantics: y = (x - mean) / sqrt(var + eps) * gamma + beta):
+// the packing kernels scale output channel o of the weights by fold_scale and write fold_shift(o) next to the packed weights.
+__device__ __forceinline__ float fold_scale(const mode_bn_epilogue& e, int o) { return e.gamma[o] / sqrtf(e.var[o] + e.eps); }
+__device__ __forceinline__ float fold_shift(const mode_bn_epilogue& e, int o) { return e.beta[o] - e.mean[o] * fold_scale(e, o); }
+__device__ __forceinline__ float apply_epi(const Epi& e, float v, int o, long long idx) {
+  v += e.shift[o];
+  if (e.add) v += e.add[idx];
+  return e.relu ? fmaxf(v, 0.f) : v;
+}
+
 // XCD-aware bijective remap of a block id in [0, n): consecutive ids are dispatched round-robin over the 8 XCDs, each with its
 // own L2; this gives every XCD a contiguous range of work items, so that neighbouring tiles (shared halo rows, overlapping
 // gather footprints) meet in one L2.  Measured on the ring weight-gradient kernel: 1.20 GB -> 0.42 GB fetched per launch.

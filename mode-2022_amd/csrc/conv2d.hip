@@ -28,8 +28,12 @@ struct C2Dims {
 // wp[((mt*NCHUNK + ch)*9 + tap)*64 + lane][cp] = Wsrc(o = mt*32 + (lane&31), c = ch*8 + 2*cp + (lane>>5), tap)
 //   flip == 0: Wsrc(o,c,tap) = w[o][c][tap]      (forward; w is (Co,Ci,3,3), rows = Co, K = Ci)
 //   flip == 1: Wsrc(o,c,tap) = w[c][o][8 - tap]  (input gradient: rows = Ci of the convolution, K = Co)
-__global__ void pack_w2d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip) {
+//   fold != 0: row o is scaled by the folded BatchNorm scale of `bn` and block 0 writes the shifts to wp[total + o] (common.h).
+__global__ void pack_w2d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip, int fold,
+                         mode_bn_epilogue bn) {
   const long long total = (long long)MT * NCHUNK * 9 * 64 * 4;
+  if (fold && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) wp[total + o] = fold_shift(bn, o);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int cp = (int)(idx & 3);
     const int lane = (int)((idx >> 2) & 63);
@@ -42,13 +46,14 @@ __global__ void pack_w2d(const float* __restrict__ w, float* __restrict__ wp, in
     const int c = ch * CCH + 2 * cp + (lane >> 5);
     float v = 0.f;
     if (o < rows && c < K) v = flip ? w[((long long)c * rows + o) * 9 + 8 - tap] : w[((long long)o * K + c) * 9 + tap];
+    if (fold && o < rows) v *= fold_scale(bn, o);
     wp[idx] = v;
   }
 }
 
-template <int MT, int TH, int DIL>
+template <int MT, int TH, int DIL, bool EPI>
 __global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x, const float4* __restrict__ wp, float* __restrict__ y,
-                                                    C2Dims d) {
+                                                    C2Dims d, Epi epi) {
   constexpr int R = TH / 4;  // output rows per wave
   constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
   constexpr int PLANE = (IH * IW) | 1;
@@ -178,38 +183,46 @@ __global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x,
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int o = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          if (o < d.Co) yb[(long long)o * HW + sp] = acc[m][r][q];
+          if (o < d.Co) {
+            const long long idx = (long long)o * HW + sp;
+            yb[idx] = EPI ? apply_epi(epi, acc[m][r][q], o, (long long)b * d.Co * HW + idx) : acc[m][r][q];
+          }
         }
     }
   }
 }
 
 template <int MT, int TH, int DIL>
-int launch(const float* x, const float* wpack, float* y, C2Dims d, hipStream_t st, const char* who) {
+int launch(const float* x, const float* wpack, float* y, C2Dims d, hipStream_t st, const char* who, Epi epi) {
   d.nHt = mode::cdiv(d.H, TH);
   d.nWt = mode::cdiv(d.W, 32);
   d.ntiles = d.B * d.nHt * d.nWt;
   constexpr int PLANE = ((TH + 2 * DIL) * (32 + 2 * DIL)) | 1;
   const size_t lds = (size_t)CCH * PLANE * sizeof(float);
-  hipLaunchKernelGGL((conv2d_kernel<MT, TH, DIL>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack), y, d);
+  if (epi.shift)  // eval-mode layer with the folded BatchNorm epilogue: its own instantiation
+    hipLaunchKernelGGL((conv2d_kernel<MT, TH, DIL, true>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack), y,
+                       d, epi);
+  else
+    hipLaunchKernelGGL((conv2d_kernel<MT, TH, DIL, false>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack), y,
+                       d, epi);
   return mode::check_launch(who);
 }
 
 template <int DIL>
-int dispatch(const float* x, const float* wpack, float* y, const C2Dims& d, int MT, hipStream_t st, const char* who) {
+int dispatch(const float* x, const float* wpack, float* y, const C2Dims& d, int MT, hipStream_t st, const char* who, Epi epi) {
   // 8 rows per tile (two per wave) when that still gives every CU two workgroups, else 4
   const bool big = (long long)d.B * mode::cdiv(d.H, 8) * mode::cdiv(d.W, 32) >= 2 * kNumCU;
   switch (MT) {
-    case 1: return big ? launch<1, 8, DIL>(x, wpack, y, d, st, who) : launch<1, 4, DIL>(x, wpack, y, d, st, who);
-    case 2: return big ? launch<2, 8, DIL>(x, wpack, y, d, st, who) : launch<2, 4, DIL>(x, wpack, y, d, st, who);
-    case 3: return big ? launch<3, 8, DIL>(x, wpack, y, d, st, who) : launch<3, 4, DIL>(x, wpack, y, d, st, who);
-    default: return big ? launch<4, 8, DIL>(x, wpack, y, d, st, who) : launch<4, 4, DIL>(x, wpack, y, d, st, who);
+    case 1: return big ? launch<1, 8, DIL>(x, wpack, y, d, st, who, epi) : launch<1, 4, DIL>(x, wpack, y, d, st, who, epi);
+    case 2: return big ? launch<2, 8, DIL>(x, wpack, y, d, st, who, epi) : launch<2, 4, DIL>(x, wpack, y, d, st, who, epi);
+    case 3: return big ? launch<3, 8, DIL>(x, wpack, y, d, st, who, epi) : launch<3, 4, DIL>(x, wpack, y, d, st, who, epi);
+    default: return big ? launch<4, 8, DIL>(x, wpack, y, d, st, who, epi) : launch<4, 4, DIL>(x, wpack, y, d, st, who, epi);
   }
 }
 
 // rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels
 int run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip, hipStream_t st,
-        const char* who) {
+        const char* who, const mode_bn_epilogue* bn = nullptr) {
   MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
   MODE_REQUIRE(dilation == 1 || dilation == 2, MODE_ERR_UNSUPPORTED, "%s: dilation %d not implemented (1 or 2)", who, dilation);
   MODE_REQUIRE(rows <= 128, MODE_ERR_UNSUPPORTED, "%s: more than 128 output channels (%d) not supported", who, rows);
@@ -221,8 +234,10 @@ int run(const float* x, const float* w, float* y, float* wpack, int B, int K, in
   d.NCHUNK = mode::cdiv(K, CCH);
   const int MT = mode::cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 256;
-  hipLaunchKernelGGL(pack_w2d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, MT, d.NCHUNK, flip);
-  return dilation == 1 ? dispatch<1>(x, wpack, y, d, MT, st, who) : dispatch<2>(x, wpack, y, d, MT, st, who);
+  hipLaunchKernelGGL(pack_w2d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
+                     bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
+  return dilation == 1 ? dispatch<1>(x, wpack, y, d, MT, st, who, epi) : dispatch<2>(x, wpack, y, d, MT, st, who, epi);
 }
 
 }  // namespace
@@ -231,7 +246,7 @@ extern "C" size_t mode_conv2d_wpack_bytes(int Ci, int Co) {
   if (Ci <= 0 || Co <= 0) return 0;
   const size_t f = (size_t)mode::cdiv(Co, 32) * mode::cdiv(Ci, CCH) * 9 * 256;
   const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 9 * 256;
-  return (f > b ? f : b) * sizeof(float);
+  return ((f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32)) * sizeof(float);  // + the folded BatchNorm shifts
 }
 
 extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
@@ -242,4 +257,11 @@ extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* 
 extern "C" int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co,
                                     int dilation, mode_stream_t stream) {
   return run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data");
+}
+
+extern "C" int mode_conv2d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
+                                  int W, int Co, int dilation, mode_stream_t stream) {
+  int rc = mode::check_bn(bn, "mode_conv2d_fwd_bn");
+  if (rc != MODE_OK) return rc;
+  return run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd_bn", bn);
 }

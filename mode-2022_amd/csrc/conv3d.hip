@@ -41,8 +41,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 //   flip == 0: Wsrc(o,c,tap) = w[o][c][tap]            (forward; w is (Co,Ci,3,3,3), rows = Co, K = Ci)
 //   flip == 1: Wsrc(o,c,tap) = w[c][o][26 - tap]       (backward-data: rows = Ci of the conv, K = Co)
 //   flip == 2: Wsrc(o,c,tap) = w[c][o][tap]            (transposed conv: w is (Cin,Cout,3,3,3), rows = Cout, K = Cin)
-__global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip) {
+//   fold != 0: row o is scaled by the folded BatchNorm scale of `bn` and block 0 writes the shifts to wp[total + o] (common.h).
+__global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip,
+                         int fold, mode_bn_epilogue bn) {
   const long long total = (long long)MT * NCHUNK * 27 * 64 * 4;
+  if (fold && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) wp[total + o] = fold_shift(bn, o);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int cp = (int)(idx & 3);
@@ -57,6 +61,7 @@ __global__ void pack_w3d(const float* __restrict__ w, float* __restrict__ wp, in
     float v = 0.f;
     if (o < rows && c < K)
       v = flip == 0 ? w[((long long)o * K + c) * 27 + tap] : w[((long long)c * rows + o) * 27 + (flip == 1 ? 26 - tap : tap)];
+    if (fold && o < rows) v *= fold_scale(bn, o);
     wp[idx] = v;
   }
 }
@@ -68,9 +73,9 @@ __device__ __forceinline__ constexpr int tap_woff(int kw) {
   return S == 1 ? kw : (kw == 0 ? 0 : kw == 1 ? 33 : 1);
 }
 
-template <int MT, int TD, int TH, int S>
+template <int MT, int TD, int TH, int S, bool EPI>
 __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
-                                                    float* __restrict__ y, CDims d) {
+                                                    float* __restrict__ y, CDims d, Epi epi) {
   constexpr int R = TD * TH / 4;  // output rows per wave
   constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3;
   constexpr int IW = (S == 1) ? 34 : 65;
@@ -245,30 +250,40 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int o = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          if (o < d.Co) yb[o * oDHW + sp] = acc[m][r][q];
+          if (o < d.Co) {
+            const long long idx = o * oDHW + sp;
+            yb[idx] = EPI ? apply_epi(epi, acc[m][r][q], o, (long long)b * d.Co * oDHW + idx) : acc[m][r][q];
+          }
         }
     }
   }
 }
 
 template <int MT, int TD, int TH, int S>
-int launch_conv(const float* x, const float* wpack, float* y, CDims d, hipStream_t st, const char* who) {
+int launch_conv(const float* x, const float* wpack, float* y, CDims d, hipStream_t st, const char* who, Epi epi) {
   d.nWt = mode::cdiv(d.Wo, 32);
   d.nHt = mode::cdiv(d.Ho, TH);
   d.nDt = mode::cdiv(d.Do, TD);
   d.ntiles = d.B * d.nDt * d.nHt * d.nWt;
   constexpr int kRows = CCH * ((TD - 1) * S + 3) * ((TH - 1) * S + 3);
   const size_t lds = (size_t)kRows * (S == 1 ? 34 : 65) * sizeof(float) + (size_t)kRows * sizeof(int);  // tile + row table
-  int rc = mode::allow_lds(conv3d_kernel<MT, TD, TH, S>, lds, who);
+  if (epi.shift) {  // eval-mode layer with the folded BatchNorm epilogue: its own instantiation, the plain kernel is untouched
+    int rc = mode::allow_lds(conv3d_kernel<MT, TD, TH, S, true>, lds, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv3d_kernel<MT, TD, TH, S, true>), dim3(d.ntiles), dim3(NT), lds, st, x,
+                       reinterpret_cast<const float4*>(wpack), y, d, epi);
+    return mode::check_launch(who);
+  }
+  int rc = mode::allow_lds(conv3d_kernel<MT, TD, TH, S, false>, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL((conv3d_kernel<MT, TD, TH, S>), dim3(d.ntiles), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
-                     y, d);
+  hipLaunchKernelGGL((conv3d_kernel<MT, TD, TH, S, false>), dim3(d.ntiles), dim3(NT), lds, st, x,
+                     reinterpret_cast<const float4*>(wpack), y, d, epi);
   return mode::check_launch(who);
 }
 
 // rows = output channels of THIS GEMM (Co for forward, Ci for backward-data), K = its reduction channels.
 int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-              hipStream_t st, const char* who) {
+              hipStream_t st, const char* who, const mode_bn_epilogue* bn = nullptr) {
   CDims d;
   d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.Do = D; d.Ho = H; d.Wo = W;
@@ -276,23 +291,25 @@ int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int
   d.NCHUNK = mode::cdiv(K, CCH);
   MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, flip);
+  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, flip, bn ? 1 : 0,
+                     bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
   // tile choice: keep >= 2 workgroups per CU worth of tiles if possible
   const long long big = (long long)B * mode::cdiv(D, 2) * mode::cdiv(H, 8) * mode::cdiv(W, 32);
   const long long mid = (long long)B * mode::cdiv(D, 2) * mode::cdiv(H, 4) * mode::cdiv(W, 32);
   if (d.MT == 1) {
-    if (big >= 2 * kNumCU) return launch_conv<1, 2, 8, 1>(x, wpack, y, d, st, who);
-    if (mid >= 2 * kNumCU) return launch_conv<1, 2, 4, 1>(x, wpack, y, d, st, who);
-    return launch_conv<1, 1, 4, 1>(x, wpack, y, d, st, who);
+    if (big >= 2 * kNumCU) return launch_conv<1, 2, 8, 1>(x, wpack, y, d, st, who, epi);
+    if (mid >= 2 * kNumCU) return launch_conv<1, 2, 4, 1>(x, wpack, y, d, st, who, epi);
+    return launch_conv<1, 1, 4, 1>(x, wpack, y, d, st, who, epi);
   }
   // (the 2x8 tile with two output-channel tiles needs 268 registers -> one wave per SIMD; 2x4 keeps two)
-  if (mid >= 2 * kNumCU) return launch_conv<2, 2, 4, 1>(x, wpack, y, d, st, who);
-  return launch_conv<2, 1, 4, 1>(x, wpack, y, d, st, who);
+  if (mid >= 2 * kNumCU) return launch_conv<2, 2, 4, 1>(x, wpack, y, d, st, who, epi);
+  return launch_conv<2, 1, 4, 1>(x, wpack, y, d, st, who, epi);
 }
 
 // Stride-2 forward (also the backward-data of ConvTranspose3d k3 s2 p1 op1): output = ((X - 1) / 2 + 1).
 int conv3d_s2(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W,
-              hipStream_t st, const char* who) {
+              hipStream_t st, const char* who, const mode_bn_epilogue* bn = nullptr) {
   CDims d;
   d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.Do = (D - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1;
@@ -300,9 +317,11 @@ int conv3d_s2(const float* x, const float* w, float* y, float* wpack, int B, int
   d.NCHUNK = mode::cdiv(K, CCH);
   MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 0);
-  if (d.MT == 1) return launch_conv<1, 1, 4, 2>(x, wpack, y, d, st, who);
-  return launch_conv<2, 1, 4, 2>(x, wpack, y, d, st, who);
+  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 0, bn ? 1 : 0,
+                     bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
+  if (d.MT == 1) return launch_conv<1, 1, 4, 2>(x, wpack, y, d, st, who, epi);
+  return launch_conv<2, 1, 4, 2>(x, wpack, y, d, st, who, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -327,9 +346,9 @@ __host__ __device__ constexpr int deconv_wtap(int n) {
   return 0;
 }
 
-template <int TD, int TH>
+template <int TD, int TH, bool EPI>
 __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ x, const float4* __restrict__ wp,
-                                                      float* __restrict__ y, CDims d) {
+                                                      float* __restrict__ y, CDims d, Epi epi) {
   static_assert(TD * TH == 4, "one low-resolution row per wave");
   constexpr int ID = TD + 1, IH = TH + 1, IW = 33;
   constexpr int PLANE = ID * IH * IW;
@@ -456,7 +475,15 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int o = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          if (o < d.Co) *reinterpret_cast<float2*>(yb + o * oDHW + sp) = make_float2(acc[pd][ph][0][q], acc[pd][ph][1][q]);
+          if (o < d.Co) {
+            float2 v = make_float2(acc[pd][ph][0][q], acc[pd][ph][1][q]);
+            if (EPI) {
+              const long long idx = (long long)b * d.Co * oDHW + o * oDHW + sp;
+              v.x = apply_epi(epi, v.x, o, idx);
+              v.y = apply_epi(epi, v.y, o, idx + 1);
+            }
+            *reinterpret_cast<float2*>(yb + o * oDHW + sp) = v;
+          }
         }
       }
   }
@@ -465,22 +492,28 @@ __global__ __launch_bounds__(NT) void deconv3d_kernel(const float* __restrict__ 
 // x (B,K,D,H,W) -> y (B,rows,2D,2H,2W);  flip selects how `w` is indexed (see pack_w3d): 2 for ConvTranspose3d weights
 // (Cin,Cout,27), and also 2 for the backward-data of a stride-2 Conv3d whose weight is (Co,Ci,27) with K = Co, rows = Ci.
 int deconv3d(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
-             const char* who) {
+             const char* who, const mode_bn_epilogue* bn = nullptr) {
   CDims d;
   d.B = B; d.Ci = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.Do = 2 * D; d.Ho = 2 * H; d.Wo = 2 * W;
   d.MT = mode::cdiv(rows, 32);
   d.NCHUNK = mode::cdiv(K, CCH);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 2);
+  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 2, bn ? 1 : 0,
+                     bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
   constexpr int TD = 2, TH = 2;
   d.nWt = mode::cdiv(W, 32);
   d.nHt = mode::cdiv(H, TH);
   d.nDt = mode::cdiv(D, TD);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const size_t lds = (size_t)CCH * (TD + 1) * (TH + 1) * 33 * sizeof(float);
-  hipLaunchKernelGGL((deconv3d_kernel<TD, TH>), dim3(d.ntiles, d.MT), dim3(NT), lds, st, x, reinterpret_cast<const float4*>(wpack),
-                     y, d);
+  if (epi.shift)
+    hipLaunchKernelGGL((deconv3d_kernel<TD, TH, true>), dim3(d.ntiles, d.MT), dim3(NT), lds, st, x,
+                       reinterpret_cast<const float4*>(wpack), y, d, epi);
+  else
+    hipLaunchKernelGGL((deconv3d_kernel<TD, TH, false>), dim3(d.ntiles, d.MT), dim3(NT), lds, st, x,
+                       reinterpret_cast<const float4*>(wpack), y, d, epi);
   return mode::check_launch(who);
 }
 
@@ -501,7 +534,7 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
   if (Ci <= 0 || Co <= 0) return 0;
   const size_t f = (size_t)mode::cdiv(Co, 32) * mode::cdiv(Ci, CCH) * 27 * 256;
   const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 27 * 256;
-  return (f > b ? f : b) * sizeof(float);
+  return ((f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32)) * sizeof(float);  // + the folded BatchNorm shifts
 }
 
 extern "C" int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
@@ -511,6 +544,17 @@ extern "C" int mode_conv3d_fwd(const float* x, const float* w, float* y, float* 
   if (stride == 2) return conv3d_s2(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), "mode_conv3d_fwd");
   if (Co == 1) return mode::conv3d_co1_fwd(x, w, y, B, Ci, D, H, W, mode::as_stream(stream), "mode_conv3d_fwd");
   return conv3d_s1(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), "mode_conv3d_fwd");
+}
+
+extern "C" int mode_conv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
+                                  int D, int H, int W, int Co, int stride, mode_stream_t stream) {
+  const char* who = "mode_conv3d_fwd_bn";
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, stride, who, true);
+  if (rc == MODE_OK) rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE(Co > 1, MODE_ERR_UNSUPPORTED, "%s: the single-output-channel kernels have no epilogue", who);
+  if (stride == 2) return conv3d_s2(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who, bn);
+  return conv3d_s1(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, bn);
 }
 
 extern "C" int mode_conv3d_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
@@ -1163,4 +1207,14 @@ extern "C" int mode_deconv3d_fwd(const float* x, const float* w, float* y, float
   if (rc != MODE_OK || B == 0) return rc;
   MODE_REQUIRE((long long)Cout * D * H * W * 8 < (1ll << 31), MODE_ERR_UNSUPPORTED, "mode_deconv3d_fwd: output sample too large");
   return deconv3d(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), "mode_deconv3d_fwd");
+}
+
+extern "C" int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin,
+                                    int D, int H, int W, int Cout, mode_stream_t stream) {
+  const char* who = "mode_deconv3d_fwd_bn";
+  int rc = check_conv_args(x, w, y, wpack, B, Cin, D, H, W, Cout, 1, who);
+  if (rc == MODE_OK) rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE((long long)Cout * D * H * W * 8 < (1ll << 31), MODE_ERR_UNSUPPORTED, "%s: output sample too large", who);
+  return deconv3d(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who, bn);
 }

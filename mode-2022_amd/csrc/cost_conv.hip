@@ -17,8 +17,12 @@ namespace {
 constexpr int NT = 128;
 
 // grid = B*Co*H blocks; LDS = 9*(W+2) + 9*W floats.  R, T: (B, 9*Co, H, W) with channel = t*Co + o.
+// EPI: eval-mode BatchNorm (+ ReLU) of dres0[0] applied to the assembled value on its way out (scale and shift of channel o from
+// the four BatchNorm vectors, common.h); `add` is not supported here (dres0[0] has no residual).
+template <bool EPI>
 __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float* __restrict__ R, const float* __restrict__ T,
-                                                                    float* __restrict__ out, int B, int Co, int D, int H, int W) {
+                                                                    float* __restrict__ out, int B, int Co, int D, int H, int W,
+                                                                    mode_bn_epilogue bn) {
   extern __shared__ float sm[];
   float* Rl = sm;                  // [9][W+2], columns -1 and W are zeros
   float* Tl = sm + 9 * (W + 2);    // [9][W]
@@ -37,6 +41,11 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float*
   if (threadIdx.x < 18) Rl[(threadIdx.x >> 1) * (W + 2) + ((threadIdx.x & 1) ? W + 1 : 0)] = 0.f;
   __syncthreads();
   float* ob = out + (((long long)b * Co + o) * D) * HW + (long long)h * W;
+  float sc = 1.f, sh = 0.f;
+  if (EPI) {
+    sc = fold_scale(bn, o);
+    sh = fold_shift(bn, o);
+  }
   for (int w = threadIdx.x; w < W; w += NT) {
     float r[9];
 #pragma unroll
@@ -52,6 +61,10 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float*
           const int wp = w + kw - 1;
           if (wp >= dp && wp < W) acc += r[kd * 3 + kw] + Tl[(kd * 3 + kw) * W + wp - dp];
         }
+      }
+      if (EPI) {
+        acc = fmaf(acc, sc, sh);
+        if (bn.relu) acc = fmaxf(acc, 0.f);
       }
       ob[(long long)d * HW + w] = acc;
     }
@@ -154,17 +167,34 @@ int check_args(const void* a, const void* b, const void* c, int B, int Co, int D
 
 }  // namespace
 
-extern "C" int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W,
-                                           mode_stream_t stream) {
-  const char* who = "mode_cost_conv_assemble_fwd";
+namespace {
+template <bool EPI>
+int assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W, mode_stream_t stream,
+                 const mode_bn_epilogue& bn, const char* who) {
   int rc = check_args(R, T, out, B, Co, D, H, W, who);
   if (rc != MODE_OK || B == 0) return rc;
   const size_t lds = (size_t)(9 * (W + 2) + 9 * W) * sizeof(float);
   MODE_REQUIRE(lds <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: W = %d too wide for the row buffers", who, W);
-  rc = mode::allow_lds(cost_conv_assemble_fwd_kernel, lds, who);
+  rc = mode::allow_lds(cost_conv_assemble_fwd_kernel<EPI>, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(cost_conv_assemble_fwd_kernel, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), R, T, out, B, Co, D, H, W);
+  hipLaunchKernelGGL(cost_conv_assemble_fwd_kernel<EPI>, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), R, T, out, B, Co, D,
+                     H, W, bn);
   return mode::check_launch(who);
+}
+}  // namespace
+
+extern "C" int mode_cost_conv_assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W,
+                                           mode_stream_t stream) {
+  return assemble_fwd<false>(R, T, out, B, Co, D, H, W, stream, mode_bn_epilogue(), "mode_cost_conv_assemble_fwd");
+}
+
+extern "C" int mode_cost_conv_assemble_fwd_bn(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, int B, int Co,
+                                              int D, int H, int W, mode_stream_t stream) {
+  const char* who = "mode_cost_conv_assemble_fwd_bn";
+  int rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(bn->add == nullptr, MODE_ERR_UNSUPPORTED, "%s: no residual input on this layer", who);
+  return assemble_fwd<true>(R, T, out, B, Co, D, H, W, stream, *bn, who);
 }
 
 extern "C" int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W,

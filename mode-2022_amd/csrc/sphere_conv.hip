@@ -103,8 +103,12 @@ __device__ __forceinline__ float sample(const float* __restrict__ xc, unsigned p
 //
 // forward:  wp[((g*MT + mt)*NCHUNK + ch)*KK + quad][lane][j] = W[g*Cog + mt*32 + (lane&31)][ch*8 + kl/KK][kl%KK],
 //           kl = 2*(quad*4 + j) + (lane>>5), zero outside the real weight.
-__global__ void pack_w_fwd(const float* __restrict__ w, float* __restrict__ wp, Dims d) {
+//           fold != 0: output channel co is scaled by the folded BatchNorm scale of `bn`; block 0 writes the shifts to
+//           wp[total + channel] (common.h).
+__global__ void pack_w_fwd(const float* __restrict__ w, float* __restrict__ wp, Dims d, int fold, mode_bn_epilogue bn) {
   const long long total = (long long)d.G * d.MT * d.NCHUNK * d.KK * 64 * 4;
+  if (fold && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < d.Co; o += blockDim.x) wp[total + o] = fold_shift(bn, o);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(idx & 3);
@@ -156,10 +160,10 @@ __global__ void pack_w_bwd(const float* __restrict__ w, float* __restrict__ wp, 
 // KT = compile-time tap count (9 for the 3x3 kernels of the network) enables the software pipeline: the 4*2*KT corner
 // loads of the NEXT chunk are issued into registers before the MFMA phase of the current chunk and combined / written to
 // the other LDS buffer after it, so the gather latency hides under the MFMAs.  KT = 0: generic tap count, no pipelining.
-template <int KT>
+template <int KT, bool EPI>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                const float4* __restrict__ wp, float* __restrict__ y,
-                                                               Dims dd) {
+                                                               Dims dd, Epi epi) {
   Dims d = dd;
   if (KT > 0) d.KK = KT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,8 +285,15 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_kernel(const float* __res
       const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (co < d.Cog) {
         const int px = pix0 + (lane & 31);
-        if (px < d.npix) yb[(long long)co * d.npix + px] = acc0[r];
-        if (px + 32 < d.npix) yb[(long long)co * d.npix + px + 32] = acc1[r];
+        const long long i0 = (long long)co * d.npix + px;
+        if (EPI) {  // eval mode: folded BatchNorm shift (+ residual) (+ ReLU) on the way out
+          const int ch = g * d.Cog + co;
+          if (px < d.npix) yb[i0] = apply_epi(epi, acc0[r], ch, (yb - y) + i0);
+          if (px + 32 < d.npix) yb[i0 + 32] = apply_epi(epi, acc1[r], ch, (yb - y) + i0 + 32);
+        } else {
+          if (px < d.npix) yb[i0] = acc0[r];
+          if (px + 32 < d.npix) yb[i0 + 32] = acc1[r];
+        }
       }
     }
   }
@@ -829,7 +840,7 @@ size_t wpack_floats(const Dims& d) {
   const size_t f = (size_t)d.G * d.MT * d.NCHUNK * d.KK * 256;
   const size_t bw = (size_t)d.G * d.NB * 4 * d.KSQ * 256;
   const size_t adj = (size_t)d.G * mode::cdiv(d.Cig, 32) * mode::cdiv(d.Cog, CCH) * d.KK * 256;
-  return std::max(f, std::max(bw, adj));
+  return std::max(f, std::max(bw, adj)) + (size_t)d.Co;  // + the folded BatchNorm shifts of the *_bn entry point
 }
 
 int bww_splits(const Dims& d, int MG) {
@@ -848,9 +859,20 @@ extern "C" size_t mode_sphere_conv_wpack_bytes(int Ci, int Co, int Kh, int Kw, i
   return wpack_floats(d) * sizeof(float);
 }
 
-extern "C" int mode_sphere_conv_fwd(const float* x, const float* pos, const float* w, float* y, float* wpack, int B, int Ci,
-                                    int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups,
-                                    mode_stream_t stream) {
+namespace {
+template <int KT, bool EPI>
+int launch_fwd(const float* x, const float* pos, const float* wpack, float* y, const Dims& d, dim3 grid, size_t lds, hipStream_t st,
+               const Epi& epi) {
+  int rc = mode::allow_lds(sphere_fwd_kernel<KT, EPI>, lds, "mode_sphere_conv_fwd");
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL((sphere_fwd_kernel<KT, EPI>), grid, dim3(NTHREADS), lds, st, x, pos, reinterpret_cast<const float4*>(wpack), y, d, epi);
+  return mode::check_launch("mode_sphere_conv_fwd");
+}
+}  // namespace
+
+static int sphere_conv_fwd_impl(const float* x, const float* pos, const float* w, float* y, float* wpack, int B, int Ci, int H, int W,
+                                int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups, mode_stream_t stream,
+                                const mode_bn_epilogue* bn) {
   MODE_REQUIRE(x && pos && w && y && wpack, MODE_ERR_BAD_ARG, "mode_sphere_conv_fwd: null pointer");
   Dims d;
   int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, "mode_sphere_conv_fwd");
@@ -858,19 +880,27 @@ extern "C" int mode_sphere_conv_fwd(const float* x, const float* pos, const floa
   if (B == 0) return MODE_OK;
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.MT * d.NCHUNK * d.KK * 256;
-  hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
   const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)CCH * d.KK * P * 4;
   const dim3 grid(B * d.tps, mode::cdiv(d.MT, 4), d.G);
-  if (d.KK == 9) {  // the 3x3 kernels of the network: software-pipelined gather
-    rc = mode::allow_lds(sphere_fwd_kernel<9>, lds, "mode_sphere_conv_fwd");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_fwd_kernel<9>, grid, dim3(NTHREADS), lds, st, x, pos, reinterpret_cast<const float4*>(wpack), y, d);
-  } else {
-    rc = mode::allow_lds(sphere_fwd_kernel<0>, lds, "mode_sphere_conv_fwd");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_fwd_kernel<0>, grid, dim3(NTHREADS), lds, st, x, pos, reinterpret_cast<const float4*>(wpack), y, d);
-  }
-  return mode::check_launch("mode_sphere_conv_fwd");
+  if (d.KK == 9)  // the 3x3 kernels of the network: software-pipelined gather
+    return bn ? launch_fwd<9, true>(x, pos, wpack, y, d, grid, lds, st, epi) : launch_fwd<9, false>(x, pos, wpack, y, d, grid, lds, st, epi);
+  return bn ? launch_fwd<0, true>(x, pos, wpack, y, d, grid, lds, st, epi) : launch_fwd<0, false>(x, pos, wpack, y, d, grid, lds, st, epi);
+}
+
+extern "C" int mode_sphere_conv_fwd(const float* x, const float* pos, const float* w, float* y, float* wpack, int B, int Ci,
+                                    int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho, int Wo, int groups,
+                                    mode_stream_t stream) {
+  return sphere_conv_fwd_impl(x, pos, w, y, wpack, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, stream, nullptr);
+}
+
+extern "C" int mode_sphere_conv_fwd_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y,
+                                       float* wpack, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int sH, int sW, int Ho,
+                                       int Wo, int groups, mode_stream_t stream) {
+  int rc = mode::check_bn(bn, "mode_sphere_conv_fwd_bn");
+  if (rc != MODE_OK) return rc;
+  return sphere_conv_fwd_impl(x, pos, w, y, wpack, B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, groups, stream, bn);
 }
 
 extern "C" int mode_sphere_conv_bwd_data(const float* gy, const float* pos, const float* w, float* gx, float* wpack, int B,

@@ -64,8 +64,11 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // wp[(((g*MG + mg)*NCH + ch)*KT + tap)*MTW + m][lane] (float4 = 4 k-steps) = W[g*Cog + mg*128 + m*32 + (lane&31)][ch*8 + 2*s + (lane>>5)][tap]
-__global__ void pack_w_win(const float* __restrict__ w, float* __restrict__ wp, WinDims d) {
+//   fold != 0: output channel co is scaled by the folded BatchNorm scale of `bn`; block 0 writes the shifts to wp[total + channel]
+__global__ void pack_w_win(const float* __restrict__ w, float* __restrict__ wp, WinDims d, int fold, mode_bn_epilogue bn) {
   const long long total = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
+  if (fold && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < d.Co; o += blockDim.x) wp[total + o] = fold_shift(bn, o);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int s = (int)(idx & 3);
     const int lane = (int)((idx >> 2) & 63);
@@ -81,7 +84,10 @@ __global__ void pack_w_win(const float* __restrict__ w, float* __restrict__ wp, 
     const int co = mg * 128 + m * 32 + (lane & 31);
     const int c = ch * CCH + 2 * s + (lane >> 5);
     float v = 0.f;
-    if (co < d.Cog && c < d.Cig) v = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
+    if (co < d.Cog && c < d.Cig) {
+      v = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
+      if (fold) v *= fold_scale(bn, g * d.Cog + co);
+    }
     wp[idx] = v;
   }
 }
@@ -89,9 +95,10 @@ __global__ void pack_w_win(const float* __restrict__ w, float* __restrict__ wp, 
 // One tile.  WR_T > 0: compile-time window rows; WR_T == 0: window rows = d.wr (wrap-around class).  PIPE: double-buffered,
 // the next chunk's rows are prefetched into registers under the MFMA phase, in NPH phases of CCH/NPH channels each (a tall
 // window has too many rows to hold a whole chunk in registers); otherwise single buffer, staged in place.
-template <int WR_T, bool PIPE, int NRB, int NPH>
+template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI>
 __device__ __forceinline__ void fwd_tile(const float* __restrict__ x, const float* __restrict__ pos, const float4* __restrict__ wp,
-                                         float* __restrict__ y, const WinDims& d, int h0, int w0, int rbase, int cbase, float* smem) {
+                                         float* __restrict__ y, const WinDims& d, int h0, int w0, int rbase, int cbase, float* smem,
+                                         const Epi& epi) {
   const int WRP = WR_T > 0 ? WR_T : d.wr;
   const int CP = chan_pitch(WRP);
   const int bufsz = CCH * CP;
@@ -274,35 +281,44 @@ __device__ __forceinline__ void fwd_tile(const float* __restrict__ x, const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cmax) yb[(long long)co * HW] = acc[m][r];
+        if (co < cmax) {
+          if (EPI) {  // eval mode: folded BatchNorm shift (+ residual) (+ ReLU) on the way out
+            const int ch = g * d.Cog + mg * 128 + co;
+            yb[(long long)co * HW] = apply_epi(epi, acc[m][r], ch, (yb - y) + (long long)co * HW);
+          } else {
+            yb[(long long)co * HW] = acc[m][r];
+          }
+        }
       }
   }
 }
 
 // grid = (tiles, B, G*MG); tiles[i] = (h0, w0, rbase, cbase | class << 16).  All window classes run in ONE launch so that
 // the few tall-window tiles next to the poles overlap with the rest instead of forming an under-filled tail of their own.
+template <bool EPI>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                    const float4* __restrict__ wp, float* __restrict__ y, WinDims d,
-                                                                   const int4* __restrict__ tiles) {
+                                                                   const int4* __restrict__ tiles, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int4 t = tiles[blockIdx.x];  // (list order = tall-window tiles first; an XCD-contiguous order would pile them on one XCD)
   const int cls = t.w >> 16, cbase = t.w & 0xffff;
   if (cls == 0)
-    fwd_tile<WR_SMALL, true, (WR_SMALL + SROWS - 1) / SROWS, 1>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+    fwd_tile<WR_SMALL, true, (WR_SMALL + SROWS - 1) / SROWS, 1, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
   else if (cls == 1)
-    fwd_tile<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+    fwd_tile<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
   else
-    fwd_tile<0, true, WR_PIPE_MAX / SROWS, 4>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem);
+    fwd_tile<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
 }
 
 // Wrap-around tiles of images too tall for the double-buffered form (H + 1 > 320 rows, or more LDS than there is): single
 // buffer, staged in place.  A kernel of its own so that its register needs do not weigh on the main one.
+template <bool EPI>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_win_tall_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                         const float4* __restrict__ wp, float* __restrict__ y,
-                                                                        WinDims d, const int4* __restrict__ tiles) {
+                                                                        WinDims d, const int4* __restrict__ tiles, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int4 t = tiles[blockIdx.x];  // (list order = tall-window tiles first; an XCD-contiguous order would pile them on one XCD)
-  fwd_tile<0, false, 1, 1>(x, pos, wp, y, d, t.x, t.y, t.z, t.w & 0xffff, smem);
+  fwd_tile<0, false, 1, 1, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, t.w & 0xffff, smem, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -852,12 +868,18 @@ extern "C" int mode_sphere_plan_build(const float* pos_host, int H, int W, int K
 extern "C" size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups) {
   if (Ci <= 0 || Co <= 0 || groups <= 0 || Kh * Kw != KT || Ci % groups || Co % groups) return 0;
   const int Cig = Ci / groups, Cog = Co / groups;
-  return (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 * sizeof(float);
+  return ((size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 + (size_t)Co) * sizeof(float);  // + shifts
 }
 
-extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, float* y, float* wpack,
-                                        const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co,
-                                        int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+namespace {
+template <bool EPI>
+int fwd_win_launch(const float* x, const float* pos, float* y, const float* wpack, const int32_t* tiles, int n_small, int n_mid,
+                   int n_wrap, int B, const WinDims& d, hipStream_t st, const Epi& epi);
+}
+
+static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const float* w, float* y, float* wpack, const int32_t* tiles,
+                                    int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                    int transposed, mode_stream_t stream, const mode_bn_epilogue* bn) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_fwd_win");
   if (rc != MODE_OK) return rc;
@@ -873,16 +895,26 @@ extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const 
   MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "mode_sphere_conv_fwd_win: grid limit");
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
-  hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack);
+  return bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, n_small, n_mid, n_wrap, B, d, st, epi)
+            : fwd_win_launch<false>(x, pos, y, wpack, tiles, n_small, n_mid, n_wrap, B, d, st, epi);
+}
+
+namespace {
+template <bool EPI>
+int fwd_win_launch(const float* x, const float* pos, float* y, const float* wpack, const int32_t* tiles, int n_small, int n_mid,
+                   int n_wrap, int B, const WinDims& d, hipStream_t st, const Epi& epi) {
   // tile list order: wrap-around tiles, then mid, then small
   const float4* wp4 = reinterpret_cast<const float4*>(wpack);
   const int4* tl = reinterpret_cast<const int4*>(tiles);
   int n_main = n_small + n_mid + n_wrap;
+  int rc = MODE_OK;
   if (n_wrap > 0 && !d.wrap_pipe) {
     const size_t lds = win_lds_bytes(d.wr, false);
-    rc = mode::allow_lds(sphere_fwd_win_tall_kernel, lds, "mode_sphere_conv_fwd_win");
+    rc = mode::allow_lds(sphere_fwd_win_tall_kernel<EPI>, lds, "mode_sphere_conv_fwd_win");
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_fwd_win_tall_kernel, dim3(n_wrap, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl);
+    hipLaunchKernelGGL(sphere_fwd_win_tall_kernel<EPI>, dim3(n_wrap, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl, epi);
     tl += n_wrap;
     n_main -= n_wrap;
     n_wrap = 0;
@@ -892,11 +924,27 @@ extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const 
     if (n_small > 0) lds = std::max(lds, win_lds_bytes(WR_SMALL, true));
     if (n_mid > 0) lds = std::max(lds, win_lds_bytes(WR_MID, true));
     if (n_wrap > 0) lds = std::max(lds, win_lds_bytes(d.wr, true));
-    rc = mode::allow_lds(sphere_fwd_win_kernel, lds, "mode_sphere_conv_fwd_win");
+    rc = mode::allow_lds(sphere_fwd_win_kernel<EPI>, lds, "mode_sphere_conv_fwd_win");
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_fwd_win_kernel, dim3(n_main, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl);
+    hipLaunchKernelGGL(sphere_fwd_win_kernel<EPI>, dim3(n_main, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wp4, y, d, tl, epi);
   }
   return mode::check_launch("mode_sphere_conv_fwd_win");
+}
+}  // namespace
+
+extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, float* y, float* wpack,
+                                        const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co,
+                                        int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream,
+                                  nullptr);
+}
+
+extern "C" int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y,
+                                           float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H,
+                                           int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  int rc = mode::check_bn(bn, "mode_sphere_conv_fwd_win_bn");
+  if (rc != MODE_OK) return rc;
+  return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream, bn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -42,17 +42,23 @@ SIGNATURES = {
                                         [_c_ptr] * 3),
     'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_fwd_bn': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_fwd_win_bn': (_c_int, [_c_ptr] * 7 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_volume_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_conv2d_wpack_bytes': (_c_size, [_c_int] * 2),
     'mode_conv2d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv2d_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 5),
     'mode_conv2d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
+    'mode_cost_conv_assemble_fwd_bn': (_c_int, [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_conv_assemble_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_conv3d_wpack_bytes': (_c_size, [_c_int] * 2),
     'mode_conv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_conv3d_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 7 + [_c_ptr]),
+    'mode_deconv3d_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 7),
     'mode_deconv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
@@ -74,7 +80,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 8  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 9  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 
@@ -99,6 +105,12 @@ def lib():
                              'mode-2022_amd/mode_hip/build.py)' % (have, ABI_VERSION))
         _lib = handle
   return _lib
+
+
+class BnEpilogue(ctypes.Structure):
+  """struct mode_bn_epilogue of include/mode_hip.h (host-side struct of device pointers)."""
+  _fields_ = [('gamma', _c_ptr), ('beta', _c_ptr), ('mean', _c_ptr), ('var', _c_ptr), ('eps', ctypes.c_float), ('add', _c_ptr),
+              ('relu', _c_int)]
 
 
 def check(rc, what):

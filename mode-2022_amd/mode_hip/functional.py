@@ -5,7 +5,7 @@ import threading
 
 import torch
 
-from . import check, lib, profiling, ptr, require_f32c, require_gpu, stream_of
+from . import BnEpilogue, check, lib, profiling, ptr, require_f32c, require_gpu, stream_of
 
 
 # ------------------------------------------------------------------------------------ cost volume
@@ -556,17 +556,21 @@ _conv_tables = {}
 _conv_table_lock = threading.Lock()
 
 
-def conv2d_table(H, W, kh, kw, stride, pad, dil, device):
-  """(1, 2*kh*kw, H, W) float32 table on `device`: channel 2k = row, 2k+1 = column read by tap k at the output pixel whose
-  top-left input position is (h, w) (the operator samples it at (h_out*stride, w_out*stride), cu:206-261).  Cached."""
-  key = (H, W, kh, kw, tuple(stride), tuple(pad), tuple(dil), str(device))
+MAX_TAPS = 32  # tap limit of the general gather-and-MAC kernels (csrc/sphere_conv.hip)
+
+
+def conv2d_table(H, W, kh, kw, stride, pad, dil, device, row0=0):
+  """(1, 2*kh*kw, H, W) float32 table on `device`: channel 2k = row, 2k+1 = column read by tap k = (i, j) at the output pixel
+  whose top-left input position is (h, w) (the operator samples it at (h_out*stride, w_out*stride), cu:206-261); tap rows are
+  numbered from `row0` (a kernel with more than MAX_TAPS taps runs as several row bands).  Cached."""
+  key = (H, W, kh, kw, tuple(stride), tuple(pad), tuple(dil), str(device), row0)
   with _conv_table_lock:
     t = _conv_tables.get(key)
     if t is None:
       hh = torch.arange(H, dtype=torch.float32).view(H, 1).expand(H, W)
       ww = torch.arange(W, dtype=torch.float32).view(1, W).expand(H, W)
       planes = []
-      for i in range(kh):
+      for i in range(row0, row0 + kh):
         for j in range(kw):
           planes += [hh + float(i * dil[0] - pad[0]), ww + float(j * dil[1] - pad[1])]
       t = _conv_tables[key] = torch.stack(planes, 0).unsqueeze(0).contiguous().to(device)
@@ -575,8 +579,14 @@ def conv2d_table(H, W, kh, kw, stride, pad, dil, device):
 
 def conv2d_tabled_supported(x, conv):
   return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None and
-          conv.padding_mode == 'zeros' and not isinstance(conv.padding, str) and
+          conv.padding_mode == 'zeros' and not isinstance(conv.padding, str) and conv.kernel_size[1] <= MAX_TAPS and
           x.shape[2] >= conv.kernel_size[0] and x.shape[3] >= conv.kernel_size[1])
+
+
+def _row_bands(kh, kw):
+  """[(first row, rows)] with rows * kw <= MAX_TAPS each: 3x3 -> [(0, 3)], 7x7 -> [(0, 4), (4, 3)]."""
+  per = max(1, MAX_TAPS // kw)
+  return [(r, min(per, kh - r)) for r in range(0, kh, per)]
 
 
 class Conv2dTabledFunction(torch.autograd.Function):
@@ -588,27 +598,54 @@ class Conv2dTabledFunction(torch.autograd.Function):
     Co, _, kh, kw = w.shape
     Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
     Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
-    pos = conv2d_table(H, W, kh, kw, stride, pad, dil, x.device)
     y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
-    sphere_conv_fwd(x, pos, w, y, stride, 1)
-    ctx.save_for_backward(x, w, pos)
-    ctx.stride = tuple(stride)
+    bands = _row_bands(kh, kw)
+    for r0, rows in bands:
+      pos = conv2d_table(H, W, rows, kw, stride, pad, dil, x.device, r0)
+      if len(bands) == 1:
+        sphere_conv_fwd(x, pos, w, y, stride, 1)
+      else:  # y = sum over the row bands of the kernel
+        part = y if r0 == 0 else torch.empty_like(y)
+        sphere_conv_fwd(x, pos, w[:, :, r0:r0 + rows].contiguous(), part, stride, 1)
+        if r0:
+          y += part
+    ctx.save_for_backward(x, w)
+    ctx.geom = (tuple(stride), tuple(pad), tuple(dil))
     return y
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, gy):
-    x, w, pos = ctx.saved_tensors
+    x, w = ctx.saved_tensors
+    stride, pad, dil = ctx.geom
+    H, W = x.shape[2:]
+    kh, kw = w.shape[2:]
     gy = gy.contiguous()
+    bands = _row_bands(kh, kw)
     gx = None
     if ctx.needs_input_grad[0]:
       gx = torch.empty_like(x)
-      sphere_conv_bwd_data(gy, pos, w, gx, ctx.stride, 1, overwrite=True)
+      for r0, rows in bands:
+        pos = conv2d_table(H, W, rows, kw, stride, pad, dil, x.device, r0)
+        if len(bands) == 1:
+          sphere_conv_bwd_data(gy, pos, w, gx, stride, 1, overwrite=True)
+        else:
+          part = gx if r0 == 0 else torch.empty_like(gx)
+          sphere_conv_bwd_data(gy, pos, w[:, :, r0:r0 + rows].contiguous(), part, stride, 1, overwrite=True)
+          if r0:
+            gx += part
     gw = None
     if ctx.needs_input_grad[1]:
       sink = grad_sink(w)
       gw = sink if sink is not None else torch.zeros_like(w)
-      sphere_conv_bwd_weight(gy, pos, x, gw, ctx.stride, 1)
+      for r0, rows in bands:
+        pos = conv2d_table(H, W, rows, kw, stride, pad, dil, x.device, r0)
+        if len(bands) == 1:
+          sphere_conv_bwd_weight(gy, pos, x, gw, stride, 1)
+        else:
+          part = torch.zeros((w.shape[0], w.shape[1], rows, kw), dtype=w.dtype, device=w.device)
+          sphere_conv_bwd_weight(gy, pos, x, part, stride, 1)
+          gw[:, :, r0:r0 + rows] += part
       if sink is not None:
         gw = None
     return gx, gw, None, None, None
@@ -951,3 +988,184 @@ def bn_act(bn, y, add=None, relu=False, groups=1):
     out = out + add if add is not None else out
     return torch.relu(out) if relu else out
   return bn_eval(y, add, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+
+
+# ------------------------------------------------------------------------------------ eval mode: convolution + folded BatchNorm
+# In inference every convbn / convbn_3d / sphereConvbn block (models/submodule.py:15-22, 61-74) is ONE launch: the BatchNorm
+# scale goes into the packed weights, shift / residual add / ReLU into the store of the convolution kernel (the *_bn entry points
+# of include/mode_hip.h).  No BatchNorm launch is left in an eval forward, and the un-normalised convolution result never
+# reaches HBM.
+def bn_foldable(bn, y_like=None):
+  """Eval-mode BatchNorm with running statistics and affine parameters, fp32 on the GPU."""
+  return (not bn.training and bn.running_mean is not None and bn.weight is not None and bn.bias is not None and bn.weight.is_cuda and
+          bn.weight.dtype == torch.float32 and not torch.is_grad_enabled())
+
+
+def _epilogue(bn, add, relu, out):
+  """(ctypes struct, tensors to keep alive): `add` must have the layout of `out`."""
+  keep = [bn.weight.detach().contiguous(), bn.bias.detach().contiguous(), bn.running_mean.contiguous(), bn.running_var.contiguous()]
+  if add is not None:
+    add = add.contiguous()
+    require_gpu(add)
+    require_f32c(add)
+    if tuple(add.shape) != tuple(out.shape):
+      raise RuntimeError('residual input %s does not match the output %s' % (tuple(add.shape), tuple(out.shape)))
+    keep.append(add)
+  e = BnEpilogue(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), float(bn.eps), ptr(add) if add is not None else None, int(bool(relu)))
+  return e, keep
+
+
+def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
+  """relu?(bn(conv3d(x, w, stride, padding 1)) [+ add]) with bn in eval mode; Co > 1."""
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.detach().contiguous()
+  require_f32c(x, w)
+  B, Ci, D, H, W = x.shape
+  Co = w.shape[0]
+  y = torch.empty((B, Co, _out3(D, stride), _out3(H, stride), _out3(W, stride)), dtype=x.dtype, device=x.device)
+  e, keep = _epilogue(bn, add, relu, y)
+  flops = 2 * y.numel() * Ci * 27
+  with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
+                                                 flops, x.device):
+    wp = _wpack3d(Ci, Co, x.device)
+    check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
+          'mode_conv3d_fwd_bn')
+  return y
+
+
+def deconv3d_bn_eval(x, w, bn, add=None, relu=False):
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.detach().contiguous()
+  require_f32c(x, w)
+  B, Cin, D, H, W = x.shape
+  Cout = w.shape[1]
+  y = torch.empty((B, Cout, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+  e, keep = _epilogue(bn, add, relu, y)
+  flops = 2 * x.numel() * Cout * 27
+  with torch.cuda.device_of(x), profiling.region('deconv3d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+    wp = _wpack3d(Cin, Cout, x.device)
+    check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
+          'mode_deconv3d_fwd_bn')
+  return y
+
+
+def conv2d_bn_eval(x, w, bn, dilation=1, add=None, relu=False):
+  """Stride-1 3x3 convolution with padding = dilation (1 | 2) + eval BatchNorm (+ add) (+ ReLU)."""
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.detach().contiguous()
+  require_f32c(x, w)
+  B, Ci, H, W = x.shape
+  Co = w.shape[0]
+  y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device)
+  e, keep = _epilogue(bn, add, relu, y)
+  flops = 2 * y.numel() * Ci * 9
+  with torch.cuda.device_of(x), profiling.region('conv2d_bn_eval[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
+                                                 else 'conv2d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+    wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
+    check(lib().mode_conv2d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
+          'mode_conv2d_fwd_bn')
+  return y
+
+
+def sphere_conv_bn_eval(x, pos, w, bn, stride, groups, add=None, relu=False, transposed=False):
+  """Spherical (or integer-table) convolution + eval BatchNorm (+ add) (+ ReLU).  transposed: x, add and the result are in
+  plane-transposed storage (B, C, W, H) -- only with a plannable table (sphere_t_supported)."""
+  require_gpu(x, pos, w)
+  x, w = x.contiguous(), w.detach().contiguous()
+  require_f32c(x, pos, w)
+  Co, _, Kh, Kw = w.shape
+  if transposed:
+    B, Ci, W, H = x.shape
+    y = torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
+  else:
+    B, Ci, H, W = x.shape
+    Ho, Wo = (H - 1) // stride[0] + 1, (W - 1) // stride[1] + 1  # (the table carries padding / dilation: 'same' geometry)
+    y = None
+  plan = None
+  if tuple(stride) == (1, 1) and Kh * Kw == 9:
+    plan = sphere_plan(pos, Kh, Kw)
+    if plan is not None and not transposed:
+      n_wg = sum(plan[1]) * B * groups * (-(-(Co // groups) // 128))
+      if n_wg < SPHERE_FWD_MIN_WG:
+        plan = None
+  if transposed and plan is None:
+    raise RuntimeError('sphere_conv_bn_eval: plane-transposed storage needs a plannable sampling table')
+  flops = 2 * B * Co * H * W // (stride[0] * stride[1]) * w[0].numel()
+  name = 'sphere_conv_bn_eval[%d->%d %dx%d]' % (Ci, Co, H, W) if profiling.ENABLED else 'sphere_conv_bn_eval'
+  with torch.cuda.device_of(x), profiling.region(name, 4 * (2 * x.numel() + w.numel()), flops, x.device):
+    if plan is not None:
+      tiles, (n0, n1, n2) = plan[:2]
+      wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+      if transposed:
+        e, keep = _epilogue(bn, add, relu, y)
+        check(lib().mode_sphere_conv_fwd_win_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci,
+                                                H, W, Co, Kh, Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win_bn')
+      else:  # NCHW caller: the windowed kernel on plane-transposed copies (the residual is transposed with it)
+        xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
+        e, keep = _epilogue(bn, transpose_planes(add.contiguous()) if add is not None else None, relu, yt)
+        check(lib().mode_sphere_conv_fwd_win_bn(ptr(xt), ptr(pos), ptr(w), ctypes.byref(e), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci,
+                                                H, W, Co, Kh, Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win_bn')
+        y = transpose_planes(yt)
+    else:
+      y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
+      e, keep = _epilogue(bn, add, relu, y)
+      wp = _wpack(w, groups)
+      check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
+                                          stride[1], Ho, Wo, groups, stream_of(x)), 'mode_sphere_conv_fwd_bn')
+  return y
+
+
+def conv2d_tabled_bn_eval(x, conv, bn, add=None, relu=False):
+  """nn.Conv2d `conv` (anything but the stride-1 3x3 layers) + eval BatchNorm (+ add) (+ ReLU) on the gather-and-MAC kernel; a
+  kernel with more than MAX_TAPS taps (the 7x7 stem) runs its first row bands plainly and the epilogue on the last."""
+  x = x.contiguous()
+  w = conv.weight.detach().contiguous()
+  B, Ci, H, W = x.shape
+  Co, _, kh, kw = w.shape
+  stride, pad, dil = tuple(conv.stride), tuple(conv.padding), tuple(conv.dilation)
+  Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
+  Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
+  bands = _row_bands(kh, kw)
+  if len(bands) == 1:
+    pos = conv2d_table(H, W, kh, kw, stride, pad, dil, x.device)
+    y = _tabled_bn(x, pos, w, bn, stride, add, relu, Ho, Wo)
+    return y
+  # several bands (the 7x7 stem): every band would need the scale, and only the last one the shift -- not worth a second epilogue
+  # form for one 3 -> 32 layer: the bands run plainly and one fused BatchNorm pass follows (a 67 MB tensor, once per image pair)
+  y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
+  for r0, rows in bands:
+    pos = conv2d_table(H, W, rows, kw, stride, pad, dil, x.device, r0)
+    part = y if r0 == 0 else torch.empty_like(y)
+    sphere_conv_fwd(x, pos, w[:, :, r0:r0 + rows].contiguous(), part, stride, 1)
+    if r0:
+      y += part
+  return bn_eval(y, add, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+
+
+def _tabled_bn(x, pos, w, bn, stride, add, relu, Ho, Wo):
+  B, Ci, H, W = x.shape
+  Co, _, Kh, Kw = w.shape
+  y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
+  e, keep = _epilogue(bn, add, relu, y)
+  flops = 2 * y.numel() * w[0].numel()
+  name = 'sphere_conv_bn_eval[%d->%d %dx%d]' % (Ci, Co, H, W) if profiling.ENABLED else 'sphere_conv_bn_eval'
+  with torch.cuda.device_of(x), profiling.region(name, 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
+    wp = _wpack(w, 1)
+    check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
+                                        stride[1], Ho, Wo, 1, stream_of(x)), 'mode_sphere_conv_fwd_bn')
+  return y
+
+
+def cost_conv_bn_eval(ref, tgt, weight, d4, bn, relu=True):
+  """relu?(bn(conv3d(cost_volume(ref, tgt, d4), weight))) in eval mode, without the volume (cost_conv + folded BatchNorm)."""
+  C = ref.shape[1]
+  R, T = _tap_products(ref, weight[:, :C]), _tap_products(tgt, weight[:, C:])
+  require_f32c(R, T)
+  B, C9, H, W = R.shape
+  Co = C9 // 9
+  out = torch.empty((B, Co, d4, H, W), dtype=R.dtype, device=R.device)
+  e, keep = _epilogue(bn, None, relu, out)
+  with torch.cuda.device_of(R), profiling.region('cost_conv_assemble_fwd', 4 * (R.numel() + T.numel() + out.numel()), 0, R.device):
+    check(lib().mode_cost_conv_assemble_fwd_bn(ptr(R), ptr(T), ctypes.byref(e), ptr(out), B, Co, d4, H, W, stream_of(R)),
+          'mode_cost_conv_assemble_fwd_bn')
+  return out

@@ -274,6 +274,21 @@ class SphereConv(nn.Module):
     return sphere_conv(x, self.position_on(x.device), self.weight, self.bias, self.stride, self.padding, self.dilation,
                        self.groups)
 
+  def forward_bn(self, x, bn, add=None, relu=False):
+    """Inference only (an extension; the reference has no counterpart): relu?(bn(self(x)) [+ add]) with `bn` in eval mode as ONE
+    launch -- the BatchNorm folded into the convolution kernel (models/stage3d.conv_bn).  None if this layer has no fused form."""
+    if self.bias is not None or self.dilation != (1, 1):
+      return None
+    pos = self.position_on(x.device)
+    if getattr(_tls, 'transposed', False):
+      if not self.supports_transposed_io(x.shape[0], x.device):
+        raise RuntimeError('SphereConv: this layer cannot run on plane-transposed storage (see supports_transposed_io)')
+      return _F.sphere_conv_bn_eval(x, pos, self.weight, bn, self.stride, self.groups, add, relu, transposed=True)
+    if SphereConvFunction._infer_shape(self, x, self.weight)[2:] != ((x.shape[2] - 1) // self.stride[0] + 1,
+                                                                     (x.shape[3] - 1) // self.stride[1] + 1):
+      return None  # (not the 'same' geometry the fused entry assumes)
+    return _F.sphere_conv_bn_eval(x, pos, self.weight, bn, self.stride, self.groups, add, relu)
+
   def supports_transposed_io(self, batch, device):
     """Whether forward() can run inside `with transposed_io()` for this batch size: stride 1, 3x3, no bias, a sampling table
     the windowed kernels can plan, and enough tiles to fill the chip."""

@@ -121,8 +121,11 @@ class ModeDisparity(nn.Module):
         HF.cost_conv_supported(ref_fea, self.maxdisp // 4, conv0.out_channels)):
       # the volume is constant along d in its reference half and a function of w-d in its target half: its first convolution
       # collapses to 18 small 2-D products and one assembly pass (HF.cost_conv), and the 402.7 MB volume is never built
-      y0 = HF.cost_conv(ref_fea, tgt_fea, conv0.weight, self.maxdisp // 4)
-      cost0 = stage3d.bn_act(self.dres0[0][1], y0, None, True)
+      if HF.bn_foldable(self.dres0[0][1]):  # inference: the BatchNorm + ReLU inside the assembly kernel
+        cost0 = HF.cost_conv_bn_eval(ref_fea, tgt_fea, conv0.weight, self.maxdisp // 4, self.dres0[0][1], relu=True)
+      else:
+        y0 = HF.cost_conv(ref_fea, tgt_fea, conv0.weight, self.maxdisp // 4)
+        cost0 = stage3d.bn_act(self.dres0[0][1], y0, None, True)
     else:
       cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
       cost0 = stage3d.conv_bn(self.dres0[0], cost, relu=True)

@@ -60,9 +60,36 @@ def conv3(conv, x):
 
 
 def conv_bn(seq, x, relu=False, add=None):
-  """seq = Sequential(Conv3d | ConvTranspose3d, BatchNorm3d): y = bn(conv(x)) [+ add] [relu]
-  (convbn_3d submodule.py:20-22; transposed form mode_disparity.py:23, 25)."""
-  return bn_act(seq[1], conv3(seq[0], x), add, relu)
+  """seq = Sequential(Conv2d | SphereConv | Conv3d | ConvTranspose3d, BatchNorm): y = bn(conv(x)) [+ add] [relu]
+  (convbn / convbn_3d / sphereConvbn submodule.py:15-22, 61-74; transposed form mode_disparity.py:23, 25).
+  Inference (eval mode, no autograd): ONE launch per layer -- the BatchNorm is folded into the convolution kernel (scale into the
+  packed weights, shift / residual / ReLU into its store), so an eval forward contains no BatchNorm launch at all."""
+  conv, bn = seq[0], seq[1]
+  if x.is_cuda and x.dtype == torch.float32 and HF.bn_foldable(bn):
+    y = _conv_bn_folded(conv, bn, x, add, relu)
+    if y is not None:
+      return y
+  return bn_act(bn, conv3(conv, x), add, relu)
+
+
+def _conv_bn_folded(conv, bn, x, add, relu):
+  """The layer as one fused launch, or None when no fused form exists for it (then: convolution, then the fused BatchNorm pass)."""
+  kind = _hip_kind(conv, x)
+  if kind == 'conv1' and conv.out_channels > 1:
+    return HF.conv3d_bn_eval(x, conv.weight, bn, 1, add, relu)
+  if kind == 'conv2':
+    return HF.conv3d_bn_eval(x, conv.weight, bn, 2, add, relu)
+  if kind == 'deconv':
+    return HF.deconv3d_bn_eval(x, conv.weight, bn, add, relu)
+  if hasattr(conv, 'forward_bn'):  # SphereConv
+    return conv.forward_bn(x, bn, add, relu)
+  if type(conv) is nn.Conv2d and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros':
+    if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation in ((1, 1), (2, 2)) and \
+        HF._conv2d_own(x, conv.weight):
+      return HF.conv2d_bn_eval(x, conv.weight, bn, conv.dilation[0], add, relu)
+    if HF.conv2d_tabled_supported(x, conv):
+      return HF.conv2d_tabled_bn_eval(x, conv, bn, add, relu)
+  return None
 
 
 # nn.DataParallel (train_disparity.py:264-265 and the other reference call sites) runs forward() of one replica per GPU on

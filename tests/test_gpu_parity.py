@@ -11,7 +11,8 @@ size 1024x512 / 192 (B=1, configs[1] forward and the per-sample share of configs
     on the 8x8 block means of ALL pixels;
   * loss to 2e-5 relative;
   * parameter gradients: relative L2 error per tensor <= max(1e-3, 5 x the reference's own fp32-vs-fp64 error of that tensor),
-    estimated from 16 Rademacher projections stored in the fixture (E <e, v>^2 = |e|^2), plus 32 sampled entries per tensor.
+    estimated from 16 Rademacher projections stored in the fixture (E <e, v>^2 = |e|^2), plus 32 sampled entries per tensor
+    (median at the L2 level, maximum within 100x of it).
     (The extractor's gradients are a ~1e-3 residual after ~60 BatchNorm backward passes: the reference's own fp32 gradients
     there are only good to 1e-3 .. 4e-3 relative, so 1e-3 cannot be asked of them; the 3-D stage is held to 1e-3.)
 The ill-conditioned random-init fixtures of round 1 (tests/test_gpu_model.py) stay as the stress tier."""
@@ -92,9 +93,14 @@ def test_train_outputs_and_gradients_within_1e3_of_the_reference(golden, tag):
     if not name.startswith('feature_extraction'):
       worst_3d = max(worst_3d, rel)
     assert rel <= bound, (name, rel, bound)
+    # 32 sampled entries: round-off of a back-propagated gradient is heavy-tailed over the entries of a tensor (the reference's own
+    # fp32 run against fp64: median 7e-5 rms, 99th percentile 1e-3 rms, maximum 1e-2 rms at config 1), hence a robust pair of
+    # bounds -- the median at the L2 level, every entry within 100x of it (0.1 rms at most: a wrong entry is O(1) rms)
     idx = z['train/grad_idx'][i]
     rms = norm / np.sqrt(g.size)
-    assert np.abs(g[idx] - z['train/grad_val'][i]).max() <= 10.0 * bound * rms + 1e-12, (name, 'sampled entries')
+    diff = np.abs(g[idx] - z['train/grad_val'][i])
+    assert np.median(diff) <= 3.0 * bound * rms + 1e-12, (name, 'sampled entries: median', float(np.median(diff)), bound * rms)
+    assert diff.max() <= 100.0 * bound * rms + 1e-12, (name, 'sampled entries: max', float(diff.max()), bound * rms)
   print('%s: relative L2 error of the parameter gradients (243 tensors): worst %.3e, worst outside the extractor %.3e' % (tag, worst, worst_3d))
 
 
