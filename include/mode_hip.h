@@ -229,6 +229,45 @@ int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpac
 /* convbn (models/submodule.py:15-17) in eval mode as one launch: mode_conv2d_fwd with the folded-BatchNorm epilogue. */
 int mode_conv2d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
                        int W, int Co, int dilation, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1x1 convolutions of the extractor (nn.Conv2d(kernel_size=1), models/submodule.py:162, 167-174: the `downsample` branches and
+ * lastconv[0] / lastconv[4]; stride 1 or 2, no bias) as plain MFMA GEMMs over the NCHW planes -- csrc/conv1x1.hip.
+ *   x (B, Ci, H, W)   w (Co, Ci[, 1, 1])   y (B, Co, Ho, Wo),  Ho = (H - 1) / stride + 1
+ *   bwd_data WRITES gx (zeros where a stride-2 layer never read); bwd_weight writes gw (accumulate = 0) or adds to it, needs
+ *   Wo % 4 == 0 (stride 2: W % 8 == 0) and `workspace` >= mode_conv1x1_bwd_weight_workspace_bytes().  Deterministic. */
+size_t mode_conv1x1_wpack_bytes(int Ci, int Co);
+
+int mode_conv1x1_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int stride,
+                     mode_stream_t stream);
+
+int mode_conv1x1_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
+                        int W, int Co, int stride, mode_stream_t stream);
+
+int mode_conv1x1_bwd_data(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int stride,
+                          mode_stream_t stream);
+
+size_t mode_conv1x1_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co, int stride);
+
+int mode_conv1x1_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
+                            int stride, int accumulate, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The stem of the extractor: Conv2d(3 -> 32, kernel 7, stride 2, padding 3, no bias) on the full-resolution image
+ * (firstconv[0], models/submodule.py:155) -- csrc/conv_stem.hip.  The image carries no gradient: forward and weight gradient only.
+ *   x (B, 3, H, W)   w (Co <= 32, 3, 7, 7)   y (B, Co, Ho, Wo),  Ho = (H - 1) / 2 + 1
+ *   bwd_weight writes gw (accumulate = 0) or adds to it; `workspace` >= mode_conv_stem_bwd_weight_workspace_bytes().  Deterministic. */
+size_t mode_conv_stem_wpack_bytes(int Ci, int Co);
+
+int mode_conv_stem_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, mode_stream_t stream);
+
+int mode_conv_stem_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
+                          int W, int Co, mode_stream_t stream);
+
+size_t mode_conv_stem_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co);
+
+int mode_conv_stem_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
+                              int accumulate, mode_stream_t stream);
 size_t mode_conv2d_bwd_weight_workspace_bytes(int B, int Ci, int H, int W, int Co);
 int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                            int dilation, int accumulate, mode_stream_t stream);

@@ -125,7 +125,10 @@ __global__ void pack_w_fwd(const float* __restrict__ w, float* __restrict__ wp, 
     const int tap = kl % d.KK;
     const int co = mt * 32 + (lane & 31);
     float v = 0.f;
-    if (co < d.Cog && c < d.Cig) v = w[((long long)(g * d.Cog + co) * d.Cig + c) * d.KK + tap];
+    if (co < d.Cog && c < d.Cig) {
+      v = w[((long long)(g * d.Cog + co) * d.Cig + c) * d.KK + tap];
+      if (fold) v *= fold_scale(bn, g * d.Cog + co);
+    }
     wp[idx] = v;
   }
 }

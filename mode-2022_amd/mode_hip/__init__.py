@@ -52,6 +52,17 @@ SIGNATURES = {
     'mode_conv2d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 5),
     'mode_conv2d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_conv1x1_wpack_bytes': (_c_size, [_c_int] * 2),
+    'mode_conv1x1_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv1x1_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv1x1_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv1x1_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 6),
+    'mode_conv1x1_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_conv_stem_wpack_bytes': (_c_size, [_c_int] * 2),
+    'mode_conv_stem_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr]),
+    'mode_conv_stem_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 5 + [_c_ptr]),
+    'mode_conv_stem_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 5),
+    'mode_conv_stem_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd_bn': (_c_int, [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_conv_assemble_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),

@@ -546,6 +546,145 @@ def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
   return gw
 
 
+# ------------------------------------------------------------------------------------ 1x1 Conv2d (stride 1 | 2): plain MFMA GEMMs
+def conv1x1_supported(x, conv):
+  """The extractor's 1x1 layers (downsample branches, lastconv[0], lastconv[4]) on csrc/conv1x1.hip; the weight gradient loads
+  16-byte row pieces, hence the divisibility conditions (other shapes run on the integer-table kernels)."""
+  if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.groups == 1 and
+          conv.bias is None and conv.padding == (0, 0) and conv.stride in ((1, 1), (2, 2))):
+    return False
+  H, W = x.shape[2:]
+  s = conv.stride[0]
+  return ((W - 1) // s + 1) % 4 == 0 and (s == 1 or W % 8 == 0) and max(conv.in_channels, conv.out_channels) * H * W < 2**31
+
+
+def _tag1(name, ci, co, s, h, w):
+  return '%s[%d->%d s%d %dx%d]' % (name, ci, co, s, h, w) if profiling.ENABLED else name
+
+
+def conv1x1_fwd(x, w, stride=1, bn=None, add=None, relu=False):
+  """y = conv2d(x, w (Co, Ci, 1, 1), stride); with bn: relu?(eval-mode bn(y) [+ add]) in the same launch."""
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.detach().contiguous() if bn is not None else w.contiguous()
+  require_f32c(x, w)
+  B, Ci, H, W = x.shape
+  Co = w.shape[0]
+  y = torch.empty((B, Co, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=x.dtype, device=x.device)
+  flops = 2 * y.numel() * Ci
+  with torch.cuda.device_of(x), profiling.region(_tag1('conv1x1_fwd', Ci, Co, stride, H, W), 4 * (x.numel() // stride**2 + y.numel() + w.numel()),
+                                                 flops, x.device):
+    wp = torch.empty(lib().mode_conv1x1_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
+    if bn is None:
+      check(lib().mode_conv1x1_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, H, W, Co, stride, stream_of(x)), 'mode_conv1x1_fwd')
+    else:
+      e, keep = _epilogue(bn, add, relu, y)
+      check(lib().mode_conv1x1_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stride, stream_of(x)),
+            'mode_conv1x1_fwd_bn')
+  return y
+
+
+class Conv1x1Function(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, w, stride):
+    ctx.save_for_backward(x, w)
+    ctx.stride = stride
+    return conv1x1_fwd(x, w, stride)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    x, w, gy = x.contiguous(), w.contiguous(), gy.contiguous()
+    B, Ci, H, W = x.shape
+    Co, s = w.shape[0], ctx.stride
+    gx = None
+    if ctx.needs_input_grad[0]:
+      gx = torch.empty_like(x)
+      with torch.cuda.device_of(x), profiling.region(_tag1('conv1x1_bwd_data', Ci, Co, s, H, W), 4 * (gx.numel() + gy.numel() + w.numel()),
+                                                     2 * gy.numel() * Ci, x.device):
+        wp = torch.empty(lib().mode_conv1x1_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
+        check(lib().mode_conv1x1_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, H, W, Co, s, stream_of(x)), 'mode_conv1x1_bwd_data')
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = sink if sink is not None else torch.empty_like(w)
+      with torch.cuda.device_of(x), profiling.region(_tag1('conv1x1_bwd_weight', Ci, Co, s, H, W), 4 * (x.numel() // s**2 + gy.numel() + w.numel()),
+                                                     2 * gy.numel() * Ci, x.device):
+        ws = torch.empty(max(lib().mode_conv1x1_bwd_weight_workspace_bytes(B, Ci, H, W, Co, s) // 4, 1), dtype=torch.float32, device=x.device)
+        check(lib().mode_conv1x1_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, s, int(sink is not None), stream_of(x)),
+              'mode_conv1x1_bwd_weight')
+      if sink is not None:
+        gw = None
+    return gx, gw, None
+
+
+def conv1x1(x, conv):
+  return Conv1x1Function.apply(x, conv.weight, conv.stride[0])
+
+
+# ------------------------------------------------------------------------------------ the 7x7 stride-2 stem (3 -> 32)
+def conv_stem_supported(x, conv):
+  """firstconv[0] (submodule.py:155): Conv2d(3, <= 32, 7, stride 2, padding 3), on an input that needs no gradient."""
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and
+          conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels == 3 and
+          conv.out_channels <= 32 and conv.padding_mode == 'zeros' and not (torch.is_grad_enabled() and x.requires_grad) and
+          32 * x.shape[2] * x.shape[3] < 2**31)
+
+
+def conv_stem_fwd(x, w, bn=None, add=None, relu=False):
+  require_gpu(x, w)
+  x, w = x.contiguous(), w.detach().contiguous() if bn is not None else w.contiguous()
+  require_f32c(x, w)
+  B, Ci, H, W = x.shape
+  Co = w.shape[0]
+  y = torch.empty((B, Co, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+  with torch.cuda.device_of(x), profiling.region(_tag1('conv_stem_fwd', Ci, Co, 2, H, W), 4 * (x.numel() + y.numel() + w.numel()),
+                                                 2 * y.numel() * Ci * 49, x.device):
+    wp = torch.empty(lib().mode_conv_stem_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
+    if bn is None:
+      check(lib().mode_conv_stem_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, H, W, Co, stream_of(x)), 'mode_conv_stem_fwd')
+    else:
+      e, keep = _epilogue(bn, add, relu, y)
+      check(lib().mode_conv_stem_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stream_of(x)),
+            'mode_conv_stem_fwd_bn')
+  return y
+
+
+class ConvStemFunction(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, w):
+    ctx.save_for_backward(x, w)
+    return conv_stem_fwd(x, w)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    if ctx.needs_input_grad[0]:
+      raise RuntimeError('conv_stem: the stem kernels have no input gradient (conv_stem_supported excludes such inputs)')
+    gw = None
+    if ctx.needs_input_grad[1]:
+      x, gy = x.contiguous(), gy.contiguous()
+      B, Ci, H, W = x.shape
+      Co = w.shape[0]
+      sink = grad_sink(w)
+      gw = sink if sink is not None else torch.empty_like(w)
+      with torch.cuda.device_of(x), profiling.region(_tag1('conv_stem_bwd_weight', Ci, Co, 2, H, W), 4 * (x.numel() + gy.numel() + w.numel()),
+                                                     2 * gy.numel() * Ci * 49, x.device):
+        ws = torch.empty(max(lib().mode_conv_stem_bwd_weight_workspace_bytes(B, Ci, H, W, Co) // 4, 1), dtype=torch.float32, device=x.device)
+        check(lib().mode_conv_stem_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, int(sink is not None), stream_of(x)),
+              'mode_conv_stem_bwd_weight')
+      if sink is not None:
+        gw = None
+    return None, gw
+
+
+def conv_stem(x, conv):
+  return ConvStemFunction.apply(x, conv.weight)
+
+
 # ------------------------------------------------------------------------------------ any other Conv2d: gather-and-MAC on an integer table
 # The extractor's remaining regular convolutions -- 7x7 stride 2 (stem), 3x3 stride 2, 1x1 (stride 1 and 2); submodule.py:155,
 # 158, 162, 167-174 -- are the spherical operator with an INTEGER sampling table: tap (i, j) of output pixel (h, w) reads input
@@ -578,9 +717,17 @@ def conv2d_table(H, W, kh, kw, stride, pad, dil, device, row0=0):
 
 
 def conv2d_tabled_supported(x, conv):
-  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None and
+  """The operator reads its table at (h_out * stride, w_out * stride): the output grid must fit into the input grid (any 'same'
+  or shrinking geometry; a convolution padded beyond that stays with the vendor library)."""
+  if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None and
           conv.padding_mode == 'zeros' and not isinstance(conv.padding, str) and conv.kernel_size[1] <= MAX_TAPS and
-          x.shape[2] >= conv.kernel_size[0] and x.shape[3] >= conv.kernel_size[1])
+          x.shape[2] >= conv.kernel_size[0] and x.shape[3] >= conv.kernel_size[1]):
+    return False
+  for n, k, s, p, d in zip(x.shape[2:], conv.kernel_size, conv.stride, conv.padding, conv.dilation):
+    out = (n + 2 * p - (d * (k - 1) + 1)) // s + 1
+    if out < 1 or (out - 1) * s > n - 1:
+      return False
+  return True
 
 
 def _row_bands(kh, kw):

@@ -53,6 +53,10 @@ def conv3(conv, x):
         return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
     elif HF._conv2d_own(x, conv.weight):
       return HF.conv2d_fwd(x.contiguous(), conv.weight.detach().contiguous(), conv.dilation[0])
+  if type(conv) is nn.Conv2d and HF.conv_stem_supported(x, conv):
+    return HF.conv_stem(x, conv)  # firstconv[0]: 7x7 stride 2 on the image (csrc/conv_stem.hip)
+  if type(conv) is nn.Conv2d and HF.conv1x1_supported(x, conv):
+    return HF.conv1x1(x, conv)  # downsample branches, lastconv[0] / [4]: plain MFMA GEMMs over the planes (csrc/conv1x1.hip)
   if type(conv) is nn.Conv2d and HF.conv2d_tabled_supported(x, conv):
     # every other regular convolution (7x7 stride 2, 3x3 stride 2, 1x1): the gather-and-MAC kernels on an integer table
     return HF.conv2d_tabled(x, conv)
@@ -87,6 +91,10 @@ def _conv_bn_folded(conv, bn, x, add, relu):
     if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation in ((1, 1), (2, 2)) and \
         HF._conv2d_own(x, conv.weight):
       return HF.conv2d_bn_eval(x, conv.weight, bn, conv.dilation[0], add, relu)
+    if HF.conv_stem_supported(x, conv):
+      return HF.conv_stem_fwd(x, conv.weight, bn, add, relu)
+    if HF.conv1x1_supported(x, conv):
+      return HF.conv1x1_fwd(x, conv.weight, conv.stride[0], bn, add, relu)
     if HF.conv2d_tabled_supported(x, conv):
       return HF.conv2d_tabled_bn_eval(x, conv, bn, add, relu)
   return None

@@ -581,8 +581,8 @@ def test_conv2d_on_the_integer_table(B, Ci, Co, H, W, k, s, p, d):
   from models import stage3d
   with torch.no_grad():
     via_module = stage3d.conv3(conv, x.to(DEV))
-  if (k, s, p) == (3, 1, d):  # a stride-1 3x3 layer has kernels of its own (csrc/conv2d.hip): same result up to summation order
-    assert (via_module - y.detach()).abs().max() < tol * max(1.0, float(y_ref.abs().max()))
+  if (k, s, p) == (3, 1, d) or k in (1, 7):  # layers with kernels of their own (conv2d.hip, conv1x1.hip, conv_stem.hip): same
+    assert (via_module - y.detach()).abs().max() < tol * max(1.0, float(y_ref.abs().max()))  # result up to summation order
   else:
     assert torch.equal(via_module, y.detach())
 
@@ -761,70 +761,94 @@ def _unfused(bn, y, add, relu):
   return torch.relu(y) if relu else y
 
 
-@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True), (False, False)])
-def test_folded_batchnorm_epilogues_match_the_two_step_form(relu, with_add):
-  """Every *_bn entry point (conv3d stride 1 / 2, transposed conv, regular 3x3 conv2d, spherical conv on the general and the
-  windowed kernel incl. plane-transposed storage, integer-table conv2d, cost_conv assembly) against convolution -> fp64 eval
-  BatchNorm (+ add) (+ ReLU), with torch.no_grad (the fused form is inference only)."""
-  import torch.nn as nn
+FOLD_VARIANTS = [(True, False), (False, True), (True, True), (False, False)]
+
+
+@pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
+def test_folded_batchnorm_conv3d(relu, with_add):
+  """mode_conv3d_fwd_bn (stride 1 with one and two output-channel tiles, stride 2) and mode_deconv3d_fwd_bn against convolution ->
+  fp64 eval BatchNorm (+ add) (+ ReLU), under torch.no_grad (the fused form is inference only)."""
   import torch.nn.functional as F
-  from models.basic import SphereConv
-  from models.basic.spherical_conv import sphere_conv as sc
   with torch.no_grad():
-    # 3-D: stride 1 (one and two output-channel tiles), stride 2, transposed
     for (ci, co, stride) in ((8, 32, 1), (20, 40, 1), (16, 24, 2)):
       x, w = _rand((2, ci, 6, 10, 36), 91).to(DEV), _rand((co, ci, 3, 3, 3), 92, 0.1).to(DEV)
       bn = _eval_bn(co, 93)
-      want = F.conv3d(x.double(), w.double(), None, stride, 1)
+      want = F.conv3d(x.cpu().double(), w.cpu().double(), None, stride, 1).to(DEV)
       add = _rand(tuple(want.shape), 94).to(DEV) if with_add else None
       got = HF.conv3d_bn_eval(x, w, bn, stride, add, relu)
-      assert (got.double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
+      assert (got.double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (ci, co, stride)
     x, w = _rand((2, 24, 3, 5, 34), 95).to(DEV), _rand((24, 40, 3, 3, 3), 96, 0.1).to(DEV)
     bn = _eval_bn(40, 97)
-    want = F.conv_transpose3d(x.double(), w.double(), None, 2, 1, 1)
+    want = F.conv_transpose3d(x.cpu().double(), w.cpu().double(), None, 2, 1, 1).to(DEV)
     add = _rand(tuple(want.shape), 98).to(DEV) if with_add else None
     assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
-    # 2-D 3x3 (dilation 1, 2)
-    for dil in (1, 2):
-      x, w = _rand((2, 20, 9, 40), 99).to(DEV), _rand((40, 20, 3, 3), 100, 0.1).to(DEV)
-      bn = _eval_bn(40, 101, 2)
-      want = F.conv2d(x.double(), w.double(), None, 1, dil, dil)
-      add = _rand(tuple(want.shape), 102).to(DEV) if with_add else None
-      assert (HF.conv2d_bn_eval(x, w, bn, dil, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
-    # integer-table layers (1x1, 3x3 stride 2, the 7x7 stem) through the module route
-    from models import stage3d
-    for (ci, co, k, s, p) in ((16, 24, 1, 1, 0), (16, 24, 3, 2, 1), (8, 8, 1, 2, 0), (3, 32, 7, 2, 3)):
-      conv = nn.Conv2d(ci, co, k, s, p, bias=False).to(DEV)
-      x = _rand((2, ci, 16, 24), 103).to(DEV)
-      bn = _eval_bn(co, 104, 2)
-      want = conv.double()(x.double())
-      conv.float()
-      add = _rand(tuple(want.shape), 105).to(DEV) if with_add else None
-      seq = nn.Sequential(conv, bn).eval()
-      assert (stage3d.conv_bn(seq, x, relu, add).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
-    # spherical convolution: general kernel (small geometry) and windowed kernel (NCHW caller and plane-transposed storage)
-    for (ih, iw, B) in ((16, 32, 2), (64, 128, 4)):
-      m = SphereConv(iw, ih, 'Cassini', 16, 32, 3, 1, 1, 1, 1, False).to(DEV)
-      H, W = m.position.shape[2:]
-      x = _rand((B, 16, H, W), 106).to(DEV)
-      bn = _eval_bn(32, 107, 2)
-      want = sphere_conv_ref.forward(x.cpu().double(), m.position, m.weight.detach().cpu().double(), (1, 1), (1, 1), (1, 1), 1).to(DEV)
-      add = _rand(tuple(want.shape), 108).to(DEV) if with_add else None
-      ref = _unfused(bn, want, add, relu)
-      assert (m.forward_bn(x, bn, add, relu).double() - ref).abs().max() < 1e-4
-      if m.supports_transposed_io(B, x.device):
-        with sc.transposed_io():
-          got_t = m.forward_bn(HF.transpose_planes(x), bn, HF.transpose_planes(add) if add is not None else None, relu)
-        assert (HF.transpose_planes(got_t).double() - ref).abs().max() < 1e-4
-      else:
-        assert (ih, iw) == (16, 32)
-    # cost volume + dres0[0] + BatchNorm + ReLU
-    if not with_add:
-      fr, ft = _rand((2, 8, 6, 20), 109).to(DEV), _rand((2, 8, 6, 20), 110).to(DEV)
-      w = _rand((12, 16, 3, 3, 3), 111, 0.1).to(DEV)
-      bn = _eval_bn(12, 112)
-      want = F.conv3d(mode_ref.cost_volume(fr.cpu().double(), ft.cpu().double(), 5), w.cpu().double(), None, 1, 1).to(DEV)
-      assert (HF.cost_conv_bn_eval(fr, ft, w, 5, bn, relu).double() - _unfused(bn, want, None, relu)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
+@pytest.mark.parametrize('dil', [1, 2])
+def test_folded_batchnorm_conv2d_3x3(dil, relu, with_add):
+  import torch.nn.functional as F
+  with torch.no_grad():
+    x, w = _rand((2, 20, 9, 40), 99).to(DEV), _rand((40, 20, 3, 3), 100, 0.1).to(DEV)
+    bn = _eval_bn(40, 101, 2)
+    want = F.conv2d(x.cpu().double(), w.cpu().double(), None, 1, dil, dil).to(DEV)
+    add = _rand(tuple(want.shape), 102).to(DEV) if with_add else None
+    assert (HF.conv2d_bn_eval(x, w, bn, dil, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
+@pytest.mark.parametrize('ci,co,k,s,p', [(16, 24, 1, 1, 0), (16, 24, 3, 2, 1), (8, 8, 1, 2, 0), (3, 32, 7, 2, 3), (6, 40, 5, 1, 2), (16, 24, 1, 1, 1), (5, 7, 1, 1, 0)])
+def test_folded_batchnorm_other_conv2d_layers(ci, co, k, s, p, relu, with_add):
+  """Sequential(Conv2d, BatchNorm2d).eval() through stage3d.conv_bn: the 1x1 GEMM kernels, the 7x7 stem and the integer-table
+  gather kernels with the folded-BatchNorm epilogue."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  from models import stage3d
+  with torch.no_grad():
+    conv = nn.Conv2d(ci, co, k, s, p, bias=False).to(DEV)
+    x = _rand((2, ci, 16, 24), 103).to(DEV)
+    bn = _eval_bn(co, 104, 2)
+    want = F.conv2d(x.cpu().double(), conv.weight.detach().cpu().double(), None, s, p).to(DEV)
+    add = _rand(tuple(want.shape), 105).to(DEV) if with_add else None
+    seq = nn.Sequential(conv, bn).eval()
+    got = stage3d.conv_bn(seq, x, relu, add)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert (got.double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
+@pytest.mark.parametrize('ih,iw,B', [(16, 32, 2), (64, 128, 8)])
+def test_folded_batchnorm_sphere_conv(ih, iw, B, relu, with_add):
+  """SphereConv.forward_bn: the general kernel (small geometry), the windowed kernel behind an NCHW caller and on plane-transposed
+  storage."""
+  from models.basic import SphereConv
+  from models.basic.spherical_conv import sphere_conv as sc
+  with torch.no_grad():
+    m = SphereConv(iw, ih, 'Cassini', 16, 32, 3, 1, 1, 1, 1, False).to(DEV)
+    H, W = m.position.shape[2:]
+    x = _rand((B, 16, H, W), 106).to(DEV)
+    bn = _eval_bn(32, 107, 2)
+    want = sphere_conv_ref.forward(x.cpu().double(), m.position, m.weight.detach().cpu().double(), (1, 1), (1, 1), (1, 1), 1).to(DEV)
+    add = _rand(tuple(want.shape), 108).to(DEV) if with_add else None
+    ref = _unfused(bn, want, add, relu)
+    assert (m.forward_bn(x, bn, add, relu).double() - ref).abs().max() < 1e-4
+    if m.supports_transposed_io(B, x.device):
+      with sc.transposed_io():
+        got_t = m.forward_bn(HF.transpose_planes(x), bn, HF.transpose_planes(add) if add is not None else None, relu)
+      assert (HF.transpose_planes(got_t).double() - ref).abs().max() < 1e-4
+    else:
+      assert (ih, iw) == (16, 32)
+
+
+@pytest.mark.parametrize('relu', [True, False])
+def test_folded_batchnorm_cost_conv(relu):
+  import torch.nn.functional as F
+  with torch.no_grad():
+    fr, ft = _rand((2, 8, 6, 20), 109).to(DEV), _rand((2, 8, 6, 20), 110).to(DEV)
+    w = _rand((12, 16, 3, 3, 3), 111, 0.1).to(DEV)
+    bn = _eval_bn(12, 112)
+    want = F.conv3d(mode_ref.cost_volume(fr.cpu().double(), ft.cpu().double(), 5), w.cpu().double(), None, 1, 1).to(DEV)
+    assert (HF.cost_conv_bn_eval(fr, ft, w, 5, bn, relu).double() - _unfused(bn, want, None, relu)).abs().max() < 1e-4
 
 
 def test_eval_forward_launches_no_batchnorm_kernel():
@@ -835,9 +859,14 @@ def test_eval_forward_launches_no_batchnorm_kernel():
   net = models.ModeDisparity(32, 'Sphere', 128, 64, 'Cassini').to(DEV)
   net.load_state_dict(recipe.recipe_state_wc(recipe.load_manifest(), 77))  # well conditioned: round-off stays round-off
   left, right = [t.to(DEV) for t in recipe.recipe_images(2, 128, 64, 78)]
+  bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+  for m in bns:
+    m.momentum = 1.0  # running statistics := this batch's statistics, so that eval mode is as well conditioned as train mode
   net.train()
   with torch.no_grad():
-    net(left, right)  # running statistics away from (0, 1)
+    net(left, right)
+  for m in bns:
+    m.momentum = 0.1
   net.eval()
   profiling.enable(True)
   with torch.no_grad():
@@ -854,3 +883,85 @@ def test_eval_forward_launches_no_batchnorm_kernel():
   finally:
     HF.bn_foldable = saved
   assert (folded - plain).abs().max() < 2e-4, float((folded - plain).abs().max())
+
+
+# ------------------------------------------------------------------ 1x1 Conv2d layers: plain MFMA GEMMs (a3)
+@pytest.mark.parametrize('B,Ci,Co,H,W,s', [
+    (2, 32, 64, 16, 24, 1),     # layer1.0.downsample (submodule.py:167-174)
+    (2, 64, 64, 16, 32, 2),     # layer2.0.downsample, stride 2
+    (2, 64, 128, 12, 8, 1),     # layer4.0.downsample
+    (1, 256, 128, 8, 16, 1),    # lastconv[0] (:162)
+    (1, 128, 32, 8, 16, 1),     # lastconv[4]
+    (1, 5, 7, 3, 12, 1),        # channel counts off the 8 / 32 blocks, pixel count off the 32-pixel segment
+    (2, 12, 200, 6, 8, 1),      # more than 128 output channels (two launch rows)
+    (1, 10, 6, 6, 16, 2),
+])
+def test_conv1x1_kernels(B, Ci, Co, H, W, s):
+  """mode_conv1x1_fwd / _bwd_data / _bwd_weight against torch's fp64 conv2d autograd, through the autograd Function."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  conv = nn.Conv2d(Ci, Co, 1, s, 0, bias=False)
+  with torch.no_grad():
+    conv.weight.copy_(_rand((Co, Ci, 1, 1), 121, (2.0 / Ci)**0.5))
+  x = _rand((B, Ci, H, W), 122)
+  xa, wa = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+  y_ref = F.conv2d(xa, wa, None, s)
+  gy = _rand(tuple(y_ref.shape), 123)
+  y_ref.backward(gy.double())
+  conv = conv.to(DEV)
+  xd = x.to(DEV).requires_grad_(True)
+  assert HF.conv1x1_supported(xd, conv)
+  y = HF.conv1x1(xd, conv)
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 2e-6 * Ci * max(1.0, float(y_ref.abs().max()))
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 2e-6 * Co * max(1.0, float(xa.grad.abs().max()))
+  assert (conv.weight.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+  # deterministic, and `accumulate` adds
+  g1 = conv.weight.grad.clone()
+  conv.weight.grad = None
+  xd2 = x.to(DEV).requires_grad_(True)
+  HF.conv1x1(xd2, conv).backward(gy.to(DEV))
+  assert torch.equal(conv.weight.grad, g1) and torch.equal(xd2.grad, xd.grad)
+  from models import stage3d
+  with torch.no_grad():
+    assert torch.equal(stage3d.conv3(conv, x.to(DEV)), y.detach())
+    # eval-mode fold
+    bn = _eval_bn(Co, 124, 2)
+    add = _rand(tuple(y_ref.shape), 125).to(DEV)
+    got = stage3d.conv_bn(nn.Sequential(conv, bn).eval(), x.to(DEV), True, add)
+    assert (got.double() - _unfused(bn, y_ref.detach().to(DEV), add, True)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('B,Co,H,W', [(2, 32, 64, 32), (1, 32, 32, 128), (2, 20, 26, 70), (1, 32, 8, 8)])
+def test_conv_stem_kernels(B, Co, H, W):
+  """firstconv[0] = Conv2d(3, 32, 7, stride 2, padding 3) (submodule.py:155) on csrc/conv_stem.hip: forward and weight gradient
+  against torch's fp64 conv2d autograd (ragged tiles, fewer output channels, images smaller than a tile); eval-mode fold."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  from models import stage3d
+  conv = nn.Conv2d(3, Co, 7, 2, 3, bias=False)
+  with torch.no_grad():
+    conv.weight.copy_(_rand((Co, 3, 7, 7), 131, (2.0 / 147)**0.5))
+  x = _rand((B, 3, H, W), 132)
+  wa = conv.weight.detach().double().requires_grad_(True)
+  y_ref = F.conv2d(x.double(), wa, None, 2, 3)
+  gy = _rand(tuple(y_ref.shape), 133)
+  y_ref.backward(gy.double())
+  conv = conv.to(DEV)
+  xd = x.to(DEV)
+  assert HF.conv_stem_supported(xd, conv)
+  y = stage3d.conv3(conv, xd)
+  assert tuple(y.shape) == tuple(y_ref.shape)
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 2e-6 * 147 * max(1.0, float(y_ref.abs().max()))
+  assert (conv.weight.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+  g1 = conv.weight.grad.clone()
+  conv.weight.grad = None
+  stage3d.conv3(conv, xd).backward(gy.to(DEV))
+  assert torch.equal(conv.weight.grad, g1)  # deterministic
+  # an input that needs a gradient is not this kernel's business (integer-table kernels)
+  assert not HF.conv_stem_supported(x.to(DEV).requires_grad_(True), conv)
+  with torch.no_grad():
+    bn = _eval_bn(Co, 134, 2)
+    got = stage3d.conv_bn(nn.Sequential(conv, bn).eval(), xd, True, None)
+    assert (got.double() - _unfused(bn, y_ref.detach().to(DEV), None, True)).abs().max() < 1e-4
