@@ -345,6 +345,10 @@ def main():
                            else 'built (mode_cost_volume_fwd)',
             'launch': 'hipGraph replay of zero-grad+forward+loss+backward, then all-reduce and fused Adam' if args.launch == 'graph'
                       else 'eager (one launch per kernel)',
+            'roofline_timing': ('per-kernel HIP events over %d eager steps run right AFTER the timed region (events cannot sit inside a '
+                                'replayed hipGraph); `value` / `ms_per_step` come from the %d timed replays only' %
+                                (args.profile_steps, args.steps)) if args.launch == 'graph'
+                               else 'per-kernel HIP events inside the timed region',
         },
     }
     if kern:

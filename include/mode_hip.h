@@ -230,6 +230,10 @@ int mode_conv2d_bwd_data(const float* gy, const float* w, float* gx, float* wpac
 int mode_conv2d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
                        int W, int Co, int dilation, mode_stream_t stream);
 
+/* out (planes, 2*Ho, 2*Wo): out[p][2h][2w] = in[p][h][w], zero elsewhere (Wo even).  The gradients of the extractor's one
+ * stride-2 3x3 layer (models/submodule.py:158) are the stride-1 gradients of the zero-inserted output gradient. */
+int mode_zero_insert2(const float* in, float* out, long long planes, int Ho, int Wo, mode_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 1x1 convolutions of the extractor (nn.Conv2d(kernel_size=1), models/submodule.py:162, 167-174: the `downsample` branches and
  * lastconv[0] / lastconv[4]; stride 1 or 2, no bias) as plain MFMA GEMMs over the NCHW planes -- csrc/conv1x1.hip.

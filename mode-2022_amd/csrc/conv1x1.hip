@@ -11,10 +11,10 @@
 //     (<= 128 per launch row), so x is read exactly once.  The input gradient is the same kernel on W^T (stride 2: scattered
 //     into a zero-filled gx).
 //   weight gradient:  gW[o, c] = sum_{b, q} gy[b, o, q] * x[b, c, s*q]   D[i = o][j = c], K = pixels.  Both operands are
-//     K-contiguous, the layout MFMA does not like; instead of a transpose through LDS every lane loads a float4 = 4 consecutive
-//     pixels of ITS row (o or c): lanes 0..31 use elements 0 and 2, lanes 32..63 elements 1 and 3, i.e. one 16-byte load feeds
-//     two k-steps, and the 32 rows of a fragment stream through L1 line by line.  4 waves = 4 K-slices summed through LDS in wave
-//     order; split-K partials reduced in fixed order (deterministic).
+//     K-contiguous, the layout MFMA does not like: 64-row x 64-pixel tiles of gy and x are staged in LDS with coalesced 16-byte row
+//     loads (double-buffered, the next tile in flight under the MFMAs) and read back transposed.  (A first version let every lane
+//     load 16 bytes of ITS row straight from global memory -- 32 cache lines per instruction: 1 TB/s.)  4 waves = 4 K-slices
+//     summed through LDS in wave order; split-K partials reduced in fixed order (deterministic).
 #include "common.h"
 
 namespace {
@@ -175,55 +175,96 @@ struct W1 {
   int S;
 };
 
+// Both operands are staged through LDS with coalesced 16-byte row loads (a 64-row x 64-pixel tile of gy and of x per step, double
+// buffered: the next tile travels global -> registers under the MFMAs) and read back transposed (lane = row, odd row pitch).
+constexpr int BW_PX = 64;            // pixels per tile
+constexpr int BW_PITCH = BW_PX + 1;  // odd: a fragment read (32 rows, one pixel) hits 32 banks
+constexpr int BW_TILE = 128 * BW_PITCH;  // 64 gy rows + 64 x rows
+constexpr int BW_LDS_FLOATS = 2 * BW_TILE > 3 * 4 * 1024 ? 2 * BW_TILE : 3 * 4 * 1024;
+
 template <int S2>
 __global__ __launch_bounds__(NT) void conv1x1_bww_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ part,
                                                          W1 d) {
-  __shared__ float red[3][4][1024];  // waves 1..3 hand their 2x2 accumulator tiles to wave 0
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // BW_LDS_FLOATS: the two tiles; at the end: waves 1..3 -> wave 0
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = lane & 31, half = lane >> 5;
   const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
   const long long No = (long long)d.Ho * d.Wo, HW = (long long)d.H * d.W;
-  const long long total = (long long)d.B * d.groups;
+  const int tiles_img = (int)((No + BW_PX - 1) / BW_PX);
+  const long long total = (long long)d.B * tiles_img;
   const long long per = (total + d.S - 1) / d.S;
-  const long long g_lo = (long long)blockIdx.x * per, g_hi = min(total, g_lo + per);
-  // rows past the tensor read row 0 and are masked out at the end
-  const int oa = o0 + row < d.Co ? o0 + row : 0, ob = o0 + 32 + row < d.Co ? o0 + 32 + row : 0;
-  const int ca = c0 + row < d.Ci ? c0 + row : 0, cb = c0 + 32 + row < d.Ci ? c0 + 32 + row : 0;
+  const long long t_lo = (long long)blockIdx.x * per, t_hi = min(total, t_lo + per);
+
+  // staging map: thread -> (row r = tid / 16 + 16 u, pixel group of 4 = tid % 16), u = 0..7: rows 0..63 gy, 64..127 x
+  const int sr = threadIdx.x >> 4, sp = (threadIdx.x & 15) * 4;
+  float4 v[8];
+  auto issue = [&](long long t) {
+    const int b = (int)(t / tiles_img);
+    const long long q = (t % tiles_img) * BW_PX + sp;  // first of this thread's 4 output pixels (No % 4 == 0: all in or all out)
+    const bool ok = q < No;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = sr + 16 * u;
+      if (r < 64) {
+        const int o = o0 + r;
+        v[u] = *reinterpret_cast<const float4*>(gy + ((long long)b * d.Co + (o < d.Co ? o : 0)) * No + (ok ? q : 0));
+        if (!ok || o >= d.Co) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int c = c0 + r - 64;
+        const float* xr = x + ((long long)b * d.Ci + (c < d.Ci ? c : 0)) * HW;
+        if (S2 == 1) {
+          v[u] = *reinterpret_cast<const float4*>(xr + (ok ? q : 0));
+        } else {  // x at (2*ho, 2*wo .. 2*wo + 6): the even elements of 8 consecutive floats
+          const int ho = (int)((ok ? q : 0) / d.Wo), wo = (int)((ok ? q : 0) - (long long)ho * d.Wo);
+          const float* p = xr + (long long)ho * 2 * d.W + 2 * wo;
+          const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+          v[u] = make_float4(u0.x, u0.z, u1.x, u1.z);
+        }
+        if (!ok || c >= d.Ci) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float* p = buf + (sr + 16 * u) * BW_PITCH + sp;
+      p[0] = v[u].x;
+      p[1] = v[u].y;
+      p[2] = v[u].z;
+      p[3] = v[u].w;
+    }
+  };
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (f32x16){0};
-
-  for (long long g = g_lo + wave; g < g_hi; g += 4) {
-    const int b = (int)(g / d.groups);
-    const int q = (int)(g % d.groups) * 4;  // 4 consecutive output pixels of one row (Wo % 4 == 0)
-    const float* gb = gy + (long long)b * d.Co * No + q;
-    const float4 a0 = *reinterpret_cast<const float4*>(gb + (long long)oa * No);
-    const float4 a1 = *reinterpret_cast<const float4*>(gb + (long long)ob * No);
-    float4 b0, b1;
-    if (S2 == 1) {
-      const float* xb = x + (long long)b * d.Ci * HW + q;
-      b0 = *reinterpret_cast<const float4*>(xb + (long long)ca * HW);
-      b1 = *reinterpret_cast<const float4*>(xb + (long long)cb * HW);
-    } else {  // x at (2*ho, 2*wo .. 2*wo + 6): the even elements of 8 consecutive floats
-      const int ho = q / d.Wo, wo = q - ho * d.Wo;
-      const float* xb = x + (long long)b * d.Ci * HW + (long long)ho * 2 * d.W + 2 * wo;
-      const float4 u0 = *reinterpret_cast<const float4*>(xb + (long long)ca * HW), u1 = *reinterpret_cast<const float4*>(xb + (long long)ca * HW + 4);
-      const float4 v0 = *reinterpret_cast<const float4*>(xb + (long long)cb * HW), v1 = *reinterpret_cast<const float4*>(xb + (long long)cb * HW + 4);
-      b0 = make_float4(u0.x, u0.z, u1.x, u1.z);
-      b1 = make_float4(v0.x, v0.z, v1.x, v1.z);
-    }
-    // k-step 0: pixels q (lanes 0..31) and q+1 (lanes 32..63); k-step 1: q+2 and q+3
-    const float a00 = half ? a0.y : a0.x, a01 = half ? a0.w : a0.z, a10 = half ? a1.y : a1.x, a11 = half ? a1.w : a1.z;
-    const float b00 = half ? b0.y : b0.x, b01 = half ? b0.w : b0.z, b10 = half ? b1.y : b1.x, b11 = half ? b1.w : b1.z;
-    acc[0][0] = mfma32(a00, b00, acc[0][0]);
-    acc[0][1] = mfma32(a00, b10, acc[0][1]);
-    acc[1][0] = mfma32(a10, b00, acc[1][0]);
-    acc[1][1] = mfma32(a10, b10, acc[1][1]);
-    acc[0][0] = mfma32(a01, b01, acc[0][0]);
-    acc[0][1] = mfma32(a01, b11, acc[0][1]);
-    acc[1][0] = mfma32(a11, b01, acc[1][0]);
-    acc[1][1] = mfma32(a11, b11, acc[1][1]);
+  if (t_lo < t_hi) {
+    issue(t_lo);
+    commit(sm);
   }
+  __syncthreads();
+  int buf = 0;
+  for (long long t = t_lo; t < t_hi; ++t) {
+    const bool more = t + 1 < t_hi;
+    if (more) issue(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // wave w takes pixels 16 w .. 16 w + 15 of the tile: 8 k-steps of 2 pixels (lanes 0..31: even pixel, 32..63: odd pixel)
+    const float* gt = sm + buf * BW_TILE + row * BW_PITCH + wave * 16 + half;
+    const float* xt = gt + 64 * BW_PITCH;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float a0 = gt[2 * ks], a1 = gt[32 * BW_PITCH + 2 * ks];
+      const float b0 = xt[2 * ks], b1 = xt[32 * BW_PITCH + 2 * ks];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    if (more) commit(sm + (buf ^ 1) * BW_TILE);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float (*red)[4][1024] = reinterpret_cast<float (*)[4][1024]>(sm);
   if (wave > 0) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -237,13 +278,13 @@ __global__ __launch_bounds__(NT) void conv1x1_bww_kernel(const float* __restrict
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = acc[t >> 1][t & 1][r];
-        v += red[0][t][r * 64 + lane];
-        v += red[1][t][r * 64 + lane];
-        v += red[2][t][r * 64 + lane];
+        float v2 = acc[t >> 1][t & 1][r];
+        v2 += red[0][t][r * 64 + lane];
+        v2 += red[1][t][r * 64 + lane];
+        v2 += red[2][t][r * 64 + lane];
         const int o = o0 + (t >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // D[i = o][j = c = lane & 31]
         const int c = c0 + (t & 1) * 32 + row;
-        if (o < d.Co && c < d.Ci) pb[(long long)o * d.Ci + c] = v;
+        if (o < d.Co && c < d.Ci) pb[(long long)o * d.Ci + c] = v2;
       }
   }
 }
@@ -264,11 +305,11 @@ __global__ __launch_bounds__(256) void reduce_gw1(const float* __restrict__ part
   gw[i] = accumulate ? gw[i] + v : v;
 }
 
-int bww_splits(int B, int groups, int Co, int Ci) {
+int bww_splits(int B, int groups, int Co, int Ci) {  // groups = groups of 4 output pixels per image
   const long long blocks = (long long)mode::cdiv(Co, 64) * mode::cdiv(Ci, 64);
   long long S = (4LL * kNumCU + blocks - 1) / blocks;
-  const long long total = (long long)B * groups;
-  if (S > (total + 15) / 16) S = (total + 15) / 16;  // at least 16 pixel groups (4 per wave) per slice
+  const long long total = (long long)B * mode::cdiv(groups, 16);  // tiles of 64 pixels
+  if (S > (total + 3) / 4) S = (total + 3) / 4;  // at least 4 tiles per slice (the double buffer pays from the second on)
   return (int)std::max(1LL, S);
 }
 
@@ -349,10 +390,13 @@ extern "C" int mode_conv1x1_bwd_weight(const float* gy, const float* x, float* g
   d.groups = d.Ho * d.Wo / 4;
   d.S = bww_splits(B, d.groups, Co, Ci);
   const dim3 grid(d.S, mode::cdiv(Co, 64), mode::cdiv(Ci, 64));
+  const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
+  rc = stride == 1 ? mode::allow_lds(conv1x1_bww_kernel<1>, lds, who) : mode::allow_lds(conv1x1_bww_kernel<2>, lds, who);
+  if (rc != MODE_OK) return rc;
   if (stride == 1)
-    hipLaunchKernelGGL(conv1x1_bww_kernel<1>, grid, dim3(NT), 0, st, gy, x, workspace, d);
+    hipLaunchKernelGGL(conv1x1_bww_kernel<1>, grid, dim3(NT), lds, st, gy, x, workspace, d);
   else
-    hipLaunchKernelGGL(conv1x1_bww_kernel<2>, grid, dim3(NT), 0, st, gy, x, workspace, d);
+    hipLaunchKernelGGL(conv1x1_bww_kernel<2>, grid, dim3(NT), lds, st, gy, x, workspace, d);
   const int n = Co * Ci;
   hipLaunchKernelGGL(reduce_gw1, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, n, d.S, accumulate);
   return mode::check_launch(who);

@@ -49,6 +49,7 @@ SIGNATURES = {
     'mode_conv2d_wpack_bytes': (_c_size, [_c_int] * 2),
     'mode_conv2d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_fwd_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
+    'mode_zero_insert2': (_c_int, [_c_ptr] * 2 + [ctypes.c_longlong] + [_c_int] * 2 + [_c_ptr]),
     'mode_conv2d_bwd_data': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 5),
     'mode_conv2d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),

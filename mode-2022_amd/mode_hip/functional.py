@@ -1,5 +1,5 @@
-"""torch.autograd wrappers over the C-ABI kernels (host-side glue; the only arithmetic left to torch is the pair of small GEMMs
-of cost_conv, which run on rocBLAS)."""
+"""torch.autograd wrappers over the C-ABI kernels (host-side glue: shapes, workspaces, autograd; no arithmetic of the path is left
+to torch or to a vendor library)."""
 import ctypes
 import threading
 
@@ -187,14 +187,12 @@ class CostConvAssemble(torch.autograd.Function):
 
 
 def _tap_products(fea, wpart):
-  """(B, 9*Co, H, W): channel (kd*3+kw)*Co + o = sum_{c,kh} wpart[o,c,kd,kh,kw] * fea[b,c,h+kh-1,w] (zero padding in h): one
-  GEMM with K = 3C over the feature map (rocBLAS fp32)."""
-  B, C, H, W = fea.shape
-  Co = wpart.shape[0]
-  wr = wpart.permute(2, 4, 0, 1, 3).reshape(9 * Co, C * 3)            # rows (kd, kw, o), columns (c, kh)
-  x = torch.nn.functional.pad(fea, (0, 0, 1, 1))                       # rows -1 and H
-  xs = torch.stack([x[:, :, kh:kh + H] for kh in range(3)], 2).reshape(B, C * 3, H * W)
-  return torch.matmul(wr, xs).view(B, 9 * Co, H, W)
+  """(B, 9*Co, H, W): channel (kd*3+kw)*Co + o = sum_{c,kh} wpart[o,c,kd,kh,kw] * fea[b,c,h+kh-1,w] (zero padding in h): a
+  convolution with a 3 x 1 kernel from C to 9*Co channels -- the gather-and-MAC kernels on an integer table (conv2d_tabled: own
+  forward, input gradient and weight gradient; autograd carries the weight gradient back through the permutation)."""
+  Co, C = wpart.shape[:2]
+  wr = wpart.permute(2, 4, 0, 1, 3).reshape(9 * Co, C, 3, 1)          # rows (kd, kw, o), taps kh
+  return Conv2dTabledFunction.apply(fea, wr, (1, 1), (1, 0), (1, 1))
 
 
 def cost_conv_supported(fea, d4, co):
@@ -544,6 +542,50 @@ def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
                                                 ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, groups, ptr(gyt), ptr(xt),
                                                 stream_of(gyt)), 'mode_sphere_conv_bwd_weight_win')
   return gw
+
+
+# ------------------------------------------------------------------------------------ the stride-2 3x3 layer (layer2[0].conv1)
+def conv2d_3x3_s2_supported(x, conv):
+  """Conv2d(k3, stride 2, padding 1) on even-sized planes, within the limits of the stride-1 kernels its gradients run on."""
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and
+          conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros' and
+          x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and _conv2d_own(x, conv.weight) and conv2d_wgrad_supported(x, conv.weight))
+
+
+class Conv2d3x3S2Function(torch.autograd.Function):
+  """Forward on the integer-table gather kernel; both gradients as stride-1 gradients of the zero-inserted output gradient, on the
+  MFMA kernels of the stride-1 layers (csrc/conv2d.hip, conv2d_wgrad.hip)."""
+
+  @staticmethod
+  def forward(ctx, x, w):
+    x, w = x.contiguous(), w.contiguous()
+    B, Ci, H, W = x.shape
+    y = torch.empty((B, w.shape[0], H // 2, W // 2), dtype=x.dtype, device=x.device)
+    sphere_conv_fwd(x, conv2d_table(H, W, 3, 3, (2, 2), (1, 1), (1, 1), x.device), w, y, (2, 2), 1)
+    ctx.save_for_backward(x, w)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, Co, Ho, Wo = gy.shape
+    up = torch.empty((B, Co, 2 * Ho, 2 * Wo), dtype=gy.dtype, device=gy.device)
+    with torch.cuda.device_of(gy):
+      check(lib().mode_zero_insert2(ptr(gy), ptr(up), B * Co, Ho, Wo, stream_of(gy)), 'mode_zero_insert2')
+    gx = conv2d_bwd_data(up, w, 1) if ctx.needs_input_grad[0] else None
+    gw = None
+    if ctx.needs_input_grad[1]:
+      sink = grad_sink(w)
+      gw = conv2d_bwd_weight(up, x, 1, into=sink)
+      if sink is not None:
+        gw = None
+    return gx, gw
+
+
+def conv2d_3x3_s2(x, conv):
+  return Conv2d3x3S2Function.apply(x, conv.weight)
 
 
 # ------------------------------------------------------------------------------------ 1x1 Conv2d (stride 1 | 2): plain MFMA GEMMs

@@ -53,6 +53,8 @@ def conv3(conv, x):
         return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
     elif HF._conv2d_own(x, conv.weight):
       return HF.conv2d_fwd(x.contiguous(), conv.weight.detach().contiguous(), conv.dilation[0])
+  if type(conv) is nn.Conv2d and HF.conv2d_3x3_s2_supported(x, conv) and torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
+    return HF.conv2d_3x3_s2(x, conv)  # layer2[0].conv1: gradients on the stride-1 MFMA kernels (zero-inserted output gradient)
   if type(conv) is nn.Conv2d and HF.conv_stem_supported(x, conv):
     return HF.conv_stem(x, conv)  # firstconv[0]: 7x7 stride 2 on the image (csrc/conv_stem.hip)
   if type(conv) is nn.Conv2d and HF.conv1x1_supported(x, conv):

@@ -965,3 +965,34 @@ def test_conv_stem_kernels(B, Co, H, W):
     bn = _eval_bn(Co, 134, 2)
     got = stage3d.conv_bn(nn.Sequential(conv, bn).eval(), xd, True, None)
     assert (got.double() - _unfused(bn, y_ref.detach().to(DEV), None, True)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 20, 40, 10, 36), (2, 8, 8, 2, 4)])
+def test_conv2d_3x3_stride2_layer(B, Ci, Co, H, W):
+  """layer2[0].conv1 (submodule.py:158): forward on the integer-table kernel, gradients = stride-1 gradients of the zero-inserted
+  output gradient on the MFMA kernels (functional.Conv2d3x3S2Function), against torch's fp64 conv2d autograd."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  from models import stage3d
+  conv = nn.Conv2d(Ci, Co, 3, 2, 1, bias=False)
+  with torch.no_grad():
+    conv.weight.copy_(_rand((Co, Ci, 3, 3), 141, (2.0 / (9 * Ci))**0.5))
+  x = _rand((B, Ci, H, W), 142)
+  xa, wa = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+  y_ref = F.conv2d(xa, wa, None, 2, 1)
+  gy = _rand(tuple(y_ref.shape), 143)
+  y_ref.backward(gy.double())
+  conv = conv.to(DEV)
+  xd = x.to(DEV).requires_grad_(True)
+  assert HF.conv2d_3x3_s2_supported(xd, conv)
+  y = stage3d.conv3(conv, xd)
+  assert y.grad_fn is not None and 'Conv2d3x3S2' in type(y.grad_fn).__name__
+  y.backward(gy.to(DEV))
+  assert (y.detach().cpu().double() - y_ref.detach()).abs().max() < 2e-6 * 9 * Ci * max(1.0, float(y_ref.abs().max()))
+  assert (xd.grad.cpu().double() - xa.grad).abs().max() < 2e-6 * 9 * Co * max(1.0, float(xa.grad.abs().max()))
+  assert (conv.weight.grad.cpu().double() - wa.grad).abs().max() < 2e-5 * max(1.0, float(wa.grad.abs().max()))
+  up = torch.empty(B, Co, H, W, device=DEV)
+  mode_hip.check(mode_hip.lib().mode_zero_insert2(mode_hip.ptr(gy.to(DEV)), mode_hip.ptr(up), B * Co, H // 2, W // 2, None), 'mode_zero_insert2')
+  want = torch.zeros(B, Co, H, W)
+  want[:, :, ::2, ::2] = gy
+  assert torch.equal(up.cpu(), want)
