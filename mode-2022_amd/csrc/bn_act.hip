@@ -49,13 +49,18 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
   const long long S4 = S >> 2;
+  // Shifted sums: everything is accumulated relative to a pivot -- the first element of the group's first sample of this channel
+  // (bn_pivot, re-read by the finalisation) -- so that var = E[(y-K)^2] - E[y-K]^2 does not cancel when |mean| >> std
+  // (torch / MIOpen use Welford; with K inside the data range the shifted form is as accurate and stays a single pass).
+  const float K = y[((long long)b0 * C + c) * S];
   float s0 = 0.f, s1 = 0.f;
   for (int b = b0; b < b0 + Bg; ++b) {
     const float4* p = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * S);
     // four independent loads per iteration (see bn_apply_kernel); the sums are taken in the same order as element by element
     auto acc1 = [&](const float4& v) {
-      s0 += (v.x + v.y) + (v.z + v.w);
-      s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      const float dx = v.x - K, dy = v.y - K, dz = v.z - K, dw = v.w - K;
+      s0 += (dx + dy) + (dz + dw);
+      s1 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     };
     // block `split` takes the 4 KB pieces split, split + nsplit, ... of the row (not one contiguous slice): concurrently running
     // blocks then read neighbouring addresses instead of addresses a multiple of 96 KB apart (same access pattern as the apply
@@ -73,8 +78,9 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
     if (split == 0) {  // ragged tail (S % 4)
       const float* q = y + ((long long)b * C + c) * S;
       for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
-        s0 += q[i];
-        s1 += q[i] * q[i];
+        const float dq = q[i] - K;
+        s0 += dq;
+        s1 += dq * dq;
       }
     }
   }
@@ -147,8 +153,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     double s0, s1;
     reduce_partials(k.partial, g * C + c, k.nsplit, s0, s1, shd);
     if (threadIdx.x == 0) {
-      const double mean = s0 / k.count;
-      double var = s1 / k.count - mean * mean;
+      const double dm = s0 / k.count;  // mean of y - K, K = the pivot of bn_stats_kernel
+      const double mean = (double)y[((long long)(g * k.Bg) * C + c) * S] + dm;
+      double var = s1 / k.count - dm * dm;
       if (var < 0.0) var = 0.0;
       const double invstd = 1.0 / sqrt(var + (double)k.eps);
       const double sc = (double)k.gamma[c] * invstd;
@@ -170,8 +177,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
         double t0, t1;
         reduce_partials(k.partial, gg * C + c, k.nsplit, t0, t1, shd);
         if (threadIdx.x == 0) {
-          const double mean = t0 / k.count;
-          double var = t1 / k.count - mean * mean;
+          const double dm = t0 / k.count;
+          const double mean = (double)y[((long long)(gg * k.Bg) * C + c) * S] + dm;
+          double var = t1 / k.count - dm * dm;
           if (var < 0.0) var = 0.0;
           const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
           k.running_mean[c] = (float)((1.0 - k.momentum) * (double)k.running_mean[c] + k.momentum * mean);

@@ -82,6 +82,8 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
   constexpr int PLANE = ID * IH * IW;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [CCH][PLANE]
 
+  // (tile order w, h, d inside an XCD's contiguous range: x is fetched 2.03 x, the depth halo of the 2-row tiles; depth-fastest
+  // order was measured -- 2.26 x and the same 1.36 ms: the kernel is MFMA-bound, profiles/traffic.json)
   int t = xcd_remap(blockIdx.x, d.ntiles);
   const int wt = t % d.nWt;
   t /= d.nWt;

@@ -110,7 +110,7 @@ class Deep360DatasetFusion(Dataset):
     self.depthloader, self.rgbloader = depthloader, rgbloader
 
   def __len__(self):
-    return len(self.gt)
+    return len(self.depthes[0])  # as the reference (deep360_loader.py: the first depth list, not the ground truth list)
 
   def __getitem__(self, index):
     depth_maps = [self.depthloader(paths[index]) for paths in self.depthes]

@@ -53,7 +53,7 @@ def _run(module, x):
 
 class BasicBlock(nn.Module):
   """Two convbn + ReLU pairs; `downsample` is accepted and unused, as in the reference (mode_fusion.py:17-34) -- the 1x1
-  projections the reference builds for it are never registered, so they are not built here (same state_dict)."""
+  projections the reference builds for it are never registered (same state_dict; see _rng_parity_downsample)."""
   expansion = 1
 
   def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
@@ -66,7 +66,17 @@ class BasicBlock(nn.Module):
     return _run(self.conv2, _run(self.conv1, x))
 
 
+def _rng_parity_downsample(inplanes, planes, stride):
+  """The reference builds a 1x1 `downsample` projection for the first block of a layer (mode_fusion.py:50-54, 117-120, ...) that
+  BasicBlock never registers or uses.  It is built and dropped here too, for one reason only: its default initialisation draws from
+  the global RNG, and without those draws the ConvTranspose2d / bias defaults and the He-normal re-initialisation that follow would
+  differ from the reference's under the same torch.manual_seed."""
+  nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False)
+
+
 def _blocks(inplanes, planes, blocks, stride, pad, dilation):
+  if stride != 1 or inplanes != planes:
+    _rng_parity_downsample(inplanes, planes, stride)
   layers = [BasicBlock(inplanes, planes, stride, None, pad, dilation)]
   layers += [BasicBlock(planes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
   return layers
@@ -112,7 +122,8 @@ class feature_extraction_MODE_Fusion(nn.Module):
 
     def take(kind, planes, blocks, before=(), after=()):
       cin = getattr(self, kind + '_inplanes')
-      seq = nn.Sequential(*(list(before) + _blocks(cin, planes, blocks, 1, 1, 1) + list(after)))
+      body = _blocks(cin, planes, blocks, 1, 1, 1)
+      seq = nn.Sequential(*(list(before) + body + (after() if callable(after) else list(after))))  # construction (= RNG) order of the reference
       setattr(self, kind + '_inplanes', planes)
       return seq
 
@@ -126,15 +137,16 @@ class feature_extraction_MODE_Fusion(nn.Module):
     self.fusion_layer1 = self._make_fusion_layer(c[0], 2)
     self.fusion_layer2 = self._make_fusion_layer(c[1], 2)
     self.fusion_layer3 = self._make_fusion_layer(c[2], 2)
-    self.depth_layer4 = take('depth', c[3], 1, before=pool(), after=_up(c[3]))
-    self.depth_layer5 = take('depth', c[2], 1, after=_up(c[2]))
-    self.depth_layer6 = take('depth', c[1], 1, after=_up(c[1]))
-    self.depth_layer7 = take('depth', c[0], 2, after=_head(c[0]))
+    self.depth_layer4 = take('depth', c[3], 1, before=pool(), after=lambda: _up(c[3]))
+    self.depth_layer5 = take('depth', c[2], 1, after=lambda: _up(c[2]))
+    self.depth_layer6 = take('depth', c[1], 1, after=lambda: _up(c[1]))
+    self.depth_layer7 = take('depth', c[0], 2, after=lambda: _head(c[0]))
     self.maxdepth = torch.tensor(maxdepth)
 
   @staticmethod
   def _make_fusion_layer(planes, blocks):
     """mode_fusion.py:176-184: blocks on the concatenation of the depth and RGB features of one scale."""
+    _rng_parity_downsample(int(2 * planes), planes, 1)  # (unconditional in the reference)
     return nn.Sequential(*([BasicBlock(int(2 * planes), planes, 1, None, 1, 1)] + [BasicBlock(planes, planes, 1, None, 1, 1)
                                                                                       for _ in range(1, blocks)]))
 

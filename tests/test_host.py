@@ -227,3 +227,17 @@ def test_product_reads_no_environment_switches():
     files = [path] if path.endswith('.py') else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs if f.endswith('.py')]
     for f in files:
       assert 'environ' not in open(f).read().replace('reads no environment', '').replace('read no environment', ''), f
+
+
+def test_seeded_initialisation_is_the_references(golden):
+  """Under the same torch.manual_seed the drop-in modules construct bit-identical weights to the imported reference (fixture:
+  tests/golden/seeded_init.json from make_golden_seeded_init.py): same RNG draws in the same order -- including the 1x1
+  `downsample` projections ModeFusion's reference builds and never registers."""
+  import sys
+  sys.path.insert(0, GOLDEN)
+  from make_golden_seeded_init import CASES, digest
+  with open(os.path.join(GOLDEN, 'seeded_init.json')) as f:
+    want = json.load(f)
+  for tag, (cls, args) in CASES.items():
+    torch.manual_seed(want['seed'])
+    assert digest(getattr(models, cls)(*args).state_dict()) == want[tag], tag

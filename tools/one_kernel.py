@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""Runs ONE kernel shape a few times, for PMC passes that must not mix shapes (rocprofv3 --pmc ... -- python3 tools/one_kernel.py <what>).
-  conv3d_bwd_weight_32   : mode_conv3d_bwd_weight 32->32 at 48x256x128, batch 2 (the bench's roofline kernel)
-  conv3d_fwd_32          : mode_conv3d_fwd 32->32, same volume
-  bn3d_32                : BatchNorm3d(32) + ReLU training forward + backward on the same volume (mode_bn_train_fwd / _bwd)"""
+"""Runs ONE kernel shape a few times, for PMC passes that must not mix shapes:
+
+    rocprofv3 --pmc FETCH_SIZE -- python3 tools/one_kernel.py <case> [--no-flush]
+
+Between the launches a 1 GiB fill evicts the 256 MiB Infinity Cache (MI355X_MICROARCH.md: launches that re-read the tensors of the
+previous launch otherwise find part of them on-die, and FETCH_SIZE comes out below the compulsory bytes).  Cases (batch = what the
+benchmark step launches): conv3d_{fwd,bwd_data,bwd_weight}_32 (32->32 at 48x256x128, B=2; bwd_weight = the bench's roofline
+kernel), sphere_{fwd,bwd_data,bwd_weight}_t (128->128 at 256x128, 4 images, plane-transposed storage), cost_volume_fwd (B=2),
+bn3d_32 (BatchNorm3d(32)+ReLU train fwd+bwd on the 48x256x128 volume, B=2)."""
 import os
 import sys
 
@@ -14,24 +19,58 @@ import torch  # noqa: E402
 from mode_hip import functional as HF  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else 'conv3d_bwd_weight_32'
+flush = '--no-flush' not in sys.argv
 dev = torch.device('cuda', 0)
-x = torch.randn(2, 32, 48, 256, 128, device=dev)
-w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
-gy = torch.randn_like(x)
-if what == 'bn3d_32':
-  bn = torch.nn.BatchNorm3d(32).to(dev)
-  xr = x.clone().requires_grad_(True)
-  for _ in range(4):
-    xr.grad = None
-    out = HF.bn_act(bn, xr, None, True)
-    out.backward(gy)
+thrash = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev) if flush else None
+
+
+def run(fn, n=4):
+  for _ in range(n):
+    if flush:
+      thrash.fill_(1.0)
+    fn()
   torch.cuda.synchronize()
-  print('done', what)
-  sys.exit(0)
-for _ in range(4):
-  if what == 'conv3d_bwd_weight_32':
-    HF.conv3d_bwd_weight(gy, x, 1)
+
+
+if what.startswith('conv3d') or what == 'bn3d_32':
+  x = torch.randn(2, 32, 48, 256, 128, device=dev)
+  w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+  gy = torch.randn_like(x)
+  if what == 'bn3d_32':
+    bn = torch.nn.BatchNorm3d(32).to(dev)
+    xr = x.clone().requires_grad_(True)
+
+    def step():
+      xr.grad = None
+      HF.bn_act(bn, xr, None, True).backward(gy)
+    run(step)
+  elif what == 'conv3d_bwd_weight_32':
+    run(lambda: HF.conv3d_bwd_weight(gy, x, 1))
+  elif what == 'conv3d_bwd_data_32':
+    run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 1))
   else:
-    HF.conv3d_fwd(x, w, 1)
-torch.cuda.synchronize()
+    run(lambda: HF.conv3d_fwd(x, w, 1))
+elif what.startswith('sphere'):
+  from models.basic.spherical_conv.sphere_conv import SphereConv
+  m = SphereConv(256, 128, 'Cassini', 128, 128, 3, 1, 1).to(dev)
+  pos = m.position_on(dev)
+  H, W = pos.shape[2:]
+  xt = torch.randn(4, 128, W, H, device=dev)
+  gyt = torch.randn_like(xt)
+  w = m.weight.detach()
+  if what == 'sphere_fwd_t':
+    yt = torch.empty_like(xt)
+    run(lambda: HF.sphere_conv_fwd_t(xt, pos, w, yt, 1))
+  elif what == 'sphere_bwd_data_t':
+    gxt = torch.empty_like(xt)
+    run(lambda: HF.sphere_conv_bwd_data_t(gyt, pos, w, gxt, 1))
+  else:
+    gw = torch.zeros_like(w)
+    run(lambda: HF.sphere_conv_bwd_weight_t(gyt, pos, xt, gw, 1))
+elif what == 'cost_volume_fwd':
+  fr = torch.randn(2, 32, 256, 128, device=dev)
+  ft = torch.randn_like(fr)
+  run(lambda: HF.cost_volume_fwd(fr, ft, 48))
+else:
+  raise SystemExit('unknown case ' + what)
 print('done', what)
