@@ -107,6 +107,36 @@ __device__ __forceinline__ float apply_epi(const Epi& e, float v, int o, long lo
   if (e.add) v += e.add[idx];
   return e.relu ? fmaxf(v, 0.f) : v;
 }
+// Register-lean form for the MFMA epilogues (D[i = o][j]: accumulator register q of lane l holds output channel
+// o = tile * 32 + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)).  Fetching shift[o] per element made the compiler preload 16 values per
+// M-tile next to the accumulators (conv2d 61 -> 80 VGPRs, deconv3d 94 -> 148: one wave per SIMD less).  Instead every lane loads
+// ONE shift per M-tile -- lane l that of channel tile * 32 + (l & 31) -- and an element takes its value from the lane that holds it
+// with a cross-lane read (ds_bpermute: no memory access, nothing to keep live).
+__device__ __forceinline__ float epi_tile_shift(const Epi& e, int tile_channel0, int nchan) {
+  const int c = tile_channel0 + (int)(threadIdx.x & 31);
+  return e.shift[c < nchan ? c : nchan - 1];
+}
+__device__ __forceinline__ float epi_apply_q(const Epi& e, float v, float tile_shift, int q, long long idx) {
+  const int src = (q & 3) + 8 * (q >> 2) + 4 * (int)((threadIdx.x & 63) >> 5);  // lane (= channel within the tile) holding this element's shift
+  v += __shfl(tile_shift, src, 64);
+  if (e.add) v += e.add[idx];
+  return e.relu ? fmaxf(v, 0.f) : v;
+}
+
+// Split-K reduction out[i] (+)= sum_s part[s * n + i], one wave per output element: lane l takes the slices l, l + 64, ... in
+// ascending order, then a fixed butterfly over the lanes -- deterministic, and S loads deep instead of S loads long (a thread
+// per element walked its S slices one dependent load after the other: 40 us for a 4 704-element gradient with 512 slices).
+// grid = ceil(n / 4) blocks of 256 threads.
+static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int S,
+                                                                   int accumulate) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int s = lane; s < S; s += 64) v += part[(long long)s * n + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) out[i] = accumulate ? out[i] + v : v;
+}
 
 // XCD-aware bijective remap of a block id in [0, n): consecutive ids are dispatched round-robin over the 8 XCDs, each with its
 // own L2; this gives every XCD a contiguous range of work items, so that neighbouring tiles (shared halo rows, overlapping

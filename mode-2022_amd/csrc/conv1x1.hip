@@ -289,22 +289,6 @@ __global__ __launch_bounds__(NT) void conv1x1_bww_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_gw1(const float* __restrict__ part, float* __restrict__ gw, int n, int S, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved running sums, fixed association
-  int s = 0;
-  for (; s + 3 < S; s += 4) {
-    s0 += part[(long long)s * n + i];
-    s1 += part[(long long)(s + 1) * n + i];
-    s2 += part[(long long)(s + 2) * n + i];
-    s3 += part[(long long)(s + 3) * n + i];
-  }
-  for (; s < S; ++s) s0 += part[(long long)s * n + i];
-  const float v = (s0 + s1) + (s2 + s3);
-  gw[i] = accumulate ? gw[i] + v : v;
-}
-
 int bww_splits(int B, int groups, int Co, int Ci) {  // groups = groups of 4 output pixels per image
   const long long blocks = (long long)mode::cdiv(Co, 64) * mode::cdiv(Ci, 64);
   long long S = (4LL * kNumCU + blocks - 1) / blocks;
@@ -398,6 +382,6 @@ extern "C" int mode_conv1x1_bwd_weight(const float* gy, const float* x, float* g
   else
     hipLaunchKernelGGL(conv1x1_bww_kernel<2>, grid, dim3(NT), lds, st, gy, x, workspace, d);
   const int n = Co * Ci;
-  hipLaunchKernelGGL(reduce_gw1, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, n, d.S, accumulate);
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(mode::cdiv(n, 4)), dim3(256), 0, st, workspace, gw, n, d.S, accumulate);
   return mode::check_launch(who);
 }

@@ -51,8 +51,12 @@ __global__ void pack_w2d(const float* __restrict__ w, float* __restrict__ wp, in
   }
 }
 
+// Waves per SIMD the eval variant (folded-BatchNorm epilogue) is held to: the occupancy of the plain kernel.  Left alone the compiler
+// spends 20-60 more registers on the epilogue's address arithmetic and drops a wave (144 vs 85 VGPRs for <4, 8>: one wave per SIMD instead of two; <2, 8> stays at three instead of four -- four spills).
+__host__ __device__ constexpr int epi_waves(int MT, int TH) { return TH == 8 ? (MT == 1 ? 5 : MT == 2 ? 3 : 2) : 1; }
+
 template <int MT, int TH, int DIL, bool EPI>
-__global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x, const float4* __restrict__ wp, float* __restrict__ y,
+__global__ __launch_bounds__(NT, EPI ? epi_waves(MT, TH) : 1) void conv2d_kernel(const float* __restrict__ x, const float4* __restrict__ wp, float* __restrict__ y,
                                                     C2Dims d, Epi epi) {
   constexpr int R = TH / 4;  // output rows per wave
   constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(NT) void conv2d_kernel(const float* __restrict__ x,
             const long long idx = (long long)o * HW + sp;
             yb[idx] = EPI ? apply_epi(epi, acc[m][r][q], o, (long long)b * d.Co * HW + idx) : acc[m][r][q];
           }
+          if (EPI && (q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (four elements' loads in flight: see conv3d_kernel's epilogue)
         }
     }
   }

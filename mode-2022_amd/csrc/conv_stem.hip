@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void stem_fwd_kernel(const float* __restrict__ 
 }
 
 // Weight gradient: persistent workgroups over the tiles, accumulators in registers; the 4 waves (= the 4 rows of a tile) are summed
-// through LDS in wave order at the end; part[workgroup][Co][KK], reduced in fixed order by reduce_stem.
+// through LDS in wave order at the end; part[workgroup][Co][KK], reduced in fixed order by reduce_slices_kernel (common.h).
 template <int CI>
 __global__ __launch_bounds__(NT) void stem_bww_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ part,
                                                       SDims d) {
@@ -180,22 +180,6 @@ __global__ __launch_bounds__(NT) void stem_bww_kernel(const float* __restrict__ 
         if (o < d.Co && kk < KK) pb[o * KK + kk] = v;
       }
   }
-}
-
-__global__ __launch_bounds__(256) void reduce_stem(const float* __restrict__ part, float* __restrict__ gw, int n, int S, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 3 < S; s += 4) {
-    s0 += part[(long long)s * n + i];
-    s1 += part[(long long)(s + 1) * n + i];
-    s2 += part[(long long)(s + 2) * n + i];
-    s3 += part[(long long)(s + 3) * n + i];
-  }
-  for (; s < S; ++s) s0 += part[(long long)s * n + i];
-  const float v = (s0 + s1) + (s2 + s3);
-  gw[i] = accumulate ? gw[i] + v : v;
 }
 
 int make_dims(SDims& d, int B, int Ci, int H, int W, int Co, const char* who) {
@@ -274,6 +258,6 @@ extern "C" int mode_conv_stem_bwd_weight(const float* gy, const float* x, float*
   const int S = stem_groups(d);
   hipLaunchKernelGGL(stem_bww_kernel<3>, dim3(S), dim3(NT), 0, st, gy, x, workspace, d);
   const int n = Co * d.KK;
-  hipLaunchKernelGGL(reduce_stem, dim3(mode::cdiv(n, 256)), dim3(256), 0, st, workspace, gw, n, S, accumulate);
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(mode::cdiv(n, 4)), dim3(256), 0, st, workspace, gw, n, S, accumulate);
   return mode::check_launch(who);
 }

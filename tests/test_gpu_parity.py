@@ -10,11 +10,11 @@ size 1024x512 / 192 (B=1, configs[1] forward and the per-sample share of configs
   * max |HIP - reference fp32| <= 1e-3 px on every stored pixel (all pixels at tiny, every 4th / 8th at the larger sizes), and
     on the 8x8 block means of ALL pixels;
   * loss to 2e-5 relative;
-  * parameter gradients: relative L2 error per tensor <= max(1e-3, 5 x the reference's own fp32-vs-fp64 error of that tensor),
+  * parameter gradients: relative L2 error per tensor <= max(floor, 5 x the reference's own fp32-vs-fp64 error of that tensor),
+    floor = 1e-3 for the 3-D stage, 4e-3 / 1e-2 for the extractor's convolution weights / BatchNorm vectors (_grad_floor), and
+    the L2 error over ALL parameters <= max(1e-3, 3 x own), over the whole extractor <= max(2e-3, 3 x own),
     estimated from 16 Rademacher projections stored in the fixture (E <e, v>^2 = |e|^2), plus 32 sampled entries per tensor
     (median at the L2 level, maximum within 100x of it).
-    (The extractor's gradients are a ~1e-3 residual after ~60 BatchNorm backward passes: the reference's own fp32 gradients
-    there are only good to 1e-3 .. 4e-3 relative, so 1e-3 cannot be asked of them; the 3-D stage is held to 1e-3.)
 The ill-conditioned random-init fixtures of round 1 (tests/test_gpu_model.py) stay as the stress tier."""
 import numpy as np
 import pytest
@@ -53,6 +53,67 @@ def _load(z, bn_from_fixture=False):
   return net, left.to(DEV), right.to(DEV), gt.to(DEV), seed
 
 
+def _grad_floor(name, ndim):
+  """Relative L2 level a parameter gradient is held to at least.
+    3-D stage (dres*, classif*): 1e-3.
+    extractor: its gradients are what is left of O(1) terms after ~60 BatchNorm backward passes cancel all but ~1e-3 of them
+    (grad_norm 1e-3 .. 5e-2 for its BatchNorm vectors, ~5 for its convolution weights, ~1 .. 40 in the 3-D stage).  Measured in
+    fp64 on the 64 x 32 fixture: perturbing the weights by 1e-7 relative -- one fp32 rounding each -- moves the extractor's
+    BatchNorm gradients by up to 1.1e-3 and its convolution-weight gradients by up to 4e-4, the 3-D stage's by 2.5e-6; the
+    reference's own fp32 run against fp64 shows 1e-3 .. 4e-3 on extractor tensors at config 1 and up to 1.7e-2 at full size.
+    Hence 4e-3 for the extractor's convolution weights and 1e-2 for its BatchNorm vectors; a dropped or wrong term is O(1), and
+    the whole-network and whole-extractor L2 errors are held to max(1e-3 / 2e-3, 3 x the reference's own) on top (_check_grads)."""
+  if not name.startswith('feature_extraction'):
+    return 1e-3
+  return 4e-3 if ndim > 1 else 1e-2
+
+
+def _check_grads(tag, net, z, seed):
+  grads = dict(net.named_parameters())
+  own = z['truth64/grad_rel_l2'] if 'truth64/grad_rel_l2' in z.files else None
+  K = z['train/grad_proj'].shape[1]
+  worst, worst_3d = 0.0, 0.0
+  d_all, d_ext = np.zeros(K), np.zeros(K)
+  n_all = n_ext = o_all = o_ext = 0.0  # squared norms of the reference gradient and of the reference's own fp32 error
+  for i, name in enumerate(z['train/grad_names']):
+    name = str(name)
+    p = grads[name]
+    g = p.grad.detach().cpu().reshape(-1).double().numpy()
+    norm = float(z['train/grad_norm'][i])
+    proj = recipe.projection_signs(seed, i, g.size, K).astype(np.float64) @ g
+    delta = proj - z['train/grad_proj'][i]
+    rel = float(np.sqrt(np.mean(delta**2))) / (norm + 1e-300)
+    e_own = float(own[i]) if own is not None else 2e-4
+    bound = max(_grad_floor(name, p.dim()), 5.0 * e_own)
+    worst = max(worst, rel)
+    d_all += delta
+    n_all += norm**2
+    o_all += (e_own * norm)**2
+    if name.startswith('feature_extraction'):
+      d_ext += delta
+      n_ext += norm**2
+      o_ext += (e_own * norm)**2
+    else:
+      worst_3d = max(worst_3d, rel)
+    assert rel <= 1.5 * bound, (name, rel, bound)  # (16 projections: the estimate itself scatters by ~ +-35 %)
+    # 32 sampled entries: round-off of a back-propagated gradient is heavy-tailed over the entries of a tensor (the reference's own
+    # fp32 run against fp64: median 7e-5 rms, 99th percentile 1e-3 rms, maximum 1e-2 rms at config 1), hence a robust pair of
+    # bounds -- the median at the L2 level, every entry within 100x of it (a wrong entry is O(1) rms)
+    idx = z['train/grad_idx'][i]
+    rms = norm / np.sqrt(g.size)
+    diff = np.abs(g[idx] - z['train/grad_val'][i])
+    assert np.median(diff) <= 3.0 * bound * rms + 1e-12, (name, 'sampled entries: median', float(np.median(diff)), bound * rms)
+    assert diff.max() <= 100.0 * bound * rms + 1e-12, (name, 'sampled entries: max', float(diff.max()), bound * rms)
+  rel_all = float(np.sqrt(np.mean(d_all**2)) / np.sqrt(n_all))
+  rel_ext = float(np.sqrt(np.mean(d_ext**2)) / np.sqrt(n_ext))
+  print('%s: relative L2 error of the parameter gradients: whole network %.2e, whole extractor %.2e; per tensor (243): worst %.2e, '
+        'worst outside the extractor %.2e' % (tag, rel_all, rel_ext, worst, worst_3d))
+  # flattened over all parameters / over the extractor: at most 3 x the reference's own fp32 error of the same vector
+  own_all, own_ext = float(np.sqrt(o_all / n_all)), float(np.sqrt(o_ext / n_ext))
+  assert rel_all <= max(1e-3, 3.0 * own_all), (rel_all, own_all)
+  assert rel_ext <= max(2e-3, 3.0 * own_ext), (rel_ext, own_ext)
+
+
 def _check_pred(name, got, z, key, e_ref):
   sub = int(z['sub'])
   g = got.detach()
@@ -76,32 +137,7 @@ def test_train_outputs_and_gradients_within_1e3_of_the_reference(golden, tag):
   ref_loss = float(z['train/loss'])
   assert abs(float(loss.detach()) - ref_loss) <= 2e-5 * ref_loss, (float(loss.detach()), ref_loss)
   loss.backward()
-  grads = dict(net.named_parameters())
-  own = z['truth64/grad_rel_l2'] if 'truth64/grad_rel_l2' in z.files else None
-  worst, worst_3d = 0.0, 0.0
-  for i, name in enumerate(z['train/grad_names']):
-    name = str(name)
-    g = grads[name].grad.detach().cpu().reshape(-1).double().numpy()
-    norm = float(z['train/grad_norm'][i])
-    proj = recipe.projection_signs(seed, i, g.size, z['train/grad_proj'].shape[1]).astype(np.float64) @ g
-    rel = float(np.sqrt(np.mean((proj - z['train/grad_proj'][i])**2))) / (norm + 1e-300)
-    # the reference's own fp32 error of this tensor against fp64 (not stored for the full-size fixture: its extractor tensors
-    # get the config-1 level, 4e-3)
-    e_own = float(own[i]) if own is not None else (4e-3 if name.startswith('feature_extraction') else 2e-4)
-    bound = max(1e-3, 5.0 * e_own)
-    worst = max(worst, rel)
-    if not name.startswith('feature_extraction'):
-      worst_3d = max(worst_3d, rel)
-    assert rel <= 1.5 * bound, (name, rel, bound)  # (16 projections: the estimate itself scatters by ~ +-35 %)
-    # 32 sampled entries: round-off of a back-propagated gradient is heavy-tailed over the entries of a tensor (the reference's own
-    # fp32 run against fp64: median 7e-5 rms, 99th percentile 1e-3 rms, maximum 1e-2 rms at config 1), hence a robust pair of
-    # bounds -- the median at the L2 level, every entry within 100x of it (0.1 rms at most: a wrong entry is O(1) rms)
-    idx = z['train/grad_idx'][i]
-    rms = norm / np.sqrt(g.size)
-    diff = np.abs(g[idx] - z['train/grad_val'][i])
-    assert np.median(diff) <= 3.0 * bound * rms + 1e-12, (name, 'sampled entries: median', float(np.median(diff)), bound * rms)
-    assert diff.max() <= 100.0 * bound * rms + 1e-12, (name, 'sampled entries: max', float(diff.max()), bound * rms)
-  print('%s: relative L2 error of the parameter gradients (243 tensors): worst %.3e, worst outside the extractor %.3e' % (tag, worst, worst_3d))
+  _check_grads(tag, net, z, seed)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'cfg1', 'full'])
@@ -119,3 +155,23 @@ def test_eval_output_within_1e3_of_the_reference(golden, tag):
   stable = np.abs(np.abs(ref_pred - np.round(ref_pred)) - 0.5) > 0.01
   diff = np.abs(conf[:, :, ::sub, ::sub].cpu().numpy() - z['eval/conf'])
   assert diff[stable].max() < 1e-3, diff[stable].max()
+
+
+def test_config2_batch_of_two_at_full_size(golden):
+  """BASELINE configs[2]: 1024 x 512, 192 disparities, batch 2, forward + backward.  The reference fixture holds ONE pair (a CPU
+  run of two costs minutes and ~50 GB); a batch of two copies of that pair has the same BatchNorm statistics as the pair alone, so
+  every sample of the batch-2 step must reproduce the reference's batch-1 outputs to the north_star's 1e-3, and the parameter
+  gradients (mean over twice the pixels of twice the terms) the batch-1 gradients."""
+  z = golden('model_wc_full.npz')
+  net, left, right, gt, seed = _load(z)
+  net.train()
+  left2, right2, gt2 = [torch.cat((t, t), 0) for t in (left, right, gt)]
+  preds = net(left2, right2)
+  for i, p in enumerate(preds):
+    assert tuple(p.shape) == (2, 1, 1024, 512)
+    for b in range(2):
+      _check_pred('configs[2] sample %d pred%d' % (b, i + 1), p[b:b + 1], z, 'train/pred%d' % (i + 1), z['truth64/train_E_ref'])
+  loss = mode_ref.training_loss(preds, gt2, ~torch.isnan(gt2))
+  assert abs(float(loss.detach()) - float(z['train/loss'])) <= 2e-5 * float(z['train/loss'])
+  loss.backward()
+  _check_grads('configs[2] batch-2 step', net, z, seed)

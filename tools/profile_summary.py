@@ -18,7 +18,8 @@ def grp(n):
     return 'sphere'
   if 'cost_conv' in n:
     return 'cost_conv assembly'
-  if 'conv2d_' in n or 'reduce_gw2d' in n or 'pack_w2d' in n:
+  if 'conv2d_' in n or 'reduce_gw2d' in n or 'pack_w2d' in n or 'conv1x1' in n or 'stem_' in n or 'pack_w1' in n or 'pack_w_stem' in n or \
+      'zero_insert2' in n or 'reduce_slices' in n:
     return 'conv2d (own)'
   if 'conv3d' in n or 'deconv3d' in n or 'reduce_gw3d' in n or 'pack_w3d' in n:
     return 'conv3d'
