@@ -8,8 +8,9 @@ Follows the reference line by line:
   erp2rect_cassini         utils/geometry.py:160-198
 Pinned against the imported reference by tests/golden/geometry.npz (tests/golden/make_golden_geometry.py: the reference module
 itself, with a pass-through stand-in for the absent `numba.jit` decorator and an identity `.cuda()`) -- except `depth_left` /
-`disp2depth`: PARITY UNPINNED for the sine-rule arithmetic (the script holding it cannot be imported here: argparse at import,
-torchvision and cv2 absent); the functions it dispatches to are pinned."""
+`disp2depth`: the script holding it cannot be imported (argparse at import, torchvision and cv2 absent), so the reference FUNCTION
+is taken out of it with ast and run by tests/golden/make_golden_disp2depth.py; tests/golden/disp2depth.npz pins this restatement
+(tests/test_geometry.py: 5e-5 relative -- the reference evaluates in float64 under the container's NumPy 2, this file in float32)."""
 import math
 
 import numpy as np

@@ -205,3 +205,32 @@ def test_hip_disp2depth(pair, dbname):
     assert abs((d > 0).mean() - (rd > 0).mean()) < 0.05
     assert np.allclose(np.sort(d[d > 0])[::37][:20], np.sort(rd[rd > 0])[::37][:20], rtol=0.05)
   assert HG.disp2depth(disp, conf, '99') is None
+
+
+@pytest.mark.parametrize('dbname', ['Deep360', 'other'])
+@pytest.mark.parametrize('pair', ['12', '13', '14', '23', '24', '34'])
+def test_oracle_disp2depth_pinned_by_the_reference_function(golden, pair, dbname):
+  """tests/golden/disp2depth.npz holds outputs of the reference's OWN disp2depth (save_output_disparity_stage.py:105-160, taken
+  out of the un-importable script with ast by tests/golden/make_golden_disp2depth.py).  Under the container's NumPy 2 the
+  reference evaluates the sine rule in float64 for the direct pairs; the oracle keeps float32 throughout: agreement to 5e-5
+  relative away from the 1000 m clip, the clipped / masked pixels identical."""
+  z = golden('disp2depth.npz')
+  d, c = G.disp2depth(z['disp'].copy(), z['conf'].copy(), pair, dbname)
+  rd, rc = z['%s/%s/depth' % (dbname, pair)], z['%s/%s/conf' % (dbname, pair)]
+  far = rd >= 999
+  assert (np.abs(d - rd)[~far] <= 1e-4 * np.maximum(np.abs(rd[~far]), 1e-3)).all()
+  assert (np.abs(d[far] - rd[far]) < 1).all()
+  assert np.abs(c - rc).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dbname', ['Deep360', 'other'])
+def test_hip_disp2depth_against_the_reference_function(golden, dbname):
+  """The HIP sine-rule kernel (mode_disp2depth) against the reference function's own output, direct pair '12'."""
+  from utils import geometry as HG
+  z = golden('disp2depth.npz')
+  d, c = HG.disp2depth(z['disp'].copy(), z['conf'].copy(), '12', dbname)
+  rd = z['%s/12/depth' % dbname]
+  far = rd >= 999
+  assert (np.abs(d - rd)[~far] <= 1e-4 * np.maximum(np.abs(rd[~far]), 1e-3)).all()
+  assert (np.abs(d[far] - rd[far]) < 1).all() and np.array_equal(c, z['conf'])
