@@ -191,7 +191,6 @@ __global__ __launch_bounds__(NT, EPI ? epi_waves(MT, TH) : 1) void conv2d_kernel
             const long long idx = (long long)o * HW + sp;
             yb[idx] = EPI ? apply_epi(epi, acc[m][r][q], o, (long long)b * d.Co * HW + idx) : acc[m][r][q];
           }
-          if (EPI && (q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (four elements' loads in flight: see conv3d_kernel's epilogue)
         }
     }
   }

@@ -256,9 +256,6 @@ __global__ __launch_bounds__(NT) void conv3d_kernel(const float* __restrict__ x,
             const long long idx = o * oDHW + sp;
             yb[idx] = EPI ? apply_epi(epi, acc[m][r][q], o, (long long)b * d.Co * oDHW + idx) : acc[m][r][q];
           }
-          // eval epilogue: at most four elements' shift / residual loads in flight -- left alone the compiler issues all 16 * MT * R of
-          // them up front and pays with registers (one wave per SIMD less on the larger tiles)
-          if (EPI && (q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
   }
@@ -489,7 +486,6 @@ __global__ __launch_bounds__(NT, EPI ? 2 : 1) void deconv3d_kernel(const float* 
             }
             *reinterpret_cast<float2*>(yb + o * oDHW + sp) = v;
           }
-          if (EPI && (q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (see conv3d_kernel's epilogue)
         }
       }
   }
