@@ -30,6 +30,7 @@ import torch.nn.functional as F  # noqa: E402
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense; a split-bf16 fp32 product costs six bf16 MFMAs (csrc/conv3d_split.hip)
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm'}
 
@@ -53,6 +54,9 @@ def parse():
   ap.add_argument('--vendor-autotune', type=int, default=int(os.environ.get('MODE_VENDOR_AUTOTUNE', '0')),
                   help='1: torch.backends.cudnn.benchmark = True (MIOpen times its solvers for the regular 2-D convolutions)')
   ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
+  ap.add_argument('--conv3d-arith', default='f32', choices=['f32', 'bf16x6'],
+                  help="stride-1 3x3x3 layers: 'f32' = fp32 MFMA; 'bf16x6' = fp32 operands split into three bf16 pieces, six bf16 MFMAs "
+                  'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV3D_ARITH)')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
                   '(RCCL refuses two ranks on the same device)')
@@ -72,6 +76,17 @@ def launch_ranks(args):
          '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
   return subprocess.call(cmd, env=env)
+
+
+def _on_split_path(label):
+  """Does the kernel behind a profiling label like conv3d_fwd[32->32 s1 48x256x128] run on the split-bf16 kernels in bf16x6 mode?"""
+  import re
+  m = re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bn_eval)\[(\d+)->(\d+) s(\d) ', label)
+  if not m:
+    return False
+  import mode_hip
+  ci, co, stride = int(m.group(2)), int(m.group(3)), int(m.group(4))
+  return mode_hip.lib().mode_conv3d_split_supported(ci, co, stride, int(m.group(1) == 'conv3d_bwd_data')) == 1
 
 
 def synthetic_batch(B, H, W, maxdisp, device, seed):
@@ -181,6 +196,8 @@ def main():
   from mode_hip import data_parallel, profiling
   import mode_hip
   mode_hip.lib()  # fail loudly if the native library is missing
+  from mode_hip import functional as HF
+  HF.set_conv3d_arith(args.conv3d_arith)
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)
@@ -325,7 +342,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': 'f32' if args.conv3d_arith == 'f32' else 'f32 (stride-1 3x3x3 forward / input-gradient layers as 6 x bf16 MFMA on exactly split fp32 operands, fp32 accumulate)',
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
@@ -339,6 +356,7 @@ def main():
                         (args.maxdisp, args.height, args.width, 'fwd+bwd+Adam' if args.mode == 'train' else 'eval fwd',
                          args.batch, 2 if world == 1 else 3),
             'global_batch': args.batch * world,
+            'conv3d_arith': args.conv3d_arith,
             'parallelism': 'dp%d' % world,
             'cost_volume': ('folded into dres0[0][0] (cost_conv: 18 partial 2-D products + assembly kernel); the volume is not built, '
                             'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if net.fold_cost_volume
@@ -360,6 +378,8 @@ def main():
         achieved, peak, unit, per_launch = a['GBps'], HBM_PEAK_GBPS, 'GB/s', a['bytes_per_call']
       else:
         achieved, peak, unit, per_launch = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', a['flops_per_call']
+        if args.conv3d_arith == 'bf16x6' and _on_split_path(dom):
+          peak = MFMA_BF16_PEAK_TFLOPS / 6.0  # fp32-equivalent flops against the bf16 pipe: six MFMAs per product
       traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
       try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:

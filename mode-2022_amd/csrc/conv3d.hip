@@ -536,7 +536,31 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
   if (Ci <= 0 || Co <= 0) return 0;
   const size_t f = (size_t)mode::cdiv(Co, 32) * mode::cdiv(Ci, CCH) * 27 * 256;
   const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 27 * 256;
-  return ((f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32)) * sizeof(float);  // + the folded BatchNorm shifts
+  size_t n = (f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32);  // + the folded BatchNorm shifts
+  n = std::max(n, std::max(mode::conv3d_split_wpack_floats(Ci, Co), mode::conv3d_split_wpack_floats(Co, Ci)));
+  return n * sizeof(float);
+}
+
+extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int backward_data) {
+  if (stride != 1 || Ci <= 0 || Co <= 0) return 0;
+  return backward_data ? mode::conv3d_split_supported(Co, Ci) : mode::conv3d_split_supported(Ci, Co);
+}
+
+extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
+                                     int D, int H, int W, int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_fwd_split";
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 1, who);
+  if (rc == MODE_OK && bn) rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, bn);
+}
+
+extern "C" int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
+                                          int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_data_split";
+  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, 1, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  return mode::conv3d_s1_split(gy, w, gx, wpack, B, Co, Ci, D, H, W, 1, mode::as_stream(stream), who, nullptr);
 }
 
 extern "C" int mode_conv3d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,

@@ -16,4 +16,12 @@ size_t conv3d_co1_bwd_weight_workspace_floats(int B, int Ci, int D, int H, int W
 int conv3d_co1_bwd_weight(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,
                           int accumulate, hipStream_t st, const char* who);
 
+// conv3d_split.hip: stride-1 3x3x3 convolution on the bf16 matrix pipe with three-way split fp32 operands (fp32 accuracy).  Same
+// argument meaning as conv3d_s1 in conv3d.hip (rows = output channels of the GEMM, K = its reduction channels, flip 0 forward /
+// 1 backward-data); wpack >= conv3d_split_wpack_floats(K, rows) floats.
+bool conv3d_split_supported(int K, int rows);
+size_t conv3d_split_wpack_floats(int K, int rows);
+int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn);
+
 }  // namespace mode

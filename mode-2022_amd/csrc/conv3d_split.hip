@@ -1,0 +1,374 @@
+// 3x3x3 stride-1 convolution (pad 1) of the 3D regulariser on the bf16 matrix pipe with fp32 operands: every fp32 value is split
+// EXACTLY into three bf16 pieces,  a = a1 + a2 + a3  (a1 = rne(a), a2 = rne(a - a1), a3 = rne(a - a1 - a2): 24 mantissa bits),
+// and a product a*b is the sum of the six partial products of weight >= 2^-16 relative to |a||b|,
+//     a3*b1 + a1*b3 + a2*b2 + a2*b1 + a1*b2 + a1*b1        (dropped: a2*b3, a3*b2, a3*b3 <= 3 * 2^-24 |a||b|),
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 and added smallest first.  The result carries the rounding of an
+// fp32 convolution (tools/experiments/conv3d_bf16x6.hip measures it against an exact evaluation: max 4.5e-6 / rms 4.3e-7 at
+// |y| <= 4.8, a sequential fp32 fma loop 4.7e-6 / 5.1e-7) at 6 / 16 of the bf16 MFMA rate = 2.7 x the fp32 MFMA rate.
+//
+// Reference: the same nn.Conv3d layers as conv3d.hip (models/submodule.py:20-22, models/mode_disparity.py:11-46, 66-80).
+//
+// Layout.  D[i = o][j = 32 consecutive w] as in conv3d.hip, NCDHW kept.  GEMM-K of one MFMA = 16 = 8 input channels x 2 taps
+// (lanes 0..31 carry tap 2p, lanes 32..63 tap 2p+1 of tap pair p; 27 taps = 13 pairs + 1 half-empty pair), so an LDS chunk is 8
+// channels deep: [3 pieces][4 x 10 haloed rows x 34 w, padded to 1 536] of uint4 (= 8 channels of bf16), 73 728 B for a 2 x 8-row
+// output tile, double-buffered (147 KB: one workgroup of 4 waves per CU, one wave per SIMD, 256 VGPRs + 130 AGPRs).
+// Every wave runs ONE instruction stream per chunk of 336 MFMAs (4 output rows x 14 pairs x 6 terms) that also carries, between
+// the MFMAs (sched_group_barrier: 1 MFMA, <= 3 VALU, 1 LDS read), everything else:
+//   * the fragment reads of the next pair (12 x ds_read_b128) and the weight fragments 6 pairs ahead (ring of 7, from L2);
+//   * the loads of the NEXT chunk (8 channels x 6 positions per thread), position k under pair k, and their split
+//     (v_cvt_pk_bf16_f32) + 3 x ds_write_b128 under pair k + 8;
+// one LDS-only barrier per chunk.  What was measured on the way (32->32 at 48x256x128, B = 2, fp32 MFMA kernel 1.43 ms):
+//   two workgroups of 4 waves per CU, stage -> barrier -> MFMA phases                                      1.00 ms
+//   8 waves with fixed roles (4 matrix + 4 staging, one of each per SIMD)                                    0.89 ms: both roles
+//       slow each other down on their shared SIMD (matrix wave 13.6k -> 21.2k cycles per chunk, staging 5.8k -> 23.2k)
+//   one role, staging in the MFMA stream, 48 loads at the chunk start                                       0.92 ms: every CU is at
+//       the same point of its chunk, the loads arrive as one burst and take a chunk time to drain (same loads from cache: 0.74)
+//   loads spread over pairs 0..5, split under pairs 8..13 (this file)                                       0.83 ms = 209 TFLOP/s
+// Workgroups are persistent (one per CU), walk an XCD-contiguous tile range, and the chunk stream runs across tile boundaries.
+// Weights are split and packed once per launch ([m][chunk][pair][piece][lane] uint4, L2-resident).
+#include "common.h"
+
+#include "conv3d_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 256;
+constexpr int TD = 2, TH = 8, ID = TD + 2, IH = TH + 2, IW = 34;
+constexpr int ROWS = ID * IH;           // 40 haloed rows
+constexpr int ITEMS = ROWS * IW;        // 1 360 positions per chunk
+constexpr int KIT = (ITEMS + 256 - 1) / 256;  // 6 positions per thread
+constexpr int PIECE = KIT * 256;        // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
+constexpr int BUF = 3 * PIECE;          // uint4 per buffer
+constexpr int NPAIR = 14;
+constexpr int R = TD * TH / 4;          // 4 output rows per matrix wave
+constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
+
+struct SDims {
+  int B, K, Co, D, H, W;  // K = reduction channels of this GEMM, Co = its output channels
+  int nWt, nHt, nDt;
+  int MT, NCHUNK;
+  int ntiles;
+};
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// (a, b) -> the three packed bf16 pairs; the remainders are exact in fp32
+__device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = pack2(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  p3 = pack2(sa, sb);
+}
+
+// wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of Wsrc(o = m*32 + (lane & 31), c = ch*8 + j,
+// tap = 2 * pair + (lane >> 5)), j = 0..7; zero for tap 27, o >= rows, c >= K.  flip / fold as pack_w3d (conv3d.hip): flip 0 forward
+// (w is (rows, K, 27)), flip 1 backward-data (w is (K, rows, 27), taps mirrored); fold: row o scaled by the folded BatchNorm scale
+// and the shifts written to the floats at wp + total.
+__global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip,
+                               int fold, mode_bn_epilogue bn) {
+  const long long total = (long long)MT * NCHUNK * NPAIR * 64;
+  if (fold && blockIdx.x == 0) {
+    float* shifts = reinterpret_cast<float*>(wp + total * 3);
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+  }
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int pair = (int)(r % NPAIR);
+    r /= NPAIR;
+    const int ch = (int)(r % NCHUNK);
+    const int m = (int)(r / NCHUNK);
+    const int o = m * 32 + (lane & 31);
+    const int tap = 2 * pair + (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * 8 + j;
+      v[j] = 0.f;
+      if (o < rows && c < K && tap < 27)
+        v[j] = flip == 0 ? w[((long long)o * K + c) * 27 + tap] : w[((long long)c * rows + o) * 27 + (26 - tap)];
+      if (fold && o < rows) v[j] *= fold_scale(bn, o);
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wp + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also drains the vector-memory counter, i.e. waits for the weight
+// fragments already requested for the next chunk and for the output stores of a finished tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of a tap inside the haloed tile
+  return (tap / 9) * (IH * IW) + ((tap / 3) % 3) * IW + tap % 3;
+}
+
+template <int MT, bool EPI>
+__global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                          float* __restrict__ y, SDims d, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][ITEMS]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+  // this workgroup's tiles: XCD x = blockIdx % 8 owns a contiguous tile range, its workgroups take every nwx-th tile of it
+  const int nwx = gridDim.x / kNumXCD;
+  const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+  const int q = d.ntiles / kNumXCD, rr = d.ntiles % kNumXCD;
+  const int t_begin = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+  const int t_count = xcd < rr ? q + 1 : q;
+  const int mine = slot < t_count ? (t_count - slot + nwx - 1) / nwx : 0;  // tiles of this workgroup
+  const int G = mine * d.NCHUNK;                                           // chunks in its stream
+
+  const long long HW = (long long)d.H * d.W;
+  const long long DHW = (long long)d.D * HW;
+
+  auto tile_of = [&](int k, int& b, int& d0, int& h0, int& w0) {
+    int t = t_begin + slot + k * nwx;
+    w0 = (t % d.nWt) * 32;
+    t /= d.nWt;
+    h0 = (t % d.nHt) * TH;
+    t /= d.nHt;
+    d0 = (t % d.nDt) * TD;
+    b = t / d.nDt;
+  };
+
+  // ---- staging: position k of this thread is (depth row, row, column) = (pdz, phy, pwi)[k] of the haloed tile, in every tile
+  int pdz[KIT], phy[KIT], pwi[KIT], poff[KIT];
+#pragma unroll
+  for (int k = 0; k < KIT; ++k) {
+    const int item = min(tid + k * NT, ITEMS - 1);
+    const int row = item / IW;
+    pwi[k] = item - row * IW;
+    pdz[k] = row / IH;
+    phy[k] = row - pdz[k] * IH;
+    poff[k] = pdz[k] * (int)HW + phy[k] * d.W + pwi[k];
+  }
+  float raw[KIT][8];
+  unsigned okmask = 0;
+  // Loads of the next chunk: unconditional, from clamped addresses, position k under tap pair k and split under pair k + 8 -- the
+  // workgroups run in lockstep, and 48 loads per thread issued at once by every CU arrive as one 20 MB burst that takes a whole
+  // chunk time to drain (measured: 0.92 ms per launch against 0.74 with the same loads served from cache).  No `&&` in here: the
+  // compiler turns a chain of short-circuit tests into nested branches, and a branch ends the region in which these instructions
+  // can move under the MFMAs.
+  const float* st_xc = x;
+  int st_base = 0, st_d0 = 0, st_h0 = 0, st_w0 = 0;
+  auto stage_begin = [&](int g) {  // scalar part: which tile / channels chunk g reads
+    int b;
+    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
+    tile_of(k_tile, b, st_d0, st_h0, st_w0);
+    st_xc = x + ((long long)b * d.K + ch * 8) * DHW;
+    st_base = (st_d0 - 1) * (int)HW + (st_h0 - 1) * d.W + (st_w0 - 1);
+    okmask = 0;
+  };
+  auto stage_load = [&](int k) {  // the 8 channel values of position k
+    const unsigned ok = (unsigned)((unsigned)(st_d0 + pdz[k] - 1) < (unsigned)d.D) & (unsigned)((unsigned)(st_h0 + phy[k] - 1) < (unsigned)d.H) &
+                        (unsigned)((unsigned)(st_w0 + pwi[k] - 1) < (unsigned)d.W);
+    okmask |= ok << k;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* xcc = st_xc + (long long)c * DHW;  // uniform base (scalar registers) + 32-bit lane offset: no 64-bit vector adds
+      raw[k][c] = xcc[off];                            // (K is a multiple of 8)
+    }
+  };
+  // split position k of the loaded chunk and write its three pieces into buffer `buf`, in two halves (one per tap pair):
+  // half 0 splits channels 0..3, half 1 channels 4..7 and stores.  Branch-free: the code sits between the MFMAs of a pair.
+  uint32_t sq[3][4];
+  auto stage_commit = [&](int buf, int k, int h) {
+    const bool ok = (okmask >> k) & 1;
+#pragma unroll
+    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(ok ? raw[k][2 * j] : 0.f, ok ? raw[k][2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+    if (h == 1) {
+      uint4* dst = sm + buf * BUF + tid + k * NT;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[p * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
+    }
+  };
+
+  f32x16 acc[MT][R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[m][r] = (f32x16){0};
+  int rowpos[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = wave * R + r;
+    rowpos[r] = (row / TH) * (IH * IW) + (row % TH) * IW + (lane & 31);
+  }
+  const int half = lane >> 5;
+  const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
+
+  // weight fragments: a ring of 7 tap pairs, fetched 6 pairs ahead (their loads queue behind the 48 staging loads of a chunk)
+  uint4 aring[7][MT][3];
+  auto load_a = [&](int slot7, int ch, int pair) {
+    const uint4* wq = wp + ((long long)ch * NPAIR + pair) * 192 + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) aring[slot7][m][p] = wq[m * mstride + p * 64];
+  };
+
+  if (G > 0) {
+    stage_begin(0);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) stage_load(k);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) {
+      stage_commit(0, k, 0);
+      stage_commit(0, k, 1);
+    }
+#pragma unroll
+    for (int pair = 0; pair < 6; ++pair) load_a(pair, 0, pair);
+  }
+  __syncthreads();
+
+  int ch = 0, k_tile = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint4* src = sm + (g & 1) * BUF;
+    const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
+    // the chunk staged under this one; after the last chunk it is staged once more into the idle buffer, which keeps the loop body
+    // free of branches (a branch would pin the staging code to one spot instead of letting it spread between the MFMAs)
+    stage_begin(min(g + 1, G - 1));
+    uint4 bq[2][R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? tap_off(1) : tap_off(0))];
+#pragma unroll
+    for (int pair = 0; pair < NPAIR; ++pair) {
+      // fragments of the next pair (the empty second half of the last pair reads tap 26 again: finite data under zero weights)
+      if (pair + 1 < NPAIR) {
+        const int t0 = 2 * (pair + 1), t1 = t0 + 1 < 27 ? t0 + 1 : 26;
+        const int toff = half ? tap_off(t1) : tap_off(t0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bq[(pair + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];
+      }
+      // weights 6 pairs ahead, into the slot the previous pair has left
+      if (pair + 6 < NPAIR)
+        load_a((pair + 6) % 7, ch, pair + 6);
+      else
+        load_a((pair + 6) % 7, ch_next, pair + 6 - NPAIR);
+      // the staging arithmetic sits under the last 6 pairs, one position each: the loads have had 8 pairs (~6 000 cycles) to land
+      if (pair < KIT) stage_load(pair);
+      if (pair >= NPAIR - KIT) {
+        stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 0);
+        stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 1);
+      }
+      // smallest terms first; consecutive MFMAs go to different accumulators
+#define MODE_SPLIT_TERM(PA, PB)                                                      \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
+      acc[m][r] = mfma_bf16(aring[pair % 7][m][PA], bq[pair & 1][r][PB], acc[m][r]);
+      MODE_SPLIT_TERM(2, 0)
+      MODE_SPLIT_TERM(0, 2)
+      MODE_SPLIT_TERM(1, 1)
+      MODE_SPLIT_TERM(1, 0)
+      MODE_SPLIT_TERM(0, 1)
+      MODE_SPLIT_TERM(0, 0)
+#undef MODE_SPLIT_TERM
+      // one MFMA, then up to 3 vector-ALU instructions and one fragment read, 24 times: spreads the staging arithmetic and the
+      // next pair's reads over the matrix instructions (5 single-issue slots fit under one 32x32x16 MFMA)
+#pragma unroll
+      for (int i = 0; i < MT * R * 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch == d.NCHUNK - 1) {  // tile finished: D[i = o][j = w]
+      int b, d0, h0, w0;
+      tile_of(k_tile, b, d0, h0, w0);
+      float* yb = y + (long long)b * d.Co * DHW;
+      const int gw = w0 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = wave * R + r;
+        const int gd = d0 + row / TH, gh = h0 + row % TH;
+        if (gd < d.D && gh < d.H && gw < d.W) {
+          const long long sp = gd * HW + (long long)gh * d.W + gw;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              if (o < d.Co) {
+                const long long idx = o * DHW + sp;
+                yb[idx] = EPI ? apply_epi(epi, acc[m][r][qq], o, (long long)b * d.Co * DHW + idx) : acc[m][r][qq];
+              }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][r] = (f32x16){0};
+      }
+      ++k_tile;
+    }
+    ch = ch_next;
+    lds_barrier();
+  }
+}
+
+template <int MT>
+int launch_split(const float* x, const float* wpack, float* y, SDims d, hipStream_t st, const char* who, Epi epi) {
+  const uint4* wp = reinterpret_cast<const uint4*>(wpack);
+  const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
+  if (epi.shift) {
+    int rc = mode::allow_lds(conv3d_split_kernel<MT, true>, LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, true>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    return mode::check_launch(who);
+  }
+  int rc = mode::allow_lds(conv3d_split_kernel<MT, false>, LDS_BYTES, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL((conv3d_split_kernel<MT, false>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+  return mode::check_launch(who);
+}
+
+}  // namespace
+
+namespace mode {
+
+size_t conv3d_split_wpack_floats(int K, int rows) {
+  return (size_t)cdiv(rows, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4 + 32 * (size_t)cdiv(rows, 32);
+}
+
+bool conv3d_split_supported(int K, int rows) { return rows > 1 && rows <= 32 && K % 8 == 0; }
+
+int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn) {
+  SDims d;
+  d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
+  d.MT = cdiv(rows, 32);
+  d.NCHUNK = cdiv(K, 8);
+  MODE_REQUIRE(conv3d_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output channels not supported by the split kernel", who,
+               rows);
+  d.nWt = cdiv(W, 32);
+  d.nHt = cdiv(H, TH);
+  d.nDt = cdiv(D, TD);
+  d.ntiles = B * d.nDt * d.nHt * d.nWt;
+  const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
+  hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
+                     d.NCHUNK, flip, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  return launch_split<1>(x, wpack, y, d, st, who, epi);
+}
+
+}  // namespace mode

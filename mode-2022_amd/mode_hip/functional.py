@@ -873,6 +873,26 @@ def _wpack3d(ci, co, device):
   return torch.empty(n // 4, dtype=torch.float32, device=device)
 
 
+# Arithmetic of the stride-1 3x3x3 layers (the 3D regulariser's 45 ms):
+#   'f32'    v_mfma_f32_32x32x2_f32 (csrc/conv3d.hip)
+#   'bf16x6' fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32 accumulation
+#            (csrc/conv3d_split.hip): the rounding of an fp32 convolution at ~1.7 x the speed; layers the split kernels do not cover
+#            (stride 2, transposed, > 32 output channels of the GEMM, single-channel heads) stay on the fp32 kernels.
+# Process-wide, read at call time; set it before the first forward (bench.py --conv3d-arith).
+CONV3D_ARITH = 'f32'
+
+
+def set_conv3d_arith(kind):
+  global CONV3D_ARITH
+  if kind not in ('f32', 'bf16x6'):
+    raise ValueError("conv3d arithmetic must be 'f32' or 'bf16x6', got %r" % (kind,))
+  CONV3D_ARITH = kind
+
+
+def _split3d(ci, co, stride, backward_data):
+  return CONV3D_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(backward_data)) == 1
+
+
 def _out3(n, stride):
   return (n - 1) // stride + 1
 
@@ -896,7 +916,10 @@ def conv3d_fwd(x, w, stride=1):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)), 'mode_conv3d_fwd')
+    if _split3d(Ci, Co, stride, False):
+      check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_split')
+    else:
+      check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)), 'mode_conv3d_fwd')
   return y
 
 
@@ -912,8 +935,12 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                   4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
-    check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
-          'mode_conv3d_bwd_data')
+    if _split3d(Ci, Co, stride, True):
+      check(lib().mode_conv3d_bwd_data_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
+            'mode_conv3d_bwd_data_split')
+    else:
+      check(lib().mode_conv3d_bwd_data(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
+            'mode_conv3d_bwd_data')
   return gx
 
 
@@ -1217,8 +1244,12 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
-          'mode_conv3d_fwd_bn')
+    if _split3d(Ci, Co, stride, False):
+      check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+            'mode_conv3d_fwd_split')
+    else:
+      check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
+            'mode_conv3d_fwd_bn')
   return y
 
 

@@ -38,6 +38,15 @@ def _need_gpu():
   mode_hip.lib()
 
 
+@pytest.fixture(params=['f32', 'bf16x6'])
+def arith(request):
+  """Both arithmetics of the stride-1 3x3x3 layers (functional.CONV3D_ARITH): fp32 MFMA and the split-bf16 matrix path."""
+  from mode_hip import functional as HF
+  HF.set_conv3d_arith(request.param)
+  yield request.param
+  HF.set_conv3d_arith('f32')
+
+
 def _load(z, bn_from_fixture=False):
   maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
   mix, logit_scale = [float(v) for v in z['wc']]
@@ -126,29 +135,29 @@ def _check_pred(name, got, z, key, e_ref):
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'cfg1', 'full'])
-def test_train_outputs_and_gradients_within_1e3_of_the_reference(golden, tag):
+def test_train_outputs_and_gradients_within_1e3_of_the_reference(golden, tag, arith):
   z = golden('model_wc_%s.npz' % tag)
   net, left, right, gt, seed = _load(z)
   net.train()
   preds = net(left, right)
   for i, p in enumerate(preds):
-    _check_pred('%s train pred%d' % (tag, i + 1), p, z, 'train/pred%d' % (i + 1), z['truth64/train_E_ref'])
+    _check_pred('%s [%s] train pred%d' % (tag, arith, i + 1), p, z, 'train/pred%d' % (i + 1), z['truth64/train_E_ref'])
   loss = mode_ref.training_loss(preds, gt, ~torch.isnan(gt))
   ref_loss = float(z['train/loss'])
   assert abs(float(loss.detach()) - ref_loss) <= 2e-5 * ref_loss, (float(loss.detach()), ref_loss)
   loss.backward()
-  _check_grads(tag, net, z, seed)
+  _check_grads('%s [%s]' % (tag, arith), net, z, seed)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'cfg1', 'full'])
-def test_eval_output_within_1e3_of_the_reference(golden, tag):
+def test_eval_output_within_1e3_of_the_reference(golden, tag, arith):
   z = golden('model_wc_%s.npz' % tag)
   net, left, right, gt, seed = _load(z, bn_from_fixture=True)
   net.eval()
   net.out_conf = True
   with torch.no_grad():
     pred, conf = net(left, right)
-  _check_pred('%s eval pred3' % tag, pred, z, 'eval/pred3', z['truth64/eval_E_ref'])
+  _check_pred('%s [%s] eval pred3' % (tag, arith), pred, z, 'eval/pred3', z['truth64/eval_E_ref'])
   sub = int(z['sub'])
   # confidence = P(round(d) - 1) + P(round(d)) + P(round(d) + 1): compare where round(d) is not at a tie
   ref_pred = z['eval/pred3']
@@ -157,7 +166,7 @@ def test_eval_output_within_1e3_of_the_reference(golden, tag):
   assert diff[stable].max() < 1e-3, diff[stable].max()
 
 
-def test_config2_batch_of_two_at_full_size(golden):
+def test_config2_batch_of_two_at_full_size(golden, arith):
   """BASELINE configs[2]: 1024 x 512, 192 disparities, batch 2, forward + backward.  The reference fixture holds ONE pair (a CPU
   run of two costs minutes and ~50 GB); a batch of two copies of that pair has the same BatchNorm statistics as the pair alone, so
   every sample of the batch-2 step must reproduce the reference's batch-1 outputs to the north_star's 1e-3, and the parameter

@@ -1,0 +1,151 @@
+"""GPU (-m gpu): the stride-1 3x3x3 layers on the split-bf16 matrix path (csrc/conv3d_split.hip, functional.CONV3D_ARITH = 'bf16x6').
+
+The claim under test is that this path computes an fp32 convolution: every check uses the SAME bound as the fp32 MFMA kernels'
+tests (2^-22 * sqrt(terms) * 8 relative to the largest exact output, tests/test_gpu_fullsize.py), against float64 references
+(torch's conv3d on the CPU for the small shapes, oracle/conv_ref.py at the benchmark size), and the error is printed next to the
+fp32 kernel's on the same inputs.  Whole-model parity with the reference in this mode: tests/test_gpu_parity.py (parametrised
+over both arithmetics)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import conv_ref
+
+import mode_hip
+from mode_hip import functional as HF
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+  assert torch.cuda.is_available(), 'GPU tests need a GPU'
+  mode_hip.lib()
+
+
+@pytest.fixture
+def split_arith():
+  HF.set_conv3d_arith('bf16x6')
+  yield
+  HF.set_conv3d_arith('f32')
+
+
+def _rand(shape, seed, scale=1.0):
+  return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _err(got, want):
+  return float((got.detach().cpu().double() - want).abs().max())
+
+
+def _tol(terms, want):
+  return 2.0**-22 * np.sqrt(terms) * 8 * max(1.0, float(want.abs().max()))
+
+
+CASES = [
+    (2, 8, 8, 8, 8, 8),       # one chunk, 8 of 32 output rows, narrower than a column tile
+    (1, 32, 32, 6, 10, 40),   # ragged W and H tiles
+    (1, 64, 32, 4, 8, 32),    # dres0.0 (two chunk quartets)
+    (2, 16, 20, 5, 7, 33),    # nothing divides anything
+    (1, 32, 32, 3, 17, 130),  # odd depth, 5 column tiles
+    (1, 32, 32, 12, 64, 64),  # several tiles per workgroup: the chunk stream crosses tile boundaries
+    (3, 24, 32, 2, 8, 32),    # batch of three
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,D,H,W', CASES)
+def test_split_forward_and_input_gradient_are_fp32_convolutions(B, Ci, Co, D, H, W, split_arith):
+  assert mode_hip.lib().mode_conv3d_split_supported(Ci, Co, 1, 0) == 1
+  x = _rand((B, Ci, D, H, W), 141)
+  w = _rand((Co, Ci, 3, 3, 3), 142, (2.0 / (27 * Co))**0.5)
+  gy = _rand((B, Co, D, H, W), 143)
+  xa = x.double().requires_grad_(True)
+  want = F.conv3d(xa, w.double(), None, 1, 1)
+  want.backward(gy.double())
+  xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
+  y = HF.conv3d_fwd(xd, wd, 1)
+  e_split, tol = _err(y, want.detach()), _tol(Ci * 27, want.detach())
+  HF.set_conv3d_arith('f32')
+  e_f32 = _err(HF.conv3d_fwd(xd, wd, 1), want.detach())
+  HF.set_conv3d_arith('bf16x6')
+  print('fwd %s: split %.3e, fp32 MFMA %.3e, bound %.3e' % ((B, Ci, Co, D, H, W), e_split, e_f32, tol))
+  assert e_split <= tol
+  assert torch.equal(y, HF.conv3d_fwd(xd, wd, 1)), 'not deterministic'
+  if mode_hip.lib().mode_conv3d_split_supported(Ci, Co, 1, 1) == 1:
+    gx = HF.conv3d_bwd_data(gd, wd, x.shape, 1)
+    e_split, tol = _err(gx, xa.grad), _tol(Co * 27, xa.grad)
+    print('bwd_data: split %.3e, bound %.3e' % (e_split, tol))
+    assert e_split <= tol
+
+
+def test_split_through_autograd_and_fallback_layers(split_arith):
+  """HF.conv3d (the autograd op the model calls) in split mode; a 32 -> 64 layer (two output tiles: not covered) and a stride-2
+  layer keep running on the fp32 kernels, and so does the input gradient of a 64 -> 32 layer (64 rows)."""
+  lib = mode_hip.lib()
+  assert lib.mode_conv3d_split_supported(32, 64, 1, 0) == 0 and lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0
+  assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 0
+  assert lib.mode_conv3d_split_supported(12, 32, 1, 0) == 0  # reduction channels not a multiple of 8
+  for (ci, co, stride) in ((64, 32, 1), (32, 64, 1), (32, 32, 2), (12, 32, 1)):
+    x = _rand((1, ci, 4, 8, 32), 151)
+    w = _rand((co, ci, 3, 3, 3), 152, 0.05)
+    xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = F.conv3d(xa, wa, None, stride, 1)
+    gy = _rand(tuple(want.shape), 153)
+    want.backward(gy.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = HF.conv3d(xd, wd, stride)
+    y.backward(gy.to(DEV))
+    assert _err(y, want.detach()) <= _tol(ci * 27, want.detach()), (ci, co, stride)
+    assert _err(xd.grad, xa.grad) <= _tol(co * 27, xa.grad), (ci, co, stride)
+    assert _err(wd.grad, wa.grad) <= 2e-5 * max(1.0, float(wa.grad.abs().max())), (ci, co, stride)
+
+
+@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True), (False, False)])
+def test_split_with_the_folded_batchnorm_epilogue(relu, with_add, split_arith):
+  with torch.no_grad():
+    for ci, co in ((8, 32), (32, 20)):
+      x, w = _rand((2, ci, 6, 10, 36), 161).to(DEV), _rand((co, ci, 3, 3, 3), 162, 0.1).to(DEV)
+      bn = torch.nn.BatchNorm3d(co).to(DEV).eval()
+      r = np.random.RandomState(163)
+      bn.weight.copy_(torch.from_numpy(r.uniform(0.5, 1.5, co).astype(np.float32)))
+      bn.bias.copy_(torch.from_numpy(r.standard_normal(co).astype(np.float32)))
+      bn.running_mean.copy_(torch.from_numpy(r.standard_normal(co).astype(np.float32)))
+      bn.running_var.copy_(torch.from_numpy(r.uniform(0.5, 2.0, co).astype(np.float32)))
+      want = F.conv3d(x.cpu().double(), w.cpu().double(), None, 1, 1)
+      want = (want - bn.running_mean.cpu().double().view(1, -1, 1, 1, 1)) / torch.sqrt(bn.running_var.cpu().double().view(1, -1, 1, 1, 1) + bn.eps)
+      want = want * bn.weight.cpu().double().view(1, -1, 1, 1, 1) + bn.bias.cpu().double().view(1, -1, 1, 1, 1)
+      add = _rand(tuple(want.shape), 164).to(DEV) if with_add else None
+      if add is not None:
+        want = want + add.cpu().double()
+      if relu:
+        want = torch.relu(want)
+      got = HF.conv3d_bn_eval(x, w, bn, 1, add, relu)
+      assert _err(got, want) < 1e-5 * max(1.0, float(want.abs().max())) * 4, (ci, co)
+
+
+def test_split_at_the_benchmark_size_against_the_float64_oracle(split_arith):
+  """32 -> 32 at 48 x 256 x 128 (one sample): forward and input gradient against oracle/conv_ref.py, same bound as the fp32 kernels'
+  full-size test; the fp32 MFMA kernel's error on the same inputs is printed beside it."""
+  D, H, W = 48, 256, 128
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  x = _rand((1, 32, D, H, W), 1)
+  w = _rand((32, 32, 3, 3, 3), 2, (2.0 / (27 * 32))**0.5)
+  gy = _rand((1, 32, D, H, W), 3)
+  xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
+  want = conv_ref.conv3d_fwd(x, w, 1)
+  got = HF.conv3d_fwd(xd, wd, 1)
+  HF.set_conv3d_arith('f32')
+  got32 = HF.conv3d_fwd(xd, wd, 1)
+  HF.set_conv3d_arith('bf16x6')
+  e, e32, tol = _err(got, want), _err(got32, want), _tol(32 * 27, want)
+  rms = float((got.cpu().double() - want).pow(2).mean().sqrt())
+  rms32 = float((got32.cpu().double() - want).pow(2).mean().sqrt())
+  print('conv3d_fwd 32->32 full size: split max %.3e rms %.3e | fp32 MFMA max %.3e rms %.3e | bound %.3e' % (e, rms, e32, rms32, tol))
+  assert e <= tol
+  assert rms <= 1.25 * rms32, 'the split path must not be less accurate than the fp32 MFMA kernel'
+  want = conv_ref.conv3d_bwd_data(gy, w, x.shape, 1)
+  e = _err(HF.conv3d_bwd_data(gd, wd, x.shape, 1), want)
+  print('conv3d_bwd_data 32->32 full size: split max %.3e (bound %.3e)' % (e, _tol(32 * 27, want)))
+  assert e <= _tol(32 * 27, want)
