@@ -311,13 +311,16 @@ int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue*
 /* The same stride-1 layers on the bf16 matrix pipe with three-way split fp32 operands (csrc/conv3d_split.hip): six exact bf16
  * partial products per fp32 product, fp32 accumulation -- the rounding of an fp32 convolution at ~1.7 x the speed of the fp32 MFMA
  * kernels.  mode_conv3d_split_supported() says whether a layer can take this path (stride 1, <= 32 output channels of the GEMM,
- * reduction channels a multiple of 8; backward_data != 0 asks for the input-gradient GEMM, whose roles of Ci / Co are swapped);
- * mode_conv3d_fwd_split takes an optional folded-BatchNorm epilogue (NULL: plain convolution); wpack as mode_conv3d_fwd. */
-int mode_conv3d_split_supported(int Ci, int Co, int stride, int backward_data);
+ * reduction channels a multiple of 8; in the input-gradient GEMM the roles of Ci / Co are swapped; weight gradient: stride 1 and
+ * more than one output channel).  mode_conv3d_fwd_split takes an optional folded-BatchNorm epilogue (NULL: plain convolution);
+ * wpack as mode_conv3d_fwd; mode_conv3d_bwd_weight_split: arguments and workspace as mode_conv3d_bwd_weight with stride 1. */
+int mode_conv3d_split_supported(int Ci, int Co, int stride, int which /* 0 forward, 1 input gradient, 2 weight gradient */);
 int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int D,
                           int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                mode_stream_t stream);
+int mode_conv3d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,
+                                 int Co, int accumulate, mode_stream_t stream);
 
 size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride);
 

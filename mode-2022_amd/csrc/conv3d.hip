@@ -541,9 +541,10 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
   return n * sizeof(float);
 }
 
-extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int backward_data) {
+extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int which) {
   if (stride != 1 || Ci <= 0 || Co <= 0) return 0;
-  return backward_data ? mode::conv3d_split_supported(Co, Ci) : mode::conv3d_split_supported(Ci, Co);
+  if (which == 2) return Co > 1;  // weight gradient: any channel counts (32 x 32 blocks, masked)
+  return which == 1 ? mode::conv3d_split_supported(Co, Ci) : mode::conv3d_split_supported(Ci, Co);
 }
 
 extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
@@ -1221,6 +1222,38 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
+}
+
+extern "C" int mode_conv3d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
+                                            int W, int Co, int accumulate, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_weight_split";
+  int rc = check_conv_args(gy, x, gw, workspace, B, Ci, D, H, W, Co, 1, who);
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(mode_conv3d_split_supported(Ci, Co, 1, 2) == 1 && (long long)std::max(Ci, Co) * D * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED,
+               "%s: layer not covered by the split kernels (single output channel, or a sample beyond 2^29 elements)", who);
+  hipStream_t st = mode::as_stream(stream);
+  if (B == 0) {
+    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
+    return MODE_OK;
+  }
+  WDims d;
+  make_wdims(d, B, Ci, D, H, W, Co, 1);
+  mode::WgradSplitDims q;
+  q.Ci = Ci; q.Co = Co; q.D = D; q.H = H; q.W = W;
+  q.nWt = d.nWt; q.nHt = d.nHt; q.MTo = d.MTo; q.MTc = d.MTc;
+  // one workgroup per CU and (o, c) block pair (152 KB of LDS each); depths per unit as for the fp32 ring kernel
+  int S = mode::cdiv(kNumCU, d.MTo * d.MTc);
+  int ring_dc = D;
+  while (ring_dc > 6 && (long long)B * d.nHt * d.nWt * mode::cdiv(D, ring_dc) < 2ll * S) ring_dc = mode::cdiv(ring_dc, 2);
+  q.ring_dc = ring_dc;
+  q.nDc = mode::cdiv(D, ring_dc);
+  q.units = B * d.nHt * d.nWt * q.nDc;
+  if (S > q.units) S = q.units;
+  q.S = d.S = S;  // (<= the S of make_wdims, which sized the workspace)
+  rc = mode::conv3d_bww_split_launch(gy, x, workspace, q, st, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  return mode::check_launch("mode_conv3d_bwd_weight_split(reduce)");
 }
 
 // Transposed convolution k3 s2 p1 op1 (= backward-data of the stride-2 convolution).

@@ -24,4 +24,13 @@ size_t conv3d_split_wpack_floats(int K, int rows);
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
                     hipStream_t st, const char* who, const mode_bn_epilogue* bn);
 
+// conv3d_split_wgrad.hip: split-K partials of the stride-1 weight gradient on the split-bf16 matrix path, written in the layout of
+// conv3d.hip's weight-gradient kernels (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.
+struct WgradSplitDims {
+  int Ci, Co, D, H, W;
+  int nWt, nHt, nDc, ring_dc, units;  // units = B * nHt * nWt * nDc work units of ring_dc depths x 2 rows x 32 voxels
+  int S, MTo, MTc;                    // workgroups along the split-K axis, 32-channel blocks of gy / x
+};
+int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who);
+
 }  // namespace mode

@@ -889,8 +889,9 @@ def set_conv3d_arith(kind):
   CONV3D_ARITH = kind
 
 
-def _split3d(ci, co, stride, backward_data):
-  return CONV3D_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(backward_data)) == 1
+def _split3d(ci, co, stride, which):
+  """which: 0 forward, 1 input gradient, 2 weight gradient."""
+  return CONV3D_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(which)) == 1
 
 
 def _out3(n, stride):
@@ -959,8 +960,12 @@ def conv3d_bwd_weight(gy, x, stride=1, into=None):
                                                   4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
     n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, stride)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-    check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, int(into is not None), stream_of(gy)),
-          'mode_conv3d_bwd_weight')
+    if _split3d(Ci, Co, stride, 2) and max(Ci, Co) * D * H * W < 2**29:
+      check(lib().mode_conv3d_bwd_weight_split(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None), stream_of(gy)),
+            'mode_conv3d_bwd_weight_split')
+    else:
+      check(lib().mode_conv3d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, stride, int(into is not None), stream_of(gy)),
+            'mode_conv3d_bwd_weight')
   return gw
 
 

@@ -80,6 +80,40 @@ def test_split_forward_and_input_gradient_are_fp32_convolutions(B, Ci, Co, D, H,
     assert e_split <= tol
 
 
+WGRAD_CASES = [
+    (2, 8, 8, 8, 8, 8),
+    (1, 32, 32, 6, 10, 40),
+    (1, 64, 32, 4, 8, 32),    # two x blocks
+    (1, 32, 64, 4, 8, 32),    # two gy blocks
+    (2, 20, 40, 5, 7, 33),    # partial blocks, odd width: the pair loads straddle the row end
+    (1, 32, 32, 13, 64, 64),  # several units per workgroup, depth runs of different length
+    (1, 16, 16, 1, 2, 31),    # a single depth
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,D,H,W', WGRAD_CASES)
+def test_split_weight_gradient_is_an_fp32_weight_gradient(B, Ci, Co, D, H, W, split_arith):
+  assert mode_hip.lib().mode_conv3d_split_supported(Ci, Co, 1, 2) == 1
+  x = _rand((B, Ci, D, H, W), 171)
+  gy = _rand((B, Co, D, H, W), 172)
+  wa = torch.zeros((Co, Ci, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+  F.conv3d(x.double(), wa, None, 1, 1).backward(gy.double())
+  want = wa.grad
+  xd, gd = x.to(DEV), gy.to(DEV)
+  got = HF.conv3d_bwd_weight(gd, xd, 1)
+  HF.set_conv3d_arith('f32')
+  got32 = HF.conv3d_bwd_weight(gd, xd, 1)
+  HF.set_conv3d_arith('bf16x6')
+  scale = max(1.0, float(want.abs().max()))
+  e, e32 = _err(got, want), _err(got32, want)
+  print('bwd_weight %s: split %.3e, fp32 MFMA %.3e (scale %.3g)' % ((B, Ci, Co, D, H, W), e, e32, scale))
+  assert e <= 2e-5 * scale  # the bound of the fp32 kernels' test (tests/test_gpu_kernels.py::test_conv3d_fwd_bwd)
+  assert torch.equal(got, HF.conv3d_bwd_weight(gd, xd, 1)), 'not deterministic'
+  acc = torch.ones_like(got)
+  HF.conv3d_bwd_weight(gd, xd, 1, into=acc)
+  assert torch.allclose(acc, got + 1.0, rtol=0, atol=1e-5 * scale), 'accumulating form'
+
+
 def test_split_through_autograd_and_fallback_layers(split_arith):
   """HF.conv3d (the autograd op the model calls) in split mode; a 32 -> 64 layer (two output tiles: not covered) and a stride-2
   layer keep running on the fp32 kernels, and so does the input gradient of a 64 -> 32 layer (64 rows)."""
@@ -87,6 +121,7 @@ def test_split_through_autograd_and_fallback_layers(split_arith):
   assert lib.mode_conv3d_split_supported(32, 64, 1, 0) == 0 and lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0
   assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 0
   assert lib.mode_conv3d_split_supported(12, 32, 1, 0) == 0  # reduction channels not a multiple of 8
+  assert lib.mode_conv3d_split_supported(12, 32, 1, 2) == 1 and lib.mode_conv3d_split_supported(32, 1, 1, 2) == 0
   for (ci, co, stride) in ((64, 32, 1), (32, 64, 1), (32, 32, 2), (12, 32, 1)):
     x = _rand((1, ci, 4, 8, 32), 151)
     w = _rand((co, ci, 3, 3, 3), 152, 0.05)
@@ -149,3 +184,12 @@ def test_split_at_the_benchmark_size_against_the_float64_oracle(split_arith):
   e = _err(HF.conv3d_bwd_data(gd, wd, x.shape, 1), want)
   print('conv3d_bwd_data 32->32 full size: split max %.3e (bound %.3e)' % (e, _tol(32 * 27, want)))
   assert e <= _tol(32 * 27, want)
+  want = conv_ref.conv3d_bwd_weight(gy, x, 1)
+  got = HF.conv3d_bwd_weight(gd, xd, 1)
+  HF.set_conv3d_arith('f32')
+  got32 = HF.conv3d_bwd_weight(gd, xd, 1)
+  HF.set_conv3d_arith('bf16x6')
+  scale = max(1.0, float(want.abs().max()))
+  print('conv3d_bwd_weight 32->32 full size: split max %.3e, fp32 MFMA max %.3e (scale %.3g; bound 1e-4 * scale)' %
+        (_err(got, want), _err(got32, want), scale))
+  assert _err(got, want) <= 1e-4 * scale  # the bound of tests/test_gpu_fullsize.py for the fp32 kernels

@@ -14,6 +14,7 @@
 
 extern "C" int mode_conv3d_fwd_split(const float*, const float*, const mode_bn_epilogue*, float*, float*, int, int, int, int, int, int,
                                      mode_stream_t);
+extern "C" int mode_conv3d_bwd_weight_split(const float*, const float*, float*, float*, int, int, int, int, int, int, int, mode_stream_t);
 extern "C" int mode_conv3d_bwd_data_split(const float*, const float*, float*, float*, int, int, int, int, int, int, mode_stream_t);
 
 #define CK(e)                                                                 \
@@ -100,5 +101,57 @@ int main(int argc, char** argv) {
   }
   printf("error against an exact evaluation at %d sampled outputs (|y| up to %.2f):\n  split bf16 x 6 : max %.3e rms %.3e\n"
          "  fp32 MFMA      : max %.3e rms %.3e\n", NS, ymax, m_s, std::sqrt(s_s / NS), m_f, std::sqrt(s_f / NS));
-  return (m_s < 5e-5 && m_f < 5e-5) ? 0 : 2;
+  // ---- weight gradient: gW = sum gy * x over all voxels (x doubles as the operand, y32 as gy)
+  float *gw, *gw32, *ws;
+  CK(hipMalloc(&gw, nw * 4));
+  CK(hipMalloc(&gw32, nw * 4));
+  CK(hipMalloc(&ws, mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, 1)));
+  for (int which = 0; which < 2; ++which) {
+    auto run = [&]() {
+      return which == 0 ? mode_conv3d_bwd_weight(y32, x, gw32, ws, B, Ci, D, H, W, Co, 1, 0, nullptr)
+                        : mode_conv3d_bwd_weight_split(y32, x, gw, ws, B, Ci, D, H, W, Co, 0, nullptr);
+    };
+    for (int i = 0; i < 3; ++i)
+      if (run() != MODE_OK) {
+        printf("weight gradient %s failed: %s\n", which ? "split" : "fp32", mode_last_error());
+        return 1;
+      }
+    CK(hipDeviceSynchronize());
+    const int n = 20;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < n; ++i) run();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("conv3d weight gradient %d->%d  %-22s %.3f ms per launch (incl. the split-K reduction) = %.1f TFLOP/s fp32-equivalent\n", Ci, Co,
+           which ? "split bf16 x 6:" : "fp32 MFMA:", ms / n, flop / (ms / n * 1e-3) / 1e12);
+  }
+  std::vector<float> hgw(nw), hgw32(nw);
+  CK(hipMemcpy(hgw.data(), gw, nw * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hgw32.data(), gw32, nw * 4, hipMemcpyDeviceToHost));
+  std::uniform_int_distribution<long long> pickw(0, (long long)nw - 1);
+  double wm_s = 0, wm_f = 0, wmax = 0;
+  for (int sidx = 0; sidx < 64; ++sidx) {
+    const long long idx = sidx < 27 ? sidx : pickw(rng);  // all 27 taps of (o, c) = (0, 0), then random entries
+    const int t = (int)(idx % 27), c = (int)((idx / 27) % Ci), o = (int)(idx / 27 / Ci);
+    double acc = 0;
+    for (int b = 0; b < B; ++b)
+      for (int dq = 0; dq < D; ++dq)
+        for (int hq = 0; hq < H; ++hq) {
+          const int dd = dq + t / 9 - 1, hh = hq + (t / 3) % 3 - 1;
+          if (dd < 0 || dd >= D || hh < 0 || hh >= H) continue;
+          const float* gp = &hy32[((size_t)b * Co + o) * DHW + (size_t)dq * H * W + (size_t)hq * W];
+          const float* xp = &hx[((size_t)b * Ci + c) * DHW + (size_t)dd * H * W + (size_t)hh * W];
+          for (int wq = 0; wq < W; ++wq) {
+            const int ww = wq + t % 3 - 1;
+            if (ww >= 0 && ww < W) acc += (double)gp[wq] * (double)xp[ww];
+          }
+        }
+    wm_s = std::max(wm_s, std::fabs(hgw[idx] - acc));
+    wm_f = std::max(wm_f, std::fabs(hgw32[idx] - acc));
+    wmax = std::max(wmax, std::fabs(acc));
+  }
+  printf("weight gradient against an exact evaluation at 64 entries (|gW| up to %.1f): split max %.3e, fp32 MFMA max %.3e\n", wmax, wm_s, wm_f);
+  return (m_s < 5e-5 && m_f < 5e-5 && wm_s < 1e-4 * std::max(1.0, wmax)) ? 0 : 2;
 }
