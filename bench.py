@@ -54,7 +54,7 @@ def parse():
   ap.add_argument('--vendor-autotune', type=int, default=int(os.environ.get('MODE_VENDOR_AUTOTUNE', '0')),
                   help='1: torch.backends.cudnn.benchmark = True (MIOpen times its solvers for the regular 2-D convolutions)')
   ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
-  ap.add_argument('--conv3d-arith', default='f32', choices=['f32', 'bf16x6'],
+  ap.add_argument('--conv3d-arith', default='bf16x6', choices=['f32', 'bf16x6'],
                   help="stride-1 3x3x3 layers: 'f32' = fp32 MFMA; 'bf16x6' = fp32 operands split into three bf16 pieces, six bf16 MFMAs "
                   'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV3D_ARITH)')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -342,7 +342,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.conv3d_arith == 'f32' else 'f32 (stride-1 3x3x3 forward / input-gradient layers as 6 x bf16 MFMA on exactly split fp32 operands, fp32 accumulate)',
+        'dtype': 'f32' if args.conv3d_arith == 'f32' else 'f32 (stride-1 3x3x3 layers: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j)',
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
@@ -383,7 +383,14 @@ def main():
       traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
       try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-          traffic = json.load(f).get('%s B=%d' % (dom, args.batch), {}).get('hbm_bytes_per_launch')
+          table = json.load(f)
+        # (the extractor's kernels see both views: 2 x batch images; entries measured on the fp32 MFMA 3-D kernels do not describe
+        # the split kernels)
+        if not (args.conv3d_arith == 'bf16x6' and _on_split_path(dom)):
+          for key in ('%s B=%d' % (dom, args.batch), '%s B=%d' % (dom, 2 * args.batch), dom):
+            if key in table:
+              traffic = table[key].get('hbm_bytes_per_launch')
+              break
       except (OSError, ValueError):
         pass
       out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,

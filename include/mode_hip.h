@@ -310,7 +310,7 @@ int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue*
 
 /* The same stride-1 layers on the bf16 matrix pipe with three-way split fp32 operands (csrc/conv3d_split.hip): six exact bf16
  * partial products per fp32 product, fp32 accumulation -- the rounding of an fp32 convolution at ~1.7 x the speed of the fp32 MFMA
- * kernels.  mode_conv3d_split_supported() says whether a layer can take this path (stride 1, <= 32 output channels of the GEMM,
+ * kernels.  mode_conv3d_split_supported() says whether a layer can take this path (stride 1, <= 64 output channels of the GEMM,
  * reduction channels a multiple of 8; in the input-gradient GEMM the roles of Ci / Co are swapped; weight gradient: stride 1 and
  * more than one output channel).  mode_conv3d_fwd_split takes an optional folded-BatchNorm epilogue (NULL: plain convolution);
  * wpack as mode_conv3d_fwd; mode_conv3d_bwd_weight_split: arguments and workspace as mode_conv3d_bwd_weight with stride 1. */

@@ -873,13 +873,15 @@ def _wpack3d(ci, co, device):
   return torch.empty(n // 4, dtype=torch.float32, device=device)
 
 
-# Arithmetic of the stride-1 3x3x3 layers (the 3D regulariser's 45 ms):
-#   'f32'    v_mfma_f32_32x32x2_f32 (csrc/conv3d.hip)
-#   'bf16x6' fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32 accumulation
-#            (csrc/conv3d_split.hip): the rounding of an fp32 convolution at ~1.7 x the speed; layers the split kernels do not cover
-#            (stride 2, transposed, > 32 output channels of the GEMM, single-channel heads) stay on the fp32 kernels.
-# Process-wide, read at call time; set it before the first forward (bench.py --conv3d-arith).
-CONV3D_ARITH = 'f32'
+# Arithmetic of the stride-1 3x3x3 layers (forward, input gradient, weight gradient: 2/3 of the 3D regulariser's time):
+#   'bf16x6' (default) fp32 operands split EXACTLY into three bf16 pieces when a tile is staged, six bf16 MFMAs per product (the
+#            terms >= 2^-16 of it), fp32 accumulation (csrc/conv3d_split.hip, conv3d_split_wgrad.hip).  Results carry the rounding of
+#            an fp32 convolution -- measured against float64 they are at least as close as the fp32 MFMA kernels' on the same inputs
+#            (tests/test_gpu_split.py) -- at 1.5-1.8 x their speed.  Layers the split kernels do not cover (stride 2, transposed,
+#            single-channel heads, > 64 output channels) run on the fp32 kernels.
+#   'f32'    v_mfma_f32_32x32x2_f32 everywhere (csrc/conv3d.hip).
+# Process-wide, read at call time (bench.py --conv3d-arith; the parity tests run under both).
+CONV3D_ARITH = 'bf16x6'
 
 
 def set_conv3d_arith(kind):

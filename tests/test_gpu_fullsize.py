@@ -52,7 +52,7 @@ def _close(name, got, want, terms):
 
 
 @pytest.mark.parametrize('Ci,Co,vol', [(32, 32, FULL), (64, 64, HALF), (64, 64, QUARTER)])
-def test_conv3d_stride1_all_three_kernels(Ci, Co, vol):
+def test_conv3d_stride1_all_three_kernels(Ci, Co, vol, arith):
   """dres0/dres1/classifier-type 32 -> 32 layers at 48 x 256 x 128 and the hourglass' 64 -> 64 layers at 1/8 and 1/16."""
   D, H, W = vol
   x = _rand((1, Ci, D, H, W), 1)

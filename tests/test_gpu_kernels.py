@@ -406,7 +406,7 @@ CONV3D_CASES = [
 
 
 @pytest.mark.parametrize('B,Ci,Co,D,H,W', CONV3D_CASES)
-def test_conv3d_fwd_bwd(B, Ci, Co, D, H, W):
+def test_conv3d_fwd_bwd(B, Ci, Co, D, H, W, arith):
   import torch.nn.functional as F
   x = _rand((B, Ci, D, H, W), 41)
   w = _rand((Co, Ci, 3, 3, 3), 42, (2.0 / (27 * Co))**0.5)
@@ -774,7 +774,7 @@ FOLD_VARIANTS = [(True, False), (False, True), (True, True), (False, False)]
 
 
 @pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
-def test_folded_batchnorm_conv3d(relu, with_add):
+def test_folded_batchnorm_conv3d(relu, with_add, arith):
   """mode_conv3d_fwd_bn (stride 1 with one and two output-channel tiles, stride 2) and mode_deconv3d_fwd_bn against convolution ->
   fp64 eval BatchNorm (+ add) (+ ReLU), under torch.no_grad (the fused form is inference only)."""
   import torch.nn.functional as F

@@ -38,15 +38,6 @@ def _need_gpu():
   mode_hip.lib()
 
 
-@pytest.fixture(params=['f32', 'bf16x6'])
-def arith(request):
-  """Both arithmetics of the stride-1 3x3x3 layers (functional.CONV3D_ARITH): fp32 MFMA and the split-bf16 matrix path."""
-  from mode_hip import functional as HF
-  HF.set_conv3d_arith(request.param)
-  yield request.param
-  HF.set_conv3d_arith('f32')
-
-
 def _load(z, bn_from_fixture=False):
   maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
   mix, logit_scale = [float(v) for v in z['wc']]

@@ -29,7 +29,7 @@ def _need_gpu():
 def split_arith():
   HF.set_conv3d_arith('bf16x6')
   yield
-  HF.set_conv3d_arith('f32')
+  HF.set_conv3d_arith('bf16x6')
 
 
 def _rand(shape, seed, scale=1.0):
@@ -115,14 +115,15 @@ def test_split_weight_gradient_is_an_fp32_weight_gradient(B, Ci, Co, D, H, W, sp
 
 
 def test_split_through_autograd_and_fallback_layers(split_arith):
-  """HF.conv3d (the autograd op the model calls) in split mode; a 32 -> 64 layer (two output tiles: not covered) and a stride-2
-  layer keep running on the fp32 kernels, and so does the input gradient of a 64 -> 32 layer (64 rows)."""
+  """HF.conv3d (the autograd op the model calls) in split mode: 64-channel layers run as two launches of 32 output channels; a
+  stride-2 layer, a layer whose reduction channels are not a multiple of 8 and one with 96 output channels keep running on the fp32
+  kernels."""
   lib = mode_hip.lib()
-  assert lib.mode_conv3d_split_supported(32, 64, 1, 0) == 0 and lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0
-  assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 0
+  assert lib.mode_conv3d_split_supported(32, 64, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 1
+  assert lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0 and lib.mode_conv3d_split_supported(32, 96, 1, 0) == 0
   assert lib.mode_conv3d_split_supported(12, 32, 1, 0) == 0  # reduction channels not a multiple of 8
   assert lib.mode_conv3d_split_supported(12, 32, 1, 2) == 1 and lib.mode_conv3d_split_supported(32, 1, 1, 2) == 0
-  for (ci, co, stride) in ((64, 32, 1), (32, 64, 1), (32, 32, 2), (12, 32, 1)):
+  for (ci, co, stride) in ((64, 32, 1), (32, 64, 1), (64, 64, 1), (24, 40, 1), (32, 32, 2), (12, 32, 1)):
     x = _rand((1, ci, 4, 8, 32), 151)
     w = _rand((co, ci, 3, 3, 3), 152, 0.05)
     xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
@@ -140,7 +141,7 @@ def test_split_through_autograd_and_fallback_layers(split_arith):
 @pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True), (False, False)])
 def test_split_with_the_folded_batchnorm_epilogue(relu, with_add, split_arith):
   with torch.no_grad():
-    for ci, co in ((8, 32), (32, 20)):
+    for ci, co in ((8, 32), (32, 20), (16, 64)):
       x, w = _rand((2, ci, 6, 10, 36), 161).to(DEV), _rand((co, ci, 3, 3, 3), 162, 0.1).to(DEV)
       bn = torch.nn.BatchNorm3d(co).to(DEV).eval()
       r = np.random.RandomState(163)

@@ -248,14 +248,15 @@ def test_conv3d_arithmetic_switch_and_split_predicate():
   GPU (stride 1, <= 32 output channels of the GEMM, reduction channels a multiple of 8)."""
   import mode_hip
   from mode_hip import functional as HF
-  assert HF.CONV3D_ARITH == 'f32'
+  assert HF.CONV3D_ARITH == 'bf16x6'
   with pytest.raises(ValueError):
     HF.set_conv3d_arith('bf16')
-  HF.set_conv3d_arith('bf16x6')
-  assert HF.CONV3D_ARITH == 'bf16x6'
   HF.set_conv3d_arith('f32')
+  assert HF.CONV3D_ARITH == 'f32'
+  HF.set_conv3d_arith('bf16x6')
   lib = mode_hip.lib()
   assert lib.mode_conv3d_split_supported(32, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(32, 32, 1, 1) == 1
-  assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 0
+  assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 1
+  assert lib.mode_conv3d_split_supported(32, 96, 1, 0) == 0 and lib.mode_conv3d_split_supported(12, 32, 1, 0) == 0
   assert lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0 and lib.mode_conv3d_split_supported(32, 1, 1, 0) == 0
   assert lib.mode_conv3d_wpack_bytes(32, 32) >= 4 * 14 * 3 * 64 * 16

@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-ring = [int(r['Calls']) for r in rows if 'conv3d_bwd_weight_ring_kernel' in r['Name']]
+ring = [int(r['Calls']) for r in rows if 'conv3d_bwd_weight_ring_kernel' in r['Name'] or 'conv3d_bww_split_kernel' in r['Name']]
 steps = (ring[0] / 12.0) if ring else 1.0  # 12 stride-1 3-D weight gradients with Co > 1 per step (13 without the cost-conv fusion: pass the step count as argv[3] then)
 if len(sys.argv) > 3:
   steps = float(sys.argv[3])
