@@ -54,9 +54,9 @@ def parse():
   ap.add_argument('--vendor-autotune', type=int, default=int(os.environ.get('MODE_VENDOR_AUTOTUNE', '0')),
                   help='1: torch.backends.cudnn.benchmark = True (MIOpen times its solvers for the regular 2-D convolutions)')
   ap.add_argument('--profile-steps', type=int, default=2, help='eager steps with per-kernel HIP-event timing (after the timed region)')
-  ap.add_argument('--conv3d-arith', default='bf16x6', choices=['f32', 'bf16x6'],
+  ap.add_argument('--conv-arith', default='bf16x6', choices=['f32', 'bf16x6'],
                   help="stride-1 3x3x3 layers: 'f32' = fp32 MFMA; 'bf16x6' = fp32 operands split into three bf16 pieces, six bf16 MFMAs "
-                  'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV3D_ARITH)')
+                  'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV_ARITH)')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
                   '(RCCL refuses two ranks on the same device)')
@@ -197,7 +197,7 @@ def main():
   import mode_hip
   mode_hip.lib()  # fail loudly if the native library is missing
   from mode_hip import functional as HF
-  HF.set_conv3d_arith(args.conv3d_arith)
+  HF.set_conv_arith(args.conv_arith)
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)
@@ -342,7 +342,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.conv3d_arith == 'f32' else 'f32 (stride-1 3x3x3 layers: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j)',
+        'dtype': 'f32' if args.conv_arith == 'f32' else 'f32 (stride-1 3x3x3 layers: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j)',
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
@@ -356,7 +356,7 @@ def main():
                         (args.maxdisp, args.height, args.width, 'fwd+bwd+Adam' if args.mode == 'train' else 'eval fwd',
                          args.batch, 2 if world == 1 else 3),
             'global_batch': args.batch * world,
-            'conv3d_arith': args.conv3d_arith,
+            'conv_arith': args.conv_arith,
             'parallelism': 'dp%d' % world,
             'cost_volume': ('folded into dres0[0][0] (cost_conv: 18 partial 2-D products + assembly kernel); the volume is not built, '
                             'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if net.fold_cost_volume
@@ -378,7 +378,7 @@ def main():
         achieved, peak, unit, per_launch = a['GBps'], HBM_PEAK_GBPS, 'GB/s', a['bytes_per_call']
       else:
         achieved, peak, unit, per_launch = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', a['flops_per_call']
-        if args.conv3d_arith == 'bf16x6' and _on_split_path(dom):
+        if args.conv_arith == 'bf16x6' and _on_split_path(dom):
           peak = MFMA_BF16_PEAK_TFLOPS / 6.0  # fp32-equivalent flops against the bf16 pipe: six MFMAs per product
       traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
       try:
@@ -386,7 +386,7 @@ def main():
           table = json.load(f)
         # (the extractor's kernels see both views: 2 x batch images; entries measured on the fp32 MFMA 3-D kernels do not describe
         # the split kernels)
-        if not (args.conv3d_arith == 'bf16x6' and _on_split_path(dom)):
+        if not (args.conv_arith == 'bf16x6' and _on_split_path(dom)):
           for key in ('%s B=%d' % (dom, args.batch), '%s B=%d' % (dom, 2 * args.batch), dom):
             if key in table:
               traffic = table[key].get('hbm_bytes_per_launch')

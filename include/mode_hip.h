@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 10 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 11 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -321,6 +321,16 @@ int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float
                                mode_stream_t stream);
 int mode_conv3d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,
                                  int Co, int accumulate, mode_stream_t stream);
+
+/* The regular 3x3 Conv2d layers (stride 1, dilation 1 / 2) on the same split-bf16 path (csrc/conv2d_split.hip): reduction channels
+ * a multiple of 16, <= 128 output channels of the GEMM; arguments and wpack as mode_conv2d_fwd / _bwd_data (+ optional epilogue). */
+int mode_conv2d_split_supported(int Ci, int Co, int dilation, int which /* 0 forward, 1 input gradient */);
+int mode_conv2d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H, int W,
+                          int Co, int dilation, mode_stream_t stream);
+int mode_conv2d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                               mode_stream_t stream);
+int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
+                                 int dilation, int accumulate, mode_stream_t stream); /* arguments / workspace: mode_conv2d_bwd_weight */
 
 size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride);
 

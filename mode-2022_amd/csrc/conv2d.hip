@@ -9,6 +9,7 @@
 // addresses, masks at the LDS store); weights pre-packed in fragment order and requested one tap ahead.  The input gradient is the
 // same kernel on gy with the weights transposed and flipped by the packing kernel.
 #include "common.h"
+#include "conv3d_internal.h"
 
 namespace {
 
@@ -250,7 +251,28 @@ extern "C" size_t mode_conv2d_wpack_bytes(int Ci, int Co) {
   if (Ci <= 0 || Co <= 0) return 0;
   const size_t f = (size_t)mode::cdiv(Co, 32) * mode::cdiv(Ci, CCH) * 9 * 256;
   const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 9 * 256;
-  return ((f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32)) * sizeof(float);  // + the folded BatchNorm shifts
+  size_t n = (f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32);  // + the folded BatchNorm shifts
+  n = std::max(n, std::max(mode::conv2d_split_wpack_floats(Ci, Co), mode::conv2d_split_wpack_floats(Co, Ci)));
+  return n * sizeof(float);
+}
+
+extern "C" int mode_conv2d_split_supported(int Ci, int Co, int dilation, int which) {
+  if (Ci <= 0 || Co <= 0) return 0;
+  return which == 1 ? mode::conv2d_split_supported(Co, Ci, dilation) : mode::conv2d_split_supported(Ci, Co, dilation);
+}
+
+extern "C" int mode_conv2d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H,
+                                     int W, int Co, int dilation, mode_stream_t stream) {
+  if (bn) {
+    int rc = mode::check_bn(bn, "mode_conv2d_fwd_split");
+    if (rc != MODE_OK) return rc;
+  }
+  return mode::conv2d_split_run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd_split", bn);
+}
+
+extern "C" int mode_conv2d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co,
+                                          int dilation, mode_stream_t stream) {
+  return mode::conv2d_split_run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data_split", nullptr);
 }
 
 extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,

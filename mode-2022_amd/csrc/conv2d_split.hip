@@ -1,0 +1,332 @@
+// Regular 3x3 Conv2d layers (stride 1, dilation 1 / 2, pad = dilation) of the extractor as fp32 convolutions on the bf16 matrix pipe:
+// conv3d_split.hip one dimension down.  Operands are split exactly into three bf16 pieces when a tile is staged, a product is six
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the arithmetic and its error analysis: conv3d_split.hip).
+//
+// Reference: the stock nn.Conv2d 3x3 layers of convbn (models/submodule.py:13-17) in firstconv / layer1-3 (submodule.py:155-172) and
+// the tap products of the folded cost volume -- cuDNN NCHW fp32 there.
+//
+// What differs from the 3-D kernel: K of one MFMA = 16 input CHANNELS of one tap (lanes 0..31 channels 0..7, lanes 32..63 channels
+// 8..15 of the chunk) -- with 9 taps there is no tap to pair up without wasting a tenth of the MFMAs -- so an LDS chunk is 16
+// channels deep, [3 pieces][2 channel octets][(16 + 2d) x (32 + 2d) haloed positions, padded to 768] of uint4 = 73 728 B for a
+// 16-row x 32-column output tile, double-buffered.  Per chunk a wave issues 9 taps x 4 rows x MT tiles x 6 terms = 216 / 432 MFMAs
+// and, between them, stages the next chunk: 3 positions x 16 channels per thread, position k loaded under tap k and split + stored
+// under tap 6 + k.  Weight fragments come from L2 two taps ahead (ring of 3).  Persistent workgroups, XCD-contiguous tile ranges,
+// chunk stream across tile boundaries, LDS-only barrier: as in conv3d_split.hip.
+#include "common.h"
+
+#include "conv3d_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 256;
+constexpr int TH = 16;
+constexpr int R = TH / 4;      // output rows per wave
+constexpr int KIT = 3;         // haloed positions per thread and chunk
+constexpr int PIECE = KIT * NT;  // 768 positions per (piece, octet) incl. the unused tail: no staging store is conditional
+constexpr int BUF = 3 * 2 * PIECE;  // uint4 per buffer
+constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
+
+struct S2Dims {
+  int B, K, Co, H, W;  // K = reduction channels of this GEMM, Co = its output channels
+  int nWt, nHt;
+  int NCHUNK;
+  int ntiles;
+  int o0;  // first output channel of this launch
+};
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = pack2(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  p3 = pack2(sa, sb);
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// wp[(((m * NCHUNK + ch) * 9 + tap) * 3 + piece) * 64 + lane] = 8 bf16: piece of Wsrc(o = m*32 + (lane & 31), c = ch*16 + 8 * (lane >> 5)
+// + j, tap), j = 0..7; zero for o >= rows, c >= K.  flip 0: Wsrc = w[o][c][tap] (forward, w is (rows, K, 9)); flip 1: w[c][o][8 - tap]
+// (input gradient, w is (K, rows, 9)); fold: row o scaled by the folded BatchNorm scale, shifts written behind the fragments.
+__global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip, int fold,
+                               mode_bn_epilogue bn) {
+  const long long total = (long long)MT * NCHUNK * 9 * 64;
+  if (fold && blockIdx.x == 0) {
+    float* shifts = reinterpret_cast<float*>(wp + total * 3);
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+  }
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int ch = (int)(r % NCHUNK);
+    const int m = (int)(r / NCHUNK);
+    const int o = m * 32 + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * 16 + 8 * (lane >> 5) + j;
+      v[j] = 0.f;
+      if (o < rows && c < K) v[j] = flip ? w[((long long)c * rows + o) * 9 + 8 - tap] : w[((long long)o * K + c) * 9 + tap];
+      if (fold && o < rows) v[j] *= fold_scale(bn, o);
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wp + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+template <int MT, int DIL, bool EPI>
+__global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, float* __restrict__ y,
+                                                          S2Dims d, Epi epi) {
+  constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
+  constexpr int ITEMS = IH * IW;
+  static_assert(ITEMS <= PIECE, "tile does not fit the staging slots");
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3 pieces][2 octets][PIECE]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+
+  const int nwx = gridDim.x / kNumXCD;
+  const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+  const int q = d.ntiles / kNumXCD, rr = d.ntiles % kNumXCD;
+  const int t_begin = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+  const int t_count = xcd < rr ? q + 1 : q;
+  const int mine = slot < t_count ? (t_count - slot + nwx - 1) / nwx : 0;
+  const int G = mine * d.NCHUNK;
+  const int HWi = d.H * d.W;  // (host guarantees max(K, Co) * H * W < 2^29)
+
+  auto tile_of = [&](int k, int& b, int& h0, int& w0) {
+    int t = t_begin + slot + k * nwx;
+    w0 = (t % d.nWt) * 32;
+    t /= d.nWt;
+    h0 = (t % d.nHt) * TH;
+    b = t / d.nHt;
+  };
+
+  // ---- staging: position k of this thread is (row, column) = (phy, pwi)[k] of the haloed tile, in every tile
+  int phy[KIT], pwi[KIT], poff[KIT];
+#pragma unroll
+  for (int k = 0; k < KIT; ++k) {
+    const int item = min(tid + k * NT, ITEMS - 1);
+    phy[k] = item / IW;
+    pwi[k] = item - phy[k] * IW;
+    poff[k] = phy[k] * d.W + pwi[k];
+  }
+  float raw[KIT][16];
+  unsigned okmask = 0;
+  const float* st_xc = x;
+  int st_base = 0, st_h0 = 0, st_w0 = 0;
+  auto stage_begin = [&](int g) {
+    int b;
+    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
+    tile_of(k_tile, b, st_h0, st_w0);
+    st_xc = x + ((long long)b * d.K + ch * 16) * HWi;
+    st_base = (st_h0 - DIL) * d.W + (st_w0 - DIL);
+    okmask = 0;
+  };
+  auto stage_load = [&](int k) {  // the 16 channel values of position k: unconditional, clamped address (no && : no branches)
+    const unsigned ok = (unsigned)((unsigned)(st_h0 + phy[k] - DIL) < (unsigned)d.H) & (unsigned)((unsigned)(st_w0 + pwi[k] - DIL) < (unsigned)d.W);
+    okmask |= ok << k;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float* xcc = st_xc + (long long)c * HWi;  // uniform base + 32-bit lane offset (K is a multiple of 16)
+      raw[k][c] = xcc[off];
+    }
+  };
+  auto stage_commit = [&](int buf, int k) {
+    const bool ok = (okmask >> k) & 1;
+    uint4* dst = sm + buf * BUF + tid + k * NT;
+#pragma unroll
+    for (int oct = 0; oct < 2; ++oct) {
+      uint32_t sq[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        split2(ok ? raw[k][8 * oct + 2 * j] : 0.f, ok ? raw[k][8 * oct + 2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[(2 * p + oct) * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
+    }
+  };
+
+  f32x16 acc[MT][R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[m][r] = (f32x16){0};
+  int rowpos[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) rowpos[r] = half * PIECE + (wave * R + r) * IW + (lane & 31);
+  const long long mstride = (long long)d.NCHUNK * 9 * 192;
+
+  // weight fragments: ring of 3 taps, fetched 2 taps ahead
+  uint4 aring[3][MT][3];
+  auto load_a = [&](int slot3, int ch, int tap) {
+    const uint4* wq = wp + ((long long)ch * 9 + tap) * 192 + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) aring[slot3][m][p] = wq[m * mstride + p * 64];
+  };
+
+  if (G > 0) {
+    stage_begin(0);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) stage_load(k);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) stage_commit(0, k);
+    load_a(0, 0, 0);
+    load_a(1, 0, 1);
+  }
+  lds_barrier();
+
+  int ch = 0, k_tile = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint4* src = sm + (g & 1) * BUF;
+    const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
+    stage_begin(min(g + 1, G - 1));  // (after the last chunk: once more into the idle buffer -- keeps the body free of branches)
+    uint4 bq[2][R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[2 * p * PIECE + rowpos[r]];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) {
+        const int toff = ((tap + 1) / 3) * DIL * IW + ((tap + 1) % 3) * DIL;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bq[(tap + 1) & 1][r][p] = src[2 * p * PIECE + rowpos[r] + toff];
+      }
+      if (tap + 2 < 9)
+        load_a((tap + 2) % 3, ch, tap + 2);
+      else
+        load_a((tap + 2) % 3, ch_next, tap + 2 - 9);
+      if (tap < KIT) stage_load(tap);
+      if (tap >= 9 - KIT) stage_commit((g + 1) & 1, tap - (9 - KIT));
+#define MODE_SPLIT_TERM(PA, PB)                                                      \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
+      acc[m][r] = mfma_bf16(aring[tap % 3][m][PA], bq[tap & 1][r][PB], acc[m][r]);
+      MODE_SPLIT_TERM(2, 0)
+      MODE_SPLIT_TERM(0, 2)
+      MODE_SPLIT_TERM(1, 1)
+      MODE_SPLIT_TERM(1, 0)
+      MODE_SPLIT_TERM(0, 1)
+      MODE_SPLIT_TERM(0, 0)
+#undef MODE_SPLIT_TERM
+#pragma unroll
+      for (int i = 0; i < MT * R * 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MT == 1 ? 5 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch == d.NCHUNK - 1) {  // tile finished: D[i = o][j = w]
+      int b, h0, w0;
+      tile_of(k_tile, b, h0, w0);
+      float* yb = y + (long long)b * d.Co * HWi;
+      const int gw = w0 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int gh = h0 + wave * R + r;
+        if (gh < d.H && gw < d.W) {
+          const int sp = gh * d.W + gw;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              const int o = d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              if (o < d.Co) {
+                const long long idx = (long long)o * HWi + sp;
+                yb[idx] = EPI ? apply_epi(epi, acc[m][r][qq], o, (long long)b * d.Co * HWi + idx) : acc[m][r][qq];
+              }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][r] = (f32x16){0};
+      }
+      ++k_tile;
+    }
+    ch = ch_next;
+    lds_barrier();
+  }
+}
+
+template <int MT, int DIL>
+int launch2(const float* x, const uint4* wp, float* y, const S2Dims& d, hipStream_t st, const char* who, Epi epi) {
+  const int grid = kNumCU;
+  if (epi.shift) {
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, DIL, true>, LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, DIL, true>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+  } else {
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, DIL, false>, LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, DIL, false>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+  }
+  return mode::check_launch(who);
+}
+
+}  // namespace
+
+namespace mode {
+
+size_t conv2d_split_wpack_floats(int K, int rows) {
+  return (size_t)cdiv(rows, 32) * cdiv(K, 16) * 9 * 3 * 64 * 4 + 32 * (size_t)cdiv(rows, 32);
+}
+
+bool conv2d_split_supported(int K, int rows, int dilation) {
+  return rows > 1 && rows <= 128 && K % 16 == 0 && (dilation == 1 || dilation == 2);
+}
+
+// rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels; flip 0 / 1 as pack_w2d_split
+int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
+                     hipStream_t st, const char* who, const mode_bn_epilogue* bn) {
+  MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(conv2d_split_supported(K, rows, dilation), MODE_ERR_UNSUPPORTED,
+               "%s: %d output / %d reduction channels, dilation %d not covered by the split kernel", who, rows, K, dilation);
+  MODE_REQUIRE((long long)std::max(K, rows) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(x && w && y && wpack, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  S2Dims d;
+  d.B = B; d.K = K; d.Co = rows; d.H = H; d.W = W;
+  d.NCHUNK = K / 16;
+  d.nWt = cdiv(W, 32);
+  d.nHt = cdiv(H, TH);
+  d.ntiles = B * d.nHt * d.nWt;
+  const int MT = cdiv(rows, 32);
+  const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
+  uint4* wp = reinterpret_cast<uint4*>(wpack);
+  hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
+                     bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  // two output-channel tiles per launch (64 channels); 128-channel layers run as two launches
+  for (int m = 0; m < MT; m += 2) {
+    d.o0 = 32 * m;
+    const uint4* wpm = wp + (long long)m * d.NCHUNK * 9 * 192;
+    int rc;
+    if (m + 1 < MT)
+      rc = dilation == 1 ? launch2<2, 1>(x, wpm, y, d, st, who, epi) : launch2<2, 2>(x, wpm, y, d, st, who, epi);
+    else
+      rc = dilation == 1 ? launch2<1, 1>(x, wpm, y, d, st, who, epi) : launch2<1, 2>(x, wpm, y, d, st, who, epi);
+    if (rc != MODE_OK) return rc;
+  }
+  return MODE_OK;
+}
+
+}  // namespace mode

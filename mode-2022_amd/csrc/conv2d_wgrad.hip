@@ -11,6 +11,7 @@
 //   unconditional from clamped addresses, masks at the LDS store, operands of k-step n+1 read before the MFMAs of step n).
 //   The four waves' sums are combined through LDS at the end; split-K partials are reduced in a fixed order: deterministic.
 #include "common.h"
+#include "conv3d_internal.h"
 
 namespace {
 
@@ -276,4 +277,39 @@ extern "C" int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(reduce_gw2d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 9 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv2d_bwd_weight(reduce)");
+}
+
+extern "C" int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
+                                            int dilation, int accumulate, mode_stream_t stream) {
+  const char* who = "mode_conv2d_bwd_weight_split";
+  MODE_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(dilation == 1 || dilation == 2, MODE_ERR_UNSUPPORTED, "%s: dilation %d not implemented (1 or 2)", who, dilation);
+  MODE_REQUIRE((long long)std::max(Ci, Co) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
+  hipStream_t st = mode::as_stream(stream);
+  if (B == 0) {
+    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 9 * sizeof(float), st);
+    return MODE_OK;
+  }
+  MODE_REQUIRE(gy && x && gw && workspace, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  W2Dims d;
+  make_dims(d, B, Ci, H, W, Co);
+  mode::Wgrad2SplitDims q;
+  q.Ci = Ci; q.Co = Co; q.H = H; q.W = W;
+  q.nWt = d.nWt; q.MTo = d.MTo; q.MTc = d.MTc;
+  q.nGroups = mode::cdiv(H, 4);
+  // one workgroup per CU and (o, c) block pair; a unit starts with an un-pipelined prologue, so runs as long as the image allows
+  // while every workgroup still gets a unit
+  int S = mode::cdiv(kNumCU, d.MTo * d.MTc);
+  int run = q.nGroups;
+  while (run > 4 && (long long)B * d.nWt * mode::cdiv(q.nGroups, run) < S) run = mode::cdiv(run, 2);
+  q.run_groups = run;
+  q.nRun = mode::cdiv(q.nGroups, run);
+  q.units = B * d.nWt * q.nRun;
+  if (S > q.units) S = q.units;
+  if (S > d.S) S = d.S;  // never more slices than the workspace query assumed
+  q.S = d.S = S;
+  int rc = mode::conv2d_bww_split_launch(gy, x, workspace, q, dilation, st, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(reduce_gw2d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 9 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  return mode::check_launch("mode_conv2d_bwd_weight_split(reduce)");
 }

@@ -33,4 +33,21 @@ struct WgradSplitDims {
 };
 int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who);
 
+// conv2d_split.hip: the regular 3x3 Conv2d layers (stride 1, dilation 1 / 2) on the split-bf16 matrix path; arguments as conv2d.hip's
+// run() (rows = output channels of the GEMM, K = its reduction channels, flip 0 forward / 1 input gradient).
+bool conv2d_split_supported(int K, int rows, int dilation);
+size_t conv2d_split_wpack_floats(int K, int rows);
+int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
+                     hipStream_t st, const char* who, const mode_bn_epilogue* bn);
+
+// conv2d_split_wgrad.hip: split-K partials of the 3x3 Conv2d weight gradient on the split-bf16 path, in the layout of conv2d_wgrad.hip
+// (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.
+struct Wgrad2SplitDims {
+  int Ci, Co, H, W;
+  int nWt, nGroups, run_groups, nRun, units;  // units = B * nWt * nRun runs of run_groups 4-row groups x 32 columns
+  int S, MTo, MTc;
+};
+int conv2d_bww_split_launch(const float* gy, const float* x, float* part, const Wgrad2SplitDims& d, int dilation, hipStream_t st,
+                            const char* who);
+
 }  // namespace mode

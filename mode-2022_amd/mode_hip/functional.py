@@ -71,8 +71,9 @@ def conv2d_bwd_weight(gy, x, dilation=1, into=None):
   with torch.cuda.device_of(x), profiling.region('conv2d_bwd_weight[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
                                                  else 'conv2d_bwd_weight', nbytes, flops, x.device):
     ws = torch.empty(max(lib().mode_conv2d_bwd_weight_workspace_bytes(B, Ci, H, W, Co) // 4, 1), dtype=torch.float32, device=x.device)
-    check(lib().mode_conv2d_bwd_weight(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, dilation, 1 if into is not None else 0,
-                                       stream_of(x)), 'mode_conv2d_bwd_weight')
+    entry = 'mode_conv2d_bwd_weight_split' if CONV_ARITH == 'bf16x6' else 'mode_conv2d_bwd_weight'  # (any channel counts: masked blocks)
+    check(getattr(lib(), entry)(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, dilation, 1 if into is not None else 0, stream_of(x)),
+          entry)
   return gw
 
 
@@ -104,7 +105,16 @@ def _conv2d_run(entry, name, src, w, out_channels, dilation):
   with torch.cuda.device_of(src), profiling.region('%s[%d->%d d%d %dx%d]' % (name, Ci, Co, dilation, H, W) if profiling.ENABLED else name,
                                                    nbytes, flops, src.device):
     wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=src.device)
-    check(getattr(lib(), entry)(ptr(src), ptr(w), ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)), entry)
+    which = int(entry == 'mode_conv2d_bwd_data')
+    if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, which) == 1:
+      if which:
+        check(lib().mode_conv2d_bwd_data_split(ptr(src), ptr(w), ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)),
+              'mode_conv2d_bwd_data_split')
+      else:
+        check(lib().mode_conv2d_fwd_split(ptr(src), ptr(w), None, ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)),
+              'mode_conv2d_fwd_split')
+    else:
+      check(getattr(lib(), entry)(ptr(src), ptr(w), ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)), entry)
   return out
 
 
@@ -873,27 +883,28 @@ def _wpack3d(ci, co, device):
   return torch.empty(n // 4, dtype=torch.float32, device=device)
 
 
-# Arithmetic of the stride-1 3x3x3 layers (forward, input gradient, weight gradient: 2/3 of the 3D regulariser's time):
+# Arithmetic of the 3x3(x3) stride-1 convolution layers -- the 3D regulariser's stride-1 layers (forward, input gradient, weight
+# gradient) and the extractor's regular 3x3 Conv2d layers (forward, input gradient):
 #   'bf16x6' (default) fp32 operands split EXACTLY into three bf16 pieces when a tile is staged, six bf16 MFMAs per product (the
-#            terms >= 2^-16 of it), fp32 accumulation (csrc/conv3d_split.hip, conv3d_split_wgrad.hip).  Results carry the rounding of
-#            an fp32 convolution -- measured against float64 they are at least as close as the fp32 MFMA kernels' on the same inputs
-#            (tests/test_gpu_split.py) -- at 1.5-1.8 x their speed.  Layers the split kernels do not cover (stride 2, transposed,
-#            single-channel heads, > 64 output channels) run on the fp32 kernels.
-#   'f32'    v_mfma_f32_32x32x2_f32 everywhere (csrc/conv3d.hip).
-# Process-wide, read at call time (bench.py --conv3d-arith; the parity tests run under both).
-CONV3D_ARITH = 'bf16x6'
+#            terms >= 2^-16 of it), fp32 accumulation (csrc/conv3d_split.hip, conv3d_split_wgrad.hip, conv2d_split.hip).  Results carry
+#            the rounding of an fp32 convolution -- measured against float64 they are at least as close as the fp32 MFMA kernels' on
+#            the same inputs (tests/test_gpu_split.py) -- at 1.5-2 x their speed.  Layers the split kernels do not cover (stride 2,
+#            transposed, single-channel heads, channel counts off their grid) run on the fp32 kernels.
+#   'f32'    v_mfma_f32_32x32x2_f32 everywhere (csrc/conv3d.hip, conv2d.hip).
+# Process-wide, read at call time (bench.py --conv-arith; the parity tests run under both).
+CONV_ARITH = 'bf16x6'
 
 
-def set_conv3d_arith(kind):
-  global CONV3D_ARITH
+def set_conv_arith(kind):
+  global CONV_ARITH
   if kind not in ('f32', 'bf16x6'):
-    raise ValueError("conv3d arithmetic must be 'f32' or 'bf16x6', got %r" % (kind,))
-  CONV3D_ARITH = kind
+    raise ValueError("convolution arithmetic must be 'f32' or 'bf16x6', got %r" % (kind,))
+  CONV_ARITH = kind
 
 
 def _split3d(ci, co, stride, which):
   """which: 0 forward, 1 input gradient, 2 weight gradient."""
-  return CONV3D_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(which)) == 1
+  return CONV_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(which)) == 1
 
 
 def _out3(n, stride):
@@ -1289,8 +1300,12 @@ def conv2d_bn_eval(x, w, bn, dilation=1, add=None, relu=False):
   with torch.cuda.device_of(x), profiling.region('conv2d_bn_eval[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
                                                  else 'conv2d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
     wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
-    check(lib().mode_conv2d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
-          'mode_conv2d_fwd_bn')
+    if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 0) == 1:
+      check(lib().mode_conv2d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
+            'mode_conv2d_fwd_split')
+    else:
+      check(lib().mode_conv2d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
+            'mode_conv2d_fwd_bn')
   return y
 
 

@@ -45,9 +45,9 @@ def _threads():
 
 @pytest.fixture(params=['f32', 'bf16x6'])
 def arith(request):
-  """Both arithmetics of the stride-1 3x3x3 layers (mode_hip.functional.CONV3D_ARITH): fp32 MFMA and the split-bf16 matrix path
+  """Both arithmetics of the stride-1 3x3x3 layers (mode_hip.functional.CONV_ARITH): fp32 MFMA and the split-bf16 matrix path
   (the default).  Tests of those layers take this fixture, so neither kernel family goes untested whichever is the default."""
   from mode_hip import functional as HF
-  HF.set_conv3d_arith(request.param)
+  HF.set_conv_arith(request.param)
   yield request.param
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')

@@ -487,7 +487,7 @@ def test_conv3d_single_output_channel(B, Ci, D, H, W):
 # ------------------------------------------------------------------ regular 3x3 Conv2d: weight gradient (a3)
 @pytest.mark.parametrize('B,Ci,Co,H,W,dil', [(2, 32, 32, 16, 64, 1), (1, 64, 64, 9, 40, 1), (2, 20, 40, 7, 33, 1), (1, 64, 64, 12, 32, 2),
                                              (2, 3, 5, 5, 70, 2), (1, 128, 128, 8, 32, 1), (1, 8, 8, 2, 3, 2), (4, 64, 64, 64, 32, 1), (1, 96, 72, 10, 64, 2)])
-def test_conv2d_3x3_kernels(B, Ci, Co, H, W, dil, monkeypatch):
+def test_conv2d_3x3_kernels(B, Ci, Co, H, W, dil, monkeypatch, arith):
   """mode_conv2d_bwd_weight against torch's fp64 conv2d autograd: ragged tiles, channel counts off the 32-wide block, dilation 2,
   images smaller than the halo; accumulate semantics; the autograd Function (vendor forward / input gradient + own weight
   gradient) end to end."""
@@ -795,7 +795,7 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
 
 @pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
 @pytest.mark.parametrize('dil', [1, 2])
-def test_folded_batchnorm_conv2d_3x3(dil, relu, with_add):
+def test_folded_batchnorm_conv2d_3x3(dil, relu, with_add, arith):
   import torch.nn.functional as F
   with torch.no_grad():
     x, w = _rand((2, 20, 9, 40), 99).to(DEV), _rand((40, 20, 3, 3), 100, 0.1).to(DEV)

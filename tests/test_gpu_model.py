@@ -240,12 +240,17 @@ def test_graph_replay_matches_eager():
   assert abs(l2 - float(body())) <= 1e-4 * abs(l2) and abs(l2 - l_graph) > 1e-7
 
 
-def test_regular_extractor_variant(golden):
+def test_regular_extractor_variant(golden, arith):
   """ModeDisparity(conv='Regular') -- the PSMNet SPP extractor -- on the HIP path against the reference's
   golden vectors: same state_dict, train / eval outputs as close to the fp64 network as the reference's own fp32 run."""
   import json
   z = golden('model_regular.npz')
   maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
+  # ill-conditioned fixture (random initialisation): the mean error against fp64 is round-off amplified ~10^3 x and moves with the
+  # summation order -- 4.5e-5 ... 1.3e-4 px over six runs of the fp32 MFMA kernels, 2.4e-4 with all 39 regular 3x3 layers of this
+  # variant on the split-bf16 path (kernel by kernel at least as close to fp64, tests/test_gpu_split.py); the reference's own fp32
+  # run: 2.9e-5.  The north_star's bound is asserted on the well-conditioned fixtures (tests/test_gpu_parity.py).
+  mean_floor = DISP_TOL / 5 if arith == 'f32' else DISP_TOL / 3
   manifest = [(k, tuple(s)) for k, s in json.loads(str(z['manifest']))]
   net = models.ModeDisparity(maxdisp, 'Regular').to(DEV)
   assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == manifest
@@ -262,7 +267,7 @@ def test_regular_extractor_variant(golden):
     # E_ref, the largest on a box where MIOpen's find picked other solvers): floor at DISP_TOL/5, max at 8 x E_ref -- a wrong
     # layer is an O(0.1 .. 1) px difference.
     _check_disp('regular train pred%d' % (i + 1), p[:, :, ::4, ::4], z['train/pred%d' % (i + 1)], z['truth64/train_pred%d' % (i + 1)], e_ref,
-                mean_floor=DISP_TOL / 5, max_factor=8.0)
+                mean_floor=mean_floor, max_factor=8.0)
   loss = mode_ref.training_loss(preds, gt, ~torch.isnan(gt))
   assert abs(float(loss.detach()) - float(z['train/loss'])) < 2e-4 * float(z['train/loss'])
   loss.backward()
@@ -279,7 +284,7 @@ def test_regular_extractor_variant(golden):
   with torch.no_grad():
     pred = net(left, right)
   _check_disp('regular eval pred3', pred[:, :, ::4, ::4], z['eval/pred3'], z['truth64/eval_pred3'],
-              np.abs(z['eval/pred3'] - z['truth64/eval_pred3']).max(), mean_floor=DISP_TOL / 5, max_factor=8.0)
+              np.abs(z['eval/pred3'] - z['truth64/eval_pred3']).max(), mean_floor=mean_floor, max_factor=8.0)
 
 
 def test_sphere_layers_on_transposed_storage_match_the_nchw_operator(monkeypatch):

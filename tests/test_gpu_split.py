@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the stride-1 3x3x3 layers on the split-bf16 matrix path (csrc/conv3d_split.hip, functional.CONV3D_ARITH = 'bf16x6').
+"""GPU (-m gpu): the stride-1 3x3x3 layers on the split-bf16 matrix path (csrc/conv3d_split.hip, functional.CONV_ARITH = 'bf16x6').
 
 The claim under test is that this path computes an fp32 convolution: every check uses the SAME bound as the fp32 MFMA kernels'
 tests (2^-22 * sqrt(terms) * 8 relative to the largest exact output, tests/test_gpu_fullsize.py), against float64 references
@@ -27,9 +27,9 @@ def _need_gpu():
 
 @pytest.fixture
 def split_arith():
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
   yield
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
 
 
 def _rand(shape, seed, scale=1.0):
@@ -67,9 +67,9 @@ def test_split_forward_and_input_gradient_are_fp32_convolutions(B, Ci, Co, D, H,
   xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
   y = HF.conv3d_fwd(xd, wd, 1)
   e_split, tol = _err(y, want.detach()), _tol(Ci * 27, want.detach())
-  HF.set_conv3d_arith('f32')
+  HF.set_conv_arith('f32')
   e_f32 = _err(HF.conv3d_fwd(xd, wd, 1), want.detach())
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
   print('fwd %s: split %.3e, fp32 MFMA %.3e, bound %.3e' % ((B, Ci, Co, D, H, W), e_split, e_f32, tol))
   assert e_split <= tol
   assert torch.equal(y, HF.conv3d_fwd(xd, wd, 1)), 'not deterministic'
@@ -101,9 +101,9 @@ def test_split_weight_gradient_is_an_fp32_weight_gradient(B, Ci, Co, D, H, W, sp
   want = wa.grad
   xd, gd = x.to(DEV), gy.to(DEV)
   got = HF.conv3d_bwd_weight(gd, xd, 1)
-  HF.set_conv3d_arith('f32')
+  HF.set_conv_arith('f32')
   got32 = HF.conv3d_bwd_weight(gd, xd, 1)
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
   scale = max(1.0, float(want.abs().max()))
   e, e32 = _err(got, want), _err(got32, want)
   print('bwd_weight %s: split %.3e, fp32 MFMA %.3e (scale %.3g)' % ((B, Ci, Co, D, H, W), e, e32, scale))
@@ -172,9 +172,9 @@ def test_split_at_the_benchmark_size_against_the_float64_oracle(split_arith):
   xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
   want = conv_ref.conv3d_fwd(x, w, 1)
   got = HF.conv3d_fwd(xd, wd, 1)
-  HF.set_conv3d_arith('f32')
+  HF.set_conv_arith('f32')
   got32 = HF.conv3d_fwd(xd, wd, 1)
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
   e, e32, tol = _err(got, want), _err(got32, want), _tol(32 * 27, want)
   rms = float((got.cpu().double() - want).pow(2).mean().sqrt())
   rms32 = float((got32.cpu().double() - want).pow(2).mean().sqrt())
@@ -187,10 +187,112 @@ def test_split_at_the_benchmark_size_against_the_float64_oracle(split_arith):
   assert e <= _tol(32 * 27, want)
   want = conv_ref.conv3d_bwd_weight(gy, x, 1)
   got = HF.conv3d_bwd_weight(gd, xd, 1)
-  HF.set_conv3d_arith('f32')
+  HF.set_conv_arith('f32')
   got32 = HF.conv3d_bwd_weight(gd, xd, 1)
-  HF.set_conv3d_arith('bf16x6')
+  HF.set_conv_arith('bf16x6')
   scale = max(1.0, float(want.abs().max()))
   print('conv3d_bwd_weight 32->32 full size: split max %.3e, fp32 MFMA max %.3e (scale %.3g; bound 1e-4 * scale)' %
         (_err(got, want), _err(got32, want), scale))
   assert _err(got, want) <= 1e-4 * scale  # the bound of tests/test_gpu_fullsize.py for the fp32 kernels
+
+
+# ------------------------------------------------------------------------------------------------ regular 3x3 Conv2d layers
+CONV2D_CASES = [
+    (2, 32, 32, 16, 64, 1),    # firstconv / layer1 shape, one output tile
+    (1, 64, 64, 9, 40, 1),     # two output tiles in one launch, ragged tile
+    (2, 16, 40, 7, 33, 1),     # partial second output tile, nothing divides anything
+    (1, 64, 64, 12, 32, 2),    # dilation 2
+    (1, 128, 128, 20, 32, 1),  # four output tiles = two launches
+    (1, 32, 96, 18, 70, 2),    # three output tiles (one launch of two, one of one), dilation 2
+    (4, 64, 64, 48, 64, 1),    # several tiles per workgroup: the chunk stream crosses tile boundaries
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W,dil', CONV2D_CASES)
+def test_split_conv2d_forward_and_input_gradient(B, Ci, Co, H, W, dil, split_arith):
+  lib = mode_hip.lib()
+  assert lib.mode_conv2d_split_supported(Ci, Co, dil, 0) == 1
+  x = _rand((B, Ci, H, W), 181)
+  w = _rand((Co, Ci, 3, 3), 182, (2.0 / (9 * Co))**0.5)
+  gy = _rand((B, Co, H, W), 183)
+  xa = x.double().requires_grad_(True)
+  want = F.conv2d(xa, w.double(), None, 1, dil, dil)
+  want.backward(gy.double())
+  xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
+  y = HF.conv2d_fwd(xd, wd, dil)
+  HF.set_conv_arith('f32')
+  y32 = HF.conv2d_fwd(xd, wd, dil)
+  HF.set_conv_arith('bf16x6')
+  e, e32, tol = _err(y, want.detach()), _err(y32, want.detach()), _tol(Ci * 9, want.detach())
+  print('conv2d fwd %s: split %.3e, fp32 MFMA %.3e, bound %.3e' % ((B, Ci, Co, H, W, dil), e, e32, tol))
+  assert e <= tol
+  assert torch.equal(y, HF.conv2d_fwd(xd, wd, dil)), 'not deterministic'
+  if lib.mode_conv2d_split_supported(Ci, Co, dil, 1) == 1:
+    gx = HF.conv2d_bwd_data(gd, wd, dil)
+    e, tol = _err(gx, xa.grad), _tol(Co * 9, xa.grad)
+    print('conv2d bwd_data: split %.3e, bound %.3e' % (e, tol))
+    assert e <= tol
+
+
+@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True), (False, False)])
+def test_split_conv2d_with_the_folded_batchnorm_epilogue(relu, with_add, split_arith):
+  with torch.no_grad():
+    for ci, co, dil in ((16, 32, 1), (32, 64, 2), (16, 128, 1)):
+      x, w = _rand((2, ci, 20, 36), 191).to(DEV), _rand((co, ci, 3, 3), 192, 0.1).to(DEV)
+      bn = torch.nn.BatchNorm2d(co).to(DEV).eval()
+      r = np.random.RandomState(193)
+      bn.weight.copy_(torch.from_numpy(r.uniform(0.5, 1.5, co).astype(np.float32)))
+      bn.bias.copy_(torch.from_numpy(r.standard_normal(co).astype(np.float32)))
+      bn.running_mean.copy_(torch.from_numpy(r.standard_normal(co).astype(np.float32)))
+      bn.running_var.copy_(torch.from_numpy(r.uniform(0.5, 2.0, co).astype(np.float32)))
+      want = F.conv2d(x.cpu().double(), w.cpu().double(), None, 1, dil, dil)
+      v = lambda t: t.cpu().double().view(1, -1, 1, 1)
+      want = (want - v(bn.running_mean)) / torch.sqrt(v(bn.running_var) + bn.eps) * v(bn.weight) + v(bn.bias)
+      add = _rand(tuple(want.shape), 194).to(DEV) if with_add else None
+      if add is not None:
+        want = want + add.cpu().double()
+      if relu:
+        want = torch.relu(want)
+      got = HF.conv2d_bn_eval(x, w, bn, dil, add, relu)
+      assert _err(got, want) < 4e-5 * max(1.0, float(want.abs().max())), (ci, co, dil)
+
+
+def test_split_conv2d_at_the_extractor_sizes_against_float64(split_arith):
+  """64 -> 64 at 256 x 128 and 512 x 256, four images (the step's shapes): forward against torch's float64 conv2d on the CPU."""
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  for H, W in ((256, 128), (512, 256)):
+    x = _rand((4, 64, H, W), 201)
+    w = _rand((64, 64, 3, 3), 202, (2.0 / (9 * 64))**0.5)
+    want = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    got = HF.conv2d_fwd(xd, wd, 1)
+    HF.set_conv_arith('f32')
+    got32 = HF.conv2d_fwd(xd, wd, 1)
+    HF.set_conv_arith('bf16x6')
+    rms = float((got.cpu().double() - want).pow(2).mean().sqrt())
+    rms32 = float((got32.cpu().double() - want).pow(2).mean().sqrt())
+    print('conv2d_fwd 64->64 %dx%d x 4: split max %.3e rms %.3e | fp32 MFMA max %.3e rms %.3e' % (H, W, _err(got, want), rms, _err(got32, want), rms32))
+    assert _err(got, want) <= _tol(64 * 9, want)
+    assert rms <= 1.25 * rms32
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W,dil', CONV2D_CASES + [(2, 20, 40, 7, 33, 1), (1, 8, 8, 3, 5, 2), (3, 32, 32, 64, 96, 1)])
+def test_split_conv2d_weight_gradient(B, Ci, Co, H, W, dil, split_arith):
+  x = _rand((B, Ci, H, W), 211)
+  gy = _rand((B, Co, H, W), 212)
+  wa = torch.zeros((Co, Ci, 3, 3), dtype=torch.float64, requires_grad=True)
+  F.conv2d(x.double(), wa, None, 1, dil, dil).backward(gy.double())
+  want = wa.grad
+  xd, gd = x.to(DEV), gy.to(DEV)
+  got = HF.conv2d_bwd_weight(gd, xd, dil)
+  HF.set_conv_arith('f32')
+  got32 = HF.conv2d_bwd_weight(gd, xd, dil)
+  HF.set_conv_arith('bf16x6')
+  scale = max(1.0, float(want.abs().max()))
+  e, e32 = _err(got, want), _err(got32, want)
+  print('conv2d bwd_weight %s: split %.3e, fp32 MFMA %.3e (scale %.3g)' % ((B, Ci, Co, H, W, dil), e, e32, scale))
+  assert e <= 2e-5 * scale
+  assert torch.equal(got, HF.conv2d_bwd_weight(gd, xd, dil)), 'not deterministic'
+  acc = torch.ones_like(got)
+  HF.conv2d_bwd_weight(gd, xd, dil, into=acc)
+  assert torch.allclose(acc, got + 1.0, rtol=0, atol=1e-5 * scale), 'accumulating form'

@@ -243,17 +243,17 @@ def test_seeded_initialisation_is_the_references(golden):
     assert digest(getattr(models, cls)(*args).state_dict()) == want[tag], tag
 
 
-def test_conv3d_arithmetic_switch_and_split_predicate():
-  """functional.CONV3D_ARITH is a plain process-wide setting with two values; the library's predicate for the split kernels needs no
+def test_conv_arithmetic_switch_and_split_predicate():
+  """functional.CONV_ARITH is a plain process-wide setting with two values; the library's predicate for the split kernels needs no
   GPU (stride 1, <= 32 output channels of the GEMM, reduction channels a multiple of 8)."""
   import mode_hip
   from mode_hip import functional as HF
-  assert HF.CONV3D_ARITH == 'bf16x6'
+  assert HF.CONV_ARITH == 'bf16x6'
   with pytest.raises(ValueError):
-    HF.set_conv3d_arith('bf16')
-  HF.set_conv3d_arith('f32')
-  assert HF.CONV3D_ARITH == 'f32'
-  HF.set_conv3d_arith('bf16x6')
+    HF.set_conv_arith('bf16')
+  HF.set_conv_arith('f32')
+  assert HF.CONV_ARITH == 'f32'
+  HF.set_conv_arith('bf16x6')
   lib = mode_hip.lib()
   assert lib.mode_conv3d_split_supported(32, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(32, 32, 1, 1) == 1
   assert lib.mode_conv3d_split_supported(64, 32, 1, 0) == 1 and lib.mode_conv3d_split_supported(64, 32, 1, 1) == 1
