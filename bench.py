@@ -384,13 +384,12 @@ def main():
       try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
           table = json.load(f)
-        # (the extractor's kernels see both views: 2 x batch images; entries measured on the fp32 MFMA 3-D kernels do not describe
-        # the split kernels)
-        if not (args.conv_arith == 'bf16x6' and _on_split_path(dom)):
-          for key in ('%s B=%d' % (dom, args.batch), '%s B=%d' % (dom, 2 * args.batch), dom):
-            if key in table:
-              traffic = table[key].get('hbm_bytes_per_launch')
-              break
+        # (the extractor's kernels see both views: 2 x batch images; the split kernels have their own entries)
+        tail = ' bf16x6' if (args.conv_arith == 'bf16x6' and _on_split_path(dom)) else ''
+        for key in ('%s B=%d%s' % (dom, args.batch, tail), '%s B=%d%s' % (dom, 2 * args.batch, tail), dom + tail):
+          if key in table:
+            traffic = table[key].get('hbm_bytes_per_launch')
+            break
       except (OSError, ValueError):
         pass
       out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,

@@ -24,12 +24,17 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NT = 256;
-constexpr int TH = 16;
-constexpr int R = TH / 4;      // output rows per wave
-constexpr int KIT = 3;         // haloed positions per thread and chunk
-constexpr int PIECE = KIT * NT;  // 768 positions per (piece, octet) incl. the unused tail: no staging store is conditional
-constexpr int BUF = 3 * 2 * PIECE;  // uint4 per buffer
-constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
+// Tile geometry for TH output rows (16, or 8 when the layer has fewer than two 16-row tiles per CU) and dilation DIL
+template <int TH, int DIL>
+struct Geo2 {
+  static constexpr int R = TH / 4;                                   // output rows per wave
+  static constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
+  static constexpr int ITEMS = IH * IW;
+  static constexpr int KIT = (ITEMS + NT - 1) / NT;                  // haloed positions per thread and chunk (3 / 2)
+  static constexpr int PIECE = KIT * NT;                             // positions per (piece, octet) incl. the unused tail
+  static constexpr int BUF = 3 * 2 * PIECE;                          // uint4 per buffer
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 / 98 304 B
+};
 
 struct S2Dims {
   int B, K, Co, H, W;  // K = reduction channels of this GEMM, Co = its output channels
@@ -91,12 +96,11 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
   }
 }
 
-template <int MT, int DIL, bool EPI>
+template <int MT, int TH, int DIL, bool EPI>
 __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, float* __restrict__ y,
                                                           S2Dims d, Epi epi) {
-  constexpr int IH = TH + 2 * DIL, IW = 32 + 2 * DIL;
-  constexpr int ITEMS = IH * IW;
-  static_assert(ITEMS <= PIECE, "tile does not fit the staging slots");
+  using G2 = Geo2<TH, DIL>;
+  constexpr int R = G2::R, IW = G2::IW, ITEMS = G2::ITEMS, KIT = G2::KIT, PIECE = G2::PIECE, BUF = G2::BUF;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3 pieces][2 octets][PIECE]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
 
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < MT * R * 6; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, MT == 1 ? 5 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MT * R <= 4 ? 5 : 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -267,19 +271,30 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   }
 }
 
-template <int MT, int DIL>
-int launch2(const float* x, const uint4* wp, float* y, const S2Dims& d, hipStream_t st, const char* who, Epi epi) {
+template <int MT, int TH, int DIL>
+int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st, const char* who, Epi epi) {
+  constexpr size_t LDS = Geo2<TH, DIL>::LDS_BYTES;
+  d.nHt = mode::cdiv(d.H, TH);
+  d.ntiles = d.B * d.nHt * d.nWt;
   const int grid = kNumCU;
   if (epi.shift) {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, DIL, true>, LDS_BYTES, who);
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, true>, LDS, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, DIL, true>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, true>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
   } else {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, DIL, false>, LDS_BYTES, who);
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, false>, LDS, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, DIL, false>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, false>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
   }
   return mode::check_launch(who);
+}
+
+template <int MT>
+int launch_tile(const float* x, const uint4* wp, float* y, const S2Dims& d, int dilation, hipStream_t st, const char* who, Epi epi) {
+  // 16-row tiles unless that leaves fewer than two tiles per CU (a workgroup's first chunk is staged un-overlapped)
+  const bool big = (long long)d.B * mode::cdiv(d.H, 16) * d.nWt >= 2 * kNumCU;
+  if (dilation == 1) return big ? launch2<MT, 16, 1>(x, wp, y, d, st, who, epi) : launch2<MT, 8, 1>(x, wp, y, d, st, who, epi);
+  return big ? launch2<MT, 16, 2>(x, wp, y, d, st, who, epi) : launch2<MT, 8, 2>(x, wp, y, d, st, who, epi);
 }
 
 }  // namespace
@@ -307,8 +322,6 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
   d.B = B; d.K = K; d.Co = rows; d.H = H; d.W = W;
   d.NCHUNK = K / 16;
   d.nWt = cdiv(W, 32);
-  d.nHt = cdiv(H, TH);
-  d.ntiles = B * d.nHt * d.nWt;
   const int MT = cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
   uint4* wp = reinterpret_cast<uint4*>(wpack);
@@ -320,10 +333,7 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
     d.o0 = 32 * m;
     const uint4* wpm = wp + (long long)m * d.NCHUNK * 9 * 192;
     int rc;
-    if (m + 1 < MT)
-      rc = dilation == 1 ? launch2<2, 1>(x, wpm, y, d, st, who, epi) : launch2<2, 2>(x, wpm, y, d, st, who, epi);
-    else
-      rc = dilation == 1 ? launch2<1, 1>(x, wpm, y, d, st, who, epi) : launch2<1, 2>(x, wpm, y, d, st, who, epi);
+    rc = m + 1 < MT ? launch_tile<2>(x, wpm, y, d, dilation, st, who, epi) : launch_tile<1>(x, wpm, y, d, dilation, st, who, epi);
     if (rc != MODE_OK) return rc;
   }
   return MODE_OK;
