@@ -96,7 +96,8 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
   }
 }
 
-template <int MT, int TH, int DIL, bool EPI>
+// EPI: 0 plain store; 1 folded-BatchNorm shift (+ ReLU); 2 shift + residual add (+ ReLU)
+template <int MT, int TH, int DIL, int EPI>
 __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, float* __restrict__ y,
                                                           S2Dims d, Epi epi) {
   using G2 = Geo2<TH, DIL>;
@@ -175,6 +176,17 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < R; ++r) rowpos[r] = half * PIECE + (wave * R + r) * IW + (lane & 31);
   const long long mstride = (long long)d.NCHUNK * 9 * 192;
+  // Eval epilogues as in conv3d_split.hip: the shifts live in registers for the whole kernel; the residual values of a tile are
+  // fetched under the last taps of its last chunk where the registers allow (64 values per lane), else in the epilogue itself.
+  constexpr bool ADD_AHEAD = EPI == 2 && MT * R * 16 <= 64;
+  float shiftv[MT][16], addv[ADD_AHEAD ? MT : 1][ADD_AHEAD ? R : 1][16];
+  const float relu_floor = (EPI && epi.relu) ? 0.f : -__builtin_inff();
+  if (EPI) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) shiftv[m][qq] = epi.shift[min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1)];
+  }
 
   // weight fragments: ring of 3 taps, fetched 2 taps ahead
   uint4 aring[3][MT][3];
@@ -202,6 +214,20 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
     const uint4* src = sm + (g & 1) * BUF;
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
     stage_begin(min(g + 1, G - 1));  // (after the last chunk: once more into the idle buffer -- keeps the body free of branches)
+    int ep_off[R];
+    const float* ep_base = epi.add;
+    if (ADD_AHEAD) {
+      int b, h0, w0;
+      tile_of(k_tile, b, h0, w0);
+      const bool last = ch == d.NCHUNK - 1;
+      ep_base = epi.add + (last ? (long long)b * d.Co * HWi : 0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int gh = h0 + wave * R + r, gw = w0 + (lane & 31);
+        const unsigned ok = (unsigned)last & (unsigned)(gh < d.H) & (unsigned)(gw < d.W);
+        ep_off[r] = ok ? gh * d.W + gw : -1;
+      }
+    }
     uint4 bq[2][R][3];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -221,6 +247,14 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
       else
         load_a((tap + 2) % 3, ch_next, tap + 2 - 9);
       if (tap < KIT) stage_load(tap);
+      if (ADD_AHEAD && tap >= 9 - 2 * R * MT && tap < 9) {  // 8 residual values under each of the last 2 * R * MT taps
+        const int i = tap - (9 - 2 * R * MT), m = i / (2 * R), r = (i / 2) % R;
+#pragma unroll
+        for (int qq = 8 * (i & 1); qq < 8 * (i & 1) + 8; ++qq) {
+          const int o = min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
+          addv[m][r][qq] = ep_base[ep_off[r] >= 0 ? (long long)o * HWi + ep_off[r] : (lane & 31)];
+        }
+      }
       if (tap >= 9 - KIT) stage_commit((g + 1) & 1, tap - (9 - KIT));
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
@@ -257,7 +291,10 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
               const int o = d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
               if (o < d.Co) {
                 const long long idx = (long long)o * HWi + sp;
-                yb[idx] = EPI ? apply_epi(epi, acc[m][r][qq], o, (long long)b * d.Co * HWi + idx) : acc[m][r][qq];
+                float v = acc[m][r][qq];
+                if (EPI) v += shiftv[m][qq];
+                if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : epi.add[(long long)b * d.Co * HWi + idx];
+                yb[idx] = EPI ? fmaxf(v, relu_floor) : v;
               }
             }
         }
@@ -277,14 +314,18 @@ int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st,
   d.nHt = mode::cdiv(d.H, TH);
   d.ntiles = d.B * d.nHt * d.nWt;
   const int grid = kNumCU;
-  if (epi.shift) {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, true>, LDS, who);
+  if (epi.shift && epi.add) {
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 2>, LDS, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, true>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 2>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
+  } else if (epi.shift) {
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 1>, LDS, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 1>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
   } else {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, false>, LDS, who);
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 0>, LDS, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, false>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 0>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
   }
   return mode::check_launch(who);
 }
