@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 11 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 12 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -129,6 +129,11 @@ int mode_sphere_conv_fwd_win(const float* x, const float* pos, const float* w, f
                              int groups, int transposed, mode_stream_t stream);
 
 int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack,
+                                const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh,
+                                int Kw, int groups, int transposed, mode_stream_t stream);
+/* The same call with the small-window tiles on the split-bf16 matrix path (needs Ci / groups % 16 == 0, else it is the
+ * call above); bn may be NULL (plain convolution). */
+int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack,
                                 const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh,
                                 int Kw, int groups, int transposed, mode_stream_t stream);
 

@@ -748,6 +748,286 @@ int bww_win_splits(const WinDims& d, int ntiles) {
   return std::max(1, mode::cdiv(T, per));
 }
 
+
+// =====================================================================================================================
+// Forward on the small-window tiles with the split-bf16 arithmetic of conv3d_split.hip: fp32 operands split exactly
+// into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation.
+//
+// Same tile (64 rows x 4 columns), window (81 rows x 8 columns per channel, fp32, double-buffered) and sampling records as
+// fwd_tile; what differs is who does what.  K of an MFMA is 16 input channels of one tap, so a chunk is 16 channels deep and
+//   * SAMPLING: wave v builds the B fragment of its own 32 pixels (column v % 4, row block v / 4) for tap t + 1 -- 8 channels
+//     per lane (lanes 0..31 channels 0..7, lanes 32..63 channels 8..15), 4 LDS words + 4 FMAs each, then the exact 3-way split --
+//     and writes the three uint4 to an operand buffer in LDS (2 x 24 KB);
+//   * MATRIX: wave v owns output-channel tile v % 4 for the 4 pixel groups of its row block: per tap it reads the 4 x 3
+//     fragments the waves of its row block have written and issues 24 MFMAs against ONE weight fragment set (3 KB from L2 per
+//     tap and wave -- with all four output tiles per wave, as in fwd_tile, the weights would be 12 KB per tap and wave, and 96 KB per
+//     tap for the workgroup through a 64 B/clk L1 lasts as long as the tap's MFMAs at this matrix rate).
+// Both run in one instruction stream per wave, the sampling of tap t + 1 under the MFMAs of tap t; one LDS barrier per tap.
+// The window of the next chunk is loaded under taps 0..6 and stored under taps 1..7.
+constexpr int SP_CCH = 16;
+constexpr int SP_CP = chan_pitch(WR_SMALL);
+constexpr int SP_WIN = SP_CCH * SP_CP;                      // floats per window buffer
+constexpr int SP_WIN_FLOATS = ((2 * SP_WIN + WR_SMALL + 8 + 3) / 4) * 4;  // both buffers + slack, 16-byte multiple
+constexpr int SP_OP = 8 * 3 * 64;                           // uint4 per operand buffer
+constexpr size_t SP_LDS_BYTES = (size_t)SP_WIN_FLOATS * sizeof(float) + 2 * (size_t)SP_OP * sizeof(uint4);
+
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sp_pack2(float a, float b) {
+  const sp_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sp_bf16x2));
+}
+__device__ __forceinline__ void sp_split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = sp_pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = sp_pack2(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  p3 = sp_pack2(sa, sb);
+}
+__device__ __forceinline__ f32x16 sp_mfma(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sp_bf16x8, a), __builtin_bit_cast(sp_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void sp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wps[(((((g*MG + mg)*NCH16 + ch)*KT + tap)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[g*Cog + mg*128 + m*32 + (lane&31)]
+// [ch*16 + 8*(lane>>5) + j][tap], j = 0..7 (scaled by the folded BatchNorm scale when fold != 0; the shifts are the ones pack_w_win wrote)
+__global__ void pack_w_win_split(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16, int fold, mode_bn_epilogue bn) {
+  const long long total = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int m = (int)(r % MTW);
+    r /= MTW;
+    const int tap = (int)(r % KT);
+    r /= KT;
+    const int ch = (int)(r % NCH16);
+    r /= NCH16;
+    const int mg = (int)(r % d.MG);
+    const int g = (int)(r / d.MG);
+    const int co = mg * 128 + m * 32 + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * SP_CCH + 8 * (lane >> 5) + j;
+      v[j] = 0.f;
+      if (co < d.Cog && c < d.Cig) {
+        v[j] = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
+        if (fold) v[j] *= fold_scale(bn, g * d.Cog + co);
+      }
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wps + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+template <bool EPI>
+__global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                                    const uint4* __restrict__ wps, const float4* __restrict__ wp,
+                                                                    float* __restrict__ y, WinDims d, int NCH16,
+                                                                    const int4* __restrict__ tiles, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WRP = WR_SMALL, CP = SP_CP;
+  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
+  const int4 t = tiles[blockIdx.x];
+  const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
+  // the few tall-window tiles (next to the poles) run on the fp32 path INSIDE this launch: as a launch of their own they would be an
+  // under-filled tail (0.37 ms for the two launches against 0.26 for the old single one)
+  const int cls = t.w >> 16;
+  if (cls == 1) {
+    fwd_tile<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    return;
+  }
+  if (cls != 0) {
+    fwd_tile<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    return;
+  }
+  const int b = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+  const int h = h0 + (wave / TW) * 32 + (lane & 31), w = w0 + (wave % TW);  // the pixel this lane SAMPLES
+  const bool pix_ok = h < d.H && w < d.W;
+  const long long HW = (long long)d.H * d.W;
+
+  int roff[KT];
+  float4 rw[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    int r0 = 0, c0 = 0;
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix_ok) {
+      const long long idx = (long long)h * d.W + w;
+      mode::tap_record_fixed(pos[(2 * k) * HW + idx], pos[(2 * k + 1) * HW + idx], d.H, d.W, r0, c0, wt);
+    }
+    int lr = r0 - rbase;
+    if (lr < 0) lr += d.H;
+    const int lc = c0 - cbase;
+    const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
+    roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
+    rw[k] = wt;
+  }
+  for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
+  __syncthreads();
+
+  // window staging: thread -> (window column, row within a pass of SROWS rows), as in fwd_tile; 2 passes cover the 81 rows
+  const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
+  const int gcol = cbase + scol;
+  const bool col_ok = gcol < d.W;
+  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW + (col_ok ? gcol * d.sw : 0);
+  int rowoff[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int r = rb * SROWS + srow;
+    rowoff[rb] = ((rbase + (r < WRP ? r : 0)) % d.H) * d.sh;
+  }
+  float lv[8][4];  // the 8 staging phases of a chunk (phase = 2 channels x 2 row passes), all in flight at once
+  auto issue = [&](int ch, int ph, int set) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int chan = ch * SP_CCH + ph * 2 + cc;
+      const float* xc = xg + (long long)(chan < d.Cig ? chan : 0) * HW;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) lv[set][cc * 2 + rb] = xc[rowoff[rb]];
+    }
+  };
+  auto commit = [&](int ch, int ph, int set, float* buf) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = ph * 2 + cc;
+      const bool ok = col_ok && (ch * SP_CCH + c < d.Cig);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int r = rb * SROWS + srow;
+        if (r < WRP) buf[c * CP + scol * WRP + r] = ok ? lv[set][cc * 2 + rb] : 0.f;
+      }
+    }
+  };
+  // B fragment of this lane's pixel for tap k of the chunk in `win`: 8 channels, split, stored as this wave's group
+  auto sample = [&](const float* win, int k, uint4* op) {
+    const float* p = win + half * 8 * CP + roff[k];
+    const float4 tw = rw[k];
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = p + c * CP;
+      v[c] = tw.x * q[0] + tw.y * q[WRP] + tw.z * q[1] + tw.w * q[WRP + 1];
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = op + (wave * 3) * 64 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[gi][r] = 0.f;
+  const int m = wave % TW, gset = (wave / TW) * 4;  // output tile and first pixel group of the MATRIX role
+  const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192 + lane;
+  const int nsteps = NCH16 * KT;
+  uint4 aring[3][3];  // weight fragments of taps k, k + 1, k + 2 (slot = tap % 3; 9 taps per chunk keep the slots aligned)
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    aring[0][p] = wpa[p * 64];
+    aring[1][p] = wpa[((long long)(nsteps > 1 ? 1 : 0) * MTW) * 192 + p * 64];
+  }
+
+  // prologue: window of chunk 0, operand of tap 0
+#pragma unroll
+  for (int ph = 0; ph < 8; ++ph) {
+    issue(0, ph, ph);
+    commit(0, ph, ph, smem);
+  }
+  __syncthreads();
+  sample(smem, 0, opbuf);
+  sp_lds_barrier();
+
+  for (int ch = 0; ch < NCH16; ++ch) {
+    float* cur = smem + (ch & 1) * SP_WIN;
+    float* nxt = smem + ((ch + 1) & 1) * SP_WIN;
+    const int chn = ch + 1 < NCH16 ? ch + 1 : ch;  // (after the last chunk the same window is staged again: no branch in the body)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int step = ch * KT + k;
+      const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = wpa[((long long)nstep * MTW) * 192 + p * 64];
+      // window of the next chunk: two phases loaded under each of taps 0..3, stored under taps 4..7 (four taps for the loads to land;
+      // the whole window is in LDS at the barrier that ends tap 7)
+      if (k < 4) {
+        issue(chn, 2 * k, 2 * k);
+        issue(chn, 2 * k + 1, 2 * k + 1);
+      }
+      // operand of the next tap (of the next chunk after tap 8: its window was complete at the barrier that ended tap 7)
+      const uint4* opr = opbuf + (step & 1) * SP_OP;
+      uint4* opw = opbuf + ((step + 1) & 1) * SP_OP;
+      if (k + 1 < KT)
+        sample(cur, k + 1, opw);
+      else
+        sample(nxt, 0, opw);
+      uint4 bq[4][3];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
+#define MODE_SP_TERM(PA, PB) \
+  _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
+      MODE_SP_TERM(2, 0)
+      MODE_SP_TERM(0, 2)
+      MODE_SP_TERM(1, 1)
+      MODE_SP_TERM(1, 0)
+      MODE_SP_TERM(0, 1)
+      MODE_SP_TERM(0, 0)
+#undef MODE_SP_TERM
+      if (k >= 4 && k < 8) {
+        commit(chn, 2 * (k - 4), 2 * (k - 4), nxt);
+        commit(chn, 2 * (k - 4) + 1, 2 * (k - 4) + 1, nxt);
+      }
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sp_lds_barrier();
+    }
+  }
+
+  // D[i = o][j = pixel of group gset + gi]
+  const int hh = h0 + (wave / TW) * 32 + (lane & 31);
+  const int cmax = d.Cog - mg * 128;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int ww = w0 + gi;
+    if (hh < d.H && ww < d.W) {
+      float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)hh * d.sh + (long long)ww * d.sw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < cmax) {
+          if (EPI) {
+            const int chn_o = g * d.Cog + mg * 128 + co;
+            yb[(long long)co * HW] = apply_epi(epi, acc[gi][r], chn_o, (yb - y) + (long long)co * HW);
+          } else {
+            yb[(long long)co * HW] = acc[gi][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 size_t win_lds_bytes(int wr, bool pipe) { return ((size_t)(pipe ? 2 : 1) * CCH * chan_pitch(wr) + wr + 8) * sizeof(float); }
 bool wrap_is_pipelined(int H) { return H + 1 <= WR_PIPE_MAX && win_lds_bytes(H + 1, true) <= 160 * 1024; }
 
@@ -868,7 +1148,9 @@ extern "C" int mode_sphere_plan_build(const float* pos_host, int H, int W, int K
 extern "C" size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups) {
   if (Ci <= 0 || Co <= 0 || groups <= 0 || Kh * Kw != KT || Ci % groups || Co % groups) return 0;
   const int Cig = Ci / groups, Cog = Co / groups;
-  return ((size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 + (size_t)Co) * sizeof(float);  // + shifts
+  const size_t f32 = (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 + (size_t)Co;  // + shifts
+  const size_t split = (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, SP_CCH) * KT * MTW * 3 * 64 * 4;       // split-bf16 fragments
+  return (((f32 + 3) / 4) * 4 + split) * sizeof(float);
 }
 
 namespace {
@@ -879,7 +1161,7 @@ int fwd_win_launch(const float* x, const float* pos, float* y, const float* wpac
 
 static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const float* w, float* y, float* wpack, const int32_t* tiles,
                                     int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
-                                    int transposed, mode_stream_t stream, const mode_bn_epilogue* bn) {
+                                    int transposed, mode_stream_t stream, const mode_bn_epilogue* bn, int split = 0) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_fwd_win");
   if (rc != MODE_OK) return rc;
@@ -897,6 +1179,41 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
   const long long npack = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
   hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
+  if (split && n_small > 0 && d.Cig % SP_CCH == 0) {
+    // small-window tiles (the tail of the tile list) on the split-bf16 kernel, the tall-window classes on the fp32 kernels
+    const int NCH16 = d.Cig / SP_CCH;
+    uint4* wps = reinterpret_cast<uint4*>(wpack + ((npack + d.Co + 3) / 4) * 4);
+    const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
+    hipLaunchKernelGGL(pack_w_win_split, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
+                       bn ? *bn : mode_bn_epilogue());
+    // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
+    const int4* tl = reinterpret_cast<const int4*>(tiles);
+    const float4* wp4 = reinterpret_cast<const float4*>(wpack);
+    int n_all = n_small + n_mid + n_wrap;
+    if (n_wrap > 0 && !d.wrap_pipe) {
+      rc = bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi)
+              : fwd_win_launch<false>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi);
+      if (rc != MODE_OK) return rc;
+      tl += n_wrap;
+      n_all -= n_wrap;
+      n_wrap = 0;
+    }
+    size_t lds = SP_LDS_BYTES;
+    if (n_mid > 0) lds = std::max(lds, win_lds_bytes(WR_MID, true));
+    if (n_wrap > 0) lds = std::max(lds, win_lds_bytes(d.wr, true));
+    if (bn) {
+      rc = mode::allow_lds(sphere_fwd_split_kernel<true>, lds, "mode_sphere_conv_fwd_win_split");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_fwd_split_kernel<true>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wp4, y, d, NCH16, tl,
+                         epi);
+    } else {
+      rc = mode::allow_lds(sphere_fwd_split_kernel<false>, lds, "mode_sphere_conv_fwd_win_split");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_fwd_split_kernel<false>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wp4, y, d, NCH16, tl,
+                         epi);
+    }
+    return mode::check_launch("mode_sphere_conv_fwd_win_split");
+  }
   return bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, n_small, n_mid, n_wrap, B, d, st, epi)
             : fwd_win_launch<false>(x, pos, y, wpack, tiles, n_small, n_mid, n_wrap, B, d, st, epi);
 }
@@ -937,6 +1254,18 @@ extern "C" int mode_sphere_conv_fwd_win(const float* x, const float* pos, const 
                                         int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
   return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream,
                                   nullptr);
+}
+
+// Small-window tiles on the split-bf16 matrix path (sphere_fwd_split_kernel), the other classes on the fp32 kernels; bn may be NULL.
+extern "C" int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y,
+                                              float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H,
+                                              int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  if (bn) {
+    int rc = mode::check_bn(bn, "mode_sphere_conv_fwd_win_split");
+    if (rc != MODE_OK) return rc;
+  }
+  return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream, bn,
+                                  1);
 }
 
 extern "C" int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y,

@@ -44,6 +44,7 @@ SIGNATURES = {
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_fwd_bn': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_fwd_win_bn': (_c_int, [_c_ptr] * 7 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_fwd_win_split': (_c_int, [_c_ptr] * 7 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_volume_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_conv2d_wpack_bytes': (_c_size, [_c_int] * 2),
@@ -100,7 +101,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 11  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 12  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

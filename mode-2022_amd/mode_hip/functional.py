@@ -342,17 +342,29 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
       xt = None
       if SPHERE_LAYOUT == 'transposed':
         xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
-        check(lib().mode_sphere_conv_fwd_win(ptr(xt), ptr(pos), ptr(w), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
-                                             Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win')
+        _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
         transpose_planes(yt, out)
       else:
-        check(lib().mode_sphere_conv_fwd_win(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh,
-                                             Kw, groups, 0, stream_of(x)), 'mode_sphere_conv_fwd_win')
+        _sphere_fwd_win(ptr(x), pos, w, None, ptr(out), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 0, stream_of(x))
     else:
       xt = None
       wp = _wpack(w, groups)
       check(lib().mode_sphere_conv_fwd(ptr(x), ptr(pos), ptr(w), ptr(out), ptr(wp), *dims, stream_of(x)), 'mode_sphere_conv_fwd')
   return xt if return_transposed else out
+
+
+def _sphere_fwd_win(xp, pos, w, e, yp, wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream):
+  """Windowed spherical forward (optional folded-BatchNorm epilogue `e`): the small-window tiles on the split-bf16 kernel when
+  CONV_ARITH says so (the library falls back to the fp32 kernels by itself when the channel count does not fit)."""
+  if CONV_ARITH == 'bf16x6':
+    check(lib().mode_sphere_conv_fwd_win_split(xp, ptr(pos), ptr(w), ctypes.byref(e) if e is not None else None, yp, ptr(wp), ptr(tiles), n0, n1,
+                                               n2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream), 'mode_sphere_conv_fwd_win_split')
+  elif e is not None:
+    check(lib().mode_sphere_conv_fwd_win_bn(xp, ptr(pos), ptr(w), ctypes.byref(e), yp, ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh, Kw,
+                                            groups, transposed, stream), 'mode_sphere_conv_fwd_win_bn')
+  else:
+    check(lib().mode_sphere_conv_fwd_win(xp, ptr(pos), ptr(w), yp, ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups,
+                                         transposed, stream), 'mode_sphere_conv_fwd_win')
 
 
 _adjoint_cache = {}
@@ -511,8 +523,7 @@ def sphere_conv_fwd_t(xt, pos, w, yt, groups):
   nbytes = 4 * (xt.numel() + yt.numel() + pos.numel() + w.numel())
   with torch.cuda.device_of(xt), profiling.region('sphere_conv_fwd[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, xt.device):
     wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
-    check(lib().mode_sphere_conv_fwd_win(ptr(xt), ptr(pos), ptr(w), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H, W, Co, Kh, Kw,
-                                         groups, 1, stream_of(xt)), 'mode_sphere_conv_fwd_win')
+    _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(xt))
   return yt
 
 
@@ -1340,13 +1351,11 @@ def sphere_conv_bn_eval(x, pos, w, bn, stride, groups, add=None, relu=False, tra
       wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
       if transposed:
         e, keep = _epilogue(bn, add, relu, y)
-        check(lib().mode_sphere_conv_fwd_win_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci,
-                                                H, W, Co, Kh, Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win_bn')
+        _sphere_fwd_win(ptr(x), pos, w, e, ptr(y), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
       else:  # NCHW caller: the windowed kernel on plane-transposed copies (the residual is transposed with it)
         xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
         e, keep = _epilogue(bn, transpose_planes(add.contiguous()) if add is not None else None, relu, yt)
-        check(lib().mode_sphere_conv_fwd_win_bn(ptr(xt), ptr(pos), ptr(w), ctypes.byref(e), ptr(yt), ptr(wp), ptr(tiles), n0, n1, n2, B, Ci,
-                                                H, W, Co, Kh, Kw, groups, 1, stream_of(x)), 'mode_sphere_conv_fwd_win_bn')
+        _sphere_fwd_win(ptr(xt), pos, w, e, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
         y = transpose_planes(yt)
     else:
       y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
