@@ -879,32 +879,34 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
   const int gcol = cbase + scol;
   const bool col_ok = gcol < d.W;
-  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW + (col_ok ? gcol * d.sw : 0);
-  int rowoff[2];
+  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;  // uniform; lanes add 32-bit element offsets (H * W < 2^30)
+  unsigned rowoff[2];  // BYTE offsets inside a channel plane
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const int r = rb * SROWS + srow;
-    rowoff[rb] = ((rbase + (r < WRP ? r : 0)) % d.H) * d.sh;
+    rowoff[rb] = 4u * (unsigned)(((rbase + (r < WRP ? r : 0)) % d.H) * d.sh + (col_ok ? gcol * d.sw : 0));
   }
+  const long long plane_bytes = 4 * HW;
   float lv[8][4];  // the 8 staging phases of a chunk (phase = 2 channels x 2 row passes), all in flight at once
-  auto issue = [&](int ch, int ph, int set) {
+  auto issue = [&](int ch, int ph, int set) {  // (Cig is a multiple of 16: every channel of a chunk exists)
+    const char* xc = reinterpret_cast<const char*>(xg) + ((long long)ch * SP_CCH + ph * 2) * plane_bytes;  // uniform
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      const int chan = ch * SP_CCH + ph * 2 + cc;
-      const float* xc = xg + (long long)(chan < d.Cig ? chan : 0) * HW;
+    for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) lv[set][cc * 2 + rb] = xc[rowoff[rb]];
-    }
+      for (int rb = 0; rb < 2; ++rb) lv[set][cc * 2 + rb] = *reinterpret_cast<const float*>(xc + cc * plane_bytes + rowoff[rb]);
   };
   auto commit = [&](int ch, int ph, int set, float* buf) {
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int c = ph * 2 + cc;
-      const bool ok = col_ok && (ch * SP_CCH + c < d.Cig);
+      const bool ok = col_ok;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
+        // rows beyond the window go to the slack words behind the two buffers (finite values, read only under zero weights): an
+        // `if` here is a branch, and a branch in the middle of a tap pins the sampling code behind the MFMAs
         const int r = rb * SROWS + srow;
-        if (r < WRP) buf[c * CP + scol * WRP + r] = ok ? lv[set][cc * 2 + rb] : 0.f;
+        float* dst = r < WRP ? buf + c * CP + scol * WRP + r : smem + 2 * SP_WIN + (tid & 7);
+        *dst = ok ? lv[set][cc * 2 + rb] : 0.f;
       }
     }
   };
@@ -916,7 +918,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float* q = p + c * CP;
-      v[c] = tw.x * q[0] + tw.y * q[WRP] + tw.z * q[1] + tw.w * q[WRP + 1];
+      // (one fma chain per value: left to itself the compiler SLP-packs these into v_pk_fma_f32, which costs the MFMA stream more
+      // than two plain FMAs)
+      v[c] = __builtin_fmaf(tw.w, q[WRP + 1], __builtin_fmaf(tw.z, q[1], __builtin_fmaf(tw.y, q[WRP], tw.x * q[0])));
+      asm("" : "+v"(v[c]));  // (opaque, not volatile -- a volatile asm pins the schedule: keeps the chains of two channels from being packed pairwise -- 24 v_mov + 24 v_pk_*)
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -933,13 +938,13 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[gi][r] = 0.f;
   const int m = wave % TW, gset = (wave / TW) * 4;  // output tile and first pixel group of the MATRIX role
-  const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192 + lane;
+  const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;  // uniform; + p * 64 + lane per fragment
   const int nsteps = NCH16 * KT;
   uint4 aring[3][3];  // weight fragments of taps k, k + 1, k + 2 (slot = tap % 3; 9 taps per chunk keep the slots aligned)
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-    aring[0][p] = wpa[p * 64];
-    aring[1][p] = wpa[((long long)(nsteps > 1 ? 1 : 0) * MTW) * 192 + p * 64];
+    aring[0][p] = wpa[(unsigned)(p * 64 + lane)];
+    aring[1][p] = (wpa + (long long)(nsteps > 1 ? 1 : 0) * MTW * 192)[(unsigned)(p * 64 + lane)];
   }
 
   // prologue: window of chunk 0, operand of tap 0
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       const int step = ch * KT + k;
       const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = wpa[((long long)nstep * MTW) * 192 + p * 64];
+      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
       // window of the next chunk: two phases loaded under each of taps 0..3, stored under taps 4..7 (four taps for the loads to land;
       // the whole window is in LDS at the barrier that ends tap 7)
       if (k < 4) {
@@ -971,15 +976,18 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       // operand of the next tap (of the next chunk after tap 8: its window was complete at the barrier that ended tap 7)
       const uint4* opr = opbuf + (step & 1) * SP_OP;
       uint4* opw = opbuf + ((step + 1) & 1) * SP_OP;
-      if (k + 1 < KT)
-        sample(cur, k + 1, opw);
-      else
-        sample(nxt, 0, opw);
+      // (this tap's operand reads come FIRST in program order: the two operand buffers are told apart by a run-time parity, so the
+      // compiler keeps every LDS read behind the stores of sample() -- with the reads behind them the whole tap ran as "sample, then
+      // 24 MFMAs" instead of the MFMAs over the sampling arithmetic)
       uint4 bq[4][3];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
         for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
+      if (k + 1 < KT)
+        sample(cur, k + 1, opw);
+      else
+        sample(nxt, 0, opw);
 #define MODE_SP_TERM(PA, PB) \
   _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
       MODE_SP_TERM(2, 0)

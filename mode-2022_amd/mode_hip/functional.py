@@ -895,7 +895,7 @@ def _wpack3d(ci, co, device):
 
 
 # Arithmetic of the 3x3(x3) stride-1 convolution layers -- the 3D regulariser's stride-1 layers (forward, input gradient, weight
-# gradient) and the extractor's regular 3x3 Conv2d layers (forward, input gradient):
+# gradient), the extractor's regular 3x3 Conv2d layers (all three) and the forward of its spherical layers (small-window tiles):
 #   'bf16x6' (default) fp32 operands split EXACTLY into three bf16 pieces when a tile is staged, six bf16 MFMAs per product (the
 #            terms >= 2^-16 of it), fp32 accumulation (csrc/conv3d_split.hip, conv3d_split_wgrad.hip, conv2d_split.hip).  Results carry
 #            the rounding of an fp32 convolution -- measured against float64 they are at least as close as the fp32 MFMA kernels' on
