@@ -260,3 +260,17 @@ def test_conv_arithmetic_switch_and_split_predicate():
   assert lib.mode_conv3d_split_supported(32, 96, 1, 0) == 0 and lib.mode_conv3d_split_supported(12, 32, 1, 0) == 0
   assert lib.mode_conv3d_split_supported(32, 32, 2, 0) == 0 and lib.mode_conv3d_split_supported(32, 1, 1, 0) == 0
   assert lib.mode_conv3d_wpack_bytes(32, 32) >= 4 * 14 * 3 * 64 * 16
+
+
+def test_bench_labels_on_the_split_path():
+  """bench.py prices a dominant kernel against the bf16 pipe (2 500 / 6 TFLOP/s) only when its layer runs on the split kernels."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('bench_module', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  assert bench._on_split_path('conv3d_fwd[32->32 s1 48x256x128]')
+  assert bench._on_split_path('conv3d_bwd_data[64->64 s1 24x128x64]')
+  assert not bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]')
+  assert not bench._on_split_path('conv3d_fwd[32->1 s1 48x256x128]')
+  assert not bench._on_split_path('sphere_conv_bwd_weight[128->128 256x128]')
+  assert abs(bench.MFMA_BF16_PEAK_TFLOPS / 6.0 - 416.67) < 0.01
