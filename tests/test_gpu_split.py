@@ -296,3 +296,39 @@ def test_split_conv2d_weight_gradient(B, Ci, Co, H, W, dil, split_arith):
   acc = torch.ones_like(got)
   HF.conv2d_bwd_weight(gd, xd, dil, into=acc)
   assert torch.allclose(acc, got + 1.0, rtol=0, atol=1e-5 * scale), 'accumulating form'
+
+
+def test_split_kernels_on_random_small_shapes(split_arith):
+  """Seeded random shapes around the tile edges (volumes smaller than a tile, widths 1..70, single rows / depths, partial channel
+  blocks) for all five split kernel families, against torch's float64 convolutions."""
+  r = np.random.RandomState(2022)
+  for it in range(24):
+    B = int(r.randint(1, 3))
+    Ci3, Co3 = 8 * int(r.randint(1, 5)), int(r.choice([8, 20, 32, 40, 64]))
+    D, H, W = int(r.randint(1, 6)), int(r.randint(1, 20)), int(r.randint(1, 71))
+    x = _rand((B, Ci3, D, H, W), 300 + it)
+    w = _rand((Co3, Ci3, 3, 3, 3), 400 + it, 0.1)
+    gy = _rand((B, Co3, D, H, W), 500 + it)
+    xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = F.conv3d(xa, wa, None, 1, 1)
+    want.backward(gy.double())
+    xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
+    tag = ('3d', B, Ci3, Co3, D, H, W)
+    assert _err(HF.conv3d_fwd(xd, wd, 1), want.detach()) <= _tol(Ci3 * 27, want.detach()), tag
+    if Co3 % 8 == 0:
+      assert _err(HF.conv3d_bwd_data(gd, wd, x.shape, 1), xa.grad) <= _tol(Co3 * 27, xa.grad), tag
+    assert _err(HF.conv3d_bwd_weight(gd, xd, 1), wa.grad) <= 2e-5 * max(1.0, float(wa.grad.abs().max())), tag
+    Ci2, Co2, dil = 16 * int(r.randint(1, 5)), int(r.choice([16, 24, 32, 64, 96])), int(r.randint(1, 3))
+    H2, W2 = int(r.randint(1, 40)), int(r.randint(1, 71))
+    x = _rand((B, Ci2, H2, W2), 600 + it)
+    w = _rand((Co2, Ci2, 3, 3), 700 + it, 0.1)
+    gy = _rand((B, Co2, H2, W2), 800 + it)
+    xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = F.conv2d(xa, wa, None, 1, dil, dil)
+    want.backward(gy.double())
+    xd, wd, gd = x.to(DEV), w.to(DEV), gy.to(DEV)
+    tag = ('2d', B, Ci2, Co2, H2, W2, dil)
+    assert _err(HF.conv2d_fwd(xd, wd, dil), want.detach()) <= _tol(Ci2 * 9, want.detach()), tag
+    if Co2 % 16 == 0:
+      assert _err(HF.conv2d_bwd_data(gd, wd, dil), xa.grad) <= _tol(Co2 * 9, xa.grad), tag
+    assert _err(HF.conv2d_bwd_weight(gd, xd, dil), wa.grad) <= 2e-5 * max(1.0, float(wa.grad.abs().max())), tag
