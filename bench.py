@@ -79,14 +79,21 @@ def launch_ranks(args):
 
 
 def _on_split_path(label):
-  """Does the kernel behind a profiling label like conv3d_fwd[32->32 s1 48x256x128] run on the split-bf16 kernels in bf16x6 mode?"""
+  """Does the kernel behind a profiling label like conv3d_fwd[32->32 s1 48x256x128] or conv2d_bwd_weight[64->64 d1 256x128] run on
+  the split-bf16 kernels in bf16x6 mode?"""
   import re
-  m = re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bn_eval)\[(\d+)->(\d+) s(\d) ', label)
-  if not m:
-    return False
   import mode_hip
-  ci, co, stride = int(m.group(2)), int(m.group(3)), int(m.group(4))
-  return mode_hip.lib().mode_conv3d_split_supported(ci, co, stride, int(m.group(1) == 'conv3d_bwd_data')) == 1
+  lib = mode_hip.lib()
+  m = re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight|conv3d_bn_eval)\[(\d+)->(\d+) s(\d) ', label)
+  if m:
+    which = {'conv3d_bwd_data': 1, 'conv3d_bwd_weight': 2}.get(m.group(1), 0)
+    return lib.mode_conv3d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), which) == 1
+  m = re.match(r'(conv2d_fwd|conv2d_bwd_data|conv2d_bwd_weight|conv2d_bn_eval)\[(\d+)->(\d+) d(\d) ', label)
+  if m:
+    if m.group(1) == 'conv2d_bwd_weight':
+      return True  # any channel counts
+    return lib.mode_conv2d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(1) == 'conv2d_bwd_data')) == 1
+  return False
 
 
 def synthetic_batch(B, H, W, maxdisp, device, seed):

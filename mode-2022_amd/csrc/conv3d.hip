@@ -1201,7 +1201,8 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
     }
   } else {
     const size_t lds = WGeom<2, WTH2>::LDS;
-    if ((long long)std::max(Ci, Co) * D * H * W < (1ll << 29)) {  // 32-bit element offsets within a sample
+    // 32-bit element offsets within a sample of x (Ci channels at D x H x W) and of gy (Co channels at the output resolution)
+    if (std::max((long long)Ci * D * H * W, (long long)Co * d.Do * d.Ho * d.Wo) < (1ll << 29)) {
       if (d.MTo >= 2) {  // two output-channel blocks per workgroup share the staged x tile
         const size_t lds2 = lds + (size_t)32 * WGeom<2, WTH2>::GPLANE * sizeof(float);
         rc = mode::allow_lds(conv3d_bwd_weight_s2_kernel<2>, lds2, "mode_conv3d_bwd_weight");

@@ -149,6 +149,18 @@ def test_batchnorm3d_train_forward_backward(C, vol, relu, with_add):
     assert (got.cpu().double() - want).abs().max() < 2.0**-22 * np.sqrt(n) * 8 * max(1.0, float(want.abs().max()))
 
 
+def test_conv3d_stride2_weight_gradient_at_the_config4_volume():
+  """32 -> 64 stride 2 at 64 x 512 x 256 (configs[4]'s quarter-resolution volume, one sample): 32 * D * H * W = 2^28 elements of x
+  and 64 * 2^20 of gy still fit 32-bit lane offsets, so this layer must take the pipelined stride-2 kernel (it fell to the generic
+  one while the limit was taken on max(Ci, Co) * D * H * W: 23 % instead of ~55 % of the MFMA peak) -- checked against the float64
+  oracle."""
+  D, H, W = 64, 512, 256
+  x = _rand((1, 32, D, H, W), 11)
+  gy = _rand((1, 64, D // 2, H // 2, W // 2), 12)
+  got = HF.conv3d_bwd_weight(gy.to(DEV), x.to(DEV), 2)
+  _close('conv3d_bwd_weight s2 32->64 at 64x512x256', got, conv_ref.conv3d_bwd_weight(gy, x, 2), WGRAD)
+
+
 def test_whole_model_at_config4_per_gpu_share():
   """BASELINE configs[4]: 2048 x 1024 Cassini, 256 disparities, one pair per GPU -- the largest workload the north_star names
   (cost volume 2.15 GB if it were built; 64 x 512 x 256 quarter-resolution volume).  No CPU reference exists at this size

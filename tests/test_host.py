@@ -272,5 +272,7 @@ def test_bench_labels_on_the_split_path():
   assert bench._on_split_path('conv3d_bwd_data[64->64 s1 24x128x64]')
   assert not bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]')
   assert not bench._on_split_path('conv3d_fwd[32->1 s1 48x256x128]')
+  assert bench._on_split_path('conv3d_bwd_weight[32->32 s1 64x512x256]') and bench._on_split_path('conv2d_fwd[64->64 d2 256x128]')
+  assert bench._on_split_path('conv2d_bwd_weight[20->40 d1 26x70]') and not bench._on_split_path('conv2d_fwd[20->40 d1 26x70]')
   assert not bench._on_split_path('sphere_conv_bwd_weight[128->128 256x128]')
   assert abs(bench.MFMA_BF16_PEAK_TFLOPS / 6.0 - 416.67) < 0.01
