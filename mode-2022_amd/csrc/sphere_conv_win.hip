@@ -857,14 +857,23 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
 
   int roff[KT];
   float4 rw[KT];
+  // (all 18 table values first, from a clamped index: inside `if (pix_ok)` they were nine dependent load -> compute rounds, and the
+  // prologue of a tile is not overlapped with anything)
+  float ph_[KT], pw_[KT];
+  {
+    const long long idx = pix_ok ? (long long)h * d.W + w : 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      ph_[k] = pos[(2 * k) * HW + idx];
+      pw_[k] = pos[(2 * k + 1) * HW + idx];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     int r0 = 0, c0 = 0;
     float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pix_ok) {
-      const long long idx = (long long)h * d.W + w;
-      mode::tap_record_fixed(pos[(2 * k) * HW + idx], pos[(2 * k + 1) * HW + idx], d.H, d.W, r0, c0, wt);
-    }
+    mode::tap_record_fixed(ph_[k], pw_[k], d.H, d.W, r0, c0, wt);
+    if (!pix_ok) wt = make_float4(0.f, 0.f, 0.f, 0.f);
     int lr = r0 - rbase;
     if (lr < 0) lr += d.H;
     const int lc = c0 - cbase;
@@ -949,10 +958,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
 
   // prologue: window of chunk 0, operand of tap 0
 #pragma unroll
-  for (int ph = 0; ph < 8; ++ph) {
-    issue(0, ph, ph);
-    commit(0, ph, ph, smem);
-  }
+  for (int ph = 0; ph < 8; ++ph) issue(0, ph, ph);  // 32 loads in flight, then the stores: one memory round trip, not eight
+#pragma unroll
+  for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
   __syncthreads();
   sample(smem, 0, opbuf);
   sp_lds_barrier();
