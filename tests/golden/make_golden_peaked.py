@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Peaked-softmax whole-model fixtures: tests/golden/model_peaked_{tiny,cfg1}.npz, made by the *imported reference* on the CPU.
+
+The well-conditioned fixtures of make_golden_wc.py keep the soft-argmin in its smooth regime by shrinking the three 32 -> 1
+classifier convolutions: their softmax over the disparity axis is close to uniform (confidence = 3 / D), where
+d(disparity) / d(logit) ~ (d - mean) / D -- the regime in which the north_star's 1e-3 px bound is EASIEST to meet.  A trained
+network is peaked.  These fixtures put the same bound where it is hard: starting from ``recipe.recipe_state_wc``, the three
+classifier heads (`classifN.*`: 32 -> 32 convolution, its BatchNorm affine, 32 -> 1 convolution; everything upstream frozen) are
+trained by the imported reference with Adam on a pair whose right image is the left one shifted by `shift` px (ground truth = that
+shift), until the mean confidence of the eval output (probability mass within +-1 px of the prediction,
+models/mode_disparity.py:157-183) is >= 0.5.  Only the trained tensors are stored (`state/<key>`, ~340 KB per fixture); the rest
+of the state is regenerated from the recipe as before.  Everything else -- outputs, gradients, E_ref against an fp64 evaluation --
+is produced exactly as in make_golden_wc.py (same `run`).
+
+Usage:  python tests/golden/make_golden_peaked.py [--only tiny,cfg1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+import make_golden_wc as wc  # noqa: E402
+import recipe  # noqa: E402
+
+
+def heads(m, ins, maxdisp, size, train=True):
+  """The tail of models/mode_disparity.py:127-152 on captured classifier inputs (the reference's own modules do the work)."""
+  from models.submodule import disparityregression
+  c1 = m.classif1(ins[0])
+  c2 = m.classif2(ins[1]) + c1
+  c3 = m.classif3(ins[2]) + c2
+  preds, probs = [], []
+  for c in (c1, c2, c3):
+    c = F.interpolate(c, [maxdisp, size[0], size[1]], mode='trilinear', align_corners=True)
+    p = F.softmax(torch.squeeze(c, 1), dim=1)
+    probs.append(p)
+    preds.append(disparityregression(maxdisp)(p))
+  return preds, probs
+
+
+def confidence(prob, pred):
+  """Mass within +-1 of round(pred) (clamped at the borders like padding_mode='border')."""
+  D = prob.shape[1]
+  r = torch.round(pred).long()
+  tot = 0
+  for o in (-1, 0, 1):
+    tot = tot + torch.gather(prob, 1, (r + o).clamp(0, D - 1))
+  return tot
+
+
+def train_heads(models, maxdisp, H, W, B, seed, shift, steps, lr, target_conf, logit_scale, max_loss=1.0, peak_weight=0.3):
+  torch.manual_seed(0)
+  m = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini', out_conf=False)
+  manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+  m.load_state_dict(recipe.recipe_state_wc(manifest, seed, logit_scale=logit_scale))
+  left, right = recipe.recipe_images(B, H, W, seed + 1, shift=shift)
+  # the cost volume's plane i holds the match for a shift of 4 i px, and the align_corners up-sampling of the logits puts plane i
+  # at disparity i (D - 1) / (D / 4 - 1) (mode_disparity.py:104-113, 131-146): that is the disparity the heads are trained towards
+  gt_value = (shift // 4) * (maxdisp - 1.0) / (maxdisp // 4 - 1.0)
+  gt = torch.full((B, 1, H, W), float(gt_value))
+  near = (torch.arange(maxdisp, dtype=torch.float32) - gt_value).abs().lt(1.5).view(1, maxdisp, 1, 1)
+  m.train()
+  ins = [None] * 3
+  hooks = [getattr(m, 'classif%d' % (i + 1)).register_forward_pre_hook(lambda mod, a, i=i: ins.__setitem__(i, a[0].detach())) for i in range(3)]
+  with torch.no_grad():
+    m(left, right)
+  for h in hooks:
+    h.remove()
+  for p in m.parameters():
+    p.requires_grad_(False)
+  trained = [(k, p) for k, p in m.named_parameters() if k.startswith('classif')]
+  for _, p in trained:
+    p.requires_grad_(True)
+  opt = torch.optim.Adam([p for _, p in trained], lr=lr)
+  t0 = time.time()
+  for it in range(steps):
+    opt.zero_grad()
+    preds, probs = heads(m, ins, maxdisp, (H, W))
+    loss = sum(wgt * F.smooth_l1_loss(p, gt) for wgt, p in zip((0.5, 0.7, 1.0), preds))
+    # + a term that rewards probability mass near the target (smooth-L1 on the expectation alone is satisfied by a flat softmax)
+    loss = loss + peak_weight * sum(wgt * -torch.log((q * near).sum(1) + 1e-6).mean() for wgt, q in zip((0.5, 0.7, 1.0), probs))
+    loss.backward()
+    opt.step()
+    with torch.no_grad():
+      conf = float(confidence(probs[2], preds[2]).mean())
+    if it % 5 == 0 or conf >= target_conf:
+      print('    step %3d loss %.4f  pred3 mean %.3f std %.4f  mean confidence %.3f  (%.0f s)' % (it, float(loss), float(preds[2].mean()), float(preds[2].std()), conf, time.time() - t0),
+            flush=True)
+    if conf >= target_conf and float(loss) < max_loss and it >= 5:
+      break
+  return {k: p.detach().clone() for k, p in trained}, conf, gt_value
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--only', default='tiny,cfg1')
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--lr', type=float, default=3e-3)
+  ap.add_argument('--target-conf', type=float, default=0.6)
+  ap.add_argument('--dry', action='store_true', help='train only, write nothing')
+  args = ap.parse_args()
+  torch.set_num_threads(8)
+  models, _ = mg.import_reference()
+  cases = {'tiny': (16, 64, 32, 2, 700, 1, 8, 0.1), 'cfg1': (64, 512, 256, 1, 800, 4, 8, 0.05)}
+  for tag in args.only.split(','):
+    maxdisp, H, W, B, seed, sub, shift, ls = cases[tag]
+    print('%s: training the classifier heads of the imported reference' % tag, flush=True)
+    state, conf, gt_value = train_heads(models, maxdisp, H, W, B, seed, shift, args.steps, args.lr, args.target_conf, ls)
+    print('  %s: mean confidence %.3f after training' % (tag, conf))
+    if args.dry:
+      continue
+    wc.run(models, tag, maxdisp, H, W, B, seed, sub=sub, grad64=True, logit_scale=ls, override=state, shift=shift, prefix='model_peaked_')
+
+
+if __name__ == '__main__':
+  main()

@@ -58,17 +58,29 @@ def grad_summary(named_grads, seed):
               grad_val=np.array(vals))
 
 
-def run(models, tag, maxdisp, H, W, B, seed, sub, grad64, logit_scale):
+def _state(manifest, seed, logit_scale, override):
+  sd = recipe.recipe_state_wc(manifest, seed, logit_scale=logit_scale)
+  for k, v in (override or {}).items():
+    assert k in sd and sd[k].shape == v.shape, k
+    sd[k] = v.detach().clone().float()
+  return sd
+
+
+def run(models, tag, maxdisp, H, W, B, seed, sub, grad64, logit_scale, override=None, shift=3, prefix='model_wc_'):
+  """override: {state_dict key: tensor} replacing recipe tensors (stored in the fixture as `state/<key>`: make_golden_peaked.py);
+  shift: the right image is the left one rolled by this many px."""
   t0 = time.time()
   torch.manual_seed(0)
   m = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini', out_conf=False)
   manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
   assert manifest == recipe.load_manifest()
-  m.load_state_dict(recipe.recipe_state_wc(manifest, seed, logit_scale=logit_scale))
-  left, right = recipe.recipe_images(B, H, W, seed + 1)
+  m.load_state_dict(_state(manifest, seed, logit_scale, override))
+  left, right = recipe.recipe_images(B, H, W, seed + 1, shift=shift)
   gt = recipe.recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)
   mask = ~torch.isnan(gt)
-  out = dict(cfg=np.array([maxdisp, H, W, B, seed]), sub=np.array(sub), wc=np.array([recipe.WC_MIX, logit_scale]))
+  out = dict(cfg=np.array([maxdisp, H, W, B, seed]), sub=np.array(sub), wc=np.array([recipe.WC_MIX, logit_scale]), shift=np.array(shift))
+  for k, v in (override or {}).items():
+    out['state/' + k] = v.detach().float().numpy()
   s = (slice(None), slice(None), slice(None, None, sub), slice(None, None, sub))
 
   m.train()
@@ -108,7 +120,7 @@ def run(models, tag, maxdisp, H, W, B, seed, sub, grad64, logit_scale):
   print('  %s: reference eval done (%.0f s)' % (tag, time.time() - t0), flush=True)
 
   # fp64 evaluation of the same network (oracle): how reproducible is the reference's own fp32 run on this state?
-  P64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in recipe.recipe_state_wc(manifest, seed, logit_scale=logit_scale).items()}
+  P64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in _state(manifest, seed, logit_scale, override).items()}
   pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
   if grad64:
     for k, v in P64.items():
@@ -140,7 +152,9 @@ def run(models, tag, maxdisp, H, W, B, seed, sub, grad64, logit_scale):
   out['truth64/eval_E_ref'] = np.array(float((pred.double() - e64).abs().max()))
   print('  %s: E_ref (reference fp32 vs fp64, ALL pixels): train %.3e  eval %.3e   (%.0f s)' %
         (tag, e_train, float(out['truth64/eval_E_ref']), time.time() - t0), flush=True)
-  path = os.path.join(HERE, 'model_wc_%s.npz' % tag)
+  out['eval/conf_mean'] = np.array(float(conf.mean()))
+  print('  %s: mean eval confidence %.4f (uniform softmax: %.4f); eval pred3 mean %.3f std %.3f' % (tag, float(conf.mean()), 3.0 / maxdisp, float(pred.mean()), float(pred.std())))
+  path = os.path.join(HERE, '%s%s.npz' % (prefix, tag))
   np.savez_compressed(path, **out)
   print('  wrote %s (%.0f KB)' % (path, os.path.getsize(path) / 1024))
 

@@ -122,3 +122,26 @@ def recipe_disparity_smooth(B, H, W, seed, maxdisp):
   d = d.astype(np.float32)
   d[rs.rand(B, 1, H, W) < 0.05] = np.nan
   return torch.from_numpy(d)
+
+
+def fixture_state(z, manifest=None):
+  """The network state of a whole-model fixture (np.load of model_wc_*.npz / model_peaked_*.npz): recipe_state_wc from the stored
+  seed / mix / classifier scale, with the tensors the fixture carries itself (`state/<key>`: the classifier heads the imported
+  reference trained, make_golden_peaked.py) put in place of the recipe's."""
+  seed = int(z['cfg'][4])
+  mix, logit_scale = [float(v) for v in z['wc']]
+  sd = recipe_state_wc(manifest if manifest is not None else load_manifest(), seed, mix, logit_scale)
+  for k in z.files:
+    if k.startswith('state/'):
+      t = torch.from_numpy(z[k]).clone()
+      assert sd[k[6:]].shape == t.shape, k
+      sd[k[6:]] = t
+  return sd
+
+
+def fixture_inputs(z):
+  """(left, right, smooth ground truth) of a whole-model fixture."""
+  maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
+  shift = int(z['shift']) if 'shift' in z.files else 3
+  left, right = recipe_images(B, H, W, seed + 1, shift=shift)
+  return left, right, recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)

@@ -30,6 +30,7 @@ import mode_hip
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 DISP_TOL = 1e-3  # BASELINE.json north_star
+GRAD_CAP = 5e-2  # absolute cap on the relative L2 error of any parameter-gradient tensor
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -40,16 +41,14 @@ def _need_gpu():
 
 def _load(z, bn_from_fixture=False):
   maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
-  mix, logit_scale = [float(v) for v in z['wc']]
-  sd = recipe.recipe_state_wc(recipe.load_manifest(), seed, mix, logit_scale)
+  sd = recipe.fixture_state(z)
   if bn_from_fixture:
     for k in z.files:
       if k.startswith('bn/'):
         sd[k[3:]] = torch.from_numpy(z[k]).clone()
   net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
   net.load_state_dict(sd)
-  left, right = recipe.recipe_images(B, H, W, seed + 1)
-  gt = recipe.recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)
+  left, right, gt = recipe.fixture_inputs(z)
   return net, left.to(DEV), right.to(DEV), gt.to(DEV), seed
 
 
@@ -101,7 +100,8 @@ def _check_grads(tag, net, z, seed):
       o_ext += (e_own * norm)**2
     else:
       worst_3d = max(worst_3d, rel)
-    assert rel <= 1.5 * bound, (name, rel, bound)  # (16 projections: the estimate itself scatters by ~ +-35 %)
+    # (16 projections: the estimate itself scatters by ~ +-35 %); whatever the reference's own error, never more than 5 % of a tensor
+    assert rel <= min(1.5 * bound, GRAD_CAP), (name, rel, bound)
     # 32 sampled entries: round-off of a back-propagated gradient is heavy-tailed over the entries of a tensor (the reference's own
     # fp32 run against fp64: median 7e-5 rms, 99th percentile 1e-3 rms, maximum 1e-2 rms at config 1), hence a robust pair of
     # bounds -- the median at the L2 level, every entry within 100x of it (a wrong entry is O(1) rms)
@@ -120,15 +120,19 @@ def _check_grads(tag, net, z, seed):
   assert rel_ext <= max(2e-3, 3.0 * own_ext), (rel_ext, own_ext)
 
 
-def _check_pred(name, got, z, key, e_ref):
+def _check_pred(name, got, z, key, e_ref, tol=DISP_TOL):
   sub = int(z['sub'])
   g = got.detach()
   d_pix = np.abs(g[:, :, ::sub, ::sub].cpu().numpy().astype(np.float64) - z[key])
   d_blk = np.abs(F.avg_pool2d(g.double(), 8).cpu().numpy() - z[key + '_block'])
   print('%s: max|HIP - reference fp32| = %.3e px (stored pixels), %.3e (8x8 block means, all pixels); reference vs fp64: %.3e' %
         (name, d_pix.max(), d_blk.max(), float(e_ref)))
-  assert d_pix.max() <= DISP_TOL, (name, d_pix.max())
-  assert d_blk.max() <= DISP_TOL, (name, d_blk.max())
+  assert d_pix.max() <= tol, (name, d_pix.max())
+  assert d_blk.max() <= tol, (name, d_blk.max())
+  if tol > DISP_TOL:  # a bound widened by the reference's own error at a few multi-modal pixels: 99.9 % of the pixels within 1e-3 all the same
+    q = float(np.quantile(d_pix, 0.999))
+    print('%s: 99.9th percentile of |HIP - reference fp32| = %.3e px' % (name, q))
+    assert q <= DISP_TOL, (name, q)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'cfg1', 'full'])
@@ -181,3 +185,49 @@ def test_config2_batch_of_two_at_full_size(golden, arith):
   assert abs(float(loss.detach()) - float(z['train/loss'])) <= 2e-5 * float(z['train/loss'])
   loss.backward()
   _check_grads('configs[2] batch-2 step', net, z, seed)
+
+
+# ------------------------------------------------------------------ the same bar where it is hard: a peaked (trained) softmax
+@pytest.mark.parametrize('tag', ['tiny', 'cfg1'])
+def test_peaked_softmax_train_outputs_and_gradients(golden, tag, arith):
+  """tests/golden/model_peaked_*.npz: the classifier heads were TRAINED by the imported reference until the softmax over the
+  disparity axis holds most of its mass within +-1 px of the prediction (mean confidence 0.63 / 0.96 against 3/D = 0.19 / 0.05 for
+  the near-uniform softmax of the model_wc_* fixtures) -- the regime of a trained network, where d(disparity)/d(logit) is not
+  damped by a flat distribution.  Bound: max(1e-3, 3 x E_ref) with E_ref = the reference's own fp32-vs-fp64 error on the fixture,
+  printed so that the regime is visible."""
+  z = golden('model_peaked_%s.npz' % tag)
+  conf_mean, e_ref = float(z['eval/conf'].mean()), float(z['truth64/train_E_ref'])
+  assert conf_mean >= 0.5
+  tol = max(DISP_TOL, 3.0 * e_ref)
+  print('peaked %s: mean confidence of the reference output %.3f (a uniform softmax has %.3f); E_ref(train) = %.3e px -> bound %.3e px' %
+        (tag, conf_mean, 3.0 / int(z['cfg'][0]), e_ref, tol))
+  net, left, right, gt, seed = _load(z)
+  net.train()
+  preds = net(left, right)
+  for i, p in enumerate(preds):
+    _check_pred('peaked %s [%s] train pred%d' % (tag, arith, i + 1), p, z, 'train/pred%d' % (i + 1), e_ref, tol)
+  loss = mode_ref.training_loss(preds, gt, ~torch.isnan(gt))
+  ref_loss = float(z['train/loss'])
+  assert abs(float(loss.detach()) - ref_loss) <= 2e-5 * ref_loss, (float(loss.detach()), ref_loss)
+  loss.backward()
+  _check_grads('peaked %s [%s]' % (tag, arith), net, z, seed)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'cfg1'])
+def test_peaked_softmax_eval_output_and_confidence(golden, tag, arith):
+  z = golden('model_peaked_%s.npz' % tag)
+  e_ref = float(z['truth64/eval_E_ref'])
+  tol = max(DISP_TOL, 3.0 * e_ref)
+  net, left, right, gt, seed = _load(z, bn_from_fixture=True)
+  net.eval()
+  net.out_conf = True
+  with torch.no_grad():
+    pred, conf = net(left, right)
+  print('peaked %s: E_ref(eval) = %.3e px -> bound %.3e px' % (tag, e_ref, tol))
+  _check_pred('peaked %s [%s] eval pred3' % (tag, arith), pred, z, 'eval/pred3', e_ref, tol)
+  sub = int(z['sub'])
+  ref_pred = z['eval/pred3']
+  stable = np.abs(np.abs(ref_pred - np.round(ref_pred)) - 0.5) > 0.01
+  diff = np.abs(conf[:, :, ::sub, ::sub].cpu().numpy() - z['eval/conf'])
+  assert diff[stable].max() < 1e-3, diff[stable].max()
+  assert float(conf.mean()) >= 0.5

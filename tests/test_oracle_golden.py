@@ -184,19 +184,19 @@ def test_model_cfg1_eval(golden):
 
 
 # ------------------------------------------------------------------ well-conditioned fixtures (the 1e-3 bar itself)
-@pytest.mark.parametrize('tag', ['tiny', 'cfg1'])
+@pytest.mark.parametrize('tag', ['wc_tiny', 'wc_cfg1', 'peaked_tiny'])
 def test_model_wellconditioned_matches_the_reference_to_1e4(golden, tag):
   """The oracle on the fixtures tests/test_gpu_parity.py holds the HIP path to (made by the imported reference,
   tests/golden/make_golden_wc.py): same torch CPU kernels in the same order, so the agreement is at round-off level --
   outputs to 1e-4 px (a tenth of the north_star's bound), gradients to the reference's own fp32 reproducibility."""
-  z = golden('model_wc_%s.npz' % tag)
+  z = golden('model_%s.npz' % tag)
   maxdisp, H, W, B, seed = [int(v) for v in z['cfg']]
-  mix, logit_scale = [float(v) for v in z['wc']]
   sub = int(z['sub'])
   assert float(z['truth64/train_E_ref']) <= 1.5e-4 and float(z['truth64/eval_E_ref']) <= 1.5e-4  # what "well conditioned" means
-  P = recipe.recipe_state_wc(recipe.load_manifest(), seed, mix, logit_scale)
-  left, right = recipe.recipe_images(B, H, W, seed + 1)
-  gt = recipe.recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)
+  if tag.startswith('peaked'):  # ... and what "peaked" means: the softmax of the trained heads holds most of its mass within +-1 px
+    assert float(z['eval/conf'].mean()) >= 0.5 and float(z['eval/conf'].mean()) >= 3.0 * 3.0 / maxdisp
+  P = recipe.fixture_state(z)
+  left, right, gt = recipe.fixture_inputs(z)
   pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
   params = [k for k, v in P.items() if v.is_floating_point() and 'running' not in k]
   for k in params:
