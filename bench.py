@@ -57,6 +57,9 @@ def parse():
   ap.add_argument('--conv-arith', default='bf16x6', choices=['f32', 'bf16x6'],
                   help="stride-1 3x3x3 layers: 'f32' = fp32 MFMA; 'bf16x6' = fp32 operands split into three bf16 pieces, six bf16 MFMAs "
                   'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV_ARITH)')
+  ap.add_argument('--value-1gpu', type=float, default=None,
+                  help='pairs/s of the same workload on ONE GPU, if known: rank 0 adds value / (N * value_1gpu) to the line')
+  ap.add_argument('--no-eval-b1', action='store_true', help='skip the BASELINE configs[1] leg (eval forward, batch 1) after the timed region')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
                   '(RCCL refuses two ranks on the same device)')
@@ -94,6 +97,77 @@ def _on_split_path(label):
       return True  # any channel counts
     return lib.mode_conv2d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(1) == 'conv2d_bwd_data')) == 1
   return False
+
+
+def label_peak(label, conv_arith, on_split=None):
+  """(bound, peak, unit) a profiling label is priced against: HBM for the bandwidth-bound kernels; for the matrix kernels the fp32
+  MFMA peak, or -- where the layer runs on the split-bf16 kernels (`on_split(label)`) -- the dense bf16 peak / 6 (six bf16 MFMAs per
+  fp32 product): always the pipe the instructions actually issue on."""
+  if KERNEL_BOUND.get(label.split('[')[0], 'mfma') == 'hbm':
+    return 'hbm', HBM_PEAK_GBPS, 'GB/s'
+  split = conv_arith == 'bf16x6' and (on_split if on_split is not None else _on_split_path)(label)
+  return 'mfma', (MFMA_BF16_PEAK_TFLOPS / 6.0 if split else MFMA_F32_PEAK_TFLOPS), 'TFLOP/s'
+
+
+def blended_mfma_fraction(kern, conv_arith, on_split=None, prefixes=('conv3d_', 'deconv3d_')):
+  """Time-weighted fraction of the matrix-pipe peak over a group of labels, each priced against ITS pipe:
+  sum_k (flops_k / peak_k) / sum_k t_k.  A fraction of the time the pipes could have done the work in -- never above 1 (dividing
+  the summed fp32-equivalent flops by the fp32 peak, as round 2 did, exceeds 1 once part of the work runs on the bf16 pipe)."""
+  need = total = 0.0
+  for k, v in kern.items():
+    if not k.startswith(prefixes):
+      continue
+    peak = label_peak(k, conv_arith, on_split)[1]
+    need += v['flops'] / (peak * 1e12)
+    total += v['total_ms'] * 1e-3
+  return need / total if total > 0 else None
+
+
+# profiling label -> the device kernel that does its work (names as rocprofv3 --kernel-trace --stats prints them), so that the bench
+# line can name the dominant KERNEL next to the dominant (kernel, layer shape) label.
+def kernel_of(label, conv_arith, on_split=None):
+  import re
+  name = label.split('[')[0]
+  split = conv_arith == 'bf16x6' and (on_split if on_split is not None else _on_split_path)(label)
+  m = re.search(r' s(\d) ', label)
+  stride = int(m.group(1)) if m else 1
+  if name in ('conv3d_fwd', 'conv3d_bwd_data', 'conv3d_bn_eval'):
+    if re.search(r'->1 ', label):
+      return 'conv3d_co1_fwd_mfma_kernel' if name != 'conv3d_bwd_data' else 'conv3d_co1_bwd_data_kernel'
+    if split:
+      return 'conv3d_split_kernel<1,0>' if stride == 1 else 'conv3d_s2_split_kernel'
+    return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
+  if name == 'conv3d_bwd_weight':
+    if re.search(r'->1 ', label):
+      return 'conv3d_co1_bwd_weight_kernel'
+    if split:
+      return 'conv3d_bww_split_kernel'
+    return 'conv3d_bwd_weight_ring_kernel' if stride == 1 else 'conv3d_bwd_weight_s2_kernel'
+  if name in ('deconv3d_fwd', 'deconv3d_bn_eval'):
+    return 'deconv3d_split_kernel' if split else 'deconv3d_kernel'
+  if name in ('conv2d_fwd', 'conv2d_bwd_data', 'conv2d_bn_eval'):
+    return 'conv2d_split_kernel' if split else 'conv2d_kernel'
+  if name == 'conv2d_bwd_weight':
+    return 'conv2d_bww_split_kernel' if split else 'conv2d_bww_kernel'
+  return {'sphere_conv_fwd': 'sphere_fwd_split_kernel' if conv_arith == 'bf16x6' else 'sphere_fwd_win_kernel',
+          'sphere_conv_bn_eval': 'sphere_fwd_split_kernel' if conv_arith == 'bf16x6' else 'sphere_fwd_win_kernel',
+          'sphere_conv_bwd_data': 'sphere_bwd_data_adj9_kernel', 'sphere_conv_bwd_weight': 'sphere_bww_win_kernel',
+          'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel'}.get(name, name)
+
+
+def by_kernel(kern, conv_arith, on_split=None):
+  """{device kernel: dict(total_ms, calls, flops, bytes, need_s)} over all labels (need_s = time its pipe's peak would need)."""
+  out = {}
+  for k, v in kern.items():
+    bound, peak, unit = label_peak(k, conv_arith, on_split)
+    a = out.setdefault(kernel_of(k, conv_arith, on_split), dict(total_ms=0.0, calls=0, flops=0, bytes=0, need_s=0.0, bound=bound, labels=[]))
+    a['total_ms'] += v['total_ms']
+    a['calls'] += v['calls']
+    a['flops'] += v['flops']
+    a['bytes'] += v['bytes']
+    a['need_s'] += (v['bytes'] / (peak * 1e9)) if bound == 'hbm' else (v['flops'] / (peak * 1e12))
+    a['labels'].append(k)
+  return out
 
 
 def synthetic_batch(B, H, W, maxdisp, device, seed):
@@ -177,6 +251,55 @@ def cpu_baseline_subprocess(args):
   except subprocess.TimeoutExpired:
     return dict(value=None, unit='pairs/s', cores=usable_cores(), kind='port',
                 sample='timed out after %d s (1 pair fwd+bwd at Cassini 512x256, D=64)' % args.cpu_baseline_timeout)
+
+
+def eval_b1_leg(net, left, right, args, steps=20, warmup=3):
+  """BASELINE configs[1]: eval forward of ONE pair (BatchNorm folded into the convolution kernels, hipGraph replay), timed right
+  after the training steps on the same weights: ms per pair, pairs/s, and the dominant kernel label of two profiled eager passes."""
+  from mode_hip import profiling
+  from mode_hip.graph_step import GraphedStep
+  was_training = net.training
+  net.eval()
+
+  def fwd():
+    with torch.no_grad():
+      return net(left, right)
+
+  try:
+    for _ in range(warmup):
+      fwd()
+    torch.cuda.synchronize()
+    launch = 'hipGraph replay'
+    try:
+      graphed = GraphedStep(fwd, (left, right), warmup=1)
+      run = graphed.replay
+    except Exception as e:
+      sys.stderr.write('bench.py: eval_b1 capture failed (%s); eager\n' % e)
+      launch, run = 'eager', fwd
+    run()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+      run()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.time() - t0) / steps
+    out = {'workload': 'eval forward, batch 1 (BASELINE configs[1])', 'ms_per_pair': ms, 'pairs_per_s': 1e3 / ms, 'steps': steps, 'launch': launch}
+    if not args.no_kernel_timing:
+      profiling.enable(True)
+      for _ in range(2):
+        fwd()
+      torch.cuda.synchronize()
+      kern = profiling.summary()
+      profiling.enable(False)
+      if kern:
+        dom = max(kern, key=lambda k: kern[k]['total_ms'])
+        bound, peak, unit = label_peak(dom, args.conv_arith)
+        ach = kern[dom]['GBps'] if bound == 'hbm' else kern[dom]['TFLOPs']
+        out['dominant'] = {'kernel': dom, 'ms_per_pair': kern[dom]['total_ms'] / 2, 'calls_per_pair': kern[dom]['calls'] // 2, 'achieved': ach,
+                           'unit': unit, 'frac': ach / peak}
+    return out
+  finally:
+    net.train(was_training)
 
 
 def main():
@@ -328,6 +451,9 @@ def main():
     if not bool(torch.isfinite(flat).all()):
       raise RuntimeError('bench.py: non-finite parameters after %d training steps' % (args.warmup + args.steps))
   profiling.enable(False)
+  eval_b1 = None
+  if world == 1 and args.mode == 'train' and not args.no_eval_b1:
+    eval_b1 = eval_b1_leg(net, left[:1], right[:1], args)
   rank_ms = [1e3 * elapsed / args.steps]
   if world > 1:
     t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -377,16 +503,14 @@ def main():
         },
     }
     if kern:
-      # dominant hand-written kernel = the (kernel, layer shape) label with the largest total time in the timed region
+      # dominant hand-written kernel = the (kernel, layer shape) LABEL with the largest total time over the profiled steps ...
       dom = max(kern, key=lambda k: kern[k]['total_ms'])
       a = kern[dom]
-      bound = KERNEL_BOUND.get(dom.split('[')[0], 'mfma')
+      bound, peak, unit = label_peak(dom, args.conv_arith)
       if bound == 'hbm':
-        achieved, peak, unit, per_launch = a['GBps'], HBM_PEAK_GBPS, 'GB/s', a['bytes_per_call']
+        achieved, per_launch = a['GBps'], a['bytes_per_call']
       else:
-        achieved, peak, unit, per_launch = a['TFLOPs'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', a['flops_per_call']
-        if args.conv_arith == 'bf16x6' and _on_split_path(dom):
-          peak = MFMA_BF16_PEAK_TFLOPS / 6.0  # fp32-equivalent flops against the bf16 pipe: six MFMAs per product
+        achieved, per_launch = a['TFLOPs'], a['flops_per_call']
       traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
       try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
@@ -399,23 +523,41 @@ def main():
             break
       except (OSError, ValueError):
         pass
+      # ... and the dominant DEVICE KERNEL over all the layer shapes it serves (what `rocprofv3 --stats` ranks first), priced against
+      # the pipe each of its launches runs on
+      groups = by_kernel(kern, args.conv_arith)
+      kdom = max(groups, key=lambda k: groups[k]['total_ms'])
+      g = groups[kdom]
+      g_sec = g['total_ms'] * 1e-3
       out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
                          'frac': achieved / peak, 'traffic': traffic, 'algorithmic_per_launch': per_launch,
                          'avg_ms': a['avg_ms'], 'calls': a['calls'],
+                         'selected_by': 'largest total time of one (operator, layer shape) label; by_kernel = largest total time of one device '
+                                        'kernel over all its shapes (the first row of rocprofv3 --stats)',
+                         'by_kernel': {'kernel': kdom, 'bound': g['bound'], 'ms_per_step': g['total_ms'] / max(args.profile_steps, 1),
+                                       'launches_per_step': g['calls'] / max(args.profile_steps, 1),
+                                       'achieved': (g['bytes'] / g_sec / 1e9) if g['bound'] == 'hbm' else (g['flops'] / g_sec / 1e12),
+                                       'unit': 'GB/s' if g['bound'] == 'hbm' else 'TFLOP/s',
+                                       'frac': g['need_s'] / g_sec, 'labels': g['labels']},
                          'timed_over': ('%d eager steps after the timed region (the timed steps replay a hipGraph)' % args.profile_steps)
                                        if args.launch == 'graph' else 'the timed region'}
-      # north_star targets: HBM fraction of the cost-volume build, MFMA fraction of the whole 3D regulariser
+      # north_star targets: HBM fraction of the cost-volume build, MFMA fraction of the whole 3D regulariser -- every label against
+      # the pipe it runs on (fp32 MFMA 157.3, or bf16 / 6 = 416.7 for the split kernels), time-weighted: never above 1
       cv = kern.get('cost_volume_fwd')
       k3 = [v for k, v in kern.items() if k.startswith(('conv3d_', 'deconv3d_'))]
       out['targets'] = {
           'cost_volume_fwd_hbm_frac': round(cv['GBps'] / HBM_PEAK_GBPS, 4) if cv else None,
-          'regulariser3d_mfma_frac': round(sum(v['flops'] for v in k3) / (sum(v['total_ms'] for v in k3) * 1e9) / MFMA_F32_PEAK_TFLOPS, 4)
-          if k3 else None,
+          'regulariser3d_mfma_frac': round(blended_mfma_fraction(kern, args.conv_arith), 4) if k3 else None,
+          'regulariser3d_tflops_fp32_equivalent': round(sum(v['flops'] for v in k3) / (sum(v['total_ms'] for v in k3) * 1e9), 2) if k3 else None,
       }
       out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
                             'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}
     else:
       out['roofline'] = None
+    if eval_b1 is not None:
+      out['eval_b1'] = eval_b1
+    if args.value_1gpu:
+      out['scaling_vs_1gpu'] = {'value_1gpu': args.value_1gpu, 'efficiency': out['value'] / (world * args.value_1gpu)}
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline_subprocess(args)
     print(json.dumps(out))

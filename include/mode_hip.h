@@ -383,6 +383,8 @@ int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float
  *        consecutive calls of the module on the sub-batches would compute, including the order of the running-statistics
  *        updates; save_* hold groups * C values.  Used to run the left and right images through the shared extractor as one batch.
  * `workspace` >= mode_bn_workspace_bytes(C * groups) for the training calls.
+ * mode_bn_train_fwd is NOT in-place: `out` must not alias `y` (the normalisation pass re-reads one element per channel of y -- the
+ *        pivot of the shifted sums -- while it writes `out`); out == y returns MODE_ERR_BAD_ARG.
  */
 size_t mode_bn_workspace_bytes(int C);
 

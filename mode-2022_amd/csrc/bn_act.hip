@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
     if (RELU) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
     }
     return v;
   };
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
       float v = __builtin_fmaf(y[base + i], sc, sh);
       if (ADD) v += add[base + i];
-      if (RELU) v = fmaxf(v, 0.f);
+      if (RELU) v = relu_nan(v);
       out[base + i] = v;
     }
 }
@@ -456,6 +456,8 @@ extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* 
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
   MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: save_scale / save_shift come in pairs");
   MODE_REQUIRE(groups >= 1 && B % groups == 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: batch %d not divisible into %d groups", B, groups);
+  // the apply pass re-reads the pivot of the shifted sums from y while other blocks of the same launch write `out`
+  MODE_REQUIRE(out != y, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: in-place operation (out == y) is not supported");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = pick_nsplit(C * groups, S);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);

@@ -102,10 +102,12 @@ inline Epi make_epi(const mode_bn_epilogue* e, const float* shift) {
 // the packing kernels scale output channel o of the weights by fold_scale and write fold_shift(o) next to the packed weights.
 __device__ __forceinline__ float fold_scale(const mode_bn_epilogue& e, int o) { return e.gamma[o] / sqrtf(e.var[o] + e.eps); }
 __device__ __forceinline__ float fold_shift(const mode_bn_epilogue& e, int o) { return e.beta[o] - e.mean[o] * fold_scale(e, o); }
+// ReLU as torch computes it: NaN stays NaN (fmaxf(NaN, 0) would return 0 and hide a diverged activation).
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 __device__ __forceinline__ float apply_epi(const Epi& e, float v, int o, long long idx) {
   v += e.shift[o];
   if (e.add) v += e.add[idx];
-  return e.relu ? fmaxf(v, 0.f) : v;
+  return e.relu ? relu_nan(v) : v;
 }
 // Register-lean form for the MFMA epilogues (D[i = o][j]: accumulator register q of lane l holds output channel
 // o = tile * 32 + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)).  Fetching shift[o] per element made the compiler preload 16 values per
@@ -120,7 +122,7 @@ __device__ __forceinline__ float epi_apply_q(const Epi& e, float v, float tile_s
   const int src = (q & 3) + 8 * (q >> 2) + 4 * (int)((threadIdx.x & 63) >> 5);  // lane (= channel within the tile) holding this element's shift
   v += __shfl(tile_shift, src, 64);
   if (e.add) v += e.add[idx];
-  return e.relu ? fmaxf(v, 0.f) : v;
+  return e.relu ? relu_nan(v) : v;
 }
 
 // Split-K reduction out[i] (+)= sum_s part[s * n + i], one wave per output element: lane l takes the slices l, l + 64, ... in

@@ -363,7 +363,7 @@ extern "C" int mode_conv1x1_bwd_weight(const float* gy, const float* x, float* g
   W1 d;
   d.B = B; d.Ci = Ci; d.Co = Co; d.H = H; d.W = W; d.s = stride;
   d.Ho = (H - 1) / stride + 1; d.Wo = (W - 1) / stride + 1;
-  MODE_REQUIRE(d.Wo % 4 == 0 && (stride == 1 || (W % 8 == 0 && H % 2 == 0)), MODE_ERR_UNSUPPORTED,
+  MODE_REQUIRE(d.Wo % 4 == 0 && (stride == 1 || W % 8 == 0), MODE_ERR_UNSUPPORTED,  // (any H: the last row read is 2 (Ho - 1) <= H - 1)
                "%s: needs an output width divisible by 4 (stride 2: input width divisible by 8), got %dx%d stride %d", who, H, W, stride);
   MODE_REQUIRE(((size_t)gy % 16) == 0 && ((size_t)x % 16) == 0, MODE_ERR_UNSUPPORTED, "%s: tensors must be 16-byte aligned", who);
   hipStream_t st = mode::as_stream(stream);

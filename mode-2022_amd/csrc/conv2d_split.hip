@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
                 float v = acc[m][r][qq];
                 if (EPI) v += shiftv[m][qq];
                 if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : epi.add[(long long)b * d.Co * HWi + idx];
-                yb[idx] = EPI ? fmaxf(v, relu_floor) : v;
+                yb[idx] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
               }
             }
         }

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
                 float v = acc[m][r][qq];
                 if (EPI) v += shiftv[m][qq];
                 if (EPI == 2) v += addv[m][r][qq];
-                yb[idx] = EPI ? fmaxf(v, relu_floor) : v;
+                yb[idx] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
               }
             }
         }

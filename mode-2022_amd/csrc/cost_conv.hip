@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float*
       }
       if (EPI) {
         acc = fmaf(acc, sc, sh);
-        if (bn.relu) acc = fmaxf(acc, 0.f);
+        if (bn.relu) acc = relu_nan(acc);
       }
       ob[(long long)d * HW + w] = acc;
     }

@@ -1,11 +1,47 @@
 """torch.autograd wrappers over the C-ABI kernels (host-side glue: shapes, workspaces, autograd; no arithmetic of the path is left
 to torch or to a vendor library)."""
+import collections
 import ctypes
 import threading
 
 import torch
 
 from . import BnEpilogue, check, lib, profiling, ptr, require_f32c, require_gpu, stream_of
+
+
+class _LRU(object):
+  """Bounded cache for the per-geometry device tables (sampling tables of the integer-table convolutions, tile plans, adjoint
+  tables, transposed tables): a process that evaluates many resolutions (fisheye / 3D60 / Deep360 in one run) would otherwise pin
+  one set per shape for ever -- the adjoint of the 7x7 stem at 1024 x 512 alone is ~100 MB.  Callers hold their own lock."""
+
+  def __init__(self, maxsize):
+    self.maxsize = maxsize
+    self.d = collections.OrderedDict()
+
+  def get(self, key, default=None):
+    if key in self.d:
+      self.d.move_to_end(key)
+      return self.d[key]
+    return default
+
+  def __contains__(self, key):
+    return key in self.d
+
+  def __getitem__(self, key):
+    self.d.move_to_end(key)
+    return self.d[key]
+
+  def __setitem__(self, key, value):
+    self.d[key] = value
+    self.d.move_to_end(key)
+    while len(self.d) > self.maxsize:
+      self.d.popitem(last=False)
+
+  def __len__(self):
+    return len(self.d)
+
+
+TABLE_CACHE_ENTRIES = 24  # per cache; one ModeDisparity geometry uses 1 plan, 2 adjoints, 1 transposed table and 5 integer tables
 
 
 # ------------------------------------------------------------------------------------ cost volume
@@ -251,7 +287,7 @@ def _check_pos(pos, x, Kh, Kw):
                        (x.shape[2], x.shape[3], pos.shape[2], pos.shape[3]))
 
 
-_plan_cache = {}
+_plan_cache = _LRU(TABLE_CACHE_ENTRIES)
 _plan_lock = threading.Lock()
 SPHERE_LAYOUT = 'transposed'  # windowed kernels on plane-transposed copies | 'nchw'
 SPHERE_FWD_MIN_WG = 200  # fewer workgroups than this: the windowed forward under-fills the chip, use the general kernel
@@ -367,7 +403,7 @@ def _sphere_fwd_win(xp, pos, w, e, yp, wp, tiles, n0, n1, n2, B, Ci, H, W, Co, K
                                          transposed, stream), 'mode_sphere_conv_fwd_win')
 
 
-_adjoint_cache = {}
+_adjoint_cache = _LRU(TABLE_CACHE_ENTRIES)
 _adjoint_lock = threading.Lock()
 SPHERE_BWD_DATA = 'gather'  # 'gather' (adjoint table) | 'scatter' (atomics)
 
@@ -395,7 +431,7 @@ def sphere_adjoint(pos, kh, kw, stride, out_hw):
 
 
 SPHERE_BWD_DATA_T = True  # adjoint gather on plane-transposed storage
-_pos_t_cache = {}
+_pos_t_cache = _LRU(TABLE_CACHE_ENTRIES)
 
 
 def _transposed_table(pos):
@@ -754,7 +790,7 @@ def conv_stem(x, conv):
 # pixel (h*s + i*d - p, w*s + j*d - p), the bilinear weights are exactly (1, 0, 0, 0) and positions outside the image are dropped
 # by the operator's own guard (cu:246), which is zero padding.  Same kernels as SphereConv (general gather-and-MAC forward,
 # adjoint-gather input gradient, split-K weight gradient), bit-for-bit a plain convolution up to the order of the fp32 sums.
-_conv_tables = {}
+_conv_tables = _LRU(TABLE_CACHE_ENTRIES)
 _conv_table_lock = threading.Lock()
 
 

@@ -183,3 +183,25 @@ def test_sphere_polar_plan_items():
       r0 = np.maximum(np.floor(y).astype(int), 0)
       lr = (r0 - it[i, 2 + k]) % H
       assert (lr + 1 < 34).all()
+
+
+def test_bn_train_fwd_refuses_in_place_operation():
+  """The normalisation pass re-reads the pivot of the shifted sums from y while it writes out: out == y is rejected on the host."""
+  lib = mode_hip.lib()
+  a, b = ctypes.c_void_p(4096), ctypes.c_void_p(8192)
+  rc = lib.mode_bn_train_fwd(a, None, b, b, None, None, None, 0.1, 1e-5, 1, a, b, b, None, None, b, 2, 4, 64, 1, None)
+  assert rc == -1 and b'in-place' in lib.mode_last_error()
+
+
+def test_table_caches_are_bounded():
+  from mode_hip import functional as HF
+  c = HF._LRU(3)
+  for i in range(5):
+    c[i] = i * i
+  assert len(c) == 3 and 0 not in c and 1 not in c and c[4] == 16
+  assert c.get(2) == 4  # touching an entry makes it the newest
+  c[9] = 81
+  assert 2 in c and 3 not in c
+  for i in range(HF.TABLE_CACHE_ENTRIES + 5):  # the integer tables of many resolutions do not accumulate
+    HF.conv2d_table(8 + i, 8, 3, 3, (1, 1), (1, 1), (1, 1), 'cpu')
+  assert len(HF._conv_tables) == HF.TABLE_CACHE_ENTRIES

@@ -1,0 +1,56 @@
+"""CPU: the arithmetic of bench.py's `roofline` / `targets` block (no GPU, no native call: the split-path predicate is injected)."""
+import bench
+
+
+def _kern():
+  # two labels on the split-bf16 kernels (priced against 2500 / 6 TFLOP/s), one on the fp32 MFMA kernels (157.3), one HBM-bound
+  k = {
+      'conv3d_fwd[32->32 s1 48x256x128]': dict(calls=12, total_ms=12 * 0.80, flops=12 * 173.95e9, bytes=0),
+      'conv3d_bwd_weight[32->32 s1 48x256x128]': dict(calls=6, total_ms=6 * 0.95, flops=6 * 173.95e9, bytes=0),
+      'conv3d_fwd[32->64 s2 48x256x128]': dict(calls=6, total_ms=6 * 0.44, flops=6 * 43.5e9, bytes=0),
+      'bn_train_fwd[2x32 48x256x128]': dict(calls=10, total_ms=10 * 0.255, flops=0, bytes=10 * 1.208e9),
+  }
+  for v in k.values():
+    v['avg_ms'] = v['total_ms'] / v['calls']
+    v['TFLOPs'] = v['flops'] / (v['total_ms'] * 1e9)
+    v['GBps'] = v['bytes'] / (v['total_ms'] * 1e6)
+  return k
+
+
+def _split(label):
+  return ' s1 ' in label and label.startswith('conv3d')
+
+
+def test_each_label_is_priced_against_the_pipe_it_runs_on():
+  assert bench.label_peak('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  assert bench.label_peak('conv3d_fwd[32->32 s1 48x256x128]', 'f32', _split) == ('mfma', 157.3, 'TFLOP/s')
+  assert bench.label_peak('conv3d_fwd[32->64 s2 48x256x128]', 'bf16x6', _split) == ('mfma', 157.3, 'TFLOP/s')
+  assert bench.label_peak('bn_train_fwd[2x32 48x256x128]', 'bf16x6', _split) == ('hbm', 8000.0, 'GB/s')
+
+
+def test_blended_regulariser_fraction_is_a_fraction():
+  k = _kern()
+  f = bench.blended_mfma_fraction(k, 'bf16x6', _split)
+  # by hand: time the pipes' peaks need / time taken
+  need = (12 + 6) * 173.95e9 / (2500e12 / 6) + 6 * 43.5e9 / 157.3e12
+  took = (12 * 0.80 + 6 * 0.95 + 6 * 0.44) * 1e-3
+  assert abs(f - need / took) < 1e-12 and 0.0 < f < 1.0
+  # round 2's formula (all flops against the fp32 peak) exceeds 1 on the same numbers -- the defect this replaces
+  old = sum(v['flops'] for n, v in k.items() if n.startswith('conv3d')) / (took * 1e12) / 157.3
+  assert old > 1.0
+  # in f32 mode every label is priced against the fp32 MFMA peak
+  f32 = bench.blended_mfma_fraction(k, 'f32', _split)
+  assert abs(f32 - old) < 1e-12
+
+
+def test_by_kernel_groups_labels_of_one_device_kernel():
+  k = _kern()
+  k['conv3d_bwd_data[32->32 s1 48x256x128]'] = dict(k['conv3d_fwd[32->32 s1 48x256x128]'])
+  g = bench.by_kernel(k, 'bf16x6', _split)
+  a = g['conv3d_split_kernel<1,0>']
+  assert a['calls'] == 24 and abs(a['total_ms'] - 2 * 12 * 0.80) < 1e-9 and len(a['labels']) == 2
+  assert abs(a['need_s'] / (a['total_ms'] * 1e-3) - (173.95e9 / (2500e12 / 6)) / 0.80e-3) < 1e-9
+  assert g['conv3d_bww_split_kernel']['calls'] == 6 and g['conv3d_kernel']['calls'] == 6
+  assert g['bn_stats_kernel+bn_apply_kernel']['bound'] == 'hbm'
+  hb = g['bn_stats_kernel+bn_apply_kernel']
+  assert abs(hb['need_s'] - 10 * 1.208e9 / 8000e9) < 1e-12

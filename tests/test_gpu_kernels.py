@@ -793,6 +793,28 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
     assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize('relu', [True, False])
+def test_folded_epilogues_propagate_nan_like_torch(relu, arith):
+  """A NaN activation stays NaN through conv + folded BatchNorm (+ ReLU) in BOTH arithmetics -- torch.relu(NaN) is NaN, and the
+  reference's eval forward would show a diverged layer; fmaxf(NaN, 0) = 0 (or fmaxf(NaN, -inf) = -inf without ReLU) would hide it."""
+  with torch.no_grad():
+    x, w = _rand((1, 32, 4, 8, 32), 301).to(DEV), _rand((32, 32, 3, 3, 3), 302, 0.1).to(DEV)
+    x[0, 3, 2, 4, 7] = float('nan')
+    got = HF.conv3d_bn_eval(x, w, _eval_bn(32, 303), 1, None, relu)
+    near = got[0, :, 1:4, 3:6, 6:9]
+    assert bool(torch.isnan(near).all()), 'every output within one tap of the NaN input is NaN'
+    assert int(torch.isnan(got).sum()) == near.numel() and not bool(torch.isinf(got).any())
+    x2, w2 = _rand((1, 64, 16, 32), 304).to(DEV), _rand((64, 64, 3, 3), 305, 0.1).to(DEV)
+    x2[0, 5, 8, 9] = float('nan')
+    got = HF.conv2d_bn_eval(x2, w2, _eval_bn(64, 306), 1, None, relu)
+    assert bool(torch.isnan(got[0, :, 7:10, 8:11]).all()) and int(torch.isnan(got).sum()) == 64 * 9 and not bool(torch.isinf(got).any())
+  y = _rand((2, 8, 64), 307).to(DEV)
+  y[1, 2, 5] = float('nan')
+  bn = __import__('torch').nn.BatchNorm1d(8).to(DEV).train()
+  out = HF.bn_act(bn, y, None, relu)
+  assert bool(torch.isnan(out[:, 2]).all()) and int(torch.isnan(out).sum()) == 2 * 64  # that channel's statistics are NaN, like torch
+
+
 @pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
 @pytest.mark.parametrize('dil', [1, 2])
 def test_folded_batchnorm_conv2d_3x3(dil, relu, with_add, arith):
@@ -904,6 +926,7 @@ def test_eval_forward_launches_no_batchnorm_kernel():
     (1, 5, 7, 3, 12, 1),        # channel counts off the 8 / 32 blocks, pixel count off the 32-pixel segment
     (2, 12, 200, 6, 8, 1),      # more than 128 output channels (two launch rows)
     (1, 10, 6, 6, 16, 2),
+    (2, 16, 24, 7, 16, 2),      # stride 2 on an ODD input height: forward, input gradient and weight gradient all take it
 ])
 def test_conv1x1_kernels(B, Ci, Co, H, W, s):
   """mode_conv1x1_fwd / _bwd_data / _bwd_weight against torch's fp64 conv2d autograd, through the autograd Function."""

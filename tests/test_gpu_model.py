@@ -152,7 +152,7 @@ def test_bench_two_ranks_share_one_gpu():
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
   cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '256',
-         '--width', '128', '--maxdisp', '64', '--batch', '1', '--no-cpu-baseline', '--dist-backend', 'gloo']
+         '--width', '128', '--maxdisp', '64', '--batch', '1', '--no-cpu-baseline', '--dist-backend', 'gloo', '--value-1gpu', '10.0']
   r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
   lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
   assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
@@ -160,6 +160,12 @@ def test_bench_two_ranks_share_one_gpu():
   assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
   assert len(d['rank_ms_per_step']) == 2 and d['collective']['ranks'] == 2 and d['collective']['bytes'] == 4 * 5489280
   assert abs(d['per_gpu_value'] * 2 - d['value']) < 1e-9 * d['value']
+  # the timed steps were hipGraph replays under the process group too (bench.py falls back to eager launches when capture fails,
+  # and says so in this field: a silent fallback would be timed as if it were the product's launch path)
+  assert d['config']['launch'].startswith('hipGraph'), d['config']['launch']
+  assert d['collective']['avg_ms_rank0'] is not None and d['collective']['avg_ms_rank0'] > 0
+  assert d['scaling_vs_1gpu']['value_1gpu'] == 10.0 and abs(d['scaling_vs_1gpu']['efficiency'] - d['value'] / 20.0) < 1e-12
+  assert 0 < d['targets']['regulariser3d_mfma_frac'] < 1 and 0 < d['roofline']['by_kernel']['frac'] < 1
 
 
 def test_smoke_entry():
