@@ -370,6 +370,11 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
       n_wg = sum(plan[1]) * x.shape[0] * groups * (-(-(w.shape[0] // groups) // 128))
       if n_wg < SPHERE_FWD_MIN_WG:
         plan = None
+    if not _plan_usable(plan):
+      post = sphere_native_t(pos, w.shape[2], w.shape[3])  # ERP-like table: the `_t` operator on the NCHW tensors themselves
+      if post is not None and sphere_t_supported(post, w, x.shape[0], groups):
+        sphere_conv_fwd_t(x, post, w, out, groups)
+        return None if return_transposed else out
   with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
     if plan is not None:
       B, Ci, H, W, Co, Kh, Kw = dims[:7]
@@ -448,6 +453,31 @@ def _transposed_table(pos):
     return hit[0]
 
 
+def _plan_usable(plan):
+  """A plan the windowed forward / weight-gradient kernels can run as a whole: compact tiles exist and the tall-window tiles (if
+  any) have polar items."""
+  return plan is not None and plan[1][0] > 0 and not (plan[3] and not (plan[6] is not None and SPHERE_POLAR))
+
+
+def sphere_native_t(pos, kh, kw):
+  """sphereType = 'ERP' on the fast path.  The windowed kernels want the shift-invariant (longitude) axis of the table along the
+  lanes and contiguous in memory.  For the Cassini layout that axis is H, the strided one, hence the plane-transposed copies.  For
+  an ERP table it is W -- already contiguous: an ERP problem on NCHW storage IS the Cassini problem of the transposed table on
+  plane-transposed storage (sphere_conv.py:226-236 builds the Cassini table as exactly that transpose), so the `_t` operators run
+  on the NCHW tensors as they are, with no transpose at all.  Returns the transposed table when `pos` itself cannot be planned but
+  its transpose can; else None."""
+  if kh * kw != 9 or SPHERE_LAYOUT != 'transposed' or _plan_usable(sphere_plan(pos, kh, kw)):
+    return None
+  post = _transposed_table(pos)
+  return post if _plan_usable(sphere_plan(post, kh, kw)) else None
+
+
+def sphere_uses_transposed_copies(pos, kh, kw):
+  """Whether the gradients of this table run on plane-transposed COPIES of their operands (Cassini-like tables); ERP-like tables
+  (sphere_native_t) and tables without a plan do not."""
+  return SPHERE_LAYOUT == 'transposed' and kh * kw == 9 and sphere_plan(pos, kh, kw) is not None
+
+
 def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_transposed=None):
   """Accumulates into `gx` (B,Ci,H,W) (caller zero-fills, sphere_conv.py:62); with overwrite=True `gx` may hold anything and
   is overwritten.  gy_transposed: the plane-transposed copy of gy, if the caller has one (the weight gradient needs it too):
@@ -461,6 +491,12 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_tra
   nbytes = 4 * (gx.numel() + gy.numel() + pos.numel() + w.numel())
   if SPHERE_BWD_DATA == 'gather':
     B, Ci, H, W, Co, Kh, Kw, sH, sW, Ho, Wo, G = dims
+    post = sphere_native_t(pos, Kh, Kw) if ((sH, sW) == (1, 1) and (Ho, Wo) == (H, W) and SPHERE_BWD_DATA_T) else None
+    if post is not None:  # ERP-like table: the adjoint gather of the transposed problem reads and writes the NCHW tensors directly
+      if overwrite:
+        return sphere_conv_bwd_data_t(gy, post, w, gx, groups)
+      gx += sphere_conv_bwd_data_t(gy, post, w, torch.empty_like(gx), groups)
+      return gx
     use_t = (SPHERE_BWD_DATA_T and overwrite and gy_transposed is not None and (sH, sW) == (1, 1) and (Ho, Wo) == (H, W) and
              tuple(gy_transposed.shape) == (B, Co, Wo, Ho))
     with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
@@ -503,6 +539,10 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy
     plan = sphere_plan(pos, Kh, Kw)
     if plan is not None and plan[1][0] == 0:
       plan = None  # no compact tile at all: nothing to gain
+    if plan is None:
+      post = sphere_native_t(pos, Kh, Kw)
+      if post is not None:  # ERP-like table
+        return sphere_conv_bwd_weight_t(gy, post, x, gw, groups)
   with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_weight', gw, x), nbytes, flops, gy.device):
     if plan is not None:
       tiles, (n0, n1, n2), rest, nrest, rec_w, rec_off, polar = plan
@@ -542,7 +582,7 @@ def sphere_t_supported(pos, w, B, groups):
   if w.shape[2] * w.shape[3] != 9:
     return False
   plan = sphere_plan(pos, w.shape[2], w.shape[3])
-  if plan is None or plan[1][0] == 0 or (plan[3] and not (plan[6] is not None and SPHERE_POLAR)):
+  if not _plan_usable(plan):
     return False
   return sum(plan[1]) * B * groups * (-(-(w.shape[0] // groups) // 128)) >= SPHERE_FWD_MIN_WG
 
@@ -1379,6 +1419,10 @@ def sphere_conv_bn_eval(x, pos, w, bn, stride, groups, add=None, relu=False, tra
         plan = None
   if transposed and plan is None:
     raise RuntimeError('sphere_conv_bn_eval: plane-transposed storage needs a plannable sampling table')
+  if not transposed and not _plan_usable(plan) and tuple(stride) == (1, 1) and Kh * Kw == 9:
+    post = sphere_native_t(pos, Kh, Kw)
+    if post is not None and sphere_t_supported(post, w, B, groups):  # ERP-like table: NCHW storage is its transposed storage
+      return sphere_conv_bn_eval(x, post, w, bn, stride, groups, add, relu, transposed=True)
   flops = 2 * B * Co * H * W // (stride[0] * stride[1]) * w[0].numel()
   name = 'sphere_conv_bn_eval[%d->%d %dx%d]' % (Ci, Co, H, W) if profiling.ENABLED else 'sphere_conv_bn_eval'
   with torch.cuda.device_of(x), profiling.region(name, 4 * (2 * x.numel() + w.numel()), flops, x.device):

@@ -93,7 +93,8 @@ def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad
   pos = position.contiguous()
   # one plane-transposed copy of grad_output serves both gradients (windowed weight gradient, transposed adjoint gather)
   gyt = None
-  if _F.SPHERE_LAYOUT == 'transposed' and (stride_h, stride_w) == (1, 1) and kernel_h * kernel_w == 9 and gy.shape[2:] == input.shape[2:]:
+  if ((stride_h, stride_w) == (1, 1) and gy.shape[2:] == input.shape[2:] and
+      _F.sphere_uses_transposed_copies(pos, kernel_h, kernel_w)):  # (Cassini-like tables; an ERP table runs on the NCHW tensors as they are)
     gyt = _F.transpose_planes(gy)
   _F.sphere_conv_bwd_data(gy, pos, weight.contiguous(), grad_input, (stride_h, stride_w), group, overwrite=overwrite_grad_input,
                           gy_transposed=gyt)

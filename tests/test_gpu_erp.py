@@ -1,0 +1,174 @@
+"""GPU (-m gpu): sphereType = 'ERP' on the fast path.
+
+The reference's single kernel serves 'ERP' and 'Cassini' alike (sphere_conv.py:123, 226-236; sphere_conv_cuda_kernel.cu:195-262).
+Here the windowed / split kernels want the table's shift-invariant (longitude) axis along the lanes and contiguous in memory: for
+Cassini that needs plane-transposed copies, for ERP the NCHW tensors ARE that storage -- the ERP problem is the Cassini problem of the
+transposed table (mode_hip.functional.sphere_native_t), so the same kernels run with no transpose at all.  Checked here: the fast
+path is taken at the benchmark's quarter-resolution shape (128 x 256), its results against the float64 oracle (forward, input
+gradient, weight gradient), bit-equality with the Cassini operator on transposed tensors, its time against the Cassini operator's,
+a whole ModeDisparity(..., 'ERP') against the CPU oracle, and a full-size 512 x 1024 ERP training step."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import mode_ref, sphere_conv_ref
+
+import models
+import mode_hip
+from mode_hip import functional as HF
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(shape, seed, scale=1.0):
+  return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _time_ms(fn, n=10):
+  fn()
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(n):
+    fn()
+  b.record()
+  torch.cuda.synchronize()
+  return a.elapsed_time(b) / n
+
+
+def test_erp_operator_at_the_benchmark_shape_against_the_float64_oracle(arith):
+  """128 -> 128 channels on the ERP grid 128 x 256 (the quarter-resolution maps of a 512 x 1024 ERP pair), 2 images."""
+  mode_hip.lib()
+  B, C, H, W = 2, 128, 128, 256
+  pos = mode_ref.sphere_position(H, W, 'ERP').contiguous()
+  pd = pos.to(DEV)
+  post = HF.sphere_native_t(pd, 3, 3)
+  assert HF.sphere_plan(pd, 3, 3) is None and post is not None, 'the ERP table runs through its transposed plan'
+  assert HF.sphere_t_supported(post, torch.empty(C, C, 3, 3), B, 1), 'and the windowed forward is taken at this size'
+  x, w, gy = _rand((B, C, H, W), 1), _rand((C, C, 3, 3), 2, (2.0 / (9 * C))**0.5), _rand((B, C, H, W), 3)
+  cfg = ((1, 1), (1, 1), (1, 1), 1)
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  y_ref = sphere_conv_ref.forward(x.double(), pos, w.double(), *cfg)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x.double(), pos, w.double(), gy.double(), *cfg)
+  xd, wd, gyd = x.to(DEV), w.to(DEV), gy.to(DEV)
+  y = torch.full((B, C, H, W), float('nan'), device=DEV)
+  HF.sphere_conv_fwd(xd, pd, wd, y, (1, 1), 1)
+  gx = torch.full((B, C, H, W), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, gx, (1, 1), 1, overwrite=True)
+  gw = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (1, 1), 1)
+  e_y = float((y.cpu().double() - y_ref).abs().max())
+  e_gx = float((gx.cpu().double() - gx_ref).abs().max())
+  e_gw = float((gw.cpu().double() - gw_ref).abs().max())
+  print('ERP 128x256 128->128 [%s]: max error fwd %.2e  bwd-data %.2e  bwd-weight %.2e (|gw| <= %.3g)' %
+        (arith, e_y, e_gx, e_gw, float(gw_ref.abs().max())))
+  assert e_y < 2e-6 * (C * 9) * max(1.0, float(y_ref.abs().max()))
+  assert e_gx < 2e-6 * (C * 9) * max(1.0, float(gx_ref.abs().max()))
+  assert e_gw < 1e-5 * max(1.0, float(gw_ref.abs().max()))
+  # accumulate semantics of the reference seam (sphere_conv.py:62-64)
+  gx2 = torch.ones_like(gx)
+  HF.sphere_conv_bwd_data(gyd, pd, wd, gx2, (1, 1), 1, overwrite=False)
+  assert float((gx2 - 1 - gx).abs().max()) < 1e-5 * max(1.0, float(gx.abs().max()))
+
+  # the same numbers, bit for bit, as the Cassini operator on the transposed tensors (one set of kernels, one summation order)
+  pos_c = mode_ref.sphere_position(H, W, 'Cassini').contiguous().to(DEV)  # (1, 18, 256, 128)
+  assert torch.equal(post, pos_c)
+  xc, gyc = xd.transpose(2, 3).contiguous(), gyd.transpose(2, 3).contiguous()
+  yc = torch.empty((B, C, W, H), device=DEV)
+  HF.sphere_conv_fwd(xc, pos_c, wd, yc, (1, 1), 1)
+  assert torch.equal(yc.transpose(2, 3), y)
+  gxc = torch.empty_like(xc)
+  HF.sphere_conv_bwd_data(gyc, pos_c, wd, gxc, (1, 1), 1, overwrite=True, gy_transposed=HF.transpose_planes(gyc))
+  assert torch.equal(gxc.transpose(2, 3), gx)
+  gwc = torch.zeros_like(wd)
+  HF.sphere_conv_bwd_weight(gyc, pos_c, xc, gwc, (1, 1), 1)
+  assert torch.equal(gwc, gw)
+
+  # time: the ERP operator needs no transposes, so it must not be slower than the Cassini operator (bound: within 10 %)
+  t = {}
+  for name, fn_e, fn_c in (
+      ('fwd', lambda: HF.sphere_conv_fwd(xd, pd, wd, y, (1, 1), 1), lambda: HF.sphere_conv_fwd(xc, pos_c, wd, yc, (1, 1), 1)),
+      ('bwd_data', lambda: HF.sphere_conv_bwd_data(gyd, pd, wd, gx, (1, 1), 1, overwrite=True),
+       lambda: HF.sphere_conv_bwd_data(gyc, pos_c, wd, gxc, (1, 1), 1, overwrite=True, gy_transposed=HF.transpose_planes(gyc))),
+      ('bwd_weight', lambda: HF.sphere_conv_bwd_weight(gyd, pd, xd, gw, (1, 1), 1), lambda: HF.sphere_conv_bwd_weight(gyc, pos_c, xc, gwc, (1, 1), 1))):
+    t[name] = (_time_ms(fn_e), _time_ms(fn_c))
+  print('ERP vs Cassini operator, ms per call (128->128, 2 images): ' + ', '.join('%s %.3f / %.3f' % (k, a, b) for k, (a, b) in t.items()))
+  for k, (a, b) in t.items():
+    assert a <= 1.10 * b + 0.01, (k, a, b)
+
+
+def test_erp_model_against_the_cpu_oracle(arith):
+  """ModeDisparity(32, 'Sphere', 64, 128, 'ERP'), train mode, batch 2, on the well-conditioned recipe state: outputs to the
+  north_star's 1e-3 px against the CPU oracle with the ERP table, loss and parameter gradients like the parity tier."""
+  maxdisp, H, W, B = 32, 64, 128, 2
+  sd = recipe.recipe_state_wc(recipe.load_manifest(), 321)
+  left, right = recipe.recipe_images(B, H, W, 322, shift=4)
+  gt = recipe.recipe_disparity_smooth(B, H, W, 323, maxdisp)
+  net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'ERP').to(DEV)
+  net.load_state_dict(sd)
+  net.train()
+  preds = net(left.to(DEV), right.to(DEV))
+  loss = mode_ref.training_loss(preds, gt.to(DEV), ~torch.isnan(gt).to(DEV))
+  loss.backward()
+  P = {k: v.clone() for k, v in sd.items()}
+  for k, v in P.items():
+    if v.is_floating_point() and 'running' not in k:
+      v.requires_grad_(True)
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'ERP')
+  ref = mode_ref.mode_disparity(P, left, right, maxdisp, pos, True)
+  ref_loss = mode_ref.training_loss(ref, gt, ~torch.isnan(gt))
+  ref_loss.backward()
+  err = max(float((a.detach().cpu() - b.detach()).abs().max()) for a, b in zip(preds, ref))
+  num = den = 0.0
+  for k, p in net.named_parameters():
+    num += float((p.grad.detach().cpu().double() - P[k].grad.double()).pow(2).sum())
+    den += float(P[k].grad.double().pow(2).sum())
+  rel = (num / den)**0.5
+  print('ERP model 64x128/32 [%s]: max |disp - oracle| %.2e px, loss %.6f vs %.6f, relative L2 error of the whole gradient %.2e' %
+        (arith, err, float(loss), float(ref_loss), rel))
+  assert err <= 1e-3
+  assert abs(float(loss) - float(ref_loss)) <= 2e-5 * float(ref_loss)
+  assert rel <= 1e-3
+
+
+def test_erp_training_step_at_512x1024():
+  """The benchmark's workload in the ERP orientation (BASELINE's metric is worded in ERP terms): one pair 512 x 1024, 192
+  disparities, forward + backward; the spherical layers run on the windowed / split kernels (no general gather kernel for them), the
+  extractor's output equals the Cassini extractor's on the transposed image (same spherical weights, regular kernels transposed),
+  and the step takes about as long as the Cassini step."""
+  maxdisp, H, W = 192, 512, 1024
+  torch.manual_seed(5)
+  net_e = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'ERP').to(DEV).train()
+  net_c = models.ModeDisparity(maxdisp, 'Sphere', W, H, 'Cassini').to(DEV).train()
+  sd = net_e.state_dict()
+  sd_c = {k: (v.transpose(2, 3).contiguous() if (k.startswith('feature_extraction') and v.dim() == 4 and 'layer4' not in k) else v.clone())
+          for k, v in sd.items()}
+  # layer4: SphereConv weights are indexed by the tap's direction on the sphere -- the same in both layouts; its 1x1 downsample too
+  net_c.load_state_dict(sd_c)
+  left = torch.randn(1, 3, H, W, device=DEV)
+  right = torch.roll(left, -5, 3) + 0.01 * torch.randn_like(left)
+  pos = net_e.feature_extraction.layer4[0].conv1[0][0].position_on(torch.device(DEV))
+  assert HF.sphere_native_t(pos, 3, 3) is not None
+  with torch.no_grad():
+    fe = net_e.feature_extraction(left)
+    fc = net_c.feature_extraction(left.transpose(2, 3).contiguous())
+  d = float((fe - fc.transpose(2, 3)).abs().max())
+  print('ERP extractor vs Cassini extractor on the transposed image: max |diff| %.2e (|f| <= %.3g)' % (d, float(fe.abs().max())))
+  assert d <= 5e-4 * max(1.0, float(fe.abs().max()))
+
+  def step(net, l, r):
+    net.zero_grad(set_to_none=True)
+    loss = sum(p.mean() for p in net(l, r))
+    loss.backward()
+    return loss
+
+  loss = step(net_e, left, right)
+  assert torch.isfinite(loss)
+  assert all(torch.isfinite(p.grad).all() for p in net_e.parameters())
+  lc, rc = left.transpose(2, 3).contiguous(), right.transpose(2, 3).contiguous()
+  t_e = _time_ms(lambda: step(net_e, left, right), 3)
+  t_c = _time_ms(lambda: step(net_c, lc, rc), 3)
+  print('training step, one pair, eager: ERP 512x1024 %.1f ms, Cassini 1024x512 %.1f ms' % (t_e, t_c))
+  assert t_e <= 1.10 * t_c

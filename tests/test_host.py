@@ -276,3 +276,19 @@ def test_bench_labels_on_the_split_path():
   assert bench._on_split_path('conv2d_bwd_weight[20->40 d1 26x70]') and not bench._on_split_path('conv2d_fwd[20->40 d1 26x70]')
   assert not bench._on_split_path('sphere_conv_bwd_weight[128->128 256x128]')
   assert abs(bench.MFMA_BF16_PEAK_TFLOPS / 6.0 - 416.67) < 0.01
+
+
+def test_erp_tables_are_planned_through_their_transpose():
+  """sphereType='ERP' on the windowed kernels (host logic only): an ERP table is not plannable as it stands (its shift-invariant
+  axis is W), its transpose is the Cassini table bit for bit (sphere_conv.py:226-236) and gets the Cassini plan -- so the ERP
+  operator runs the `_t` kernels on the NCHW tensors themselves (mode_hip.functional.sphere_native_t)."""
+  from mode_hip import functional as HF
+  from oracle import mode_ref
+  for h, w in ((128, 256), (256, 512)):  # the quarter-resolution maps of 512 x 1024 and 1024 x 2048 ERP pairs
+    erp = mode_ref.sphere_position(h, w, 'ERP').contiguous()
+    cas = mode_ref.sphere_position(h, w, 'Cassini').contiguous()
+    assert HF.sphere_plan(erp, 3, 3) is None
+    post = HF.sphere_native_t(erp, 3, 3)
+    assert post is not None and torch.equal(post, cas)
+    assert HF.sphere_plan(post, 3, 3)[1] == HF.sphere_plan(cas, 3, 3)[1]
+    assert HF.sphere_native_t(cas, 3, 3) is None and HF.sphere_uses_transposed_copies(cas, 3, 3) and not HF.sphere_uses_transposed_copies(erp, 3, 3)
