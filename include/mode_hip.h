@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 12 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 13 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -111,6 +111,34 @@ int mode_sphere_adjoint_build(const float* pos_host, int H, int W, int Kh, int K
 int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
                                   const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
                                   int Ho, int Wo, int groups, int accumulate, mode_stream_t stream);
+
+/* The gather form restricted to a LIST of 64-pixel tiles of gx (tile t = linear pixels 64 t .. 64 t + 63 of the H x W image as it is
+ * stored; n_list tiles per sample; 3x3 kernels): everything outside the list is left untouched. */
+int mode_sphere_conv_bwd_data_adj_list(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                                       const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                                       int Ho, int Wo, int groups, int accumulate, const int32_t* tile_list, int n_list,
+                                       mode_stream_t stream);
+
+/* Windowed input gradient on the split-bf16 matrix path (csrc/sphere_conv_win.hip; replaces the col2im scatter of
+ * sphere_conv_cuda_kernel.cu:293-356 + the GEMM of sphere_conv_cuda.cpp:275-315 for stride 1, 3x3 taps, output grid = input grid).
+ * Host planning, once per table: mode_sphere_adjplan_build(pos_host, H, W, Kh, Kw, good_tiles[4 n], bad_tiles[2 n], counts[2],
+ *   rec_off_host[n * 9 * 256 * 4], rec_w_host[same]) with n = mode_sphere_plan_max_tiles(H, W): for every 64 x 4 tile of INPUT pixels
+ *   whose adjoint lists all have <= 4 entries inside one 81-row x 8-column window of gy it writes (h0, w0, rbase, cbase) and, per
+ *   (tile, tap, pixel), 4 (window offset, weight) slots; the other tiles go to bad_tiles as (h0, w0).  counts = (good, bad).
+ * mode_sphere_conv_bwd_data_win_split WRITES gx on the good tiles (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per
+ *   product, fp32 accumulation); the caller runs mode_sphere_conv_bwd_data_adj_list (accumulate = 0) on the bad ones.  `transposed`: gy
+ *   and gx are plane-transposed (B, C, W, H).  Needs mode_sphere_conv_bwd_data_win_supported(Ci, Co, groups) == 1 (output channels per
+ *   group a multiple of 16); `wpack` >= mode_sphere_conv_bwd_data_win_wpack_bytes(). */
+int mode_sphere_adjplan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* good_tiles, int32_t* bad_tiles,
+                              int32_t* counts, int32_t* rec_off_host, float* rec_w_host);
+
+size_t mode_sphere_conv_bwd_data_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups);
+
+int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int groups);
+
+int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles, int n_tiles,
+                                        const int32_t* rec_off, const float* rec_w, int B, int Ci, int H, int W, int Co, int Kh,
+                                        int Kw, int groups, int transposed, mode_stream_t stream);
 
 /* Windowed forward (csrc/sphere_conv_win.hip): same result as mode_sphere_conv_fwd for stride 1 and 3x3 taps, ~2x faster on
  * tables whose samples are spatially compact (the gnomonic tables of the network).  The caller plans the table once on the HOST:

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj_kernel(const flo
 __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const float* __restrict__ gy, const int* __restrict__ rowptr,
                                                                          const int2* __restrict__ entries,
                                                                          const float4* __restrict__ wp, float* __restrict__ gx, Dims d,
-                                                                         int MTc, int NCHo, int qtiles) {
+                                                                         int MTc, int NCHo, int qtiles, const int* __restrict__ tile_list) {
   constexpr int KT = 9, EC = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int4* ent_p = reinterpret_cast<int4*>(smem);                          // [KT][P] output pixels of the first 4 entries
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring pixel tiles (overlapping gather footprints) on one XCD
   const int b = tile / qtiles;
-  const int q0 = (tile - b * qtiles) * P;
+  // tile_list: only the listed 64-pixel tiles (qtiles of them per sample) -- the rest of the image belongs to the windowed kernel
+  const int q0 = (tile_list ? tile_list[tile - b * qtiles] : tile - b * qtiles) * P;
   const int g = blockIdx.z;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -1052,9 +1053,32 @@ extern "C" int mode_sphere_adjoint_build(const float* pos_host, int H, int W, in
   return MODE_OK;
 }
 
+static int bwd_data_adj_impl(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                             const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int Ho, int Wo, int groups,
+                             int accumulate, const int32_t* tile_list, int n_list, mode_stream_t stream);
+
 extern "C" int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
                                              const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
                                              int Ho, int Wo, int groups, int accumulate, mode_stream_t stream) {
+  return bwd_data_adj_impl(gy, w, gx, wpack, adj_rowptr, adj_entries, B, Ci, H, W, Co, Kh, Kw, Ho, Wo, groups, accumulate, nullptr, 0, stream);
+}
+
+// The same on a LIST of 64-pixel tiles (tile t = linear input pixels 64 t .. 64 t + 63 of the H x W image as stored): the input-gradient
+// tiles the windowed split kernel does not take (mode_sphere_adjplan_build).  3x3 kernels only.
+extern "C" int mode_sphere_conv_bwd_data_adj_list(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                                                  const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                                                  int Ho, int Wo, int groups, int accumulate, const int32_t* tile_list, int n_list,
+                                                  mode_stream_t stream) {
+  MODE_REQUIRE(Kh * Kw == 9, MODE_ERR_UNSUPPORTED, "mode_sphere_conv_bwd_data_adj_list: 3x3 kernels only");
+  MODE_REQUIRE(n_list >= 0 && (n_list == 0 || tile_list), MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_data_adj_list: bad tile list");
+  if (n_list == 0) return MODE_OK;
+  return bwd_data_adj_impl(gy, w, gx, wpack, adj_rowptr, adj_entries, B, Ci, H, W, Co, Kh, Kw, Ho, Wo, groups, accumulate, tile_list, n_list,
+                           stream);
+}
+
+static int bwd_data_adj_impl(const float* gy, const float* w, float* gx, float* wpack, const int32_t* adj_rowptr,
+                             const int32_t* adj_entries, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int Ho, int Wo, int groups,
+                             int accumulate, const int32_t* tile_list, int n_list, mode_stream_t stream) {
   Dims d;
   int rc = make_dims(d, B, Ci, H, W, Co, Kh, Kw, 1, 1, Ho, Wo, groups, "mode_sphere_conv_bwd_data_adj");
   if (rc != MODE_OK) return rc;
@@ -1066,14 +1090,14 @@ extern "C" int mode_sphere_conv_bwd_data_adj(const float* gy, const float* w, fl
   const int NCHo = mode::cdiv(d.Cog, CCH);
   const long long npack = (long long)d.G * MTc * NCHo * d.KK * 256;
   hipLaunchKernelGGL(pack_w_adj, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, MTc, NCHo);
-  const int qtiles = mode::cdiv((long long)H * W, P);
+  const int qtiles = tile_list ? n_list : mode::cdiv((long long)H * W, P);
   const dim3 grid(B * qtiles, mode::cdiv(MTc, 4), d.G);
   if (d.KK == 9) {
     const size_t lds = (size_t)9 * P * 40 + 2 * (size_t)CCH * 9 * P * 4;
     rc = mode::allow_lds(sphere_bwd_data_adj9_kernel, lds, "mode_sphere_conv_bwd_data_adj");
     if (rc != MODE_OK) return rc;
     hipLaunchKernelGGL(sphere_bwd_data_adj9_kernel, grid, dim3(NTHREADS), lds, st, gy, adj_rowptr,
-                       reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles);
+                       reinterpret_cast<const int2*>(adj_entries), reinterpret_cast<const float4*>(wpack), gx, d, MTc, NCHo, qtiles, tile_list);
   } else {
     const size_t lds = (size_t)d.KK * P * 8 + 2 * (size_t)CCH * d.KK * P * 4;
     rc = mode::allow_lds(sphere_bwd_data_adj_kernel, lds, "mode_sphere_conv_bwd_data_adj");

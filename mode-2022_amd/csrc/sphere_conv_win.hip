@@ -1526,3 +1526,388 @@ extern "C" int mode_transpose_planes(const float* in, float* out, long long plan
   }
   return mode::check_launch("mode_transpose_planes");
 }
+
+// =====================================================================================================================
+// Input gradient on the split-bf16 matrix path: the ADJOINT of the sampling as a windowed gather.
+//
+//   gx[c][q] = sum_{k, o} W[o][c][k] * G_k[o][q],     G_k[o][q] = sum_{(p, wt) in L(k, q)} wt * gy[o][p]
+//
+// L(k, q) = the output pixels whose tap k touches input pixel q (the transpose of the sampling table; cu:293-356 scatters the same
+// terms with atomics).  Away from the poles the table moves slowly, so L(k, q) has at most four entries and the sources of a 64 x 4
+// block of q fall into the same compact window of gy that the forward kernel stages of x.  The host plans every tile from the actual
+// table (mode_sphere_adjplan_build): tiles whose lists all have <= 4 entries inside an 81-row x 8-column window get records of
+// 4 (window offset, weight) slots per (pixel, tap) and run here -- the structure of sphere_fwd_split_kernel, with the sampling
+// record read from the plan instead of computed from the table: gy window of 16 channels in LDS (fp32, double-buffered), every wave
+// samples its 32 pixels for the next tap into an LDS operand buffer (exact 3-way bf16 split), one output-channel tile per wave for the
+// MFMAs.  All other tiles (next to the poles, and the few columns where a list has 5 or 6 entries) stay on the gather kernel of
+// sphere_conv.hip, restricted to a tile list (mode_sphere_conv_bwd_data_adj_list).
+namespace {
+
+constexpr int AJ_PIX = TH * TW;  // 256 pixels per tile = 8 waves x 32 lanes
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const float* __restrict__ gy, const uint4* __restrict__ wps,
+                                                                         float* __restrict__ gx, WinDims d /* roles swapped: Ci = gy channels */,
+                                                                         int NCH16, const int4* __restrict__ tiles,
+                                                                         const int4* __restrict__ rec_off, const float4* __restrict__ rec_w) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WRP = WR_SMALL, CP = SP_CP;
+  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
+  const int4 t = tiles[blockIdx.x];
+  const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w;
+  const int b = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+  const long long HW = (long long)d.H * d.W;
+
+  // records of the pixel this lane SAMPLES (column wave % 4, row block wave / 4, row lane & 31), one (int4, float4) per tap
+  const long long rbase_idx = (long long)blockIdx.x * KT * AJ_PIX + wave * 32 + (lane & 31);
+  const int4* rop = rec_off + rbase_idx;
+  const float4* rwp = rec_w + rbase_idx;
+  int4 ro[3];   // ring over taps k, k + 1, k + 2 (slot = tap % 3; nine taps keep the slots aligned across chunks)
+  float4 rw[3];
+  ro[0] = rop[0];
+  rw[0] = rwp[0];
+  ro[1] = rop[AJ_PIX];
+  rw[1] = rwp[AJ_PIX];
+
+  for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
+  __syncthreads();
+
+  // window staging exactly as in sphere_fwd_split_kernel
+  const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
+  const int gcol = cbase + scol;
+  const bool col_ok = gcol < d.W;
+  const float* xg = gy + ((long long)b * d.Ci + (long long)g * d.Cig) * HW;
+  unsigned rowoff[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int r = rb * SROWS + srow;
+    rowoff[rb] = 4u * (unsigned)(((rbase + (r < WRP ? r : 0)) % d.H) * d.sh + (col_ok ? gcol * d.sw : 0));
+  }
+  const long long plane_bytes = 4 * HW;
+  float lv[8][4];
+  auto issue = [&](int ch, int ph, int set) {
+    const char* xc = reinterpret_cast<const char*>(xg) + ((long long)ch * SP_CCH + ph * 2) * plane_bytes;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) lv[set][cc * 2 + rb] = *reinterpret_cast<const float*>(xc + cc * plane_bytes + rowoff[rb]);
+  };
+  auto commit = [&](int ch, int ph, int set, float* buf) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = ph * 2 + cc;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int r = rb * SROWS + srow;
+        float* dst = r < WRP ? buf + c * CP + scol * WRP + r : smem + 2 * SP_WIN + (tid & 7);
+        *dst = col_ok ? lv[set][cc * 2 + rb] : 0.f;
+      }
+    }
+  };
+  // B fragment of this lane's pixel for one tap: G_k[o][q] for 8 channels o, <= 4 sources each, split, stored as this wave's group
+  auto sample = [&](const float* win, const int4 o4, const float4 tw, uint4* op) {
+    const float* p = win + half * 8 * CP;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = p + c * CP;
+      v[c] = __builtin_fmaf(tw.w, q[o4.w], __builtin_fmaf(tw.z, q[o4.z], __builtin_fmaf(tw.y, q[o4.y], tw.x * q[o4.x])));
+      asm("" : "+v"(v[c]));  // (keeps the chains of two channels from being SLP-packed pairwise, see sphere_fwd_split_kernel)
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = op + (wave * 3) * 64 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[gi][r] = 0.f;
+  const int m = wave % TW, gset = (wave / TW) * 4;
+  const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;
+  const int nsteps = NCH16 * KT;
+  uint4 aring[3][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    aring[0][p] = wpa[(unsigned)(p * 64 + lane)];
+    aring[1][p] = (wpa + (long long)(nsteps > 1 ? 1 : 0) * MTW * 192)[(unsigned)(p * 64 + lane)];
+  }
+
+#pragma unroll
+  for (int ph = 0; ph < 8; ++ph) issue(0, ph, ph);
+#pragma unroll
+  for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
+  __syncthreads();
+  sample(smem, ro[0], rw[0], opbuf);
+  sp_lds_barrier();
+
+  for (int ch = 0; ch < NCH16; ++ch) {
+    float* cur = smem + (ch & 1) * SP_WIN;
+    float* nxt = smem + ((ch + 1) & 1) * SP_WIN;
+    const int chn = ch + 1 < NCH16 ? ch + 1 : ch;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int step = ch * KT + k;
+      const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
+      // records of tap k + 2 (the same nine for every chunk; L2-resident, shared by all samples and layers of the geometry)
+      ro[(k + 2) % 3] = rop[((k + 2) % KT) * AJ_PIX];
+      rw[(k + 2) % 3] = rwp[((k + 2) % KT) * AJ_PIX];
+      if (k < 4) {
+        issue(chn, 2 * k, 2 * k);
+        issue(chn, 2 * k + 1, 2 * k + 1);
+      }
+      const uint4* opr = opbuf + (step & 1) * SP_OP;
+      uint4* opw = opbuf + ((step + 1) & 1) * SP_OP;
+      uint4 bq[4][3];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
+      if (k + 1 < KT)
+        sample(cur, ro[(k + 1) % 3], rw[(k + 1) % 3], opw);
+      else
+        sample(nxt, ro[0], rw[0], opw);
+#define MODE_SP_TERM(PA, PB) \
+  _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
+      MODE_SP_TERM(2, 0)
+      MODE_SP_TERM(0, 2)
+      MODE_SP_TERM(1, 1)
+      MODE_SP_TERM(1, 0)
+      MODE_SP_TERM(0, 1)
+      MODE_SP_TERM(0, 0)
+#undef MODE_SP_TERM
+      if (k >= 4 && k < 8) {
+        commit(chn, 2 * (k - 4), 2 * (k - 4), nxt);
+        commit(chn, 2 * (k - 4) + 1, 2 * (k - 4) + 1, nxt);
+      }
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sp_lds_barrier();
+    }
+  }
+
+  // D[i = c][j = pixel of group gset + gi]: written (this kernel owns every element of its tiles)
+  const int hh = h0 + (wave / TW) * 32 + (lane & 31);
+  const int cmax = d.Cog - mg * 128;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int ww = w0 + gi;
+    if (hh < d.H && ww < d.W) {
+      float* yb = gx + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)hh * d.sh + (long long)ww * d.sw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < cmax) yb[(long long)co * HW] = acc[gi][r];
+      }
+    }
+  }
+}
+
+// wps[(((((g*MG + mg)*NCH16 + ch)*KT + tap)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[o = g*Cog' + ch*16 + 8*(lane>>5) + j]
+// [c = mg*128 + m*32 + (lane&31)][tap] -- the transposed weight: rows of this GEMM are the INPUT channels c of the layer, its reduction
+// runs over the output channels o.  `d` carries the swapped roles (d.Cog = input channels per group, d.Cig = output channels per group).
+__global__ void pack_w_win_split_t(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16) {
+  const long long total = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int m = (int)(r % MTW);
+    r /= MTW;
+    const int tap = (int)(r % KT);
+    r /= KT;
+    const int ch = (int)(r % NCH16);
+    r /= NCH16;
+    const int mg = (int)(r % d.MG);
+    const int g = (int)(r / d.MG);
+    const int c = mg * 128 + m * 32 + (lane & 31);  // row of the GEMM = input channel of the layer (within the group)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = ch * SP_CCH + 8 * (lane >> 5) + j;  // reduction index = output channel of the layer (within the group)
+      v[j] = (c < d.Cog && o < d.Cig) ? w[((long long)(g * d.Cig + o) * d.Cog + c) * KT + tap] : 0.f;
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wps + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+}  // namespace
+
+// Host-side plan of the adjoint windows (stride 1, output grid = input grid).  For every 64 x 4 tile of INPUT pixels q (same tiling as
+// mode_sphere_plan_build) it collects L(k, q) for all nine taps and all pixels of the tile.  A tile is "good" when every list has at
+// most 4 entries and all their source pixels lie in one window of WR_SMALL rows x WC columns:
+//   good_tiles[4 i ..] = (h0, w0, rbase, cbase);   rec_off / rec_w [((i * 9 + tap) * 256 + pixel) * 4 + slot], pixel =
+//   ((rowblock * 4 + column) * 32 + row) -- the lane order of the kernel; offset = (source column - cbase) * WR_SMALL + (source row -
+//   rbase) mod H, unused slots (0, 0.0f); slots in ascending source-pixel order (the gather kernel's summation order).
+//   bad_tiles[2 j ..] = (h0, w0) of the others.  counts = (good, bad).
+extern "C" int mode_sphere_adjplan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* good_tiles, int32_t* bad_tiles,
+                                         int32_t* counts, int32_t* rec_off_host, float* rec_w_host) {
+  MODE_REQUIRE(pos_host && good_tiles && bad_tiles && counts && rec_off_host && rec_w_host, MODE_ERR_BAD_ARG,
+               "mode_sphere_adjplan_build: null pointer");
+  MODE_REQUIRE(H > 0 && W > 0 && Kh * Kw == KT, MODE_ERR_BAD_ARG, "mode_sphere_adjplan_build: needs a positive size and %d taps", KT);
+  const long long HW = (long long)H * W;
+  MODE_REQUIRE((long long)KT * HW * 4 < (1ll << 31), MODE_ERR_UNSUPPORTED, "mode_sphere_adjplan_build: table too large");
+  // adjoint lists in CSR form, rows (tap, q), filled in ascending p (the order of mode_sphere_adjoint_build)
+  std::vector<int32_t> rowptr((size_t)KT * HW + 1, 0);
+  auto corners = [&](int k, long long p, int qs[4], float ws[4]) -> int {
+    const float h = pos_host[(long long)(2 * k) * HW + p], w = pos_host[(long long)(2 * k + 1) * HW + p];
+    if (!(h > -1.f && w > -1.f && h < (float)H && w < (float)W)) return 0;
+    const float hf = floorf(h), wf = floorf(w);
+    const int hl = (int)hf, wl = (int)wf, hh = hl + 1, wh = wl + 1;
+    const float lh = h - hf, lw = w - wf, uh = 1.f - lh, uw = 1.f - lw;
+    const float wt[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+    const int hc[4] = {hl, hl, hh, hh}, wc[4] = {wl, wh, wl, wh};
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+      if (hc[i] >= 0 && hc[i] <= H - 1 && wc[i] >= 0 && wc[i] <= W - 1 && wt[i] != 0.f) {
+        qs[n] = hc[i] * W + wc[i];
+        ws[n] = wt[i];
+        ++n;
+      }
+    return n;
+  };
+  int qs[4];
+  float ws[4];
+  for (int k = 0; k < KT; ++k)
+    for (long long p = 0; p < HW; ++p) {
+      const int n = corners(k, p, qs, ws);
+      for (int i = 0; i < n; ++i) rowptr[(size_t)k * HW + qs[i] + 1]++;
+    }
+  for (size_t i = 0; i < (size_t)KT * HW; ++i) rowptr[i + 1] += rowptr[i];
+  std::vector<int32_t> ep(rowptr.back());
+  std::vector<float> ew(rowptr.back());
+  {
+    std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
+    for (int k = 0; k < KT; ++k)
+      for (long long p = 0; p < HW; ++p) {
+        const int n = corners(k, p, qs, ws);
+        for (int i = 0; i < n; ++i) {
+          const int32_t at = cur[(size_t)k * HW + qs[i]]++;
+          ep[at] = (int32_t)p;
+          ew[at] = ws[i];
+        }
+      }
+  }
+  const int nth = mode::cdiv(H, TH), ntw = mode::cdiv(W, TW);
+  int ngood = 0, nbad = 0;
+  for (int hg = 0; hg < nth; hg += kNumXCD)  // tile order as in mode_sphere_plan_build (tiles sharing rows meet on one XCD)
+    for (int tw = 0; tw < ntw; ++tw)
+      for (int hs = 0; hs < kNumXCD && hg + hs < nth; ++hs) {
+        const int h0 = (hg + hs) * TH, w0 = tw * TW;
+        bool ok = h0 + TH <= H && w0 + TW <= W;  // whole tiles only: ragged edges stay on the gather kernel
+        int dmin = 1 << 30, dmax = -(1 << 30), cmin = 1 << 30, cmax = -(1 << 30);
+        for (int k = 0; k < KT && ok; ++k)
+          for (int h = h0; h < h0 + TH && ok; ++h)
+            for (int w = w0; w < w0 + TW; ++w) {
+              const size_t row = (size_t)k * HW + (size_t)h * W + w;
+              if (rowptr[row + 1] - rowptr[row] > 4) {
+                ok = false;
+                break;
+              }
+              for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+                const int hp = ep[e] / W, wp = ep[e] % W;
+                int dr = (hp - h0) % H;
+                if (dr > H / 2) dr -= H;
+                if (dr <= -(H + 1) / 2) dr += H;
+                dmin = std::min(dmin, dr);
+                dmax = std::max(dmax, dr);
+                cmin = std::min(cmin, wp);
+                cmax = std::max(cmax, wp);
+              }
+            }
+        int rbase = h0, cbase = std::min(w0, std::max(W - WC, 0));
+        if (ok && dmax >= dmin) {
+          if (dmax - dmin + 1 > WR_SMALL || cmax - cmin + 1 > WC || cmin >= (1 << 16)) ok = false;
+          rbase = ((h0 + dmin) % H + H) % H;
+          cbase = cmin;
+        }
+        if (!ok) {
+          bad_tiles[2 * nbad] = h0;
+          bad_tiles[2 * nbad + 1] = w0;
+          ++nbad;
+          continue;
+        }
+        int32_t* tl = good_tiles + 4 * (size_t)ngood;
+        tl[0] = h0; tl[1] = w0; tl[2] = rbase; tl[3] = cbase;
+        for (int k = 0; k < KT; ++k)
+          for (int pix = 0; pix < AJ_PIX; ++pix) {
+            const int wv = pix >> 5, h = h0 + (wv / TW) * 32 + (pix & 31), w = w0 + (wv % TW);
+            const size_t row = (size_t)k * HW + (size_t)h * W + w;
+            const size_t o = (((size_t)ngood * KT + k) * AJ_PIX + pix) * 4;
+            for (int s = 0; s < 4; ++s) {
+              rec_off_host[o + s] = 0;
+              rec_w_host[o + s] = 0.f;
+            }
+            int s = 0;
+            for (int e = rowptr[row]; e < rowptr[row + 1]; ++e, ++s) {
+              const int hp = ep[e] / W, wp = ep[e] % W;
+              rec_off_host[o + s] = (wp - cbase) * WR_SMALL + ((hp - rbase) % H + H) % H;
+              rec_w_host[o + s] = ew[e];
+            }
+          }
+        ++ngood;
+      }
+  counts[0] = ngood;
+  counts[1] = nbad;
+  return MODE_OK;
+}
+
+extern "C" size_t mode_sphere_conv_bwd_data_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups) {
+  if (Ci <= 0 || Co <= 0 || groups <= 0 || Kh * Kw != KT || Ci % groups || Co % groups) return 0;
+  const int Cig = Ci / groups, Cog = Co / groups;
+  return (size_t)groups * mode::cdiv(Cig, 128) * mode::cdiv(Cog, SP_CCH) * KT * MTW * 3 * 64 * sizeof(uint4);
+}
+
+// 1 if the split kernel takes this layer: the reduction runs over the output channels of the layer in chunks of 16.
+extern "C" int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int groups) {
+  return (Ci > 0 && Co > 0 && groups > 0 && Ci % groups == 0 && Co % groups == 0 && (Co / groups) % SP_CCH == 0) ? 1 : 0;
+}
+
+// gx (written, not added to) on the n_tiles good tiles of the adjoint plan; `transposed`: gy and gx are plane-transposed (B, C, W, H).
+// The caller runs mode_sphere_conv_bwd_data_adj_list on the plan's bad tiles.
+extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles,
+                                                   int n_tiles, const int32_t* rec_off, const float* rec_w, int B, int Ci, int H, int W,
+                                                   int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  const char* who = "mode_sphere_conv_bwd_data_win_split";
+  WinDims d;
+  int rc = make_win_dims(d, B, Co, H, W, Ci, Kh, Kw, groups, who);  // roles swapped: this GEMM reduces over the layer's output channels
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(mode_sphere_conv_bwd_data_win_supported(Ci, Co, groups) == 1, MODE_ERR_UNSUPPORTED,
+               "%s: the output channels per group (%d) must be a multiple of %d", who, Co / std::max(groups, 1), SP_CCH);
+  MODE_REQUIRE(n_tiles >= 0 && (size_t)n_tiles <= mode_sphere_plan_max_tiles(H, W), MODE_ERR_BAD_ARG, "%s: bad tile count %d", who, n_tiles);
+  if (transposed) {
+    d.sh = 1;
+    d.sw = H;
+  }
+  if (B == 0 || n_tiles == 0) return MODE_OK;
+  MODE_REQUIRE(gy && w && gx && wpack && tiles && rec_off && rec_w, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "%s: grid limit", who);
+  hipStream_t st = mode::as_stream(stream);
+  const int NCH16 = d.Cig / SP_CCH;
+  uint4* wps = reinterpret_cast<uint4*>(wpack);
+  const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
+  hipLaunchKernelGGL(pack_w_win_split_t, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16);
+  rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP_LDS_BYTES, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP_LDS_BYTES, st, gy, wps, gx, d, NCH16,
+                     reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w));
+  return mode::check_launch(who);
+}

@@ -499,18 +499,16 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_tra
       return gx
     use_t = (SPHERE_BWD_DATA_T and overwrite and gy_transposed is not None and (sH, sW) == (1, 1) and (Ho, Wo) == (H, W) and
              tuple(gy_transposed.shape) == (B, Co, Wo, Ho))
+    if use_t:  # the operator on the plane-transposed problem (windowed split kernel where the adjoint plan allows), then back
+      gxt = sphere_conv_bwd_data_t(gy_transposed, pos, w, torch.empty((B, Ci, W, H), dtype=gx.dtype, device=gx.device), groups)
+      with torch.cuda.device_of(gy):
+        transpose_planes(gxt, gx)
+      return gx
     with torch.cuda.device_of(gy), profiling.region(_tag2('sphere_conv_bwd_data', w, gx), nbytes, flops, gy.device):
       wp = _wpack(w, groups)
-      if use_t:
-        rowptr, entries, _ = sphere_adjoint(_transposed_table(pos), Kh, Kw, stride, (Wo, Ho))
-        gxt = torch.empty((B, Ci, W, H), dtype=gx.dtype, device=gx.device)
-        check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy_transposed), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W,
-                                                  H, Co, Kh, Kw, Wo, Ho, G, 0, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
-        transpose_planes(gxt, gx)
-      else:
-        rowptr, entries, _ = sphere_adjoint(pos, Kh, Kw, stride, gy.shape[2:])
-        check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
-                                                  Kw, Ho, Wo, G, 0 if overwrite else 1, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
+      rowptr, entries, _ = sphere_adjoint(pos, Kh, Kw, stride, gy.shape[2:])
+      check(lib().mode_sphere_conv_bwd_data_adj(ptr(gy), ptr(w), ptr(gx), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, H, W, Co, Kh,
+                                                Kw, Ho, Wo, G, 0 if overwrite else 1, stream_of(gy)), 'mode_sphere_conv_bwd_data_adj')
     return gx
   if overwrite:
     gx.zero_()  # the scatter form adds with atomics
@@ -603,6 +601,45 @@ def sphere_conv_fwd_t(xt, pos, w, yt, groups):
   return yt
 
 
+_adjplan_cache = _LRU(TABLE_CACHE_ENTRIES)
+SPHERE_BWD_DATA_SPLIT = True  # windowed adjoint on the split-bf16 kernel where the plan allows (CONV_ARITH 'bf16x6' only)
+SPHERE_BWD_SPLIT_MIN_WG = 200  # fewer 64 x 4 tiles x samples than this: the 64-pixel tiles of the gather kernel fill the chip better
+
+
+def sphere_adjplan(pos, kh, kw):
+  """Adjoint-window plan of the sampling table `pos` (H, W) for the windowed input-gradient kernel, or None when no tile qualifies
+  (or H is not a multiple of 64: the left-over tiles are handed to the gather kernel as whole 64-pixel runs of one stored row).
+  (good tiles int32 device, n_good, rec_off int32 device, rec_w float32 device, bad 64-pixel tile ids of the plane-transposed
+  storage int32 device, n_bad_ids).  Built on the host by mode_sphere_adjplan_build once per (table, device), cached."""
+  key = (pos.data_ptr(), pos._version, tuple(pos.shape), kh, kw, str(pos.device))
+  with _plan_lock:
+    if key in _adjplan_cache:
+      return _adjplan_cache[key][0]
+    H, W = pos.shape[2:]
+    plan = None
+    if kh * kw == 9 and H % 64 == 0 and W % 4 == 0:
+      host = pos.detach().to('cpu', torch.float32).contiguous()
+      n = lib().mode_sphere_plan_max_tiles(H, W)
+      good = torch.zeros(4 * n, dtype=torch.int32)
+      bad = torch.zeros(2 * n, dtype=torch.int32)
+      counts = torch.zeros(2, dtype=torch.int32)
+      rec_off = torch.zeros(n * 9 * 256 * 4, dtype=torch.int32)
+      rec_w = torch.zeros(n * 9 * 256 * 4, dtype=torch.float32)
+      check(lib().mode_sphere_adjplan_build(ptr(host), H, W, kh, kw, ptr(good), ptr(bad), ptr(counts), ptr(rec_off), ptr(rec_w)),
+            'mode_sphere_adjplan_build')
+      ng, nb = int(counts[0]), int(counts[1])
+      if ng > 0:
+        # a bad tile (h0, w0) = the 64-pixel runs h0 .. h0 + 63 of the stored rows w0 .. w0 + 3 of the (W, H) planes
+        b2 = bad[:2 * nb].view(nb, 2).to(torch.int64)
+        ids = ((b2[:, 1:2] + torch.arange(4).view(1, 4)) * H + b2[:, 0:1]) // 64 if nb else torch.zeros((0, 4), dtype=torch.int64)
+        ids = ids.reshape(-1).sort().values.to(torch.int32)
+        dev = pos.device
+        plan = (good[:4 * ng].contiguous().to(dev), ng, rec_off[:ng * 9 * 256 * 4].contiguous().to(dev),
+                rec_w[:ng * 9 * 256 * 4].contiguous().to(dev), ids.contiguous().to(dev) if nb else None, int(ids.numel()))
+    _adjplan_cache[key] = (plan, pos)  # keep `pos` alive: the key uses its address
+    return plan
+
+
 def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
   """gxt (B,Ci,W,H) = input gradient for gyt (B,Co,W,H), both plane-transposed (written, not added to)."""
   require_gpu(gyt, pos, w, gxt)
@@ -612,10 +649,26 @@ def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
   flops = 2 * gyt.numel() * w[0].numel()
   nbytes = 4 * (gxt.numel() + gyt.numel() + pos.numel() + w.numel())
   rowptr, entries, _ = sphere_adjoint(_transposed_table(pos), Kh, Kw, (1, 1), (W, H))
+  aplan = None
+  if (CONV_ARITH == 'bf16x6' and SPHERE_BWD_DATA_SPLIT and Kh * Kw == 9 and tuple(pos.shape[2:]) == (H, W) and
+      lib().mode_sphere_conv_bwd_data_win_supported(Ci, Co, groups) == 1):
+    aplan = sphere_adjplan(pos, Kh, Kw)
+    if aplan is not None and aplan[1] * B * groups * (-(-(Ci // groups) // 128)) < SPHERE_BWD_SPLIT_MIN_WG:
+      aplan = None
   with torch.cuda.device_of(gyt), profiling.region('sphere_conv_bwd_data[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, gyt.device):
     wp = _wpack(w, groups)
-    check(lib().mode_sphere_conv_bwd_data_adj(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co, Kh, Kw,
-                                              W, H, groups, 0, stream_of(gyt)), 'mode_sphere_conv_bwd_data_adj')
+    if aplan is not None:
+      tiles, ng, rec_off, rec_w, bad_ids, nbad = aplan
+      wps = torch.empty(lib().mode_sphere_conv_bwd_data_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+      check(lib().mode_sphere_conv_bwd_data_win_split(ptr(gyt), ptr(w), ptr(gxt), ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w), B, Ci,
+                                                      H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)), 'mode_sphere_conv_bwd_data_win_split')
+      if nbad:  # the tiles next to the poles and the few columns with more than four sources per tap: gather kernel on a tile list
+        check(lib().mode_sphere_conv_bwd_data_adj_list(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co,
+                                                       Kh, Kw, W, H, groups, 0, ptr(bad_ids), nbad, stream_of(gyt)),
+              'mode_sphere_conv_bwd_data_adj_list')
+    else:
+      check(lib().mode_sphere_conv_bwd_data_adj(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co, Kh, Kw,
+                                                W, H, groups, 0, stream_of(gyt)), 'mode_sphere_conv_bwd_data_adj')
   return gxt
 
 

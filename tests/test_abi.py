@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 12
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 13
 
 
 def test_argument_validation_without_gpu():
@@ -205,3 +205,47 @@ def test_table_caches_are_bounded():
   for i in range(HF.TABLE_CACHE_ENTRIES + 5):  # the integer tables of many resolutions do not accumulate
     HF.conv2d_table(8 + i, 8, 3, 3, (1, 1), (1, 1), (1, 1), 'cpu')
   assert len(HF._conv_tables) == HF.TABLE_CACHE_ENTRIES
+
+
+@pytest.mark.parametrize('ih,iw', [(128, 256), (32, 64)])
+def test_adjoint_window_plan_reproduces_the_adjoint_table(ih, iw):
+  """mode_sphere_adjplan_build (host code): on its good tiles the 4-slot records, read back through the window geometry, are exactly
+  the (source pixel, weight) lists of mode_sphere_adjoint_build, in the same order; good and bad tiles partition the image."""
+  import numpy as np
+  import torch
+  from oracle import mode_ref
+  lib = mode_hip.lib()
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  n = lib.mode_sphere_plan_max_tiles(H, W)
+  good, bad, counts = torch.zeros(4 * n, dtype=torch.int32), torch.zeros(2 * n, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
+  rec_off, rec_w = torch.zeros(n * 9 * 256 * 4, dtype=torch.int32), torch.zeros(n * 9 * 256 * 4, dtype=torch.float32)
+  assert lib.mode_sphere_adjplan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(good), mode_hip.ptr(bad), mode_hip.ptr(counts),
+                                       mode_hip.ptr(rec_off), mode_hip.ptr(rec_w)) == 0
+  ng, nb = counts.tolist()
+  assert ng > 0 and ng + nb == n
+  g, b = good[:4 * ng].view(ng, 4).numpy(), bad[:2 * nb].view(nb, 2).numpy()
+  assert len({(int(a), int(c)) for a, c in g[:, :2]} | {(int(a), int(c)) for a, c in b}) == n
+  nmax = lib.mode_sphere_adjoint_max_entries(3, 3, H, W)
+  rowptr, entries, ne = torch.empty(9 * H * W + 1, dtype=torch.int32), torch.empty(2 * nmax, dtype=torch.int32), ctypes.c_int64(0)
+  assert lib.mode_sphere_adjoint_build(mode_hip.ptr(pos), H, W, 3, 3, 1, 1, H, W, mode_hip.ptr(rowptr), mode_hip.ptr(entries),
+                                       ctypes.cast(ctypes.pointer(ne), ctypes.c_void_p)) == 0
+  rp, ent = rowptr.numpy(), entries[:2 * ne.value].view(-1, 2).numpy()
+  ro, rw = rec_off[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy(), rec_w[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy()
+  assert (ro >= 0).all() and (ro < 8 * 81).all()
+  for i in (0, ng // 2, ng - 1):
+    h0, w0, rbase, cbase = [int(v) for v in g[i]]
+    for k in range(9):
+      for pix in (0, 31, 100, 255):
+        wv = pix >> 5
+        h, w = h0 + (wv // 4) * 32 + (pix & 31), w0 + (wv % 4)
+        row = k * H * W + h * W + w
+        lst = ent[rp[row]:rp[row + 1]]
+        assert len(lst) <= 4
+        for s in range(4):
+          if s < len(lst):
+            hp, wp = divmod(int(lst[s, 0]), W)
+            assert ro[i, k, pix, s] == (wp - cbase) * 81 + (hp - rbase) % H
+            assert rw[i, k, pix, s] == lst[s, 1:2].view(np.float32)[0]
+          else:
+            assert ro[i, k, pix, s] == 0 and rw[i, k, pix, s] == 0.0

@@ -332,3 +332,49 @@ def test_split_kernels_on_random_small_shapes(split_arith):
     if Co2 % 16 == 0:
       assert _err(HF.conv2d_bwd_data(gd, wd, dil), xa.grad) <= _tol(Co2 * 9, xa.grad), tag
     assert _err(HF.conv2d_bwd_weight(gd, xd, dil), wa.grad) <= 2e-5 * max(1.0, float(wa.grad.abs().max())), tag
+
+
+# ------------------------------------------------------------------------------------------------ spherical input gradient (a8)
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(128, 256, 2, 128, 128, 1), (128, 256, 4, 64, 128, 1), (128, 256, 1, 48, 32, 2), (32, 64, 3, 40, 16, 1)])
+def test_split_sphere_input_gradient_against_float64(ih, iw, B, ci, co, groups, split_arith, monkeypatch):
+  """mode_sphere_conv_bwd_data_win_split (windowed adjoint, split-bf16) + the gather kernel on the left-over tile list against the
+  float64 oracle (oracle/sphere_conv_ref.py: cu:293-356 + cpp:275-315 restated), at the benchmark's quarter-resolution Cassini grid
+  256 x 128 (128 -> 128 and the 64 -> 128 layer, groups, channel counts off the 128 / 32 blocks) and at 64 x 32 (5 good tiles);
+  same bound as the fp32 gather kernel, whose error on the same inputs is printed beside it; written (not added to), deterministic."""
+  from oracle import mode_ref, sphere_conv_ref
+  monkeypatch.setattr(HF, 'SPHERE_BWD_SPLIT_MIN_WG', 0)
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  w = _rand((co, ci // groups, 3, 3), 401, (2.0 / (9 * ci // groups))**0.5)
+  gy = _rand((B, co, H, W), 402)
+  x0 = torch.zeros((B, ci, H, W), dtype=torch.float64)
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  want, _ = sphere_conv_ref.backward(x0, pos, w.double(), gy.double(), (1, 1), (1, 1), (1, 1), groups)
+  pd, wd = pos.to(DEV), w.to(DEV)
+  ap = HF.sphere_adjplan(pd, 3, 3)
+  assert ap is not None and ap[1] > 0, 'the windowed adjoint must be planned for this table'
+  assert mode_hip.lib().mode_sphere_conv_bwd_data_win_supported(ci, co, groups) == 1
+  gyt = gy.to(DEV).transpose(2, 3).contiguous()
+  gxt = torch.full((B, ci, W, H), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data_t(gyt, pd, wd, gxt, groups)
+  got = gxt.transpose(2, 3)
+  monkeypatch.setattr(HF, 'SPHERE_BWD_DATA_SPLIT', False)
+  old = torch.full((B, ci, W, H), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data_t(gyt, pd, wd, old, groups)
+  monkeypatch.setattr(HF, 'SPHERE_BWD_DATA_SPLIT', True)
+  e, e_old = _err(got, want), _err(old.transpose(2, 3), want)
+  tol = 2e-6 * (co // groups * 9) * max(1.0, float(want.abs().max()))
+  rms = float((got.cpu().double() - want).pow(2).mean().sqrt())
+  rms_old = float((old.transpose(2, 3).cpu().double() - want).pow(2).mean().sqrt())
+  print('sphere_conv_bwd_data %d->%d %dx%d B=%d g=%d: split max %.3e rms %.3e | fp32 gather kernel max %.3e rms %.3e | bound %.3e; %d of %d tiles on '
+        'the split kernel' % (ci, co, H, W, B, groups, e, rms, e_old, rms_old, tol, ap[1], ap[1] + ap[5] // 4))
+  assert torch.isfinite(got).all()
+  assert e <= tol
+  assert rms <= 1.25 * rms_old + 1e-12, 'the split path must not be less accurate than the fp32 kernel'
+  again = torch.empty_like(gxt)
+  HF.sphere_conv_bwd_data_t(gyt, pd, wd, again, groups)
+  assert torch.equal(again, gxt)  # deterministic
+  # the NCHW operator (reference seam) takes the same route through its transposed copies
+  gx = torch.full((B, ci, H, W), float('nan'), device=DEV)
+  HF.sphere_conv_bwd_data(gy.to(DEV), pd, wd, gx, (1, 1), groups, overwrite=True, gy_transposed=gyt)
+  assert torch.equal(gx, got)
