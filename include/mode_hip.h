@@ -199,6 +199,15 @@ int mode_sphere_plan_polar(const float* pos_host, const int32_t* tiles_host, con
 size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
                                                        int n_small, int n_rest_pixels, int n_polar_items);
 
+/* mode_sphere_conv_bwd_weight_win_split: the same call with the compact-window tiles on the split-bf16 kernel (K = 16 pixels per
+ * v_mfma_f32_32x32x16_bf16, fp32 operands split exactly into three bf16 pieces, fp32 accumulation). */
+int mode_sphere_conv_bwd_weight_win_split(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                          const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
+                                          const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels,
+                                          const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
+                                          int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t,
+                                          const float* x_t, mode_stream_t stream);
+
 int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                     const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
                                     const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, const int32_t* pitems,

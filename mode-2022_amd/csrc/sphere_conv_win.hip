@@ -1044,6 +1044,242 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   }
 }
 
+// =====================================================================================================================
+// Weight gradient on the compact-window tiles with the split-bf16 arithmetic:  gW[o][c][k] = sum_p gy[o][p] * col[c][k][p],
+// D[i = o][j = c] per tap on v_mfma_f32_32x32x16_bf16 with K = 16 PIXELS per instruction (sphere_bww_win_kernel: one pixel per fp32
+// MFMA).  Same work items (half a plan tile = 32 rows x 4 columns of one sample, column by column), x window, record table, wave roles
+// (wave v owns tap v for all four o-tiles; tap 8 is shared), partial-sum layout and reduction as sphere_bww_win_kernel.  New:
+//   * gy is split when a column is staged: LDS holds [3 pieces][128 o][32 px] bf16 (row pitch 80 B: the 16 lanes of a b128 read
+//     group hit 16 different 16-byte slots), so an A fragment (lane = o, 8 consecutive pixels) is ONE ds_read_b128 per piece;
+//   * the B fragment (lane = c, 8 consecutive pixels) needs the sampled values pixel-fastest per channel, while sampling wants one
+//     pixel per lane (its record in registers).  So a wave samples 16 pixels x 32 channels per K-step with lane = (pixel octet h,
+//     channel octet q, pixel p8): 8 channels x (4 window words + 4 FMAs) for ITS pixel, transposes the 8 x 8 blocks through a
+//     wave-private LDS scratch (8 ds_write_b32 + 8 ds_read_b32, conflict-free at pitch 17), and splits the 8 pixels of its channel
+//     into the three bf16 fragments in registers -- no operand buffer, no extra barrier;
+//   * per column a wave runs 2 K-steps of its own tap (2 x 24 MFMAs) and one (K-step, o-tile) piece of tap 8 (6 MFMAs): wave v takes
+//     K-step v / 4, o-tile v % 4; the two shares of an o-tile are added through LDS at the end, in wave order.
+// One accumulator per (tap, o-tile): a workgroup sums ~900 K-steps, i.e. ~5 400 roundings at the magnitude of the running sum
+// against the fp32 kernel's ~14 000 (one per pixel); measured against float64 in tests/test_gpu_split.py.
+constexpr int BS_GP = 20;                      // dwords per gy row: 16 (32 bf16) + 4 of padding
+constexpr int BS_GYB = 3 * 128 * BS_GP;        // dwords of the gy column buffer (3 pieces)
+constexpr int BS_SCRP = 17;                    // scratch row pitch (floats)
+constexpr int BS_SCR = 32 * BS_SCRP;           // floats of one wave's transposition scratch
+constexpr int BS_X2 = ((2 * BW_XW + 3) / 4) * 4;  // both x windows, rounded so that the gy buffer behind them is 16-byte aligned
+constexpr int BS_LDS_DWORDS = BS_X2 + BS_GYB + 8 * BS_SCR;
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                     float* __restrict__ part, WinDims d, const int4* __restrict__ tiles,
+                                                                     const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
+                                                                     int ntiles, int S) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint32_t* gyb = reinterpret_cast<uint32_t*>(smem + BS_X2);  // [3][128][BS_GP]
+  constexpr int WRP = BW_WR, CP = BW_CP;
+  const int s = blockIdx.x, cg = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, half = lane >> 5;
+  float* scr = smem + BS_X2 + BS_GYB + wave * BS_SCR;  // this wave's transposition scratch [32 c][BS_SCRP]
+  const long long HW = (long long)d.H * d.W;
+  const int T = ntiles * 2 * d.B;  // (sample, tile, half) items
+  const int NCG = gridDim.y;
+
+  f32x16 acc[4], acc8;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[0][r] = acc[1][r] = acc[2][r] = acc[3][r] = 0.f;
+    acc8[r] = 0.f;
+  }
+  for (int i = tid; i < BS_LDS_DWORDS; i += NTHREADS) smem[i] = 0.f;  // every word that may be read is finite
+
+  const int omax = d.Cog - mg * 128;
+  const int cmax = d.Cig - cg * BW_CG;
+  // sampling role of this lane: pixel 16 ks + 8 sh + sp8 of the column, channels 8 sq .. 8 sq + 7 of the chunk
+  const int sh = half, sq = j >> 3, sp8 = j & 7;
+  const int ks8 = wave >> 2, m8 = wave & 3;  // this wave's piece of tap 8
+
+  struct Item {
+    int b, ti, hf, h0, w0, rbase, cbase;
+  };
+  auto item_of = [&](int t) {
+    Item it;
+    it.b = t / (ntiles * 2);
+    const int r = t - it.b * ntiles * 2;
+    it.ti = r >> 1;
+    it.hf = r & 1;
+    const int4 tl = tiles[it.ti];
+    it.h0 = tl.x + it.hf * BW_TH;
+    it.w0 = tl.y;
+    it.rbase = (tl.z + it.hf * BW_TH) % d.H;
+    it.cbase = tl.w & 0xffff;
+    return it;
+  };
+  // x window staging exactly as in sphere_bww_win_kernel
+  const int xcol = d.sh == 1 ? tid >> 6 : tid & (WC - 1), xrow = d.sh == 1 ? tid & 63 : tid >> 3;
+  const bool xrow_ok = xrow < WRP;
+  float pxw[BW_NXW];
+  bool pxw_ok = false;
+  auto issue_xw = [&](const Item& it, int part) {
+    pxw_ok = xrow_ok && it.cbase + xcol < d.W;
+    const int grow = (it.rbase + (xrow_ok ? xrow : 0)) % d.H;
+    const float* xg = x + ((long long)it.b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
+                      (pxw_ok ? (long long)grow * d.sh + (long long)(it.cbase + xcol) * d.sw : 0);
+#pragma unroll
+    for (int c = 0; c < BW_NXW; ++c) pxw[c] = xg[(long long)min(part * BW_NXW + c, cmax - 1) * HW];
+  };
+  auto commit_xw = [&](float* xwdst, int part) {
+    if (xrow_ok) {
+      float* dst = xwdst + xcol * WRP + xrow;
+#pragma unroll
+      for (int c = 0; c < BW_NXW; ++c) dst[(part * BW_NXW + c) * BW_CP] = (pxw_ok && part * BW_NXW + c < cmax) ? pxw[c] : 0.f;
+    }
+  };
+  // gy column staging: thread -> (o = (tid >> 4) + 32 u, pixel pair tid & 15): two pixels per value pair, split into packed bf16 dwords
+  const int gpp = tid & 15, go0 = tid >> 4;
+  float pg0[4], pg1[4];
+  unsigned pgy_ok = 0;  // bit 2u: first pixel of pair real, bit 2u + 1: second
+  // records of the next column: own tap at K-steps 0 / 1, tap 8 at K-step ks8 -- for the pixel this lane samples
+  float4 prw0, prw1, prw8;
+  int pro0, pro1, pro8;
+  auto issue_col = [&](const Item& it, int wc) {
+    const int h = it.h0 + 2 * gpp, w = it.w0 + wc;
+    const bool ok0 = h < d.H && w < d.W, ok1 = h + 1 < d.H && w < d.W;
+    const float* gyb0 = gy + ((long long)it.b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
+                        (ok0 ? (long long)h * d.sh + (long long)w * d.sw : 0);
+    const long long step1 = ok1 ? d.sh : 0;
+    pgy_ok = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = go0 + 32 * u;
+      const float* p = gyb0 + (long long)min(o, omax - 1) * HW;
+      pg0[u] = p[0];
+      pg1[u] = p[step1];
+      pgy_ok |= ((ok0 && o < omax) ? 1u : 0u) << (2 * u) | ((ok1 && o < omax) ? 2u : 0u) << (2 * u);
+    }
+    const long long rcol = (((long long)it.ti * 2 + it.hf) * TW + wc) * BW_NREC;
+    const int px0 = 8 * sh + sp8;
+    prw0 = rec_w[rcol + wave * BW_TH + px0];
+    pro0 = rec_off[rcol + wave * BW_TH + px0];
+    prw1 = rec_w[rcol + wave * BW_TH + 16 + px0];
+    pro1 = rec_off[rcol + wave * BW_TH + 16 + px0];
+    prw8 = rec_w[rcol + 8 * BW_TH + 16 * ks8 + px0];
+    pro8 = rec_off[rcol + 8 * BW_TH + 16 * ks8 + px0];
+  };
+  auto commit_col = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = (pgy_ok >> (2 * u) & 1u) ? pg0[u] : 0.f, b2 = (pgy_ok >> (2 * u + 1) & 1u) ? pg1[u] : 0.f;
+      uint32_t p1, p2, p3;
+      sp_split2(a, b2, p1, p2, p3);
+      uint32_t* dst = gyb + (go0 + 32 * u) * BS_GP + gpp;
+      dst[0] = p1;
+      dst[128 * BS_GP] = p2;
+      dst[2 * 128 * BS_GP] = p3;
+    }
+  };
+  // B fragment of one K-step: sample this lane's pixel for 8 channels, transpose through the scratch, split this lane's channel
+  auto sample = [&](const float* xw, const float4 w4, const int ro, uint4 (&bf)[3]) {
+    const float* xb = xw + (8 * sq) * CP + ro;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = xb + c * CP;
+      v[c] = __builtin_fmaf(w4.w, q[WRP + 1], __builtin_fmaf(w4.z, q[1], __builtin_fmaf(w4.y, q[WRP], w4.x * q[0])));
+      asm("" : "+v"(v[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) scr[(8 * sq + c) * BS_SCRP + 8 * sh + sp8] = v[c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own stores have landed (LDS serves a wave in order)
+    float t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = scr[j * BS_SCRP + 8 * half + i];
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp_split2(t8[2 * i], t8[2 * i + 1], q1[i], q2[i], q3[i]);
+    bf[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    bf[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    bf[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next sample overwrites the scratch
+  };
+  // the six MFMAs of one (o-tile, K-step): smallest terms first
+  auto mma6 = [&](f32x16 a0, int m, int ks, const uint4 (&bf)[3]) {
+    const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m * 32 + j) * BS_GP + 8 * ks + 4 * half);
+    const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4], a3 = ga[2 * 128 * BS_GP / 4];
+    a0 = sp_mfma(a3, bf[0], a0);
+    a0 = sp_mfma(a1, bf[2], a0);
+    a0 = sp_mfma(a2, bf[1], a0);
+    a0 = sp_mfma(a2, bf[0], a0);
+    a0 = sp_mfma(a1, bf[1], a0);
+    a0 = sp_mfma(a1, bf[0], a0);
+    return a0;
+  };
+
+  Item cur = item_of(s);
+  __syncthreads();  // zero fill done
+  for (int part = 0; part < TW; ++part) {
+    issue_xw(cur, part);
+    commit_xw(smem, part);
+  }
+  issue_col(cur, 0);
+  commit_col();
+  __syncthreads();
+
+  int xbuf = 0;
+  for (int t = s; t < T; t += S) {
+    const bool more_items = t + S < T;
+    const Item nxt = item_of(more_items ? t + S : t);
+    const float* xw = smem + xbuf * BW_XW;
+    for (int wc = 0; wc < TW; ++wc) {
+      const bool last_col = wc == TW - 1;
+      const bool have_next = !last_col || more_items;
+      const float4 rw0 = prw0, rw1 = prw1, rw8 = prw8;
+      const int ro0 = pro0, ro1 = pro1, ro8 = pro8;
+      if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
+      if (more_items) issue_xw(nxt, wc);
+
+      uint4 b0[3], b1[3], b8[3];
+      sample(xw, rw0, ro0, b0);
+      sample(xw, rw1, ro1, b1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = mma6(acc[m], m, 0, b0);
+      sample(xw, rw8, ro8, b8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = mma6(acc[m], m, 1, b1);
+      acc8 = mma6(acc8, m8, ks8, b8);
+
+      __syncthreads();  // everyone is done with this column's gy
+      if (have_next) commit_col();
+      if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);
+      __syncthreads();
+    }
+    cur = nxt;
+    xbuf ^= 1;
+  }
+
+  // partials: [tap][128 o][32 c] per (slice, z, channel group), the layout reduce_gw_win sums
+  float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      pb[((long long)wave * 128 + o) * BW_CG + j] = acc[m][r];
+    }
+  // tap 8: o-tile m8 = the share of K-step 0 (waves 0..3) + the share of K-step 1 (waves 4..7), added in that order through LDS
+  float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] = acc8[r];
+  }
+  __syncthreads();
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] += acc8[r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
+}
+
 size_t win_lds_bytes(int wr, bool pipe) { return ((size_t)(pipe ? 2 : 1) * CCH * chan_pitch(wr) + wr + 8) * sizeof(float); }
 bool wrap_is_pipelined(int H) { return H + 1 <= WR_PIPE_MAX && win_lds_bytes(H + 1, true) <= 160 * 1024; }
 
@@ -1449,12 +1685,39 @@ extern "C" size_t mode_sphere_conv_bwd_weight_win_workspace_bytes(int B, int Ci,
 // Weight gradient, ADDED to gw like mode_sphere_conv_bwd_weight: windowed kernel on the n_small compact tiles of the plan
 // (tile list order: wrap-around, mid, small), the polar kernel on the n_polar_items column items of the other tiles
 // (mode_sphere_plan_polar), or -- when those could not be planned -- the general kernels on their n_rest_pixels pixels.
+static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x, float* gw, float* workspace, const int32_t* tiles,
+                               int n_small, int n_mid, int n_wrap, const float* rec_w, const int32_t* rec_off, const int32_t* rest_pixels,
+                               int n_rest_pixels, const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
+                               int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
+                               mode_stream_t stream, int split);
+
 extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                                const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
                                                const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels,
                                                const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
                                                int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t,
                                                const float* x_t, mode_stream_t stream) {
+  return bwd_weight_win_impl(gy, pos, x, gw, workspace, tiles, n_small, n_mid, n_wrap, rec_w, rec_off, rest_pixels, n_rest_pixels, pitems,
+                             prec_w, prec_off, n_polar_items, B, Ci, H, W, Co, Kh, Kw, groups, gy_t, x_t, stream, 0);
+}
+
+// The same with the compact-window tiles on the split-bf16 kernel (sphere_bww_split_kernel: fp32 operands split exactly into three
+// bf16 pieces, six bf16 MFMAs per product, fp32 accumulation); polar items and listed pixels as above.
+extern "C" int mode_sphere_conv_bwd_weight_win_split(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
+                                                     const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
+                                                     const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels,
+                                                     const int32_t* pitems, const float* prec_w, const int32_t* prec_off,
+                                                     int n_polar_items, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                                     const float* gy_t, const float* x_t, mode_stream_t stream) {
+  return bwd_weight_win_impl(gy, pos, x, gw, workspace, tiles, n_small, n_mid, n_wrap, rec_w, rec_off, rest_pixels, n_rest_pixels, pitems,
+                             prec_w, prec_off, n_polar_items, B, Ci, H, W, Co, Kh, Kw, groups, gy_t, x_t, stream, 1);
+}
+
+static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x, float* gw, float* workspace, const int32_t* tiles,
+                               int n_small, int n_mid, int n_wrap, const float* rec_w, const int32_t* rec_off, const int32_t* rest_pixels,
+                               int n_rest_pixels, const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
+                               int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
+                               mode_stream_t stream, int split) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win");
   if (rc != MODE_OK) return rc;
@@ -1480,11 +1743,19 @@ extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos
   int S = 0;
   if (n_small > 0) {
     S = bww_win_splits(d, n_small);
-    const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
-    rc = mode::allow_lds(sphere_bww_win_kernel, lds, "mode_sphere_conv_bwd_weight_win");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_bww_win_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
-                       reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
+    if (split) {
+      const size_t lds = (size_t)BS_LDS_DWORDS * sizeof(float);
+      rc = mode::allow_lds(sphere_bww_split_kernel, lds, "mode_sphere_conv_bwd_weight_win_split");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_bww_split_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
+                         reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
+    } else {
+      const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
+      rc = mode::allow_lds(sphere_bww_win_kernel, lds, "mode_sphere_conv_bwd_weight_win");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_bww_win_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
+                         reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
+    }
     rc = mode::check_launch("mode_sphere_conv_bwd_weight_win");
     if (rc != MODE_OK) return rc;
   }

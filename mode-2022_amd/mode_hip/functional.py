@@ -520,6 +520,11 @@ def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_tra
 
 
 SPHERE_POLAR = True  # polar kernel for the tall-window tiles (else: pixel list + general kernel)
+SPHERE_BWD_WEIGHT_SPLIT = True  # compact-window tiles of the weight gradient on the split-bf16 kernel (CONV_ARITH 'bf16x6' only)
+
+
+def _bww_win_entry():
+  return 'mode_sphere_conv_bwd_weight_win_split' if (CONV_ARITH == 'bf16x6' and SPHERE_BWD_WEIGHT_SPLIT) else 'mode_sphere_conv_bwd_weight_win'
 SPHERE_BWD_WEIGHT = 'window'  # 'window' (where the table allows) | 'gather'
 
 
@@ -556,11 +561,12 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy
       if SPHERE_LAYOUT == 'transposed':
         gyt = gy_transposed if gy_transposed is not None and tuple(gy_transposed.shape) == (B, Co, Wo, Ho) else transpose_planes(gy)
         xt = x_transposed if x_transposed is not None and tuple(x_transposed.shape) == (B, Ci, W, H) else transpose_planes(x)
-      check(lib().mode_sphere_conv_bwd_weight_win(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
-                                                  ptr(rec_off), ptr(rest), nrest, ptr(pitems) if npol else None, ptr(prw) if npol else None,
-                                                  ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, G,
-                                                  ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,
-                                                  stream_of(gy)), 'mode_sphere_conv_bwd_weight_win')
+      entry = _bww_win_entry()
+      check(getattr(lib(), entry)(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
+                                  ptr(rec_off), ptr(rest), nrest, ptr(pitems) if npol else None, ptr(prw) if npol else None,
+                                  ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, G,
+                                  ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,
+                                  stream_of(gy)), entry)
     else:
       n = lib().mode_sphere_conv_bwd_weight_workspace_bytes(B, Ci, Co, Kh, Kw, Ho, Wo, G)
       ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
@@ -687,10 +693,11 @@ def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
   with torch.cuda.device_of(gyt), profiling.region('sphere_conv_bwd_weight[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, gyt.device):
     n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, groups, n0, 0, npol)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gyt.device)
-    check(lib().mode_sphere_conv_bwd_weight_win(None, ptr(pos), None, ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w), ptr(rec_off),
-                                                ptr(rest), 0, ptr(pitems) if npol else None, ptr(prw) if npol else None,
-                                                ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, groups, ptr(gyt), ptr(xt),
-                                                stream_of(gyt)), 'mode_sphere_conv_bwd_weight_win')
+    entry = _bww_win_entry()
+    check(getattr(lib(), entry)(None, ptr(pos), None, ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w), ptr(rec_off),
+                                ptr(rest), 0, ptr(pitems) if npol else None, ptr(prw) if npol else None,
+                                ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, groups, ptr(gyt), ptr(xt),
+                                stream_of(gyt)), entry)
   return gw
 
 

@@ -378,3 +378,45 @@ def test_split_sphere_input_gradient_against_float64(ih, iw, B, ci, co, groups, 
   gx = torch.full((B, ci, H, W), float('nan'), device=DEV)
   HF.sphere_conv_bwd_data(gy.to(DEV), pd, wd, gx, (1, 1), groups, overwrite=True, gy_transposed=gyt)
   assert torch.equal(gx, got)
+
+
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(128, 256, 2, 128, 128, 1), (128, 256, 4, 64, 128, 1), (128, 256, 1, 40, 24, 1), (32, 64, 3, 48, 200, 1),
+                                                   (64, 128, 2, 64, 64, 2)])
+def test_split_sphere_weight_gradient_against_float64(ih, iw, B, ci, co, groups, split_arith, monkeypatch):
+  """sphere_bww_split_kernel (K = 16 pixels per bf16 MFMA, split operands) + the polar kernel + the reduction against the float64
+  oracle, on plane-transposed storage as the model uses it: benchmark shape 128 -> 128 and 64 -> 128 at 256 x 128, channel counts off
+  the 32 / 128 blocks (masked), more than 128 output channels (two slices), groups; same bound as the fp32 windowed kernel, whose
+  error on the same inputs is printed beside it; adds to gw (reference contract), deterministic."""
+  from oracle import mode_ref, sphere_conv_ref
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  x = _rand((B, ci, H, W), 411)
+  gy = _rand((B, co, H, W), 412)
+  w0 = torch.zeros((co, ci // groups, 3, 3), dtype=torch.float64)
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  _, want = sphere_conv_ref.backward(x.double(), pos, w0, gy.double(), (1, 1), (1, 1), (1, 1), groups)
+  pd = pos.to(DEV)
+  plan = HF.sphere_plan(pd, 3, 3)
+  assert plan is not None and plan[1][0] > 0
+  xt, gyt = x.to(DEV).transpose(2, 3).contiguous(), gy.to(DEV).transpose(2, 3).contiguous()
+  gw = torch.zeros((co, ci // groups, 3, 3), device=DEV)
+  HF.sphere_conv_bwd_weight_t(gyt, pd, xt, gw, groups)
+  monkeypatch.setattr(HF, 'SPHERE_BWD_WEIGHT_SPLIT', False)
+  old = torch.zeros_like(gw)
+  HF.sphere_conv_bwd_weight_t(gyt, pd, xt, old, groups)
+  monkeypatch.setattr(HF, 'SPHERE_BWD_WEIGHT_SPLIT', True)
+  scale = max(1.0, float(want.abs().max()))
+  e, e_old = _err(gw, want), _err(old, want)
+  rms = float((gw.cpu().double() - want).pow(2).mean().sqrt())
+  rms_old = float((old.cpu().double() - want).pow(2).mean().sqrt())
+  print('sphere_conv_bwd_weight %d->%d %dx%d B=%d g=%d: split max %.3e rms %.3e | fp32 windowed kernel max %.3e rms %.3e | bound %.3e (|gw| <= %.3g)' %
+        (ci, co, H, W, B, groups, e, rms, e_old, rms_old, 1e-5 * scale, scale))
+  assert e <= 1e-5 * scale
+  assert rms <= 1.5 * rms_old + 1e-12
+  HF.sphere_conv_bwd_weight_t(gyt, pd, xt, gw, groups)  # a second call adds on top (sphere_conv.py:62-64)
+  assert _err(gw, 2 * want) <= 2e-5 * scale
+  again = torch.zeros_like(old)
+  HF.sphere_conv_bwd_weight_t(gyt, pd, xt, again, groups)
+  again2 = torch.zeros_like(old)
+  HF.sphere_conv_bwd_weight_t(gyt, pd, xt, again2, groups)
+  assert torch.equal(again, again2)  # deterministic
