@@ -91,6 +91,15 @@ def _on_split_path(label):
   if m:
     which = {'conv3d_bwd_data': 1, 'conv3d_bwd_weight': 2}.get(m.group(1), 0)
     return lib.mode_conv3d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), which) == 1
+  m = re.match(r'(sphere_conv_fwd|sphere_conv_bwd_data|sphere_conv_bwd_weight|sphere_conv_bn_eval)\[(\d+)->(\d+) (\d+)x(\d+)\]', label)
+  if m:
+    # the spherical layers of the extractor (3x3 taps on the gnomonic table): compact-window tiles on the split-bf16 kernels, the
+    # tiles next to the poles on fp32 MFMA inside the same operator -- priced against the faster pipe (the lower fraction).  The
+    # integer-table layers that share these labels (32 -> 288 tap products, the stride-2 layer) stay on the fp32 gather kernels.
+    ci, co = int(m.group(2)), int(m.group(3))
+    if m.group(1) == 'sphere_conv_bwd_data':
+      return ci >= 64 and lib.mode_sphere_conv_bwd_data_win_supported(ci, co, 1) == 1
+    return ci >= 64 and ci % 16 == 0
   m = re.match(r'(conv2d_fwd|conv2d_bwd_data|conv2d_bwd_weight|conv2d_bn_eval)\[(\d+)->(\d+) d(\d) ', label)
   if m:
     if m.group(1) == 'conv2d_bwd_weight':

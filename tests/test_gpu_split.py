@@ -380,7 +380,7 @@ def test_split_sphere_input_gradient_against_float64(ih, iw, B, ci, co, groups, 
   assert torch.equal(gx, got)
 
 
-@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(128, 256, 2, 128, 128, 1), (128, 256, 4, 64, 128, 1), (128, 256, 1, 40, 24, 1), (32, 64, 3, 48, 200, 1),
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(128, 256, 2, 128, 128, 1), (128, 256, 4, 64, 128, 1), (128, 256, 1, 40, 24, 1), (128, 256, 1, 48, 200, 1),
                                                    (64, 128, 2, 64, 64, 2)])
 def test_split_sphere_weight_gradient_against_float64(ih, iw, B, ci, co, groups, split_arith, monkeypatch):
   """sphere_bww_split_kernel (K = 16 pixels per bf16 MFMA, split operands) + the polar kernel + the reduction against the float64
