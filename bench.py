@@ -98,8 +98,8 @@ def _on_split_path(label):
     # integer-table layers that share these labels (32 -> 288 tap products, the stride-2 layer) stay on the fp32 gather kernels.
     ci, co = int(m.group(2)), int(m.group(3))
     if m.group(1) == 'sphere_conv_bwd_data':
-      return ci >= 64 and lib.mode_sphere_conv_bwd_data_win_supported(ci, co, 1) == 1
-    return ci >= 64 and ci % 16 == 0
+      return co % 128 == 0 and lib.mode_sphere_conv_bwd_data_win_supported(ci, co, 1) == 1
+    return co % 128 == 0 and ci % 16 == 0  # (layer4 of the extractor: 64 -> 128 and 128 -> 128)
   m = re.match(r'(conv2d_fwd|conv2d_bwd_data|conv2d_bwd_weight|conv2d_bn_eval)\[(\d+)->(\d+) d(\d) ', label)
   if m:
     if m.group(1) == 'conv2d_bwd_weight':
