@@ -122,23 +122,25 @@ int mode_sphere_conv_bwd_data_adj_list(const float* gy, const float* w, float* g
 /* Windowed input gradient on the split-bf16 matrix path (csrc/sphere_conv_win.hip; replaces the col2im scatter of
  * sphere_conv_cuda_kernel.cu:293-356 + the GEMM of sphere_conv_cuda.cpp:275-315 for stride 1, 3x3 taps, output grid = input grid).
  * Host planning, once per table: mode_sphere_adjplan_build(pos_host, H, W, Kh, Kw, good_tiles[4 n], bad_tiles[2 n], counts[2],
- *   rec_off_host[n * 9 * 256 * 4], rec_w_host[same]) with n = mode_sphere_plan_max_tiles(H, W): for every 64 x 4 tile of INPUT pixels
- *   whose adjoint lists all have <= 4 entries inside one 81-row x 8-column window of gy it writes (h0, w0, rbase, cbase) and, per
- *   (tile, tap, pixel), 4 (window offset, weight) slots; the other tiles go to bad_tiles as (h0, w0).  counts = (good, bad).
+ *   rec_off_host[n * 9 * 256 * 4], rec_w_host[same], rec_off2_host[n * 9 * 256 * 2], rec_w2_host[same]) with n =
+ *   mode_sphere_plan_max_tiles(H, W): for every 64 x 4 tile of INPUT pixels whose adjoint lists all have <= 6 entries inside one 81-row
+ *   x 8-column window of gy it writes (h0, w0, rbase, cbase | six << 16) and, per (tile, tap, pixel), 4 (window offset, weight) slots
+ *   + 2 more in the second pair of arrays (six = 1 when any list of the tile uses them); the other tiles go to bad_tiles as (h0, w0).
+ *   counts = (good, bad).
  * mode_sphere_conv_bwd_data_win_split WRITES gx on the good tiles (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per
  *   product, fp32 accumulation); the caller runs mode_sphere_conv_bwd_data_adj_list (accumulate = 0) on the bad ones.  `transposed`: gy
  *   and gx are plane-transposed (B, C, W, H).  Needs mode_sphere_conv_bwd_data_win_supported(Ci, Co, groups) == 1 (output channels per
  *   group a multiple of 16); `wpack` >= mode_sphere_conv_bwd_data_win_wpack_bytes(). */
 int mode_sphere_adjplan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* good_tiles, int32_t* bad_tiles,
-                              int32_t* counts, int32_t* rec_off_host, float* rec_w_host);
+                              int32_t* counts, int32_t* rec_off_host, float* rec_w_host, int32_t* rec_off2_host, float* rec_w2_host);
 
 size_t mode_sphere_conv_bwd_data_win_wpack_bytes(int Ci, int Co, int Kh, int Kw, int groups);
 
 int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int groups);
 
 int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles, int n_tiles,
-                                        const int32_t* rec_off, const float* rec_w, int B, int Ci, int H, int W, int Co, int Kh,
-                                        int Kw, int groups, int transposed, mode_stream_t stream);
+                                        const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2, const float* rec_w2, int B,
+                                        int Ci, int H, int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream);
 
 /* Windowed forward (csrc/sphere_conv_win.hip): same result as mode_sphere_conv_fwd for stride 1 and 3x3 taps, ~2x faster on
  * tables whose samples are spatially compact (the gnomonic tables of the network).  The caller plans the table once on the HOST:

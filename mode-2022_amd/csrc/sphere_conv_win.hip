@@ -1177,7 +1177,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       dst[2 * 128 * BS_GP] = p3;
     }
   };
-  // B fragment of one K-step: sample this lane's pixel for 8 channels, transpose through the scratch, split this lane's channel
+  // B fragment of one K-step: sample this lane's pixel for 8 channels, transpose through the scratch, split this lane's channel.
+  // No wait between the scratch stores and loads: the LDS serves the instructions of one wave in order, and the compiler keeps
+  // may-aliasing LDS accesses in program order -- an explicit s_waitcnt here would pin the whole sample in front of the MFMAs.
   auto sample = [&](const float* xw, const float4 w4, const int ro, uint4 (&bf)[3]) {
     const float* xb = xw + (8 * sq) * CP + ro;
     float v[8];
@@ -1187,32 +1189,49 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       v[c] = __builtin_fmaf(w4.w, q[WRP + 1], __builtin_fmaf(w4.z, q[1], __builtin_fmaf(w4.y, q[WRP], w4.x * q[0])));
       asm("" : "+v"(v[c]));
     }
+    float* sw = scr + (8 * sq) * BS_SCRP + 8 * sh + sp8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) scr[(8 * sq + c) * BS_SCRP + 8 * sh + sp8] = v[c];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own stores have landed (LDS serves a wave in order)
+    for (int c = 0; c < 8; ++c) sw[c * BS_SCRP] = v[c];
+    const float* sr = scr + j * BS_SCRP + 8 * half;
     float t8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t8[i] = scr[j * BS_SCRP + 8 * half + i];
+    for (int i = 0; i < 8; ++i) t8[i] = sr[i];
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sp_split2(t8[2 * i], t8[2 * i + 1], q1[i], q2[i], q3[i]);
     bf[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     bf[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
     bf[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next sample overwrites the scratch
   };
-  // the six MFMAs of one (o-tile, K-step): smallest terms first
-  auto mma6 = [&](f32x16 a0, int m, int ks, const uint4 (&bf)[3]) {
-    const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m * 32 + j) * BS_GP + 8 * ks + 4 * half);
-    const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4], a3 = ga[2 * 128 * BS_GP / 4];
-    a0 = sp_mfma(a3, bf[0], a0);
-    a0 = sp_mfma(a1, bf[2], a0);
-    a0 = sp_mfma(a2, bf[1], a0);
-    a0 = sp_mfma(a2, bf[0], a0);
-    a0 = sp_mfma(a1, bf[1], a0);
-    a0 = sp_mfma(a1, bf[0], a0);
-    return a0;
+  // A fragments (gy, lane = o, 8 consecutive pixels) of the four o-tiles for K-step ks
+  auto load_a = [&](int ks, uint4 (&a)[4][3]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m * 32 + j) * BS_GP + 8 * ks + 4 * half);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[m][p] = ga[p * (128 * BS_GP / 4)];
+    }
   };
+  // the 24 MFMAs of one K-step of this wave's tap: smallest terms first, consecutive MFMAs on different accumulators
+  auto mma24 = [&](const uint4 (&a)[4][3], const uint4 (&bf)[3]) {
+#define MODE_BS_TERM(PA, PB) _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = sp_mfma(a[m][PA], bf[PB], acc[m]);
+    MODE_BS_TERM(2, 0)
+    MODE_BS_TERM(0, 2)
+    MODE_BS_TERM(1, 1)
+    MODE_BS_TERM(1, 0)
+    MODE_BS_TERM(0, 1)
+    MODE_BS_TERM(0, 0)
+#undef MODE_BS_TERM
+  };
+  // one MFMA, then up to 4 vector-ALU instructions and 3 LDS instructions, n times: spreads a sample (and the next fragment reads)
+  // over the matrix instructions issued beside it
+#define MODE_BS_SPREAD(n)                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     \
+  }                                                        \
+  __builtin_amdgcn_sched_barrier(0);
 
   Item cur = item_of(s);
   __syncthreads();  // zero fill done
@@ -1225,6 +1244,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
   __syncthreads();
 
   int xbuf = 0;
+  uint4 b0[3];
+  sample(smem, prw0, pro0, b0);  // K-step 0 of the first column
   for (int t = s; t < T; t += S) {
     const bool more_items = t + S < T;
     const Item nxt = item_of(more_items ? t + S : t);
@@ -1232,29 +1253,46 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     for (int wc = 0; wc < TW; ++wc) {
       const bool last_col = wc == TW - 1;
       const bool have_next = !last_col || more_items;
-      const float4 rw0 = prw0, rw1 = prw1, rw8 = prw8;
-      const int ro0 = pro0, ro1 = pro1, ro8 = pro8;
+      const float4 rw1 = prw1, rw8 = prw8;
+      const int ro1 = pro1, ro8 = pro8;
       if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
       if (more_items) issue_xw(nxt, wc);
+      __builtin_amdgcn_sched_barrier(0);
 
-      uint4 b0[3], b1[3], b8[3];
-      sample(xw, rw0, ro0, b0);
+      uint4 a[4][3], b1[3], b8[3];
+      // K-step 0 of the own tap beside the sampling of K-step 1
+      load_a(0, a);
       sample(xw, rw1, ro1, b1);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = mma6(acc[m], m, 0, b0);
+      mma24(a, b0);
+      MODE_BS_SPREAD(24)
+      // K-step 1 beside the sampling of this wave's piece of tap 8
+      load_a(1, a);
       sample(xw, rw8, ro8, b8);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = mma6(acc[m], m, 1, b1);
-      acc8 = mma6(acc8, m8, ks8, b8);
+      mma24(a, b1);
+      MODE_BS_SPREAD(24)
+      // tap 8: o-tile m8, K-step ks8
+      {
+        const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m8 * 32 + j) * BS_GP + 8 * ks8 + 4 * half);
+        const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4], a3 = ga[2 * (128 * BS_GP / 4)];
+        acc8 = sp_mfma(a3, b8[0], acc8);
+        acc8 = sp_mfma(a1, b8[2], acc8);
+        acc8 = sp_mfma(a2, b8[1], acc8);
+        acc8 = sp_mfma(a2, b8[0], acc8);
+        acc8 = sp_mfma(a1, b8[1], acc8);
+        acc8 = sp_mfma(a1, b8[0], acc8);
+      }
+      if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);  // the other window buffer: nobody reads it now
 
       __syncthreads();  // everyone is done with this column's gy
       if (have_next) commit_col();
-      if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);
       __syncthreads();
+      // K-step 0 of the next column (after the barrier: at an item boundary its window was completed by the commit above)
+      if (have_next) sample(last_col ? smem + (xbuf ^ 1) * BW_XW : xw, prw0, pro0, b0);
     }
     cur = nxt;
     xbuf ^= 1;
   }
+#undef MODE_BS_SPREAD
 
   // partials: [tap][128 o][32 c] per (slice, z, channel group), the layout reduce_gw_win sums
   float* pb = part + ((((long long)s * gridDim.z + blockIdx.z) * NCG + cg) * BW_SLOTS) * (128 * BW_CG);
@@ -1267,6 +1305,190 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     }
   // tap 8: o-tile m8 = the share of K-step 0 (waves 0..3) + the share of K-step 1 (waves 4..7), added in that order through LDS
   float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] = acc8[r];
+  }
+  __syncthreads();
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] += acc8[r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
+}
+
+// The same contraction for the polar items (sphere_bww_polar_kernel's work items: one column of 32 pixels with nine per-tap windows,
+// staged in place per item), on the split-bf16 arithmetic: the sampling / transposition / MFMA sequence of sphere_bww_split_kernel on
+// the per-tap window layout.
+constexpr int BQ_X = ((BP_XW + 3) / 4) * 4;
+constexpr int BQ_LDS_DWORDS = BQ_X + BS_GYB + 8 * BS_SCR;
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bww_polar_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                           float* __restrict__ part, WinDims d,
+                                                                           const int* __restrict__ pitems, const float4* __restrict__ rec_w,
+                                                                           const int* __restrict__ rec_off, int nitems, int S, int s_base) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xw = smem;
+  uint32_t* gyb = reinterpret_cast<uint32_t*>(smem + BQ_X);
+  constexpr int WRP = BP_WR, CP = BP_CP;
+  const int s = blockIdx.x, cg = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, half = lane >> 5;
+  float* scr = smem + BQ_X + BS_GYB + wave * BS_SCR;
+  const long long HW = (long long)d.H * d.W;
+  const int T = nitems * d.B;
+  const int omax = d.Cog - mg * 128, cmax = d.Cig - cg * BW_CG;
+  const int sh = half, sq = j >> 3, sp8 = j & 7;
+  const int ks8 = wave >> 2, m8 = wave & 3;
+  const int gpp = tid & 15, go0 = tid >> 4;
+
+  f32x16 acc[4], acc8;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[0][r] = acc[1][r] = acc[2][r] = acc[3][r] = 0.f;
+    acc8[r] = 0.f;
+  }
+  for (int i = tid; i < BQ_LDS_DWORDS; i += NTHREADS) smem[i] = 0.f;
+
+  constexpr int NE = KT * BP_TAPW;  // 612 window words per channel
+  const int e0 = tid, e1 = tid + NTHREADS;
+  const bool has1 = e1 < NE;
+  const int k0 = e0 / BP_TAPW, k1 = (has1 ? e1 : 0) / BP_TAPW;
+  const int col0 = (e0 % BP_TAPW) / BP_WR, r0 = e0 % BP_WR;
+  const int col1 = ((has1 ? e1 : 0) % BP_TAPW) / BP_WR, r1 = (has1 ? e1 : 0) % BP_WR;
+
+  auto sample = [&](const float4 w4, const int ro, uint4 (&bf)[3]) {
+    const float* xb = xw + (8 * sq) * CP + ro;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = xb + c * CP;
+      v[c] = __builtin_fmaf(w4.w, q[WRP + 1], __builtin_fmaf(w4.z, q[1], __builtin_fmaf(w4.y, q[WRP], w4.x * q[0])));
+      asm("" : "+v"(v[c]));
+    }
+    float* sw = scr + (8 * sq) * BS_SCRP + 8 * sh + sp8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sw[c * BS_SCRP] = v[c];
+    const float* sr = scr + j * BS_SCRP + 8 * half;
+    float t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = sr[i];
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp_split2(t8[2 * i], t8[2 * i + 1], q1[i], q2[i], q3[i]);
+    bf[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    bf[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    bf[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  };
+  auto load_a = [&](int ks, uint4 (&a)[4][3]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m * 32 + j) * BS_GP + 8 * ks + 4 * half);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[m][p] = ga[p * (128 * BS_GP / 4)];
+    }
+  };
+  auto mma24 = [&](const uint4 (&a)[4][3], const uint4 (&bf)[3]) {
+#define MODE_BS_TERM(PA, PB) _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = sp_mfma(a[m][PA], bf[PB], acc[m]);
+    MODE_BS_TERM(2, 0)
+    MODE_BS_TERM(0, 2)
+    MODE_BS_TERM(1, 1)
+    MODE_BS_TERM(1, 0)
+    MODE_BS_TERM(0, 1)
+    MODE_BS_TERM(0, 0)
+#undef MODE_BS_TERM
+  };
+
+  for (int t = s; t < T; t += S) {
+    const int b = t / nitems, it = t - b * nitems;
+    const int* pi = pitems + (long long)it * BP_ITEM_INTS;
+    const int h0 = pi[0], w = pi[1];
+    __syncthreads();  // previous item consumed (first pass: zero fill done)
+    {
+      const int rb0 = pi[2 + k0], cb0 = pi[2 + KT + k0], rb1 = pi[2 + k1], cb1 = pi[2 + KT + k1];
+      const bool ok0 = cb0 + col0 < d.W, ok1 = has1 && cb1 + col1 < d.W;
+      const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW;
+      const long long a0 = ok0 ? (long long)((rb0 + r0) % d.H) * d.sh + (long long)(cb0 + col0) * d.sw : 0;
+      const long long a1 = ok1 ? (long long)((rb1 + r1) % d.H) * d.sh + (long long)(cb1 + col1) * d.sw : 0;
+#pragma unroll 1
+      for (int c8 = 0; c8 < BW_CG; c8 += 8) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const long long co = (long long)min(c8 + c, cmax - 1) * HW;
+          v0[c] = xg[co + a0];
+          v1[c] = xg[co + a1];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          xw[(c8 + c) * BP_CP + e0] = (ok0 && c8 + c < cmax) ? v0[c] : 0.f;
+          if (has1) xw[(c8 + c) * BP_CP + e1] = (ok1 && c8 + c < cmax) ? v1[c] : 0.f;
+        }
+      }
+    }
+    {
+      const int h = h0 + 2 * gpp;
+      const bool ok0 = h < d.H && w < d.W, ok1 = h + 1 < d.H && w < d.W;
+      const float* gyb0 = gy + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
+                          (ok0 ? (long long)h * d.sh + (long long)w * d.sw : 0);
+      const long long step1 = ok1 ? d.sh : 0;
+      float v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = gyb0 + (long long)min(go0 + 32 * u, omax - 1) * HW;
+        v0[u] = p[0];
+        v1[u] = p[step1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool oo = go0 + 32 * u < omax;
+        uint32_t p1, p2, p3;
+        sp_split2((ok0 && oo) ? v0[u] : 0.f, (ok1 && oo) ? v1[u] : 0.f, p1, p2, p3);
+        uint32_t* dst = gyb + (go0 + 32 * u) * BS_GP + gpp;
+        dst[0] = p1;
+        dst[128 * BS_GP] = p2;
+        dst[2 * 128 * BS_GP] = p3;
+      }
+    }
+    const long long rbase = (long long)it * BW_NREC;
+    const int px0 = 8 * sh + sp8;
+    const float4 rw0 = rec_w[rbase + wave * BW_TH + px0], rw1 = rec_w[rbase + wave * BW_TH + 16 + px0];
+    const float4 rw8 = rec_w[rbase + 8 * BW_TH + 16 * ks8 + px0];
+    const int ro0 = rec_off[rbase + wave * BW_TH + px0], ro1 = rec_off[rbase + wave * BW_TH + 16 + px0];
+    const int ro8 = rec_off[rbase + 8 * BW_TH + 16 * ks8 + px0];
+    __syncthreads();
+    uint4 a[4][3], b0[3], b1[3], b8[3];
+    sample(rw0, ro0, b0);
+    load_a(0, a);
+    sample(rw1, ro1, b1);
+    mma24(a, b0);
+    load_a(1, a);
+    sample(rw8, ro8, b8);
+    mma24(a, b1);
+    {
+      const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m8 * 32 + j) * BS_GP + 8 * ks8 + 4 * half);
+      const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4], a3 = ga[2 * (128 * BS_GP / 4)];
+      acc8 = sp_mfma(a3, b8[0], acc8);
+      acc8 = sp_mfma(a1, b8[2], acc8);
+      acc8 = sp_mfma(a2, b8[1], acc8);
+      acc8 = sp_mfma(a2, b8[0], acc8);
+      acc8 = sp_mfma(a1, b8[1], acc8);
+      acc8 = sp_mfma(a1, b8[0], acc8);
+    }
+  }
+  __syncthreads();
+  float* pb = part + ((((long long)(s_base + s) * gridDim.z + blockIdx.z) * gridDim.y + cg) * BW_SLOTS) * (128 * BW_CG);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      pb[((long long)wave * 128 + o) * BW_CG + j] = acc[m][r];
+    }
+  float* red = smem;
   if (wave < 4) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] = acc8[r];
@@ -1762,11 +1984,19 @@ static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x
   int Sp = 0;
   if (n_polar_items > 0) {
     Sp = bww_polar_splits(d, n_polar_items);
-    const size_t lds = (size_t)BP_LDS_FLOATS * sizeof(float);
-    rc = mode::allow_lds(sphere_bww_polar_kernel, lds, "mode_sphere_conv_bwd_weight_win");
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(sphere_bww_polar_kernel, dim3(Sp, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d, pitems,
-                       reinterpret_cast<const float4*>(prec_w), prec_off, n_polar_items, Sp, S);
+    if (split) {
+      const size_t lds = (size_t)BQ_LDS_DWORDS * sizeof(float);
+      rc = mode::allow_lds(sphere_bww_polar_split_kernel, lds, "mode_sphere_conv_bwd_weight_win_split");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_bww_polar_split_kernel, dim3(Sp, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d, pitems,
+                         reinterpret_cast<const float4*>(prec_w), prec_off, n_polar_items, Sp, S);
+    } else {
+      const size_t lds = (size_t)BP_LDS_FLOATS * sizeof(float);
+      rc = mode::allow_lds(sphere_bww_polar_kernel, lds, "mode_sphere_conv_bwd_weight_win");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL(sphere_bww_polar_kernel, dim3(Sp, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d, pitems,
+                         reinterpret_cast<const float4*>(prec_w), prec_off, n_polar_items, Sp, S);
+    }
     rc = mode::check_launch("mode_sphere_conv_bwd_weight_win(polar)");
     if (rc != MODE_OK) return rc;
   }
@@ -1816,15 +2046,17 @@ namespace {
 
 constexpr int AJ_PIX = TH * TW;  // 256 pixels per tile = 8 waves x 32 lanes
 
-__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const float* __restrict__ gy, const uint4* __restrict__ wps,
-                                                                         float* __restrict__ gx, WinDims d /* roles swapped: Ci = gy channels */,
-                                                                         int NCH16, const int4* __restrict__ tiles,
-                                                                         const int4* __restrict__ rec_off, const float4* __restrict__ rec_w) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// NS = 4: every adjoint list of the tile has at most four entries; NS = 6: up to six (the columns around the equator, where the
+// sampling positions of neighbouring output columns straddle a pixel boundary): slots 4 and 5 come from a second record array, read
+// when the tap is sampled (one tile in sixteen: not worth prefetch registers in a kernel at 249 VGPRs).
+template <int NS>
+__device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, const uint4* __restrict__ wps, float* __restrict__ gx,
+                                              const WinDims& d /* roles swapped: Ci = gy channels */, int NCH16, const int4 t,
+                                              const int4* __restrict__ rec_off, const float4* __restrict__ rec_w,
+                                              const int2* __restrict__ rec_off2, const float2* __restrict__ rec_w2, float* smem) {
   constexpr int WRP = WR_SMALL, CP = SP_CP;
   uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
-  const int4 t = tiles[blockIdx.x];
-  const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w;
+  const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
   const int b = blockIdx.y;
   const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
@@ -1834,12 +2066,20 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
   const long long rbase_idx = (long long)blockIdx.x * KT * AJ_PIX + wave * 32 + (lane & 31);
   const int4* rop = rec_off + rbase_idx;
   const float4* rwp = rec_w + rbase_idx;
-  int4 ro[3];   // ring over taps k, k + 1, k + 2 (slot = tap % 3; nine taps keep the slots aligned across chunks)
-  float4 rw[3];
-  ro[0] = rop[0];
-  rw[0] = rwp[0];
-  ro[1] = rop[AJ_PIX];
-  rw[1] = rwp[AJ_PIX];
+  const int2* rop2 = rec_off2 + rbase_idx;
+  const float2* rwp2 = rec_w2 + rbase_idx;
+  // the record of the tap sampled in this iteration (o_use) and of the one after it (o_next, requested a tap ahead: L2-resident,
+  // shared by all samples and layers of the geometry)
+  int4 o_use = rop[0], o_next = rop[AJ_PIX];
+  float4 w_use = rwp[0], w_next = rwp[AJ_PIX];
+  int2 o2_use = make_int2(0, 0), o2_next = make_int2(0, 0);
+  float2 w2_use = make_float2(0.f, 0.f), w2_next = make_float2(0.f, 0.f);
+  if (NS == 6) {
+    o2_use = rop2[0];
+    w2_use = rwp2[0];
+    o2_next = rop2[AJ_PIX];
+    w2_next = rwp2[AJ_PIX];
+  }
 
   for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
   __syncthreads();
@@ -1877,13 +2117,14 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
     }
   };
   // B fragment of this lane's pixel for one tap: G_k[o][q] for 8 channels o, <= 4 sources each, split, stored as this wave's group
-  auto sample = [&](const float* win, const int4 o4, const float4 tw, uint4* op) {
+  auto sample = [&](const float* win, const int4 o4, const float4 tw, const int2 o2, const float2 t2, uint4* op) {
     const float* p = win + half * 8 * CP;
     float v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float* q = p + c * CP;
       v[c] = __builtin_fmaf(tw.w, q[o4.w], __builtin_fmaf(tw.z, q[o4.z], __builtin_fmaf(tw.y, q[o4.y], tw.x * q[o4.x])));
+      if (NS == 6) v[c] = __builtin_fmaf(t2.y, q[o2.y], __builtin_fmaf(t2.x, q[o2.x], v[c]));
       asm("" : "+v"(v[c]));  // (keeps the chains of two channels from being SLP-packed pairwise, see sphere_fwd_split_kernel)
     }
     uint32_t q1[4], q2[4], q3[4];
@@ -1915,7 +2156,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
   __syncthreads();
-  sample(smem, ro[0], rw[0], opbuf);
+  sample(smem, o_use, w_use, o2_use, w2_use, opbuf);
   sp_lds_barrier();
 
   for (int ch = 0; ch < NCH16; ++ch) {
@@ -1928,9 +2169,17 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
       const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
 #pragma unroll
       for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
-      // records of tap k + 2 (the same nine for every chunk; L2-resident, shared by all samples and layers of the geometry)
-      ro[(k + 2) % 3] = rop[((k + 2) % KT) * AJ_PIX];
-      rw[(k + 2) % 3] = rwp[((k + 2) % KT) * AJ_PIX];
+      // this iteration samples tap k + 1 with the record requested one iteration ago; the record of tap k + 2 is requested now
+      o_use = o_next;
+      w_use = w_next;
+      o_next = rop[((k + 2) % KT) * AJ_PIX];
+      w_next = rwp[((k + 2) % KT) * AJ_PIX];
+      if (NS == 6) {
+        o2_use = o2_next;
+        w2_use = w2_next;
+        o2_next = rop2[((k + 2) % KT) * AJ_PIX];
+        w2_next = rwp2[((k + 2) % KT) * AJ_PIX];
+      }
       if (k < 4) {
         issue(chn, 2 * k, 2 * k);
         issue(chn, 2 * k + 1, 2 * k + 1);
@@ -1942,10 +2191,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
       for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
         for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
-      if (k + 1 < KT)
-        sample(cur, ro[(k + 1) % 3], rw[(k + 1) % 3], opw);
-      else
-        sample(nxt, ro[0], rw[0], opw);
+      sample(k + 1 < KT ? cur : nxt, o_use, w_use, o2_use, w2_use, opw);
 #define MODE_SP_TERM(PA, PB) \
   _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
       MODE_SP_TERM(2, 0)
@@ -1955,9 +2201,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
       MODE_SP_TERM(0, 1)
       MODE_SP_TERM(0, 0)
 #undef MODE_SP_TERM
-      if (k >= 4 && k < 8) {
-        commit(chn, 2 * (k - 4), 2 * (k - 4), nxt);
-        commit(chn, 2 * (k - 4) + 1, 2 * (k - 4) + 1, nxt);
+      if (k >= 2 && k < 6) {  // two taps after their loads were issued (24 staging registers live at most, not 32)
+        commit(chn, 2 * (k - 2), 2 * (k - 2), nxt);
+        commit(chn, 2 * (k - 2) + 1, 2 * (k - 2) + 1, nxt);
       }
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
@@ -1985,6 +2231,19 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const f
       }
     }
   }
+}
+
+__global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const float* __restrict__ gy, const uint4* __restrict__ wps,
+                                                                         float* __restrict__ gx, WinDims d, int NCH16,
+                                                                         const int4* __restrict__ tiles, const int4* __restrict__ rec_off,
+                                                                         const float4* __restrict__ rec_w, const int2* __restrict__ rec_off2,
+                                                                         const float2* __restrict__ rec_w2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int4 t = tiles[blockIdx.x];
+  if ((t.w >> 16) == 0)
+    bwd_data_tile<4>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem);
+  else
+    bwd_data_tile<6>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem);
 }
 
 // wps[(((((g*MG + mg)*NCH16 + ch)*KT + tap)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[o = g*Cog' + ch*16 + 8*(lane>>5) + j]
@@ -2025,14 +2284,17 @@ __global__ void pack_w_win_split_t(const float* __restrict__ w, uint4* __restric
 // Host-side plan of the adjoint windows (stride 1, output grid = input grid).  For every 64 x 4 tile of INPUT pixels q (same tiling as
 // mode_sphere_plan_build) it collects L(k, q) for all nine taps and all pixels of the tile.  A tile is "good" when every list has at
 // most 4 entries and all their source pixels lie in one window of WR_SMALL rows x WC columns:
-//   good_tiles[4 i ..] = (h0, w0, rbase, cbase);   rec_off / rec_w [((i * 9 + tap) * 256 + pixel) * 4 + slot], pixel =
+//   good_tiles[4 i ..] = (h0, w0, rbase, cbase | six << 16), six = 1 when some list of the tile has 5 or 6 entries (slots 4, 5 in
+//   rec_off2 / rec_w2 [((i * 9 + tap) * 256 + pixel) * 2 + slot - 4]; lists longer than 6 make a tile bad);
+//   rec_off / rec_w [((i * 9 + tap) * 256 + pixel) * 4 + slot], pixel =
 //   ((rowblock * 4 + column) * 32 + row) -- the lane order of the kernel; offset = (source column - cbase) * WR_SMALL + (source row -
 //   rbase) mod H, unused slots (0, 0.0f); slots in ascending source-pixel order (the gather kernel's summation order).
 //   bad_tiles[2 j ..] = (h0, w0) of the others.  counts = (good, bad).
 extern "C" int mode_sphere_adjplan_build(const float* pos_host, int H, int W, int Kh, int Kw, int32_t* good_tiles, int32_t* bad_tiles,
-                                         int32_t* counts, int32_t* rec_off_host, float* rec_w_host) {
-  MODE_REQUIRE(pos_host && good_tiles && bad_tiles && counts && rec_off_host && rec_w_host, MODE_ERR_BAD_ARG,
-               "mode_sphere_adjplan_build: null pointer");
+                                         int32_t* counts, int32_t* rec_off_host, float* rec_w_host, int32_t* rec_off2_host,
+                                         float* rec_w2_host) {
+  MODE_REQUIRE(pos_host && good_tiles && bad_tiles && counts && rec_off_host && rec_w_host && rec_off2_host && rec_w2_host,
+               MODE_ERR_BAD_ARG, "mode_sphere_adjplan_build: null pointer");
   MODE_REQUIRE(H > 0 && W > 0 && Kh * Kw == KT, MODE_ERR_BAD_ARG, "mode_sphere_adjplan_build: needs a positive size and %d taps", KT);
   const long long HW = (long long)H * W;
   MODE_REQUIRE((long long)KT * HW * 4 < (1ll << 31), MODE_ERR_UNSUPPORTED, "mode_sphere_adjplan_build: table too large");
@@ -2079,20 +2341,27 @@ extern "C" int mode_sphere_adjplan_build(const float* pos_host, int H, int W, in
   }
   const int nth = mode::cdiv(H, TH), ntw = mode::cdiv(W, TW);
   int ngood = 0, nbad = 0;
+  struct GoodTile {
+    int h0, w0, rbase, cbase, six;
+  };
+  std::vector<GoodTile> good;
   for (int hg = 0; hg < nth; hg += kNumXCD)  // tile order as in mode_sphere_plan_build (tiles sharing rows meet on one XCD)
     for (int tw = 0; tw < ntw; ++tw)
       for (int hs = 0; hs < kNumXCD && hg + hs < nth; ++hs) {
         const int h0 = (hg + hs) * TH, w0 = tw * TW;
         bool ok = h0 + TH <= H && w0 + TW <= W;  // whole tiles only: ragged edges stay on the gather kernel
+        bool six = false;                        // some list has 5 or 6 entries: the 6-slot class
         int dmin = 1 << 30, dmax = -(1 << 30), cmin = 1 << 30, cmax = -(1 << 30);
         for (int k = 0; k < KT && ok; ++k)
           for (int h = h0; h < h0 + TH && ok; ++h)
             for (int w = w0; w < w0 + TW; ++w) {
               const size_t row = (size_t)k * HW + (size_t)h * W + w;
-              if (rowptr[row + 1] - rowptr[row] > 4) {
+              const int nent = rowptr[row + 1] - rowptr[row];
+              if (nent > 6) {
                 ok = false;
                 break;
               }
+              if (nent > 4) six = true;
               for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
                 const int hp = ep[e] / W, wp = ep[e] % W;
                 int dr = (hp - h0) % H;
@@ -2116,26 +2385,40 @@ extern "C" int mode_sphere_adjplan_build(const float* pos_host, int H, int W, in
           ++nbad;
           continue;
         }
-        int32_t* tl = good_tiles + 4 * (size_t)ngood;
-        tl[0] = h0; tl[1] = w0; tl[2] = rbase; tl[3] = cbase;
-        for (int k = 0; k < KT; ++k)
-          for (int pix = 0; pix < AJ_PIX; ++pix) {
-            const int wv = pix >> 5, h = h0 + (wv / TW) * 32 + (pix & 31), w = w0 + (wv % TW);
-            const size_t row = (size_t)k * HW + (size_t)h * W + w;
-            const size_t o = (((size_t)ngood * KT + k) * AJ_PIX + pix) * 4;
-            for (int s = 0; s < 4; ++s) {
-              rec_off_host[o + s] = 0;
-              rec_w_host[o + s] = 0.f;
-            }
-            int s = 0;
-            for (int e = rowptr[row]; e < rowptr[row + 1]; ++e, ++s) {
-              const int hp = ep[e] / W, wp = ep[e] % W;
-              rec_off_host[o + s] = (wp - cbase) * WR_SMALL + ((hp - rbase) % H + H) % H;
-              rec_w_host[o + s] = ew[e];
-            }
-          }
-        ++ngood;
+        good.push_back({h0, w0, rbase, cbase, six ? 1 : 0});
       }
+  // the 6-slot tiles first: they are the slowest workgroups of the launch, and started first they end inside its last round
+  std::stable_sort(good.begin(), good.end(), [](const GoodTile& a, const GoodTile& b2) { return a.six > b2.six; });
+  for (const GoodTile& gt : good) {
+    const int h0 = gt.h0, w0 = gt.w0, rbase = gt.rbase, cbase = gt.cbase;
+    int32_t* tl = good_tiles + 4 * (size_t)ngood;
+    tl[0] = h0; tl[1] = w0; tl[2] = rbase; tl[3] = cbase | (gt.six << 16);
+    for (int k = 0; k < KT; ++k)
+      for (int pix = 0; pix < AJ_PIX; ++pix) {
+        const int wv = pix >> 5, h = h0 + (wv / TW) * 32 + (pix & 31), w = w0 + (wv % TW);
+        const size_t row = (size_t)k * HW + (size_t)h * W + w;
+        const size_t o = (((size_t)ngood * KT + k) * AJ_PIX + pix) * 4, o2 = o / 2;
+        for (int s = 0; s < 4; ++s) {
+          rec_off_host[o + s] = 0;
+          rec_w_host[o + s] = 0.f;
+        }
+        rec_off2_host[o2] = rec_off2_host[o2 + 1] = 0;
+        rec_w2_host[o2] = rec_w2_host[o2 + 1] = 0.f;
+        int s = 0;
+        for (int e = rowptr[row]; e < rowptr[row + 1]; ++e, ++s) {
+          const int hp = ep[e] / W, wp = ep[e] % W;
+          const int off = (wp - cbase) * WR_SMALL + ((hp - rbase) % H + H) % H;
+          if (s < 4) {
+            rec_off_host[o + s] = off;
+            rec_w_host[o + s] = ew[e];
+          } else {
+            rec_off2_host[o2 + s - 4] = off;
+            rec_w2_host[o2 + s - 4] = ew[e];
+          }
+        }
+      }
+    ++ngood;
+  }
   counts[0] = ngood;
   counts[1] = nbad;
   return MODE_OK;
@@ -2155,8 +2438,9 @@ extern "C" int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int group
 // gx (written, not added to) on the n_tiles good tiles of the adjoint plan; `transposed`: gy and gx are plane-transposed (B, C, W, H).
 // The caller runs mode_sphere_conv_bwd_data_adj_list on the plan's bad tiles.
 extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles,
-                                                   int n_tiles, const int32_t* rec_off, const float* rec_w, int B, int Ci, int H, int W,
-                                                   int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+                                                   int n_tiles, const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2,
+                                                   const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                                   int transposed, mode_stream_t stream) {
   const char* who = "mode_sphere_conv_bwd_data_win_split";
   WinDims d;
   int rc = make_win_dims(d, B, Co, H, W, Ci, Kh, Kw, groups, who);  // roles swapped: this GEMM reduces over the layer's output channels
@@ -2169,7 +2453,7 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
     d.sw = H;
   }
   if (B == 0 || n_tiles == 0) return MODE_OK;
-  MODE_REQUIRE(gy && w && gx && wpack && tiles && rec_off && rec_w, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  MODE_REQUIRE(gy && w && gx && wpack && tiles && rec_off && rec_w && rec_off2 && rec_w2, MODE_ERR_BAD_ARG, "%s: null pointer", who);
   MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "%s: grid limit", who);
   hipStream_t st = mode::as_stream(stream);
   const int NCH16 = d.Cig / SP_CCH;
@@ -2179,6 +2463,7 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
   rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP_LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP_LDS_BYTES, st, gy, wps, gx, d, NCH16,
-                     reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w));
+                     reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w),
+                     reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2));
   return mode::check_launch(who);
 }

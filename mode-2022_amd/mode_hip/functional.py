@@ -631,8 +631,10 @@ def sphere_adjplan(pos, kh, kw):
       counts = torch.zeros(2, dtype=torch.int32)
       rec_off = torch.zeros(n * 9 * 256 * 4, dtype=torch.int32)
       rec_w = torch.zeros(n * 9 * 256 * 4, dtype=torch.float32)
-      check(lib().mode_sphere_adjplan_build(ptr(host), H, W, kh, kw, ptr(good), ptr(bad), ptr(counts), ptr(rec_off), ptr(rec_w)),
-            'mode_sphere_adjplan_build')
+      rec_off2 = torch.zeros(n * 9 * 256 * 2, dtype=torch.int32)
+      rec_w2 = torch.zeros(n * 9 * 256 * 2, dtype=torch.float32)
+      check(lib().mode_sphere_adjplan_build(ptr(host), H, W, kh, kw, ptr(good), ptr(bad), ptr(counts), ptr(rec_off), ptr(rec_w), ptr(rec_off2),
+                                            ptr(rec_w2)), 'mode_sphere_adjplan_build')
       ng, nb = int(counts[0]), int(counts[1])
       if ng > 0:
         # a bad tile (h0, w0) = the 64-pixel runs h0 .. h0 + 63 of the stored rows w0 .. w0 + 3 of the (W, H) planes
@@ -641,7 +643,8 @@ def sphere_adjplan(pos, kh, kw):
         ids = ids.reshape(-1).sort().values.to(torch.int32)
         dev = pos.device
         plan = (good[:4 * ng].contiguous().to(dev), ng, rec_off[:ng * 9 * 256 * 4].contiguous().to(dev),
-                rec_w[:ng * 9 * 256 * 4].contiguous().to(dev), ids.contiguous().to(dev) if nb else None, int(ids.numel()))
+                rec_w[:ng * 9 * 256 * 4].contiguous().to(dev), ids.contiguous().to(dev) if nb else None, int(ids.numel()),
+                rec_off2[:ng * 9 * 256 * 2].contiguous().to(dev), rec_w2[:ng * 9 * 256 * 2].contiguous().to(dev))
     _adjplan_cache[key] = (plan, pos)  # keep `pos` alive: the key uses its address
     return plan
 
@@ -664,10 +667,11 @@ def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
   with torch.cuda.device_of(gyt), profiling.region('sphere_conv_bwd_data[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, gyt.device):
     wp = _wpack(w, groups)
     if aplan is not None:
-      tiles, ng, rec_off, rec_w, bad_ids, nbad = aplan
+      tiles, ng, rec_off, rec_w, bad_ids, nbad, rec_off2, rec_w2 = aplan
       wps = torch.empty(lib().mode_sphere_conv_bwd_data_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
-      check(lib().mode_sphere_conv_bwd_data_win_split(ptr(gyt), ptr(w), ptr(gxt), ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w), B, Ci,
-                                                      H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)), 'mode_sphere_conv_bwd_data_win_split')
+      check(lib().mode_sphere_conv_bwd_data_win_split(ptr(gyt), ptr(w), ptr(gxt), ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w),
+                                                      ptr(rec_off2), ptr(rec_w2), B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)),
+            'mode_sphere_conv_bwd_data_win_split')
       if nbad:  # the tiles next to the poles and the few columns with more than four sources per tap: gather kernel on a tile list
         check(lib().mode_sphere_conv_bwd_data_adj_list(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co,
                                                        Kh, Kw, W, H, groups, 0, ptr(bad_ids), nbad, stream_of(gyt)),

@@ -220,8 +220,9 @@ def test_adjoint_window_plan_reproduces_the_adjoint_table(ih, iw):
   n = lib.mode_sphere_plan_max_tiles(H, W)
   good, bad, counts = torch.zeros(4 * n, dtype=torch.int32), torch.zeros(2 * n, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
   rec_off, rec_w = torch.zeros(n * 9 * 256 * 4, dtype=torch.int32), torch.zeros(n * 9 * 256 * 4, dtype=torch.float32)
+  rec_off2, rec_w2 = torch.zeros(n * 9 * 256 * 2, dtype=torch.int32), torch.zeros(n * 9 * 256 * 2, dtype=torch.float32)
   assert lib.mode_sphere_adjplan_build(mode_hip.ptr(pos), H, W, 3, 3, mode_hip.ptr(good), mode_hip.ptr(bad), mode_hip.ptr(counts),
-                                       mode_hip.ptr(rec_off), mode_hip.ptr(rec_w)) == 0
+                                       mode_hip.ptr(rec_off), mode_hip.ptr(rec_w), mode_hip.ptr(rec_off2), mode_hip.ptr(rec_w2)) == 0
   ng, nb = counts.tolist()
   assert ng > 0 and ng + nb == n
   g, b = good[:4 * ng].view(ng, 4).numpy(), bad[:2 * nb].view(nb, 2).numpy()
@@ -231,18 +232,24 @@ def test_adjoint_window_plan_reproduces_the_adjoint_table(ih, iw):
   assert lib.mode_sphere_adjoint_build(mode_hip.ptr(pos), H, W, 3, 3, 1, 1, H, W, mode_hip.ptr(rowptr), mode_hip.ptr(entries),
                                        ctypes.cast(ctypes.pointer(ne), ctypes.c_void_p)) == 0
   rp, ent = rowptr.numpy(), entries[:2 * ne.value].view(-1, 2).numpy()
-  ro, rw = rec_off[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy(), rec_w[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy()
+  ro = np.concatenate((rec_off[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy(), rec_off2[:ng * 9 * 256 * 2].view(ng, 9, 256, 2).numpy()), -1)
+  rw = np.concatenate((rec_w[:ng * 9 * 256 * 4].view(ng, 9, 256, 4).numpy(), rec_w2[:ng * 9 * 256 * 2].view(ng, 9, 256, 2).numpy()), -1)
   assert (ro >= 0).all() and (ro < 8 * 81).all()
-  for i in (0, ng // 2, ng - 1):
+  six = (g[:, 3] >> 16) == 1
+  assert ((ro[~six][..., 4:] == 0) & (rw[~six][..., 4:] == 0)).all()  # the 4-slot class never uses slots 4, 5
+  if (ih, iw) == (128, 256):
+    assert sorted(set(g[six][:, 1].tolist())) == [60, 64] and ng == 112  # the equator columns 63..65; all but the 16 polar tiles planned
+  for i in [0, ng // 2, ng - 1] + np.nonzero(six)[0][:2].tolist():
     h0, w0, rbase, cbase = [int(v) for v in g[i]]
+    cbase &= 0xffff
     for k in range(9):
       for pix in (0, 31, 100, 255):
         wv = pix >> 5
         h, w = h0 + (wv // 4) * 32 + (pix & 31), w0 + (wv % 4)
         row = k * H * W + h * W + w
         lst = ent[rp[row]:rp[row + 1]]
-        assert len(lst) <= 4
-        for s in range(4):
+        assert len(lst) <= (6 if six[i] else 4)
+        for s in range(6):
           if s < len(lst):
             hp, wp = divmod(int(lst[s, 0]), W)
             assert ro[i, k, pix, s] == (wp - cbase) * 81 + (hp - rbase) % H
