@@ -1134,28 +1134,34 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       for (int c = 0; c < BW_NXW; ++c) dst[(part * BW_NXW + c) * BW_CP] = (pxw_ok && part * BW_NXW + c < cmax) ? pxw[c] : 0.f;
     }
   };
-  // gy column staging: thread -> (o = (tid >> 4) + 32 u, pixel pair tid & 15): two pixels per value pair, split into packed bf16 dwords
+  // gy is requested TWO columns ahead (a column lasts ~1.5 us, less than a trip to HBM under load: with one column of lead the
+  // commit between the two barriers waited for it -- measured 0.08 ms of a 0.36 ms call), into two register sets
   const int gpp = tid & 15, go0 = tid >> 4;
-  float pg0[4], pg1[4];
-  unsigned pgy_ok = 0;  // bit 2u: first pixel of pair real, bit 2u + 1: second
+  struct GyPF {
+    float g0[4], g1[4];
+    unsigned ok;  // bit 2u: first pixel of pair real, bit 2u + 1: second
+  };
+  GyPF gpf[2];
   // records of the next column: own tap at K-steps 0 / 1, tap 8 at K-step ks8 -- for the pixel this lane samples
   float4 prw0, prw1, prw8;
   int pro0, pro1, pro8;
-  auto issue_col = [&](const Item& it, int wc) {
+  auto issue_gy = [&](const Item& it, int wc, GyPF& pf) {
     const int h = it.h0 + 2 * gpp, w = it.w0 + wc;
     const bool ok0 = h < d.H && w < d.W, ok1 = h + 1 < d.H && w < d.W;
     const float* gyb0 = gy + ((long long)it.b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
                         (ok0 ? (long long)h * d.sh + (long long)w * d.sw : 0);
     const long long step1 = ok1 ? d.sh : 0;
-    pgy_ok = 0;
+    pf.ok = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int o = go0 + 32 * u;
       const float* p = gyb0 + (long long)min(o, omax - 1) * HW;
-      pg0[u] = p[0];
-      pg1[u] = p[step1];
-      pgy_ok |= ((ok0 && o < omax) ? 1u : 0u) << (2 * u) | ((ok1 && o < omax) ? 2u : 0u) << (2 * u);
+      pf.g0[u] = p[0];
+      pf.g1[u] = p[step1];
+      pf.ok |= ((ok0 && o < omax) ? 1u : 0u) << (2 * u) | ((ok1 && o < omax) ? 2u : 0u) << (2 * u);
     }
+  };
+  auto issue_rec = [&](const Item& it, int wc) {  // records: L2-resident, one column of lead is plenty
     const long long rcol = (((long long)it.ti * 2 + it.hf) * TW + wc) * BW_NREC;
     const int px0 = 8 * sh + sp8;
     prw0 = rec_w[rcol + wave * BW_TH + px0];
@@ -1165,10 +1171,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     prw8 = rec_w[rcol + 8 * BW_TH + 16 * ks8 + px0];
     pro8 = rec_off[rcol + 8 * BW_TH + 16 * ks8 + px0];
   };
-  auto commit_col = [&]() {
+  auto commit_col = [&](const GyPF& pf) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float a = (pgy_ok >> (2 * u) & 1u) ? pg0[u] : 0.f, b2 = (pgy_ok >> (2 * u + 1) & 1u) ? pg1[u] : 0.f;
+      const float a = (pf.ok >> (2 * u) & 1u) ? pf.g0[u] : 0.f, b2 = (pf.ok >> (2 * u + 1) & 1u) ? pf.g1[u] : 0.f;
       uint32_t p1, p2, p3;
       sp_split2(a, b2, p1, p2, p3);
       uint32_t* dst = gyb + (go0 + 32 * u) * BS_GP + gpp;
@@ -1239,8 +1245,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     issue_xw(cur, part);
     commit_xw(smem, part);
   }
-  issue_col(cur, 0);
-  commit_col();
+  issue_gy(cur, 0, gpf[0]);
+  issue_rec(cur, 0);
+  commit_col(gpf[0]);
+  issue_gy(cur, 1, gpf[1]);
   __syncthreads();
 
   int xbuf = 0;
@@ -1250,12 +1258,18 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     const bool more_items = t + S < T;
     const Item nxt = item_of(more_items ? t + S : t);
     const float* xw = smem + xbuf * BW_XW;
-    for (int wc = 0; wc < TW; ++wc) {
+#pragma unroll
+    for (int wc = 0; wc < TW; ++wc) {  // (unrolled: the gy register set of a column is wc % 2)
       const bool last_col = wc == TW - 1;
       const bool have_next = !last_col || more_items;
       const float4 rw1 = prw1, rw8 = prw8;
       const int ro1 = pro1, ro8 = pro8;
-      if (have_next) issue_col(last_col ? nxt : cur, last_col ? 0 : wc + 1);
+      // gy of the column after next (its register set held this column's gy, committed at the end of the previous column)
+      if (wc < 2)
+        issue_gy(cur, wc + 2, gpf[wc & 1]);
+      else if (more_items)
+        issue_gy(nxt, wc - 2, gpf[wc & 1]);
+      if (have_next) issue_rec(last_col ? nxt : cur, last_col ? 0 : wc + 1);
       if (more_items) issue_xw(nxt, wc);
       __builtin_amdgcn_sched_barrier(0);
 
@@ -1284,7 +1298,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);  // the other window buffer: nobody reads it now
 
       __syncthreads();  // everyone is done with this column's gy
-      if (have_next) commit_col();
+      if (have_next) commit_col(gpf[(wc + 1) & 1]);
       __syncthreads();
       // K-step 0 of the next column (after the barrier: at an item boundary its window was completed by the commit above)
       if (have_next) sample(last_col ? smem + (xbuf ^ 1) * BW_XW : xw, prw0, pro0, b0);
