@@ -359,6 +359,12 @@ int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue*
  * more than one output channel).  mode_conv3d_fwd_split takes an optional folded-BatchNorm epilogue (NULL: plain convolution);
  * wpack as mode_conv3d_fwd; mode_conv3d_bwd_weight_split: arguments and workspace as mode_conv3d_bwd_weight with stride 1. */
 int mode_conv3d_split_supported(int Ci, int Co, int stride, int which /* 0 forward, 1 input gradient, 2 weight gradient */);
+/* Stride-2 forward (k3 p1) on the split-bf16 kernel (csrc/conv3d_split_s2.hip): hourglass conv1 / conv3 (mode_disparity.py:17-19) and
+ * the input gradient of the transposed convolutions conv5 / conv6 (w = their (Cin, Cout, 27) weight read as (Co = Cin, Ci = Cout));
+ * 33..64 output channels, input channels a multiple of 8: mode_conv3d_split_supported(Ci, Co, 2, 0) == 1. */
+int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
+                             mode_stream_t stream);
+
 int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int D,
                           int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,

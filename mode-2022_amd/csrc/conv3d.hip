@@ -538,11 +538,14 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
   const size_t b = (size_t)mode::cdiv(Ci, 32) * mode::cdiv(Co, CCH) * 27 * 256;
   size_t n = (f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32);  // + the folded BatchNorm shifts
   n = std::max(n, std::max(mode::conv3d_split_wpack_floats(Ci, Co), mode::conv3d_split_wpack_floats(Co, Ci)));
+  n = std::max(n, mode::conv3d_s2_split_wpack_floats(Ci, Co));
   return n * sizeof(float);
 }
 
 extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int which) {
-  if (stride != 1 || Ci <= 0 || Co <= 0) return 0;
+  if (Ci <= 0 || Co <= 0) return 0;
+  if (stride == 2) return (which == 0 && mode::conv3d_s2_split_supported(Ci, Co)) ? 1 : 0;  // forward only (mode_conv3d_fwd_s2_split)
+  if (stride != 1) return 0;
   if (which == 2) return Co > 1;  // weight gradient: any channel counts (32 x 32 blocks, masked)
   return which == 1 ? mode::conv3d_split_supported(Co, Ci) : mode::conv3d_split_supported(Ci, Co);
 }
@@ -554,6 +557,16 @@ extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_
   if (rc == MODE_OK && bn) rc = mode::check_bn(bn, who);
   if (rc != MODE_OK || B == 0) return rc;
   return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, bn);
+}
+
+// Stride-2 forward on the split-bf16 kernel of conv3d_split_s2.hip (also the input gradient of the transposed convolution, with
+// w = its (Cin, Cout, 27) weight read as (Co = Cin, Ci = Cout)); needs mode_conv3d_split_supported(Ci, Co, 2, 0) == 1.
+extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
+                                        mode_stream_t stream) {
+  const char* who = "mode_conv3d_fwd_s2_split";
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who);
 }
 
 extern "C" int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,

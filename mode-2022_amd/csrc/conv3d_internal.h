@@ -24,6 +24,13 @@ size_t conv3d_split_wpack_floats(int K, int rows);
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
                     hipStream_t st, const char* who, const mode_bn_epilogue* bn);
 
+// conv3d_split_s2.hip: the stride-2 forward (= input gradient of the transposed convolution) on the same arithmetic; rows = output
+// channels (33..64), K = reduction channels (multiple of 8); w is (rows, K, 27); wpack >= conv3d_s2_split_wpack_floats(K, rows).
+bool conv3d_s2_split_supported(int K, int rows);
+size_t conv3d_s2_split_wpack_floats(int K, int rows);
+int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
+                    const char* who);
+
 // conv3d_split_wgrad.hip: split-K partials of the stride-1 weight gradient on the split-bf16 matrix path, written in the layout of
 // conv3d.hip's weight-gradient kernels (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.
 struct WgradSplitDims {

@@ -1,0 +1,328 @@
+// 3x3x3 STRIDE-2 convolution (pad 1) of the 3D regulariser on the bf16 matrix pipe with fp32 operands split exactly into three bf16
+// pieces -- the arithmetic and the structure of conv3d_split.hip (read that file first), re-tiled for stride 2.
+//
+// Reference: hourglass conv1 / conv3 (models/mode_disparity.py:17-19: Conv3d k3 s2 p1, 32 -> 64 and 64 -> 64) and, with the roles of
+// input and output gradient exchanged, the input gradient of the two transposed convolutions conv5 / conv6 (:23-25).
+//
+// D[i = o][j = 32 consecutive output columns wo], K of one MFMA = 8 input channels x 2 taps, 14 tap pairs per 8-channel chunk, as for
+// stride 1.  What changes is the LDS tile: output voxel (od, oh, wo) reads input (2 od + kd - 1, 2 oh + kh - 1, 2 wo + kw - 1), so
+//   * an output tile of 1 x 2 rows x 32 columns needs 3 x 5 input rows of 65 columns: 990 positions of 8 channels x 3 pieces = 46 KB
+//     per chunk, double-buffered 96 KB (a 2 x 8-row tile as for stride 1 would need 265 KB);
+//   * the B fragment of tap kw is input column 2 wo + kw for wo = 0..31 -- every second column.  Rows are therefore stored
+//     de-interleaved, [33 even columns | 33 odd columns], and the three kw become the contiguous runs starting at slots 0, 33 and 1:
+//     conflict-free ds_read_b128 as for stride 1.
+// Four waves = 2 output-channel tiles (the stride-2 layers of the network all have 64 output channels) x 2 halves of the tap pairs
+// (wave w takes the pairs of parity w / 2 for BOTH output rows: two independent accumulators to alternate between -- one accumulator
+// per wave would chain 84 dependent MFMAs); the two halves of a tile are added through LDS when the tile's last chunk is done.
+// 84 MFMAs per wave and chunk against 4 staged positions per thread -- four times less matrix work per staged position than stride 1,
+// which is what bounds this kernel (the loads of a chunk sit under tap pairs 0..3, their split and LDS stores under pairs 10..13).
+// Persistent workgroups, XCD-contiguous tile ranges, weights split and packed once per launch: conv3d_split.hip.
+#include "common.h"
+
+#include "conv3d_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 256;
+constexpr int TD = 1, TH = 2;                    // output rows of a tile (depth x height); 32 output columns
+constexpr int ID = 2 * TD + 1, IH = 2 * TH + 1;  // haloed input planes / rows
+constexpr int IWH = 33, IW = 2 * IWH;            // 65 input columns stored as [33 even | 33 odd] (the last odd slot is unused)
+constexpr int ROWS = ID * IH;                    // 15
+constexpr int ITEMS = ROWS * IW;                 // 990 positions per chunk
+constexpr int KIT = (ITEMS + NT - 1) / NT;       // 4 positions per thread
+constexpr int PIECE = KIT * NT;                  // 1 024
+constexpr int BUF = 3 * PIECE;                   // uint4 per buffer
+constexpr int NPAIR = 14;
+constexpr int MT = 2;                            // output-channel tiles per launch
+constexpr int RED_FLOATS = 2 * TH * 16 * 64;  // the odd-pair waves' accumulators: [2 m][2 rows][16][64 lanes]
+constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 98 304 + 16 384 B
+
+struct S2Dims {
+  int B, K, Co, D, H, W;  // input volume; K = reduction channels
+  int Do, Ho, Wo;
+  int nWt, nHt, nDt, NCHUNK, ntiles;
+};
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = pack2(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  p3 = pack2(sa, sb);
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of W(o = m*32 + (lane & 31), c = ch*8 + j,
+// tap = 2 * pair + (lane >> 5)), j = 0..7; zero for tap 27, o >= rows, c >= K.  W is (rows, K, 27) as stored for both uses: the
+// forward layer's weight (Co, Ci, 27), and the transposed convolution's weight (Cin, Cout, 27) read as (rows = Cin, K = Cout).
+__global__ void pack_w3d_s2_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MTr, int NCHUNK) {
+  const long long total = (long long)MTr * NCHUNK * NPAIR * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int pair = (int)(r % NPAIR);
+    r /= NPAIR;
+    const int ch = (int)(r % NCHUNK);
+    const int m = (int)(r / NCHUNK);
+    const int o = m * 32 + (lane & 31);
+    const int tap = 2 * pair + (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * 8 + j;
+      v[j] = (o < rows && c < K && tap < 27) ? w[((long long)o * K + c) * 27 + tap] : 0.f;
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wp + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+__host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of a tap relative to the output voxel's origin
+  return ((tap / 9) * IH + (tap / 3) % 3) * IW + (tap % 3 == 0 ? 0 : tap % 3 == 1 ? IWH : 1);
+}
+
+__global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                             float* __restrict__ y, S2Dims d) {
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][PIECE]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = wave & 1, kpar = wave >> 1;  // this wave's output-channel tile and the parity of the tap pairs it takes
+  float* red = reinterpret_cast<float*>(sm + 2 * BUF) + m * (TH * 16 * 64);
+
+  const int nwx = gridDim.x / kNumXCD;
+  const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+  const int q = d.ntiles / kNumXCD, rr = d.ntiles % kNumXCD;
+  const int t_begin = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+  const int t_count = xcd < rr ? q + 1 : q;
+  const int mine = slot < t_count ? (t_count - slot + nwx - 1) / nwx : 0;
+  const int G = mine * d.NCHUNK;
+
+  const long long HW = (long long)d.H * d.W;
+  const long long DHW = (long long)d.D * HW;
+  const long long oHW = (long long)d.Ho * d.Wo, oDHW = (long long)d.Do * oHW;
+
+  auto tile_of = [&](int k, int& b, int& d0, int& h0, int& w0) {  // output coordinates of the tile's first voxel
+    int t = t_begin + slot + k * nwx;
+    w0 = (t % d.nWt) * 32;
+    t /= d.nWt;
+    h0 = (t % d.nHt) * TH;
+    t /= d.nHt;
+    d0 = (t % d.nDt) * TD;
+    b = t / d.nDt;
+  };
+
+  // staging: position k of this thread is (input plane, row, column) = (pdz, phy, pwx)[k] of the haloed tile, stored at slot tid + k NT
+  int pdz[KIT], phy[KIT], pwx[KIT], poff[KIT];
+#pragma unroll
+  for (int k = 0; k < KIT; ++k) {
+    const int item = min(tid + k * NT, ITEMS - 1);
+    const int r = item / IW, s = item - r * IW;
+    pwx[k] = s < IWH ? 2 * s : 2 * (s - IWH) + 1;  // (65 for the unused last odd slot: masked by the bounds test below)
+    pdz[k] = r / IH;
+    phy[k] = r - pdz[k] * IH;
+    poff[k] = pdz[k] * (int)HW + phy[k] * d.W + pwx[k];
+  }
+  float raw[KIT][8];
+  unsigned okmask = 0;
+  const float* st_xc = x;
+  int st_base = 0, st_d0 = 0, st_h0 = 0, st_w0 = 0;  // input coordinates of the haloed tile's first voxel
+  auto stage_begin = [&](int g) {
+    int b, od, oh, ow;
+    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
+    tile_of(k_tile, b, od, oh, ow);
+    st_d0 = 2 * od - 1;
+    st_h0 = 2 * oh - 1;
+    st_w0 = 2 * ow - 1;
+    st_xc = x + ((long long)b * d.K + ch * 8) * DHW;
+    st_base = st_d0 * (int)HW + st_h0 * d.W + st_w0;
+    okmask = 0;
+  };
+  auto stage_load = [&](int k) {
+    const unsigned ok = (unsigned)((unsigned)(st_d0 + pdz[k]) < (unsigned)d.D) & (unsigned)((unsigned)(st_h0 + phy[k]) < (unsigned)d.H) &
+                        (unsigned)((unsigned)(st_w0 + pwx[k]) < (unsigned)d.W) & (unsigned)(pwx[k] < 2 * IWH - 1);
+    okmask |= ok << k;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* xcc = st_xc + (long long)c * DHW;
+      raw[k][c] = xcc[off];
+    }
+  };
+  uint32_t sq[3][4];
+  auto stage_commit = [&](int buf, int k, int h) {
+    const bool ok = (okmask >> k) & 1;
+#pragma unroll
+    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(ok ? raw[k][2 * j] : 0.f, ok ? raw[k][2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+    if (h == 1) {
+      uint4* dst = sm + buf * BUF + tid + k * NT;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[p * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
+    }
+  };
+
+  f32x16 acc[TH];
+#pragma unroll
+  for (int r = 0; r < TH; ++r) acc[r] = (f32x16){0};
+  const int half = lane >> 5;
+  const int rowpos = lane & 31;  // origin of this lane's output voxel of row 0 (row r: + 2 r IW; TD = 1: plane 0)
+  const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
+  const uint4* wpm = wp + m * mstride;
+
+  // this wave's seven tap pairs of a chunk: pair 2 i + kpar, i = 0..6; weight fragments 3 of them ahead (ring of 4)
+  uint4 aring[4][3];
+  auto load_a = [&](int slot4, int ch, int i) {
+    const uint4* wq = wpm + ((long long)ch * NPAIR + 2 * i + kpar) * 192 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) aring[slot4][p] = wq[p * 64];
+  };
+
+  if (G > 0) {
+    stage_begin(0);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) stage_load(k);
+#pragma unroll
+    for (int k = 0; k < KIT; ++k) {
+      stage_commit(0, k, 0);
+      stage_commit(0, k, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) load_a(i, 0, i);
+  }
+  __syncthreads();
+
+  // LDS offset of the two taps of pair 2 i + kpar for this half-wave (tap 27 of the last pair reads tap 26 again: zero weights)
+  int toff[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int t0e = 4 * i, t1e = 4 * i + 1;                                  // kpar = 0: pair 2 i
+    const int t0o = 4 * i + 2, t1o = 4 * i + 3 < 27 ? 4 * i + 3 : 26;        // kpar = 1: pair 2 i + 1
+    toff[i] = kpar ? (half ? tap_off(t1o) : tap_off(t0o)) : (half ? tap_off(t1e) : tap_off(t0e));
+  }
+
+  int ch = 0, k_tile = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint4* src = sm + (g & 1) * BUF;
+    const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
+    stage_begin(min(g + 1, G - 1));  // (after the last chunk it is staged once more into the idle buffer: no branch in the body)
+    uint4 bq[2][TH][3];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos + 2 * r * IW + toff[0]];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (i + 1 < 7) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bq[(i + 1) & 1][r][p] = src[p * PIECE + rowpos + 2 * r * IW + toff[i + 1]];
+      }
+      if (i + 3 < 7)
+        load_a((i + 3) % 4, ch, i + 3);
+      else
+        load_a((i + 3) % 4, ch_next, i + 3 - 7);
+      if (i < KIT) stage_load(i);  // the next chunk: loads under this wave's first four pairs, split + stores under its last ones
+      if (i >= 7 - KIT + 1) {     // positions 0, 1 under pair 4, then one per pair (4 positions, 3 pairs left after the loads)
+        stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 0);
+        stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 1);
+      }
+      if (i == 7 - KIT + 1) {
+        stage_commit((g + 1) & 1, 0, 0);
+        stage_commit((g + 1) & 1, 0, 1);
+      }
+      // smallest terms first; consecutive MFMAs alternate between the two rows' accumulators
+#define MODE_S2_TERM(PA, PB) _Pragma("unroll") for (int r = 0; r < TH; ++r) acc[r] = mfma_bf16(aring[i % 4][PA], bq[i & 1][r][PB], acc[r]);
+      MODE_S2_TERM(2, 0)
+      MODE_S2_TERM(0, 2)
+      MODE_S2_TERM(1, 1)
+      MODE_S2_TERM(1, 0)
+      MODE_S2_TERM(0, 1)
+      MODE_S2_TERM(0, 0)
+#undef MODE_S2_TERM
+#pragma unroll
+      for (int q2 = 0; q2 < 6 * TH; ++q2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch == d.NCHUNK - 1) {  // tile finished: the odd-pair waves hand their sums over, the even-pair waves add and store D[o][wo]
+      if (kpar == 1) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+          for (int qq = 0; qq < 16; ++qq) red[(r * 16 + qq) * 64 + lane] = acc[r][qq];
+      }
+      lds_barrier();
+      if (kpar == 0) {
+        int b, d0, h0, w0;
+        tile_of(k_tile, b, d0, h0, w0);
+        const int gw = w0 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+          const int gh = h0 + r;
+          if (d0 < d.Do && gh < d.Ho && gw < d.Wo) {
+            float* yb = y + (long long)b * d.Co * oDHW + d0 * oHW + (long long)gh * d.Wo + gw;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              if (o < d.Co) yb[o * oDHW] = acc[r][qq] + red[(r * 16 + qq) * 64 + lane];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < TH; ++r) acc[r] = (f32x16){0};
+      ++k_tile;
+    }
+    ch = ch_next;
+    lds_barrier();
+  }
+}
+
+}  // namespace
+
+namespace mode {
+
+size_t conv3d_s2_split_wpack_floats(int K, int rows) { return (size_t)cdiv(rows, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4; }
+
+// rows = output channels of this GEMM (33..64: two 32-channel tiles), K = its reduction channels (a multiple of 8); 32-bit lane offsets
+bool conv3d_s2_split_supported(int K, int rows) { return rows > 32 && rows <= 64 && K > 0 && K % 8 == 0; }
+
+int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
+                    const char* who) {
+  MODE_REQUIRE(conv3d_s2_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the stride-2 split kernel",
+               who, rows, K);
+  MODE_REQUIRE((long long)D * H * W < (1ll << 30) / 8, MODE_ERR_UNSUPPORTED, "%s: volume beyond the 32-bit lane offsets of the split kernel", who);
+  S2Dims d;
+  d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
+  d.Do = (D - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1;
+  d.nWt = cdiv(d.Wo, 32); d.nHt = cdiv(d.Ho, TH); d.nDt = cdiv(d.Do, TD);
+  d.NCHUNK = cdiv(K, 8);
+  d.ntiles = B * d.nDt * d.nHt * d.nWt;
+  const long long npack = (long long)MT * d.NCHUNK * NPAIR * 64;
+  hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK);
+  int rc = mode::allow_lds(conv3d_s2_split_kernel, LDS_BYTES, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
+  return mode::check_launch(who);
+}
+
+}  // namespace mode

@@ -1081,7 +1081,9 @@ def conv3d_fwd(x, w, stride=1):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    if _split3d(Ci, Co, stride, False):
+    if _split3d(Ci, Co, stride, False) and stride == 2 and D * H * W < 2**27:
+      check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_s2_split')
+    elif _split3d(Ci, Co, stride, False) and stride == 1:
       check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_split')
     else:
       check(lib().mode_conv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)), 'mode_conv3d_fwd')
@@ -1413,7 +1415,7 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    if _split3d(Ci, Co, stride, False):
+    if stride == 1 and _split3d(Ci, Co, stride, False):  # (the stride-2 split kernel has no folded-BatchNorm epilogue: fp32 kernel)
       check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
             'mode_conv3d_fwd_split')
     else:

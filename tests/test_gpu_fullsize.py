@@ -66,7 +66,7 @@ def test_conv3d_stride1_all_three_kernels(Ci, Co, vol, arith):
 
 
 @pytest.mark.parametrize('Ci,Co,vol', [(32, 64, FULL), (64, 64, HALF)])
-def test_conv3d_stride2_all_three_kernels(Ci, Co, vol):
+def test_conv3d_stride2_all_three_kernels(Ci, Co, vol, arith):
   """hourglass conv1 (32 -> 64, 1/4 -> 1/8) and conv3 (64 -> 64, 1/8 -> 1/16)."""
   D, H, W = vol
   x = _rand((1, Ci, D, H, W), 4)
@@ -79,7 +79,7 @@ def test_conv3d_stride2_all_three_kernels(Ci, Co, vol):
 
 
 @pytest.mark.parametrize('Cin,Cout,vol', [(64, 64, QUARTER), (64, 32, HALF)])
-def test_deconv3d_forward_and_gradients(Cin, Cout, vol):
+def test_deconv3d_forward_and_gradients(Cin, Cout, vol, arith):
   """hourglass conv5 (64 -> 64, 1/16 -> 1/8) and conv6 (64 -> 32, 1/8 -> 1/4): ConvTranspose3d k3 s2 p1 op1.  Its input gradient
   is the stride-2 convolution with the same weight, its weight gradient the stride-2 weight gradient with the roles exchanged
   (functional.Deconv3dFunction)."""

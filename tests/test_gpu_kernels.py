@@ -428,7 +428,7 @@ def test_conv3d_fwd_bwd(B, Ci, Co, D, H, W, arith):
 
 
 @pytest.mark.parametrize('B,Ci,Co,D,H,W', [(2, 8, 16, 8, 8, 8), (1, 32, 64, 4, 8, 64), (1, 64, 64, 6, 12, 40), (2, 20, 40, 4, 6, 70)])
-def test_conv3d_stride2(B, Ci, Co, D, H, W):
+def test_conv3d_stride2(B, Ci, Co, D, H, W, arith):
   """hourglass conv1 / conv3 (mode_disparity.py:15, 19): k3 s2 p1."""
   import torch.nn.functional as F
   x = _rand((B, Ci, D, H, W), 44)
@@ -447,7 +447,7 @@ def test_conv3d_stride2(B, Ci, Co, D, H, W):
 
 
 @pytest.mark.parametrize('B,Ci,Co,D,H,W', [(2, 8, 16, 4, 4, 4), (1, 64, 64, 3, 8, 32), (1, 64, 32, 6, 16, 32), (2, 24, 40, 2, 5, 35)])
-def test_deconv3d(B, Ci, Co, D, H, W):
+def test_deconv3d(B, Ci, Co, D, H, W, arith):
   """hourglass conv5 / conv6 (mode_disparity.py:23, 25): ConvTranspose3d k3 s2 p1 op1, weight (Cin, Cout, 3,3,3)."""
   import torch.nn.functional as F
   x = _rand((B, Ci, D, H, W), 47)
