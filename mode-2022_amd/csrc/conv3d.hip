@@ -564,7 +564,7 @@ extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_
 extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                         mode_stream_t stream) {
   const char* who = "mode_conv3d_fwd_s2_split";
-  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who);
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who, true);
   if (rc != MODE_OK || B == 0) return rc;
   return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who);
 }
