@@ -184,8 +184,9 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
   const uint4* wpm = wp + m * mstride;
 
-  // this wave's seven tap pairs of a chunk: pair 2 i + kpar, i = 0..6; weight fragments 3 of them ahead (ring of 4)
-  uint4 aring[4][3];
+  // this wave's seven tap pairs of a chunk: pair 2 i + kpar, i = 0..6; weight fragments 3 of them ahead (slot = i: seven pairs per
+  // chunk keep the slots aligned from chunk to chunk; four of them are live at any time)
+  uint4 aring[7][3];
   auto load_a = [&](int slot4, int ch, int i) {
     const uint4* wq = wpm + ((long long)ch * NPAIR + 2 * i + kpar) * 192 + lane;
 #pragma unroll
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
           for (int p = 0; p < 3; ++p) bq[(i + 1) & 1][r][p] = src[p * PIECE + rowpos + 2 * r * IW + toff[i + 1]];
       }
       if (i + 3 < 7)
-        load_a((i + 3) % 4, ch, i + 3);
+        load_a(i + 3, ch, i + 3);
       else
-        load_a((i + 3) % 4, ch_next, i + 3 - 7);
+        load_a(i + 3 - 7, ch_next, i + 3 - 7);
       if (i < KIT) stage_load(i);  // the next chunk: loads under this wave's first four pairs, split + stores under its last ones
       if (i >= 7 - KIT + 1) {     // positions 0, 1 under pair 4, then one per pair (4 positions, 3 pairs left after the loads)
         stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 0);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
         stage_commit((g + 1) & 1, 0, 1);
       }
       // smallest terms first; consecutive MFMAs alternate between the two rows' accumulators
-#define MODE_S2_TERM(PA, PB) _Pragma("unroll") for (int r = 0; r < TH; ++r) acc[r] = mfma_bf16(aring[i % 4][PA], bq[i & 1][r][PB], acc[r]);
+#define MODE_S2_TERM(PA, PB) _Pragma("unroll") for (int r = 0; r < TH; ++r) acc[r] = mfma_bf16(aring[i][PA], bq[i & 1][r][PB], acc[r]);
       MODE_S2_TERM(2, 0)
       MODE_S2_TERM(0, 2)
       MODE_S2_TERM(1, 1)
