@@ -238,17 +238,14 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
         load_a(i + 3, ch, i + 3);
       else
         load_a(i + 3 - 7, ch_next, i + 3 - 7);
-      // the next chunk: two positions' loads under each of this wave's first two pairs, their split + stores under its last two --
-      // four pairs (~1 500 cycles) for the loads to land; one wave per SIMD has nothing else to cover a late load with
-      if (i < 2) {
-        stage_load(2 * i);
-        stage_load(2 * i + 1);
+      if (i < KIT) stage_load(i);  // the next chunk: loads under this wave's first four pairs, split + stores under its last ones
+      if (i >= 7 - KIT + 1) {     // positions 0, 1 under pair 4, then one per pair (4 positions, 3 pairs left after the loads)
+        stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 0);
+        stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 1);
       }
-      if (i >= 5) {
-        stage_commit((g + 1) & 1, 2 * (i - 5), 0);
-        stage_commit((g + 1) & 1, 2 * (i - 5), 1);
-        stage_commit((g + 1) & 1, 2 * (i - 5) + 1, 0);
-        stage_commit((g + 1) & 1, 2 * (i - 5) + 1, 1);
+      if (i == 7 - KIT + 1) {
+        stage_commit((g + 1) & 1, 0, 0);
+        stage_commit((g + 1) & 1, 0, 1);
       }
       // smallest terms first; consecutive MFMAs alternate between the two rows' accumulators
 #define MODE_S2_TERM(PA, PB) _Pragma("unroll") for (int r = 0; r < TH; ++r) acc[r] = mfma_bf16(aring[i][PA], bq[i & 1][r][PB], acc[r]);
