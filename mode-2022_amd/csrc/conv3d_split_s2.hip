@@ -98,12 +98,18 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
   return ((tap / 9) * IH + (tap / 3) % 3) * IW + (tap % 3 == 0 ? 0 : tap % 3 == 1 ? IWH : 1);
 }
 
-__global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                             float* __restrict__ y, S2Dims d) {
-  extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][PIECE]
+// PHASED = false: one workgroup per CU, LDS double-buffered, the next chunk staged inside the MFMA stream (conv3d_split.hip's scheme).
+// PHASED = true: ONE LDS buffer (64 KB with the reduction area), two workgroups per CU: the next chunk's loads still fly under this
+// chunk's MFMAs (into registers), but their split + LDS stores form a phase of their own between two barriers -- which overlaps with
+// the MFMA phase of the CU's other workgroup.  With only 84 MFMAs per wave and chunk the staging arithmetic does not fit under them
+// (the stride-1 kernel has 336), and one wave per SIMD has nothing else to run while it waits.
+template <bool PHASED>
+__global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                                             float* __restrict__ y, S2Dims d) {
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [PHASED ? 1 : 2][3][PIECE], then the reduction area
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m = wave & 1, kpar = wave >> 1;  // this wave's output-channel tile and the parity of the tap pairs it takes
-  float* red = reinterpret_cast<float*>(sm + 2 * BUF) + m * (TH * 16 * 64);
+  float* red = reinterpret_cast<float*>(sm + (PHASED ? 1 : 2) * BUF) + m * (TH * 16 * 64);
 
   const int nwx = gridDim.x / kNumXCD;
   const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
 
   int ch = 0, k_tile = 0;
   for (int g = 0; g < G; ++g) {
-    const uint4* src = sm + (g & 1) * BUF;
+    const uint4* src = sm + (PHASED ? 0 : (g & 1) * BUF);
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
     stage_begin(min(g + 1, G - 1));  // (after the last chunk it is staged once more into the idle buffer: no branch in the body)
     uint4 bq[2][TH][3];
@@ -239,11 +245,11 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
       else
         load_a(i + 3 - 7, ch_next, i + 3 - 7);
       if (i < KIT) stage_load(i);  // the next chunk: loads under this wave's first four pairs, split + stores under its last ones
-      if (i >= 7 - KIT + 1) {     // positions 0, 1 under pair 4, then one per pair (4 positions, 3 pairs left after the loads)
+      if (!PHASED && i >= 7 - KIT + 1) {  // positions 0, 1 under pair 4, then one per pair (4 positions, 3 pairs left after the loads)
         stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 0);
         stage_commit((g + 1) & 1, i - (7 - KIT + 1) + 1, 1);
       }
-      if (i == 7 - KIT + 1) {
+      if (!PHASED && i == 7 - KIT + 1) {
         stage_commit((g + 1) & 1, 0, 0);
         stage_commit((g + 1) & 1, 0, 1);
       }
@@ -295,6 +301,14 @@ __global__ __launch_bounds__(NT) void conv3d_s2_split_kernel(const float* __rest
     }
     ch = ch_next;
     lds_barrier();
+    if (PHASED) {  // everyone is done reading the chunk: the next one goes into the same buffer
+#pragma unroll
+      for (int k = 0; k < KIT; ++k) {
+        stage_commit(0, k, 0);
+        stage_commit(0, k, 1);
+      }
+      lds_barrier();
+    }
   }
 }
 
@@ -320,9 +334,10 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)MT * d.NCHUNK * NPAIR * 64;
   hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK);
-  int rc = mode::allow_lds(conv3d_s2_split_kernel, LDS_BYTES, who);
+  constexpr size_t LDS1 = (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 65 536 B: two workgroups per CU
+  int rc = mode::allow_lds(conv3d_s2_split_kernel<true>, LDS1, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
+  hipLaunchKernelGGL(conv3d_s2_split_kernel<true>, dim3(2 * kNumCU), dim3(NT), LDS1, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
   return mode::check_launch(who);
 }
 
