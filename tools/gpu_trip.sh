@@ -1,17 +1,16 @@
 #!/bin/bash
-# One GPU-box session: parity tests, micro-benchmarks, bench line, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
-# usage (from the repo root on the GPU box):  bash tools/gpu_trip.sh [tag]
+# One GPU-box session: the whole -m gpu tier, the bench line, rocprofv3 kernel stats of the same command.  Everything lands in
+# gpurun_out/<tag>/.   usage (from the repo root on the GPU box):  bash tools/gpu_trip.sh [tag]
 TAG=${1:-r1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
-echo "== pytest -m gpu" ; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | grep -v 'MIOpen\|^add \|^MODE\|^using' > $OUT/pytest_gpu.log ; grep -E '^(FAILED|ERROR|[0-9]+ (passed|failed))|passed|failed' $OUT/pytest_gpu.log | tail -30
-echo "== microbench" ; timeout 900 python tools/microbench.py > $OUT/microbench.log 2>&1 ; tail -60 $OUT/microbench.log
-echo "== bench" ; timeout 1200 python bench.py --steps 3 --warmup 1 > $OUT/bench.log 2>&1 ; grep -v 'MIOpen' $OUT/bench.log | tail -3 | cut -c1-2500
-echo "== rocprofv3 kernel-trace" ; cd /tmp ; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/rocprof.log 2>&1 ; tail -3 $OUT/rocprof.log
-cd $R ; find $OUT/prof -name "*stats*" | head ; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -40 $f > $OUT/kernel_stats_top40.csv; cat $OUT/kernel_stats_top40.csv | cut -c1-220; done
-# keep the merge small: drop the raw trace
+echo "== pytest -m gpu" ; timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -s 2>&1 | grep -v 'MIOpen\|^add \|^MODE\|^using' > $OUT/pytest_gpu.log ; grep -E '^(FAILED|ERROR)|passed|failed' $OUT/pytest_gpu.log | tail -30
+echo "== bench" ; timeout 1200 python bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1 ; grep '^{' $OUT/bench.log > $OUT/bench.json; cut -c1-400 $OUT/bench.json
+echo "== bench f32" ; timeout 600 python bench.py --steps 5 --warmup 2 --conv-arith f32 --no-cpu-baseline --no-eval-b1 2>/dev/null | grep '^{' > $OUT/bench_conv_arith_f32.json; cut -c1-200 $OUT/bench_conv_arith_f32.json
+echo "== rocprofv3 kernel-trace" ; cd /tmp ; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-eval-b1 > $OUT/rocprof.log 2>&1 ; tail -2 $OUT/rocprof.log | cut -c1-300
+cd $R ; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -101 $f > $OUT/kernel_stats_top100.csv; python3 tools/profile_summary.py $f 60 > $OUT/profile_summary_per_step.txt; head -14 $OUT/profile_summary_per_step.txt; done
 find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete
 du -sh $OUT
