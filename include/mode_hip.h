@@ -365,6 +365,16 @@ int mode_conv3d_split_supported(int Ci, int Co, int stride, int which /* 0 forwa
 int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                              mode_stream_t stream);
 
+/* The transposed convolution (ConvTranspose3d k3 s2 p1 op1, hourglass conv5 / conv6, mode_disparity.py:23-25) and the input gradient
+ * of the stride-2 convolution -- one operator -- on the split-bf16 kernel of csrc/conv3d_split_deconv.hip: input channels of the
+ * transposed convolution a multiple of 8, 2..64 output channels (mode_deconv3d_split_supported(Cin, Cout) /
+ * mode_conv3d_split_supported(Ci, Co, 2, 1)); even D, H, W for the gradient form. */
+int mode_deconv3d_split_supported(int Cin, int Cout);
+int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpack, int B, int Cin, int D, int H, int W, int Cout,
+                            mode_stream_t stream);
+int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,
+                                  mode_stream_t stream);
+
 int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int D,
                           int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,

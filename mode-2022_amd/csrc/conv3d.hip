@@ -539,12 +539,16 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
   size_t n = (f > b ? f : b) + 32 * (size_t)mode::cdiv(Co > Ci ? Co : Ci, 32);  // + the folded BatchNorm shifts
   n = std::max(n, std::max(mode::conv3d_split_wpack_floats(Ci, Co), mode::conv3d_split_wpack_floats(Co, Ci)));
   n = std::max(n, mode::conv3d_s2_split_wpack_floats(Ci, Co));
+  n = std::max(n, std::max(mode::deconv3d_split_wpack_floats(Ci, Co), mode::deconv3d_split_wpack_floats(Co, Ci)));
   return n * sizeof(float);
 }
 
 extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int which) {
   if (Ci <= 0 || Co <= 0) return 0;
-  if (stride == 2) return (which == 0 && mode::conv3d_s2_split_supported(Ci, Co)) ? 1 : 0;  // forward only (mode_conv3d_fwd_s2_split)
+  if (stride == 2) {  // forward: mode_conv3d_fwd_s2_split; input gradient: mode_conv3d_bwd_data_s2_split (even volumes); no weight gradient
+    if (which == 0) return mode::conv3d_s2_split_supported(Ci, Co) ? 1 : 0;
+    return (which == 1 && mode::deconv3d_split_supported(Co, Ci)) ? 1 : 0;
+  }
   if (stride != 1) return 0;
   if (which == 2) return Co > 1;  // weight gradient: any channel counts (32 x 32 blocks, masked)
   return which == 1 ? mode::conv3d_split_supported(Co, Ci) : mode::conv3d_split_supported(Ci, Co);
@@ -567,6 +571,28 @@ extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y
   int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who, true);
   if (rc != MODE_OK || B == 0) return rc;
   return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who);
+}
+
+// Input gradient of the stride-2 convolution = the transposed convolution of gy with the same (Co, Ci, 27) weight, on the split-bf16
+// kernel of conv3d_split_deconv.hip; even D, H, W; needs mode_conv3d_split_supported(Ci, Co, 2, 1) == 1.
+extern "C" int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
+                                             int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_data_s2_split";
+  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, 2, who, true);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MODE_ERR_UNSUPPORTED, "%s: stride 2 needs even input sizes (got %dx%dx%d)", who, D, H, W);
+  return mode::deconv3d_split(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), who);
+}
+
+// ConvTranspose3d k3 s2 p1 op1 on the same kernel: x (B, Cin, D, H, W), w (Cin, Cout, 27) -> y (B, Cout, 2D, 2H, 2W).
+extern "C" int mode_deconv3d_split_supported(int Cin, int Cout) { return mode::deconv3d_split_supported(Cin, Cout) ? 1 : 0; }
+
+extern "C" int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpack, int B, int Cin, int D, int H, int W, int Cout,
+                                       mode_stream_t stream) {
+  const char* who = "mode_deconv3d_fwd_split";
+  int rc = check_conv_args(x, w, y, wpack, B, Cin, D, H, W, Cout, 1, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  return mode::deconv3d_split(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who);
 }
 
 extern "C" int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,

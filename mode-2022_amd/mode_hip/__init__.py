@@ -87,6 +87,9 @@ SIGNATURES = {
     'mode_conv3d_split_supported': (_c_int, [_c_int] * 4),
     'mode_conv3d_fwd_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_fwd_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_deconv3d_split_supported': (_c_int, [_c_int] * 2),
+    'mode_deconv3d_fwd_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv3d_bwd_data_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 7),

@@ -1102,7 +1102,10 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                   4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
-    if _split3d(Ci, Co, stride, True):
+    if stride == 2 and _split3d(Ci, Co, stride, True) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and D * H * W < 2**30:
+      check(lib().mode_conv3d_bwd_data_s2_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
+            'mode_conv3d_bwd_data_s2_split')
+    elif stride == 1 and _split3d(Ci, Co, stride, True):
       check(lib().mode_conv3d_bwd_data_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
             'mode_conv3d_bwd_data_split')
     else:
@@ -1148,7 +1151,10 @@ def deconv3d_fwd(x, w):
   flops = 2 * x.numel() * Cout * 27
   with torch.cuda.device_of(x), profiling.region('deconv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
     wp = _wpack3d(Cin, Cout, x.device)
-    check(lib().mode_deconv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd')
+    if CONV_ARITH == 'bf16x6' and lib().mode_deconv3d_split_supported(Cin, Cout) == 1 and D * H * W < 2**27:
+      check(lib().mode_deconv3d_fwd_split(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd_split')
+    else:
+      check(lib().mode_deconv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd')
   return y
 
 
