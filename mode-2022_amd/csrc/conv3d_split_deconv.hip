@@ -5,15 +5,17 @@
 //   y[o][2 q + p] = sum_c sum_{taps of parity class p} w[c][o][k] * x[c][q + s(k)]        (q: low-resolution voxel, p in {0,1}^3)
 // Per axis an even output index takes kernel index 1 from input q, an odd one kernel index 0 from input q + 1 and kernel index 2
 // from input q: the 27 taps fall into 8 parity classes of 1, 2, 2, 2, 4, 4, 4, 8 taps, i.e. 14 tap PAIRS (one half-empty) -- so K of one
-// v_mfma_f32_32x32x16_bf16 is again 8 input channels x 2 taps and a chunk is 14 pairs x 6 terms, only that a pair now adds into the
-// accumulator of ITS class: D_class[i = o][j = 32 consecutive low-resolution columns].  A wave owns two low-resolution rows x one
-// 32-channel output tile = 16 accumulators (256 registers: one wave per SIMD, like the stride-1 kernel), 168 MFMAs per chunk, and
-// alternates between its two rows so that consecutive MFMAs never share an accumulator.
-// The LDS tile is tiny: (TD + 1) x 5 rows x 33 columns of the low-resolution input per 8-channel chunk (330 / 495 positions, at most
-// two per thread) against 672 MFMAs per workgroup and chunk -- the transposed convolution reads each input voxel for 27/8 taps of 8
-// outputs each, so unlike the stride-2 forward it is the weights, not the staging, that set the tile: two rows per wave halve the
-// weight-fragment traffic (42 KB per wave and chunk from L2) to what the L1 delivers beside the MFMAs.
-// Output: the two classes pw = 0 / 1 of a (pd, ph) are stored as one float2 per lane (columns 2 j, 2 j + 1).
+// v_mfma_f32_32x32x16_bf16 is again 8 input channels x 2 taps and a chunk is 14 pairs x 6 terms, only that a pair adds into the
+// accumulator of ITS class: D_class[i = o][j = 32 consecutive low-resolution columns].
+// The classes are split between two waves: set 0 = classes {0, 6, 7}, set 1 = classes {1, 2, 3, 4, 5}, seven pairs each.  A wave owns
+// two low-resolution rows x one 32-channel output tile x its class set: at most 10 accumulators (160 registers), 84 MFMAs per chunk
+// against 21 KB of weight fragments (all eight classes in one wave: 256 accumulator registers, 110 spilled, and slower than the fp32
+// kernel), alternating between its two rows so that consecutive MFMAs never share an accumulator.  No reduction between waves:
+// the classes are different output voxels.
+// The LDS tile is tiny: 2 x (TH + 1) rows x 33 columns of the low-resolution input per 8-channel chunk (198 / 330 positions) against
+// 336 MFMAs per workgroup and chunk: the staging sits inside the MFMA stream and the buffer is double.
+// Output: the classes pw = 0 / 1 of (pd, ph) = (0, 1), (1, 0), (1, 1) leave as one float2 per lane (columns 2 j, 2 j + 1); classes 0 and
+// 1 live in different waves and are stored one float each.
 #include "common.h"
 
 #include "conv3d_internal.h"
@@ -26,31 +28,28 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NT = 256;
-constexpr int TH = 4, IH = TH + 1, IW = 33;
+constexpr int IW = 33;
 constexpr int NPAIR = 14;
 constexpr int KIT = 2;
-constexpr int PIECE = KIT * NT;  // 512 >= 3 x 5 x 33 positions
+constexpr int PIECE = KIT * NT;  // 512 >= 2 x 5 x 33 positions
 constexpr int BUF = 3 * PIECE;
 constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 49 152 B
 
-// the 14 tap pairs: parity class (pd * 4 + ph * 2 + pw), kernel taps (kd * 9 + kh * 3 + kw; -1 = empty) and input shifts (sd, sh, sw)
-__host__ __device__ constexpr int pair_cls(int p) {
-  constexpr int v[NPAIR] = {0, 1, 2, 3, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7};
-  return v[p];
-}
-__host__ __device__ constexpr int pair_tap(int p, int h) {
-  constexpr int a[NPAIR] = {13, 12, 10, 9, 15, 4, 3, 21, 1, 19, 0, 6, 18, 24};
-  constexpr int b[NPAIR] = {-1, 14, 16, 11, 17, 22, 5, 23, 7, 25, 2, 8, 20, 26};
-  return h ? b[p] : a[p];
-}
-__host__ __device__ constexpr int tap_shift_off(int tap) {  // LDS offset of the input voxel a tap reads, relative to the output's q
-  // kernel index 0 along an axis reads q + 1, indices 1 and 2 read q
-  return tap < 0 ? 0 : ((tap / 9 == 0 ? 1 : 0) * IH + ((tap / 3) % 3 == 0 ? 1 : 0)) * IW + (tap % 3 == 0 ? 1 : 0);
+// kernel taps (kd * 9 + kh * 3 + kw; -1 = empty) of the 14 tap pairs in packed order: pairs 0..6 = set 0 (class 0: one pair, class 6:
+// two, class 7: four), pairs 7..13 = set 1 (classes 1, 2: one pair each, class 3: two, class 4: one, class 5: two)
+__device__ __forceinline__ int pair_tap(int q, int h) {
+  constexpr int a[NPAIR] = {13, 1, 19, 0, 6, 18, 24, 12, 10, 9, 15, 4, 3, 21};
+  constexpr int b[NPAIR] = {-1, 7, 25, 2, 8, 20, 26, 14, 16, 11, 17, 22, 5, 23};
+  int t = -1;
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p)
+    if (p == q) t = h ? b[p] : a[p];
+  return t;
 }
 
 struct DcDims {
   int B, K, Co, D, H, W;  // low-resolution input volume; K = its channels (reduction), Co = output channels
-  int nWt, nHt, nDt, NCHUNK, ntiles;
+  int nWt, nHt, NCHUNK, ntiles;
 };
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -81,10 +80,7 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
     const int ch = (int)(r % NCHUNK);
     const int m = (int)(r / NCHUNK);
     const int o = m * 32 + (lane & 31);
-    int tap = -1;
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p)
-      if (p == pair) tap = (lane >> 5) ? pair_tap(p, 1) : pair_tap(p, 0);
+    const int tap = pair_tap(pair, lane >> 5);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -101,16 +97,19 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
   }
 }
 
-// MT = output-channel tiles per launch (1: <= 32 output channels, tile 2 x 4 rows; 2: 33..64, tile 1 x 4 rows)
+// MT = output-channel tiles per launch.  MT = 2 (33..64 output channels): waves = 2 tiles x 2 class sets on a tile of 2 rows;
+// MT = 1: waves = 2 class sets x 2 row pairs on a tile of 4 rows.  One low-resolution depth plane per tile (+ its halo plane).
 template <int MT>
 __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                 float* __restrict__ y, DcDims d) {
-  constexpr int TD = 2 / MT, ID = TD + 1;
-  constexpr int ITEMS = ID * IH * IW;
+  constexpr int TH = 4 / MT, IH = TH + 1;
+  constexpr int ITEMS = 2 * IH * IW;
   static_assert(ITEMS <= PIECE, "tile does not fit the staging map");
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][PIECE]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m = wave % MT, rp = wave / MT;  // output-channel tile and row pair (tile rows 2 rp, 2 rp + 1) of this wave
+  const int m = MT == 2 ? (wave & 1) : 0;
+  const int set = MT == 2 ? (wave >> 1) : (wave & 1);  // class set of this wave
+  const int rp = MT == 2 ? 0 : (wave >> 1);            // its row pair: tile rows 2 rp, 2 rp + 1
   const int half = lane >> 5;
 
   const int nwx = gridDim.x / kNumXCD;
@@ -132,8 +131,8 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     t /= d.nWt;
     h0 = (t % d.nHt) * TH;
     t /= d.nHt;
-    d0 = (t % d.nDt) * TD;
-    b = t / d.nDt;
+    d0 = t % d.D;
+    b = t / d.D;
   };
 
   int pdz[KIT], phy[KIT], pwx[KIT], poff[KIT];
@@ -180,24 +179,21 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     }
   };
 
-  f32x16 acc[2][8];
+  f32x16 acc[2][5];  // [row][class slot]: set 0: classes 0, 6, 7; set 1: classes 1, 2, 3, 4, 5
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[r][c] = (f32x16){0};
+    for (int c = 0; c < 5; ++c) acc[r][c] = (f32x16){0};
   int rowpos[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = 2 * rp + r;
-    rowpos[r] = ((row / TH) * IH + row % TH) * IW + (lane & 31);
-  }
+  for (int r = 0; r < 2; ++r) rowpos[r] = (2 * rp + r) * IW + (lane & 31);
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
-  const uint4* wpm = wp + m * mstride;
-  uint4 aring[7][3];
-  auto load_a = [&](int slot7, int ch, int pair) {
-    const uint4* wq = wpm + ((long long)ch * NPAIR + pair) * 192 + lane;
+  const uint4* wpm = wp + m * mstride + set * (7 * 192);
+  uint4 aring[7][3];  // slot = pair of the set; fetched three pairs ahead
+  auto load_a = [&](int i, int ch) {
+    const uint4* wq = wpm + ((long long)ch * NPAIR + i) * 192 + lane;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) aring[slot7][p] = wq[p * 64];
+    for (int p = 0; p < 3; ++p) aring[i][p] = wq[p * 64];
   };
 
   if (G > 0) {
@@ -210,7 +206,7 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
       stage_commit(0, k, 1);
     }
 #pragma unroll
-    for (int pair = 0; pair < 3; ++pair) load_a(pair, 0, pair);
+    for (int i = 0; i < 3; ++i) load_a(i, 0);
   }
   __syncthreads();
 
@@ -220,54 +216,65 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
     stage_begin(min(g + 1, G - 1));  // (after the last chunk it is staged once more into the idle buffer: no branch in the body)
     uint4 bq[2][2][3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? 0 : 0)];
-    // One tap pair (P literal, so that every register array index is a compile-time constant): fragment reads of the next pair, the
-    // weight fragments six pairs ahead, the staging work of this pair, then 12 MFMAs -- smallest terms first, the two rows alternating.
-#define MODE_DC_PAIR(P, CLS, NOFFA, NOFFB)                                                                                     \
-  {                                                                                                                            \
-    if (P + 1 < NPAIR) {                                                                                                       \
-      const int toff = half ? NOFFB : NOFFA;                                                                                   \
-      _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int p = 0; p < 3; ++p)                              \
-          bq[(P + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];                                                           \
-    }                                                                                                                          \
-    if (P + 3 < NPAIR)                                                                                                         \
-      load_a((P + 3) % 7, ch, P + 3);                                                                                          \
-    else                                                                                                                       \
-      load_a((P + 3) % 7, ch_next, P + 3 - NPAIR);                                                                             \
-    if (P < KIT) stage_load(P);                                                                                                \
-    if (P >= NPAIR - KIT) {                                                                                                    \
-      stage_commit((g + 1) & 1, P - (NPAIR - KIT), 0);                                                                         \
-      stage_commit((g + 1) & 1, P - (NPAIR - KIT), 1);                                                                         \
-    }                                                                                                                          \
-    MODE_DC_TERM(P, CLS, 2, 0) MODE_DC_TERM(P, CLS, 0, 2) MODE_DC_TERM(P, CLS, 1, 1) MODE_DC_TERM(P, CLS, 1, 0)                \
-    MODE_DC_TERM(P, CLS, 0, 1) MODE_DC_TERM(P, CLS, 0, 0)                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                                        \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                       \
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                       \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                       \
-    }                                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    // One tap pair of this wave's set (I, SLOT literal: every register array index is a compile-time constant): fragment reads of the
+    // next pair, the weight fragments three pairs ahead, this pair's share of the staging, then 12 MFMAs -- smallest terms first, the
+    // two rows alternating.
+#define MODE_DC_TERM(I, SLOT, PA, PB)                                               \
+  acc[0][SLOT] = mfma_bf16(aring[I][PA], bq[(I) & 1][0][PB], acc[0][SLOT]);         \
+  acc[1][SLOT] = mfma_bf16(aring[I][PA], bq[(I) & 1][1][PB], acc[1][SLOT]);
+#define MODE_DC_PAIR(I, SLOT, NOFFA, NOFFB)                                                                        \
+  {                                                                                                                \
+    if (I + 1 < 7) {                                                                                               \
+      const int toff = half ? (NOFFB) : (NOFFA);                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int p = 0; p < 3; ++p)                  \
+          bq[(I + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];                                               \
+    }                                                                                                              \
+    if (I + 3 < 7)                                                                                                 \
+      load_a(I + 3, ch);                                                                                           \
+    else                                                                                                           \
+      load_a(I + 3 - 7, ch_next);                                                                                  \
+    if (I < KIT) stage_load(I);                                                                                    \
+    if (I >= 7 - KIT) {                                                                                            \
+      stage_commit((g + 1) & 1, I - (7 - KIT), 0);                                                                 \
+      stage_commit((g + 1) & 1, I - (7 - KIT), 1);                                                                 \
+    }                                                                                                              \
+    MODE_DC_TERM(I, SLOT, 2, 0) MODE_DC_TERM(I, SLOT, 0, 2) MODE_DC_TERM(I, SLOT, 1, 1) MODE_DC_TERM(I, SLOT, 1, 0) \
+    MODE_DC_TERM(I, SLOT, 0, 1) MODE_DC_TERM(I, SLOT, 0, 0)                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-#define MODE_DC_TERM(P, CLS, PA, PB)                                                   \
-  acc[0][CLS] = mfma_bf16(aring[(P) % 7][PA], bq[(P) & 1][0][PB], acc[0][CLS]);        \
-  acc[1][CLS] = mfma_bf16(aring[(P) % 7][PA], bq[(P) & 1][1][PB], acc[1][CLS]);
-    MODE_DC_PAIR(0, 0, 1, 0)
-    MODE_DC_PAIR(1, 1, 33, 0)
-    MODE_DC_PAIR(2, 2, 34, 33)
-    MODE_DC_PAIR(3, 3, 1, 0)
-    MODE_DC_PAIR(4, 3, 165, 0)
-    MODE_DC_PAIR(5, 4, 166, 165)
-    MODE_DC_PAIR(6, 5, 1, 0)
-    MODE_DC_PAIR(7, 5, 198, 165)
-    MODE_DC_PAIR(8, 6, 33, 0)
-    MODE_DC_PAIR(9, 6, 199, 198)
-    MODE_DC_PAIR(10, 7, 166, 165)
-    MODE_DC_PAIR(11, 7, 34, 33)
-    MODE_DC_PAIR(12, 7, 1, 0)
-    MODE_DC_PAIR(13, 7, 0, 0)
+    if (set == 0)
+      {  // classes 0, 6, 7
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? 0 : (0 * IH + 0) * IW + 0)];
+      MODE_DC_PAIR(0, 0, (1 * IH + 1) * IW + 0, (1 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(1, 1, (0 * IH + 1) * IW + 0, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(2, 1, (1 * IH + 1) * IW + 1, (1 * IH + 1) * IW + 0)
+      MODE_DC_PAIR(3, 2, (1 * IH + 0) * IW + 1, (1 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(4, 2, (0 * IH + 1) * IW + 1, (0 * IH + 1) * IW + 0)
+      MODE_DC_PAIR(5, 2, (0 * IH + 0) * IW + 1, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(6, 2, 0, 0)
+      }
+    else
+      {  // classes 1 .. 5
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? (0 * IH + 0) * IW + 0 : (0 * IH + 0) * IW + 1)];
+      MODE_DC_PAIR(0, 0, (0 * IH + 1) * IW + 0, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(1, 1, (0 * IH + 1) * IW + 1, (0 * IH + 1) * IW + 0)
+      MODE_DC_PAIR(2, 2, (0 * IH + 0) * IW + 1, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(3, 2, (1 * IH + 0) * IW + 0, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(4, 3, (1 * IH + 0) * IW + 1, (1 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(5, 4, (0 * IH + 0) * IW + 1, (0 * IH + 0) * IW + 0)
+      MODE_DC_PAIR(6, 4, 0, 0)
+      }
 #undef MODE_DC_PAIR
 #undef MODE_DC_TERM
     if (ch == d.NCHUNK - 1) {  // tile finished: D_class[i = o][j = low-resolution column]
@@ -276,26 +283,36 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
       const int gw = w0 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int row = 2 * rp + r;
-        const int gd = d0 + row / TH, gh = h0 + row % TH;
-        if (gd < d.D && gh < d.H && gw < d.W) {
-          // one running pointer per (pd, ph), advanced by whole channel planes and made opaque after every step: left to itself the
-          // compiler computes all 128 store addresses of the two rows up front (256 registers, next to 256 accumulators)
-          float* yb = y + ((long long)b * d.Co + m * 32 + 4 * half) * oDHW + (long long)(2 * gd) * oHW + (long long)(2 * gh) * oW + 2 * gw;
+        const int gh = h0 + 2 * rp + r;
+        if (gh < d.H && gw < d.W) {
+          // running pointers, advanced by whole channel planes and made opaque after every step (left to itself the compiler computes
+          // all store addresses of the two rows up front: ~200 registers next to the accumulators)
+          float* yb = y + ((long long)b * d.Co + m * 32 + 4 * half) * oDHW + (long long)(2 * d0) * oHW + (long long)(2 * gh) * oW + 2 * gw;
+          // set 0: class 0 -> (0,0,0) one float; classes 6, 7 -> (1,1,.) float2.  set 1: class 1 -> (0,0,1); 2, 3 -> (0,1,.); 4, 5 -> (1,0,.)
+          float* y1 = yb + (set == 0 ? 0 : 1);
+          float* y2a = yb + (set == 0 ? oHW + oW : oW);
+          float* y2b = yb + oHW;  // (set 1 only)
 #pragma unroll
-          for (int pdh = 0; pdh < 4; ++pdh) {  // (pd, ph): the two pw classes go out as one float2
-            float* yc = yb + (pdh >> 1) * oHW + (pdh & 1) * oW;
-#pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-              const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-              asm volatile("" : "+v"(yc));
-              if (o < d.Co) *reinterpret_cast<float2*>(yc) = make_float2(acc[r][2 * pdh][qq], acc[r][2 * pdh + 1][qq]);
-              yc += ((qq & 3) == 3 ? 5 : 1) * oDHW;
+          for (int qq = 0; qq < 16; ++qq) {
+            const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+            asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
+            if (o < d.Co) {
+              *y1 = acc[r][0][qq];
+              if (set == 0) {
+                *reinterpret_cast<float2*>(y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+              } else {
+                *reinterpret_cast<float2*>(y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+                *reinterpret_cast<float2*>(y2b) = make_float2(acc[r][3][qq], acc[r][4][qq]);
+              }
             }
+            const long long step = ((qq & 3) == 3 ? 5 : 1) * oDHW;
+            y1 += step;
+            y2a += step;
+            y2b += step;
           }
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = (f32x16){0};
+        for (int c = 0; c < 5; ++c) acc[r][c] = (f32x16){0};
       }
       ++k_tile;
     }
@@ -320,10 +337,10 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
                "%s: volume beyond the 32-bit offsets of the split kernel", who);
   DcDims d;
   d.B = B; d.K = K; d.Co = Co; d.D = D; d.H = H; d.W = W;
-  const int MTr = cdiv(Co, 32), TD = 2 / MTr;
-  d.nWt = cdiv(W, 32); d.nHt = cdiv(H, TH); d.nDt = cdiv(D, TD);
+  const int MTr = cdiv(Co, 32), TH = 4 / MTr;
+  d.nWt = cdiv(W, 32); d.nHt = cdiv(H, TH);
   d.NCHUNK = cdiv(K, 8);
-  d.ntiles = B * d.nDt * d.nHt * d.nWt;
+  d.ntiles = B * D * d.nHt * d.nWt;
   const long long npack = (long long)MTr * d.NCHUNK * NPAIR * 64;
   hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK);
   int rc;
