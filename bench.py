@@ -93,6 +93,8 @@ def _on_split_path(label):
     if m.group(1) == 'conv3d_bn_eval' and int(m.group(4)) != 1:
       return False  # (the stride-2 split kernel has no folded-BatchNorm epilogue)
     return lib.mode_conv3d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), which) == 1
+  if label.startswith('deconv3d_fwd'):
+    return True  # (64 -> 64 and 64 -> 32 in the network: mode_deconv3d_split_supported)
   m = re.match(r'(sphere_conv_fwd|sphere_conv_bwd_data|sphere_conv_bwd_weight|sphere_conv_bn_eval)\[(\d+)->(\d+) (\d+)x(\d+)\]', label)
   if m:
     # the spherical layers of the extractor (3x3 taps on the gnomonic table): compact-window tiles on the split-bf16 kernels, the
@@ -145,8 +147,10 @@ def kernel_of(label, conv_arith, on_split=None):
   if name in ('conv3d_fwd', 'conv3d_bwd_data', 'conv3d_bn_eval'):
     if re.search(r'->1 ', label):
       return 'conv3d_co1_fwd_mfma_kernel' if name != 'conv3d_bwd_data' else 'conv3d_co1_bwd_data_kernel'
+    if split and stride == 2:
+      return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
-      return 'conv3d_split_kernel<1,0>' if stride == 1 else 'conv3d_s2_split_kernel'
+      return 'conv3d_split_kernel<1,0>'
     return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
   if name == 'conv3d_bwd_weight':
     if re.search(r'->1 ', label):
@@ -154,8 +158,10 @@ def kernel_of(label, conv_arith, on_split=None):
     if split:
       return 'conv3d_bww_split_kernel'
     return 'conv3d_bwd_weight_ring_kernel' if stride == 1 else 'conv3d_bwd_weight_s2_kernel'
-  if name in ('deconv3d_fwd', 'deconv3d_bn_eval'):
-    return 'deconv3d_split_kernel' if split else 'deconv3d_kernel'
+  if name == 'deconv3d_fwd':
+    return 'deconv3d_split_kernel' if conv_arith == 'bf16x6' else 'deconv3d_kernel'
+  if name == 'deconv3d_bn_eval':
+    return 'deconv3d_kernel'
   if name in ('conv2d_fwd', 'conv2d_bwd_data', 'conv2d_bn_eval'):
     return 'conv2d_split_kernel' if split else 'conv2d_kernel'
   if name == 'conv2d_bwd_weight':
