@@ -49,24 +49,6 @@ __device__ __forceinline__ float fill_column(const float* __restrict__ Lb, const
   return m;
 }
 
-// Disparity dd interpolates between the low-resolution nodes d0 = (int)(sd * dd) and d0 + 1: d0 grows monotonically, so the D
-// disparities fall into runs ("segments") that share their two nodes.  seg[k] = first disparity whose d0 is >= k (k = 0 .. D4, seg[D4]
-// = D), from exactly the float arithmetic of src_index -- computed once per workgroup.  Walking the segments, the two node values are
-// read from LDS once per segment instead of once per disparity, and the index arithmetic (multiply, convert, clamp, compare: ~8 of
-// the ~20 vector instructions per disparity and pixel that bounded these kernels) leaves the inner loop.
-__device__ __forceinline__ void fill_segments(int* seg, const HDims& d) {
-  for (int k = threadIdx.x; k <= d.D4; k += NT) {
-    int first = d.D;
-    for (int dd = d.D - 1; dd >= 0; --dd) {
-      int d0, d1;
-      float ld;
-      src_index(dd, d.sd, d.D4, d0, d1, ld);
-      if (d0 >= k) first = dd;
-    }
-    seg[k] = k < d.D4 ? first : d.D;
-  }
-}
-
 __device__ __forceinline__ float logit_at(const float* ucol, const HDims& d, int dd) {
   int d0, d1;
   float ld;
@@ -76,28 +58,20 @@ __device__ __forceinline__ float logit_at(const float* ucol, const HDims& d, int
 
 __global__ __launch_bounds__(NT) void head_fwd_kernel(const float* __restrict__ L, float* __restrict__ pred,
                                                       float* __restrict__ conf, HDims d) {
-  extern __shared__ __attribute__((aligned(16))) float u[];  // [D4][NT], then the segment table [D4 + 1]
-  int* seg = reinterpret_cast<int*>(u + (size_t)d.D4 * NT);
-  fill_segments(seg, d);
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float u[];  // [D4][NT]
   const long long npix = (long long)d.B * d.H * d.W;
   const long long pix = (long long)blockIdx.x * NT + threadIdx.x;
-  if (pix >= npix) return;  // no further barriers in this kernel
+  if (pix >= npix) return;  // no barriers in this kernel
   const int w = (int)(pix % d.W);
   const int h = (int)((pix / d.W) % d.H);
   const int b = (int)(pix / ((long long)d.W * d.H));
   float* ucol = u + threadIdx.x;
   const float m = fill_column(L + (long long)b * d.D4 * d.H4 * d.W4, d, h, w, ucol);
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < d.D4; ++k) {  // same products, same order of the sums as the disparity-by-disparity loop
-    const int dbeg = seg[k], dend = seg[k + 1];
-    const float u0 = ucol[k * NT], u1 = ucol[min(k + 1, d.D4 - 1) * NT];
-    for (int dd = dbeg; dd < dend; ++dd) {
-      const float ld = d.sd * (float)dd - (float)k;
-      const float e = __expf(((1.f - ld) * u0 + ld * u1) - m);
-      s0 += e;
-      s1 += e * (float)dd;
-    }
+  for (int dd = 0; dd < d.D; ++dd) {
+    const float e = __expf(logit_at(ucol, d, dd) - m);
+    s0 += e;
+    s1 += e * (float)dd;
   }
   const float p = s1 / s0;
   pred[pix] = p;
@@ -117,10 +91,7 @@ __global__ __launch_bounds__(NT) void head_fwd_kernel(const float* __restrict__ 
 // Backward kernel 1: G[b][d4][h][w] = sum_d (lerp weight of d4 at d) * gpred * p_d * (d - pred)
 __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restrict__ L, const float* __restrict__ gpred,
                                                           float* __restrict__ G, HDims d) {
-  extern __shared__ __attribute__((aligned(16))) float u[];  // [D4][NT]: logits column, then the segment table [D4 + 1]
-  int* seg = reinterpret_cast<int*>(u + (size_t)d.D4 * NT);
-  fill_segments(seg, d);
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float u[];  // [D4][NT]: logits column
   const long long npix = (long long)d.B * d.H * d.W;
   const long long pix = (long long)blockIdx.x * NT + threadIdx.x;
   if (pix >= npix) return;
@@ -130,15 +101,10 @@ __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restric
   float* ucol = u + threadIdx.x;
   const float m = fill_column(L + (long long)b * d.D4 * d.H4 * d.W4, d, h, w, ucol);
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < d.D4; ++k) {
-    const int dbeg = seg[k], dend = seg[k + 1];
-    const float u0 = ucol[k * NT], u1 = ucol[min(k + 1, d.D4 - 1) * NT];
-    for (int dd = dbeg; dd < dend; ++dd) {
-      const float ld = d.sd * (float)dd - (float)k;
-      const float e = __expf(((1.f - ld) * u0 + ld * u1) - m);
-      s0 += e;
-      s1 += e * (float)dd;
-    }
+  for (int dd = 0; dd < d.D; ++dd) {
+    const float e = __expf(logit_at(ucol, d, dd) - m);
+    s0 += e;
+    s1 += e * (float)dd;
   }
   const float p = s1 / s0;
   const float g = gpred[pix] / s0;
@@ -147,23 +113,30 @@ __global__ __launch_bounds__(NT) void head_bwd_pix_kernel(const float* __restric
   // three workgroups per CU instead of one) and every node is written exactly once, straight to G, in a fixed order.
   const long long hw = (long long)d.H * d.W;
   float* Gb = G + (long long)b * d.D4 * hw + (long long)h * d.W + w;
-  // node k collects (1 - ld) gv of its own segment and ld gv of the segment before it (the last node has d1 = d0: both parts)
-  float carry = 0.f;  // what the previous segment gave to node k
-  for (int k = 0; k < d.D4; ++k) {
-    const int dbeg = seg[k], dend = seg[k + 1];
-    const bool last = k == d.D4 - 1;
-    const float u0 = ucol[k * NT], u1 = ucol[(last ? k : k + 1) * NT];
-    float a0 = carry, a1 = 0.f;
-    for (int dd = dbeg; dd < dend; ++dd) {
-      const float ld = d.sd * (float)dd - (float)k;
-      const float v = (1.f - ld) * u0 + ld * u1;
-      const float gv = g * __expf(v - m) * ((float)dd - p);
-      a0 += (1.f - ld) * gv;
-      a0 += last ? ld * gv : 0.f;  // (the last node is its own upper neighbour: same order of the sums as disparity by disparity)
-      a1 += last ? 0.f : ld * gv;
+  int cur = 0;            // node held in a0; a1 holds node cur + 1
+  float a0 = 0.f, a1 = 0.f;
+  for (int dd = 0; dd < d.D; ++dd) {
+    int d0, d1;
+    float ld;
+    src_index(dd, d.sd, d.D4, d0, d1, ld);
+    while (cur < d0) {  // flush finished nodes (nodes skipped by a coarse disparity axis get their zero)
+      Gb[(long long)cur * hw] = a0;
+      a0 = a1;
+      a1 = 0.f;
+      ++cur;
     }
-    Gb[(long long)k * hw] = a0;
-    carry = a1;
+    const float v = (1.f - ld) * ucol[d0 * NT] + ld * ucol[d1 * NT];
+    const float gv = g * __expf(v - m) * ((float)dd - p);
+    a0 += (1.f - ld) * gv;
+    if (d1 != d0)
+      a1 += ld * gv;
+    else
+      a0 += ld * gv;
+  }
+  for (; cur < d.D4; ++cur) {
+    Gb[(long long)cur * hw] = a0;
+    a0 = a1;
+    a1 = 0.f;
   }
 }
 
@@ -222,7 +195,7 @@ __global__ __launch_bounds__(NT) void head_bwd_gather_kernel(const float* __rest
 
 int make_hdims(HDims& d, int B, int D4, int H4, int W4, int D, int H, int W, const char* who) {
   MODE_REQUIRE(B >= 0 && D4 > 0 && H4 > 0 && W4 > 0 && D > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
-  MODE_REQUIRE(((size_t)D4 * NT + D4 + 1) * sizeof(float) <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D4 = %d too large for LDS", who, D4);
+  MODE_REQUIRE((size_t)D4 * NT * sizeof(float) <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D4 = %d too large for LDS", who, D4);
   d.B = B; d.D4 = D4; d.H4 = H4; d.W4 = W4; d.D = D; d.H = H; d.W = W;
   d.sd = D > 1 ? (float)(D4 - 1) / (float)(D - 1) : 0.f;
   d.sh = H > 1 ? (float)(H4 - 1) / (float)(H - 1) : 0.f;
@@ -239,7 +212,7 @@ extern "C" int mode_head_fwd(const float* logits, float* pred, float* conf, int 
   if (rc != MODE_OK) return rc;
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(logits && pred, MODE_ERR_BAD_ARG, "mode_head_fwd: null pointer");
-  const size_t lds = ((size_t)D4 * NT + D4 + 1) * sizeof(float);
+  const size_t lds = (size_t)D4 * NT * sizeof(float);
   rc = mode::allow_lds(head_fwd_kernel, lds, "mode_head_fwd");
   if (rc != MODE_OK) return rc;
   const long long npix = (long long)B * H * W;
@@ -260,7 +233,7 @@ extern "C" int mode_head_bwd(const float* logits, const float* gpred, float* glo
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(logits && gpred && glogits, MODE_ERR_BAD_ARG, "mode_head_bwd: null pointer");
   MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_head_bwd: workspace required");
-  const size_t lds = ((size_t)D4 * NT + D4 + 1) * sizeof(float);
+  const size_t lds = (size_t)D4 * NT * sizeof(float);
   rc = mode::allow_lds(head_bwd_pix_kernel, lds, "mode_head_bwd");
   if (rc != MODE_OK) return rc;
   hipStream_t st = mode::as_stream(stream);
