@@ -418,10 +418,6 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   // 32 output channels per launch: the second half of a 64-channel layer stages the input a second time, which at 6 / 16 of the
   // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70)
-  if (d.MT == 2 && !bn) {  // EXPERIMENT: both output tiles in one launch
-    d.o0 = 0;
-    return launch_split<2>(x, wpack, y, d, st, who, epi);
-  }
   for (int m = 0; m < d.MT; ++m) {
     d.o0 = 32 * m;
     int rc = launch_split<1>(x, wpack + (long long)m * d.NCHUNK * NPAIR * 192 * 4, y, d, st, who, epi);
