@@ -34,7 +34,7 @@ for case in '$CASES'.split():
       agg[k][row['Counter_Name']] += float(row['Counter_Value'])
       cnt[k][row['Counter_Name']] += 1
   for k in agg:
-    if 'sphere' not in k and 'reduce' not in k: continue
+    if not any(t in k for t in ('sphere', 'reduce_gw', 'conv3d', 'deconv3d')): continue
     print('  pmc   ', k)
     for c in sorted(agg[k]):
       print('      %-28s %16.0f per launch' % (c, agg[k][c] / max(cnt[k][c], 1)))
