@@ -33,7 +33,21 @@ def run(fn, n=4):
   torch.cuda.synchronize()
 
 
-if what.startswith('conv3d') or what == 'bn3d_32':
+if what in ('conv3d_fwd_s2', 'conv3d_bwd_data_s2', 'deconv3d_fwd_64_32'):
+  # hourglass conv1 (32 -> 64, stride 2) forward / input gradient at the 48 x 256 x 128 volume, conv6 (ConvTranspose3d 64 -> 32), B = 2
+  if what == 'deconv3d_fwd_64_32':
+    x = torch.randn(2, 64, 24, 128, 64, device=dev)
+    w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
+    run(lambda: HF.deconv3d_fwd(x, w))
+  else:
+    x = torch.randn(2, 32, 48, 256, 128, device=dev)
+    w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
+    gy = torch.randn(2, 64, 24, 128, 64, device=dev)
+    if what == 'conv3d_fwd_s2':
+      run(lambda: HF.conv3d_fwd(x, w, 2))
+    else:
+      run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 2))
+elif what.startswith('conv3d') or what == 'bn3d_32':
   x = torch.randn(2, 32, 48, 256, 128, device=dev)
   w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
   gy = torch.randn_like(x)
@@ -68,20 +82,6 @@ elif what.startswith('sphere'):
   else:
     gw = torch.zeros_like(w)
     run(lambda: HF.sphere_conv_bwd_weight_t(gyt, pos, xt, gw, 1))
-elif what in ('conv3d_fwd_s2', 'conv3d_bwd_data_s2', 'deconv3d_fwd_64_32'):
-  # hourglass conv1 (32 -> 64, stride 2) forward / input gradient at the 48 x 256 x 128 volume, conv6 (ConvTranspose3d 64 -> 32), B = 2
-  if what == 'deconv3d_fwd_64_32':
-    x = torch.randn(2, 64, 24, 128, 64, device=dev)
-    w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
-    run(lambda: HF.deconv3d_fwd(x, w))
-  else:
-    x = torch.randn(2, 32, 48, 256, 128, device=dev)
-    w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
-    gy = torch.randn(2, 64, 24, 128, 64, device=dev)
-    if what == 'conv3d_fwd_s2':
-      run(lambda: HF.conv3d_fwd(x, w, 2))
-    else:
-      run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 2))
 elif what == 'cost_volume_fwd':
   fr = torch.randn(2, 32, 256, 128, device=dev)
   ft = torch.randn_like(fr)
