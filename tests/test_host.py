@@ -270,11 +270,20 @@ def test_bench_labels_on_the_split_path():
   spec.loader.exec_module(bench)
   assert bench._on_split_path('conv3d_fwd[32->32 s1 48x256x128]')
   assert bench._on_split_path('conv3d_bwd_data[64->64 s1 24x128x64]')
-  assert not bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]')
+  assert bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]') and bench._on_split_path('conv3d_bwd_data[32->64 s2 48x256x128]')  # round 3
+  assert not bench._on_split_path('conv3d_bwd_weight[32->64 s2 48x256x128]') and not bench._on_split_path('conv3d_bn_eval[32->64 s2 48x256x128]')
+  assert bench._on_split_path('deconv3d_fwd') and not bench._on_split_path('deconv3d_bn_eval')
   assert not bench._on_split_path('conv3d_fwd[32->1 s1 48x256x128]')
   assert bench._on_split_path('conv3d_bwd_weight[32->32 s1 64x512x256]') and bench._on_split_path('conv2d_fwd[64->64 d2 256x128]')
   assert bench._on_split_path('conv2d_bwd_weight[20->40 d1 26x70]') and not bench._on_split_path('conv2d_fwd[20->40 d1 26x70]')
-  assert not bench._on_split_path('sphere_conv_bwd_weight[128->128 256x128]')
+  # the spherical layers of the extractor (64 / 128 -> 128): compact-window tiles on the split kernels; the integer-table layers that share
+  # the labels (32 -> 288 tap products, the 64 -> 64 stride-2 layer) stay on the fp32 gather kernels
+  assert bench._on_split_path('sphere_conv_bwd_weight[128->128 256x128]') and bench._on_split_path('sphere_conv_bwd_data[64->128 256x128]')
+  assert bench._on_split_path('sphere_conv_fwd[128->128 256x128]') and not bench._on_split_path('sphere_conv_fwd[32->288 256x128]')
+  assert not bench._on_split_path('sphere_conv_fwd[64->64 512x256]')
+  assert bench.kernel_of('conv3d_bwd_data[32->64 s2 48x256x128]', 'bf16x6') == 'deconv3d_split_kernel'
+  assert bench.kernel_of('conv3d_fwd[32->64 s2 48x256x128]', 'bf16x6') == 'conv3d_s2_split_kernel'
+  assert bench.kernel_of('conv3d_fwd[32->64 s2 48x256x128]', 'f32') == 'conv3d_kernel'
   assert abs(bench.MFMA_BF16_PEAK_TFLOPS / 6.0 - 416.67) < 0.01
 
 
