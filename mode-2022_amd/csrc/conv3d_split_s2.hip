@@ -16,6 +16,9 @@
 // per wave would chain 84 dependent MFMAs); the two halves of a tile are added through LDS when the tile's last chunk is done.
 // 84 MFMAs per wave and chunk against 4 staged positions per thread -- four times less matrix work per staged position than stride 1,
 // which is what bounds this kernel (the loads of a chunk sit under tap pairs 0..3, their split and LDS stores under pairs 10..13).
+// The launched form keeps ONE LDS buffer (64 KB with the reduction area) and runs two workgroups per CU: the staging arithmetic of a
+// chunk does not fit under 84 MFMAs, so it is a phase of its own that overlaps with the other workgroup's MFMA phase (template
+// parameter PHASED; the double-buffered single-workgroup form of conv3d_split.hip measured 0.376 ms against 0.350).
 // Persistent workgroups, XCD-contiguous tile ranges, weights split and packed once per launch: conv3d_split.hip.
 #include "common.h"
 
@@ -40,7 +43,6 @@ constexpr int BUF = 3 * PIECE;                   // uint4 per buffer
 constexpr int NPAIR = 14;
 constexpr int MT = 2;                            // output-channel tiles per launch
 constexpr int RED_FLOATS = 2 * TH * 16 * 64;  // the odd-pair waves' accumulators: [2 m][2 rows][16][64 lanes]
-constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 98 304 + 16 384 B
 
 struct S2Dims {
   int B, K, Co, D, H, W;  // input volume; K = reduction channels

@@ -12,7 +12,9 @@ from . import BnEpilogue, check, lib, profiling, ptr, require_f32c, require_gpu,
 class _LRU(object):
   """Bounded cache for the per-geometry device tables (sampling tables of the integer-table convolutions, tile plans, adjoint
   tables, transposed tables): a process that evaluates many resolutions (fisheye / 3D60 / Deep360 in one run) would otherwise pin
-  one set per shape for ever -- the adjoint of the 7x7 stem at 1024 x 512 alone is ~100 MB.  Callers hold their own lock."""
+  one set per shape for ever -- the adjoint of the 7x7 stem at 1024 x 512 alone is ~100 MB.  Callers hold their own lock.
+  A captured hipGraph (mode_hip.graph_step) holds the raw addresses of the tables its kernels were launched with: keep the number of
+  geometries in use below TABLE_CACHE_ENTRIES per cache while such a graph is replayed (one ModeDisparity uses ~10 entries in total)."""
 
   def __init__(self, maxsize):
     self.maxsize = maxsize
