@@ -492,7 +492,8 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.conv_arith == 'f32' else 'f32 (stride-1 3x3x3 layers: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j)',
+        'dtype': 'f32' if args.conv_arith == 'f32' else ('f32 (3x3x3, 3x3 and spherical convolution layers incl. gradients: fp32 operands split exactly into 3 bf16 '
+                                                            'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l)'),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
