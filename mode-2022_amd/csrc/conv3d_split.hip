@@ -45,6 +45,7 @@ constexpr int KIT = (ITEMS + 256 - 1) / 256;  // 6 positions per thread
 constexpr int PIECE = KIT * 256;        // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
 constexpr int BUF = 3 * PIECE;          // uint4 per buffer
 constexpr int NPAIR = 14;
+constexpr int WAHEAD = 3;  // EXPERIMENT: weight fragments this many tap pairs ahead (was 6)
 constexpr int R = TD * TH / 4;          // 4 output rows per matrix wave
 constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
 
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
       stage_commit(0, k, 1);
     }
 #pragma unroll
-    for (int pair = 0; pair < 6; ++pair) load_a(pair, 0, pair);
+    for (int pair = 0; pair < WAHEAD; ++pair) load_a(pair, 0, pair);
   }
   __syncthreads();
 
@@ -292,10 +293,10 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
           for (int p = 0; p < 3; ++p) bq[(pair + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];
       }
       // weights 6 pairs ahead, into the slot the previous pair has left
-      if (pair + 6 < NPAIR)
-        load_a((pair + 6) % 7, ch, pair + 6);
+      if (pair + WAHEAD < NPAIR)
+        load_a((pair + WAHEAD) % 7, ch, pair + WAHEAD);
       else
-        load_a((pair + 6) % 7, ch_next, pair + 6 - NPAIR);
+        load_a((pair + WAHEAD) % 7, ch_next, pair + WAHEAD - NPAIR);
       // the staging arithmetic sits under the last 6 pairs, one position each: the loads have had 8 pairs (~6 000 cycles) to land
       if (pair < KIT) stage_load(pair);
       if (EPI == 2 && pair >= NPAIR - 2 * R) {  // residual values of one row, 8 of its 16 output channels, under each of the last 8 pairs
