@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Times the stride-1 3-D convolution kernels of the regulariser in isolation (benchmark shapes, B = 2), 20 launches each after
+warm-up, torch events on the current stream (HF launches on it): ms per launch.  For A/B runs of one kernel change on one box."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'mode-2022_amd')):
+  sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from mode_hip import functional as HF  # noqa: E402
+
+dev = torch.device('cuda', 0)
+
+
+def t_ms(fn, n=20):
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(n):
+    fn()
+  b.record()
+  torch.cuda.synchronize()
+  return a.elapsed_time(b) / n
+
+
+out = []
+for (C, D, H, W) in ((32, 48, 256, 128), (64, 24, 128, 64)):
+  x = torch.randn(2, C, D, H, W, device=dev)
+  w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+  gy = torch.randn_like(x)
+  gw = torch.zeros_like(w)
+  out.append('%d->%d %dx%dx%d: fwd %.4f  bwd_data %.4f  bwd_weight %.4f' % (
+      C, C, D, H, W, t_ms(lambda: HF.conv3d_fwd(x, w, 1)), t_ms(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 1)),
+      t_ms(lambda: HF.conv3d_bwd_weight(gy, x, 1))))
+print(' | '.join(out))
