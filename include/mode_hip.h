@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 13 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 14 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -374,6 +374,13 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
                             mode_stream_t stream);
 int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                   mode_stream_t stream);
+/* The weight gradient of the stride-2 convolution on the split-bf16 kernel of csrc/conv3d_split_wgrad_s2.hip (the gradients cuDNN
+ * computes for hourglass conv1 / conv3, mode_disparity.py:17-19; called with gy := the input of a ConvTranspose3d and x := the gradient
+ * of its output it gives that layer's (Cin, Cout, 27) weight gradient: conv5 / conv6, :23-25).  Arguments and workspace as
+ * mode_conv3d_bwd_weight with stride 2; x channels a multiple of 32, gy channels a multiple of 64
+ * (mode_conv3d_split_supported(Ci, Co, 2, 2) == 1), D and H even, W a multiple of 8. */
+int mode_conv3d_bwd_weight_s2_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H, int W,
+                                    int Co, int accumulate, mode_stream_t stream);
 
 int mode_conv3d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int D,
                           int H, int W, int Co, mode_stream_t stream);

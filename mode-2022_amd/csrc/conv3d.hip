@@ -545,8 +545,10 @@ extern "C" size_t mode_conv3d_wpack_bytes(int Ci, int Co) {
 
 extern "C" int mode_conv3d_split_supported(int Ci, int Co, int stride, int which) {
   if (Ci <= 0 || Co <= 0) return 0;
-  if (stride == 2) {  // forward: mode_conv3d_fwd_s2_split; input gradient: mode_conv3d_bwd_data_s2_split (even volumes); no weight gradient
+  if (stride == 2) {  // forward: mode_conv3d_fwd_s2_split; input gradient: mode_conv3d_bwd_data_s2_split (even volumes); weight gradient:
+                      // mode_conv3d_bwd_weight_s2_split (even volumes, W a multiple of 8; gy in blocks of 64 channels, x in blocks of 32)
     if (which == 0) return mode::conv3d_s2_split_supported(Ci, Co) ? 1 : 0;
+    if (which == 2) return (Co % 64 == 0 && Ci % 32 == 0) ? 1 : 0;
     return (which == 1 && mode::deconv3d_split_supported(Co, Ci)) ? 1 : 0;
   }
   if (stride != 1) return 0;
@@ -1294,6 +1296,46 @@ extern "C" int mode_conv3d_bwd_weight_split(const float* gy, const float* x, flo
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight_split(reduce)");
+}
+
+// Weight gradient of the stride-2 convolution on the split-bf16 kernel of conv3d_split_wgrad_s2.hip: x (B, Ci, D, H, W), gy (B, Co,
+// D/2, H/2, W/2); D and H even, W a multiple of 8; needs mode_conv3d_split_supported(Ci, Co, 2, 2) == 1.  With (gy := the input of a
+// ConvTranspose3d, x := the gradient of its output) the result is that layer's (Cin, Cout, 27) weight gradient.
+extern "C" int mode_conv3d_bwd_weight_s2_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
+                                               int W, int Co, int accumulate, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_weight_s2_split";
+  int rc = check_conv_args(gy, x, gw, workspace, B, Ci, D, H, W, Co, 2, who, true);
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(mode_conv3d_split_supported(Ci, Co, 2, 2) == 1, MODE_ERR_UNSUPPORTED, "%s: %d -> %d channels are not covered by the split kernel",
+               who, Ci, Co);
+  MODE_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 8 == 0, MODE_ERR_UNSUPPORTED, "%s: needs even D, H and W a multiple of 8 (got %dx%dx%d)", who,
+               D, H, W);
+  MODE_REQUIRE(std::max((long long)std::min(Ci, 32) * D * H * W, (long long)std::min(Co, 64) * (D / 2) * (H / 2) * (W / 2)) < (1ll << 29),
+               MODE_ERR_UNSUPPORTED, "%s: a channel block of one sample exceeds 2^29 elements", who);
+  hipStream_t st = mode::as_stream(stream);
+  if (B == 0) {
+    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
+    return MODE_OK;
+  }
+  WDims d;
+  make_wdims(d, B, Ci, D, H, W, Co, 2);
+  mode::WgradS2SplitDims q;
+  q.Ci = Ci; q.Co = Co; q.D = D; q.H = H; q.W = W; q.Do = d.Do; q.Ho = d.Ho; q.Wo = d.Wo;
+  q.nWt = mode::cdiv(d.Wo, 16); q.MTo = d.MTo; q.MTc = d.MTc;
+  // one workgroup per CU (130 KB of LDS each); a unit starts with two un-pipelined stagings, so as deep as the volume allows while
+  // every workgroup still gets >= 2 units
+  int S = std::max(1, kNumCU / (mode::cdiv(d.MTo, 2) * d.MTc));
+  int ring_dc = d.Do;
+  while (ring_dc > 3 && (long long)B * d.Ho * q.nWt * mode::cdiv(d.Do, ring_dc) < 2ll * S) ring_dc = mode::cdiv(ring_dc, 2);
+  q.ring_dc = ring_dc;
+  q.nDc = mode::cdiv(d.Do, ring_dc);
+  q.units = B * d.Ho * q.nWt * q.nDc;
+  q.S = std::min(std::min(S, q.units), d.S);  // never more partials than the workspace query assumed
+  d.S = q.S;
+  rc = mode::conv3d_bww_s2_split_launch(gy, x, workspace, q, st, who);
+  if (rc != MODE_OK) return rc;
+  hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
+  return mode::check_launch("mode_conv3d_bwd_weight_s2_split(reduce)");
 }
 
 // Transposed convolution k3 s2 p1 op1 (= backward-data of the stride-2 convolution).

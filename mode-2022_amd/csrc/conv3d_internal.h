@@ -47,6 +47,15 @@ struct WgradSplitDims {
 };
 int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who);
 
+// conv3d_split_wgrad_s2.hip: the same for the stride-2 convolution (x at D x H x W, gy at Do x Ho x Wo = half of it; even D, H and
+// W a multiple of 8); a workgroup owns BOTH 32-row blocks of a 64-channel gy block (grid y = cdiv(MTo, 2)).
+struct WgradS2SplitDims {
+  int Ci, Co, D, H, W, Do, Ho, Wo;
+  int nWt, nDc, ring_dc, units;  // units = B * Ho * nWt * nDc work units of ring_dc output depths x 1 output row x 16 output voxels
+  int S, MTo, MTc;
+};
+int conv3d_bww_s2_split_launch(const float* gy, const float* x, float* part, const WgradS2SplitDims& d, hipStream_t st, const char* who);
+
 // conv2d_split.hip: the regular 3x3 Conv2d layers (stride 1, dilation 1 / 2) on the split-bf16 matrix path; arguments as conv2d.hip's
 // run() (rows = output channels of the GEMM, K = its reduction channels, flip 0 forward / 1 input gradient).
 bool conv2d_split_supported(int K, int rows, int dilation);

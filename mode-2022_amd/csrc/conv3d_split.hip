@@ -45,7 +45,7 @@ constexpr int KIT = (ITEMS + 256 - 1) / 256;  // 6 positions per thread
 constexpr int PIECE = KIT * 256;        // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
 constexpr int BUF = 3 * PIECE;          // uint4 per buffer
 constexpr int NPAIR = 14;
-constexpr int WAHEAD = 3;  // EXPERIMENT: weight fragments this many tap pairs ahead (was 6)
+constexpr int WAHEAD = 6;  // weight fragments are loaded this many tap pairs ahead (3 measured the same, r03w)
 constexpr int R = TD * TH / 4;          // 4 output rows per matrix wave
 constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
 

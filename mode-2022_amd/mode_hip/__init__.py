@@ -92,6 +92,7 @@ SIGNATURES = {
     'mode_conv3d_bwd_data_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_conv3d_bwd_weight_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 7),
     'mode_deconv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 8 + [_c_ptr]),
@@ -112,7 +113,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 13  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 14  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

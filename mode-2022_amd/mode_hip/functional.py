@@ -1131,7 +1131,10 @@ def conv3d_bwd_weight(gy, x, stride=1, into=None):
                                                   4 * (x.numel() + gy.numel() + gw.numel()), flops, gy.device):
     n = lib().mode_conv3d_bwd_weight_workspace_bytes(B, Ci, D, H, W, Co, stride)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gy.device)
-    if _split3d(Ci, Co, stride, 2) and max(Ci, Co) * D * H * W < 2**29:
+    if stride == 2 and _split3d(Ci, Co, 2, 2) and D % 2 == 0 and H % 2 == 0 and W % 8 == 0 and 32 * D * H * W < 2**29:
+      check(lib().mode_conv3d_bwd_weight_s2_split(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None), stream_of(gy)),
+            'mode_conv3d_bwd_weight_s2_split')
+    elif stride == 1 and _split3d(Ci, Co, stride, 2) and max(Ci, Co) * D * H * W < 2**29:
       check(lib().mode_conv3d_bwd_weight_split(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None), stream_of(gy)),
             'mode_conv3d_bwd_weight_split')
     else:

@@ -114,6 +114,58 @@ def test_split_weight_gradient_is_an_fp32_weight_gradient(B, Ci, Co, D, H, W, sp
   assert torch.allclose(acc, got + 1.0, rtol=0, atol=1e-5 * scale), 'accumulating form'
 
 
+S2_WGRAD_CASES = [
+    (2, 32, 64, 8, 12, 32),    # hourglass conv1 in small: x 32 channels, gy 64
+    (1, 64, 64, 6, 8, 24),     # conv3; Wo = 12: a ragged 16-voxel column block
+    (3, 64, 128, 2, 4, 8),     # two 64-channel gy blocks, one output depth
+    (1, 32, 64, 14, 6, 48),    # 7 output depths in one unit: the odd tail of the two-phase loop
+    (2, 32, 64, 40, 4, 16),    # long depth runs
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,D,H,W', S2_WGRAD_CASES)
+def test_split_stride2_weight_gradient_against_float64(B, Ci, Co, D, H, W, split_arith):
+  """mode_conv3d_bwd_weight_s2_split (csrc/conv3d_split_wgrad_s2.hip): the stride-2 layers' weight gradient on de-interleaved x rows
+  and a ring of five planes, against float64 and beside the fp32 MFMA kernel on the same inputs; deterministic; accumulating form."""
+  assert mode_hip.lib().mode_conv3d_split_supported(Ci, Co, 2, 2) == 1
+  x = _rand((B, Ci, D, H, W), 271)
+  gy = _rand((B, Co, D // 2, H // 2, W // 2), 272)
+  wa = torch.zeros((Co, Ci, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+  F.conv3d(x.double(), wa, None, 2, 1).backward(gy.double())
+  want = wa.grad
+  xd, gd = x.to(DEV), gy.to(DEV)
+  got = HF.conv3d_bwd_weight(gd, xd, 2)
+  HF.set_conv_arith('f32')
+  got32 = HF.conv3d_bwd_weight(gd, xd, 2)
+  HF.set_conv_arith('bf16x6')
+  scale = max(1.0, float(want.abs().max()))
+  e, e32 = _err(got, want), _err(got32, want)
+  print('stride-2 bwd_weight %s: split %.3e, fp32 MFMA %.3e (scale %.3g)' % ((B, Ci, Co, D, H, W), e, e32, scale))
+  assert not torch.equal(got, got32), 'the split kernel ran (its rounding differs from the fp32 MFMA kernel\'s)'
+  assert e <= 2e-5 * scale
+  assert torch.equal(got, HF.conv3d_bwd_weight(gd, xd, 2)), 'not deterministic'
+  acc = torch.ones_like(got)
+  HF.conv3d_bwd_weight(gd, xd, 2, into=acc)
+  assert torch.allclose(acc, got + 1.0, rtol=0, atol=1e-5 * scale), 'accumulating form'
+
+
+def test_split_transposed_convolution_weight_gradient_against_float64(split_arith):
+  """ConvTranspose3d k3 s2 p1 op1 (hourglass conv5 / conv6): its weight gradient is the same kernel with the operands exchanged."""
+  for (cin, cout, D, H, W) in ((64, 32, 4, 6, 16), (64, 64, 3, 4, 8)):
+    x = _rand((2, cin, D, H, W), 281)
+    w = _rand((cin, cout, 3, 3, 3), 282, 0.05)
+    xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = F.conv_transpose3d(xa, wa, None, 2, 1, 1)
+    gy = _rand(tuple(want.shape), 283)
+    want.backward(gy.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = HF.deconv3d(xd, wd)
+    y.backward(gy.to(DEV))
+    assert _err(y, want.detach()) <= _tol(cin * 27, want.detach())
+    assert _err(wd.grad, wa.grad) <= 2e-5 * max(1.0, float(wa.grad.abs().max())), (cin, cout)
+    assert _err(xd.grad, xa.grad) <= _tol(cout * 27, xa.grad)
+
+
 def test_split_through_autograd_and_fallback_layers(split_arith):
   """HF.conv3d (the autograd op the model calls) in split mode: 64-channel layers run as two launches of 32 output channels; a
   stride-2 layer, a layer whose reduction channels are not a multiple of 8 and one with 96 output channels keep running on the fp32

@@ -28,6 +28,19 @@ def t_ms(fn, n=20):
 
 
 out = []
+if 's2w' in sys.argv:
+  # stride-2 / transposed weight gradients of the hourglass: (x channels, gy channels, x volume), B = 2, both arithmetics
+  for (ci, co, D, H, W) in ((32, 64, 48, 256, 128), (64, 64, 24, 128, 64), (64, 64, 12, 64, 32)):
+    x = torch.randn(2, ci, D, H, W, device=dev)
+    gy = torch.randn(2, co, D // 2, H // 2, W // 2, device=dev)
+    r = []
+    for arith in ('bf16x6', 'f32'):
+      HF.set_conv_arith(arith)
+      r.append(t_ms(lambda: HF.conv3d_bwd_weight(gy, x, 2)))
+    HF.set_conv_arith('bf16x6')
+    out.append('s2 bwd_weight x%d gy%d %dx%dx%d: split %.4f  fp32 %.4f' % (ci, co, D, H, W, r[0], r[1]))
+  print(' | '.join(out))
+  sys.exit(0)
 for (C, D, H, W) in ((32, 48, 256, 128), (64, 24, 128, 64)):
   x = torch.randn(2, C, D, H, W, device=dev)
   w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
