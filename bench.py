@@ -156,7 +156,7 @@ def kernel_of(label, conv_arith, on_split=None):
     if re.search(r'->1 ', label):
       return 'conv3d_co1_bwd_weight_kernel'
     if split:
-      return 'conv3d_bww_split_kernel'
+      return 'conv3d_bww_split_kernel' if stride == 1 else 'conv3d_bww_s2_split_kernel'
     return 'conv3d_bwd_weight_ring_kernel' if stride == 1 else 'conv3d_bwd_weight_s2_kernel'
   if name == 'deconv3d_fwd':
     return 'deconv3d_split_kernel' if conv_arith == 'bf16x6' else 'deconv3d_kernel'

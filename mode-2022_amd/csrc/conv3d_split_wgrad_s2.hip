@@ -19,8 +19,8 @@
 // planes 2q-1, 2q, 2q+1, the next one 2q+1, 2q+2, 2q+3: the planes live in a RING of five (three in use, two being staged), 3 rows
 // each, so every x value is loaded and split once per unit; gy has two buffers.  The 27 taps are dealt to the waves as whole
 // (kd, kh) groups (wave w: groups w and w + 4, the ninth group one tap each to waves 0..2), 14 accumulators of 16 registers per wave.
-// A phase = one output depth = 84 MFMAs per wave; the loads of phase q + 2 are issued at the head of phase q and split + stored during
-// phase q + 1 (two register sets), one LDS-only barrier per phase.  Split-K partials in the layout of conv3d.hip's weight-gradient
+// A phase = one output depth = 84 MFMAs per wave; the loads of phase q + 3 are issued at the head of phase q and split + stored during
+// phase q + 2 (three register sets), one LDS-only barrier per phase.  Split-K partials in the layout of conv3d.hip's weight-gradient
 // kernels, reduced by its fixed-order kernel.
 #include "common.h"
 
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
 
   // staging items of this thread, the same in every unit
   const int f4 = tid & 7, xc = tid >> 3;                 // x: float4 f4 of a row, channel xc; item k = (plane k / 3, row k % 3)
-  const int hc = tid & 31, hk = tid >> 5;                // halo column: channel hc, (plane, row) hk < 6
+  const int hc = tid & 31, hk = (tid >> 5) < 6 ? (tid >> 5) : (tid >> 5) - 2;  // halo column: channel hc, (plane, row) hk < 6 (threads
+                                                         // 192..255 repeat the items of 128..191: no branch around the stores)
   const int hpz = hk / 3, hrw = hk % 3;
   const int go = tid >> 2, gf4 = tid & 3;                // gy: output channel go of the 64, float4 gf4 of the 16 voxels
   const int xdst = xc * XCS + 2 * f4;                    // (+ slot * XSLOT + row * XROW [+ XO] + piece * XPIECE)
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
     }
     {
       const int gh = 2 * qh - 1 + hrw, gwh = 2 * w0 - 1;
-      hm = (unsigned)(hk < 6) & (unsigned)(gwh >= 0) & (unsigned)((unsigned)gh < (unsigned)d.H) & (unsigned)(cb * 32 + hc < d.Ci);
+      hm = (unsigned)(gwh >= 0) & (unsigned)((unsigned)gh < (unsigned)d.H) & (unsigned)(cb * 32 + hc < d.Ci);
       ho = hm ? 4u * (unsigned)(hc * DHWi + gh * d.W + gwh) : 0u;
     }
     {
@@ -155,12 +156,10 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
       const float v = (hm && (unsigned)z < (unsigned)d.D) ? st.hr : 0.f;
       uint32_t p1, p2, p3;
       split2(v, 0.f, p1, p2, p3);
-      if (hk < 6) {
-        uint16_t* dst = xl + hdst + ring5(z) * XSLOT;
-        dst[0] = (uint16_t)p1;
-        dst[XPIECE] = (uint16_t)p2;
-        dst[2 * XPIECE] = (uint16_t)p3;
-      }
+      uint16_t* dst = xl + hdst + ring5(z) * XSLOT;
+      dst[0] = (uint16_t)p1;
+      dst[XPIECE] = (uint16_t)p2;
+      dst[2 * XPIECE] = (uint16_t)p3;
     }
     {
       const bool ok = gm && (unsigned)q < (unsigned)d.Do;
@@ -175,26 +174,26 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
     }
   };
 
-  // one output depth: the MFMAs of depth dd on the ring; `cs` (the planes and gy row of depth dd + 1, loaded one phase ago) is split and
-  // stored under them, the loads of depth dd + 2 go into `ls`
+  // (Measured and dropped: the six items of a set in an order rotated by channel, so that one load instruction of the workgroup spreads
+  // over six (plane, row) offsets instead of 32 channels at ONE offset -- the channels of the benchmark volume are 3 * 2^21 bytes apart
+  // and the kernel is 15-20 % faster per voxel at 50 x 256 x 128 or 46 x 256 x 128; the rotation cost 26 registers and 8 % of the time
+  // and bought nothing.)
+  // one output depth: the MFMAs of depth dd on the ring; `cs` (the planes and gy row of depth dd + 1, loaded two phases ago) is split
+  // and stored under them, the loads of depth dd + 3 go into `ls` (measured at 48 x 256 x 128: with the loads one phase ahead a phase
+  // lasted 3.4 us against 1.9 us without memory traffic -- 32 channels 6.3 MB apart, every workgroup on the same beat)
   auto phase = [&](int dd, Stage& cs, Stage& ls) {
-    load_set(ls, dd + 2);
+    load_set(ls, dd + 3);
+    __builtin_amdgcn_sched_barrier(0);  // the loads leave at the head of the phase: they are split and stored two phases later
     const int lc = (lane & 31) * XCS + 8 * half;
     const int b0 = lc + ring5(2 * dd - 1 + g0 / 3) * XSLOT + (g0 % 3) * XROW;
     const int b1 = lc + ring5(2 * dd - 1 + g1 / 3) * XSLOT + (g1 % 3) * XROW;
     const int b2 = lc + ring5(2 * dd + 1) * XSLOT + 2 * XROW;
     const uint16_t* ga = gl + (dd & 1) * GBUF + (lane & 31) * GCS + 8 * half;
     uint4 a[2][3], bq[7][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      a[0][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + p * GPIECE, 16));
-      a[1][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + 32 * GCS + p * GPIECE, 16));
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    auto read_group = [&](int g, int base) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        const uint16_t* src = xl + (g ? b1 : b0) + p * XPIECE;
+        const uint16_t* src = xl + base + p * XPIECE;
         const uint4 e = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(src, 16));
         const uint4 o = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(src + XO, 16));
         const uint32_t pv = *reinterpret_cast<const uint32_t*>(src + XO - 2);
@@ -203,15 +202,14 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
         bq[3 * g + 1][p] = e;
         bq[3 * g + 2][p] = o;
       }
-    }
+    };
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      const uint16_t* src = xl + b2 + p * XPIECE;
-      const uint4 o = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(src + off6, 16));
-      const uint32_t pv = *reinterpret_cast<const uint32_t*>(src + poff6);
-      bq[6][p] = make_uint4(__builtin_amdgcn_perm(o.x, pv, sel6), __builtin_amdgcn_perm(o.y, o.x, sel6), __builtin_amdgcn_perm(o.z, o.y, sel6),
-                            __builtin_amdgcn_perm(o.w, o.z, sel6));
+      a[0][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + p * GPIECE, 16));
+      a[1][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + 32 * GCS + p * GPIECE, 16));
     }
+    read_group(0, b0);
+    __builtin_amdgcn_sched_barrier(0);
     // smallest terms first; consecutive MFMAs go to different accumulators
 #define MODE_S2W_TERM(T0, T1, PA, PB)                          \
   _Pragma("unroll") for (int t7 = T0; t7 < T1; ++t7) {         \
@@ -225,19 +223,61 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
   MODE_S2W_TERM(T0, T1, 1, 0) \
   MODE_S2W_TERM(T0, T1, 0, 1) \
   MODE_S2W_TERM(T0, T1, 0, 0)
+    // first 36 MFMAs (group g0): under them the fragments of the other four taps are read and half of the staged set is split + stored
+    read_group(1, b1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const uint16_t* src = xl + b2 + p * XPIECE;
+      const uint4 o = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(src + off6, 16));
+      const uint32_t pv = *reinterpret_cast<const uint32_t*>(src + poff6);
+      bq[6][p] = make_uint4(__builtin_amdgcn_perm(o.x, pv, sel6), __builtin_amdgcn_perm(o.y, o.x, sel6), __builtin_amdgcn_perm(o.z, o.y, sel6),
+                            __builtin_amdgcn_perm(o.w, o.z, sel6));
+    }
     MODE_S2W_SET(0, 3)
 #pragma unroll
     for (int k = 0; k < 3; ++k) commit_x(cs, dd + 1, k);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // (a store needs the ~40 instructions of its split first: no store slots yet)
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     MODE_S2W_SET(3, 7)
 #pragma unroll
     for (int k = 3; k < 6; ++k) commit_x(cs, dd + 1, k);
     commit_hg(cs, dd + 1);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #undef MODE_S2W_SET
 #undef MODE_S2W_TERM
     lds_barrier();
   };
 
-  Stage sa, sb;
+  Stage s0, s1, s2;
   for (int u = xcd_remap(s, d.S); u < d.units; u += d.S) {
     int t = u;
     const int dc = t % d.nDc;
@@ -252,21 +292,24 @@ __global__ __launch_bounds__(NT) void conv3d_bww_s2_split_kernel(const float* __
     gb = gy + ((long long)b * d.Co + obp * 64) * oDHW;
 
     // prologue of a unit (the last barrier of the previous unit has passed): planes 2 dlo - 2 .. 2 dlo + 1 and the gy row of depth dlo
-    // (plane 2 dlo - 2 and gy row dlo - 1 ride along unused: one staging routine); the loads of depth dlo + 1 start
-#pragma unroll 1
-    for (int q = dlo - 1; q <= dlo; ++q) {
-      load_set(sa, q);
+    // (plane 2 dlo - 2 and gy row dlo - 1 ride along unused: one staging routine); the loads of depths dlo + 1 and dlo + 2 start
+    load_set(s0, dlo - 1);
+    load_set(s1, dlo);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) commit_x(sa, q, k);
-      commit_hg(sa, q);
-    }
-    load_set(sa, dlo + 1);
+    for (int k = 0; k < 6; ++k) commit_x(s0, dlo - 1, k);
+    commit_hg(s0, dlo - 1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) commit_x(s1, dlo, k);
+    commit_hg(s1, dlo);
+    load_set(s0, dlo + 1);
+    load_set(s1, dlo + 2);
     lds_barrier();
 
 #pragma unroll 1
-    for (int dd = dlo; dd < dhi; dd += 2) {
-      phase(dd, sa, sb);
-      if (dd + 1 < dhi) phase(dd + 1, sb, sa);
+    for (int dd = dlo; dd < dhi; dd += 3) {
+      phase(dd, s0, s2);
+      if (dd + 1 < dhi) phase(dd + 1, s1, s0);
+      if (dd + 2 < dhi) phase(dd + 2, s2, s1);
     }
   }
 

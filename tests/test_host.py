@@ -271,7 +271,8 @@ def test_bench_labels_on_the_split_path():
   assert bench._on_split_path('conv3d_fwd[32->32 s1 48x256x128]')
   assert bench._on_split_path('conv3d_bwd_data[64->64 s1 24x128x64]')
   assert bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]') and bench._on_split_path('conv3d_bwd_data[32->64 s2 48x256x128]')  # round 3
-  assert not bench._on_split_path('conv3d_bwd_weight[32->64 s2 48x256x128]') and not bench._on_split_path('conv3d_bn_eval[32->64 s2 48x256x128]')
+  assert bench._on_split_path('conv3d_bwd_weight[32->64 s2 48x256x128]') and not bench._on_split_path('conv3d_bn_eval[32->64 s2 48x256x128]')
+  assert not bench._on_split_path('conv3d_bwd_weight[32->32 s2 48x256x128]')  # gy in blocks of 64 channels
   assert bench._on_split_path('deconv3d_fwd') and not bench._on_split_path('deconv3d_bn_eval')
   assert not bench._on_split_path('conv3d_fwd[32->1 s1 48x256x128]')
   assert bench._on_split_path('conv3d_bwd_weight[32->32 s1 64x512x256]') and bench._on_split_path('conv2d_fwd[64->64 d2 256x128]')
@@ -284,6 +285,7 @@ def test_bench_labels_on_the_split_path():
   assert bench.kernel_of('conv3d_bwd_data[32->64 s2 48x256x128]', 'bf16x6') == 'deconv3d_split_kernel'
   assert bench.kernel_of('conv3d_fwd[32->64 s2 48x256x128]', 'bf16x6') == 'conv3d_s2_split_kernel'
   assert bench.kernel_of('conv3d_fwd[32->64 s2 48x256x128]', 'f32') == 'conv3d_kernel'
+  assert bench.kernel_of('conv3d_bwd_weight[64->64 s2 24x128x64]', 'bf16x6') == 'conv3d_bww_s2_split_kernel'
   assert abs(bench.MFMA_BF16_PEAK_TFLOPS / 6.0 - 416.67) < 0.01
 
 

@@ -30,7 +30,10 @@ def t_ms(fn, n=20):
 out = []
 if 's2w' in sys.argv:
   # stride-2 / transposed weight gradients of the hourglass: (x channels, gy channels, x volume), B = 2, both arithmetics
-  for (ci, co, D, H, W) in ((32, 64, 48, 256, 128), (64, 64, 24, 128, 64), (64, 64, 12, 64, 32)):
+  shapes = [(32, 64, 48, 256, 128), (64, 64, 24, 128, 64), (64, 64, 12, 64, 32)]
+  if 'strides' in sys.argv:  # does the time depend on the channel stride (48 x 256 x 128 x 4 B = 3 * 2^21: every channel on the same DRAM bank bits)?
+    shapes = [(32, 64, 48, 256, 128), (32, 64, 50, 256, 128), (32, 64, 48, 264, 128), (32, 64, 46, 256, 128)]
+  for (ci, co, D, H, W) in shapes:
     x = torch.randn(2, ci, D, H, W, device=dev)
     gy = torch.randn(2, co, D // 2, H // 2, W // 2, device=dev)
     r = []
