@@ -172,6 +172,51 @@ def kernel_of(label, conv_arith, on_split=None):
           'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel'}.get(name, name)
 
 
+def calibrated_traffic(label, batch, conv_arith, on_split=None):
+  """HBM bytes per launch of a label from the PMC passes (profiles/traffic.json, see profiles/README.md), or None."""
+  try:
+    with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+      table = json.load(f)
+  except (OSError, ValueError):
+    return None
+  # (the extractor's kernels see both views: 2 x batch images; the split kernels have their own entries)
+  tail = ' bf16x6' if (conv_arith == 'bf16x6' and (on_split if on_split is not None else _on_split_path)(label)) else ''
+  for key in ('%s B=%d%s' % (label, batch, tail), '%s B=%d%s' % (label, 2 * batch, tail), label + tail):
+    if key in table:
+      return table[key].get('hbm_bytes_per_launch')
+  return None
+
+
+def roofline_block(kern, conv_arith, batch, profile_steps, timed_over, on_split=None):
+  """The bench line's `roofline` object.  The dominant kernel is the DEVICE KERNEL with the largest total time over all the layer
+  shapes it serves -- the first row of `rocprofv3 --stats` for the same command -- priced against the pipe its launches run on:
+  achieved = algorithmic flops (bytes) of all its launches / their total duration, i.e. per average launch.  `traffic` is the PMC
+  figure of its heaviest layer shape (`traffic_label`).  `by_label` is the (operator, layer shape) label with the largest total
+  time, the finer-grained view the per-label table `kernels` is keyed by."""
+  steps = max(profile_steps, 1)
+  groups = by_kernel(kern, conv_arith, on_split)
+  kdom = max(groups, key=lambda k: groups[k]['total_ms'])
+  g = groups[kdom]
+  g_sec = g['total_ms'] * 1e-3
+  heavy = max(g['labels'], key=lambda k: kern[k]['total_ms'])
+  _, kpeak, kunit = label_peak(heavy, conv_arith, on_split)
+  work = g['bytes'] if g['bound'] == 'hbm' else g['flops']
+  dom = max(kern, key=lambda k: kern[k]['total_ms'])
+  a = kern[dom]
+  bound, peak, unit = label_peak(dom, conv_arith, on_split)
+  achieved, per_launch = (a['GBps'], a['bytes_per_call']) if bound == 'hbm' else (a['TFLOPs'], a['flops_per_call'])
+  return {'kernel': kdom, 'bound': g['bound'], 'achieved': work / g_sec / (1e9 if g['bound'] == 'hbm' else 1e12), 'peak': kpeak, 'unit': kunit,
+          'frac': g['need_s'] / g_sec, 'traffic': calibrated_traffic(heavy, batch, conv_arith, on_split), 'traffic_label': heavy,
+          'algorithmic_per_launch': work / max(g['calls'], 1), 'avg_ms': g['total_ms'] / max(g['calls'], 1), 'calls': g['calls'],
+          'ms_per_step': g['total_ms'] / steps, 'launches_per_step': g['calls'] / steps, 'labels': g['labels'],
+          'selected_by': 'largest total time of one device kernel over all the layer shapes it serves (the first row of rocprofv3 --stats); '
+                         'by_label = largest total time of one (operator, layer shape) label',
+          'by_label': {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
+                       'traffic': calibrated_traffic(dom, batch, conv_arith, on_split), 'algorithmic_per_launch': per_launch,
+                       'avg_ms': a['avg_ms'], 'calls': a['calls']},
+          'timed_over': timed_over}
+
+
 def by_kernel(kern, conv_arith, on_split=None):
   """{device kernel: dict(total_ms, calls, flops, bytes, need_s)} over all labels (need_s = time its pipe's peak would need)."""
   out = {}
@@ -521,44 +566,9 @@ def main():
         },
     }
     if kern:
-      # dominant hand-written kernel = the (kernel, layer shape) LABEL with the largest total time over the profiled steps ...
-      dom = max(kern, key=lambda k: kern[k]['total_ms'])
-      a = kern[dom]
-      bound, peak, unit = label_peak(dom, args.conv_arith)
-      if bound == 'hbm':
-        achieved, per_launch = a['GBps'], a['bytes_per_call']
-      else:
-        achieved, per_launch = a['TFLOPs'], a['flops_per_call']
-      traffic = None  # HBM bytes per launch from the PMC passes (profiles/traffic.json, see profiles/README.md)
-      try:
-        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-          table = json.load(f)
-        # (the extractor's kernels see both views: 2 x batch images; the split kernels have their own entries)
-        tail = ' bf16x6' if (args.conv_arith == 'bf16x6' and _on_split_path(dom)) else ''
-        for key in ('%s B=%d%s' % (dom, args.batch, tail), '%s B=%d%s' % (dom, 2 * args.batch, tail), dom + tail):
-          if key in table:
-            traffic = table[key].get('hbm_bytes_per_launch')
-            break
-      except (OSError, ValueError):
-        pass
-      # ... and the dominant DEVICE KERNEL over all the layer shapes it serves (what `rocprofv3 --stats` ranks first), priced against
-      # the pipe each of its launches runs on
-      groups = by_kernel(kern, args.conv_arith)
-      kdom = max(groups, key=lambda k: groups[k]['total_ms'])
-      g = groups[kdom]
-      g_sec = g['total_ms'] * 1e-3
-      out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
-                         'frac': achieved / peak, 'traffic': traffic, 'algorithmic_per_launch': per_launch,
-                         'avg_ms': a['avg_ms'], 'calls': a['calls'],
-                         'selected_by': 'largest total time of one (operator, layer shape) label; by_kernel = largest total time of one device '
-                                        'kernel over all its shapes (the first row of rocprofv3 --stats)',
-                         'by_kernel': {'kernel': kdom, 'bound': g['bound'], 'ms_per_step': g['total_ms'] / max(args.profile_steps, 1),
-                                       'launches_per_step': g['calls'] / max(args.profile_steps, 1),
-                                       'achieved': (g['bytes'] / g_sec / 1e9) if g['bound'] == 'hbm' else (g['flops'] / g_sec / 1e12),
-                                       'unit': 'GB/s' if g['bound'] == 'hbm' else 'TFLOP/s',
-                                       'frac': g['need_s'] / g_sec, 'labels': g['labels']},
-                         'timed_over': ('%d eager steps after the timed region (the timed steps replay a hipGraph)' % args.profile_steps)
-                                       if args.launch == 'graph' else 'the timed region'}
+      out['roofline'] = roofline_block(kern, args.conv_arith, args.batch, args.profile_steps,
+                                       ('%d eager steps after the timed region (the timed steps replay a hipGraph)' % args.profile_steps)
+                                       if args.launch == 'graph' else 'the timed region')
       # north_star targets: HBM fraction of the cost-volume build, MFMA fraction of the whole 3D regulariser -- every label against
       # the pipe it runs on (fp32 MFMA 157.3, or bf16 / 6 = 416.7 for the split kernels), time-weighted: never above 1
       cv = kern.get('cost_volume_fwd')

@@ -54,3 +54,25 @@ def test_by_kernel_groups_labels_of_one_device_kernel():
   assert g['bn_stats_kernel+bn_apply_kernel']['bound'] == 'hbm'
   hb = g['bn_stats_kernel+bn_apply_kernel']
   assert abs(hb['need_s'] - 10 * 1.208e9 / 8000e9) < 1e-12
+
+
+def test_roofline_block_names_the_dominant_device_kernel():
+  """`roofline` = the device kernel with the largest total time over all its layer shapes (rocprofv3 --stats' first row), its
+  fraction from ALL its launches; `by_label` = the single heaviest (operator, shape) label."""
+  k = _kern()
+  k['conv3d_bwd_data[32->32 s1 48x256x128]'] = dict(k['conv3d_fwd[32->32 s1 48x256x128]'])
+  k['conv3d_fwd[64->64 s1 24x128x64]'] = dict(calls=6, total_ms=6 * 0.40, flops=6 * 86.97e9, bytes=0, avg_ms=0.40, TFLOPs=86.97 / 0.40, GBps=0.0)
+  for v in k.values():
+    v['bytes_per_call'] = v['bytes'] / v['calls']
+    v['flops_per_call'] = v['flops'] / v['calls']
+  r = bench.roofline_block(k, 'bf16x6', 2, 2, 'test', _split)
+  assert r['kernel'] == 'conv3d_split_kernel<1,0>' and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
+  assert r['calls'] == 30 and abs(r['avg_ms'] - (24 * 0.80 + 6 * 0.40) / 30) < 1e-12 and abs(r['ms_per_step'] - (24 * 0.80 + 6 * 0.40) / 2) < 1e-12
+  flops, sec = 24 * 173.95e9 + 6 * 86.97e9, (24 * 0.80 + 6 * 0.40) * 1e-3
+  assert abs(r['achieved'] - flops / sec / 1e12) < 1e-9 and abs(r['peak'] - 2500.0 / 6.0) < 1e-12
+  assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] < 1
+  assert abs(r['algorithmic_per_launch'] - flops / 30) < 1e-3
+  assert r['traffic_label'] in ('conv3d_fwd[32->32 s1 48x256x128]', 'conv3d_bwd_data[32->32 s1 48x256x128]')
+  assert r['traffic'] is not None and r['traffic'] > 805306368, 'the calibrated PMC figure of the heaviest shape (profiles/traffic.json)'
+  b = r['by_label']
+  assert b['kernel'] in ('conv3d_fwd[32->32 s1 48x256x128]', 'conv3d_bwd_data[32->32 s1 48x256x128]') and abs(b['frac'] - (173.95 / 0.80) / (2500.0 / 6.0)) < 1e-9

@@ -27,15 +27,19 @@ def _rand(shape, seed, scale=1.0):
 
 
 def _time_ms(fn, n=10):
+  """Median of n per-call event timings (one slow call -- a lazily loaded code object, a neighbour on the box -- must not decide a
+  10 % comparison)."""
   fn()
   torch.cuda.synchronize()
-  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  a.record()
+  ts = []
   for _ in range(n):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     fn()
-  b.record()
-  torch.cuda.synchronize()
-  return a.elapsed_time(b) / n
+    b.record()
+    torch.cuda.synchronize()
+    ts.append(a.elapsed_time(b))
+  return sorted(ts)[n // 2]
 
 
 def test_erp_operator_at_the_benchmark_shape_against_the_float64_oracle(arith):

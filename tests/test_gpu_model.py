@@ -165,7 +165,7 @@ def test_bench_two_ranks_share_one_gpu():
   assert d['config']['launch'].startswith('hipGraph'), d['config']['launch']
   assert d['collective']['avg_ms_rank0'] is not None and d['collective']['avg_ms_rank0'] > 0
   assert d['scaling_vs_1gpu']['value_1gpu'] == 10.0 and abs(d['scaling_vs_1gpu']['efficiency'] - d['value'] / 20.0) < 1e-12
-  assert 0 < d['targets']['regulariser3d_mfma_frac'] < 1 and 0 < d['roofline']['by_kernel']['frac'] < 1
+  assert 0 < d['targets']['regulariser3d_mfma_frac'] < 1 and 0 < d['roofline']['frac'] < 1 and 0 < d['roofline']['by_label']['frac'] < 1
 
 
 def test_smoke_entry():

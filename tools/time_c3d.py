@@ -44,12 +44,24 @@ if 's2w' in sys.argv:
     out.append('s2 bwd_weight x%d gy%d %dx%dx%d: split %.4f  fp32 %.4f' % (ci, co, D, H, W, r[0], r[1]))
   print(' | '.join(out))
   sys.exit(0)
-for (C, D, H, W) in ((32, 48, 256, 128), (64, 24, 128, 64)):
+vols = ((32, 48, 256, 128), (64, 24, 128, 64))
+if 'strides' in sys.argv:  # per-voxel time against the channel stride (see the s2w case)
+  vols = ((32, 48, 256, 128), (32, 50, 256, 128), (32, 46, 256, 128), (32, 48, 264, 128), (32, 48, 256, 136))
+for (C, D, H, W) in vols:
   x = torch.randn(2, C, D, H, W, device=dev)
   w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
   gy = torch.randn_like(x)
   gw = torch.zeros_like(w)
-  out.append('%d->%d %dx%dx%d: fwd %.4f  bwd_data %.4f  bwd_weight %.4f' % (
-      C, C, D, H, W, t_ms(lambda: HF.conv3d_fwd(x, w, 1)), t_ms(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 1)),
-      t_ms(lambda: HF.conv3d_bwd_weight(gy, x, 1))))
+  bn = torch.nn.BatchNorm3d(C).to(dev)
+  xr = x.clone().requires_grad_(True)
+
+  def bn_step():
+    xr.grad = None
+    HF.bn_act(bn, xr, None, True).backward(gy)
+
+  ts = (t_ms(lambda: HF.conv3d_fwd(x, w, 1)), t_ms(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 1)), t_ms(lambda: HF.conv3d_bwd_weight(gy, x, 1)),
+        t_ms(bn_step))
+  nv = D * H * W / (48 * 256 * 128)
+  out.append('%d->%d %dx%dx%d: fwd %.4f  bwd_data %.4f  bwd_weight %.4f  bn fwd+bwd %.4f   [per 48x256x128 voxels: %.4f %.4f %.4f %.4f]' % (
+      (C, C, D, H, W) + ts + tuple(t / nv for t in ts)))
 print(' | '.join(out))
