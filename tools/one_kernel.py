@@ -7,7 +7,7 @@ Between the launches a 1 GiB fill evicts the 256 MiB Infinity Cache (MI355X_MICR
 previous launch otherwise find part of them on-die, and FETCH_SIZE comes out below the compulsory bytes).  Cases (batch = what the
 benchmark step launches): conv3d_{fwd,bwd_data,bwd_weight}_32 (32->32 at 48x256x128, B=2; bwd_weight = the bench's roofline
 kernel), sphere_{fwd,bwd_data,bwd_weight}_t (128->128 at 256x128, 4 images, plane-transposed storage), cost_volume_fwd (B=2),
-bn3d_32 (BatchNorm3d(32)+ReLU train fwd+bwd on the 48x256x128 volume, B=2), conv3d_fwd_s2 / conv3d_bwd_data_s2 (32->64 stride 2 at
+bn3d_32 (BatchNorm3d(32)+ReLU train fwd+bwd on the 48x256x128 volume, B=2), conv3d_fwd_s2 / conv3d_bwd_data_s2 / conv3d_bwd_weight_s2 (32->64 stride 2 at
 48x256x128, B=2), deconv3d_fwd_64_32 (ConvTranspose3d 64->32 at 24x128x64, B=2)."""
 import os
 import sys
@@ -33,17 +33,23 @@ def run(fn, n=4):
   torch.cuda.synchronize()
 
 
-if what in ('conv3d_fwd_s2', 'conv3d_bwd_data_s2', 'deconv3d_fwd_64_32'):
+if what in ('conv3d_fwd_s2', 'conv3d_bwd_data_s2', 'conv3d_bwd_weight_s2', 'conv3d_bwd_weight_s2_64', 'deconv3d_fwd_64_32'):
   # hourglass conv1 (32 -> 64, stride 2) forward / input gradient at the 48 x 256 x 128 volume, conv6 (ConvTranspose3d 64 -> 32), B = 2
   if what == 'deconv3d_fwd_64_32':
     x = torch.randn(2, 64, 24, 128, 64, device=dev)
     w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
     run(lambda: HF.deconv3d_fwd(x, w))
+  elif what == 'conv3d_bwd_weight_s2_64':  # hourglass conv3 (64 -> 64, stride 2) at the 24 x 128 x 64 volume
+    x = torch.randn(2, 64, 24, 128, 64, device=dev)
+    gy = torch.randn(2, 64, 12, 64, 32, device=dev)
+    run(lambda: HF.conv3d_bwd_weight(gy, x, 2))
   else:
     x = torch.randn(2, 32, 48, 256, 128, device=dev)
     w = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
     gy = torch.randn(2, 64, 24, 128, 64, device=dev)
-    if what == 'conv3d_fwd_s2':
+    if what == 'conv3d_bwd_weight_s2':
+      run(lambda: HF.conv3d_bwd_weight(gy, x, 2))
+    elif what == 'conv3d_fwd_s2':
       run(lambda: HF.conv3d_fwd(x, w, 2))
     else:
       run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 2))
