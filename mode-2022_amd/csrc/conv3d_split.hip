@@ -128,6 +128,11 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
                                                           float* __restrict__ y, SDims d, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][ITEMS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // grid.y = the 32 * MT-channel output blocks of the layer: every y-slice is the persistent grid described above on ITS block (a
+  // 64-channel layer used to be two launches; as one, the tail of the first block's tiles overlaps with the second block, and at the
+  // small volumes -- 96 tiles at 12 x 64 x 32 -- both blocks run side by side on CUs that sat idle)
+  d.o0 += 32 * MT * (int)blockIdx.y;
+  wp += (long long)blockIdx.y * MT * d.NCHUNK * NPAIR * 192;
 
   // this workgroup's tiles: XCD x = blockIdx % 8 owns a contiguous tile range, its workgroups take every nwx-th tile of it
   const int nwx = gridDim.x / kNumXCD;
@@ -370,24 +375,24 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 }
 
 template <int MT>
-int launch_split(const float* x, const float* wpack, float* y, SDims d, hipStream_t st, const char* who, Epi epi) {
+int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblocks, hipStream_t st, const char* who, Epi epi) {
   const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
   if (epi.shift && epi.add) {
     int rc = mode::allow_lds(conv3d_split_kernel<MT, 2>, LDS_BYTES, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 2>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, 2>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
     return mode::check_launch(who);
   }
   if (epi.shift) {
     int rc = mode::allow_lds(conv3d_split_kernel<MT, 1>, LDS_BYTES, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 1>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, 1>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
     return mode::check_launch(who);
   }
   int rc = mode::allow_lds(conv3d_split_kernel<MT, 0>, LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL((conv3d_split_kernel<MT, 0>), dim3(grid), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+  hipLaunchKernelGGL((conv3d_split_kernel<MT, 0>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
   return mode::check_launch(who);
 }
 
@@ -417,14 +422,11 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
                      d.NCHUNK, flip, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
-  // 32 output channels per launch: the second half of a 64-channel layer stages the input a second time, which at 6 / 16 of the
-  // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70)
-  for (int m = 0; m < d.MT; ++m) {
-    d.o0 = 32 * m;
-    int rc = launch_split<1>(x, wpack + (long long)m * d.NCHUNK * NPAIR * 192 * 4, y, d, st, who, epi);
-    if (rc != MODE_OK) return rc;
-  }
-  return MODE_OK;
+  // 32 output channels per workgroup: the second half of a 64-channel layer stages the input a second time, which at 6 / 16 of the
+  // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70); the halves are
+  // the y-slices of ONE launch
+  d.o0 = 0;
+  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi);
 }
 
 }  // namespace mode

@@ -44,7 +44,7 @@ if 's2w' in sys.argv:
     out.append('s2 bwd_weight x%d gy%d %dx%dx%d: split %.4f  fp32 %.4f' % (ci, co, D, H, W, r[0], r[1]))
   print(' | '.join(out))
   sys.exit(0)
-vols = ((32, 48, 256, 128), (64, 24, 128, 64))
+vols = ((32, 48, 256, 128), (64, 24, 128, 64), (64, 12, 64, 32))
 if 'strides' in sys.argv:  # per-voxel time against the channel stride (see the s2w case)
   vols = ((32, 48, 256, 128), (32, 50, 256, 128), (32, 46, 256, 128), (32, 48, 264, 128), (32, 48, 256, 136))
 for (C, D, H, W) in vols:
