@@ -90,8 +90,6 @@ def _on_split_path(label):
   m = re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight|conv3d_bn_eval)\[(\d+)->(\d+) s(\d) ', label)
   if m:
     which = {'conv3d_bwd_data': 1, 'conv3d_bwd_weight': 2}.get(m.group(1), 0)
-    if m.group(1) == 'conv3d_bn_eval' and int(m.group(4)) != 1:
-      return False  # (the stride-2 split kernel has no folded-BatchNorm epilogue)
     return lib.mode_conv3d_split_supported(int(m.group(2)), int(m.group(3)), int(m.group(4)), which) == 1
   if label.startswith('deconv3d_fwd'):
     return True  # (64 -> 64 and 64 -> 32 in the network: mode_deconv3d_split_supported)

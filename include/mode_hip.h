@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 14 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 15 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -361,9 +361,10 @@ int mode_deconv3d_fwd_bn(const float* x, const float* w, const mode_bn_epilogue*
 int mode_conv3d_split_supported(int Ci, int Co, int stride, int which /* 0 forward, 1 input gradient, 2 weight gradient */);
 /* Stride-2 forward (k3 p1) on the split-bf16 kernel (csrc/conv3d_split_s2.hip): hourglass conv1 / conv3 (mode_disparity.py:17-19) and
  * the input gradient of the transposed convolutions conv5 / conv6 (w = their (Cin, Cout, 27) weight read as (Co = Cin, Ci = Cout));
- * 33..64 output channels, input channels a multiple of 8: mode_conv3d_split_supported(Ci, Co, 2, 0) == 1. */
-int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
-                             mode_stream_t stream);
+ * 33..64 output channels, input channels a multiple of 8: mode_conv3d_split_supported(Ci, Co, 2, 0) == 1.  bn: optional folded
+ * eval-mode BatchNorm (+ residual) (+ ReLU) epilogue as in mode_conv3d_fwd_split. */
+int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilogue* bn /* optional: eval-mode fold, NULL = plain */,
+                             float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream);
 
 /* The transposed convolution (ConvTranspose3d k3 s2 p1 op1, hourglass conv5 / conv6, mode_disparity.py:23-25) and the input gradient
  * of the stride-2 convolution -- one operator -- on the split-bf16 kernel of csrc/conv3d_split_deconv.hip: input channels of the

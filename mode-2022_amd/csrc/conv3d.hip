@@ -567,12 +567,13 @@ extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_
 
 // Stride-2 forward on the split-bf16 kernel of conv3d_split_s2.hip (also the input gradient of the transposed convolution, with
 // w = its (Cin, Cout, 27) weight read as (Co = Cin, Ci = Cout)); needs mode_conv3d_split_supported(Ci, Co, 2, 0) == 1.
-extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co,
-                                        mode_stream_t stream) {
+extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
+                                        int D, int H, int W, int Co, mode_stream_t stream) {
   const char* who = "mode_conv3d_fwd_s2_split";
   int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who, true);
+  if (rc == MODE_OK && bn) rc = mode::check_bn(bn, who);
   if (rc != MODE_OK || B == 0) return rc;
-  return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who);
+  return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who, bn);
 }
 
 // Input gradient of the stride-2 convolution = the transposed convolution of gy with the same (Co, Ci, 27) weight, on the split-bf16

@@ -29,7 +29,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
 bool conv3d_s2_split_supported(int K, int rows);
 size_t conv3d_s2_split_wpack_floats(int K, int rows);
 int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
-                    const char* who);
+                    const char* who, const mode_bn_epilogue* bn = nullptr);  // bn: optional folded-BatchNorm epilogue (eval mode)
 
 // conv3d_split_deconv.hip: ConvTranspose3d k3 s2 p1 op1 (= the input gradient of the stride-2 convolution) on the same arithmetic;
 // x (B, K, D, H, W), w (K, Co, 27) -> y (B, Co, 2D, 2H, 2W); K a multiple of 8, 2..64 output channels.

@@ -69,8 +69,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
 // wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of W(o = m*32 + (lane & 31), c = ch*8 + j,
 // tap = 2 * pair + (lane >> 5)), j = 0..7; zero for tap 27, o >= rows, c >= K.  W is (rows, K, 27) as stored for both uses: the
 // forward layer's weight (Co, Ci, 27), and the transposed convolution's weight (Cin, Cout, 27) read as (rows = Cin, K = Cout).
-__global__ void pack_w3d_s2_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MTr, int NCHUNK) {
+__global__ void pack_w3d_s2_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MTr, int NCHUNK, int fold,
+                                  mode_bn_epilogue bn) {
   const long long total = (long long)MTr * NCHUNK * NPAIR * 64;
+  if (fold && blockIdx.x == 0) {  // eval mode: the folded BatchNorm shifts behind the packed weights (scale goes into the weights)
+    float* shifts = reinterpret_cast<float*>(wp + total * 3);
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     long long r = idx >> 6;
@@ -85,6 +90,7 @@ __global__ void pack_w3d_s2_split(const float* __restrict__ w, uint4* __restrict
     for (int j = 0; j < 8; ++j) {
       const int c = ch * 8 + j;
       v[j] = (o < rows && c < K && tap < 27) ? w[((long long)o * K + c) * 27 + tap] : 0.f;
+      if (fold && o < rows) v[j] *= fold_scale(bn, o);
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -107,7 +113,7 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
 // (the stride-1 kernel has 336), and one wave per SIMD has nothing else to run while it waits.
 template <bool PHASED>
 __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                                             float* __restrict__ y, S2Dims d) {
+                                                                             float* __restrict__ y, S2Dims d, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [PHASED ? 1 : 2][3][PIECE], then the reduction area
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m = wave & 1, kpar = wave >> 1;  // this wave's output-channel tile and the parity of the tap pairs it takes
@@ -292,7 +298,11 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
 #pragma unroll
             for (int qq = 0; qq < 16; ++qq) {
               const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-              if (o < d.Co) yb[o * oDHW] = acc[r][qq] + red[(r * 16 + qq) * 64 + lane];
+              if (o < d.Co) {
+                float v = acc[r][qq] + red[(r * 16 + qq) * 64 + lane];
+                if (epi.shift) v = apply_epi(epi, v, o, (yb - y) + o * oDHW);  // eval mode: folded BatchNorm shift (+ residual) (+ ReLU)
+                yb[o * oDHW] = v;
+              }
             }
           }
         }
@@ -318,13 +328,13 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
 
 namespace mode {
 
-size_t conv3d_s2_split_wpack_floats(int K, int rows) { return (size_t)cdiv(rows, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4; }
+size_t conv3d_s2_split_wpack_floats(int K, int rows) { return (size_t)cdiv(rows, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4 + 64; }
 
 // rows = output channels of this GEMM (33..64: two 32-channel tiles), K = its reduction channels (a multiple of 8); 32-bit lane offsets
 bool conv3d_s2_split_supported(int K, int rows) { return rows > 32 && rows <= 64 && K > 0 && K % 8 == 0; }
 
 int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
-                    const char* who) {
+                    const char* who, const mode_bn_epilogue* bn) {
   MODE_REQUIRE(conv3d_s2_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the stride-2 split kernel",
                who, rows, K);
   MODE_REQUIRE((long long)D * H * W < (1ll << 30) / 8, MODE_ERR_UNSUPPORTED, "%s: volume beyond the 32-bit lane offsets of the split kernel", who);
@@ -335,11 +345,13 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
   d.NCHUNK = cdiv(K, 8);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)MT * d.NCHUNK * NPAIR * 64;
-  hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK);
+  hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK,
+                     bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   constexpr size_t LDS1 = (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 65 536 B: two workgroups per CU
   int rc = mode::allow_lds(conv3d_s2_split_kernel<true>, LDS1, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_s2_split_kernel<true>, dim3(2 * kNumCU), dim3(NT), LDS1, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
+  hipLaunchKernelGGL(conv3d_s2_split_kernel<true>, dim3(2 * kNumCU), dim3(NT), LDS1, st, x, reinterpret_cast<const uint4*>(wpack), y, d, epi);
   return mode::check_launch(who);
 }
 

@@ -1084,7 +1084,8 @@ def conv3d_fwd(x, w, stride=1):
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
     if _split3d(Ci, Co, stride, False) and stride == 2 and D * H * W < 2**27:
-      check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_s2_split')
+      check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+            'mode_conv3d_fwd_s2_split')
     elif _split3d(Ci, Co, stride, False) and stride == 1:
       check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_split')
     else:
@@ -1426,9 +1427,12 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    if stride == 1 and _split3d(Ci, Co, stride, False):  # (the stride-2 split kernel has no folded-BatchNorm epilogue: fp32 kernel)
+    if stride == 1 and _split3d(Ci, Co, stride, False):
       check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
             'mode_conv3d_fwd_split')
+    elif stride == 2 and _split3d(Ci, Co, stride, False) and D * H * W < 2**27:
+      check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+            'mode_conv3d_fwd_s2_split')
     else:
       check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
             'mode_conv3d_fwd_bn')
@@ -1446,6 +1450,8 @@ def deconv3d_bn_eval(x, w, bn, add=None, relu=False):
   flops = 2 * x.numel() * Cout * 27
   with torch.cuda.device_of(x), profiling.region('deconv3d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
     wp = _wpack3d(Cin, Cout, x.device)
+    # (fp32 kernel: the split kernel with this epilogue was measured and is no faster at one pair -- its epilogue walks one pointer per
+    # parity class, and the residual's loads cannot be batched behind its stores)
     check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
           'mode_deconv3d_fwd_bn')
   return y

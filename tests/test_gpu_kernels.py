@@ -775,22 +775,24 @@ FOLD_VARIANTS = [(True, False), (False, True), (True, True), (False, False)]
 
 @pytest.mark.parametrize('relu,with_add', FOLD_VARIANTS)
 def test_folded_batchnorm_conv3d(relu, with_add, arith):
-  """mode_conv3d_fwd_bn (stride 1 with one and two output-channel tiles, stride 2) and mode_deconv3d_fwd_bn against convolution ->
-  fp64 eval BatchNorm (+ add) (+ ReLU), under torch.no_grad (the fused form is inference only)."""
+  """mode_conv3d_fwd_bn (stride 1 with one and two output-channel tiles, stride 2) and mode_deconv3d_fwd_bn -- and, in bf16x6 mode, the
+  split kernels with the same epilogue (mode_conv3d_fwd_split, mode_conv3d_fwd_s2_split) -- against
+  convolution -> fp64 eval BatchNorm (+ add) (+ ReLU), under torch.no_grad (the fused form is inference only)."""
   import torch.nn.functional as F
   with torch.no_grad():
-    for (ci, co, stride) in ((8, 32, 1), (20, 40, 1), (16, 24, 2)):
+    for (ci, co, stride) in ((8, 32, 1), (20, 40, 1), (16, 24, 2), (32, 64, 2)):  # (the last one: the stride-2 split kernel in bf16x6 mode)
       x, w = _rand((2, ci, 6, 10, 36), 91).to(DEV), _rand((co, ci, 3, 3, 3), 92, 0.1).to(DEV)
       bn = _eval_bn(co, 93)
       want = F.conv3d(x.cpu().double(), w.cpu().double(), None, stride, 1).to(DEV)
       add = _rand(tuple(want.shape), 94).to(DEV) if with_add else None
       got = HF.conv3d_bn_eval(x, w, bn, stride, add, relu)
       assert (got.double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (ci, co, stride)
-    x, w = _rand((2, 24, 3, 5, 34), 95).to(DEV), _rand((24, 40, 3, 3, 3), 96, 0.1).to(DEV)
-    bn = _eval_bn(40, 97)
-    want = F.conv_transpose3d(x.cpu().double(), w.cpu().double(), None, 2, 1, 1).to(DEV)
-    add = _rand(tuple(want.shape), 98).to(DEV) if with_add else None
-    assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4
+    for (cin, cout) in ((24, 40), (64, 32), (12, 40)):  # two output tiles, one (hourglass conv6), channels off the split kernel's grid
+      x, w = _rand((2, cin, 3, 5, 34), 95).to(DEV), _rand((cin, cout, 3, 3, 3), 96, 0.1).to(DEV)
+      bn = _eval_bn(cout, 97)
+      want = F.conv_transpose3d(x.cpu().double(), w.cpu().double(), None, 2, 1, 1).to(DEV)
+      add = _rand(tuple(want.shape), 98).to(DEV) if with_add else None
+      assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (cin, cout)
 
 
 @pytest.mark.parametrize('relu', [True, False])

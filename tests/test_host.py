@@ -271,7 +271,7 @@ def test_bench_labels_on_the_split_path():
   assert bench._on_split_path('conv3d_fwd[32->32 s1 48x256x128]')
   assert bench._on_split_path('conv3d_bwd_data[64->64 s1 24x128x64]')
   assert bench._on_split_path('conv3d_fwd[32->64 s2 48x256x128]') and bench._on_split_path('conv3d_bwd_data[32->64 s2 48x256x128]')  # round 3
-  assert bench._on_split_path('conv3d_bwd_weight[32->64 s2 48x256x128]') and not bench._on_split_path('conv3d_bn_eval[32->64 s2 48x256x128]')
+  assert bench._on_split_path('conv3d_bwd_weight[32->64 s2 48x256x128]') and bench._on_split_path('conv3d_bn_eval[32->64 s2 48x256x128]')
   assert not bench._on_split_path('conv3d_bwd_weight[32->32 s2 48x256x128]')  # gy in blocks of 64 channels
   assert bench._on_split_path('deconv3d_fwd') and not bench._on_split_path('deconv3d_bn_eval')
   assert not bench._on_split_path('conv3d_fwd[32->1 s1 48x256x128]')
