@@ -277,19 +277,30 @@ __device__ __forceinline__ void fwd_tile(const float* __restrict__ x, const floa
     float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)h * d.sh + (long long)w * d.sw;
     const int cmax = d.Cog - mg * 128;
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int m = 0; m < MTW; ++m) {
+      float res[16];  // eval mode: the residual of this output tile, requested ahead of its stores (see sphere_fwd_split_kernel)
+      if (EPI) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < cmax) {
-          if (EPI) {  // eval mode: folded BatchNorm shift (+ residual) (+ ReLU) on the way out
-            const int ch = g * d.Cog + mg * 128 + co;
-            yb[(long long)co * HW] = apply_epi(epi, acc[m][r], ch, (yb - y) + (long long)co * HW);
+          if (EPI) {  // folded BatchNorm shift (+ residual) (+ ReLU) on the way out
+            const float v = (acc[m][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
+            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
           } else {
             yb[(long long)co * HW] = acc[m][r];
           }
         }
       }
+      if (EPI) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -1028,18 +1039,30 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     const int ww = w0 + gi;
     if (hh < d.H && ww < d.W) {
       float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)hh * d.sh + (long long)ww * d.sw;
+      // eval mode: the residual values of this pixel group are requested together, ahead of its stores (`add` may alias `y` for all the
+      // compiler knows: read next to the stores, each load waited for the store in front of it -- see deconv3d_kernel)
+      float res[16];
+      if (EPI) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < cmax) {
           if (EPI) {
-            const int chn_o = g * d.Cog + mg * 128 + co;
-            yb[(long long)co * HW] = apply_epi(epi, acc[gi][r], chn_o, (yb - y) + (long long)co * HW);
+            const float v = (acc[gi][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
+            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
           } else {
             yb[(long long)co * HW] = acc[gi][r];
           }
         }
       }
+      if (EPI) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
