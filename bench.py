@@ -215,17 +215,6 @@ def roofline_block(kern, conv_arith, batch, profile_steps, timed_over, on_split=
           'timed_over': timed_over}
 
 
-def launches_per_call(label, conv_arith, on_split=None):
-  """Device-kernel launches behind ONE call of a labelled operator: the stride-1 3-D split kernel computes 32 output channels of its
-  GEMM per launch, so a 64-channel layer is two launches of conv3d_split_kernel<1,0> (rocprofv3 counts launches, the labels calls)."""
-  import re
-  m = re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bn_eval)\[(\d+)->(\d+) s1 ', label)
-  if m and conv_arith == 'bf16x6' and (on_split if on_split is not None else _on_split_path)(label):
-    rows = int(m.group(2)) if m.group(1) == 'conv3d_bwd_data' else int(m.group(3))
-    return max(1, (rows + 31) // 32)
-  return 1
-
-
 def by_kernel(kern, conv_arith, on_split=None):
   """{device kernel: dict(total_ms, calls = kernel LAUNCHES, flops, bytes, need_s)} over all labels (need_s = time its pipe's peak would need)."""
   out = {}
@@ -233,7 +222,7 @@ def by_kernel(kern, conv_arith, on_split=None):
     bound, peak, unit = label_peak(k, conv_arith, on_split)
     a = out.setdefault(kernel_of(k, conv_arith, on_split), dict(total_ms=0.0, calls=0, flops=0, bytes=0, need_s=0.0, bound=bound, labels=[]))
     a['total_ms'] += v['total_ms']
-    a['calls'] += v['calls'] * launches_per_call(k, conv_arith, on_split)
+    a['calls'] += v['calls']  # (every labelled operator of the step is ONE launch of its device kernel -- since round 3 also the 64-channel stride-1 3-D layers)
     a['flops'] += v['flops']
     a['bytes'] += v['bytes']
     a['need_s'] += (v['bytes'] / (peak * 1e9)) if bound == 'hbm' else (v['flops'] / (peak * 1e12))
