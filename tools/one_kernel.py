@@ -53,6 +53,17 @@ if what in ('conv3d_fwd_s2', 'conv3d_bwd_data_s2', 'conv3d_bwd_weight_s2', 'conv
       run(lambda: HF.conv3d_fwd(x, w, 2))
     else:
       run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 2))
+elif what in ('conv3d_co1_fwd', 'conv3d_co1_bwd_weight', 'conv3d_co1_bwd_data'):
+  # the classifier heads' last layer: Conv3d(32 -> 1) at the full 48 x 256 x 128 volume, B = 2
+  x = torch.randn(2, 32, 48, 256, 128, device=dev)
+  w = torch.randn(1, 32, 3, 3, 3, device=dev) * 0.05
+  gy = torch.randn(2, 1, 48, 256, 128, device=dev)
+  if what == 'conv3d_co1_fwd':
+    run(lambda: HF.conv3d_fwd(x, w, 1))
+  elif what == 'conv3d_co1_bwd_weight':
+    run(lambda: HF.conv3d_bwd_weight(gy, x, 1))
+  else:
+    run(lambda: HF.conv3d_bwd_data(gy, w, x.shape, 1))
 elif what.startswith('conv3d') or what == 'bn3d_32':
   x = torch.randn(2, 32, 48, 256, 128, device=dev)
   w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
