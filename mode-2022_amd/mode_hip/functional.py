@@ -9,38 +9,68 @@ import torch
 from . import BnEpilogue, check, lib, profiling, ptr, require_f32c, require_gpu, stream_of
 
 
+def _stream_capturing():
+  """True while the calling thread's current stream is being captured into a hipGraph."""
+  return torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing()
+
+
 class _LRU(object):
   """Bounded cache for the per-geometry device tables (sampling tables of the integer-table convolutions, tile plans, adjoint
   tables, transposed tables): a process that evaluates many resolutions (fisheye / 3D60 / Deep360 in one run) would otherwise pin
   one set per shape for ever -- the adjoint of the 7x7 stem at 1024 x 512 alone is ~100 MB.  Callers hold their own lock.
-  A captured hipGraph (mode_hip.graph_step) holds the raw addresses of the tables its kernels were launched with: keep the number of
-  geometries in use below TABLE_CACHE_ENTRIES per cache while such a graph is replayed (one ModeDisparity uses ~10 entries in total)."""
+
+  Graph safety: a captured hipGraph (mode_hip.graph_step, or any torch.cuda.graph capture) bakes the raw addresses of the tables its
+  kernels were launched with into its nodes.  An entry that is handed out WHILE A CAPTURE IS ACTIVE is therefore pinned: it no longer
+  counts against maxsize and is never evicted (a later replay would read freed or reused memory and return silently wrong numbers).
+  Pins are released only by release_graph_pins(), which callers may use once every graph that used the tables is gone."""
+  capturing = staticmethod(_stream_capturing)
 
   def __init__(self, maxsize):
     self.maxsize = maxsize
     self.d = collections.OrderedDict()
+    self.pinned = {}
+
+  def _touch(self, key):
+    if key in self.pinned:
+      return self.pinned[key]
+    value = self.d[key]
+    if self.capturing():
+      self.pinned[key] = self.d.pop(key)
+    else:
+      self.d.move_to_end(key)
+    return value
 
   def get(self, key, default=None):
-    if key in self.d:
-      self.d.move_to_end(key)
-      return self.d[key]
+    if key in self.pinned or key in self.d:
+      return self._touch(key)
     return default
 
   def __contains__(self, key):
-    return key in self.d
+    return key in self.pinned or key in self.d
 
   def __getitem__(self, key):
-    self.d.move_to_end(key)
-    return self.d[key]
+    return self._touch(key)
 
   def __setitem__(self, key, value):
+    if key in self.pinned or self.capturing():
+      self.d.pop(key, None)
+      self.pinned[key] = value
+      return
     self.d[key] = value
     self.d.move_to_end(key)
     while len(self.d) > self.maxsize:
       self.d.popitem(last=False)
 
   def __len__(self):
-    return len(self.d)
+    return len(self.d) + len(self.pinned)
+
+  def release_graph_pins(self):
+    """Make the pinned entries evictable again (they re-enter the LRU order as the most recent ones)."""
+    for key, value in self.pinned.items():
+      self.d[key] = value
+    self.pinned.clear()
+    while len(self.d) > self.maxsize:
+      self.d.popitem(last=False)
 
 
 TABLE_CACHE_ENTRIES = 24  # per cache; one ModeDisparity geometry uses 1 plan, 2 adjoints, 1 transposed table and 5 integer tables

@@ -17,6 +17,11 @@ global valid-pixel count: a tensor that fn() merely closes over is baked into th
 capture time, and a replay on new data would silently use the stale one.  bench.py therefore passes the ground truth with its
 NaNs (the mask is derived inside the step) and the valid-pixel count as static inputs.
   out = gs.replay()                        # static output tensors, overwritten by every replay
+
+The graph's nodes hold the raw addresses of everything the kernels were launched with, including the per-geometry device tables of
+mode_hip.functional (sampling tables, plans, adjoints).  Those caches are bounded LRUs; an entry they hand out while a capture is active
+is pinned (functional._LRU) and never evicted, so a live graph cannot be left pointing at freed tables however many other geometries
+the process touches afterwards.
 """
 import torch
 

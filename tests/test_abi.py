@@ -207,6 +207,29 @@ def test_table_caches_are_bounded():
   assert len(HF._conv_tables) == HF.TABLE_CACHE_ENTRIES
 
 
+def test_table_caches_never_evict_what_a_graph_capture_was_handed(monkeypatch):
+  """A captured hipGraph holds the raw addresses of the tables its kernels were launched with: an entry that is looked
+  up or stored while the stream is capturing is pinned -- it survives any number of later insertions -- until release_graph_pins()."""
+  from mode_hip import functional as HF
+  c = HF._LRU(3)
+  state = {'capturing': False}
+  monkeypatch.setattr(HF._LRU, 'capturing', staticmethod(lambda: state['capturing']))
+  c['a'], c['b'] = object(), object()
+  a = c['a']
+  state['capturing'] = True
+  assert c['a'] is a and c.get('b') is not None  # handed out during the capture -> pinned
+  c['built-in-capture'] = 1
+  state['capturing'] = False
+  for i in range(10):
+    c[i] = i
+  assert c['a'] is a and 'b' in c and c['built-in-capture'] == 1 and len(c) == 3 + 3
+  assert 0 not in c and 9 in c  # the unpinned part is still a 3-entry LRU
+  c['a'] = a  # re-storing a pinned key keeps it pinned
+  assert 'a' in c.pinned
+  c.release_graph_pins()
+  assert len(c) == 3 and not c.pinned
+
+
 @pytest.mark.parametrize('ih,iw', [(128, 256), (32, 64)])
 def test_adjoint_window_plan_reproduces_the_adjoint_table(ih, iw):
   """mode_sphere_adjplan_build (host code): on its good tiles the 4-slot records, read back through the window geometry, are exactly

@@ -246,6 +246,42 @@ def test_graph_replay_matches_eager():
   assert abs(l2 - float(body())) <= 1e-4 * abs(l2) and abs(l2 - l_graph) > 1e-7
 
 
+def test_live_graph_survives_table_cache_pressure():
+  """a captured hipGraph holds raw addresses of the cached device tables (integer sampling tables, adjoints, plans).
+  With a graph alive, push far more geometries through every cache than TABLE_CACHE_ENTRIES: the graph's tables must stay (pinned
+  at capture time, functional._LRU) and a replay must give the bits it gave before."""
+  from mode_hip import functional as HF
+  from mode_hip.graph_step import GraphedStep
+  torch.manual_seed(3)
+  conv = torch.nn.Conv2d(8, 16, 3, stride=2, padding=1, bias=False).to(DEV)
+  x = torch.randn(2, 8, 24, 40, device=DEV, requires_grad=True)
+
+  def body():
+    x.grad = None
+    conv.weight.grad = None
+    y = HF.conv2d_tabled(x, conv)
+    y.square().sum().backward()
+    return y, x.grad, conv.weight.grad
+
+  gs = GraphedStep(body, (x,), warmup=1)
+  first = [t.clone() for t in gs.replay()]
+  pinned_before = len(HF._conv_tables.pinned) + len(HF._adjoint_cache.pinned)
+  assert pinned_before >= 2  # the table and its adjoint were handed out during the capture
+  junk = []
+  for i in range(HF.TABLE_CACHE_ENTRIES + 8):  # other geometries: new tables, new adjoints, evictions, allocator reuse
+    c2 = torch.nn.Conv2d(4, 4, 3, stride=2, padding=1, bias=False).to(DEV)
+    xi = torch.randn(1, 4, 8 + 2 * i, 12, device=DEV, requires_grad=True)
+    HF.conv2d_tabled(xi, c2).sum().backward()
+    junk.append(torch.full((1 << 18,), float('nan'), device=DEV))  # whatever was freed gets overwritten
+  assert len(HF._conv_tables.d) <= HF.TABLE_CACHE_ENTRIES and len(HF._adjoint_cache.d) <= HF.TABLE_CACHE_ENTRIES
+  del junk
+  again = gs.replay()
+  for a, b in zip(first, again):
+    assert torch.equal(a, b)
+  ref = conv(x.detach())
+  assert torch.allclose(first[0], ref, rtol=1e-4, atol=1e-4)
+
+
 def test_regular_extractor_variant(golden, arith):
   """ModeDisparity(conv='Regular') -- the PSMNet SPP extractor -- on the HIP path against the reference's
   golden vectors: same state_dict, train / eval outputs as close to the fp64 network as the reference's own fp32 run."""

@@ -108,9 +108,36 @@ def test_two_rank_graph_step_equals_the_sum_of_single_process_steps(tmp_path, ma
   assert rel <= 1e-3, rel
 
 
+def _per_tensor_report(names, shapes, a, b, limit=10):
+  """Which parameter tensors of two flat gradient buffers differ, and by how much (a bit-equality that fails must name the layer)."""
+  lines, off = [], 0
+  for name, shape in zip(names, shapes):
+    n = int(np.prod(shape))
+    x, y = a[off:off + n], b[off:off + n]
+    off += n
+    if not torch.equal(x, y):
+      d = (x.double() - y.double()).abs()
+      lines.append('%s %s: %d of %d elements differ, max |d| %.3e, rms of the tensor %.3e' % (
+          name, tuple(shape), int((x != y).sum()), n, float(torch.nan_to_num(d).max()), float(x.double().pow(2).mean().sqrt())))
+  assert off == a.numel() == b.numel()
+  return '%d of %d parameter tensors differ' % (len(lines), len(names)) + ''.join('\n  ' + s for s in lines[:limit]) + \
+      ('\n  ... (%d more)' % (len(lines) - limit) if len(lines) > limit else '')
+
+
 def test_two_rank_eager_step_matches_the_graph_step(tmp_path):
-  """Same step without the hipGraph: identical numbers (the graph is a launch optimisation only)."""
-  a = _run_ranks(tmp_path, 32, 128, 64, 'eager')
-  flat_eager = a[0]['flat'].clone()
+  """Same step without the hipGraph: identical numbers (the graph is a launch optimisation only).  Every kernel of the step is
+  deterministic by construction (fixed-order split-K, no atomics), so the bits must agree; when they do not, the message names the
+  parameter tensors, per rank (`local` = a rank's own gradient before the all-reduce) and reduced (`flat`)."""
+  a = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in _run_ranks(tmp_path, 32, 128, 64, 'eager')]
   b = _run_ranks(tmp_path, 32, 128, 64, 'graph')
-  assert torch.equal(flat_eager, b[0]['flat'])
+  assert a[0]['launch'] == 'eager' and b[0]['launch'] == 'graph'
+  names, shapes = a[0]['names'], a[0]['shapes']
+  report = []
+  for k in range(2):
+    if not torch.equal(a[k]['local'], b[k]['local']):
+      report.append('rank %d local gradient, eager vs graph (loss %.9g vs %.9g): %s' % (
+          k, a[k]['loss'], b[k]['loss'], _per_tensor_report(names, shapes, a[k]['local'], b[k]['local'])))
+  if not torch.equal(a[0]['flat'], b[0]['flat']):
+    report.append('all-reduced gradient, eager vs graph: ' + _per_tensor_report(names, shapes, a[0]['flat'], b[0]['flat']))
+  assert not report, '\n'.join(report)
+  assert a[0]['loss'] == b[0]['loss'] and a[1]['loss'] == b[1]['loss']

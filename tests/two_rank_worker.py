@@ -87,7 +87,10 @@ def main():
   local = reducer.flat.clone()
   reducer.all_reduce()
   torch.cuda.synchronize()
+  named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+  assert [p.data_ptr() for _, p in named] == [p.data_ptr() for p in reducer.params]
   torch.save({'flat': reducer.flat.cpu(), 'local': local.cpu(), 'loss': float(loss), 'count': float(count), 'launch': launch,
+              'names': [n for n, _ in named], 'shapes': [tuple(p.shape) for _, p in named],
               'bn': {k: v.cpu() for k, v in net.state_dict().items() if 'running' in k}}, os.path.join(out_dir, 'rank%d.pt' % rank))
   dist.barrier()
   dist.destroy_process_group()
