@@ -164,10 +164,22 @@ def kernel_of(label, conv_arith, on_split=None):
     return 'conv2d_split_kernel' if split else 'conv2d_kernel'
   if name == 'conv2d_bwd_weight':
     return 'conv2d_bww_split_kernel' if split else 'conv2d_bww_kernel'
-  return {'sphere_conv_fwd': 'sphere_fwd_split_kernel' if conv_arith == 'bf16x6' else 'sphere_fwd_win_kernel',
-          'sphere_conv_bn_eval': 'sphere_fwd_split_kernel' if conv_arith == 'bf16x6' else 'sphere_fwd_win_kernel',
-          'sphere_conv_bwd_data': 'sphere_bwd_data_adj9_kernel', 'sphere_conv_bwd_weight': 'sphere_bww_win_kernel',
-          'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel'}.get(name, name)
+  if name in ('sphere_conv_fwd', 'sphere_conv_bn_eval', 'sphere_conv_bwd_data', 'sphere_conv_bwd_weight'):
+    # the 3x3 gnomonic layers of the extractor run on the windowed kernels (split-bf16 ones in bf16x6 mode); the integer-table layers
+    # that share these labels (32 -> 288 tap products of cost_conv, the stride-2 3x3 layer) on the general gather-and-MAC kernels
+    m = re.search(r'\[(\d+)->(\d+) ', label)
+    windowed = bool(m) and int(m.group(2)) % 128 == 0 and int(m.group(1)) % 16 == 0
+    if name in ('sphere_conv_fwd', 'sphere_conv_bn_eval'):
+      return ('sphere_fwd_split_kernel' if split else 'sphere_fwd_win_kernel') if windowed else 'sphere_fwd_kernel'
+    if name == 'sphere_conv_bwd_data':
+      return 'sphere_bwd_data_split_kernel' if split else ('sphere_bwd_data_adj9_kernel' if windowed else 'sphere_bwd_data_adj_kernel')
+    return ('sphere_bww_split_kernel' if split else 'sphere_bww_win_kernel') if windowed else 'sphere_bwd_weight_kernel'
+  return {'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel',
+          'bn_eval_fwd': 'bn_eval_kernel', 'head_fwd': 'head_fwd_kernel', 'head_bwd': 'head_bwd_pix_kernel+head_bwd_gather_kernel',
+          'cost_volume_fwd': 'cost_volume_fwd_v4', 'cost_volume_bwd': 'cost_volume_bwd_v4',
+          'cost_conv_assemble_fwd': 'cost_conv_assemble_fwd_kernel', 'cost_conv_assemble_bwd': 'cost_conv_assemble_bwd_kernel',
+          'conv_stem_fwd': 'stem_fwd_kernel', 'conv_stem_bwd_weight': 'stem_bww_kernel', 'conv1x1_fwd': 'conv1x1_kernel',
+          'conv1x1_bwd_data': 'conv1x1_kernel', 'conv1x1_bwd_weight': 'conv1x1_bww_kernel'}.get(name, name)
 
 
 def calibrated_traffic(label, batch, conv_arith, on_split=None):

@@ -507,7 +507,7 @@ def sphere_native_t(pos, kh, kw):
 def sphere_uses_transposed_copies(pos, kh, kw):
   """Whether the gradients of this table run on plane-transposed COPIES of their operands (Cassini-like tables); ERP-like tables
   (sphere_native_t) and tables without a plan do not."""
-  return SPHERE_LAYOUT == 'transposed' and kh * kw == 9 and sphere_plan(pos, kh, kw) is not None
+  return SPHERE_LAYOUT == 'transposed' and kh * kw == 9 and _plan_usable(sphere_plan(pos, kh, kw))
 
 
 def sphere_conv_bwd_data(gy, pos, w, gx, stride, groups, overwrite=False, gy_transposed=None):
@@ -574,7 +574,7 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy
     plan = sphere_plan(pos, Kh, Kw)
     if plan is not None and plan[1][0] == 0:
       plan = None  # no compact tile at all: nothing to gain
-    if plan is None:
+    if not _plan_usable(plan):  # the same predicate as the forward and the input gradient: one layout per table
       post = sphere_native_t(pos, Kh, Kw)
       if post is not None:  # ERP-like table
         return sphere_conv_bwd_weight_t(gy, post, x, gw, groups)
@@ -1090,6 +1090,12 @@ def _split3d(ci, co, stride, which):
   return CONV_ARITH == 'bf16x6' and lib().mode_conv3d_split_supported(ci, co, stride, int(which)) == 1
 
 
+def _deconv_split_fits(lowres_voxels, cout):
+  """The 32-bit offset limits of deconv3d_split (csrc/conv3d_split_deconv.hip: MODE_REQUIRE in deconv3d_split), in the voxels of its
+  LOW-resolution input and the channels of its output; volumes beyond them run on the fp32 kernel instead of failing."""
+  return lowres_voxels * 8 * max(cout, 8) < 2**31 and lowres_voxels < 2**27
+
+
 def _out3(n, stride):
   return (n - 1) // stride + 1
 
@@ -1135,7 +1141,7 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                   4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
-    if stride == 2 and _split3d(Ci, Co, stride, True) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and D * H * W < 2**30:
+    if stride == 2 and _split3d(Ci, Co, stride, True) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and _deconv_split_fits(D * H * W // 8, Ci):
       check(lib().mode_conv3d_bwd_data_s2_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
             'mode_conv3d_bwd_data_s2_split')
     elif stride == 1 and _split3d(Ci, Co, stride, True):
@@ -1187,7 +1193,7 @@ def deconv3d_fwd(x, w):
   flops = 2 * x.numel() * Cout * 27
   with torch.cuda.device_of(x), profiling.region('deconv3d_fwd', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
     wp = _wpack3d(Cin, Cout, x.device)
-    if CONV_ARITH == 'bf16x6' and lib().mode_deconv3d_split_supported(Cin, Cout) == 1 and D * H * W < 2**27:
+    if CONV_ARITH == 'bf16x6' and lib().mode_deconv3d_split_supported(Cin, Cout) == 1 and _deconv_split_fits(D * H * W, Cout):
       check(lib().mode_deconv3d_fwd_split(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd_split')
     else:
       check(lib().mode_deconv3d_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)), 'mode_deconv3d_fwd')

@@ -77,3 +77,32 @@ def test_roofline_block_names_the_dominant_device_kernel():
   assert r['traffic'] is not None and r['traffic'] > 805306368, 'the calibrated PMC figure of the heaviest shape (profiles/traffic.json)'
   b = r['by_label']
   assert b['kernel'] in ('conv3d_fwd[32->32 s1 48x256x128]', 'conv3d_bwd_data[32->32 s1 48x256x128]') and abs(b['frac'] - (173.95 / 0.80) / (2500.0 / 6.0)) < 1e-9
+
+
+def test_kernel_of_names_device_kernels_that_really_ran():
+  """kernel_of() must name the device kernel a label's launches run on -- every name it returns for the labels of a recorded
+  bench line is a kernel of the rocprofv3 --kernel-trace --stats file recorded with the same build (profiles/r03zz_*), in both the
+  split and the fp32 pricing of the label (the real predicate, mode_hip's host-side *_supported queries: no GPU needed)."""
+  import csv
+  import json
+  import os
+  prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+  with open(os.path.join(prof, 'r03zz_bench.json')) as f:
+    labels = list(json.load(f)['kernels'])
+  with open(os.path.join(prof, 'r03zz_rocprofv3_kernel_stats_bench_graph_steps2.csv')) as f:
+    ran = [row['Name'] for row in csv.DictReader(f)]
+  assert len(labels) > 60 and len(ran) > 60
+  missing = []
+  for label in labels:
+    if label.startswith('cost_volume_fwd'):
+      continue  # timed standalone after the step (the model folds the volume away): not in the step's trace
+    for part in bench.kernel_of(label, 'bf16x6').split('+'):
+      base = part.split('<')[0]
+      if not any(('::' + base + '(') in n or ('::' + base + '<') in n or n.startswith(base + '(') for n in ran):
+        missing.append((label, part))
+  assert not missing, missing
+  # the split gradients of the gnomonic layers are their own kernels; the integer-table layers under the same labels are not split
+  assert bench.kernel_of('sphere_conv_bwd_data[128->128 256x128]', 'bf16x6') == 'sphere_bwd_data_split_kernel'
+  assert bench.kernel_of('sphere_conv_bwd_weight[128->128 256x128]', 'bf16x6') == 'sphere_bww_split_kernel'
+  assert bench.kernel_of('sphere_conv_fwd[32->288 256x128]', 'bf16x6') == 'sphere_fwd_kernel'
+  assert bench.kernel_of('sphere_conv_bwd_data[128->128 256x128]', 'f32') == 'sphere_bwd_data_adj9_kernel'
