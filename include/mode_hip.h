@@ -58,9 +58,14 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 15 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 16 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
+
+/* Test utility, not part of the operator seam (no reference counterpart): fills the LDS of every CU and the vector / accumulator
+ * register files with `pattern`, on `stream`.  A kernel whose output depends on LDS words or registers it never wrote gives
+ * pattern-dependent results; tests/test_gpu_repeat.py runs every operator of the training step behind it. */
+int mode_debug_poison(unsigned pattern, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spherical convolution.

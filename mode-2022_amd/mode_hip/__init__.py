@@ -21,6 +21,7 @@ _c_size = ctypes.c_size_t
 SIGNATURES = {
     'mode_hip_abi_version': (_c_int, []),
     'mode_last_error': (ctypes.c_char_p, []),
+    'mode_debug_poison': (_c_int, [ctypes.c_uint, _c_ptr]),
     'mode_sphere_conv_wpack_bytes': (_c_size, [_c_int] * 5),
     'mode_sphere_conv_fwd': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_bwd_data': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
@@ -113,7 +114,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 15  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 16  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

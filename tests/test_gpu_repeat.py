@@ -1,0 +1,118 @@
+"""GPU (-m gpu): every operator of the training step is bit-repeatable and reads nothing it did not write.
+
+The reference's backward is not deterministic (atomicAdd scatter, sphere_conv_cuda_kernel.cu:349); this implementation claims it is
+("Determinism").  Round 3's driver run showed a two-rank eager step and its hipGraph twin differing in bits.
+These tests make such a defect name its operator:
+
+  * a poison kernel (mode_debug_poison) overwrites the LDS of every CU and the whole vector / accumulator register file before EVERY
+    native call of a training step; the step must give identical bits whatever the pattern (zeros, NaN, 1.0f, a pair of bf16 ones) and
+    no NaN: a kernel that reads LDS words or registers it never wrote cannot pass;
+  * every torch.empty the step makes is NaN-filled (a split-K reduction that reads a slot nobody wrote turns into NaN);
+  * the step is repeated while a second process runs the same kind of work on the same GPU (the only condition under which the defect
+    showed): per-operator traces (tests/op_trace.py) must be identical, step after step.
+Sizes: the tiny volumes of tests/test_gpu_two_ranks.py (quarter resolution 8 x 32 x 16 -> 4 x 16 x 8 -> 2 x 8 x 4: the general gather
+kernels, ragged tiles) and one pair at the benchmark size (windowed split-bf16 kernels, polar tiles, adjoint plans)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import recipe
+
+import models
+import mode_hip
+import op_trace
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_ONLY = ('_bytes', '_supported', '_build', '_plan_', '_max_', 'abi_version', 'last_error', 'debug_poison', 'adjplan')
+
+
+class PoisoningLib(object):
+  """Stands in for the ctypes handle: launches mode_debug_poison(pattern) on the call's stream before every kernel-launching entry."""
+
+  def __init__(self, real, pattern):
+    self._real, self._pattern, self.calls = real, pattern, 0
+
+  def __getattr__(self, name):
+    fn = getattr(self._real, name)
+    if not name.startswith('mode_') or any(s in name for s in HOST_ONLY):
+      return fn
+
+    def call(*args):
+      rc = self._real.mode_debug_poison(self._pattern, args[-1])  # (the stream is the last argument of every launching entry)
+      assert rc == 0, self._real.mode_last_error()
+      self.calls += 1
+      return fn(*args)
+
+    return call
+
+
+def _net_and_batch(maxdisp, H, W, seed=77):
+  import two_rank_worker as trw
+  net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
+  net.load_state_dict(recipe.recipe_state_wc(recipe.load_manifest(), seed))
+  net.train()
+  left, right, gt = [t.to(DEV) for t in trw.rank_batch(1, maxdisp, H, W)]  # (rank 1's batch: a third of the ground truth is NaN)
+  return net, left, right, gt
+
+
+def _traced_step(net, left, right, gt, keep):
+  import two_rank_worker as trw
+  from mode_hip import data_parallel
+  red = data_parallel.GradAllReducer(net, fuse_accumulation=True)
+  count = data_parallel.global_valid_count(~torch.isnan(gt))
+  tr = op_trace.Trace(keep=keep)
+  red.zero_grad()
+  with op_trace.tracing(tr):
+    loss = trw.step_loss(net, left, right, gt, count)
+    loss.backward()
+  torch.cuda.synchronize()
+  out = (tr.labels, tr.finish(), red.flat.cpu(), float(loss))
+  red.detach()
+  return out
+
+
+@pytest.mark.parametrize('maxdisp,H,W,keep', [(32, 128, 64, True), (192, 1024, 512, False)])
+def test_step_does_not_depend_on_inherited_lds_or_registers(maxdisp, H, W, keep, monkeypatch):
+  net, left, right, gt = _net_and_batch(maxdisp, H, W)
+  real = mode_hip.lib()
+  _traced_step(net, left, right, gt, keep)  # cold pass: tables, plans, allocator
+  names = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+  ref = None
+  for pattern in (0x00000000, 0x7fc00000, 0x3f800000, 0x3f803f80):
+    proxy = PoisoningLib(real, pattern)
+    monkeypatch.setattr(mode_hip, '_lib', proxy)
+    try:
+      with op_trace.nan_filled_allocations():
+        labels, trace, flat, loss = _traced_step(net, left, right, gt, keep)
+    finally:
+      monkeypatch.setattr(mode_hip, '_lib', real)
+    assert proxy.calls > 300, proxy.calls
+    nans = op_trace.nan_entries(labels, trace)
+    assert not nans and not bool(torch.isnan(flat).any()), ('pattern %#x: NaN in' % pattern, nans[:8])
+    if ref is None:
+      ref = (labels, trace, flat, loss)
+      continue
+    assert labels == ref[0]
+    diff = op_trace.first_difference(labels, ref[1], trace)
+    assert diff is None, 'pattern %#x against zeros: first differing operator output: %s' % (pattern, diff[1])
+    assert torch.equal(flat, ref[2]), 'pattern %#x: %s' % (pattern, op_trace.param_report(names, ref[2], flat))
+    assert loss == ref[3]
+
+
+def test_repeated_steps_with_a_second_process_on_the_gpu_are_bit_identical():
+  """tools/determinism_hunt.py: two ranks share the GPU and each repeats the traced eager step and replays its hipGraph; every repeat
+  must reproduce the first step's per-operator trace and flat gradient bit for bit."""
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  cmd = [sys.executable, os.path.join(ROOT, 'tools', 'determinism_hunt.py'), 'run', '--ranks', '2', '--steps', '30', '--replays', '30']
+  r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+  out = r.stdout + r.stderr
+  lines = [ln for ln in out.splitlines() if 'differ' in ln or 'NaN' in ln]
+  assert 'workers exit code 0' in out, out[-3000:]
+  for rank in (0, 1):
+    assert '[rank %d] eager: 0 of 29 repeated steps differ from the first' % rank in out, '\n'.join(lines)[:4000]
+    assert '[rank %d] graph: 0 of 30 replays differ from the eager step' % rank in out, '\n'.join(lines)[:4000]

@@ -5,8 +5,7 @@
 starts `--ranks` processes that share the GPU (python -m torch.distributed.run, gloo: exactly what the failing test does) and, in each,
   1. runs the data-parallel training step EAGERLY `--steps` times on identical inputs with every operator call traced
      (tests/op_trace.py) and compares each trace with the first one: the first differing entry names the operator;
-  2. captures the step as a hipGraph (with clones of every operator output when --keep) and replays it `--replays` times, comparing the
-     flat gradient (and the clones) with the eager step's.
+  2. captures the step as a hipGraph and replays it `--replays` times, comparing the flat gradient with the eager step's, per parameter.
 --hog adds one more process that keeps the GPU busy with unrelated kernels; --nanfill makes torch.empty return NaN-filled memory.
 Each rank prints one summary line per finding; exit code 0 whether or not something was found (it is a measuring tool)."""
 import argparse
@@ -97,28 +96,16 @@ def worker(args):
 
   # ---- 2. hipGraph replays against the eager step
   if args.replays:
-    gtr = op_trace.Trace(keep=args.keep)
-    calls = {'n': 0}
-
-    def fn_counted():  # GraphedStep calls it `warmup` times plainly, then once under capture: only that call is traced
-      calls['n'] += 1
-      if calls['n'] > 1:
-        with op_trace.tracing(gtr):
-          return body()
-      return body()
-
-    graphed = GraphedStep(fn_counted, (left, right, gt, count), warmup=1)
+    graphed = GraphedStep(body, (left, right, gt, count), warmup=1)  # (untraced: the flat gradient is compared per parameter)
     bad_replays = 0
     for r in range(args.replays):
       reducer.flat.fill_(float('nan'))
       graphed.replay()
       torch.cuda.synchronize()
       flat = reducer.flat.cpu()
-      assert gtr.labels == ref_labels, 'graph trace and eager trace list different operator calls'
-      diff = op_trace.first_difference(gtr.labels, ref_trace, gtr.finish())
-      if diff is not None or not torch.equal(flat, ref_flat):
+      if not torch.equal(flat, ref_flat):
         bad_replays += 1
-        print(tag, 'GRAPH replay %d differs from eager step 0: first at entry %s' % (r, diff), flush=True)
+        print(tag, 'GRAPH replay %d differs from eager step 0' % r, flush=True)
         print(tag, '  flat gradient:', op_trace.param_report(names_params, ref_flat, flat), flush=True)
     print(tag, 'graph: %d of %d replays differ from the eager step' % (bad_replays, args.replays), flush=True)
   if ctx is not None:
