@@ -59,6 +59,13 @@ inline int allow_lds(K kernel, size_t bytes, const char* what) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Fill `nwords` 32-bit words at `dst` (4-byte aligned) with `pattern` by a KERNEL on `st`.  The library never calls hipMemsetAsync:
+// captured into a hipGraph on this ROCm stack a memset node takes effect on the first launch of the graph only -- from the second
+// replay on the buffer keeps whatever it held (tools/experiments/graph_memset_probe.py; round 4: 3/4 of the stride-2 1x1 input
+// gradient came back as garbage from every replayed training step but the first).  A kernel node replays like any other.
+int fill_words(void* dst, unsigned pattern, size_t nwords, hipStream_t st, const char* what);
+inline int zero_floats(float* dst, size_t n, hipStream_t st, const char* what) { return fill_words(dst, 0u, n, st, what); }
+
 }  // namespace mode
 
 #define MODE_REQUIRE(cond, code, ...)  \

@@ -339,11 +339,8 @@ extern "C" int mode_conv1x1_bwd_data(const float* gy, const float* w, float* gx,
   if (stride == 1) {  // the forward kernel on W^T: the "input" is gy (planes Ho x Wo = H x W)
     return launch1<false, false>(gy, wpack, gx, d, st, none, who);
   }
-  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * Ci * H * W * sizeof(float), st);
-  if (e != hipSuccess) {
-    mode::set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
-    return (int)e;
-  }
+  rc = mode::zero_floats(gx, (size_t)B * Ci * H * W, st, who);  // (a kernel, not hipMemsetAsync: common.h)
+  if (rc != MODE_OK) return rc;
   return launch1<false, true>(gy, wpack, gx, d, st, none, who);
 }
 
@@ -368,7 +365,7 @@ extern "C" int mode_conv1x1_bwd_weight(const float* gy, const float* x, float* g
   MODE_REQUIRE(((size_t)gy % 16) == 0 && ((size_t)x % 16) == 0, MODE_ERR_UNSUPPORTED, "%s: tensors must be 16-byte aligned", who);
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) (void)hipMemsetAsync(gw, 0, (size_t)Co * Ci * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci, st, who);
     return MODE_OK;
   }
   d.groups = d.Ho * d.Wo / 4;

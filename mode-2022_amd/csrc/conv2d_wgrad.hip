@@ -267,7 +267,7 @@ extern "C" int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw
   MODE_REQUIRE((long long)std::max(Ci, Co) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 9 * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci * 9, st, "mode_conv2d_bwd_weight");
     return MODE_OK;
   }
   MODE_REQUIRE(gy && x && gw && workspace, MODE_ERR_BAD_ARG, "%s: null pointer", who);
@@ -287,7 +287,7 @@ extern "C" int mode_conv2d_bwd_weight_split(const float* gy, const float* x, flo
   MODE_REQUIRE((long long)std::max(Ci, Co) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 9 * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci * 9, st, "mode_conv2d_bwd_weight");
     return MODE_OK;
   }
   MODE_REQUIRE(gy && x && gw && workspace, MODE_ERR_BAD_ARG, "%s: null pointer", who);

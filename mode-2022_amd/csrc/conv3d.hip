@@ -1226,7 +1226,7 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   if (rc != MODE_OK) return rc;
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci * 27, st, "mode_conv3d_bwd_weight");
     return MODE_OK;
   }
   if (Co == 1 && stride == 1)
@@ -1289,7 +1289,7 @@ extern "C" int mode_conv3d_bwd_weight_split(const float* gy, const float* x, flo
                "%s: layer not covered by the split kernels (single output channel, or a sample beyond 2^29 elements)", who);
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci * 27, st, "mode_conv3d_bwd_weight");
     return MODE_OK;
   }
   WDims d;
@@ -1328,7 +1328,7 @@ extern "C" int mode_conv3d_bwd_weight_s2_split(const float* gy, const float* x, 
                MODE_ERR_UNSUPPORTED, "%s: a channel block of one sample exceeds 2^29 elements", who);
   hipStream_t st = mode::as_stream(stream);
   if (B == 0) {
-    if (!accumulate) return (int)hipMemsetAsync(gw, 0, (size_t)Co * Ci * 27 * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * Ci * 27, st, "mode_conv3d_bwd_weight");
     return MODE_OK;
   }
   WDims d;

@@ -251,7 +251,7 @@ extern "C" int mode_conv_stem_bwd_weight(const float* gy, const float* x, float*
   hipStream_t st = mode::as_stream(stream);
   MODE_REQUIRE(gw, MODE_ERR_BAD_ARG, "%s: null pointer", who);
   if (B == 0) {
-    if (!accumulate) (void)hipMemsetAsync(gw, 0, (size_t)Co * d.KK * sizeof(float), st);
+    if (!accumulate) return mode::zero_floats(gw, (size_t)Co * d.KK, st, "mode_conv_stem_bwd_weight");
     return MODE_OK;
   }
   MODE_REQUIRE(gy && x && workspace, MODE_ERR_BAD_ARG, "%s: null pointer", who);

@@ -227,11 +227,8 @@ extern "C" int mode_depth_view_trans(const float* view1, const float* conf1, con
   ViewXform xf;
   for (int i = 0; i < 9; ++i) xf.R[i] = R[i];
   for (int i = 0; i < 3; ++i) xf.t[i] = t[i];
-  hipError_t e = hipMemsetAsync(workspace, 0xff, (size_t)n * sizeof(unsigned long long), st);
-  if (e != hipSuccess) {
-    mode::set_error("mode_depth_view_trans: hipMemsetAsync: %s", hipGetErrorString(e));
-    return (int)e;
-  }
+  int frc = mode::fill_words(workspace, 0xffffffffu, 2 * (size_t)n, st, "mode_depth_view_trans");  // all keys = +inf (a kernel, not hipMemsetAsync: common.h)
+  if (frc != MODE_OK) return frc;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(view_trans_scatter_kernel, dim3(grid_for(n)), dim3(NT), 0, st, view1, trig, keys, H, W, xf);
   hipLaunchKernelGGL(view_trans_resolve_kernel, dim3(grid_for(n)), dim3(NT), 0, st, keys, conf1, view2, conf2, n);
@@ -258,11 +255,8 @@ extern "C" int mode_zbuffer(const double* r2, const int32_t* target, const float
   MODE_REQUIRE(r2 && target && conf1 && view2 && conf2, MODE_ERR_BAD_ARG, "mode_zbuffer: null pointer");
   MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_zbuffer: workspace required");
   hipStream_t st = mode::as_stream(stream);
-  hipError_t e = hipMemsetAsync(workspace, 0xff, (size_t)n * sizeof(unsigned long long), st);
-  if (e != hipSuccess) {
-    mode::set_error("mode_zbuffer: hipMemsetAsync: %s", hipGetErrorString(e));
-    return (int)e;
-  }
+  int frc = mode::fill_words(workspace, 0xffffffffu, 2 * (size_t)n, st, "mode_zbuffer");  // all keys = +inf (a kernel, not hipMemsetAsync: common.h)
+  if (frc != MODE_OK) return frc;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(zbuffer_scatter_kernel, dim3(grid_for(n)), dim3(NT), 0, st, r2, target, keys, n);
   hipLaunchKernelGGL(view_trans_resolve_kernel, dim3(grid_for(n)), dim3(NT), 0, st, keys, conf1, view2, conf2, n);

@@ -28,8 +28,9 @@ def functions():
 
 class Trace(object):
 
-  def __init__(self, keep=False):
+  def __init__(self, keep=False, inputs=False):
     self.keep = keep
+    self.inputs = inputs  # also record the tensor arguments (and, for backward, the saved tensors) of every call
     self.labels = []
     self.items = []
 
@@ -60,9 +61,15 @@ def tracing(trace):
     orig = getattr(cls, which)
 
     def wrapped(ctx, *args):
-      out = orig(ctx, *args)
       k = counters.get((cls.__name__, which), 0)
       counters[(cls.__name__, which)] = k + 1
+      if trace.inputs:
+        for i, t in enumerate(args):
+          trace.record('%s.%s#%d.in[%d]' % (cls.__name__, which, k, i), t)
+        if which == 'backward':
+          for i, t in enumerate(ctx.saved_tensors):
+            trace.record('%s.%s#%d.saved[%d]' % (cls.__name__, which, k, i), t)
+      out = orig(ctx, *args)
       outs = out if isinstance(out, tuple) else (out,)
       for i, t in enumerate(outs):
         trace.record('%s.%s#%d[%d]' % (cls.__name__, which, k, i), t)

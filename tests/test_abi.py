@@ -279,3 +279,18 @@ def test_adjoint_window_plan_reproduces_the_adjoint_table(ih, iw):
             assert rw[i, k, pix, s] == lst[s, 1:2].view(np.float32)[0]
           else:
             assert ro[i, k, pix, s] == 0 and rw[i, k, pix, s] == 0.0
+
+
+def test_no_hip_memset_in_the_library():
+  """hipMemsetAsync captured into a hipGraph takes effect on the first launch of the graph only on this ROCm stack (round 4,
+  tools/experiments/graph_memset_probe.py): every fill in the library is a kernel (mode::fill_words)."""
+  import re
+  csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mode-2022_amd', 'csrc')
+  hits = []
+  for f in sorted(os.listdir(csrc)):
+    if f.endswith(('.hip', '.h')):
+      for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+        code = line.split('//')[0]
+        if re.search(r'hipMemset|hipMemcpy', code):
+          hits.append('%s:%d' % (f, n))
+  assert not hits, hits

@@ -18,6 +18,7 @@ from oracle import mode_ref
 
 import models
 import mode_hip
+import op_trace
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -235,11 +236,20 @@ def test_graph_replay_matches_eager():
     return loss
 
   gs = GraphedStep(body, (left, right, gt), warmup=1)
-  l_graph = float(gs.replay())
-  g_graph = red.flat.clone()
+  # Every replay -- not only the first -- must give the eager step's BITS: the kernels are deterministic (fixed-order split-K, no
+  # atomics) and the graph is a launch optimisation only.  Round 4 found the second and later replays wrong: a hipMemsetAsync inside
+  # mode_conv1x1_bwd_data became a graph memset node, and on this ROCm stack such a node takes effect on the first launch only
+  # (tools/experiments/graph_memset_probe.py); the library fills with kernels now (csrc/common.h fill_words).
+  graph_runs = []
+  for _ in range(4):
+    red.flat.fill_(float('nan'))  # the replay itself must zero and fill the buffer
+    l_graph = float(gs.replay())
+    graph_runs.append((l_graph, red.flat.clone()))
   l_eager = float(body())
-  assert abs(l_graph - l_eager) <= 1e-4 * abs(l_eager)
-  assert float((red.flat - g_graph).norm()) <= 0.25 * float(g_graph.norm())  # run-to-run noise of the vendor atomics: a few %
+  names = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+  for r, (lg, g) in enumerate(graph_runs):
+    assert lg == l_eager, (r, lg, l_eager)
+    assert torch.equal(g, red.flat), 'replay %d: %s' % (r, op_trace.param_report(names, red.flat.cpu(), g.cpu()))
   left2 = torch.roll(left, 5, 2)
   gs.load(left2, torch.roll(right, 5, 2), gt)
   l2 = float(gs.replay())

@@ -75,12 +75,14 @@ def main():
     # from the loaded state (the parent compares them per replica)
     bn0 = {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
     graphed = GraphedStep(body, (left, right, gt, count), warmup=1)
-    with torch.no_grad():
-      for k, v in net.state_dict().items():
-        if k in bn0:
-          v.copy_(bn0[k])
-    reducer.flat.fill_(float('nan'))  # the replay itself must zero and fill the buffer
-    loss = graphed.replay()
+    for _ in range(3):  # the LAST of several replays is the one compared: a replay must not depend on what the previous one left behind
+      with torch.no_grad():
+        for k, v in net.state_dict().items():
+          if k in bn0:
+            v.copy_(bn0[k])
+      reducer.flat.fill_(float('nan'))  # the replay itself must zero and fill the buffer
+      loss = graphed.replay()
+      torch.cuda.synchronize()
   else:
     loss = body()
   torch.cuda.synchronize()

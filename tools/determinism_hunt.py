@@ -74,7 +74,7 @@ def worker(args):
   ref_trace = ref_flat = ref_labels = None
   bad_steps = 0
   for s in range(args.steps):
-    tr = op_trace.Trace(keep=args.keep)
+    tr = op_trace.Trace(keep=args.keep, inputs=args.keep and bool(args.dump))
     with op_trace.tracing(tr):
       loss = body()
     torch.cuda.synchronize()
@@ -91,22 +91,47 @@ def worker(args):
     if diff is not None or not torch.equal(flat, ref_flat):
       bad_steps += 1
       print(tag, 'EAGER step %d differs from step 0: first at entry %s' % (s, diff), flush=True)
+      if args.dump and args.keep and diff is not None and bad_steps <= 4:
+        i = diff[0]
+        call = tr.labels[i].split('[')[0].rsplit('.in', 1)[0].rsplit('.saved', 1)[0]
+        sel = [j for j, lb in enumerate(tr.labels) if lb.startswith(call + '[') or lb.startswith(call + '.in[') or lb.startswith(call + '.saved[')]
+        os.makedirs(args.dump, exist_ok=True)
+        path = os.path.join(args.dump, 'rank%d_step%d.pt' % (rank, s))
+        torch.save({'first': tr.labels[i], 'labels': [tr.labels[j] for j in sel], 'ref': [ref_trace[j] for j in sel], 'cur': [t[j] for j in sel]}, path)
+        print(tag, '  dumped', path, [tr.labels[j] for j in sel], flush=True)
       print(tag, '  flat gradient:', op_trace.param_report(names_params, ref_flat, flat), flush=True)
   print(tag, 'eager: %d of %d repeated steps differ from the first' % (bad_steps, args.steps - 1), flush=True)
 
   # ---- 2. hipGraph replays against the eager step
+  # (no autograd graph of an eager step may be alive here: its AccumulateGrad nodes are bound to the default stream and a captured
+  # backward that reuses them enqueues on that stream -- hipStreamEndCapture then dies with SIGSEGV instead of an error)
+  del loss, tr
   if args.replays:
-    graphed = GraphedStep(body, (left, right, gt, count), warmup=1)  # (untraced: the flat gradient is compared per parameter)
+    gtr = op_trace.Trace(keep=args.keep)
+    calls = {'n': 0}
+
+    def fn_counted():  # GraphedStep calls it `warmup` times plainly, then once under capture: only that call is traced
+      calls['n'] += 1
+      if calls['n'] > 1 and args.trace_graph:
+        with op_trace.tracing(gtr):
+          return body()
+      return body()
+
+    graphed = GraphedStep(fn_counted, (left, right, gt, count), warmup=1)
     bad_replays = 0
     for r in range(args.replays):
       reducer.flat.fill_(float('nan'))
       graphed.replay()
       torch.cuda.synchronize()
       flat = reducer.flat.cpu()
-      if not torch.equal(flat, ref_flat):
+      diff = None
+      if args.trace_graph:
+        assert gtr.labels == ref_labels, 'graph trace and eager trace list different operator calls'
+        diff = op_trace.first_difference(gtr.labels, ref_trace, gtr.finish())
+      if diff is not None or not torch.equal(flat, ref_flat):
         bad_replays += 1
-        print(tag, 'GRAPH replay %d differs from eager step 0' % r, flush=True)
-        print(tag, '  flat gradient:', op_trace.param_report(names_params, ref_flat, flat), flush=True)
+        print(tag, 'GRAPH replay %d differs from eager step 0: first at entry %s' % (r, diff), flush=True)
+        print(tag, '  flat gradient:', op_trace.param_report(names_params, ref_flat, flat, limit=40), flush=True)
     print(tag, 'graph: %d of %d replays differ from the eager step' % (bad_replays, args.replays), flush=True)
   if ctx is not None:
     ctx.__exit__(None, None, None)
@@ -134,6 +159,8 @@ def main():
   ap.add_argument('--hog-seconds', type=float, default=600)
   ap.add_argument('--nanfill', action='store_true')
   ap.add_argument('--keep', action='store_true')
+  ap.add_argument('--dump', default='', help='directory for the tensors of the first differing operator call (with --keep)')
+  ap.add_argument('--trace-graph', action='store_true', help='record the operator outputs inside the captured step too')
   args = ap.parse_args()
   if args.mode == 'hog':
     return hog(args.hog_seconds)
@@ -146,7 +173,7 @@ def main():
     hogp = subprocess.Popen([sys.executable, os.path.abspath(__file__), 'hog', '--hog-seconds', str(args.hog_seconds)], env=env)
     time.sleep(8)
   fwd = ['--steps', str(args.steps), '--replays', str(args.replays), '--maxdisp', str(args.maxdisp), '--H', str(args.H), '--W', str(args.W)]
-  fwd += (['--nanfill'] if args.nanfill else []) + (['--keep'] if args.keep else [])
+  fwd += (['--nanfill'] if args.nanfill else []) + (['--keep'] if args.keep else []) + (['--trace-graph'] if args.trace_graph else []) + (['--dump', args.dump] if args.dump else [])
   if args.ranks > 1:
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.abspath(__file__), 'worker'] + fwd
