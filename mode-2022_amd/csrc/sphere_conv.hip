@@ -513,8 +513,26 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const float4 we = ent_w[k * P + p];
-      v0[k] = we.x * lv[k * 8 + 0] + we.y * lv[k * 8 + 1] + we.z * lv[k * 8 + 2] + we.w * lv[k * 8 + 3];
-      v1[k] = we.x * lv[k * 8 + 4] + we.y * lv[k * 8 + 5] + we.z * lv[k * 8 + 6] + we.w * lv[k * 8 + 7];
+      // Two SCALAR FMA chains, kept apart by opaque asm.  Written as plain expressions the two chains are SLP-packed into
+      // v_pk_mul_f32 / v_pk_fma_f32 on register pairs whose halves are the results of two different gathers, and that form was not
+      // repeatable: with a second process on the GPU (loads slow enough for the wave to sit in its s_waitcnt) one (channel, tap) row of
+      // the column tile came out wrong in lanes 48..63 -- about one call in 300; in-kernel checks showed the gathered registers equal
+      // to memory afterwards and the combined value not (round 4; tools/determinism_hunt.py: 22-46 differing steps in 232
+      // with the packed form, 0 in 232 with this one).
+      float a = we.x * lv[k * 8 + 0];
+      float b = we.x * lv[k * 8 + 4];
+      asm volatile("" : "+v"(a), "+v"(b));
+      a = fmaf(we.y, lv[k * 8 + 1], a);
+      b = fmaf(we.y, lv[k * 8 + 5], b);
+      asm volatile("" : "+v"(a), "+v"(b));
+      a = fmaf(we.z, lv[k * 8 + 2], a);
+      b = fmaf(we.z, lv[k * 8 + 6], b);
+      asm volatile("" : "+v"(a), "+v"(b));
+      a = fmaf(we.w, lv[k * 8 + 3], a);
+      b = fmaf(we.w, lv[k * 8 + 7], b);
+      asm volatile("" : "+v"(a), "+v"(b));
+      v0[k] = a;
+      v1[k] = b;
     }
     if (has_tail) {  // this pixel has a list longer than EC entries for some tap (near the poles): one branch per chunk
 #pragma unroll
@@ -523,8 +541,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_adj9_kernel(const fl
         for (int e = EC; e < s.y; ++e) {
           const int2 ent = entries[s.x + e];
           const float wt = __int_as_float(ent.y);
-          v0[k] += wt * g0[ent.x];
-          v1[k] += wt * g1[ent.x];
+          float a = g0[ent.x], b = g1[ent.x];
+          asm volatile("" : "+v"(a), "+v"(b));  // (no v_pk_fma_f32 on the pair of freshly loaded values: see above)
+          v0[k] = fmaf(wt, a, v0[k]);
+          asm volatile("" : "+v"(v0[k]));
+          v1[k] = fmaf(wt, b, v1[k]);
         }
       }
     }
