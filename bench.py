@@ -59,6 +59,7 @@ def parse():
                   'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV_ARITH)')
   ap.add_argument('--value-1gpu', type=float, default=None,
                   help='pairs/s of the same workload on ONE GPU, if known: rank 0 adds value / (N * value_1gpu) to the line')
+  ap.add_argument('--no-collective-self-test', action='store_true', help='skip the world-size-1 RCCL all-reduce self-test after the timed region')
   ap.add_argument('--no-eval-b1', action='store_true', help='skip the BASELINE configs[1] leg (eval forward, batch 1) after the timed region')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
@@ -374,6 +375,38 @@ def eval_b1_leg(net, left, right, args, steps=20, warmup=3):
     net.train(was_training)
 
 
+def rccl_self_test(reducer, backend):
+  """World size 1 through the real collective path: init_process_group(backend) on 127.0.0.1, five all-reduces of the flat gradient
+  buffer, timed with events on the current stream.  One GPU cannot measure scaling, but it can prove that RCCL initialises and that
+  the buffer the 8-rank run will reduce is acceptable to it -- so that the first multi-GPU run does not discover either."""
+  import socket
+  out = {'backend': 'rccl' if backend == 'nccl' else backend, 'ranks': 1, 'self_test': True,
+         'op': 'all_reduce(sum) of the flat gradient buffer', 'bytes': reducer.flat.numel() * 4}
+  try:
+    with socket.socket() as sk:
+      sk.bind(('127.0.0.1', 0))
+      port = sk.getsockname()[1]
+    dist.init_process_group(backend, init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    try:
+      before = reducer.flat.clone()
+      dist.all_reduce(reducer.flat, op=dist.ReduceOp.SUM)  # (also creates the communicator)
+      torch.cuda.synchronize()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(5):
+        dist.all_reduce(reducer.flat, op=dist.ReduceOp.SUM)
+      e1.record()
+      torch.cuda.synchronize()
+      out['avg_ms_rank0'] = round(e0.elapsed_time(e1) / 5, 4)
+      out['ok'] = bool(torch.equal(before, reducer.flat))  # a sum over one rank is the identity
+    finally:
+      dist.destroy_process_group()
+  except Exception as e:  # reported, never fatal: the measurement above is already complete
+    out['ok'] = False
+    out['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+  return out
+
+
 def main():
   args = parse()
   if args.cpu_baseline_only:
@@ -526,6 +559,9 @@ def main():
   eval_b1 = None
   if world == 1 and args.mode == 'train' and not args.no_eval_b1:
     eval_b1 = eval_b1_leg(net, left[:1], right[:1], args)
+  self_test = None
+  if world == 1 and args.mode == 'train' and not args.no_collective_self_test:
+    self_test = rccl_self_test(reducer, args.dist_backend)
   rank_ms = [1e3 * elapsed / args.steps]
   if world > 1:
     t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -553,7 +589,7 @@ def main():
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
         'rank_ms_per_step': [round(v, 3) for v in rank_ms],
-        'collective': None if world == 1 else {'backend': 'rccl' if args.dist_backend == 'nccl' else args.dist_backend, 'ranks': world,
+        'collective': self_test if world == 1 else {'backend': 'rccl' if args.dist_backend == 'nccl' else args.dist_backend, 'ranks': world,
                                                'op': 'all_reduce(sum) of the flat gradient buffer, once per step',
                                                'bytes': reducer.flat.numel() * 4,
                                                'avg_ms_rank0': None if allreduce_ms is None else round(allreduce_ms, 3)},

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
-  const long long S4 = S >> 2;
+  const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   // Shifted sums: everything is accumulated relative to a pivot -- the first element of the group's first sample of this channel
   // (bn_pivot, re-read by the finalisation) -- so that var = E[(y-K)^2] - E[y-K]^2 does not cancel when |mean| >> std
   // (torch / MIOpen use Welford; with K inside the data range the shifted form is as accurate and stays a single pass).
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
       acc1(v3);
     }
     for (; i < S4; i += st) acc1(p[i]);
-    if (split == 0) {  // ragged tail (S % 4)
+    {  // scalar path (S % 4 != 0), spread over the blocks like the vector path; empty otherwise
       const float* q = y + ((long long)b * C + c) * S;
-      for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+      for (long long i = (S4 << 2) + (long long)split * NT + threadIdx.x; i < S; i += (long long)nsplit * NT) {
         const float dq = q[i] - K;
         s0 += dq;
         s1 += dq * dq;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   __syncthreads();
   const float sc = coef[0], sh = coef[1];
   const long long base = (long long)bc * S;
-  const long long S4 = S >> 2;
+  const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   const float4* yp = reinterpret_cast<const float4*>(y + base);
   const float4* ap = reinterpret_cast<const float4*>(add + base);
   float4* op = reinterpret_cast<float4*>(out + base);
@@ -229,8 +229,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     op[i + 3 * st] = one(v3, a3);
   }
   for (; i < S4; i += st) op[i] = one(yp[i], ADD ? ap[i] : yp[i]);
-  if (blockIdx.x == 0)
-    for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+  for (long long i = (S4 << 2) + (long long)blockIdx.x * NT + threadIdx.x; i < S; i += (long long)gridDim.x * NT) {  // scalar path (S % 4 != 0)
       float v = __builtin_fmaf(y[base + i], sc, sh);
       if (ADD) v += add[base + i];
       if (RELU) v = relu_nan(v);
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
   const float msc = RELU == 2 ? mscale[prow] : 0.f, msh = RELU == 2 ? mshift[prow] : 0.f;
-  const long long S4 = S >> 2;
+  const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   float s0 = 0.f, s1 = 0.f;
   for (int b = b0; b < b0 + Bg; ++b) {
     const long long base = ((long long)b * C + c) * S;
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
       acc1(g3, v3, o3);
     }
     for (; i < S4; i += st) acc1(gp[i], yp[i], RELU == 1 ? op[i] : yp[i]);
-    if (split == 0)
-      for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+    for (long long i = (S4 << 2) + (long long)split * NT + threadIdx.x; i < S; i += (long long)nsplit * NT) {  // scalar path (S % 4 != 0)
         float g = gout[base + i];
         if (RELU == 1) g = out[base + i] > 0.f ? g : 0.f;
         if (RELU == 2) g = __builtin_fmaf(y[base + i], msc, msh) > 0.f ? g : 0.f;
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
   const float A = coef[0], Bc = coef[1], Cc = coef[2];
   const float msc = RELU == 2 ? mscale[grp * C + c] : 0.f, msh = RELU == 2 ? mshift[grp * C + c] : 0.f;
   const long long base = (long long)bc * S;
-  const long long S4 = S >> 2;
+  const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   const float4* gp = reinterpret_cast<const float4*>(gout + base);
   const float4* yp = reinterpret_cast<const float4*>(y + base);
   const float4* op = reinterpret_cast<const float4*>(out + base);
@@ -395,8 +393,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     one(i + 3 * st, g3, v3, o3);
   }
   for (; i < S4; i += st) one(i, gp[i], yp[i], RELU == 1 ? op[i] : yp[i]);
-  if (blockIdx.x == 0)
-    for (long long i = (S4 << 2) + threadIdx.x; i < S; i += NT) {
+  for (long long i = (S4 << 2) + (long long)blockIdx.x * NT + threadIdx.x; i < S; i += (long long)gridDim.x * NT) {  // scalar path (S % 4 != 0)
       float g = gout[base + i];
       if (RELU == 1) g = out[base + i] > 0.f ? g : 0.f;
       if (RELU == 2) g = __builtin_fmaf(y[base + i], msc, msh) > 0.f ? g : 0.f;
@@ -424,11 +421,12 @@ int apply_chunks(int BC, long long S) {
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// tensors are read in 16-byte pieces when their rows are multiples of 16 bytes, element by element otherwise
+bool aligned_rows(const void* p, long long S) { return (reinterpret_cast<uintptr_t>(p) & ((S & 3) ? 3 : 15)) == 0; }
 
 int check_bn(int B, int C, long long S, const char* who) {
   MODE_REQUIRE(B >= 0 && C > 0 && S > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
   MODE_REQUIRE((long long)B * C < 65536, MODE_ERR_UNSUPPORTED, "%s: B*C = %lld exceeds the grid limit", who, (long long)B * C);
-  MODE_REQUIRE(S % 4 == 0, MODE_ERR_UNSUPPORTED, "%s: spatial size %lld not a multiple of 4 (vector path needs 16-byte rows)", who, S);
   return MODE_OK;
 }
 
@@ -451,7 +449,7 @@ extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* 
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
   MODE_REQUIRE(y && gamma && beta && out && save_mean && save_invstd && workspace, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: null pointer");
-  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)) && aligned16(workspace), MODE_ERR_UNSUPPORTED,
+  MODE_REQUIRE(aligned_rows(y, S) && aligned_rows(out, S) && (!add || aligned_rows(add, S)) && aligned16(workspace), MODE_ERR_UNSUPPORTED,
                "mode_bn_train_fwd: unaligned buffer");
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: running stats must come in pairs");
   MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_fwd: save_scale / save_shift come in pairs");
@@ -481,7 +479,7 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
   if (rc != MODE_OK) return rc;
   if (B == 0) return MODE_OK;
   MODE_REQUIRE(y && gamma && beta && running_mean && running_var && out, MODE_ERR_BAD_ARG, "mode_bn_eval_fwd: null pointer");
-  MODE_REQUIRE(aligned16(y) && aligned16(out) && (!add || aligned16(add)), MODE_ERR_UNSUPPORTED, "mode_bn_eval_fwd: unaligned buffer");
+  MODE_REQUIRE(aligned_rows(y, S) && aligned_rows(out, S) && (!add || aligned_rows(add, S)), MODE_ERR_UNSUPPORTED, "mode_bn_eval_fwd: unaligned buffer");
   hipStream_t st = mode::as_stream(stream);
   BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, nullptr,
                nullptr, 0.f,
@@ -508,8 +506,8 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   MODE_REQUIRE((save_scale == nullptr) == (save_shift == nullptr), MODE_ERR_BAD_ARG, "mode_bn_train_bwd: save_scale / save_shift come in pairs");
   MODE_REQUIRE(!relu || out || save_scale, MODE_ERR_BAD_ARG,
                "mode_bn_train_bwd: the ReLU mask needs the forward output, or (no residual add) the forward's scale / shift");
-  MODE_REQUIRE(aligned16(gout) && aligned16(y) && aligned16(gy) && (!out || aligned16(out)) && (!gadd || aligned16(gadd)) &&
-                   aligned16(workspace),
+  MODE_REQUIRE(aligned_rows(gout, S) && aligned_rows(y, S) && aligned_rows(gy, S) && (!out || aligned_rows(out, S)) &&
+                   (!gadd || aligned_rows(gadd, S)) && aligned16(workspace),
                MODE_ERR_UNSUPPORTED, "mode_bn_train_bwd: unaligned buffer");
   MODE_REQUIRE(groups >= 1 && B % groups == 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: batch %d not divisible into %d groups", B, groups);
   hipStream_t st = mode::as_stream(stream);

@@ -128,7 +128,7 @@ def bn_act(bn, y, add=None, relu=False):
   """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training)."""
   if not y.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')
-  if not HF.bn_supported(y):  # (spatial size not a multiple of 4, other dtypes): the torch module itself, on the GPU
+  if not HF.bn_supported(y):  # (other dtypes, B * C beyond the grid limit): the torch module itself, on the GPU
     return bn_act_torch(bn, y, add, relu)
   return HF.bn_act(bn, y, add, relu, groups=current_bn_groups() if bn.training else 1)
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Peaked-softmax whole-model fixtures: tests/golden/model_peaked_{tiny,cfg1}.npz, made by the *imported reference* on the CPU.
+"""Peaked-softmax whole-model fixtures: tests/golden/model_peaked_{tiny,cfg1,full}.npz, made by the *imported reference* on the CPU.
 
 The well-conditioned fixtures of make_golden_wc.py keep the soft-argmin in its smooth regime by shrinking the three 32 -> 1
 classifier convolutions: their softmax over the disparity axis is close to uniform (confidence = 3 / D), where
@@ -12,7 +12,7 @@ models/mode_disparity.py:157-183) is >= 0.5.  Only the trained tensors are store
 of the state is regenerated from the recipe as before.  Everything else -- outputs, gradients, E_ref against an fp64 evaluation --
 is produced exactly as in make_golden_wc.py (same `run`).
 
-Usage:  python tests/golden/make_golden_peaked.py [--only tiny,cfg1]
+Usage:  python tests/golden/make_golden_peaked.py [--only tiny,cfg1,full]
 """
 import argparse
 import os
@@ -105,10 +105,12 @@ def main():
   ap.add_argument('--lr', type=float, default=3e-3)
   ap.add_argument('--target-conf', type=float, default=0.6)
   ap.add_argument('--dry', action='store_true', help='train only, write nothing')
+  ap.add_argument('--full-grad64', type=int, default=0, help="'full' only: fp64 gradients too (needs ~50 GB of host memory)")
   args = ap.parse_args()
   torch.set_num_threads(8)
   models, _ = mg.import_reference()
-  cases = {'tiny': (16, 64, 32, 2, 700, 1, 8, 0.1), 'cfg1': (64, 512, 256, 1, 800, 4, 8, 0.05)}
+  # 'full' = the benchmark size (BASELINE configs[1] / [2]: 1024 x 512, 192 disparities), one pair: VERDICT r3 item 7
+  cases = {'tiny': (16, 64, 32, 2, 700, 1, 8, 0.1), 'cfg1': (64, 512, 256, 1, 800, 4, 8, 0.05), 'full': (192, 1024, 512, 1, 900, 8, 8, 0.02)}
   for tag in args.only.split(','):
     maxdisp, H, W, B, seed, sub, shift, ls = cases[tag]
     print('%s: training the classifier heads of the imported reference' % tag, flush=True)
@@ -116,7 +118,8 @@ def main():
     print('  %s: mean confidence %.3f after training' % (tag, conf))
     if args.dry:
       continue
-    wc.run(models, tag, maxdisp, H, W, B, seed, sub=sub, grad64=True, logit_scale=ls, override=state, shift=shift, prefix='model_peaked_')
+    wc.run(models, tag, maxdisp, H, W, B, seed, sub=sub, grad64=(tag != 'full' or bool(args.full_grad64)), logit_scale=ls, override=state, shift=shift,
+           prefix='model_peaked_')
 
 
 if __name__ == '__main__':

@@ -588,7 +588,9 @@ def test_conv2d_on_the_integer_table(B, Ci, Co, H, W, k, s, p, d):
 
 
 # ------------------------------------------------------------------ BatchNorm + add + ReLU (a15)
-@pytest.mark.parametrize('shape', [(2, 8, 4, 6, 8), (1, 32, 6, 16, 32), (2, 64, 24, 32), (3, 5, 2, 2, 4)])
+# (the last three: spatial sizes that are not multiples of 4 -- rows not 16-byte aligned: the kernels' scalar path, round 4)
+@pytest.mark.parametrize('shape', [(2, 8, 4, 6, 8), (1, 32, 6, 16, 32), (2, 64, 24, 32), (3, 5, 2, 2, 4), (2, 6, 3, 5, 7), (2, 16, 9, 11),
+                                   (1, 8, 5, 37, 41)])
 @pytest.mark.parametrize('relu,with_add', [(False, False), (True, False), (True, True), (False, True)])
 def test_bn_act_train_and_eval(shape, relu, with_add):
   import torch.nn as nn
@@ -639,7 +641,7 @@ def test_bn_act_train_and_eval(shape, relu, with_add):
   assert (e.cpu().double() - e_ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('shape,groups', [((4, 8, 12, 16), 2), ((6, 5, 4, 6, 8), 3), ((2, 64, 32, 64), 2)])
+@pytest.mark.parametrize('shape,groups', [((4, 8, 12, 16), 2), ((6, 5, 4, 6, 8), 3), ((2, 64, 32, 64), 2), ((4, 6, 7, 9), 2)])
 @pytest.mark.parametrize('relu,with_add', [(True, False), (True, True), (False, False)])
 def test_bn_act_grouped_statistics(shape, groups, relu, with_add):
   """groups = n: exactly what n consecutive calls of the module on the n sub-batches compute -- outputs, gradients (affine
@@ -730,9 +732,19 @@ def test_head_full_size_properties():
   assert (HF.head_fwd(lg + 3.0, (192, 1024, 512)) - pred).abs().max() < 2e-3
   flat = HF.head_fwd(torch.zeros_like(lg), (192, 1024, 512))
   assert (flat - 95.5).abs().max() < 1e-3
-  # same math as separate vendor ops on the GPU (the CPU oracle at this size needs ~1.6 GB and tens of seconds)
+  # Against the float64 oracle on a crop of the same volume (the whole volume needs ~1.6 GB and tens of seconds on the CPU), next to
+  # the composition of separate vendor ops in fp32 -- what the reference runs (F.upsample + F.softmax + disparityregression).  On random
+  # logits of this scale the softmax is multi-modal with modes ~100 px apart, so ANY fp32 evaluation is off by up to ~7e-4 px (a relative
+  # error of 3e-6 in an exponential x the distance between the modes); the fused kernel must not be further from float64 than that.
+  crop = lg[:, :, :, 96:128, 32:64].contiguous()
+  truth = mode_ref.disparity_head(crop.cpu().double(), 192, 128, 128)
+  own = (HF.head_fwd(crop, (192, 128, 128)).cpu().double() - truth).abs()
+  vend = (plain_ops.head(crop, (192, 128, 128)).cpu().double() - truth).abs()
+  print('head at benchmark depth, random logits x4: |hip - fp64| max %.2e mean %.2e; vendor fp32 composition: max %.2e mean %.2e' %
+        (own.max(), own.mean(), vend.max(), vend.mean()))
+  assert float(own.max()) <= max(1e-3, 1.5 * float(vend.max())) and float(own.mean()) <= max(5e-5, 1.5 * float(vend.mean()))
   ref = plain_ops.head(lg, (192, 1024, 512))
-  assert (ref - pred).abs().max() < 1e-3
+  assert (ref - pred).abs().max() < 3e-3 and (ref - pred).abs().mean() < 1e-4  # two fp32 evaluations of the whole volume
 
 
 def test_conv3d_full_size_vs_vendor():
