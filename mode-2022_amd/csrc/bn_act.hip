@@ -138,6 +138,7 @@ struct BnCoefArgs {
   double count;  // elements per (group, channel)
   int groups;    // statistics groups (TRAIN)
   int Bg;        // samples per group
+  const float* pivot;  // (TRAIN) per (group, channel) pivot of the shifted sums; null: the first element of the group's first sample
 };
 
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     reduce_partials(k.partial, g * C + c, k.nsplit, s0, s1, shd);
     if (threadIdx.x == 0) {
       const double dm = s0 / k.count;  // mean of y - K, K = the pivot of bn_stats_kernel
-      const double mean = (double)y[((long long)(g * k.Bg) * C + c) * S] + dm;
+      const double mean = (k.pivot ? (double)k.pivot[g * C + c] : (double)y[((long long)(g * k.Bg) * C + c) * S]) + dm;
       double var = s1 / k.count - dm * dm;
       if (var < 0.0) var = 0.0;
       const double invstd = 1.0 / sqrt(var + (double)k.eps);
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
         reduce_partials(k.partial, gg * C + c, k.nsplit, t0, t1, shd);
         if (threadIdx.x == 0) {
           const double dm = t0 / k.count;
-          const double mean = (double)y[((long long)(gg * k.Bg) * C + c) * S] + dm;
+          const double mean = (k.pivot ? (double)k.pivot[gg * C + c] : (double)y[((long long)(gg * k.Bg) * C + c) * S]) + dm;
           double var = t1 / k.count - dm * dm;
           if (var < 0.0) var = 0.0;
           const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
@@ -441,10 +442,34 @@ int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who,
 // workspace (floats): per-block partial sums, up to 1024 pairs per (group, channel); C = channels x groups
 extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 2048 * sizeof(float) : 0; }
 
+// prestats > 0: the workspace already holds `prestats` partial pairs per channel followed by the C pivots (written by a convolution
+// kernel's statistics epilogue, mode_conv3d_fwd_split_stats): no statistics pass.
+static int bn_train_fwd_impl(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                             float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
+                             int C, long long S, int groups, int prestats, mode_stream_t stream);
+
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                  float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
                                  int C, long long S, int groups, mode_stream_t stream) {
+  return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, groups, 0, stream);
+}
+
+extern "C" int mode_bn_train_fwd_prestats(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
+                                          float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                          float* workspace, int nsplit, int B, int C, long long S, mode_stream_t stream) {
+  MODE_REQUIRE(nsplit > 0 && nsplit <= 1024, MODE_ERR_BAD_ARG, "mode_bn_train_fwd_prestats: %d partial pairs per channel (1..1024)", nsplit);
+  return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, 1, nsplit, stream);
+}
+
+static int bn_train_fwd_impl(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                             float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
+                             int C, long long S, int groups, int prestats, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
@@ -457,11 +482,11 @@ extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* 
   // the apply pass re-reads the pivot of the shifted sums from y while other blocks of the same launch write `out`
   MODE_REQUIRE(out != y, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: in-place operation (out == y) is not supported");
   hipStream_t st = mode::as_stream(stream);
-  const int nsplit = pick_nsplit(C * groups, S);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  const int nsplit = prestats > 0 ? prestats : pick_nsplit(C * groups, S);
+  if (prestats <= 0) hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit,
-               (double)(B / groups) * (double)S, groups, B / groups};
+               (double)(B / groups) * (double)S, groups, B / groups, prestats > 0 ? workspace + 2LL * C * nsplit : nullptr};
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
   if (relu) {
@@ -483,7 +508,7 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
   hipStream_t st = mode::as_stream(stream);
   BnCoefArgs k{nullptr, gamma, beta, const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, nullptr, nullptr, nullptr,
                nullptr, 0.f,
-               eps, 0, 0.0, 1, 1};
+               eps, 0, 0.0, 1, 1, nullptr};
   const int BC = B * C;
   const char* who = "mode_bn_eval_fwd";
   if (relu) {
@@ -532,4 +557,53 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
   return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);
 #undef MODE_BN_BWD_APPLY
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = a + b [+ c [+ d]] in one pass (fixed association ((a + b) + c) + d): the gradient of a tensor with several consumers.  autograd
+// accumulates such gradients pairwise -- n - 1 launches that each read two tensors and write one; for the 4 consumers of cost0
+// (models/mode_disparity.py:119-125: the input of dres2 and the three residual adds) that is 3.6 GB of traffic per step instead of 2 GB.
+namespace {
+__global__ __launch_bounds__(NT) void sum_n_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                   const float* __restrict__ d, float* __restrict__ out, long long n) {
+  const long long n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* c4 = reinterpret_cast<const float4*>(c);
+  const float4* d4 = reinterpret_cast<const float4*>(d);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const long long st = (long long)gridDim.x * NT;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += st) {
+    float4 v = a4[i];
+    const float4 w = b4[i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    if (c) {
+      const float4 u = c4[i];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (d) {
+      const float4 u = d4[i];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    o4[i] = v;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * NT + threadIdx.x; i < n; i += st) {
+    float v = a[i] + b[i];
+    if (c) v += c[i];
+    if (d) v += d[i];
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int mode_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, mode_stream_t stream) {
+  MODE_REQUIRE(n >= 0, MODE_ERR_BAD_ARG, "mode_sum_n: negative size");
+  if (n == 0) return MODE_OK;
+  MODE_REQUIRE(a && b && out && (c || !d), MODE_ERR_BAD_ARG, "mode_sum_n: null pointer (operands are a, b[, c[, d]])");
+  MODE_REQUIRE(aligned16(a) && aligned16(b) && aligned16(out) && (!c || aligned16(c)) && (!d || aligned16(d)), MODE_ERR_UNSUPPORTED,
+               "mode_sum_n: unaligned buffer");
+  const long long blocks = (n / 4 + NT - 1) / NT;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, 16LL * kNumCU));
+  hipLaunchKernelGGL(sum_n_kernel, dim3(grid), dim3(NT), 0, mode::as_stream(stream), a, b, c, d, out, n);
+  return mode::check_launch("mode_sum_n");
 }

@@ -123,9 +123,15 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
 }
 
 // EPI: 0 plain store; 1 folded-BatchNorm shift (+ ReLU); 2 shift + residual add (+ ReLU) -- the eval-mode epilogues
+// EPI 3 (training): plain store + BatchNorm batch statistics of the layer's output taken from the accumulators -- per output channel
+// sum(y - K) and sum((y - K)^2) with the pivot K[c] = stat_pivot[c] (the running mean: anything near the data keeps the shifted sums
+// from cancelling; 0 if null), accumulated per lane over all tiles of the workgroup, reduced over lanes and waves at the end and
+// written as ONE partial pair per (channel, workgroup): stats[(c * gridDim.x + blockIdx.x) * 2 + {0, 1}], then the pivots at
+// stats[2 * Co * gridDim.x + c] -- the layout bn_apply_kernel reduces (mode_bn_train_fwd_prestats).  Saves the statistics pass over y.
 template <int MT, int EPI>
 __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                          float* __restrict__ y, SDims d, Epi epi) {
+                                                          float* __restrict__ y, SDims d, Epi epi, float* __restrict__ stats,
+                                                          const float* __restrict__ stat_pivot) {
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][ITEMS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // grid.y = the 32 * MT-channel output blocks of the layer: every y-slice is the persistent grid described above on ITS block (a
@@ -226,8 +232,18 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   // values of a tile are fetched under the first 8 tap pairs of its last chunk (from a dummy cached address in the other chunks:
   // a branch would split the scheduling region).
   float shiftv[MT][16], addv[MT][R][16];
-  const float relu_floor = (EPI && epi.relu) ? 0.f : -__builtin_inff();
-  if (EPI) {
+  float st0[MT][16], st1[MT][16], stK[MT][16];  // (EPI == 3) running sums and pivots of this lane's 16 output channels
+  if (EPI == 3) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) {
+        st0[m][qq] = st1[m][qq] = 0.f;
+        stK[m][qq] = stat_pivot ? stat_pivot[min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1)] : 0.f;
+      }
+  }
+  const float relu_floor = (EPI == 1 || EPI == 2) && epi.relu ? 0.f : -__builtin_inff();
+  if (EPI == 1 || EPI == 2) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -358,9 +374,14 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
               if (o < d.Co) {
                 const long long idx = o * DHW + sp;
                 float v = acc[m][r][qq];
-                if (EPI) v += shiftv[m][qq];
+                if (EPI == 1 || EPI == 2) v += shiftv[m][qq];
                 if (EPI == 2) v += addv[m][r][qq];
-                yb[idx] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+                if (EPI == 3) {
+                  const float dv = v - stK[m][qq];
+                  st0[m][qq] += dv;
+                  st1[m][qq] = __builtin_fmaf(dv, dv, st1[m][qq]);
+                }
+                yb[idx] = ((EPI == 1 || EPI == 2) && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
               }
             }
         }
@@ -372,27 +393,71 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     ch = ch_next;
     lds_barrier();
   }
+  if (EPI == 3) {
+    // lanes 0..31 / 32..63 hold the same 16 channels each (o = (qq & 3) + 8 (qq >> 2) + 4 half): butterfly over the 32 lanes of a half,
+    // then the four waves through LDS in wave order -- a fixed association
+    float* red = reinterpret_cast<float*>(sm);  // [4 waves][MT * 32 channels][2]
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) {
+        float a = st0[m][qq], b = st1[m][qq];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          a += __shfl_xor(a, off, 64);
+          b += __shfl_xor(b, off, 64);
+        }
+        if ((lane & 31) == 0) {
+          const int c = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+          red[(wave * MT * 32 + c) * 2] = a;
+          red[(wave * MT * 32 + c) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < MT * 32) {
+      const int o = d.o0 + tid;
+      if (o < d.Co) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; ++wv) {
+          a += red[(wv * MT * 32 + tid) * 2];
+          b += red[(wv * MT * 32 + tid) * 2 + 1];
+        }
+        stats[((long long)o * gridDim.x + blockIdx.x) * 2] = a;
+        stats[((long long)o * gridDim.x + blockIdx.x) * 2 + 1] = b;
+        if (blockIdx.x == 0) stats[2LL * d.Co * gridDim.x + o] = stat_pivot ? stat_pivot[o] : 0.f;
+      }
+    }
+  }
 }
 
 template <int MT>
-int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblocks, hipStream_t st, const char* who, Epi epi) {
+int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblocks, hipStream_t st, const char* who, Epi epi,
+                 float* stats = nullptr, const float* stat_pivot = nullptr) {
   const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
+  if (stats) {
+    int rc = mode::allow_lds(conv3d_split_kernel<MT, 3>, LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, 3>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, stats, stat_pivot);
+    return mode::check_launch(who);
+  }
   if (epi.shift && epi.add) {
     int rc = mode::allow_lds(conv3d_split_kernel<MT, 2>, LDS_BYTES, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 2>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, 2>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
     return mode::check_launch(who);
   }
   if (epi.shift) {
     int rc = mode::allow_lds(conv3d_split_kernel<MT, 1>, LDS_BYTES, who);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 1>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, 1>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
     return mode::check_launch(who);
   }
   int rc = mode::allow_lds(conv3d_split_kernel<MT, 0>, LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL((conv3d_split_kernel<MT, 0>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi);
+  hipLaunchKernelGGL((conv3d_split_kernel<MT, 0>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
   return mode::check_launch(who);
 }
 
@@ -406,8 +471,10 @@ size_t conv3d_split_wpack_floats(int K, int rows) {
 
 bool conv3d_split_supported(int K, int rows) { return rows > 1 && rows <= 64 && K % 8 == 0; }
 
+int conv3d_split_stat_partials() { return kNumCU; }  // partial pairs per channel that the statistics epilogue writes
+
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn) {
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* stat_pivot) {
   SDims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.MT = cdiv(rows, 32);
@@ -426,7 +493,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70); the halves are
   // the y-slices of ONE launch
   d.o0 = 0;
-  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi);
+  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, bn ? nullptr : stats, stat_pivot);
 }
 
 }  // namespace mode

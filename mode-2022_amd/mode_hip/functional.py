@@ -1060,6 +1060,45 @@ def grad_sink(param):
   return sink
 
 
+# ------------------------------------------------------------------------------------ tensors with several consumers
+def sum_n(tensors):
+  """a + b [+ c [+ d]] in one pass (mode_sum_n); more than four operands in groups of four."""
+  ts = [t.contiguous() for t in tensors]
+  require_gpu(*ts)
+  require_f32c(*ts)
+  while len(ts) > 1:
+    grp, ts = ts[:4], ts[4:]
+    out = torch.empty_like(grp[0])
+    with torch.cuda.device_of(out), profiling.region('grad_sum%d' % len(grp), 4 * out.numel() * (len(grp) + 1), 0, out.device):
+      check(lib().mode_sum_n(ptr(grp[0]), ptr(grp[1]), ptr(grp[2]) if len(grp) > 2 else None, ptr(grp[3]) if len(grp) > 3 else None, ptr(out),
+                             out.numel(), stream_of(out)), 'mode_sum_n')
+    ts = [out] + ts
+  return ts[0]
+
+
+class FanOutFunction(torch.autograd.Function):
+  """n aliases of x, one per consumer.  autograd would accumulate the consumers' gradients pairwise (n - 1 launches, each reading two
+  tensors and writing one); here they arrive together and are summed in ONE pass.  Pays from three consumers on: cost0 (the input of
+  dres2 and three residual adds) and pre1 (mode_disparity.py:119-125); exact up to the association of the fp32 sum."""
+
+  @staticmethod
+  def forward(ctx, x, n):
+    return tuple(x.view_as(x) for _ in range(n))
+
+  @staticmethod
+  def backward(ctx, *grads):
+    live = [g for g in grads if g is not None]
+    if not live:
+      return None, None
+    return (live[0] if len(live) == 1 else sum_n(live)), None
+
+
+def fan_out(x, n):
+  if n <= 1 or not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad):
+    return (x,) * max(n, 1)
+  return FanOutFunction.apply(x, n)
+
+
 # ------------------------------------------------------------------------------------ 3x3x3 convolution / transposed conv
 def _wpack3d(ci, co, device):
   n = lib().mode_conv3d_wpack_bytes(ci, co)
@@ -1248,6 +1287,55 @@ def conv3d(x, w, stride=1):
   return Conv3dFunction.apply(x, w, stride)
 
 
+def conv3d_stats_supported(x, w, bn):
+  """Training-mode convbn_3d whose stride-1 convolution runs on the split kernel: the BatchNorm batch statistics can be taken in the
+  convolution's epilogue (mode_conv3d_fwd_split_stats) instead of by a pass over its output."""
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] > 0 and bn.training and bn.momentum is not None and
+          _split3d(x.shape[1], w.shape[0], 1, False) and x.shape[0] * w.shape[0] < 65536)
+
+
+class Conv3dStatsFunction(torch.autograd.Function):
+  """Conv3dFunction (stride 1) that also fills `ws` -- the workspace of the BatchNorm that follows -- with the batch statistics of its
+  output (partial sums per workgroup + pivots).  `ws` and `pivot` are plain buffers, not differentiable."""
+
+  @staticmethod
+  def forward(ctx, x, w, ws, pivot):
+    require_gpu(x, w, ws)
+    x, w = x.contiguous(), w.contiguous()
+    require_f32c(x, w, ws)
+    B, Ci, D, H, W = x.shape
+    Co = w.shape[0]
+    if tuple(w.shape[1:]) != (Ci, 3, 3, 3):
+      raise RuntimeError('conv3d: weight %s does not match input channels %d / kernel 3' % (tuple(w.shape), Ci))
+    y = torch.empty((B, Co, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, 1, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
+                                                   2 * y.numel() * Ci * 27, x.device):
+      wp = _wpack3d(Ci, Co, x.device)
+      check(lib().mode_conv3d_fwd_split_stats(ptr(x), ptr(w), ptr(y), ptr(wp), ptr(ws), ptr(pivot) if pivot is not None else None, B, Ci, D, H, W,
+                                              Co, stream_of(x)), 'mode_conv3d_fwd_split_stats')
+    ctx.save_for_backward(x, w)
+    ctx.stride = 1
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    return Conv3dFunction.backward(ctx, gy) + (None,)
+
+
+def conv3d_bn_train(x, conv_weight, bn, add=None, relu=False):
+  """relu?(batch_norm_train(conv3d(x, w, stride 1, padding 1)) [+ add]) with the statistics pass folded into the convolution."""
+  ws = _bn_ws(conv_weight.shape[0], x.device)
+  update = bn.training and bn.track_running_stats
+  pivot = bn.running_mean.detach() if bn.running_mean is not None else None
+  y = Conv3dStatsFunction.apply(x, conv_weight, ws, pivot)
+  nbt = bn.num_batches_tracked if update else None
+  if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+    nbt.add_(1)
+    nbt = None
+  return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None, bn.momentum,
+                             bn.eps, relu, nbt, 1, ws)
+
+
 def deconv3d(x, w):
   return Deconv3dFunction.apply(x, w)
 
@@ -1331,7 +1419,7 @@ class BnActFunction(torch.autograd.Function):
   """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
 
   @staticmethod
-  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1):
+  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1, prestats_ws=None):
     require_gpu(y, add, gamma, beta)
     y = y.contiguous()
     add = add.contiguous() if add is not None else None
@@ -1347,13 +1435,18 @@ class BnActFunction(torch.autograd.Function):
     coef = torch.empty((2, groups * C), dtype=torch.float32, device=y.device) if from_y else None
     nbytes = 4 * y.numel() * (3 + (1 if add is not None else 0))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_fwd', y), nbytes, 0, y.device):
-      ws = _bn_ws(C * groups, y.device)
-      check(lib().mode_bn_train_fwd(ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta),
-                                    ptr(running_mean) if running_mean is not None else None,
-                                    ptr(running_var) if running_var is not None else None,
-                                    ptr(num_batches_tracked) if num_batches_tracked is not None else None, float(momentum), float(eps), int(relu),
-                                    ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None, ptr(coef[1]) if from_y else None,
-                                    ptr(ws), B, C, S, groups, stream_of(y)), 'mode_bn_train_fwd')
+      common = (ptr(y), ptr(add) if add is not None else None, ptr(gamma), ptr(beta), ptr(running_mean) if running_mean is not None else None,
+                ptr(running_var) if running_var is not None else None, ptr(num_batches_tracked) if num_batches_tracked is not None else None,
+                float(momentum), float(eps), int(relu), ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None,
+                ptr(coef[1]) if from_y else None)
+      if prestats_ws is not None:  # the producing convolution left the statistics in the workspace (conv3d_bn_train): no statistics pass
+        if groups != 1:
+          raise RuntimeError('BatchNorm with precomputed statistics takes one statistics group')
+        check(lib().mode_bn_train_fwd_prestats(*common, ptr(prestats_ws), lib().mode_conv3d_fwd_split_stats_partials(), B, C, S, stream_of(y)),
+              'mode_bn_train_fwd_prestats')
+      else:
+        ws = _bn_ws(C * groups, y.device)
+        check(lib().mode_bn_train_fwd(*common, ptr(ws), B, C, S, groups, stream_of(y)), 'mode_bn_train_fwd')
     ctx.save_for_backward(y, out if (relu and not from_y) else None, gamma, beta, mean, invstd, coef)
     ctx.relu, ctx.has_add, ctx.groups = bool(relu), add is not None, groups
     return out
@@ -1381,7 +1474,7 @@ class BnActFunction(torch.autograd.Function):
       ggamma = gbeta = None
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
-    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None
+    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None, None
 
 
 def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):

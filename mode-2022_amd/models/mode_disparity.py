@@ -36,16 +36,20 @@ class hourglass(nn.Module):
     self.conv6 = nn.Sequential(nn.ConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
                                nn.BatchNorm3d(inplanes))
 
-  def forward(self, x, presqu, postsqu, *, residual=None):
+  def forward(self, x, presqu, postsqu, *, residual=None, pre_consumers=1):
     """Reference signature (x, presqu, postsqu).  The keyword-only `residual` is added to the output inside the last fused
-    BatchNorm pass; the reference adds cost0 right after the call (mode_disparity.py:119, 122, 125)."""
+    BatchNorm pass; the reference adds cost0 right after the call (mode_disparity.py:119, 122, 125).  `pre_consumers`: how many times
+    the caller uses the returned `pre` (dres2's is the presqu of both later hourglasses): with more than one, `pre` comes back as a
+    tuple of that many aliases whose gradients are summed together with the internal ones in one pass (functional.fan_out)."""
     out = stage3d.conv_bn(self.conv1[0], x, relu=True)  # 1/4 -> 1/8
     pre = stage3d.conv_bn(self.conv2, out, relu=True, add=postsqu)  # relu(bn(conv) [+ postsqu])
-    out = stage3d.conv_bn(self.conv3[0], pre, relu=True)  # 1/8 -> 1/16
+    inner = 1 + (1 if presqu is None else 0)  # conv3, and conv5's skip when no presqu is given
+    alias = HF.fan_out(pre, inner + pre_consumers) if inner + pre_consumers > 2 else (pre,) * (inner + pre_consumers)
+    out = stage3d.conv_bn(self.conv3[0], alias[0], relu=True)  # 1/8 -> 1/16
     out = stage3d.conv_bn(self.conv4[0], out, relu=True)
-    post = stage3d.conv_bn(self.conv5, out, relu=True, add=presqu if presqu is not None else pre)  # 1/16 -> 1/8
+    post = stage3d.conv_bn(self.conv5, out, relu=True, add=presqu if presqu is not None else alias[1])  # 1/16 -> 1/8
     out = stage3d.conv_bn(self.conv6, post, add=residual)  # 1/8 -> 1/4
-    return out, pre, post
+    return out, (alias[inner] if pre_consumers == 1 else tuple(alias[inner:])), post
 
 
 def _cumulative_bn(module):
@@ -133,9 +137,12 @@ class ModeDisparity(nn.Module):
     t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
     cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
 
-    out1, pre1, post1 = self.dres2(cost0, None, None, residual=cost0)  # out1 = hourglass(...) + cost0
-    out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=cost0)
-    out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=cost0)  # pre1 (not pre2), as in the reference (:124)
+    # cost0 has four consumers (the input of dres2 and the three residual adds), pre1 four (two inside dres2, the presqu of dres3 and
+    # dres4): their gradients are summed in one pass each instead of pairwise by autograd (HF.fan_out; the forward is unchanged)
+    c0 = HF.fan_out(cost0, 4)
+    out1, pre1, post1 = self.dres2(c0[0], None, None, residual=c0[1], pre_consumers=2)  # out1 = hourglass(...) + cost0
+    out2, pre2, post2 = self.dres3(out1, pre1[0], post1, residual=c0[2])
+    out3, pre3, post3 = self.dres4(out2, pre1[1], post2, residual=c0[3])  # pre1 (not pre2), as in the reference (:124)
 
     cost1 = stage3d.classify(self.classif1, out1)
     cost2 = stage3d.classify(self.classif2, out2) + cost1

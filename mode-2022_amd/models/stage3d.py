@@ -75,6 +75,10 @@ def conv_bn(seq, x, relu=False, add=None):
     y = _conv_bn_folded(conv, bn, x, add, relu)
     if y is not None:
       return y
+  if (x.is_cuda and bn.training and current_bn_groups() == 1 and _hip_kind(conv, x) == 'conv1' and conv.out_channels > 1 and
+      torch.is_grad_enabled() and HF.conv3d_stats_supported(x, conv.weight, bn)):
+    # training, stride-1 3-D layer on the split kernel: the BatchNorm statistics come out of the convolution's epilogue
+    return HF.conv3d_bn_train(x, conv.weight, bn, add, relu)
   return bn_act(bn, conv3(conv, x), add, relu)
 
 
