@@ -506,13 +506,13 @@ int mode_zbuffer(const double* r2, const int32_t* target, const float* conf1, fl
                  long long n, mode_stream_t stream);
 
 /* Training forward of convbn_3d (models/submodule.py:20-22) without the statistics pass: the stride-1 split-bf16 convolution kernel
- * takes the BatchNorm batch statistics of its output from the accumulators (per channel: sum(y - K), sum((y - K)^2), K = stat_pivot[c]
- * or 0) and leaves them in `stats` = the BatchNorm workspace (>= mode_bn_workspace_bytes(Co) bytes) as
+ * takes the BatchNorm batch statistics of its output from the accumulators (per channel: sum(y - K), sum((y - K)^2), K = the layer's own
+ * first output value) and leaves them in `stats` = the BatchNorm workspace (>= mode_bn_workspace_bytes(Co) bytes) as
  * mode_conv3d_fwd_split_stats_partials() pairs per channel + the pivots; mode_bn_train_fwd_prestats(..., nsplit = that number, ...) then
  * is mode_bn_train_fwd minus its statistics kernel (one statistics group).  Needs mode_conv3d_split_supported(Ci, Co, 1, 0) == 1. */
 int mode_conv3d_fwd_split_stats_partials(void);
-int mode_conv3d_fwd_split_stats(const float* x, const float* w, float* y, float* wpack, float* stats, const float* stat_pivot, int B, int Ci,
-                                int D, int H, int W, int Co, mode_stream_t stream);
+int mode_conv3d_fwd_split_stats(const float* x, const float* w, float* y, float* wpack, float* stats, int B, int Ci, int D, int H, int W,
+                                int Co, mode_stream_t stream);
 int mode_bn_train_fwd_prestats(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int nsplit,

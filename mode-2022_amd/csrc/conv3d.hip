@@ -583,14 +583,14 @@ extern "C" int mode_conv3d_fwd_split(const float* x, const float* w, const mode_
 // (>= mode_bn_workspace_bytes(Co) bytes: the BatchNorm workspace itself), to be handed to mode_bn_train_fwd_prestats.
 extern "C" int mode_conv3d_fwd_split_stats_partials(void) { return mode::conv3d_split_stat_partials(); }
 
-extern "C" int mode_conv3d_fwd_split_stats(const float* x, const float* w, float* y, float* wpack, float* stats, const float* stat_pivot,
-                                           int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
+extern "C" int mode_conv3d_fwd_split_stats(const float* x, const float* w, float* y, float* wpack, float* stats, int B, int Ci, int D, int H,
+                                           int W, int Co, mode_stream_t stream) {
   const char* who = "mode_conv3d_fwd_split_stats";
   int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 1, who);
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(stats, MODE_ERR_WORKSPACE, "%s: statistics workspace required", who);
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "%s: empty batch has no statistics", who);
-  return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, nullptr, stats, stat_pivot);
+  return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, nullptr, stats);
 }
 
 // Stride-2 forward on the split-bf16 kernel of conv3d_split_s2.hip (also the input gradient of the transposed convolution, with

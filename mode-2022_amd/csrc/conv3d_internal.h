@@ -22,10 +22,10 @@ int conv3d_co1_bwd_weight(const float* gy, const float* x, float* gw, float* wor
 bool conv3d_split_supported(int K, int rows);
 size_t conv3d_split_wpack_floats(int K, int rows);
 // stats != nullptr (training, bn == nullptr): the kernel also leaves the BatchNorm batch statistics of y as conv3d_split_stat_partials()
-// partial pairs per channel + the pivots (layout: conv3d_split_kernel, EPI 3); stat_pivot: per-channel pivot of the shifted sums or null.
+// partial pairs per channel + the pivots of the shifted sums (layout: conv3d_split_kernel, EPI 3).
 int conv3d_split_stat_partials();
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr, const float* stat_pivot = nullptr);
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr);
 
 // conv3d_split_s2.hip: the stride-2 forward (= input gradient of the transposed convolution) on the same arithmetic; rows = output
 // channels (33..64), K = reduction channels (multiple of 8); w is (rows, K, 27); wpack >= conv3d_s2_split_wpack_floats(K, rows).

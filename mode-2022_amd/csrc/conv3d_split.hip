@@ -124,10 +124,27 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
 
 // EPI: 0 plain store; 1 folded-BatchNorm shift (+ ReLU); 2 shift + residual add (+ ReLU) -- the eval-mode epilogues
 // EPI 3 (training): plain store + BatchNorm batch statistics of the layer's output taken from the accumulators -- per output channel
-// sum(y - K) and sum((y - K)^2) with the pivot K[c] = stat_pivot[c] (the running mean: anything near the data keeps the shifted sums
-// from cancelling; 0 if null), accumulated per lane over all tiles of the workgroup, reduced over lanes and waves at the end and
-// written as ONE partial pair per (channel, workgroup): stats[(c * gridDim.x + blockIdx.x) * 2 + {0, 1}], then the pivots at
+// sum(y - K) and sum((y - K)^2) with the pivot K[c] = stat_pivot[c] (anything near the data keeps the shifted sums from cancelling;
+// first_voxel_kernel below puts the layer's own first output value there: a function of x and w only, so the result does not depend on
+// BatchNorm's running state), accumulated per lane over all tiles of the workgroup, reduced over lanes and waves at the end and
+// written as ONE partial pair per (channel, workgroup): stats[(c * gridDim.x + blockIdx.x) * 2 + {0, 1}]; the pivots sit behind them at
 // stats[2 * Co * gridDim.x + c] -- the layout bn_apply_kernel reduces (mode_bn_train_fwd_prestats).  Saves the statistics pass over y.
+__global__ void first_voxel_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ pivot, int K, int Co, int D,
+                                   int H, int W) {
+  // y[b = 0][o][0][0][0]: taps (kd, kh, kw) in {1, 2}^3 (the others fall into the zero padding), in plain fp32
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= Co) return;
+  const long long HW = (long long)H * W, DHW = (long long)D * HW;
+  float acc = 0.f;
+  for (int c = 0; c < K; ++c)
+    for (int kd = 1; kd < 3; ++kd)
+      for (int kh = 1; kh < 3; ++kh)
+        for (int kw = 1; kw < 3; ++kw)
+          if (kd - 1 < D && kh - 1 < H && kw - 1 < W)
+            acc = __builtin_fmaf(w[((long long)o * K + c) * 27 + kd * 9 + kh * 3 + kw], x[c * DHW + (kd - 1) * HW + (kh - 1) * W + (kw - 1)], acc);
+  pivot[o] = acc;
+}
+
 template <int MT, int EPI>
 __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                           float* __restrict__ y, SDims d, Epi epi, float* __restrict__ stats,
@@ -426,7 +443,6 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
         }
         stats[((long long)o * gridDim.x + blockIdx.x) * 2] = a;
         stats[((long long)o * gridDim.x + blockIdx.x) * 2 + 1] = b;
-        if (blockIdx.x == 0) stats[2LL * d.Co * gridDim.x + o] = stat_pivot ? stat_pivot[o] : 0.f;
       }
     }
   }
@@ -474,7 +490,7 @@ bool conv3d_split_supported(int K, int rows) { return rows > 1 && rows <= 64 && 
 int conv3d_split_stat_partials() { return kNumCU; }  // partial pairs per channel that the statistics epilogue writes
 
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* stat_pivot) {
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats) {
   SDims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.MT = cdiv(rows, 32);
@@ -493,7 +509,12 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70); the halves are
   // the y-slices of ONE launch
   d.o0 = 0;
-  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, bn ? nullptr : stats, stat_pivot);
+  if (stats && !bn) {  // the pivots of the statistics epilogue: behind the partial pairs, where bn_apply_kernel looks for them
+    float* pivot = stats + 2LL * rows * conv3d_split_stat_partials();
+    hipLaunchKernelGGL(first_voxel_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, st, x, w, pivot, K, rows, D, H, W);
+    return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, stats, pivot);
+  }
+  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi);
 }
 
 }  // namespace mode

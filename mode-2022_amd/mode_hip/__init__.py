@@ -24,7 +24,7 @@ SIGNATURES = {
     'mode_debug_poison': (_c_int, [ctypes.c_uint, _c_ptr]),
     'mode_sum_n': (_c_int, [_c_ptr] * 5 + [ctypes.c_longlong, _c_ptr]),
     'mode_conv3d_fwd_split_stats_partials': (_c_int, []),
-    'mode_conv3d_fwd_split_stats': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv3d_fwd_split_stats': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_bn_train_fwd_prestats': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 6 + [_c_int] * 3 +
                                    [ctypes.c_longlong, _c_ptr]),
     'mode_sphere_conv_wpack_bytes': (_c_size, [_c_int] * 5),

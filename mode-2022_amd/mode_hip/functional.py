@@ -1296,10 +1296,10 @@ def conv3d_stats_supported(x, w, bn):
 
 class Conv3dStatsFunction(torch.autograd.Function):
   """Conv3dFunction (stride 1) that also fills `ws` -- the workspace of the BatchNorm that follows -- with the batch statistics of its
-  output (partial sums per workgroup + pivots).  `ws` and `pivot` are plain buffers, not differentiable."""
+  output (partial sums per workgroup + pivots).  `ws` is a plain buffer, not differentiable."""
 
   @staticmethod
-  def forward(ctx, x, w, ws, pivot):
+  def forward(ctx, x, w, ws):
     require_gpu(x, w, ws)
     x, w = x.contiguous(), w.contiguous()
     require_f32c(x, w, ws)
@@ -1311,23 +1311,22 @@ class Conv3dStatsFunction(torch.autograd.Function):
     with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, 1, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                    2 * y.numel() * Ci * 27, x.device):
       wp = _wpack3d(Ci, Co, x.device)
-      check(lib().mode_conv3d_fwd_split_stats(ptr(x), ptr(w), ptr(y), ptr(wp), ptr(ws), ptr(pivot) if pivot is not None else None, B, Ci, D, H, W,
-                                              Co, stream_of(x)), 'mode_conv3d_fwd_split_stats')
+      check(lib().mode_conv3d_fwd_split_stats(ptr(x), ptr(w), ptr(y), ptr(wp), ptr(ws), B, Ci, D, H, W, Co, stream_of(x)),
+            'mode_conv3d_fwd_split_stats')
     ctx.save_for_backward(x, w)
     ctx.stride = 1
     return y
 
   @staticmethod
   def backward(ctx, gy):
-    return Conv3dFunction.backward(ctx, gy) + (None,)
+    return Conv3dFunction.backward(ctx, gy)
 
 
 def conv3d_bn_train(x, conv_weight, bn, add=None, relu=False):
   """relu?(batch_norm_train(conv3d(x, w, stride 1, padding 1)) [+ add]) with the statistics pass folded into the convolution."""
   ws = _bn_ws(conv_weight.shape[0], x.device)
   update = bn.training and bn.track_running_stats
-  pivot = bn.running_mean.detach() if bn.running_mean is not None else None
-  y = Conv3dStatsFunction.apply(x, conv_weight, ws, pivot)
+  y = Conv3dStatsFunction.apply(x, conv_weight, ws)
   nbt = bn.num_batches_tracked if update else None
   if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
     nbt.add_(1)

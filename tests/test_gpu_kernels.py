@@ -697,7 +697,8 @@ def test_bn_act_grouped_statistics(shape, groups, relu, with_add):
 def test_conv3d_with_batchnorm_statistics_in_its_epilogue(B, Ci, Co, D, H, W, relu, with_add):
   """Training-mode convbn_3d with the statistics pass folded into the split convolution kernel (HF.conv3d_bn_train, round 4) against
   float64: output, input / weight / affine gradients, running statistics -- and against the two-kernel path it replaces.  The input has
-  a large mean (|mean| >> std after the convolution): the shifted sums must not cancel with the running mean as pivot, nor with pivot 0."""
+  a large mean (|mean| >> std after the convolution): the shifted sums must not cancel (their pivot is the layer's own first output value,
+  whatever the running statistics hold)."""
   import torch.nn as nn
   if HF.CONV_ARITH != 'bf16x6':
     pytest.skip('the statistics epilogue belongs to the split kernel')
