@@ -59,6 +59,8 @@ def parse():
                   'per product, fp32 accumulation (fp32 accuracy; mode_hip/functional.py CONV_ARITH)')
   ap.add_argument('--value-1gpu', type=float, default=None,
                   help='pairs/s of the same workload on ONE GPU, if known: rank 0 adds value / (N * value_1gpu) to the line')
+  ap.add_argument('--fused-bn-stats', action='store_true',
+                  help='A/B: BatchNorm statistics of the stride-1 3-D layers in the convolution epilogue (functional.CONV3D_BN_STATS; measured +-0)')
   ap.add_argument('--no-collective-self-test', action='store_true', help='skip the world-size-1 RCCL all-reduce self-test after the timed region')
   ap.add_argument('--no-eval-b1', action='store_true', help='skip the BASELINE configs[1] leg (eval forward, batch 1) after the timed region')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -433,6 +435,7 @@ def main():
   mode_hip.lib()  # fail loudly if the native library is missing
   from mode_hip import functional as HF
   HF.set_conv_arith(args.conv_arith)
+  HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)

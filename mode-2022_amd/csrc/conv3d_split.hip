@@ -129,20 +129,22 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
 // BatchNorm's running state), accumulated per lane over all tiles of the workgroup, reduced over lanes and waves at the end and
 // written as ONE partial pair per (channel, workgroup): stats[(c * gridDim.x + blockIdx.x) * 2 + {0, 1}]; the pivots sit behind them at
 // stats[2 * Co * gridDim.x + c] -- the layout bn_apply_kernel reduces (mode_bn_train_fwd_prestats).  Saves the statistics pass over y.
-__global__ void first_voxel_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ pivot, int K, int Co, int D,
-                                   int H, int W) {
-  // y[b = 0][o][0][0][0]: taps (kd, kh, kw) in {1, 2}^3 (the others fall into the zero padding), in plain fp32
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= Co) return;
+__global__ __launch_bounds__(64) void first_voxel_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ pivot,
+                                                         int K, int Co, int D, int H, int W) {
+  // y[b = 0][o][0][0][0]: taps (kd, kh, kw) in {1, 2}^3 (the others fall into the zero padding), in plain fp32.  One wave per output
+  // channel, the (channel, tap) terms spread over the lanes (a single thread walking them is 2 * 8 K dependent loads: 0.25 ms)
+  const int o = blockIdx.x, lane = threadIdx.x;
   const long long HW = (long long)H * W, DHW = (long long)D * HW;
   float acc = 0.f;
-  for (int c = 0; c < K; ++c)
-    for (int kd = 1; kd < 3; ++kd)
-      for (int kh = 1; kh < 3; ++kh)
-        for (int kw = 1; kw < 3; ++kw)
-          if (kd - 1 < D && kh - 1 < H && kw - 1 < W)
-            acc = __builtin_fmaf(w[((long long)o * K + c) * 27 + kd * 9 + kh * 3 + kw], x[c * DHW + (kd - 1) * HW + (kh - 1) * W + (kw - 1)], acc);
-  pivot[o] = acc;
+  for (int item = lane; item < K * 8; item += 64) {
+    const int c = item >> 3, t = item & 7;
+    const int kd = 1 + (t >> 2), kh = 1 + ((t >> 1) & 1), kw = 1 + (t & 1);
+    if (kd - 1 < D && kh - 1 < H && kw - 1 < W)
+      acc = __builtin_fmaf(w[((long long)o * K + c) * 27 + kd * 9 + kh * 3 + kw], x[c * DHW + (kd - 1) * HW + (kh - 1) * W + (kw - 1)], acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) pivot[o] = acc;
 }
 
 template <int MT, int EPI>
@@ -511,7 +513,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.o0 = 0;
   if (stats && !bn) {  // the pivots of the statistics epilogue: behind the partial pairs, where bn_apply_kernel looks for them
     float* pivot = stats + 2LL * rows * conv3d_split_stat_partials();
-    hipLaunchKernelGGL(first_voxel_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, st, x, w, pivot, K, rows, D, H, W);
+    hipLaunchKernelGGL(first_voxel_kernel, dim3(rows), dim3(64), 0, st, x, w, pivot, K, rows, D, H, W);
     return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, stats, pivot);
   }
   return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi);

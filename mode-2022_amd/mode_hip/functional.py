@@ -1287,11 +1287,19 @@ def conv3d(x, w, stride=1):
   return Conv3dFunction.apply(x, w, stride)
 
 
+# BatchNorm statistics in the epilogue of the stride-1 split 3-D convolution (training) instead of a statistics pass over its output.
+# Built and measured in round 4 (same box, graph-replayed step): the ten BatchNorm layers behind these convolutions get 0.41 ms
+# cheaper, the convolution launches 0.36 ms dearer (0.78 -> 0.82 ms at 32 -> 32 / 48 x 256 x 128: the tile epilogue of a persistent,
+# one-workgroup-per-CU kernel is not overlapped with anything, so whatever is added to it is paid in full): 73.03-73.41 against
+# 73.17-73.39 ms per step.  Off by default -- the two-kernel path has one code path fewer; `bench.py --fused-bn-stats` measures it.
+CONV3D_BN_STATS = False
+
+
 def conv3d_stats_supported(x, w, bn):
   """Training-mode convbn_3d whose stride-1 convolution runs on the split kernel: the BatchNorm batch statistics can be taken in the
   convolution's epilogue (mode_conv3d_fwd_split_stats) instead of by a pass over its output."""
-  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] > 0 and bn.training and bn.momentum is not None and
-          _split3d(x.shape[1], w.shape[0], 1, False) and x.shape[0] * w.shape[0] < 65536)
+  return (CONV3D_BN_STATS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] > 0 and bn.training and
+          bn.momentum is not None and _split3d(x.shape[1], w.shape[0], 1, False) and x.shape[0] * w.shape[0] < 65536)
 
 
 class Conv3dStatsFunction(torch.autograd.Function):

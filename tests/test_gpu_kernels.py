@@ -694,7 +694,7 @@ def test_bn_act_grouped_statistics(shape, groups, relu, with_add):
 
 @pytest.mark.parametrize('B,Ci,Co,D,H,W', [(2, 32, 32, 6, 20, 40), (1, 32, 64, 5, 9, 33), (2, 64, 64, 4, 16, 32)])
 @pytest.mark.parametrize('relu,with_add', [(True, False), (False, True)])
-def test_conv3d_with_batchnorm_statistics_in_its_epilogue(B, Ci, Co, D, H, W, relu, with_add):
+def test_conv3d_with_batchnorm_statistics_in_its_epilogue(B, Ci, Co, D, H, W, relu, with_add, monkeypatch):
   """Training-mode convbn_3d with the statistics pass folded into the split convolution kernel (HF.conv3d_bn_train, round 4) against
   float64: output, input / weight / affine gradients, running statistics -- and against the two-kernel path it replaces.  The input has
   a large mean (|mean| >> std after the convolution): the shifted sums must not cancel (their pivot is the layer's own first output value,
@@ -724,6 +724,7 @@ def test_conv3d_with_batchnorm_statistics_in_its_epilogue(B, Ci, Co, D, H, W, re
     xd = x.to(DEV).requires_grad_(True)
     ad = add.to(DEV) if with_add else None
     if fused:
+      monkeypatch.setattr(HF, 'CONV3D_BN_STATS', True)
       assert HF.conv3d_stats_supported(xd, wd, bn)
       out = HF.conv3d_bn_train(xd, wd, bn, ad, relu)
     else:
