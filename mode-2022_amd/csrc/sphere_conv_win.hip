@@ -838,9 +838,285 @@ __global__ void pack_w_win_split(const float* __restrict__ w, uint4* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The TALL-window tiles (next to the poles: windows of 145 rows, or the whole axis with wrap-around) on the same arithmetic (round 4).
+// Until then they ran fwd_tile -- fp32 MFMA, matrix-bound, 0.2 ms per tile whatever the image count: the floor of every spherical layer
+// of an eval forward at one pair (15 x 0.23 of 11.4 ms) and a third of the training launch.  Their windows do not leave room for an
+// operand buffer, so the roles are not split as in the small-tile code below: as in fwd_tile a wave samples its own 32 pixels and
+// multiplies them with all four output-channel tiles, straight from registers.  K of one MFMA = 8 input channels x 2 taps (lanes 0..31
+// tap 2p, lanes 32..63 tap 2p + 1; five pairs, the second half of the last one multiplies zeros), so a chunk stays 8 channels deep and
+// the window staging of fwd_tile is kept as it is.  Per pair and wave: 8 samples per lane (4 LDS words + 4 FMAs each), the exact
+// 3-way split, 24 MFMAs against 12 KB of weight fragments (L2 -> L1: what bounds it now: 96 KB per pair and workgroup).
+constexpr int TP = 5;  // tap pairs of a 3 x 3 kernel
+
+// wpt[(((((g*MG + mg)*NCH + ch)*TP + pair)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[g*Cog + mg*128 + m*32 + (lane&31)]
+// [ch*8 + j][tap = 2 pair + (lane>>5)], j = 0..7 (zeros for tap 9; scaled by the folded BatchNorm scale when fold != 0)
+__global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __restrict__ wpt, WinDims d, int fold, mode_bn_epilogue bn) {
+  const long long total = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int m = (int)(r % MTW);
+    r /= MTW;
+    const int pair = (int)(r % TP);
+    r /= TP;
+    const int ch = (int)(r % d.NCH);
+    r /= d.NCH;
+    const int mg = (int)(r % d.MG);
+    const int g = (int)(r / d.MG);
+    const int co = mg * 128 + m * 32 + (lane & 31);
+    const int tap = 2 * pair + (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * CCH + j;
+      v[j] = 0.f;
+      if (tap < KT && co < d.Cog && c < d.Cig) {
+        v[j] = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
+        if (fold) v[j] *= fold_scale(bn, g * d.Cog + co);
+      }
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    uint4* dst = wpt + (idx - lane) * 3 + lane;
+    dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  }
+}
+
+// Template parameters as fwd_tile (window rows, double-buffered staging in NPH phases of NRB row passes).
+template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI>
+__device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, const float* __restrict__ pos, const uint4* __restrict__ wpt,
+                                               float* __restrict__ y, const WinDims& d, int h0, int w0, int rbase, int cbase, float* smem,
+                                               const Epi& epi) {
+  const int WRP = WR_T > 0 ? WR_T : d.wr;
+  const int CP = chan_pitch(WRP);
+  const int bufsz = CCH * CP;
+  const int b = blockIdx.y;
+  const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+  const int h = h0 + (wave / TW) * 32 + (lane & 31), w = w0 + (wave % TW);
+  const bool pix_ok = h < d.H && w < d.W;
+  const long long HW = (long long)d.H * d.W;
+
+  // sampling records of the taps THIS lane samples: tap 2p + half of pair p (tap 9 does not exist: zero weights)
+  int roff[TP];
+  float4 rw[TP];
+  {
+    float ph_[TP], pw_[TP];
+    const long long idx = pix_ok ? (long long)h * d.W + w : 0;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int k = min(2 * p + half, KT - 1);
+      ph_[p] = pos[(2 * k) * HW + idx];
+      pw_[p] = pos[(2 * k + 1) * HW + idx];
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      int r0 = 0, c0 = 0;
+      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+      mode::tap_record_fixed(ph_[p], pw_[p], d.H, d.W, r0, c0, wt);
+      if (!pix_ok || 2 * p + half >= KT) wt = make_float4(0.f, 0.f, 0.f, 0.f);
+      int lr = r0 - rbase;
+      if (lr < 0) lr += d.H;
+      const int lc = c0 - cbase;
+      const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
+      roff[p] = dead ? 0 : lc * WRP + lr;
+      rw[p] = wt;
+    }
+  }
+  const int lds_floats = (PIPE ? 2 : 1) * bufsz + WRP + 8;
+  for (int i = tid; i < lds_floats; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
+  __syncthreads();
+
+  // window staging: exactly fwd_tile's
+  const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
+  const int gcol = cbase + scol;
+  const bool col_ok = gcol < d.W;
+  const float* xg = x + ((long long)b * d.Ci + (long long)g * d.Cig) * HW + (col_ok ? gcol * d.sw : 0);
+  int rowoff[NRB];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int r = rb * SROWS + srow;
+    rowoff[rb] = ((rbase + (r < WRP ? r : 0)) % d.H) * d.sh;
+  }
+  constexpr int CPH = CCH / NPH;
+  float lv[PIPE ? CPH * NRB : 1];
+  auto issue = [&](int ch, int ph) {
+#pragma unroll
+    for (int cc = 0; cc < CPH; ++cc) {
+      const int chan = ch * CCH + ph * CPH + cc;
+      const float* xc = xg + (long long)(chan < d.Cig ? chan : 0) * HW;
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) lv[cc * NRB + rb] = xc[rowoff[rb]];
+    }
+  };
+  auto commit = [&](int ch, int ph, float* buf) {
+#pragma unroll
+    for (int cc = 0; cc < CPH; ++cc) {
+      const int c = ph * CPH + cc;
+      const bool ok = col_ok && (ch * CCH + c < d.Cig);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const int r = rb * SROWS + srow;
+        if (r < WRP) buf[c * CP + scol * WRP + r] = ok ? lv[cc * NRB + rb] : 0.f;
+      }
+    }
+  };
+  auto stage_now = [&](int ch, float* buf) {
+    for (int r = srow; r < WRP; r += SROWS) {
+      const int ro = ((rbase + r) % d.H) * d.sh;
+#pragma unroll
+      for (int c4 = 0; c4 < CCH; c4 += 4) {
+        float t4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int chan = ch * CCH + c4 + c;
+          t4[c] = xg[(long long)(chan < d.Cig ? chan : 0) * HW + ro];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) buf[(c4 + c) * CP + scol * WRP + r] = (col_ok && ch * CCH + c4 + c < d.Cig) ? t4[c] : 0.f;
+      }
+    }
+  };
+
+  f32x16 acc[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  // weight fragments: the four output tiles of a pair go through the registers in two halves (tiles 0-1, then 2-3), the next half
+  // requested while the current one multiplies -- all four at once, double-buffered, are 96 registers and spill
+  const uint4* wpa = wpt + ((long long)(g * d.MG + mg) * d.NCH) * TP * MTW * 192 + lane;  // + (pair step * MTW + m) * 192 + piece * 64
+  const int nhalf = d.NCH * TP * 2;  // half steps of the whole tile
+  uint4 a_cur[2][3], a_nxt[2][3];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a_cur[m][q] = wpa[m * 192 + q * 64];
+
+  // the 8 channel values of this lane's (pixel, tap) for pair p: 32 window words, then 4 FMAs each and the split
+  auto load_raw = [&](const float* buf, int p, float (&raw)[32]) {
+    const float* q0 = buf + roff[p];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = q0 + c * CP;
+      raw[c * 4 + 0] = q[0];
+      raw[c * 4 + 1] = q[WRP];
+      raw[c * 4 + 2] = q[1];
+      raw[c * 4 + 3] = q[WRP + 1];
+    }
+  };
+  auto combine = [&](const float (&raw)[32], int p, uint4 (&bq)[3]) {
+    const float4 tw = rw[p];
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = __builtin_fmaf(tw.w, raw[c * 4 + 3], __builtin_fmaf(tw.z, raw[c * 4 + 2], __builtin_fmaf(tw.y, raw[c * 4 + 1], tw.x * raw[c * 4])));
+      asm("" : "+v"(v[c]));  // (one scalar chain per value: see sphere_fwd_split_kernel::sample)
+    }
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    bq[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  };
+
+  if (PIPE) {
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      issue(0, ph);
+      commit(0, ph, smem);
+    }
+    __syncthreads();
+  }
+  constexpr int PPP = TP / NPH;  // tap pairs per staging phase (NPH = 2: pairs 0-1 | 2-4; NPH = 4: one pair each, the last phase two)
+  for (int ch = 0; ch < d.NCH; ++ch) {
+    float* cur = smem + (PIPE ? (ch & 1) * bufsz : 0);
+    float* nxt = smem + (PIPE ? ((ch + 1) & 1) * bufsz : 0);
+    const bool more = ch + 1 < d.NCH;
+    if (!PIPE) {
+      if (ch > 0) __syncthreads();
+      stage_now(ch, cur);
+      __syncthreads();
+    }
+    float raw[32];
+    uint4 bq[3];
+    load_raw(cur, 0, raw);
+    combine(raw, 0, bq);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      if (PIPE && p % PPP == 0 && p / PPP < NPH && more) issue(ch + 1, p / PPP);  // rows of the next chunk fly under the MFMAs below
+      if (p + 1 < TP) load_raw(cur, p + 1, raw);
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int hs = (ch * TP + p) * 2 + mh;                 // this half step: output tiles 2 mh, 2 mh + 1 of pair p
+        const int nh = hs + 1 < nhalf ? hs + 1 : hs;           // the next one (the last repeats itself)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a_nxt[m][q] = wpa[((long long)(nh >> 1) * MTW + 2 * (nh & 1) + m) * 192 + q * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#define MODE_TALL_TERM(PA, PB) \
+  _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[2 * mh + m] = sp_mfma(a_cur[m][PA], bq[PB], acc[2 * mh + m]);
+        MODE_TALL_TERM(2, 0)
+        MODE_TALL_TERM(0, 2)
+        MODE_TALL_TERM(1, 1)
+        MODE_TALL_TERM(1, 0)
+        MODE_TALL_TERM(0, 1)
+        MODE_TALL_TERM(0, 0)
+#undef MODE_TALL_TERM
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
+      }
+      if (p + 1 < TP) combine(raw, p + 1, bq);
+      if (PIPE && more && (p == TP - 1 || (p % PPP == PPP - 1 && p / PPP < NPH - 1)))
+        commit(ch + 1, p == TP - 1 ? NPH - 1 : p / PPP, nxt);  // the other buffer: nobody reads it now
+    }
+    if (PIPE) __syncthreads();
+  }
+
+  if (pix_ok) {
+    float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)h * d.sh + (long long)w * d.sw;
+    const int cmax = d.Cog - mg * 128;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      float res[16];
+      if (EPI) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < cmax) {
+          if (EPI) {
+            const float v = (acc[m][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
+            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
+          } else {
+            yb[(long long)co * HW] = acc[m][r];
+          }
+        }
+      }
+      if (EPI) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <bool EPI>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float* __restrict__ x, const float* __restrict__ pos,
-                                                                    const uint4* __restrict__ wps, const float4* __restrict__ wp,
+                                                                    const uint4* __restrict__ wps, const uint4* __restrict__ wpt,
                                                                     float* __restrict__ y, WinDims d, int NCH16,
                                                                     const int4* __restrict__ tiles, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -848,15 +1124,15 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
   const int4 t = tiles[blockIdx.x];
   const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
-  // the few tall-window tiles (next to the poles) run on the fp32 path INSIDE this launch: as a launch of their own they would be an
-  // under-filled tail (0.37 ms for the two launches against 0.26 for the old single one)
+  // the few tall-window tiles (next to the poles) run INSIDE this launch (as a launch of their own they would be an under-filled tail:
+  // 0.37 ms for the two launches against 0.26 for the old single one), on the same arithmetic since round 4 (fwd_tile_split)
   const int cls = t.w >> 16;
   if (cls == 1) {
-    fwd_tile<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    fwd_tile_split<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
     return;
   }
   if (cls != 0) {
-    fwd_tile<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wp, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    fwd_tile_split<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
     return;
   }
   const int b = blockIdx.y;
@@ -1661,7 +1937,8 @@ extern "C" size_t mode_sphere_conv_win_wpack_bytes(int Ci, int Co, int Kh, int K
   const int Cig = Ci / groups, Cog = Co / groups;
   const size_t f32 = (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * KT * MTW * 64 * 4 + (size_t)Co;  // + shifts
   const size_t split = (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, SP_CCH) * KT * MTW * 3 * 64 * 4;       // split-bf16 fragments
-  return (((f32 + 3) / 4) * 4 + split) * sizeof(float);
+  const size_t tall = (size_t)groups * mode::cdiv(Cog, 128) * mode::cdiv(Cig, CCH) * TP * MTW * 3 * 64 * 4;            // ... of the tall tiles
+  return (((f32 + 3) / 4) * 4 + split + tall) * sizeof(float);
 }
 
 namespace {
@@ -1697,9 +1974,14 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
     hipLaunchKernelGGL(pack_w_win_split, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
                        bn ? *bn : mode_bn_epilogue());
+    uint4* wpt = wps + nsplit * 3;  // fragments of the tall-window tiles: K = 8 channels x 2 taps
+    if (n_mid + n_wrap > 0) {
+      const long long ntall = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
+      hipLaunchKernelGGL(pack_w_win_split_tall, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, bn ? 1 : 0,
+                         bn ? *bn : mode_bn_epilogue());
+    }
     // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
     const int4* tl = reinterpret_cast<const int4*>(tiles);
-    const float4* wp4 = reinterpret_cast<const float4*>(wpack);
     int n_all = n_small + n_mid + n_wrap;
     if (n_wrap > 0 && !d.wrap_pipe) {
       rc = bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi)
@@ -1715,12 +1997,12 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     if (bn) {
       rc = mode::allow_lds(sphere_fwd_split_kernel<true>, lds, "mode_sphere_conv_fwd_win_split");
       if (rc != MODE_OK) return rc;
-      hipLaunchKernelGGL(sphere_fwd_split_kernel<true>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wp4, y, d, NCH16, tl,
+      hipLaunchKernelGGL(sphere_fwd_split_kernel<true>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wpt, y, d, NCH16, tl,
                          epi);
     } else {
       rc = mode::allow_lds(sphere_fwd_split_kernel<false>, lds, "mode_sphere_conv_fwd_win_split");
       if (rc != MODE_OK) return rc;
-      hipLaunchKernelGGL(sphere_fwd_split_kernel<false>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wp4, y, d, NCH16, tl,
+      hipLaunchKernelGGL(sphere_fwd_split_kernel<false>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wpt, y, d, NCH16, tl,
                          epi);
     }
     return mode::check_launch("mode_sphere_conv_fwd_win_split");

@@ -105,6 +105,7 @@ def main():
   ap.add_argument('--lr', type=float, default=3e-3)
   ap.add_argument('--target-conf', type=float, default=0.6)
   ap.add_argument('--dry', action='store_true', help='train only, write nothing')
+  ap.add_argument('--reuse-state', action='store_true', help='take the trained heads from the existing fixture instead of training again')
   ap.add_argument('--full-grad64', type=int, default=0, help="'full' only: fp64 gradients too (needs ~50 GB of host memory)")
   args = ap.parse_args()
   torch.set_num_threads(8)
@@ -113,8 +114,14 @@ def main():
   cases = {'tiny': (16, 64, 32, 2, 700, 1, 8, 0.1), 'cfg1': (64, 512, 256, 1, 800, 4, 8, 0.05), 'full': (192, 1024, 512, 1, 900, 8, 8, 0.02)}
   for tag in args.only.split(','):
     maxdisp, H, W, B, seed, sub, shift, ls = cases[tag]
-    print('%s: training the classifier heads of the imported reference' % tag, flush=True)
-    state, conf, gt_value = train_heads(models, maxdisp, H, W, B, seed, shift, args.steps, args.lr, args.target_conf, ls)
+    path = os.path.join(HERE, 'model_peaked_%s.npz' % tag)
+    if args.reuse_state and os.path.exists(path):  # the trained heads of an existing fixture (training is deterministic but slow at full size)
+      z = np.load(path)
+      state, conf = {k[len('state/'):]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith('state/')}, float(z['eval/conf_mean'])
+      print('%s: re-using the %d trained tensors of %s' % (tag, len(state), path), flush=True)
+    else:
+      print('%s: training the classifier heads of the imported reference' % tag, flush=True)
+      state, conf, gt_value = train_heads(models, maxdisp, H, W, B, seed, shift, args.steps, args.lr, args.target_conf, ls)
     print('  %s: mean confidence %.3f after training' % (tag, conf))
     if args.dry:
       continue
