@@ -52,7 +52,7 @@ def _load(z, bn_from_fixture=False):
   return net, left.to(DEV), right.to(DEV), gt.to(DEV), seed
 
 
-def _grad_floor(name, ndim, tiny=False):
+def _grad_floor(name, ndim, tiny=False, peaked_full=False):
   """Relative L2 level a parameter gradient is held to at least.
     3-D stage (dres*, classif*): 1e-3.
     extractor: its gradients are what is left of O(1) terms after ~60 BatchNorm backward passes cancel all but ~1e-3 of them
@@ -63,6 +63,14 @@ def _grad_floor(name, ndim, tiny=False):
     Hence 4e-3 for the extractor's convolution weights and 1e-2 for its BatchNorm vectors; a dropped or wrong term is O(1), and
     the whole-network and whole-extractor L2 errors are held to max(1e-3 / 2e-3, 3 x the reference's own) on top (_check_grads)."""
   if not name.startswith('feature_extraction'):
+    # The peaked-softmax fixture at the benchmark size: the loss gradient is concentrated on few voxels, and the ReLU masks of two
+    # correct fp32 evaluations differ in 1 .. 65 of the 1.5 M .. 50 M elements of every layer of the 3-D stage (counted between this
+    # implementation's own two arithmetics with tools/experiments/arith_divergence.py: e.g. 16 of 12.6 M at dres3.conv2) -- each such
+    # element moves a per-channel sum by a whole term.  The reference's own fp32 run shows the same against float64 (up to 3.6e-3 on
+    # dres2.conv3 / dres2.conv1 tensors, 1e-4 on others: which tensors are hit is chance).  Hence 4e-3 for the per-channel BatchNorm
+    # vectors and 2e-3 for the weights there; everywhere else the 3-D stage is held to 1e-3.
+    if peaked_full:
+      return 2e-3 if ndim > 1 else 4e-3
     return 1e-3
   # At the 64 x 32 fixture a layer of the extractor has 512 pixels per channel, and ONE ReLU whose pre-activation lies within a
   # rounding of zero decides ~1/500 of that layer's gradients: layer3.2.conv1 has such an element (-1.3e-6 with the fp32 MFMA
@@ -89,7 +97,7 @@ def _check_grads(tag, net, z, seed):
     delta = proj - z['train/grad_proj'][i]
     rel = float(np.sqrt(np.mean(delta**2))) / (norm + 1e-300)
     e_own = float(own[i]) if own is not None else 2e-4
-    bound = max(_grad_floor(name, p.dim(), tag.startswith('tiny')), 5.0 * e_own)
+    bound = max(_grad_floor(name, p.dim(), tag.startswith('tiny'), tag.startswith('peaked full')), 5.0 * e_own)
     worst = max(worst, rel)
     d_all += delta
     n_all += norm**2
