@@ -177,8 +177,17 @@ def kernel_of(label, conv_arith, on_split=None):
     if name == 'sphere_conv_bwd_data':
       return 'sphere_bwd_data_split_kernel' if split else ('sphere_bwd_data_adj9_kernel' if windowed else 'sphere_bwd_data_adj_kernel')
     return ('sphere_bww_split_kernel' if split else 'sphere_bww_win_kernel') if windowed else 'sphere_bwd_weight_kernel'
+  if name.startswith('grad_sum'):
+    return 'sum_n_kernel'  # (N-ary sum of the gradients that meet at a fan-out, functional.FanOutFunction)
+  if name in ('head_fwd', 'head_bwd'):
+    # one thread per pixel with the logit column in registers when maxdisp/4 is one of the instantiated depths (csrc/head.hip)
+    m = re.search(r'\[(\d+)x', label)
+    fast = (not m) or int(m.group(1)) in (4, 8, 12, 16, 48, 64)
+    if name == 'head_fwd':
+      return 'head_fwd_fast_kernel' if fast else 'head_fwd_kernel'
+    return ('head_bwd_pix_fast_kernel' if fast else 'head_bwd_pix_kernel') + '+head_bwd_rows_kernel+head_bwd_cols_kernel'
   return {'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel',
-          'bn_eval_fwd': 'bn_eval_kernel', 'head_fwd': 'head_fwd_kernel', 'head_bwd': 'head_bwd_pix_kernel+head_bwd_gather_kernel',
+          'bn_eval_fwd': 'bn_eval_kernel',
           'cost_volume_fwd': 'cost_volume_fwd_v4', 'cost_volume_bwd': 'cost_volume_bwd_v4',
           'cost_conv_assemble_fwd': 'cost_conv_assemble_fwd_kernel', 'cost_conv_assemble_bwd': 'cost_conv_assemble_bwd_kernel',
           'conv_stem_fwd': 'stem_fwd_kernel', 'conv_stem_bwd_weight': 'stem_bww_kernel', 'conv1x1_fwd': 'conv1x1_kernel',
