@@ -781,6 +781,8 @@ constexpr int SP_WIN = SP_CCH * SP_CP;                      // floats per window
 constexpr int SP_WIN_FLOATS = ((2 * SP_WIN + WR_SMALL + 8 + 3) / 4) * 4;  // both buffers + slack, 16-byte multiple
 constexpr int SP_OP = 8 * 3 * 64;                           // uint4 per operand buffer
 constexpr size_t SP_LDS_BYTES = (size_t)SP_WIN_FLOATS * sizeof(float) + 2 * (size_t)SP_OP * sizeof(uint4);
+constexpr size_t SP3_LDS_BYTES = SP_LDS_BYTES + (size_t)SP_OP * sizeof(uint4);  // the forward keeps three operand buffers
+static_assert(SP3_LDS_BYTES <= 160 * 1024, "windows + three operand buffers must fit the 160 KB of a CU");
 
 typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
@@ -791,10 +793,14 @@ __device__ __forceinline__ uint32_t sp_pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sp_bf16x2));
 }
 __device__ __forceinline__ void sp_split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  // (the two subtractions of a pair must stay scalar: SLP-packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed
+  // fp32 instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
   p1 = sp_pack2(a, b);
-  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  asm("" : "+v"(ra), "+v"(rb));
   p2 = sp_pack2(ra, rb);
-  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  asm("" : "+v"(sa), "+v"(sb));
   p3 = sp_pack2(sa, sb);
 }
 __device__ __forceinline__ f32x16 sp_mfma(uint4 a, uint4 b, f32x16 c) {
@@ -886,6 +892,13 @@ __global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __rest
   }
 }
 
+#ifdef MODE_TAPTIME
+// debug build only (tools/experiments/sphere_taptime.py): s_memtime stamps of wave 0 of every small-window workgroup
+__device__ unsigned long long g_taptime[4 * 8192];
+#define MODE_STAMP(j) if (threadIdx.x == 0) g_taptime[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 4 + (j)] = __builtin_readcyclecounter();
+#else
+#define MODE_STAMP(j)
+#endif
 // Template parameters as fwd_tile (window rows, double-buffered staging in NPH phases of NRB row passes).
 template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI>
 __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, const float* __restrict__ pos, const uint4* __restrict__ wpt,
@@ -896,6 +909,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   const int bufsz = CCH * CP;
   const int b = blockIdx.y;
   const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
+  MODE_STAMP(0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
   const int h = h0 + (wave / TW) * 32 + (lane & 31), w = w0 + (wave % TW);
   const bool pix_ok = h < d.H && w < d.W;
@@ -965,41 +979,42 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       }
     }
   };
-  auto stage_now = [&](int ch, float* buf) {
-    for (int r = srow; r < WRP; r += SROWS) {
-      const int ro = ((rbase + r) % d.H) * d.sh;
-#pragma unroll
-      for (int c4 = 0; c4 < CCH; c4 += 4) {
-        float t4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int chan = ch * CCH + c4 + c;
-          t4[c] = xg[(long long)(chan < d.Cig ? chan : 0) * HW + ro];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) buf[(c4 + c) * CP + scol * WRP + r] = (col_ok && ch * CCH + c4 + c < d.Cig) ? t4[c] : 0.f;
-      }
-    }
-  };
-
   f32x16 acc[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  // weight fragments: the four output tiles of a pair go through the registers in two halves (tiles 0-1, then 2-3), the next half
-  // requested while the current one multiplies -- all four at once, double-buffered, are 96 registers and spill
-  const uint4* wpa = wpt + ((long long)(g * d.MG + mg) * d.NCH) * TP * MTW * 192 + lane;  // + (pair step * MTW + m) * 192 + piece * 64
-  const int nhalf = d.NCH * TP * 2;  // half steps of the whole tile
-  uint4 a_cur[2][3], a_nxt[2][3];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) a_cur[m][q] = wpa[m * 192 + q * 64];
+  // WEIGHT FRAGMENTS THROUGH LDS (round 4).  A pair step multiplies this wave's B fragment with all four output tiles: 12 fragments =
+  // 12 KB, the same for the 8 waves.  Fetched by every wave on its own they were 96 KB per step and workgroup through the vector
+  // memory path (L1 holds 32 KB; a chunk's five steps are 60 KB), and a tall tile took 0.18 ms against 0.09 ms for a small-window
+  // tile -- the critical path of the launch at 2 and 4 images.  Now the workgroup fetches a step's 12 KB once (1.5 x 16 B per thread),
+  // one step ahead, into one of two LDS buffers behind the windows, and the waves read their fragments from there.  One barrier per
+  // step, in its middle: first half = tiles 0, 1 (fragments read during the second half of the previous step), second half = tiles
+  // 2, 3 (read during the first half); the next step's weights are stored at the top of a step and visible after its barrier.
+  // The sampling arithmetic of the next step sits between the MFMAs slot by slot (see sphere_fwd_split_kernel).
+  static_assert(PIPE, "the split tall tiles are double-buffered");
+  constexpr int WSTEP = MTW * 3 * 64;  // uint4 per pair step
+  uint4* wbuf = reinterpret_cast<uint4*>(smem + ((lds_floats + 3) / 4) * 4);  // [2][WSTEP]
+  const uint4* wsrc = wpt + ((long long)(g * d.MG + mg) * d.NCH) * TP * WSTEP;  // + step * WSTEP + fragment * 64 + lane
+  const int nsteps = d.NCH * TP;
+  uint4 wg0, wg1;  // the 1.5 x 16 bytes this thread fetches of the step after the next
+  auto wfetch = [&](int step) {
+    const uint4* src = wsrc + (long long)(step < nsteps ? step : nsteps - 1) * WSTEP;
+    wg0 = src[tid];
+    wg1 = src[NTHREADS + (tid & 255)];
+  };
+  auto wstore = [&](int step) {
+    uint4* dst = wbuf + (step & 1) * WSTEP;
+    dst[tid] = wg0;
+    if (tid < 256) dst[NTHREADS + tid] = wg1;
+  };
+  wfetch(0);
 
   // the 8 channel values of this lane's (pixel, tap) for pair p: 32 window words, then 4 FMAs each and the split
-  auto load_raw = [&](const float* buf, int p, float (&raw)[32]) {
+  float raw[32], v[8], ra[4], rb[4];
+  uint32_t q1[4], q2[4], q3[4];
+  auto load_raw = [&](const float* buf, int p) {
     const float* q0 = buf + roff[p];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -1010,78 +1025,142 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       raw[c * 4 + 3] = q[WRP + 1];
     }
   };
-  auto combine = [&](const float (&raw)[32], int p, uint4 (&bq)[3]) {
+  auto comb = [&](int p, int c) {  // (one scalar chain per value: see sphere_fwd_split_kernel)
     const float4 tw = rw[p];
-    float v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      v[c] = __builtin_fmaf(tw.w, raw[c * 4 + 3], __builtin_fmaf(tw.z, raw[c * 4 + 2], __builtin_fmaf(tw.y, raw[c * 4 + 1], tw.x * raw[c * 4])));
-      asm("" : "+v"(v[c]));  // (one scalar chain per value: see sphere_fwd_split_kernel::sample)
-    }
-    uint32_t q1[4], q2[4], q3[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
-    bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-    bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    bq[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    v[c] = __builtin_fmaf(tw.w, raw[c * 4 + 3], __builtin_fmaf(tw.z, raw[c * 4 + 2], __builtin_fmaf(tw.y, raw[c * 4 + 1], tw.x * raw[c * 4])));
+    asm("" : "+v"(v[c]));
   };
+  auto split_a = [&](int j) {
+    q1[j] = sp_pack2(v[2 * j], v[2 * j + 1]);
+    ra[j] = v[2 * j] - __builtin_bit_cast(float, q1[j] << 16);
+    rb[j] = v[2 * j + 1] - __builtin_bit_cast(float, q1[j] & 0xffff0000u);
+    asm("" : "+v"(ra[j]), "+v"(rb[j]));
+  };
+  auto split_b = [&](int j) {
+    q2[j] = sp_pack2(ra[j], rb[j]);
+    ra[j] = ra[j] - __builtin_bit_cast(float, q2[j] << 16);
+    rb[j] = rb[j] - __builtin_bit_cast(float, q2[j] & 0xffff0000u);
+    asm("" : "+v"(ra[j]), "+v"(rb[j]));
+  };
+  auto split_c = [&](int j) { q3[j] = sp_pack2(ra[j], rb[j]); };
 
-  if (PIPE) {
 #pragma unroll
-    for (int ph = 0; ph < NPH; ++ph) {
-      issue(0, ph);
-      commit(0, ph, smem);
-    }
-    __syncthreads();
+  for (int ph = 0; ph < NPH; ++ph) {
+    issue(0, ph);
+    commit(0, ph, smem);
   }
+  wstore(0);
+  wfetch(1);
+  __syncthreads();
+  uint4 a_cur[2][3], a_nxt[2][3], bq[3];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a_cur[m][q] = wbuf[(m * 3 + q) * 64 + lane];
   constexpr int PPP = TP / NPH;  // tap pairs per staging phase (NPH = 2: pairs 0-1 | 2-4; NPH = 4: one pair each, the last phase two)
+  // B fragment of the first pair of the first chunk; every later one is built under the MFMAs of the step before it -- the first pair
+  // of a chunk too: the last phase of the next chunk's window is stored in the FIRST half of the chunk's last step, so that window is
+  // complete at that step's barrier and its second half can sample from it (no chunk-top sampling, no barrier at the chunk end)
+  load_raw(smem, 0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) comb(0, c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    split_a(j);
+    split_b(j);
+    split_c(j);
+  }
+  bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+  bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+  bq[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  MODE_STAMP(1)
+#define MODE_SB __builtin_amdgcn_sched_barrier(0);
+#define MODE_TMF(PA, PB, m, t) acc[t] = sp_mfma(a_cur[m][PA], bq[PB], acc[t]);
   for (int ch = 0; ch < d.NCH; ++ch) {
-    float* cur = smem + (PIPE ? (ch & 1) * bufsz : 0);
-    float* nxt = smem + (PIPE ? ((ch + 1) & 1) * bufsz : 0);
+    float* cur = smem + (ch & 1) * bufsz;
+    float* nxt = smem + ((ch + 1) & 1) * bufsz;
     const bool more = ch + 1 < d.NCH;
-    if (!PIPE) {
-      if (ch > 0) __syncthreads();
-      stage_now(ch, cur);
-      __syncthreads();
-    }
-    float raw[32];
-    uint4 bq[3];
-    load_raw(cur, 0, raw);
-    combine(raw, 0, bq);
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
-      if (PIPE && p % PPP == 0 && p / PPP < NPH && more) issue(ch + 1, p / PPP);  // rows of the next chunk fly under the MFMAs below
-      if (p + 1 < TP) load_raw(cur, p + 1, raw);
+      const int step = ch * TP + p;
+      const uint4* wcur = wbuf + (step & 1) * WSTEP + lane;
+      const uint4* wnx = wbuf + ((step + 1) & 1) * WSTEP + lane;
+      const int pn = p + 1 < TP ? p + 1 : 0;  // the pair whose B fragment is built under this step (pair 0 of the next chunk under the last)
+      // ---- first half: output tiles 0, 1
+      if (p % PPP == 0 && p / PPP < NPH && more) issue(ch + 1, p / PPP);  // rows of the next chunk fly under the MFMAs below
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int hs = (ch * TP + p) * 2 + mh;                 // this half step: output tiles 2 mh, 2 mh + 1 of pair p
-        const int nh = hs + 1 < nhalf ? hs + 1 : hs;           // the next one (the last repeats itself)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 3; ++q) a_nxt[m][q] = wcur[((2 + m) * 3 + q) * 64];
+      wstore(step + 1);
+      if (p + 1 < TP) load_raw(cur, pn);
+      if (p == TP - 1 && more) commit(ch + 1, NPH - 1, nxt);  // (its loads were requested a step ago)
+      MODE_SB
+      MODE_TMF(2, 0, 0, 0) MODE_SB
+      MODE_TMF(2, 0, 1, 1) MODE_SB
+      MODE_TMF(0, 2, 0, 0) MODE_SB
+      MODE_TMF(0, 2, 1, 1) MODE_SB
+      MODE_TMF(1, 1, 0, 0) if (p + 1 < TP) comb(pn, 0); MODE_SB
+      MODE_TMF(1, 1, 1, 1) if (p + 1 < TP) comb(pn, 1); MODE_SB
+      MODE_TMF(1, 0, 0, 0) if (p + 1 < TP) comb(pn, 2); MODE_SB
+      MODE_TMF(1, 0, 1, 1) if (p + 1 < TP) comb(pn, 3); MODE_SB
+      MODE_TMF(0, 1, 0, 0) if (p + 1 < TP) comb(pn, 4); MODE_SB
+      MODE_TMF(0, 1, 1, 1) if (p + 1 < TP) comb(pn, 5); MODE_SB
+      MODE_TMF(0, 0, 0, 0) if (p + 1 < TP) comb(pn, 6); MODE_SB
+      MODE_TMF(0, 0, 1, 1) if (p + 1 < TP) comb(pn, 7); MODE_SB
+      sp_lds_barrier();  // the weights of step + 1 are in LDS
+      // ---- second half: output tiles 2, 3
 #pragma unroll
-          for (int q = 0; q < 3; ++q) a_nxt[m][q] = wpa[((long long)(nh >> 1) * MTW + 2 * (nh & 1) + m) * 192 + q * 64];
-        __builtin_amdgcn_sched_barrier(0);
-#define MODE_TALL_TERM(PA, PB) \
-  _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[2 * mh + m] = sp_mfma(a_cur[m][PA], bq[PB], acc[2 * mh + m]);
-        MODE_TALL_TERM(2, 0)
-        MODE_TALL_TERM(0, 2)
-        MODE_TALL_TERM(1, 1)
-        MODE_TALL_TERM(1, 0)
-        MODE_TALL_TERM(0, 1)
-        MODE_TALL_TERM(0, 0)
-#undef MODE_TALL_TERM
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_nxt[m][q] = wnx[(m * 3 + q) * 64];
+      wfetch(step + 2);
+      if (p + 1 == TP) load_raw(more ? nxt : cur, 0);  // (after the last chunk: any finite words, the fragment is not used)
+      MODE_SB
+      if (p + 1 < TP) {
+        MODE_TMF(2, 0, 0, 2) split_a(0); MODE_SB
+        MODE_TMF(2, 0, 1, 3) split_b(0); MODE_SB
+        MODE_TMF(0, 2, 0, 2) split_c(0); split_a(1); MODE_SB
+        MODE_TMF(0, 2, 1, 3) split_b(1); MODE_SB
+        MODE_TMF(1, 1, 0, 2) split_c(1); split_a(2); MODE_SB
+        MODE_TMF(1, 1, 1, 3) split_b(2); MODE_SB
+        MODE_TMF(1, 0, 0, 2) split_c(2); split_a(3); MODE_SB
+        MODE_TMF(1, 0, 1, 3) split_b(3); MODE_SB
+        MODE_TMF(0, 1, 0, 2) split_c(3); MODE_SB
+        MODE_TMF(0, 1, 1, 3) MODE_SB
+        MODE_TMF(0, 0, 0, 2) MODE_SB
+        MODE_TMF(0, 0, 1, 3) MODE_SB
+      } else {  // the whole B fragment of the next chunk's first pair under these twelve MFMAs
+        MODE_TMF(2, 0, 0, 2) MODE_SB
+        MODE_TMF(2, 0, 1, 3) MODE_SB
+        MODE_TMF(0, 2, 0, 2) comb(0, 0); comb(0, 1); MODE_SB
+        MODE_TMF(0, 2, 1, 3) comb(0, 2); comb(0, 3); MODE_SB
+        MODE_TMF(1, 1, 0, 2) comb(0, 4); comb(0, 5); MODE_SB
+        MODE_TMF(1, 1, 1, 3) comb(0, 6); comb(0, 7); MODE_SB
+        MODE_TMF(1, 0, 0, 2) split_a(0); split_a(1); MODE_SB
+        MODE_TMF(1, 0, 1, 3) split_b(0); split_b(1); MODE_SB
+        MODE_TMF(0, 1, 0, 2) split_c(0); split_c(1); split_a(2); MODE_SB
+        MODE_TMF(0, 1, 1, 3) split_a(3); split_b(2); MODE_SB
+        MODE_TMF(0, 0, 0, 2) split_b(3); MODE_SB
+        MODE_TMF(0, 0, 1, 3) split_c(2); split_c(3); MODE_SB
       }
-      if (p + 1 < TP) combine(raw, p + 1, bq);
-      if (PIPE && more && (p == TP - 1 || (p % PPP == PPP - 1 && p / PPP < NPH - 1)))
-        commit(ch + 1, p == TP - 1 ? NPH - 1 : p / PPP, nxt);  // the other buffer: nobody reads it now
+      if (more && p < TP - 1 && p % PPP == PPP - 1 && p / PPP < NPH - 1) commit(ch + 1, p / PPP, nxt);  // the other buffer: nobody reads it now
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
+      bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+      bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+      bq[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     }
-    if (PIPE) __syncthreads();
   }
+#undef MODE_SB
+#undef MODE_TMF
+  MODE_STAMP(2)
 
   if (pix_ok) {
     float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)h * d.sh + (long long)w * d.sw;
@@ -1112,6 +1191,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       if (EPI) __builtin_amdgcn_sched_barrier(0);
     }
   }
+  MODE_STAMP(3)
 }
 
 template <bool EPI>
@@ -1121,7 +1201,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
                                                                     const int4* __restrict__ tiles, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WRP = WR_SMALL, CP = SP_CP;
-  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
+  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [3][8 pixel groups][3 pieces][64 lanes]
   const int4 t = tiles[blockIdx.x];
   const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
   // the few tall-window tiles (next to the poles) run INSIDE this launch (as a launch of their own they would be an under-filled tail:
@@ -1135,6 +1215,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     fwd_tile_split<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
     return;
   }
+  MODE_STAMP(0)
   const int b = blockIdx.y;
   const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
@@ -1155,20 +1236,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       pw_[k] = pos[(2 * k + 1) * HW + idx];
     }
   }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    int r0 = 0, c0 = 0;
-    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-    mode::tap_record_fixed(ph_[k], pw_[k], d.H, d.W, r0, c0, wt);
-    if (!pix_ok) wt = make_float4(0.f, 0.f, 0.f, 0.f);
-    int lr = r0 - rbase;
-    if (lr < 0) lr += d.H;
-    const int lc = c0 - cbase;
-    const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
-    roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
-    rw[k] = wt;
-  }
-  for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
+  // every window word that may be read is finite: the staging stores write all rows and columns of both windows; what they never
+  // write is the pad word behind each channel and the slack behind the two buffers (read only under zero weights)
+  if (tid < 2 * SP_CCH) smem[(tid / SP_CCH) * SP_WIN + (tid % SP_CCH) * CP + WC * WRP] = 0.f;
+  if (tid < WRP + 8) smem[SP_WIN + tid] = 0.f;  // (the last channel of the first window runs over into the second, which is empty during the first chunk)
+  for (int i = 2 * SP_WIN + tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;
   __syncthreads();
 
   // window staging: thread -> (window column, row within a pass of SROWS rows), as in fwd_tile; 2 passes cover the 81 rows
@@ -1183,6 +1255,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     rowoff[rb] = 4u * (unsigned)(((rbase + (r < WRP ? r : 0)) % d.H) * d.sh + (col_ok ? gcol * d.sw : 0));
   }
   const long long plane_bytes = 4 * HW;
+  constexpr int STAGE_LAG = 2;  // taps between the loads of a staging phase and its LDS stores
   float lv[8][4];  // the 8 staging phases of a chunk (phase = 2 channels x 2 row passes), all in flight at once
   auto issue = [&](int ch, int ph, int set) {  // (Cig is a multiple of 16: every channel of a chunk exists)
     const char* xc = reinterpret_cast<const char*>(xg) + ((long long)ch * SP_CCH + ph * 2) * plane_bytes;  // uniform
@@ -1206,17 +1279,30 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       }
     }
   };
-  // B fragment of this lane's pixel for tap k of the chunk in `win`: 8 channels, split, stored as this wave's group
-  auto sample = [&](const float* win, int k, uint4* op) {
+  // B fragment of this lane's pixel for tap k of the chunk in `win`: 8 channels, split, stored as this wave's group.  In two halves:
+  // sample_read requests the 32 window words (16 ds_read2_b32) in ONE batch, sample_finish combines, splits and stores them.  As one
+  // lambda the compiler issued each read right in front of its use (`ds_read2_b32; s_waitcnt lgkmcnt(0)` sixteen times per tap, all
+  // of it BEHIND the tap's 24 MFMAs): sixteen serialised LDS round trips per tap and wave, 2 700 cycles per tap against the 1 536 the
+  // matrix pipe needs (tools/experiments/tap_pipeline.hip reproduces it without the rest of the kernel)
+  auto sample_read = [&](const float* win, int k, float (&raw)[8][4]) {
     const float* p = win + half * 8 * CP + roff[k];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = p + c * CP;
+      raw[c][0] = q[0];
+      raw[c][1] = q[WRP];
+      raw[c][2] = q[1];
+      raw[c][3] = q[WRP + 1];
+    }
+  };
+  auto sample_finish = [&](int k, float (&raw)[8][4], uint4* op) {
     const float4 tw = rw[k];
     float v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const float* q = p + c * CP;
       // (one fma chain per value: left to itself the compiler SLP-packs these into v_pk_fma_f32, which costs the MFMA stream more
       // than two plain FMAs)
-      v[c] = __builtin_fmaf(tw.w, q[WRP + 1], __builtin_fmaf(tw.z, q[1], __builtin_fmaf(tw.y, q[WRP], tw.x * q[0])));
+      v[c] = __builtin_fmaf(tw.w, raw[c][3], __builtin_fmaf(tw.z, raw[c][2], __builtin_fmaf(tw.y, raw[c][1], tw.x * raw[c][0])));
       asm("" : "+v"(v[c]));  // (opaque, not volatile -- a volatile asm pins the schedule: keeps the chains of two channels from being packed pairwise -- 24 v_mov + 24 v_pk_*)
     }
     uint32_t q1[4], q2[4], q3[4];
@@ -1227,6 +1313,12 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
     dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
   };
+  auto sample = [&](const float* win, int k, uint4* op) {
+    float raw[8][4];
+    sample_read(win, k, raw);
+    __builtin_amdgcn_sched_barrier(0);  // (all 16 reads requested before the first one is used)
+    sample_finish(k, raw, op);
+  };
 
   f32x16 acc[4];
 #pragma unroll
@@ -1236,21 +1328,61 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   const int m = wave % TW, gset = (wave / TW) * 4;  // output tile and first pixel group of the MATRIX role
   const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;  // uniform; + p * 64 + lane per fragment
   const int nsteps = NCH16 * KT;
-  uint4 aring[3][3];  // weight fragments of taps k, k + 1, k + 2 (slot = tap % 3; 9 taps per chunk keep the slots aligned)
+  uint4 acur[3], anxt[3];  // weight fragments of this tap and of the next one (requested at the top of a tap, one tap ahead)
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    aring[0][p] = wpa[(unsigned)(p * 64 + lane)];
-    aring[1][p] = (wpa + (long long)(nsteps > 1 ? 1 : 0) * MTW * 192)[(unsigned)(p * 64 + lane)];
-  }
+  for (int p = 0; p < 3; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
 
   // prologue: window of chunk 0, operand of tap 0
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) issue(0, ph, ph);  // 32 loads in flight, then the stores: one memory round trip, not eight
+  // (the sampling records are computed while those loads fly)
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    int r0 = 0, c0 = 0;
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    mode::tap_record_fixed(ph_[k], pw_[k], d.H, d.W, r0, c0, wt);
+    if (!pix_ok) wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lr = r0 - rbase;
+    if (lr < 0) lr += d.H;
+    const int lc = c0 - cbase;
+    const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
+    roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
+    rw[k] = wt;
+  }
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
   __syncthreads();
+  // ---- the tap loop.  Three operand buffers: tap t multiplies fragments of buffer t % 3, samples tap t + 2 into buffer (t + 2) % 3 and
+  // reads piece 0 of tap t + 1 near its end, so no MFMA waits for an LDS read of its own tap.  A tap is 24 SLOTS (one MFMA each) with
+  // everything else placed by hand between them and fenced with sched_barrier(0): left to the scheduler, the window reads ended up
+  // one by one in front of their uses, behind all 24 MFMAs (see sample_read above).  Fragment registers: piece 0 (slots 0..11), piece
+  // 1 (read in slot 4, used 12..19), piece 2 (read in slot 12, used 20..23), piece 0 of the next tap (read in slot 20) -- never more
+  // than two of the four sets alive.  Window words: two half batches of 4 channels (16 registers), the second requested in slot 4
+  // when the first has been consumed.  Measured on the skeleton of this loop (tools/experiments/tap_pipeline.hip, gen_tap_asm.py):
+  // 2 750 cycles per tap as it was, ~2 100 in this form, 1 500 for the MFMAs alone.
   sample(smem, 0, opbuf);
+  sample(smem, 1, opbuf + SP_OP);
   sp_lds_barrier();
+  uint4 b0[4], b0n[4], b1[4], b2[4];
+  const uint4* fragbase = opbuf + gset * 192 + lane;  // + buffer * SP_OP + (gi * 3 + piece) * 64
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) b0[gi] = fragbase[(gi * 3 + 0) * 64];
+  float raw[4][4], v[8], ra[4], rb[4];
+  uint32_t q1[4], q2[4], q3[4];
+  {
+    const float* wp0 = smem + half * 8 * CP + roff[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* q = wp0 + c * CP;
+      raw[c][0] = q[0];
+      raw[c][1] = q[WRP];
+      raw[c][2] = q[1];
+      raw[c][3] = q[WRP + 1];
+    }
+  }
+  MODE_STAMP(1)
+#define MODE_SB __builtin_amdgcn_sched_barrier(0);
+#define MODE_MF(PA, B, gi) acc[gi] = sp_mfma(acur[PA], B[gi], acc[gi]);
 
   for (int ch = 0; ch < NCH16; ++ch) {
     float* cur = smem + (ch & 1) * SP_WIN;
@@ -1259,53 +1391,109 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const int step = ch * KT + k;
-      const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+      const int nstep = step + 1 < nsteps ? step + 1 : nsteps - 1;
+      const int ks = (k + 2) % KT;                          // the tap that is sampled under this one
+      const float* wsrc = k + 2 < KT ? cur : nxt;           // (taps 0, 1 of the next chunk: its window is complete since tap 5)
+      const uint4* fcur = fragbase + (k % 3) * SP_OP;       // (9 taps per chunk: step % 3 == k % 3)
+      const uint4* fnxt = fragbase + ((k + 1) % 3) * SP_OP;
+      uint4* opw = opbuf + ((k + 2) % 3) * SP_OP + (wave * 3) * 64 + lane;
+      const float4 tw = rw[ks];
+      const float* wp_ = wsrc + half * 8 * CP + roff[ks];
+      // (the first half batch of the NEXT tap's sampling is requested in slot 20 of this one: read at the top of its own tap, the
+      // first combine waited for it right behind the barrier, with both waves of a SIMD in the same place)
+      const float* wpn_ = (k + 3 < KT ? cur : nxt) + half * 8 * CP + roff[(k + 3) % KT];
+      auto words = [&](const float* wp, int hb) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
-      // window of the next chunk: two phases loaded under each of taps 0..3, stored under taps 4..7 (four taps for the loads to land;
-      // the whole window is in LDS at the barrier that ends tap 7)
+        for (int c = 0; c < 4; ++c) {
+          const float* q = wp + (hb * 4 + c) * CP;
+          raw[c][0] = q[0];
+          raw[c][1] = q[WRP];
+          raw[c][2] = q[1];
+          raw[c][3] = q[WRP + 1];
+        }
+      };
+      auto combine = [&](int c) {  // (one fma chain per value, kept scalar: see sp_split2)
+        v[c] = __builtin_fmaf(tw.w, raw[c & 3][3], __builtin_fmaf(tw.z, raw[c & 3][2], __builtin_fmaf(tw.y, raw[c & 3][1], tw.x * raw[c & 3][0])));
+        asm("" : "+v"(v[c]));
+      };
+      auto split_a = [&](int j) {
+        q1[j] = sp_pack2(v[2 * j], v[2 * j + 1]);
+        ra[j] = v[2 * j] - __builtin_bit_cast(float, q1[j] << 16);
+        rb[j] = v[2 * j + 1] - __builtin_bit_cast(float, q1[j] & 0xffff0000u);
+        asm("" : "+v"(ra[j]), "+v"(rb[j]));
+      };
+      auto split_b = [&](int j) {
+        q2[j] = sp_pack2(ra[j], rb[j]);
+        ra[j] = ra[j] - __builtin_bit_cast(float, q2[j] << 16);
+        rb[j] = rb[j] - __builtin_bit_cast(float, q2[j] & 0xffff0000u);
+        asm("" : "+v"(ra[j]), "+v"(rb[j]));
+      };
+      auto split_c = [&](int j) { q3[j] = sp_pack2(ra[j], rb[j]); };
+
+      // top of the tap: weight fragments of the next tap (global), the first half batch of window words
+#pragma unroll
+      for (int p = 0; p < 3; ++p) anxt[p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
+      MODE_SB
+      MODE_MF(2, b0, 0) combine(0); MODE_SB
+      MODE_MF(2, b0, 1) combine(1); MODE_SB
+      MODE_MF(2, b0, 2) combine(2); MODE_SB
+      MODE_MF(2, b0, 3) combine(3); MODE_SB
+      words(wp_, 1);
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) b1[gi] = fcur[(gi * 3 + 1) * 64];
+      MODE_SB
+      MODE_MF(1, b0, 0) split_a(0); MODE_SB
+      MODE_MF(1, b0, 1) split_b(0); MODE_SB
+      MODE_MF(1, b0, 2) split_c(0); split_a(1); MODE_SB
+      MODE_MF(1, b0, 3) split_b(1); MODE_SB
+      MODE_MF(0, b0, 0) split_c(1); combine(4); MODE_SB
+      MODE_MF(0, b0, 1) combine(5); MODE_SB
+      MODE_MF(0, b0, 2) combine(6); MODE_SB
+      MODE_MF(0, b0, 3) combine(7); MODE_SB
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) b2[gi] = fcur[(gi * 3 + 2) * 64];
+      MODE_SB
+      MODE_MF(1, b1, 0) split_a(2); MODE_SB
+      MODE_MF(1, b1, 1) split_b(2); MODE_SB
+      MODE_MF(1, b1, 2) split_c(2); split_a(3); MODE_SB
+      MODE_MF(1, b1, 3) split_b(3); MODE_SB
+      MODE_MF(0, b1, 0) split_c(3); MODE_SB
+      opw[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+      opw[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+      opw[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+      MODE_SB
+      MODE_MF(0, b1, 1) MODE_SB
+      // window of the next chunk: two phases loaded under each of taps 0..3, stored STAGE_LAG taps later (the whole window is in LDS
+      // before tap 7 samples from it)
       if (k < 4) {
         issue(chn, 2 * k, 2 * k);
         issue(chn, 2 * k + 1, 2 * k + 1);
       }
-      // operand of the next tap (of the next chunk after tap 8: its window was complete at the barrier that ended tap 7)
-      const uint4* opr = opbuf + (step & 1) * SP_OP;
-      uint4* opw = opbuf + ((step + 1) & 1) * SP_OP;
-      // (this tap's operand reads come FIRST in program order: the two operand buffers are told apart by a run-time parity, so the
-      // compiler keeps every LDS read behind the stores of sample() -- with the reads behind them the whole tap ran as "sample, then
-      // 24 MFMAs" instead of the MFMAs over the sampling arithmetic)
-      uint4 bq[4][3];
+      MODE_SB
+      MODE_MF(0, b1, 2) MODE_SB
+      MODE_MF(0, b1, 3) MODE_SB
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
+      for (int gi = 0; gi < 4; ++gi) b0n[gi] = fnxt[(gi * 3 + 0) * 64];
+      words(wpn_, 0);
+      MODE_SB
+      MODE_MF(0, b2, 0) MODE_SB
+      if (k >= STAGE_LAG && k < 4 + STAGE_LAG) commit(chn, 2 * (k - STAGE_LAG), 2 * (k - STAGE_LAG), nxt);
+      MODE_SB
+      MODE_MF(0, b2, 1) MODE_SB
+      if (k >= STAGE_LAG && k < 4 + STAGE_LAG) commit(chn, 2 * (k - STAGE_LAG) + 1, 2 * (k - STAGE_LAG) + 1, nxt);
+      MODE_SB
+      MODE_MF(0, b2, 2) MODE_SB
+      MODE_MF(0, b2, 3) MODE_SB
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
-      if (k + 1 < KT)
-        sample(cur, k + 1, opw);
-      else
-        sample(nxt, 0, opw);
-#define MODE_SP_TERM(PA, PB) \
-  _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
-      MODE_SP_TERM(2, 0)
-      MODE_SP_TERM(0, 2)
-      MODE_SP_TERM(1, 1)
-      MODE_SP_TERM(1, 0)
-      MODE_SP_TERM(0, 1)
-      MODE_SP_TERM(0, 0)
-#undef MODE_SP_TERM
-      if (k >= 4 && k < 8) {
-        commit(chn, 2 * (k - 4), 2 * (k - 4), nxt);
-        commit(chn, 2 * (k - 4) + 1, 2 * (k - 4) + 1, nxt);
-      }
+      for (int p = 0; p < 3; ++p) acur[p] = anxt[p];
 #pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int gi = 0; gi < 4; ++gi) b0[gi] = b0n[gi];
       sp_lds_barrier();
     }
   }
+#undef MODE_SB
+#undef MODE_MF
+  MODE_STAMP(2)
 
   // D[i = o][j = pixel of group gset + gi]
   const int hh = h0 + (wave / TW) * 32 + (lane & 31);
@@ -1341,6 +1529,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       if (EPI) __builtin_amdgcn_sched_barrier(0);
     }
   }
+  MODE_STAMP(3)
 }
 
 // =====================================================================================================================
@@ -1816,6 +2005,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_polar_split_kernel(const 
 }
 
 size_t win_lds_bytes(int wr, bool pipe) { return ((size_t)(pipe ? 2 : 1) * CCH * chan_pitch(wr) + wr + 8) * sizeof(float); }
+// the tall tiles of the split forward keep two pair steps of weight fragments (2 x 12 KB) behind their windows
+constexpr size_t TALL_W_BYTES = 2 * (size_t)MTW * 3 * 64 * sizeof(uint4);
+size_t tall_split_lds_bytes(int wr) { return ((win_lds_bytes(wr, true) + 15) / 16) * 16 + TALL_W_BYTES; }
 bool wrap_is_pipelined(int H) { return H + 1 <= WR_PIPE_MAX && win_lds_bytes(H + 1, true) <= 160 * 1024; }
 
 // out[p][w][h] = in[p][h][w] for P planes of H x W: 32x32 tiles through LDS, both sides coalesced
@@ -1983,7 +2175,7 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
     const int4* tl = reinterpret_cast<const int4*>(tiles);
     int n_all = n_small + n_mid + n_wrap;
-    if (n_wrap > 0 && !d.wrap_pipe) {
+    if (n_wrap > 0 && (!d.wrap_pipe || tall_split_lds_bytes(d.wr) > 160 * 1024)) {
       rc = bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi)
               : fwd_win_launch<false>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi);
       if (rc != MODE_OK) return rc;
@@ -1991,9 +2183,9 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
       n_all -= n_wrap;
       n_wrap = 0;
     }
-    size_t lds = SP_LDS_BYTES;
-    if (n_mid > 0) lds = std::max(lds, win_lds_bytes(WR_MID, true));
-    if (n_wrap > 0) lds = std::max(lds, win_lds_bytes(d.wr, true));
+    size_t lds = SP3_LDS_BYTES;
+    if (n_mid > 0) lds = std::max(lds, tall_split_lds_bytes(WR_MID));
+    if (n_wrap > 0) lds = std::max(lds, tall_split_lds_bytes(d.wr));
     if (bn) {
       rc = mode::allow_lds(sphere_fwd_split_kernel<true>, lds, "mode_sphere_conv_fwd_win_split");
       if (rc != MODE_OK) return rc;
@@ -2786,3 +2978,9 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
                      reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2));
   return mode::check_launch(who);
 }
+
+#ifdef MODE_TAPTIME
+extern "C" int mode_debug_taptime(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_taptime), (size_t)n * sizeof(unsigned long long));
+}
+#endif

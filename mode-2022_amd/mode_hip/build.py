@@ -18,6 +18,8 @@ LIB = os.path.join(HERE, 'libmode_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
          '-I' + INCLUDE, '-I' + CSRC]
+# debug builds of the experiments (e.g. MODE_HIP_DEFINES=MODE_TAPTIME for tools/experiments/sphere_taptime.py); never set by the product
+FLAGS += ['-D' + d for d in os.environ.get('MODE_HIP_DEFINES', '').split()]
 
 
 def sources():

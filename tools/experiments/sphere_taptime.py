@@ -1,0 +1,51 @@
+"""Where a small-window workgroup of the spherical forward spends its cycles (debug build: MODE_HIP_DEFINES=MODE_TAPTIME python -m
+mode_hip.build --force).  s_memtime of wave 0 at kernel entry, before the tap loop, after it, at the end; all tiles replaced by
+small-window tiles so that every workgroup is stamped."""
+import ctypes, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, 'mode-2022_amd')):
+  sys.path.insert(0, p)
+import numpy as np
+import torch
+from mode_hip import functional as HF
+from models.basic.spherical_conv.sphere_conv import SphereConv
+dev = torch.device('cuda', 0)
+m = SphereConv(256, 128, 'Cassini', 128, 128, 3, 1, 1).to(dev)
+pos = m.position_on(dev)
+H, W = pos.shape[2:]
+w = m.weight.detach()
+HF.set_conv_arith('bf16x6')
+tiles, (n0, n1, n2) = HF.sphere_plan(pos, 3, 3)[:2]
+t = tiles.cpu().view(-1, 4).clone()
+small = t[n1 + n2:n1 + n2 + n0]
+for i in range(n1 + n2):
+  t[i] = small[i % n0]
+fake = t.view(-1).to(dev)
+lib = HF.lib()
+lib.mode_debug_taptime.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for B, use_fake in ((2, True), (4, True), (2, False)):
+  xt = torch.randn(B, 128, W, H, device=dev)
+  yt = torch.empty_like(xt)
+  wp = torch.empty(lib.mode_sphere_conv_win_wpack_bytes(128, 128, 3, 3, 1) // 4, dtype=torch.float32, device=dev)
+  for _ in range(3):
+    if use_fake:
+      HF._sphere_fwd_win(HF.ptr(xt), pos, w, None, HF.ptr(yt), wp, fake, n0 + n1 + n2, 0, 0, B, 128, H, W, 128, 3, 3, 1, 1, HF.stream_of(xt))
+    else:
+      HF._sphere_fwd_win(HF.ptr(xt), pos, w, None, HF.ptr(yt), wp, tiles, n0, n1, n2, B, 128, H, W, 128, 3, 3, 1, 1, HF.stream_of(xt))
+  torch.cuda.synchronize()
+  n = 128 * B
+  out = np.zeros(4 * 8192, dtype=np.uint64)
+  assert lib.mode_debug_taptime(out.ctypes.data, 4 * 8192) == 0
+  s = out[:4 * n].reshape(n, 4).astype(np.int64)
+  if not use_fake:
+    tall = np.array([i for i in range(n) if (i % 128) < n1 + n2])
+    for nm, sel in (('wrap-around', [i for i in tall if (i % 128) < n2]), ('145-row', [i for i in tall if (i % 128) >= n2])):
+      q = s[sel]
+      print('real plan, %s tiles: prologue %.0f  pair-step loop %.0f = %.0f per step  epilogue %.0f' % (nm, (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 2] - q[:, 1]).mean() / 80, (q[:, 3] - q[:, 2]).mean()))
+    s = s[[i for i in range(n) if (i % 128) >= n1 + n2]]
+    n = s.shape[0]
+  pro, loop, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
+  start = s[:, 0] - s[:, 0].min()
+  print('%d images, %d workgroups: prologue %.0f (%.0f..%.0f)  tap loop %.0f = %.0f per tap (%.0f..%.0f)  epilogue %.0f (%.0f..%.0f) counter ticks; '
+        'workgroup start %.0f..%.0f, end %.0f' % (B, n, pro.mean(), pro.min(), pro.max(), loop.mean(), loop.mean() / 72, loop.min() / 72, loop.max() / 72,
+                                                 epi.mean(), epi.min(), epi.max(), start.min(), start.max(), (s[:, 3] - s[:, 0].min()).max()))
