@@ -2980,7 +2980,13 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
 }
 
 #ifdef MODE_TAPTIME
-extern "C" int mode_debug_taptime(unsigned long long* host_out, int n) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_taptime), (size_t)n * sizeof(unsigned long long));
+namespace {
+__global__ void taptime_copy_kernel(unsigned long long* out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = g_taptime[i];
+}
+}  // namespace
+extern "C" int mode_debug_taptime(unsigned long long* dev_out, int n) {
+  hipLaunchKernelGGL(taptime_copy_kernel, dim3(64), dim3(256), 0, 0, dev_out, n);
+  return (int)hipDeviceSynchronize();
 }
 #endif

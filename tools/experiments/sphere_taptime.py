@@ -34,8 +34,9 @@ for B, use_fake in ((2, True), (4, True), (2, False)):
       HF._sphere_fwd_win(HF.ptr(xt), pos, w, None, HF.ptr(yt), wp, tiles, n0, n1, n2, B, 128, H, W, 128, 3, 3, 1, 1, HF.stream_of(xt))
   torch.cuda.synchronize()
   n = 128 * B
-  out = np.zeros(4 * 8192, dtype=np.uint64)
-  assert lib.mode_debug_taptime(out.ctypes.data, 4 * 8192) == 0
+  dbuf = torch.zeros(4 * 8192, dtype=torch.int64, device=dev)
+  assert lib.mode_debug_taptime(dbuf.data_ptr(), 4 * 8192) == 0
+  out = dbuf.cpu().numpy()
   s = out[:4 * n].reshape(n, 4).astype(np.int64)
   if not use_fake:
     tall = np.array([i for i in range(n) if (i % 128) < n1 + n2])
