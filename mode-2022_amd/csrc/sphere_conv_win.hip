@@ -2566,7 +2566,7 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
                                               const int4* __restrict__ rec_off, const float4* __restrict__ rec_w,
                                               const int2* __restrict__ rec_off2, const float2* __restrict__ rec_w2, float* smem) {
   constexpr int WRP = WR_SMALL, CP = SP_CP;
-  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [2][8 pixel groups][3 pieces][64 lanes]
+  uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [3][8 pixel groups][3 pieces][64 lanes]
   const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
   const int b = blockIdx.y;
   const int g = blockIdx.z / d.MG, mg = blockIdx.z % d.MG;
@@ -2574,23 +2574,36 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   const long long HW = (long long)d.H * d.W;
 
   // records of the pixel this lane SAMPLES (column wave % 4, row block wave / 4, row lane & 31), one (int4, float4) per tap
-  const long long rbase_idx = (long long)blockIdx.x * KT * AJ_PIX + wave * 32 + (lane & 31);
-  const int4* rop = rec_off + rbase_idx;
-  const float4* rwp = rec_w + rbase_idx;
-  const int2* rop2 = rec_off2 + rbase_idx;
-  const float2* rwp2 = rec_w2 + rbase_idx;
-  // the record of the tap sampled in this iteration (o_use) and of the one after it (o_next, requested a tap ahead: L2-resident,
-  // shared by all samples and layers of the geometry)
-  int4 o_use = rop[0], o_next = rop[AJ_PIX];
-  float4 w_use = rwp[0], w_next = rwp[AJ_PIX];
-  int2 o2_use = make_int2(0, 0), o2_next = make_int2(0, 0);
-  float2 w2_use = make_float2(0.f, 0.f), w2_next = make_float2(0.f, 0.f);
-  if (NS == 6) {
-    o2_use = rop2[0];
-    w2_use = rwp2[0];
-    o2_next = rop2[AJ_PIX];
-    w2_next = rwp2[AJ_PIX];
-  }
+  // (uniform bases + one 32-bit lane index: four per-lane 64-bit pointers were 8 registers the six-source tiles do not have)
+  const long long rtile = (long long)blockIdx.x * KT * AJ_PIX;
+  const int4* rop = rec_off + rtile;
+  const float4* rwp = rec_w + rtile;
+  const int2* rop2 = rec_off2 + rtile;
+  const float2* rwp2 = rec_w2 + rtile;
+  const unsigned rlane = wave * 32 + (lane & 31);
+  // records: taps 0 and 1 for the two prologue samples, tap 2 for the first tap of the loop; inside the loop the record of the tap
+  // after the next sampled one is requested at the top of a tap (L2-resident, shared by all samples and layers of the geometry)
+  auto record = [&](int kk, int4& o4, float4& w4, int2& o2, float2& w2) {
+    // (the lane index goes through an opaque asm: otherwise the 9 x 4 per-tap addresses are hoisted out of the tap loop as 64-bit
+    // per-lane pointers -- 72 registers, spilled and reloaded with a full vmcnt(0) in front of every record load)
+    unsigned l = rlane;
+    asm volatile("" : "+v"(l));
+    o4 = rop[kk * AJ_PIX + l];
+    w4 = rwp[kk * AJ_PIX + l];
+    o2 = make_int2(0, 0);
+    w2 = make_float2(0.f, 0.f);
+    if (NS == 6) {
+      o2 = rop2[kk * AJ_PIX + l];
+      w2 = rwp2[kk * AJ_PIX + l];
+    }
+  };
+  int4 o_p0, o_p1, o_use, o_next;
+  float4 w_p0, w_p1, w_use, w_next;
+  int2 o2_p0, o2_p1, o2_use, o2_next;
+  float2 w2_p0, w2_p1, w2_use, w2_next;
+  record(0, o_p0, w_p0, o2_p0, w2_p0);
+  record(1, o_p1, w_p1, o2_p1, w2_p1);
+  record(2, o_use, w_use, o2_use, w2_use);
 
   for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
   __syncthreads();
@@ -2630,12 +2643,24 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   // B fragment of this lane's pixel for one tap: G_k[o][q] for 8 channels o, <= 4 sources each, split, stored as this wave's group
   auto sample = [&](const float* win, const int4 o4, const float4 tw, const int2 o2, const float2 t2, uint4* op) {
     const float* p = win + half * 8 * CP;
-    float v[8];
+    float v[8], r_[8][NS];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float* q = p + c * CP;
-      v[c] = __builtin_fmaf(tw.w, q[o4.w], __builtin_fmaf(tw.z, q[o4.z], __builtin_fmaf(tw.y, q[o4.y], tw.x * q[o4.x])));
-      if (NS == 6) v[c] = __builtin_fmaf(t2.y, q[o2.y], __builtin_fmaf(t2.x, q[o2.x], v[c]));
+      r_[c][0] = q[o4.x];
+      r_[c][1] = q[o4.y];
+      r_[c][2] = q[o4.z];
+      r_[c][3] = q[o4.w];
+      if (NS == 6) {
+        r_[c][4] = q[o2.x];
+        r_[c][5] = q[o2.y];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (all window words requested before the first one is used)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = __builtin_fmaf(tw.w, r_[c][3], __builtin_fmaf(tw.z, r_[c][2], __builtin_fmaf(tw.y, r_[c][1], tw.x * r_[c][0])));
+      if (NS == 6) v[c] = __builtin_fmaf(t2.y, r_[c][NS - 1], __builtin_fmaf(t2.x, r_[c][NS - 2], v[c]));
       asm("" : "+v"(v[c]));  // (keeps the chains of two channels from being SLP-packed pairwise, see sphere_fwd_split_kernel)
     }
     uint32_t q1[4], q2[4], q3[4];
@@ -2655,20 +2680,45 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   const int m = wave % TW, gset = (wave / TW) * 4;
   const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;
   const int nsteps = NCH16 * KT;
-  uint4 aring[3][3];
+  uint4 acur[3], anxt[3];  // weight fragments of this tap and of the next one
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    aring[0][p] = wpa[(unsigned)(p * 64 + lane)];
-    aring[1][p] = (wpa + (long long)(nsteps > 1 ? 1 : 0) * MTW * 192)[(unsigned)(p * 64 + lane)];
-  }
+  for (int p = 0; p < 3; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
 
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) issue(0, ph, ph);
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
   __syncthreads();
-  sample(smem, o_use, w_use, o2_use, w2_use, opbuf);
+  // ---- the tap loop: the slot schedule of sphere_fwd_split_kernel (three operand buffers, sampling two taps ahead, one fragment set
+  // refilled in place, window words in two half batches of 4 channels); here a sample has NS sources at arbitrary window offsets
+  sample(smem, o_p0, w_p0, o2_p0, w2_p0, opbuf);
+  sample(smem, o_p1, w_p1, o2_p1, w2_p1, opbuf + SP_OP);
   sp_lds_barrier();
+  uint4 b0[4], b0n[4], b1[4], b2[4];
+  const uint4* fragbase = opbuf + gset * 192 + lane;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) b0[gi] = fragbase[(gi * 3 + 0) * 64];
+  constexpr int LAG = NS == 6 ? 1 : 2;  // (six-source tiles hold 8 more window words and 8 more record words: one tap less of staging in flight)
+  float raw[4][NS], v[8], ra[4], rb[4];
+  uint32_t q1[4], q2[4], q3[4];
+  auto words = [&](const float* win, const int4 o4, const int2 o2, int hb) {
+    const float* p = win + half * 8 * CP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* q = p + (hb * 4 + c) * CP;
+      raw[c][0] = q[o4.x];
+      raw[c][1] = q[o4.y];
+      raw[c][2] = q[o4.z];
+      raw[c][3] = q[o4.w];
+      if (NS == 6) {
+        raw[c][4] = q[o2.x];
+        raw[c][5] = q[o2.y];
+      }
+    }
+  };
+  words(smem, o_use, o2_use, 0);
+#define MODE_SB __builtin_amdgcn_sched_barrier(0);
+#define MODE_MF(PA, B, gi) acc[gi] = sp_mfma(acur[PA], B[gi], acc[gi]);
 
   for (int ch = 0; ch < NCH16; ++ch) {
     float* cur = smem + (ch & 1) * SP_WIN;
@@ -2677,55 +2727,98 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const int step = ch * KT + k;
-      const int nstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+      const int nstep = step + 1 < nsteps ? step + 1 : nsteps - 1;
+      const float* wsrc = k + 2 < KT ? cur : nxt;           // window of the tap sampled under this one (tap (k + 2) % 9)
+      const float* wsrcn = k + 3 < KT ? cur : nxt;          // ... and of the one sampled under the next tap
+      const uint4* fcur = fragbase + (k % 3) * SP_OP;
+      const uint4* fnxt = fragbase + ((k + 1) % 3) * SP_OP;
+      uint4* opw = opbuf + ((k + 2) % 3) * SP_OP + (wave * 3) * 64 + lane;
+      auto combine = [&](int c) {
+        float t = __builtin_fmaf(w_use.w, raw[c & 3][3], __builtin_fmaf(w_use.z, raw[c & 3][2], __builtin_fmaf(w_use.y, raw[c & 3][1], w_use.x * raw[c & 3][0])));
+        if (NS == 6) t = __builtin_fmaf(w2_use.y, raw[c & 3][NS - 1], __builtin_fmaf(w2_use.x, raw[c & 3][NS - 2], t));
+        v[c] = t;
+        asm("" : "+v"(v[c]));  // (scalar chains: see sp_split2)
+      };
+      auto split_a = [&](int j) {
+        q1[j] = sp_pack2(v[2 * j], v[2 * j + 1]);
+        ra[j] = v[2 * j] - __builtin_bit_cast(float, q1[j] << 16);
+        rb[j] = v[2 * j + 1] - __builtin_bit_cast(float, q1[j] & 0xffff0000u);
+        asm("" : "+v"(ra[j]), "+v"(rb[j]));
+      };
+      auto split_b = [&](int j) {
+        q2[j] = sp_pack2(ra[j], rb[j]);
+        ra[j] = ra[j] - __builtin_bit_cast(float, q2[j] << 16);
+        rb[j] = rb[j] - __builtin_bit_cast(float, q2[j] & 0xffff0000u);
+        asm("" : "+v"(ra[j]), "+v"(rb[j]));
+      };
+      auto split_c = [&](int j) { q3[j] = sp_pack2(ra[j], rb[j]); };
+
 #pragma unroll
-      for (int p = 0; p < 3; ++p) aring[(k + 2) % 3][p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
-      // this iteration samples tap k + 1 with the record requested one iteration ago; the record of tap k + 2 is requested now
-      o_use = o_next;
-      w_use = w_next;
-      o_next = rop[((k + 2) % KT) * AJ_PIX];
-      w_next = rwp[((k + 2) % KT) * AJ_PIX];
-      if (NS == 6) {
-        o2_use = o2_next;
-        w2_use = w2_next;
-        o2_next = rop2[((k + 2) % KT) * AJ_PIX];
-        w2_next = rwp2[((k + 2) % KT) * AJ_PIX];
-      }
+      for (int p = 0; p < 3; ++p) anxt[p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
+      record((k + 3) % KT, o_next, w_next, o2_next, w2_next);
+      MODE_SB
+      MODE_MF(2, b0, 0) combine(0); MODE_SB
+      MODE_MF(2, b0, 1) combine(1); MODE_SB
+      MODE_MF(2, b0, 2) combine(2); MODE_SB
+      MODE_MF(2, b0, 3) combine(3); MODE_SB
+      words(wsrc, o_use, o2_use, 1);
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) b1[gi] = fcur[(gi * 3 + 1) * 64];
+      MODE_SB
+      MODE_MF(1, b0, 0) split_a(0); MODE_SB
+      MODE_MF(1, b0, 1) split_b(0); MODE_SB
+      MODE_MF(1, b0, 2) split_c(0); split_a(1); MODE_SB
+      MODE_MF(1, b0, 3) split_b(1); MODE_SB
+      MODE_MF(0, b0, 0) split_c(1); combine(4); MODE_SB
+      MODE_MF(0, b0, 1) combine(5); MODE_SB
+      MODE_MF(0, b0, 2) combine(6); MODE_SB
+      MODE_MF(0, b0, 3) combine(7); MODE_SB
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) b2[gi] = fcur[(gi * 3 + 2) * 64];
+      MODE_SB
+      MODE_MF(1, b1, 0) split_a(2); MODE_SB
+      MODE_MF(1, b1, 1) split_b(2); MODE_SB
+      MODE_MF(1, b1, 2) split_c(2); split_a(3); MODE_SB
+      MODE_MF(1, b1, 3) split_b(3); MODE_SB
+      MODE_MF(0, b1, 0) split_c(3); MODE_SB
+      opw[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+      opw[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+      opw[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+      MODE_SB
+      MODE_MF(0, b1, 1) MODE_SB
       if (k < 4) {
         issue(chn, 2 * k, 2 * k);
         issue(chn, 2 * k + 1, 2 * k + 1);
       }
-      const uint4* opr = opbuf + (step & 1) * SP_OP;
-      uint4* opw = opbuf + ((step + 1) & 1) * SP_OP;
-      uint4 bq[4][3];
+      MODE_SB
+      MODE_MF(0, b1, 2) MODE_SB
+      MODE_MF(0, b1, 3) MODE_SB
+      // the record of the tap sampled under the NEXT tap becomes current; its first half batch of window words is requested here
+      o_use = o_next;
+      w_use = w_next;
+      o2_use = o2_next;
+      w2_use = w2_next;
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
+      for (int gi = 0; gi < 4; ++gi) b0n[gi] = fnxt[(gi * 3 + 0) * 64];
+      words(wsrcn, o_use, o2_use, 0);
+      MODE_SB
+      MODE_MF(0, b2, 0) MODE_SB
+      if (k >= LAG && k < 4 + LAG) commit(chn, 2 * (k - LAG), 2 * (k - LAG), nxt);  // LAG taps after their loads were issued
+      MODE_SB
+      MODE_MF(0, b2, 1) MODE_SB
+      if (k >= LAG && k < 4 + LAG) commit(chn, 2 * (k - LAG) + 1, 2 * (k - LAG) + 1, nxt);
+      MODE_SB
+      MODE_MF(0, b2, 2) MODE_SB
+      MODE_MF(0, b2, 3) MODE_SB
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[gi][p] = opr[((gset + gi) * 3 + p) * 64 + lane];
-      sample(k + 1 < KT ? cur : nxt, o_use, w_use, o2_use, w2_use, opw);
-#define MODE_SP_TERM(PA, PB) \
-  _Pragma("unroll") for (int gi = 0; gi < 4; ++gi) acc[gi] = sp_mfma(aring[k % 3][PA], bq[gi][PB], acc[gi]);
-      MODE_SP_TERM(2, 0)
-      MODE_SP_TERM(0, 2)
-      MODE_SP_TERM(1, 1)
-      MODE_SP_TERM(1, 0)
-      MODE_SP_TERM(0, 1)
-      MODE_SP_TERM(0, 0)
-#undef MODE_SP_TERM
-      if (k >= 2 && k < 6) {  // two taps after their loads were issued (24 staging registers live at most, not 32)
-        commit(chn, 2 * (k - 2), 2 * (k - 2), nxt);
-        commit(chn, 2 * (k - 2) + 1, 2 * (k - 2) + 1, nxt);
-      }
+      for (int p = 0; p < 3; ++p) acur[p] = anxt[p];
 #pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int gi = 0; gi < 4; ++gi) b0[gi] = b0n[gi];
       sp_lds_barrier();
     }
   }
+#undef MODE_SB
+#undef MODE_MF
 
   // D[i = c][j = pixel of group gset + gi]: written (this kernel owns every element of its tiles)
   const int hh = h0 + (wave / TW) * 32 + (lane & 31);
@@ -2971,9 +3064,9 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
   uint4* wps = reinterpret_cast<uint4*>(wpack);
   const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
   hipLaunchKernelGGL(pack_w_win_split_t, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16);
-  rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP_LDS_BYTES, who);
+  rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP3_LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP_LDS_BYTES, st, gy, wps, gx, d, NCH16,
+  hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP3_LDS_BYTES, st, gy, wps, gx, d, NCH16,
                      reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w),
                      reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2));
   return mode::check_launch(who);
