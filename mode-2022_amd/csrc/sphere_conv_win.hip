@@ -2605,7 +2605,12 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   record(1, o_p1, w_p1, o2_p1, w2_p1);
   record(2, o_use, w_use, o2_use, w2_use);
 
-  for (int i = tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;  // every window word that may be read is finite
+  // every window word that may be read is finite: the staging stores write all rows and columns of both windows; what they never write
+  // is the pad word behind each channel, the slack behind the two buffers, and -- during the first chunk -- the head of the second
+  // window, into which the last channel of the first runs over (all read only under zero weights)
+  if (tid < 2 * SP_CCH) smem[(tid / SP_CCH) * SP_WIN + (tid % SP_CCH) * CP + WC * WRP] = 0.f;
+  if (tid < WRP + 8) smem[SP_WIN + tid] = 0.f;
+  for (int i = 2 * SP_WIN + tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;
   __syncthreads();
 
   // window staging exactly as in sphere_fwd_split_kernel
