@@ -64,6 +64,8 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // replay on the buffer keeps whatever it held (tools/experiments/graph_memset_probe.py; round 4: 3/4 of the stride-2 1x1 input
 // gradient came back as garbage from every replayed training step but the first).  A kernel node replays like any other.
 int fill_words(void* dst, unsigned pattern, size_t nwords, hipStream_t st, const char* what);
+// false after mode_weight_pack_reuse(1) on this thread: the caller's wpack workspace already holds the packed weights
+bool pack_needed();
 inline int zero_floats(float* dst, size_t n, hipStream_t st, const char* what) { return fill_words(dst, 0u, n, st, what); }
 
 }  // namespace mode

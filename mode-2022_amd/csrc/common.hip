@@ -4,6 +4,9 @@
 namespace mode {
 
 static thread_local char g_err[512] = "";
+static thread_local int g_pack_reuse = 0;
+
+bool pack_needed() { return g_pack_reuse == 0; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -44,3 +47,9 @@ int fill_words(void* dst, unsigned pattern, size_t nwords, hipStream_t st, const
 extern "C" int mode_hip_abi_version(void) { return MODE_HIP_ABI_VERSION; }
 
 extern "C" const char* mode_last_error(void) { return mode::g_err; }
+
+extern "C" int mode_weight_pack_reuse(int on) {
+  const int prev = mode::g_pack_reuse;
+  mode::g_pack_reuse = on ? 1 : 0;
+  return prev;
+}

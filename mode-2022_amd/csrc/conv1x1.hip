@@ -160,7 +160,7 @@ int fwd1(const float* x, const float* w, float* y, float* wpack, int B, int Ci, 
   d.Ho = (H - 1) / stride + 1; d.Wo = (W - 1) / stride + 1;
   d.NK4 = mode::cdiv(Ci, 8); d.MT = mode::cdiv(Co, 32);
   const long long npack = (long long)d.MT * d.NK4 * 256;
-  hipLaunchKernelGGL(pack_w1, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Co, Ci, d.MT, d.NK4, 0, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w1, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Co, Ci, d.MT, d.NK4, 0, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   return bn ? launch1<true, false>(x, wpack, y, d, st, epi, who) : launch1<false, false>(x, wpack, y, d, st, epi, who);
@@ -334,7 +334,7 @@ extern "C" int mode_conv1x1_bwd_data(const float* gy, const float* w, float* gx,
   d.Ho = (H - 1) / stride + 1; d.Wo = (W - 1) / stride + 1;
   d.NK4 = mode::cdiv(Co, 8); d.MT = mode::cdiv(Ci, 32);
   const long long npack = (long long)d.MT * d.NK4 * 256;
-  hipLaunchKernelGGL(pack_w1, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Ci, Co, d.MT, d.NK4, 1, 0, mode_bn_epilogue());
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w1, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Ci, Co, d.MT, d.NK4, 1, 0, mode_bn_epilogue());
   const Epi none = make_epi(nullptr, nullptr);
   if (stride == 1) {  // the forward kernel on W^T: the "input" is gy (planes Ho x Wo = H x W)
     return launch1<false, false>(gy, wpack, gx, d, st, none, who);

@@ -239,7 +239,7 @@ int run(const float* x, const float* w, float* y, float* wpack, int B, int K, in
   d.NCHUNK = mode::cdiv(K, CCH);
   const int MT = mode::cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 256;
-  hipLaunchKernelGGL(pack_w2d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w2d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   return dilation == 1 ? dispatch<1>(x, wpack, y, d, MT, st, who, epi) : dispatch<2>(x, wpack, y, d, MT, st, who, epi);

@@ -370,7 +370,7 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
   const int MT = cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
   uint4* wp = reinterpret_cast<uint4*>(wpack);
-  hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   // two output-channel tiles per launch (64 channels); 128-channel layers run as two launches

@@ -293,7 +293,7 @@ int conv3d_s1(const float* x, const float* w, float* y, float* wpack, int B, int
   d.NCHUNK = mode::cdiv(K, CCH);
   MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, flip, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, flip, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   // tile choice: keep >= 2 workgroups per CU worth of tiles if possible
@@ -319,7 +319,7 @@ int conv3d_s2(const float* x, const float* w, float* y, float* wpack, int B, int
   d.NCHUNK = mode::cdiv(K, CCH);
   MODE_REQUIRE(d.MT <= 2, MODE_ERR_UNSUPPORTED, "%s: more than 64 output channels (%d) not supported", who, rows);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 0, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 0, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   if (d.MT == 1) return launch_conv<1, 1, 4, 2>(x, wpack, y, d, st, who, epi);
@@ -514,7 +514,7 @@ int deconv3d(const float* x, const float* w, float* y, float* wpack, int B, int 
   d.MT = mode::cdiv(rows, 32);
   d.NCHUNK = mode::cdiv(K, CCH);
   const long long npack = (long long)d.MT * d.NCHUNK * 27 * 256;
-  hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 2, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, rows, K, d.MT, d.NCHUNK, 2, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   constexpr int TD = 2, TH = 2;

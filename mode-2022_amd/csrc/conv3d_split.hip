@@ -508,7 +508,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.nDt = cdiv(D, TD);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
-  hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
                      d.NCHUNK, flip, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   // 32 output channels per workgroup: the second half of a 64-channel layer stages the input a second time, which at 6 / 16 of the

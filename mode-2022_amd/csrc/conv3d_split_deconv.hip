@@ -346,7 +346,7 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
   d.NCHUNK = cdiv(K, 8);
   d.ntiles = B * D * d.nHt * d.nWt;
   const long long npack = (long long)MTr * d.NCHUNK * NPAIR * 64;
-  hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK);
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK);
   int rc;
   if (MTr == 2) {
     rc = mode::allow_lds(deconv3d_split_kernel<2>, LDS_BYTES, who);

@@ -349,7 +349,7 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
   d.NCHUNK = cdiv(K, 8);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)MT * d.NCHUNK * NPAIR * 64;
-  hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK,
                      bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   constexpr size_t LDS1 = (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 65 536 B: two workgroups per CU

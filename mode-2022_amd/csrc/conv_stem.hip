@@ -206,7 +206,7 @@ int stem_fwd(const float* x, const float* w, float* y, float* wpack, int B, int 
   if (rc != MODE_OK || B == 0) return rc;
   MODE_REQUIRE(x && w && y && wpack, MODE_ERR_BAD_ARG, "%s: null pointer", who);
   const int npack = d.NK4 * 256;
-  hipLaunchKernelGGL(pack_w_stem, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Co, d.KK, d.NK4, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_stem, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, Co, d.KK, d.NK4, bn ? 1 : 0,
                      bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   const float4* wp4 = reinterpret_cast<const float4*>(wpack);

@@ -905,7 +905,7 @@ static int sphere_conv_fwd_impl(const float* x, const float* pos, const float* w
   if (B == 0) return MODE_OK;
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.MT * d.NCHUNK * d.KK * 256;
-  hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_fwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   const size_t lds = (size_t)d.KK * P * 20 + 2 * (size_t)CCH * d.KK * P * 4;
   const dim3 grid(B * d.tps, mode::cdiv(d.MT, 4), d.G);
@@ -938,7 +938,7 @@ extern "C" int mode_sphere_conv_bwd_data(const float* gy, const float* pos, cons
   if (B == 0) return MODE_OK;
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.NB * 4 * d.KSQ * 256;
-  hipLaunchKernelGGL(pack_w_bwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_bwd, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d);
   const size_t lds = (size_t)d.KK * P * 20 + (size_t)d.KSQ * 8 * P * 4;
   rc = mode::allow_lds(sphere_bwd_data_kernel, lds, "mode_sphere_conv_bwd_data (Co/groups too large)");
   if (rc != MODE_OK) return rc;
@@ -1110,7 +1110,7 @@ static int bwd_data_adj_impl(const float* gy, const float* w, float* gx, float* 
   const int MTc = mode::cdiv(d.Cig, 32);
   const int NCHo = mode::cdiv(d.Cog, CCH);
   const long long npack = (long long)d.G * MTc * NCHo * d.KK * 256;
-  hipLaunchKernelGGL(pack_w_adj, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, MTc, NCHo);
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_adj, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, MTc, NCHo);
   const int qtiles = tile_list ? n_list : mode::cdiv((long long)H * W, P);
   const dim3 grid(B * qtiles, mode::cdiv(MTc, 4), d.G);
   if (d.KK == 9) {

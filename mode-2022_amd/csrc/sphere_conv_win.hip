@@ -2157,19 +2157,19 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
   MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "mode_sphere_conv_fwd_win: grid limit");
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
-  hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
   if (split && n_small > 0 && d.Cig % SP_CCH == 0) {
     // small-window tiles (the tail of the tile list) on the split-bf16 kernel, the tall-window classes on the fp32 kernels
     const int NCH16 = d.Cig / SP_CCH;
     uint4* wps = reinterpret_cast<uint4*>(wpack + ((npack + d.Co + 3) / 4) * 4);
     const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
-    hipLaunchKernelGGL(pack_w_win_split, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
+    if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
                        bn ? *bn : mode_bn_epilogue());
     uint4* wpt = wps + nsplit * 3;  // fragments of the tall-window tiles: K = 8 channels x 2 taps
     if (n_mid + n_wrap > 0) {
       const long long ntall = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
-      hipLaunchKernelGGL(pack_w_win_split_tall, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, bn ? 1 : 0,
+      if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split_tall, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, bn ? 1 : 0,
                          bn ? *bn : mode_bn_epilogue());
     }
     // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
@@ -3068,7 +3068,7 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
   const int NCH16 = d.Cig / SP_CCH;
   uint4* wps = reinterpret_cast<uint4*>(wpack);
   const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
-  hipLaunchKernelGGL(pack_w_win_split_t, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16);
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split_t, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16);
   rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP3_LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP3_LDS_BYTES, st, gy, wps, gx, d, NCH16,

@@ -22,6 +22,7 @@ SIGNATURES = {
     'mode_hip_abi_version': (_c_int, []),
     'mode_last_error': (ctypes.c_char_p, []),
     'mode_debug_poison': (_c_int, [ctypes.c_uint, _c_ptr]),
+    'mode_weight_pack_reuse': (_c_int, [_c_int]),
     'mode_sum_n': (_c_int, [_c_ptr] * 5 + [ctypes.c_longlong, _c_ptr]),
     'mode_conv3d_fwd_split_stats_partials': (_c_int, []),
     'mode_conv3d_fwd_split_stats': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
@@ -119,7 +120,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 18  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 19  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

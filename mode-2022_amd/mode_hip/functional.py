@@ -808,13 +808,15 @@ def conv1x1_fwd(x, w, stride=1, bn=None, add=None, relu=False):
   flops = 2 * y.numel() * Ci
   with torch.cuda.device_of(x), profiling.region(_tag1('conv1x1_fwd', Ci, Co, stride, H, W), 4 * (x.numel() // stride**2 + y.numel() + w.numel()),
                                                  flops, x.device):
-    wp = torch.empty(lib().mode_conv1x1_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
     if bn is None:
+      wp = torch.empty(lib().mode_conv1x1_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
       check(lib().mode_conv1x1_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, H, W, Co, stride, stream_of(x)), 'mode_conv1x1_fwd')
     else:
       e, keep = _epilogue(bn, add, relu, y)
-      check(lib().mode_conv1x1_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stride, stream_of(x)),
-            'mode_conv1x1_fwd_bn')
+      wp, reuse = _eval_wpack(bn, 'conv1x1_fwd_bn', w, lib().mode_conv1x1_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv1x1_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stride, stream_of(x)),
+              'mode_conv1x1_fwd_bn')
   return y
 
 
@@ -876,13 +878,15 @@ def conv_stem_fwd(x, w, bn=None, add=None, relu=False):
   y = torch.empty((B, Co, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
   with torch.cuda.device_of(x), profiling.region(_tag1('conv_stem_fwd', Ci, Co, 2, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  2 * y.numel() * Ci * 49, x.device):
-    wp = torch.empty(lib().mode_conv_stem_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
     if bn is None:
+      wp = torch.empty(lib().mode_conv_stem_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
       check(lib().mode_conv_stem_fwd(ptr(x), ptr(w), ptr(y), ptr(wp), B, Ci, H, W, Co, stream_of(x)), 'mode_conv_stem_fwd')
     else:
       e, keep = _epilogue(bn, add, relu, y)
-      check(lib().mode_conv_stem_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stream_of(x)),
-            'mode_conv_stem_fwd_bn')
+      wp, reuse = _eval_wpack(bn, 'conv_stem_fwd_bn', w, lib().mode_conv_stem_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv_stem_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, stream_of(x)),
+              'mode_conv_stem_fwd_bn')
   return y
 
 
@@ -1536,6 +1540,52 @@ def bn_foldable(bn, y_like=None):
           bn.weight.dtype == torch.float32 and not torch.is_grad_enabled())
 
 
+# ------------------------------------------------------------------------------------ packed weights of the eval forward, kept per layer
+# Every forward entry repacks its weights (with the folded BatchNorm scale) into the `wpack` workspace before it runs: 113 small
+# launches, 0.65 ms of the 10.3 ms eval forward at one pair (profiles/r04_eval_b1_kernel_stats.txt).  In eval mode the weights do not
+# change between calls, so the *_bn_eval operators keep the workspace ON THE BatchNorm MODULE of the layer (it dies with the model:
+# no stale hit through a recycled address), keyed on the entry, the arithmetic and (data_ptr, _version) of the weight and of the four
+# BatchNorm tensors -- an optimizer step, load_state_dict or running-statistics update bumps a version and the next call repacks.  On
+# a hit the entry runs under mode_weight_pack_reuse(1) (include/mode_hip.h) and skips its pack kernels.
+EVAL_PACK_CACHE = True
+
+
+class _PackReuse(object):
+
+  def __init__(self, on):
+    self.on = on
+
+  def __enter__(self):
+    if self.on:
+      lib().mode_weight_pack_reuse(1)
+
+  def __exit__(self, *exc):
+    if self.on:
+      lib().mode_weight_pack_reuse(0)
+    return False
+
+
+def _eval_wpack(bn, tag, w, nfloats, device):
+  """(workspace, context manager to run the entry under): a kept workspace + pack reuse on a hit, a fresh one otherwise."""
+  capturing = torch.cuda.is_current_stream_capturing()
+  if not EVAL_PACK_CACHE or bn is None:
+    return torch.empty(nfloats, dtype=torch.float32, device=device), _PackReuse(False)
+  tens = (w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+  key = (tag, CONV_ARITH, nfloats, str(device), tuple(w.shape)) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tens)
+  cache = bn.__dict__.setdefault('_mode_hip_packed', {})
+  wp = cache.get(key)
+  if wp is not None:
+    if capturing:  # a live graph now reads this workspace: it stays for the lifetime of the layer
+      bn.__dict__.setdefault('_mode_hip_packed_pinned', []).append(wp)
+    return wp, _PackReuse(True)
+  wp = torch.empty(nfloats, dtype=torch.float32, device=device)
+  if not capturing:  # (memory of a capture belongs to the graph's pool: not kept)
+    if len(cache) >= 4:
+      cache.clear()
+    cache[key] = wp
+  return wp, _PackReuse(False)
+
+
 def _epilogue(bn, add, relu, out):
   """(ctypes struct, tensors to keep alive): `add` must have the layout of `out`."""
   keep = [bn.weight.detach().contiguous(), bn.bias.detach().contiguous(), bn.running_mean.contiguous(), bn.running_var.contiguous()]
@@ -1562,16 +1612,21 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   flops = 2 * y.numel() * Ci * 27
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
-    wp = _wpack3d(Ci, Co, x.device)
     if stride == 1 and _split3d(Ci, Co, stride, False):
-      check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
-            'mode_conv3d_fwd_split')
+      wp, reuse = _eval_wpack(bn, 'conv3d_fwd_split', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+              'mode_conv3d_fwd_split')
     elif stride == 2 and _split3d(Ci, Co, stride, False) and D * H * W < 2**27:
-      check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
-            'mode_conv3d_fwd_s2_split')
+      wp, reuse = _eval_wpack(bn, 'conv3d_fwd_s2_split', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+              'mode_conv3d_fwd_s2_split')
     else:
-      check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
-            'mode_conv3d_fwd_bn')
+      wp, reuse = _eval_wpack(bn, 'conv3d_fwd_bn s%d' % stride, w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(x)),
+              'mode_conv3d_fwd_bn')
   return y
 
 
@@ -1585,11 +1640,12 @@ def deconv3d_bn_eval(x, w, bn, add=None, relu=False):
   e, keep = _epilogue(bn, add, relu, y)
   flops = 2 * x.numel() * Cout * 27
   with torch.cuda.device_of(x), profiling.region('deconv3d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    wp = _wpack3d(Cin, Cout, x.device)
+    wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
     # (fp32 kernel: the split kernel with this epilogue was measured and is no faster at one pair -- its epilogue walks one pointer per
     # parity class, and the residual's loads cannot be batched behind its stores)
-    check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
-          'mode_deconv3d_fwd_bn')
+    with reuse:
+      check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
+            'mode_deconv3d_fwd_bn')
   return y
 
 
@@ -1605,13 +1661,16 @@ def conv2d_bn_eval(x, w, bn, dilation=1, add=None, relu=False):
   flops = 2 * y.numel() * Ci * 9
   with torch.cuda.device_of(x), profiling.region('conv2d_bn_eval[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
                                                  else 'conv2d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=x.device)
     if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 0) == 1:
-      check(lib().mode_conv2d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
-            'mode_conv2d_fwd_split')
+      wp, reuse = _eval_wpack(bn, 'conv2d_fwd_split', w, lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv2d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
+              'mode_conv2d_fwd_split')
     else:
-      check(lib().mode_conv2d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
-            'mode_conv2d_fwd_bn')
+      wp, reuse = _eval_wpack(bn, 'conv2d_fwd_bn', w, lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, x.device)
+      with reuse:
+        check(lib().mode_conv2d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),
+              'mode_conv2d_fwd_bn')
   return y
 
 
@@ -1647,21 +1706,25 @@ def sphere_conv_bn_eval(x, pos, w, bn, stride, groups, add=None, relu=False, tra
   with torch.cuda.device_of(x), profiling.region(name, 4 * (2 * x.numel() + w.numel()), flops, x.device):
     if plan is not None:
       tiles, (n0, n1, n2) = plan[:2]
-      wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
+      wp, reuse = _eval_wpack(bn, 'sphere_fwd_win g%d %dx%d' % (groups, H, W), w,
+                              lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, w.device)
       if transposed:
         e, keep = _epilogue(bn, add, relu, y)
-        _sphere_fwd_win(ptr(x), pos, w, e, ptr(y), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
+        with reuse:
+          _sphere_fwd_win(ptr(x), pos, w, e, ptr(y), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
       else:  # NCHW caller: the windowed kernel on plane-transposed copies (the residual is transposed with it)
         xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
         e, keep = _epilogue(bn, transpose_planes(add.contiguous()) if add is not None else None, relu, yt)
-        _sphere_fwd_win(ptr(xt), pos, w, e, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
+        with reuse:
+          _sphere_fwd_win(ptr(xt), pos, w, e, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
         y = transpose_planes(yt)
     else:
       y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
       e, keep = _epilogue(bn, add, relu, y)
-      wp = _wpack(w, groups)
-      check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
-                                          stride[1], Ho, Wo, groups, stream_of(x)), 'mode_sphere_conv_fwd_bn')
+      wp, reuse = _eval_wpack(bn, 'sphere_conv_fwd_bn g%d' % groups, w, lib().mode_sphere_conv_wpack_bytes(w.shape[1] * groups, Co, Kh, Kw, groups) // 4, w.device)
+      with reuse:
+        check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
+                                            stride[1], Ho, Wo, groups, stream_of(x)), 'mode_sphere_conv_fwd_bn')
   return y
 
 
@@ -1700,9 +1763,10 @@ def _tabled_bn(x, pos, w, bn, stride, add, relu, Ho, Wo):
   flops = 2 * y.numel() * w[0].numel()
   name = 'sphere_conv_bn_eval[%d->%d %dx%d]' % (Ci, Co, H, W) if profiling.ENABLED else 'sphere_conv_bn_eval'
   with torch.cuda.device_of(x), profiling.region(name, 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    wp = _wpack(w, 1)
-    check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
-                                        stride[1], Ho, Wo, 1, stream_of(x)), 'mode_sphere_conv_fwd_bn')
+    wp, reuse = _eval_wpack(bn, 'sphere_conv_fwd_bn g1', w, lib().mode_sphere_conv_wpack_bytes(w.shape[1], Co, Kh, Kw, 1) // 4, w.device)
+    with reuse:
+      check(lib().mode_sphere_conv_fwd_bn(ptr(x), ptr(pos), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, Kh, Kw, stride[0],
+                                          stride[1], Ho, Wo, 1, stream_of(x)), 'mode_sphere_conv_fwd_bn')
   return y
 
 

@@ -508,3 +508,50 @@ def test_under_nn_dataparallel_like_the_reference_call_sites():
   assert [k for k in dp.state_dict()][0].startswith('module.')  # the prefix loadStackHourglassOnly / load_state_dict callers see
   sd = copy.deepcopy(dp.state_dict())
   models.ModeDisparity(32, 'Sphere', 128, 64, 'Cassini').load_state_dict({k[len('module.'):]: v for k, v in sd.items()})
+
+
+def test_eval_forward_keeps_packed_weights_and_notices_changes(golden, monkeypatch):
+  """Inference keeps the packed weights of a layer on its BatchNorm module (functional._eval_wpack) and skips the pack kernels on later
+  calls: the kept forward equals the repacking one bit for bit, the second call really reuses (mode_weight_pack_reuse), and an
+  in-place change of a weight, of a BatchNorm parameter or a load_state_dict is noticed through the tensors' version counters."""
+  from mode_hip import functional as HF
+  z = golden('model_tiny.npz')
+  net, left, right, _, _ = _setup(z, bn_from_fixture=True)
+  net.eval()
+  uses = {'reuse': 0, 'pack': 0}
+  real = HF._PackReuse
+
+  class Counting(real):
+
+    def __init__(self, on):
+      uses['reuse' if on else 'pack'] += 1
+      real.__init__(self, on)
+
+  monkeypatch.setattr(HF, '_PackReuse', Counting)
+
+  def forward(cache):
+    monkeypatch.setattr(HF, 'EVAL_PACK_CACHE', cache)
+    with torch.no_grad():
+      return net(left, right).clone()
+
+  y_plain = forward(False)
+  uses.update(reuse=0, pack=0)
+  y_first = forward(True)
+  first = dict(uses)
+  y_second = forward(True)
+  calls = first['pack'] + first['reuse']  # (a layer applied twice in one forward already reuses on its second call)
+  assert first['pack'] > 40, first
+  assert uses['pack'] == first['pack'] and uses['reuse'] == first['reuse'] + calls, (first, uses)  # the second pass packed nothing
+  assert torch.equal(y_first, y_plain) and torch.equal(y_second, y_plain)
+  # in-place changes: a convolution weight, a BatchNorm scale, running statistics
+  with torch.no_grad():
+    net.dres2.conv1[0][0].weight.mul_(1.02)
+    net.feature_extraction.firstconv[0][1].weight.add_(0.01)
+    net.dres0[0][1].running_var.mul_(1.1)
+  y_changed = forward(True)
+  assert bool(torch.isfinite(y_changed).all())
+  assert torch.equal(y_changed, forward(False))
+  assert not torch.equal(y_changed, y_plain)
+  # the state loaded again (load_state_dict copies in place: every version moves)
+  net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+  assert torch.equal(forward(True), y_changed)
