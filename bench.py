@@ -368,6 +368,35 @@ def eval_b1_leg(net, left, right, args, steps=20, warmup=3):
     torch.cuda.synchronize()
     ms = 1e3 * (time.time() - t0) / steps
     out = {'workload': 'eval forward, batch 1 (BASELINE configs[1])', 'ms_per_pair': ms, 'pairs_per_s': 1e3 / ms, 'steps': steps, 'launch': launch}
+    # the same forward at the batches that fill the chip: ms per PAIR at 2 and 4 pairs per call says how much of the
+    # one-pair time is under-filled launches (one pair = 2 images: half the workgroups of a training launch)
+    fill = {'1': round(ms, 3)}
+    for nb in (2, 4):
+      try:
+        lb, rb = torch.cat([left] * nb)[:nb].contiguous(), torch.cat([right] * nb)[:nb].contiguous()
+
+        def fwd_nb():
+          with torch.no_grad():
+            return net(lb, rb)
+
+        for _ in range(2):
+          fwd_nb()
+        torch.cuda.synchronize()
+        try:
+          run_nb = GraphedStep(fwd_nb, (lb, rb), warmup=1).replay
+        except Exception:
+          run_nb = fwd_nb
+        run_nb()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(8):
+          run_nb()
+        torch.cuda.synchronize()
+        fill[str(nb)] = round(1e3 * (time.time() - t0) / 8 / nb, 3)
+        del lb, rb
+      except Exception as e:  # (memory: a 4-pair eval forward needs ~9 GB)
+        fill[str(nb)] = 'failed: %s' % str(e)[:80]
+    out['ms_per_pair_at_batch'] = fill
     if not args.no_kernel_timing:
       profiling.enable(True)
       for _ in range(2):

@@ -894,10 +894,12 @@ __global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __rest
 
 #ifdef MODE_TAPTIME
 // debug build only (tools/experiments/sphere_taptime.py): s_memtime stamps of wave 0 of every small-window workgroup
-__device__ unsigned long long g_taptime[4 * 8192];
-#define MODE_STAMP(j) if (threadIdx.x == 0) g_taptime[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 4 + (j)] = __builtin_readcyclecounter();
+__device__ unsigned long long g_taptime[8 * 8192];
+#define MODE_STAMP(j) if (threadIdx.x == 0) g_taptime[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (j)] = __builtin_readcyclecounter();
+#define MODE_STAMPV(j, v) if (threadIdx.x == 0) g_taptime[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (j)] = (v);
 #else
 #define MODE_STAMP(j)
+#define MODE_STAMPV(j, v)
 #endif
 // Template parameters as fwd_tile (window rows, double-buffered staging in NPH phases of NRB row passes).
 template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI>
@@ -1012,12 +1014,12 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   wfetch(0);
 
   // the 8 channel values of this lane's (pixel, tap) for pair p: 32 window words, then 4 FMAs each and the split
-  float raw[32], v[8], ra[4], rb[4];
+  float raw[16], v[8], ra[4], rb[4];  // window words of HALF a sample set (4 channels), requested in two batches per step
   uint32_t q1[4], q2[4], q3[4];
-  auto load_raw = [&](const float* buf, int p) {
-    const float* q0 = buf + roff[p];
+  auto load_half = [&](const float* buf, int p, int hb) {
+    const float* q0 = buf + roff[p] + hb * 4 * CP;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 4; ++c) {
       const float* q = q0 + c * CP;
       raw[c * 4 + 0] = q[0];
       raw[c * 4 + 1] = q[WRP];
@@ -1027,7 +1029,8 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   };
   auto comb = [&](int p, int c) {  // (one scalar chain per value: see sphere_fwd_split_kernel)
     const float4 tw = rw[p];
-    v[c] = __builtin_fmaf(tw.w, raw[c * 4 + 3], __builtin_fmaf(tw.z, raw[c * 4 + 2], __builtin_fmaf(tw.y, raw[c * 4 + 1], tw.x * raw[c * 4])));
+    const int r = (c & 3) * 4;
+    v[c] = __builtin_fmaf(tw.w, raw[r + 3], __builtin_fmaf(tw.z, raw[r + 2], __builtin_fmaf(tw.y, raw[r + 1], tw.x * raw[r])));
     asm("" : "+v"(v[c]));
   };
   auto split_a = [&](int j) {
@@ -1061,9 +1064,12 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   // B fragment of the first pair of the first chunk; every later one is built under the MFMAs of the step before it -- the first pair
   // of a chunk too: the last phase of the next chunk's window is stored in the FIRST half of the chunk's last step, so that window is
   // complete at that step's barrier and its second half can sample from it (no chunk-top sampling, no barrier at the chunk end)
-  load_raw(smem, 0);
+  load_half(smem, 0, 0);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) comb(0, c);
+  for (int c = 0; c < 4; ++c) comb(0, c);
+  load_half(smem, 0, 1);
+#pragma unroll
+  for (int c = 4; c < 8; ++c) comb(0, c);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     split_a(j);
@@ -1073,9 +1079,13 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
   bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
   bq[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+  load_half(smem, 1, 0);  // first half batch of the fragment built under step 0
   MODE_STAMP(1)
 #define MODE_SB __builtin_amdgcn_sched_barrier(0);
 #define MODE_TMF(PA, PB, m, t) acc[t] = sp_mfma(a_cur[m][PA], bq[PB], acc[t]);
+#ifdef MODE_TAPTIME
+  unsigned long long tt_top = 0, tt_pre = 0, tt_post = __builtin_readcyclecounter(), ts_a = 0, ts_b = 0, ts_c = 0;
+#endif
   for (int ch = 0; ch < d.NCH; ++ch) {
     float* cur = smem + (ch & 1) * bufsz;
     float* nxt = smem + ((ch + 1) & 1) * bufsz;
@@ -1086,51 +1096,69 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       const uint4* wcur = wbuf + (step & 1) * WSTEP + lane;
       const uint4* wnx = wbuf + ((step + 1) & 1) * WSTEP + lane;
       const int pn = p + 1 < TP ? p + 1 : 0;  // the pair whose B fragment is built under this step (pair 0 of the next chunk under the last)
-      // ---- first half: output tiles 0, 1
+      // ---- first half: output tiles 0, 1.  LDS traffic is spread over the slots (requested in one batch at the top, the 24 reads and
+      // stores of the 8 waves backed up in front of the first MFMA: 1 650 cycles for this half against 930 for the other)
+#ifdef MODE_TAPTIME
+      tt_top = __builtin_readcyclecounter();
+#endif
+      MODE_SB
+      MODE_TMF(2, 0, 0, 0) if (p + 1 < TP) comb(pn, 0); MODE_SB
+      MODE_TMF(2, 0, 1, 1) if (p + 1 < TP) comb(pn, 1); MODE_SB
+      MODE_TMF(0, 2, 0, 0) if (p + 1 < TP) comb(pn, 2); wstore(step + 1); MODE_SB
+      MODE_TMF(0, 2, 1, 1) if (p + 1 < TP) comb(pn, 3); wfetch(step + 2); MODE_SB
+      if (p + 1 < TP) load_half(cur, pn, 1);
       if (p % PPP == 0 && p / PPP < NPH && more) issue(ch + 1, p / PPP);  // rows of the next chunk fly under the MFMAs below
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a_nxt[m][q] = wcur[((2 + m) * 3 + q) * 64];
-      wstore(step + 1);
-      if (p + 1 < TP) load_raw(cur, pn);
       if (p == TP - 1 && more) commit(ch + 1, NPH - 1, nxt);  // (its loads were requested a step ago)
       MODE_SB
-      MODE_TMF(2, 0, 0, 0) MODE_SB
-      MODE_TMF(2, 0, 1, 1) MODE_SB
-      MODE_TMF(0, 2, 0, 0) MODE_SB
-      MODE_TMF(0, 2, 1, 1) MODE_SB
-      MODE_TMF(1, 1, 0, 0) if (p + 1 < TP) comb(pn, 0); MODE_SB
-      MODE_TMF(1, 1, 1, 1) if (p + 1 < TP) comb(pn, 1); MODE_SB
-      MODE_TMF(1, 0, 0, 0) if (p + 1 < TP) comb(pn, 2); MODE_SB
-      MODE_TMF(1, 0, 1, 1) if (p + 1 < TP) comb(pn, 3); MODE_SB
-      MODE_TMF(0, 1, 0, 0) if (p + 1 < TP) comb(pn, 4); MODE_SB
-      MODE_TMF(0, 1, 1, 1) if (p + 1 < TP) comb(pn, 5); MODE_SB
-      MODE_TMF(0, 0, 0, 0) if (p + 1 < TP) comb(pn, 6); MODE_SB
-      MODE_TMF(0, 0, 1, 1) if (p + 1 < TP) comb(pn, 7); MODE_SB
+      MODE_TMF(1, 1, 0, 0) MODE_SB
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a_nxt[0][q] = wcur[((2 + 0) * 3 + q) * 64];
+      MODE_SB
+      MODE_TMF(1, 1, 1, 1) MODE_SB
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a_nxt[1][q] = wcur[((2 + 1) * 3 + q) * 64];
+      MODE_SB
+      MODE_TMF(1, 0, 0, 0) if (p + 1 < TP) comb(pn, 4); MODE_SB
+      MODE_TMF(1, 0, 1, 1) if (p + 1 < TP) comb(pn, 5); MODE_SB
+      MODE_TMF(0, 1, 0, 0) if (p + 1 < TP) comb(pn, 6); MODE_SB
+      MODE_TMF(0, 1, 1, 1) if (p + 1 < TP) comb(pn, 7); MODE_SB
+      MODE_TMF(0, 0, 0, 0) MODE_SB
+      MODE_TMF(0, 0, 1, 1) MODE_SB
+#ifdef MODE_TAPTIME
+      tt_pre = __builtin_readcyclecounter();
+#endif
       sp_lds_barrier();  // the weights of step + 1 are in LDS
+#ifdef MODE_TAPTIME
+      ts_c += tt_top - tt_post;  // second half of the previous step
+      tt_post = __builtin_readcyclecounter();
+      ts_a += tt_pre - tt_top;
+      ts_b += tt_post - tt_pre;
+#endif
       // ---- second half: output tiles 2, 3
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a_nxt[m][q] = wnx[(m * 3 + q) * 64];
-      wfetch(step + 2);
-      if (p + 1 == TP) load_raw(more ? nxt : cur, 0);  // (after the last chunk: any finite words, the fragment is not used)
+      if (p + 1 == TP) load_half(more ? nxt : cur, 0, 0);  // (after the last chunk: any finite words, the fragment is not used)
       MODE_SB
       if (p + 1 < TP) {
         MODE_TMF(2, 0, 0, 2) split_a(0); MODE_SB
         MODE_TMF(2, 0, 1, 3) split_b(0); MODE_SB
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_nxt[0][q] = wnx[(0 * 3 + q) * 64];
+        MODE_SB
         MODE_TMF(0, 2, 0, 2) split_c(0); split_a(1); MODE_SB
         MODE_TMF(0, 2, 1, 3) split_b(1); MODE_SB
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_nxt[1][q] = wnx[(1 * 3 + q) * 64];
+        MODE_SB
         MODE_TMF(1, 1, 0, 2) split_c(1); split_a(2); MODE_SB
         MODE_TMF(1, 1, 1, 3) split_b(2); MODE_SB
         MODE_TMF(1, 0, 0, 2) split_c(2); split_a(3); MODE_SB
         MODE_TMF(1, 0, 1, 3) split_b(3); MODE_SB
         MODE_TMF(0, 1, 0, 2) split_c(3); MODE_SB
+        if (p + 2 < TP) load_half(cur, p + 2, 0);  // first half batch of the fragment built under the next step
+        MODE_SB
         MODE_TMF(0, 1, 1, 3) MODE_SB
         MODE_TMF(0, 0, 0, 2) MODE_SB
         MODE_TMF(0, 0, 1, 3) MODE_SB
@@ -1139,14 +1167,23 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
         MODE_TMF(2, 0, 1, 3) MODE_SB
         MODE_TMF(0, 2, 0, 2) comb(0, 0); comb(0, 1); MODE_SB
         MODE_TMF(0, 2, 1, 3) comb(0, 2); comb(0, 3); MODE_SB
-        MODE_TMF(1, 1, 0, 2) comb(0, 4); comb(0, 5); MODE_SB
-        MODE_TMF(1, 1, 1, 3) comb(0, 6); comb(0, 7); MODE_SB
-        MODE_TMF(1, 0, 0, 2) split_a(0); split_a(1); MODE_SB
-        MODE_TMF(1, 0, 1, 3) split_b(0); split_b(1); MODE_SB
-        MODE_TMF(0, 1, 0, 2) split_c(0); split_c(1); split_a(2); MODE_SB
-        MODE_TMF(0, 1, 1, 3) split_a(3); split_b(2); MODE_SB
-        MODE_TMF(0, 0, 0, 2) split_b(3); MODE_SB
-        MODE_TMF(0, 0, 1, 3) split_c(2); split_c(3); MODE_SB
+        load_half(more ? nxt : cur, 0, 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_nxt[0][q] = wnx[(0 * 3 + q) * 64];
+        MODE_SB
+        MODE_TMF(1, 1, 0, 2) MODE_SB
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_nxt[1][q] = wnx[(1 * 3 + q) * 64];
+        MODE_SB
+        MODE_TMF(1, 1, 1, 3) MODE_SB
+        MODE_TMF(1, 0, 0, 2) comb(0, 4); comb(0, 5); MODE_SB
+        MODE_TMF(1, 0, 1, 3) comb(0, 6); comb(0, 7); MODE_SB
+        load_half(more ? nxt : cur, 1, 0);  // (the fragment built under the next chunk's first step)
+        MODE_SB
+        MODE_TMF(0, 1, 0, 2) split_a(0); split_a(1); split_a(2); MODE_SB
+        MODE_TMF(0, 1, 1, 3) split_a(3); split_b(0); split_b(1); MODE_SB
+        MODE_TMF(0, 0, 0, 2) split_b(2); split_b(3); split_c(0); MODE_SB
+        MODE_TMF(0, 0, 1, 3) split_c(1); split_c(2); split_c(3); MODE_SB
       }
       if (more && p < TP - 1 && p % PPP == PPP - 1 && p / PPP < NPH - 1) commit(ch + 1, p / PPP, nxt);  // the other buffer: nobody reads it now
 #pragma unroll
@@ -1161,6 +1198,11 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
 #undef MODE_SB
 #undef MODE_TMF
   MODE_STAMP(2)
+#ifdef MODE_TAPTIME
+  MODE_STAMPV(4, ts_a)
+  MODE_STAMPV(5, ts_b)
+  MODE_STAMPV(6, ts_c)
+#endif
 
   if (pix_ok) {
     float* yb = y + ((long long)b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW + (long long)h * d.sh + (long long)w * d.sw;

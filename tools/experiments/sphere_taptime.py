@@ -34,14 +34,17 @@ for B, use_fake in ((2, True), (4, True), (2, False)):
       HF._sphere_fwd_win(HF.ptr(xt), pos, w, None, HF.ptr(yt), wp, tiles, n0, n1, n2, B, 128, H, W, 128, 3, 3, 1, 1, HF.stream_of(xt))
   torch.cuda.synchronize()
   n = 128 * B
-  dbuf = torch.zeros(4 * 8192, dtype=torch.int64, device=dev)
-  assert lib.mode_debug_taptime(dbuf.data_ptr(), 4 * 8192) == 0
+  dbuf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
+  assert lib.mode_debug_taptime(dbuf.data_ptr(), 8 * 8192) == 0
   out = dbuf.cpu().numpy()
-  s = out[:4 * n].reshape(n, 4).astype(np.int64)
+  full = out[:8 * n].reshape(n, 8).astype(np.int64)
+  s = full[:, :4]
   if not use_fake:
     tall = np.array([i for i in range(n) if (i % 128) < n1 + n2])
     for nm, sel in (('wrap-around', [i for i in tall if (i % 128) < n2]), ('145-row', [i for i in tall if (i % 128) >= n2])):
       q = s[sel]
+      f = full[sel]
+      print('   per step: first half %.0f, barrier %.0f, second half %.0f' % (f[:, 4].mean() / 80, f[:, 5].mean() / 80, f[:, 6].mean() / 80))
       print('real plan, %s tiles: prologue %.0f  pair-step loop %.0f = %.0f per step  epilogue %.0f' % (nm, (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 2] - q[:, 1]).mean() / 80, (q[:, 3] - q[:, 2]).mean()))
     s = s[[i for i in range(n) if (i % 128) >= n1 + n2]]
     n = s.shape[0]
