@@ -1718,11 +1718,21 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
   // may-aliasing LDS accesses in program order -- an explicit s_waitcnt here would pin the whole sample in front of the MFMAs.
   auto sample = [&](const float* xw, const float4 w4, const int ro, uint4 (&bf)[3]) {
     const float* xb = xw + (8 * sq) * CP + ro;
-    float v[8];
+    float v[8], r_[8][4];
+    // (all 32 window words requested before the first is used: as one loop the compiler issued every read right in front of its
+    // use -- 16 serialised LDS round trips per sample, three samples per column; see sphere_fwd_split_kernel::sample_read)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float* q = xb + c * CP;
-      v[c] = __builtin_fmaf(w4.w, q[WRP + 1], __builtin_fmaf(w4.z, q[1], __builtin_fmaf(w4.y, q[WRP], w4.x * q[0])));
+      r_[c][0] = q[0];
+      r_[c][1] = q[WRP];
+      r_[c][2] = q[1];
+      r_[c][3] = q[WRP + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = __builtin_fmaf(w4.w, r_[c][3], __builtin_fmaf(w4.z, r_[c][2], __builtin_fmaf(w4.y, r_[c][1], w4.x * r_[c][0])));
       asm("" : "+v"(v[c]));
     }
     float* sw = scr + (8 * sq) * BS_SCRP + 8 * sh + sp8;
