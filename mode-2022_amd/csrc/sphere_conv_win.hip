@@ -1283,7 +1283,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   if (tid < 2 * SP_CCH) smem[(tid / SP_CCH) * SP_WIN + (tid % SP_CCH) * CP + WC * WRP] = 0.f;
   if (tid < WRP + 8) smem[SP_WIN + tid] = 0.f;  // (the last channel of the first window runs over into the second, which is empty during the first chunk)
   for (int i = 2 * SP_WIN + tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;
-  __syncthreads();
+  // (no barrier here: it would drain the table loads above before the first window is even requested -- 9 k of a workgroup's 190 k
+  // cycles.  The only words both this fill and the staging stores below write are slack words, where either value will do; the barrier
+  // behind the staging stores orders everything in front of the first sample)
+  MODE_STAMP(4)
 
   // window staging: thread -> (window column, row within a pass of SROWS rows), as in fwd_tile; 2 passes cover the 81 rows
   const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;
@@ -1391,9 +1394,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
     rw[k] = wt;
   }
+  MODE_STAMP(5)
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) commit(0, ph, ph, smem);
   __syncthreads();
+  MODE_STAMP(6)
   // ---- the tap loop.  Three operand buffers: tap t multiplies fragments of buffer t % 3, samples tap t + 2 into buffer (t + 2) % 3 and
   // reads piece 0 of tap t + 1 near its end, so no MFMA waits for an LDS read of its own tap.  A tap is 24 SLOTS (one MFMA each) with
   // everything else placed by hand between them and fenced with sched_barrier(0): left to the scheduler, the window reads ended up
@@ -2663,7 +2668,7 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   if (tid < 2 * SP_CCH) smem[(tid / SP_CCH) * SP_WIN + (tid % SP_CCH) * CP + WC * WRP] = 0.f;
   if (tid < WRP + 8) smem[SP_WIN + tid] = 0.f;
   for (int i = 2 * SP_WIN + tid; i < SP_WIN_FLOATS; i += NTHREADS) smem[i] = 0.f;
-  __syncthreads();
+  // (no barrier: see sphere_fwd_split_kernel -- the one behind the first window's stores is enough)
 
   // window staging exactly as in sphere_fwd_split_kernel
   const int scol = d.sh == 1 ? tid / SROWS : tid & (WC - 1), srow = d.sh == 1 ? tid % SROWS : tid / WC;

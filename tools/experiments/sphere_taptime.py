@@ -49,6 +49,8 @@ for B, use_fake in ((2, True), (4, True), (2, False)):
     s = s[[i for i in range(n) if (i % 128) >= n1 + n2]]
     n = s.shape[0]
   pro, loop, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
+  sm = full[[i for i in range(full.shape[0]) if use_fake or (i % 128) >= n1 + n2]] if full.shape[0] != s.shape[0] else full
+  print('   prologue of a small-window workgroup: entry -> zero fill + barrier %.0f, -> first window requested + records %.0f, -> window stored + barrier %.0f, -> two samples, first fragments %.0f' % ((sm[:, 4] - sm[:, 0]).mean(), (sm[:, 5] - sm[:, 4]).mean(), (sm[:, 6] - sm[:, 5]).mean(), (sm[:, 1] - sm[:, 6]).mean()))
   start = s[:, 0] - s[:, 0].min()
   print('%d images, %d workgroups: prologue %.0f (%.0f..%.0f)  tap loop %.0f = %.0f per tap (%.0f..%.0f)  epilogue %.0f (%.0f..%.0f) counter ticks; '
         'workgroup start %.0f..%.0f, end %.0f' % (B, n, pro.mean(), pro.min(), pro.max(), loop.mean(), loop.mean() / 72, loop.min() / 72, loop.max() / 72,
