@@ -43,7 +43,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [8] 
 // per-call BatchNorm statistics: two groups.
 // grid = (nsplit, C, G).  partial[((g*C + c)*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
 __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int B, int C,
-                                                      long long S, int nsplit, int rev) {
+                                                      long long S, int nsplit) {
   __shared__ float sh[8];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
@@ -54,8 +54,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   // (torch / MIOpen use Welford; with K inside the data range the shifted form is as accurate and stays a single pass).
   const float K = y[((long long)b0 * C + c) * S];
   float s0 = 0.f, s1 = 0.f;
-  for (int bi = 0; bi < Bg; ++bi) {
-    const int b = rev ? b0 + Bg - 1 - bi : b0 + bi;
+  for (int b = b0; b < b0 + Bg; ++b) {
     const float4* p = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * S);
     // four independent loads per iteration (see bn_apply_kernel); the sums are taken in the same order as element by element
     auto acc1 = [&](const float4& v) {
@@ -145,10 +144,10 @@ struct BnCoefArgs {
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
 template <bool RELU, bool ADD, bool TRAIN>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add, BnCoefArgs k,
-                                                      float* __restrict__ out, int C, long long S, int rev) {
+                                                      float* __restrict__ out, int C, long long S) {
   __shared__ double shd[8];
   __shared__ float coef[2];
-  const int bc = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+  const int bc = blockIdx.y;
   const int c = bc % C;
   if (TRAIN) {
     const int b = bc / C, g = b / k.Bg;
@@ -246,7 +245,7 @@ template <int RELU>
 __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ gout, const float* __restrict__ y,
                                                           const float* __restrict__ out, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, float* __restrict__ partial, int B, int C,
-                                                          long long S, int nsplit, int rev) {
+                                                          long long S, int nsplit) {
   __shared__ float sh[8];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
@@ -254,8 +253,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
   const float msc = RELU == 2 ? mscale[prow] : 0.f, msh = RELU == 2 ? mshift[prow] : 0.f;
   const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   float s0 = 0.f, s1 = 0.f;
-  for (int bi = 0; bi < Bg; ++bi) {
-    const int b = rev ? b0 + Bg - 1 - bi : b0 + bi;
+  for (int b = b0; b < b0 + Bg; ++b) {
     const long long base = ((long long)b * C + c) * S;
     const float4* gp = reinterpret_cast<const float4*>(gout + base);
     const float4* yp = reinterpret_cast<const float4*>(y + base);
@@ -316,10 +314,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ save_invstd, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int accumulate, int nsplit, double count,
                                                           int groups, int Bg, float* __restrict__ gy, float* __restrict__ gadd, int C,
-                                                          long long S, int rev) {
+                                                          long long S) {
   __shared__ double shd[8];
   __shared__ float coef[3];
-  const int bc = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+  const int bc = blockIdx.y;
   const int c = bc % C;
   const int grp = (bc / C) / Bg;
   {
@@ -433,12 +431,6 @@ int check_bn(int B, int C, long long S, const char* who) {
   return MODE_OK;
 }
 
-// EXPERIMENT (MODE_BN_ORDER bit mask): bit 0 statistics pass samples descending, 1 apply rows descending, 2 / 3 the same backward
-int bn_order() {
-  static const int v = getenv("MODE_BN_ORDER") ? atoi(getenv("MODE_BN_ORDER")) : 0;
-  return v;
-}
-
 template <typename K, typename... Args>
 int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who, Args... args) {
   hipLaunchKernelGGL(kernel, dim3(apply_chunks(BC, S), BC), dim3(NT), 0, st, args...);
@@ -491,18 +483,18 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   MODE_REQUIRE(out != y, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: in-place operation (out == y) is not supported");
   hipStream_t st = mode::as_stream(stream);
   const int nsplit = prestats > 0 ? prestats : pick_nsplit(C * groups, S);
-  if (prestats <= 0) hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit, bn_order() & 1);
+  if (prestats <= 0) hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit,
                (double)(B / groups) * (double)S, groups, B / groups, prestats > 0 ? workspace + 2LL * C * nsplit : nullptr};
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
   if (relu) {
-    if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S, (bn_order() >> 1) & 1);
-    return launch_apply(bn_apply_kernel<true, false, true>, BC, S, st, who, y, y, k, out, C, S, (bn_order() >> 1) & 1);
+    if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false, true>, BC, S, st, who, y, y, k, out, C, S);
   }
-  if (add) return launch_apply(bn_apply_kernel<false, true, true>, BC, S, st, who, y, add, k, out, C, S, (bn_order() >> 1) & 1);
-  return launch_apply(bn_apply_kernel<false, false, true>, BC, S, st, who, y, y, k, out, C, S, (bn_order() >> 1) & 1);
+  if (add) return launch_apply(bn_apply_kernel<false, true, true>, BC, S, st, who, y, add, k, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false, true>, BC, S, st, who, y, y, k, out, C, S);
 }
 
 extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
@@ -520,11 +512,11 @@ extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* g
   const int BC = B * C;
   const char* who = "mode_bn_eval_fwd";
   if (relu) {
-    if (add) return launch_apply(bn_apply_kernel<true, true, false>, BC, S, st, who, y, add, k, out, C, S, 0);
-    return launch_apply(bn_apply_kernel<true, false, false>, BC, S, st, who, y, y, k, out, C, S, 0);
+    if (add) return launch_apply(bn_apply_kernel<true, true, false>, BC, S, st, who, y, add, k, out, C, S);
+    return launch_apply(bn_apply_kernel<true, false, false>, BC, S, st, who, y, y, k, out, C, S);
   }
-  if (add) return launch_apply(bn_apply_kernel<false, true, false>, BC, S, st, who, y, add, k, out, C, S, 0);
-  return launch_apply(bn_apply_kernel<false, false, false>, BC, S, st, who, y, y, k, out, C, S, 0);
+  if (add) return launch_apply(bn_apply_kernel<false, true, false>, BC, S, st, who, y, add, k, out, C, S);
+  return launch_apply(bn_apply_kernel<false, false, false>, BC, S, st, who, y, y, k, out, C, S);
 }
 
 extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
@@ -550,17 +542,17 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   const int mode = !relu ? 0 : (out ? 1 : 2);
   const float* o = out ? out : y;
   if (mode == 0)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, (bn_order() >> 2) & 1);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   else if (mode == 1)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, (bn_order() >> 2) & 1);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   else
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, (bn_order() >> 2) & 1);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
   const double count = (double)(B / groups) * (double)S;
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
   launch_apply(bn_bwd_apply_kernel<M, G>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean, save_invstd, ggamma, \
-               gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S, (bn_order() >> 3) & 1)
+               gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S)
   if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
   if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
   return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);
