@@ -69,7 +69,7 @@ int mode_debug_poison(unsigned pattern, mode_stream_t stream);
 
 /* Inference with fixed weights (no reference counterpart: the reference re-reads its weights on every call, test_disparity.py:136).
  * Every forward entry that takes a `wpack` workspace first launches a small kernel that repacks the weights (with the folded
- * BatchNorm scale) into it -- 113 launches, 0.65 ms of an 10.3 ms eval forward at one pair.  After mode_weight_pack_reuse(1) those
+ * BatchNorm scale) into it -- 113 launches, 0.65 ms of a 10.3 ms eval forward at one pair.  After mode_weight_pack_reuse(1) those
  * entries SKIP the repacking on the calling thread and use `wpack` as it is: the caller guarantees that it still holds what the same
  * entry wrote for the same weights, BatchNorm parameters and shapes (mode_hip.functional keeps such workspaces per layer and keys
  * them on the tensors' versions).  mode_weight_pack_reuse(0) restores the default.  Returns the previous setting. */
