@@ -104,15 +104,18 @@ def test_step_does_not_depend_on_inherited_lds_or_registers(maxdisp, H, W, keep,
     assert loss == ref[3]
 
 
-def test_repeated_steps_with_a_second_process_on_the_gpu_are_bit_identical():
+@pytest.mark.parametrize('size,steps', [((32, 128, 64), 30), ((192, 1024, 512), 12)])
+def test_repeated_steps_with_a_second_process_on_the_gpu_are_bit_identical(size, steps):
   """tools/determinism_hunt.py: two ranks share the GPU and each repeats the traced eager step and replays its hipGraph; every repeat
-  must reproduce the first step's per-operator trace and flat gradient bit for bit."""
+  must reproduce the first step's per-operator trace and flat gradient bit for bit.  At the tiny size (general gather kernels, ragged
+  tiles) and at the benchmark size (the windowed, hand-scheduled kernels of DESIGN 3o; polar tiles; adjoint plans)."""
   env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-  cmd = [sys.executable, os.path.join(ROOT, 'tools', 'determinism_hunt.py'), 'run', '--ranks', '2', '--steps', '30', '--replays', '30']
+  cmd = [sys.executable, os.path.join(ROOT, 'tools', 'determinism_hunt.py'), 'run', '--ranks', '2', '--steps', str(steps), '--replays', str(steps),
+         '--maxdisp', str(size[0]), '--H', str(size[1]), '--W', str(size[2])]
   r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
   out = r.stdout + r.stderr
   lines = [ln for ln in out.splitlines() if 'differ' in ln or 'NaN' in ln]
   assert 'workers exit code 0' in out, out[-3000:]
   for rank in (0, 1):
-    assert '[rank %d] eager: 0 of 29 repeated steps differ from the first' % rank in out, '\n'.join(lines)[:4000]
-    assert '[rank %d] graph: 0 of 30 replays differ from the eager step' % rank in out, '\n'.join(lines)[:4000]
+    assert '[rank %d] eager: 0 of %d repeated steps differ from the first' % (rank, steps - 1) in out, '\n'.join(lines)[:4000]
+    assert '[rank %d] graph: 0 of %d replays differ from the eager step' % (rank, steps) in out, '\n'.join(lines)[:4000]
