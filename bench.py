@@ -151,7 +151,7 @@ def kernel_of(label, conv_arith, on_split=None):
     if split and stride == 2:
       return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
-      return 'conv3d_split_kernel<1,0>'
+      return 'conv3d_split_kernel<1,0>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1>'  # (<1,2> with a residual)
     return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
   if name == 'conv3d_bwd_weight':
     if re.search(r'->1 ', label):
