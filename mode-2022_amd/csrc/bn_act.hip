@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 256;       // threads per block (512 measured in the step, round 4: 0.241 / 0.361 against 0.236 / 0.357 ms for the big 3-D layer)
+constexpr int NW = NT / 64;  // waves per block
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -23,18 +24,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // block-wide sum of two values; result valid in thread 0
-__device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [8] */) {
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [2 * NW] */) {
   a = wave_sum(a);
   b = wave_sum(b);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
     sh[wave] = a;
-    sh[4 + wave] = b;
+    sh[NW + wave] = b;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a = sh[0] + sh[1] + sh[2] + sh[3];
-    b = sh[4] + sh[5] + sh[6] + sh[7];
+    a = sh[0];
+    b = sh[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {  // fixed order
+      a += sh[w];
+      b += sh[NW + w];
+    }
   }
 }
 
@@ -44,7 +50,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [8] 
 // grid = (nsplit, C, G).  partial[((g*C + c)*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
 __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int B, int C,
                                                       long long S, int nsplit) {
-  __shared__ float sh[8];
+  __shared__ float sh[2 * NW];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
 // Block-wide fp64 sum of this channel's per-block partials (pairs); every block of a channel walks them in the same
 // order, so all blocks derive bit-identical coefficients.  Result valid in thread 0.
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int c, int nsplit, double& s0, double& s1,
-                                                double* shd /* [8] */) {
+                                                double* shd /* [2 * NW] */) {
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nsplit; i += NT) {
     const float2 v = reinterpret_cast<const float2*>(partial)[(long long)c * nsplit + i];
@@ -109,11 +115,16 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
     shd[wave] = a;
-    shd[4 + wave] = b;
+    shd[NW + wave] = b;
   }
   __syncthreads();
-  s0 = (shd[0] + shd[1]) + (shd[2] + shd[3]);
-  s1 = (shd[4] + shd[5]) + (shd[6] + shd[7]);
+  s0 = shd[0];
+  s1 = shd[NW];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {  // fixed order, the same in every block
+    s0 += shd[w];
+    s1 += shd[NW + w];
+  }
   __syncthreads();  // shd may be reused by the next call
 }
 
@@ -145,7 +156,7 @@ struct BnCoefArgs {
 template <bool RELU, bool ADD, bool TRAIN>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add, BnCoefArgs k,
                                                       float* __restrict__ out, int C, long long S) {
-  __shared__ double shd[8];
+  __shared__ double shd[2 * NW];
   __shared__ float coef[2];
   const int bc = blockIdx.y;
   const int c = bc % C;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
                                                           const float* __restrict__ out, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, float* __restrict__ partial, int B, int C,
                                                           long long S, int nsplit) {
-  __shared__ float sh[8];
+  __shared__ float sh[2 * NW];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           float* __restrict__ gbeta, int accumulate, int nsplit, double count,
                                                           int groups, int Bg, float* __restrict__ gy, float* __restrict__ gadd, int C,
                                                           long long S) {
-  __shared__ double shd[8];
+  __shared__ double shd[2 * NW];
   __shared__ float coef[3];
   const int bc = blockIdx.y;
   const int c = bc % C;
@@ -404,10 +415,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
 }
 
 int pick_nsplit(int C, long long S) {
-  // ~16 blocks per CU in total (measured on the 403 MB tensors: 4 -> 101 us, 8 -> 93, 16 -> 89, 32 -> 88 for this read-only pass,
-  // i.e. ~4.6 TB/s: a pure read stream tops out below the ~6.2 TB/s a copy reaches), each with at least 4096 elements per image
-  long long n = (16LL * kNumCU + C - 1) / C;
-  const long long maxn = std::max<long long>(1, (S / 4) / 1024);
+  // Blocks of the two statistics passes.  Round 4 (tools/experiments/stream_bw.hip, profiles/r04_microbench_stream_bw.txt): a plain read
+  // stream of 256-thread blocks reaches 5.2-5.6 TB/s with 4-16 blocks per CU and 6.2 TB/s with 32-64 -- so up to 64 blocks per CU
+  // in total, as long as a thread still has at least 8 x 16 bytes of every image (small layers pay the per-block reduction instead:
+  // measured, 16 per CU kept there by this floor)
+  long long n = (64LL * kNumCU + C - 1) / C;
+  const long long maxn = std::max<long long>(1, (S / 4) / (8 * NT));
   if (n > maxn) n = maxn;
   if (n < 1) n = 1;
   if (n > 1024) n = 1024;
@@ -415,8 +428,10 @@ int pick_nsplit(int C, long long S) {
 }
 
 int apply_chunks(int BC, long long S) {
-  long long n = (8LL * kNumCU + BC - 1) / BC;
-  const long long maxn = std::max<long long>(1, ((S / 4) + NT - 1) / NT);
+  // blocks per row of the two apply passes: up to 64 per CU in total (a read + write stream: 4.3 TB/s at 8 blocks of 256 threads per
+  // CU, 5.7 at 64), at least 8 x 16 bytes per thread
+  long long n = (64LL * kNumCU + BC - 1) / BC;
+  const long long maxn = std::max<long long>(1, (S / 4) / (8 * NT));
   if (n > maxn) n = maxn;
   return (int)std::max<long long>(1, n);
 }
