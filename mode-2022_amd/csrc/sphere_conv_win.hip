@@ -2214,9 +2214,14 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
   MODE_REQUIRE(B <= 65535 && d.G * d.MG <= 65535, MODE_ERR_UNSUPPORTED, "mode_sphere_conv_fwd_win: grid limit");
   hipStream_t st = mode::as_stream(stream);
   const long long npack = (long long)d.G * d.MG * d.NCH * KT * MTW * 64 * 4;
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const bool split_path = split && n_small > 0 && d.Cig % SP_CCH == 0;
+  const bool wrap_on_fp32 = n_wrap > 0 && (!d.wrap_pipe || tall_split_lds_bytes(d.wr) > 160 * 1024);
+  // the fp32 fragment layout (and the folded-BatchNorm shifts behind it) is read by the fp32 kernels and by the eval epilogue: a training
+  // call whose tiles all run on the split kernel does not need it
+  if (mode::pack_needed() && (!split_path || bn || wrap_on_fp32))
+    hipLaunchKernelGGL(pack_w_win, dim3(mode::cdiv(npack, 256)), dim3(256), 0, st, w, wpack, d, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack);
-  if (split && n_small > 0 && d.Cig % SP_CCH == 0) {
+  if (split_path) {
     // small-window tiles (the tail of the tile list) on the split-bf16 kernel, the tall-window classes on the fp32 kernels
     const int NCH16 = d.Cig / SP_CCH;
     uint4* wps = reinterpret_cast<uint4*>(wpack + ((npack + d.Co + 3) / 4) * 4);
@@ -2232,7 +2237,7 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
     const int4* tl = reinterpret_cast<const int4*>(tiles);
     int n_all = n_small + n_mid + n_wrap;
-    if (n_wrap > 0 && (!d.wrap_pipe || tall_split_lds_bytes(d.wr) > 160 * 1024)) {
+    if (wrap_on_fp32) {
       rc = bn ? fwd_win_launch<true>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi)
               : fwd_win_launch<false>(x, pos, y, wpack, tiles, 0, 0, n_wrap, B, d, st, epi);
       if (rc != MODE_OK) return rc;
