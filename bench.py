@@ -32,7 +32,8 @@ HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense; a split-bf16 fp32 product costs six bf16 MFMAs (csrc/conv3d_split.hip)
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
-                'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm'}
+                'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
+                'classif_fwd': 'hbm', 'classif_bwd': 'hbm'}
 
 
 def parse():
@@ -61,6 +62,12 @@ def parse():
                   help='pairs/s of the same workload on ONE GPU, if known: rank 0 adds value / (N * value_1gpu) to the line')
   ap.add_argument('--fused-bn-stats', action='store_true',
                   help='A/B: BatchNorm statistics of the stride-1 3-D layers in the convolution epilogue (functional.CONV3D_BN_STATS; measured +-0)')
+  ap.add_argument('--init', default='recipe', choices=['recipe', 'torch'],
+                  help="initial weights: 'recipe' = tests/golden/recipe.py state (SURVEY 8c/8d), 'torch' = the constructor's random init under torch.manual_seed(0)")
+  ap.add_argument('--no-fused-loss', action='store_true',
+                  help='A/B: the loss of train_disparity.py:151-158 as torch ops on the three predictions instead of ModeDisparity.forward_loss')
+  ap.add_argument('--no-fused-classif', action='store_true',
+                  help='A/B: the classifier heads as separate BatchNorm / 32->1 convolution operators (functional.CLASSIF_FUSED = False)')
   ap.add_argument('--no-collective-self-test', action='store_true', help='skip the world-size-1 RCCL all-reduce self-test after the timed region')
   ap.add_argument('--no-eval-b1', action='store_true', help='skip the BASELINE configs[1] leg (eval forward, batch 1) after the timed region')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -80,6 +87,9 @@ def launch_ranks(args):
     port = sk.getsockname()[1]
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
          '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC; without it RCCL's intra-node transport (and any
+  # device-tensor sharing between the ranks) fails in hipIpcGetMemHandle with "invalid argument".  The image exports it already;
+  # it is repeated here so that a launcher with a scrubbed environment still gets it (an explicit setting of the caller wins).
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
   return subprocess.call(cmd, env=env)
 
@@ -147,7 +157,7 @@ def kernel_of(label, conv_arith, on_split=None):
   stride = int(m.group(1)) if m else 1
   if name in ('conv3d_fwd', 'conv3d_bwd_data', 'conv3d_bn_eval'):
     if re.search(r'->1 ', label):
-      return 'conv3d_co1_fwd_mfma_kernel' if name != 'conv3d_bwd_data' else 'conv3d_co1_bwd_data_kernel'
+      return 'classif_fwd_kernel' if name != 'conv3d_bwd_data' else 'conv3d_co1_bwd_data_kernel'  # (Ci <= 32: classif_head.hip's forward without the BatchNorm prologue)
     if split and stride == 2:
       return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
@@ -186,6 +196,10 @@ def kernel_of(label, conv_arith, on_split=None):
     if name == 'head_fwd':
       return 'head_fwd_fast_kernel' if fast else 'head_fwd_kernel'
     return ('head_bwd_pix_fast_kernel' if fast else 'head_bwd_pix_kernel') + '+head_bwd_rows_kernel+head_bwd_cols_kernel'
+  if name == 'classif_fwd':
+    return 'bn_stats_kernel+classif_fwd_kernel'
+  if name == 'classif_bwd':
+    return 'classif_bww_kernel+classif_bwd_apply_kernel'
   return {'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel',
           'bn_eval_fwd': 'bn_eval_kernel',
           'cost_volume_fwd': 'cost_volume_fwd_v4', 'cost_volume_bwd': 'cost_volume_bwd_v4',
@@ -474,10 +488,16 @@ def main():
   from mode_hip import functional as HF
   HF.set_conv_arith(args.conv_arith)
   HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
+  HF.CLASSIF_FUSED = not args.no_fused_classif
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)
   net = models.ModeDisparity(args.maxdisp, 'Sphere', args.height, args.width, 'Cassini').to(dev)
+  if args.init == 'recipe':
+    # weights from the 8(c) recipe (tests/golden/recipe.py: every tensor of the state_dict drawn from
+    # numpy.random.RandomState(seed) in key order with per-kind scales) -- the state the parity fixtures use, reproducible without torch's RNG
+    import recipe
+    net.load_state_dict(recipe.recipe_state(recipe.load_manifest(), 1))
   reducer = data_parallel.GradAllReducer(net)
   reducer.broadcast_parameters(net)
   try:  # same update rule as train_disparity.py:287 (Adam, lr 1e-3, betas (0.9, 0.999)); single-kernel implementation
@@ -493,12 +513,15 @@ def main():
 
   def fwd_bwd():
     reducer.zero_grad()
-    mask = ~torch.isnan(gt)
-    gt0 = torch.nan_to_num(gt)
-    o1, o2, o3 = net(left, right)
-    loss = 0
-    for wgt, o in ((0.5, o1), (0.7, o2), (1.0, o3)):
-      loss = loss + wgt * data_parallel.global_masked_mean(F.smooth_l1_loss(o, gt0, reduction='none'), mask, count=count)
+    if not args.no_fused_loss:  # the same loss, formed next to the heads (ModeDisparity.forward_loss; tests/test_gpu_steps.py pins both forms)
+      loss, _ = net.forward_loss(left, right, gt, count=count)
+    else:
+      mask = ~torch.isnan(gt)
+      gt0 = torch.nan_to_num(gt)
+      o1, o2, o3 = net(left, right)
+      loss = 0
+      for wgt, o in ((0.5, o1), (0.7, o2), (1.0, o3)):
+        loss = loss + wgt * data_parallel.global_masked_mean(F.smooth_l1_loss(o, gt0, reduction='none'), mask, count=count)
     loss.backward()
     return loss
 
@@ -535,6 +558,13 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  # The first eager step runs under a guard that raises on any vendor-library arithmetic (convolution, BatchNorm, GEMM, softmax,
+  # interpolation) reached from the step: the host-side helpers keep silent exits to the torch module for shapes the kernels do not
+  # take (models/stage3d.conv3 -> conv(x), bn_act_torch), and a timed step must not be one of those.
+  from mode_hip import no_vendor
+  with no_vendor.no_vendor_arithmetic() as guard:
+    eager_step()
+  fence()
   for _ in range(args.warmup):
     eager_step()
   fence()
@@ -640,6 +670,7 @@ def main():
                          args.batch, 2 if world == 1 else 3),
             'global_batch': args.batch * world,
             'conv_arith': args.conv_arith,
+            'init': 'recipe state, seed 1 (tests/golden/recipe.py)' if args.init == 'recipe' else 'torch.manual_seed(0) constructor init',
             'parallelism': 'dp%d' % world,
             'cost_volume': ('folded into dres0[0][0] (cost_conv: 18 partial 2-D products + assembly kernel); the volume is not built, '
                             'targets.cost_volume_fwd_hbm_frac times the a9 kernel standalone') if net.fold_cost_volume
@@ -660,11 +691,24 @@ def main():
       # the pipe it runs on (fp32 MFMA 157.3, or bf16 / 6 = 416.7 for the split kernels), time-weighted: never above 1
       cv = kern.get('cost_volume_fwd')
       k3 = [v for k, v in kern.items() if k.startswith(('conv3d_', 'deconv3d_'))]
+      cca = [v for k, v in kern.items() if k.startswith('cost_conv_assemble_fwd')]
       out['targets'] = {
+          # the a9 operator (mode_cost_volume_fwd), timed STANDALONE after the step at the step's shapes: the product's model no longer
+          # builds the volume ...
           'cost_volume_fwd_hbm_frac': round(cv['GBps'] / HBM_PEAK_GBPS, 4) if cv else None,
+          'cost_volume_fwd_measured_on': 'mode_cost_volume_fwd launched standalone after the timed region (not part of the step)',
+          # ... it runs the folded form, whose HBM-bound assembly pass IS in the step:
+          'cost_conv_assemble_fwd_hbm_frac_in_step': round(sum(v['bytes'] for v in cca) / (sum(v['total_ms'] for v in cca) * 1e6) / HBM_PEAK_GBPS, 4) if cca else None,
+          # matrix-bound layers of the regulariser (Conv3d / ConvTranspose3d with >= 32 output channels), each against ITS pipe; the
+          # single-channel classifier convolutions are HBM-bound and priced in `classifier_heads_hbm_frac`
           'regulariser3d_mfma_frac': round(blended_mfma_fraction(kern, args.conv_arith), 4) if k3 else None,
           'regulariser3d_tflops_fp32_equivalent': round(sum(v['flops'] for v in k3) / (sum(v['total_ms'] for v in k3) * 1e9), 2) if k3 else None,
       }
+      ch = [v for k, v in kern.items() if k.startswith(('classif_fwd', 'classif_bwd'))]
+      if ch:
+        out['targets']['classifier_heads_hbm_frac'] = round(sum(v['bytes'] for v in ch) / (sum(v['total_ms'] for v in ch) * 1e6) / HBM_PEAK_GBPS, 4)
+      out['roofline']['targets'] = out['targets']  # (also inside `roofline`, where the driver's parser keeps it)
+      out['config']['vendor_guard'] = 'first eager step ran under mode_hip.no_vendor (%d aten ops seen, none of them vendor arithmetic)' % guard.seen
       out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
                             'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}
     else:

@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 19 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 21 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -440,6 +440,26 @@ size_t mode_head_bwd_workspace_bytes(int B, int D4, int H, int W);
 int mode_head_bwd(const float* logits, const float* gpred, float* glogits, float* workspace, int B, int D4, int H4,
                   int W4, int D, int H, int W, mode_stream_t stream);
 
+/* The loss of the training step next to the head (train_disparity.py:151-158: masked smooth-L1 of the three predictions, weights
+ * 0.5 / 0.7 / 1.0, mean over the valid pixels), so that nothing elementwise is launched between the head and the optimizer:
+ *   mode_smooth_l1_masked: out[0] = scale[0] * sum_i w_i * sum_pix [gt == gt] * smooth_l1(pred_i[pix] - gt[pix])   (beta = 1);
+ *     pred1 / pred2 may be NULL; NaN ground truth = masked pixel (train_disparity.py:195); scale = a DEVICE scalar, normally
+ *     1 / (number of valid pixels over all ranks); n = B * H * W; workspace >= mode_smooth_l1_workspace_bytes(n); deterministic.
+ *   mode_head_bwd_loss: mode_head_bwd with gpred = weight * scale[0] * [gt == gt] * clamp(pred - gt, -1, 1) formed inside the kernel from
+ *     the forward's own prediction `pred` (B, H, W) -- the gradient of the term weight * scale * sum smooth_l1(pred - gt) above; `scale`
+ *     here also carries the upstream gradient of the loss.  workspace as mode_head_bwd.  Only where mode_head_loss_supported(...) == 1
+ *     (D = 4 * D4 with D4 one of 4 / 8 / 12 / 16 / 48 / 64, W <= 512); otherwise form gpred and call mode_head_bwd.
+ */
+size_t mode_smooth_l1_workspace_bytes(long long n);
+
+int mode_smooth_l1_masked(const float* pred0, const float* pred1, const float* pred2, const float* gt, float w0, float w1, float w2,
+                          const float* scale, float* out, float* workspace, long long n, mode_stream_t stream);
+
+int mode_head_loss_supported(int B, int D4, int H4, int W4, int D, int H, int W);
+
+int mode_head_bwd_loss(const float* logits, const float* pred, const float* gt, float weight, const float* scale, float* glogits,
+                       float* workspace, int B, int D4, int H4, int W4, int D, int H, int W, mode_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm (+ residual add) (+ ReLU) over (B, C, S) tensors, S = D*H*W or H*W, S % 4 == 0.
  * Replaces nn.BatchNorm3d/2d of convbn_3d / convbn (models/submodule.py:15-22) fused with the adds and ReLUs that
@@ -477,6 +497,34 @@ int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const
                       const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                       float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
                       long long S, int groups, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Classifier head of the 3-D regulariser in TRAINING (SURVEY a12 + a15):
+ *     classifN = Sequential(convbn_3d(32, 32), ReLU, Conv3d(32, 1, k3 p1, bias=False))      models/mode_disparity.py:76-80
+ *     cost1 = classif1(out1); cost2 = classif2(out2) + cost1; cost3 = classif3(out3) + cost2  models/mode_disparity.py:127-129
+ * taken from the OUTPUT y (B, C, D, H, W) of the first convolution on: BatchNorm3d (batch statistics, torch defaults as in
+ * mode_bn_train_fwd) + ReLU + the single-channel convolution [+ the residual `add` (B, 1, D, H, W), may be NULL], without the
+ * activated tensor relu(bn(y)) ever being written (csrc/classif_head.hip: the normalisation is applied while the second convolution
+ * stages its operand; in the backward ONE pass over y yields the weight gradient of the second convolution and both reductions of the
+ * BatchNorm backward, a second one its input gradient with the BatchNorm backward's apply pass in the store).  C <= 32.
+ *   fwd: cost (B, 1, D, H, W) written; running_mean / running_var / *num_batches_tracked updated (any may be NULL);
+ *        save_mean / save_invstd / save_scale / save_shift (C floats each) feed the backward.
+ *   bwd: gcost (B, 1, D, H, W) = dL/dcost -> gy (B, C, D, H, W) = dL/dy written; gw (C * 27) = gradient of the second convolution's
+ *        weight (1, C, 3, 3, 3), ggamma / gbeta (C): written (accumulate = 0) or added to (accumulate = 1).  The gradient of `add` is
+ *        gcost itself.  Deterministic (fixed-order split-K).
+ * `workspace` >= mode_classif_workspace_bytes(B, C, D, H, W), 16-byte aligned, for both calls.
+ */
+size_t mode_classif_workspace_bytes(int B, int C, int D, int H, int W);
+
+int mode_classif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           long long* num_batches_tracked, float momentum, float eps, const float* w, const float* add, float* cost,
+                           float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B, int C,
+                           int D, int H, int W, mode_stream_t stream);
+
+int mode_classif_train_bwd(const float* gcost, const float* y, const float* w, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift, float* gy,
+                           float* gw, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, int D, int H, int W,
+                           mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Export-stage geometry: what happens between the disparity network and the fusion network.

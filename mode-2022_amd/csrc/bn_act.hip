@@ -9,7 +9,7 @@
 //   train fwd  : (2 reads [+1 read of the skip tensor] + 1 write) * 4 B per element
 //   train bwd  : reduce pass (reads gout, y [, out]) + apply pass (reads gout, y [, out], writes gy [, gadd])
 // Statistics are reduced per thread / per block in fp32 over short runs and combined across blocks in fp64.
-#include "common.h"
+#include "bn_internal.h"
 #include <cstdlib>
 
 namespace {
@@ -476,7 +476,8 @@ extern "C" int mode_bn_train_fwd_prestats(const float* y, const float* add, cons
                                           float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
                                           float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
                                           float* workspace, int nsplit, int B, int C, long long S, mode_stream_t stream) {
-  MODE_REQUIRE(nsplit > 0 && nsplit <= 1024, MODE_ERR_BAD_ARG, "mode_bn_train_fwd_prestats: %d partial pairs per channel (1..1024)", nsplit);
+  // the C pivots sit behind the 2 * C * nsplit partial sums in a workspace of C * 2048 floats: at most 1023 pairs per channel
+  MODE_REQUIRE(nsplit > 0 && nsplit <= 1023, MODE_ERR_BAD_ARG, "mode_bn_train_fwd_prestats: %d partial pairs per channel (1..1023)", nsplit);
   return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
                            save_invstd, save_scale, save_shift, workspace, B, C, S, 1, nsplit, stream);
 }
@@ -510,6 +511,52 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   }
   if (add) return launch_apply(bn_apply_kernel<false, true, true>, BC, S, st, who, y, add, k, out, C, S);
   return launch_apply(bn_apply_kernel<false, false, true>, BC, S, st, who, y, y, k, out, C, S);
+}
+
+// The TRAIN coefficients of bn_apply_kernel on their own, one block per channel (one statistics group): for consumers that apply the
+// normalisation themselves while they stage their operand (csrc/classif_head.hip) -- same arithmetic, same order, same saved values.
+namespace {
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ y, BnCoefArgs k, int C, long long S) {
+  __shared__ double shd[2 * NW];
+  const int c = blockIdx.x;
+  double s0, s1;
+  reduce_partials(k.partial, c, k.nsplit, s0, s1, shd);
+  if (threadIdx.x != 0) return;
+  const double dm = s0 / k.count;  // mean of y - K, K = the pivot of bn_stats_kernel
+  const double mean = (double)y[(long long)c * S] + dm;
+  double var = s1 / k.count - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)k.eps);
+  const double sc = (double)k.gamma[c] * invstd;
+  k.save_mean[c] = (float)mean;
+  k.save_invstd[c] = (float)invstd;
+  k.save_scale[c] = (float)sc;
+  k.save_shift[c] = (float)((double)k.beta[c] - mean * sc);
+  if (k.running_mean) {
+    const double unbiased = k.count > 1.0 ? var * k.count / (k.count - 1.0) : var;
+    k.running_mean[c] = (float)((1.0 - k.momentum) * (double)k.running_mean[c] + k.momentum * mean);
+    k.running_var[c] = (float)((1.0 - k.momentum) * (double)k.running_var[c] + k.momentum * unbiased);
+  }
+  if (c == 0 && k.num_batches_tracked) *k.num_batches_tracked += 1;
+}
+}  // namespace
+
+int mode::bn_train_coefficients(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
+                                float* save_scale, float* save_shift, float* workspace, int B, int C, long long S, hipStream_t st,
+                                const char* who) {
+  int rc = ::check_bn(B, C, S, who);  // (the one of this file, not mode::check_bn(const mode_bn_epilogue*, ...))
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "%s: empty batch has no statistics", who);
+  MODE_REQUIRE(y && gamma && beta && save_mean && save_invstd && save_scale && save_shift && workspace, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  MODE_REQUIRE(aligned_rows(y, S) && aligned16(workspace), MODE_ERR_UNSUPPORTED, "%s: unaligned buffer", who);
+  MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "%s: running stats must come in pairs", who);
+  const int nsplit = pick_nsplit(C, S);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, 1), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
+               momentum, eps, nsplit, (double)B * (double)S, 1, B, nullptr};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(NT), 0, st, y, k, C, S);
+  return mode::check_launch(who);
 }
 
 extern "C" int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,

@@ -460,10 +460,11 @@ int co1_splits(int T, int MTc) {
 namespace mode {
 
 int conv3d_co1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who) {
+  if (Ci <= 32 && (long long)Ci * D * H * W < (1ll << 30)) return conv3d_co1_fwd_small(x, w, y, B, Ci, D, H, W, st, who);
   if ((long long)Ci * D * H * W < (1ll << 30)) {  // MFMA form (the vector-ALU stencil below is kept for larger samples)
     const int nDc = cdiv(D, ZDC), nHt = cdiv(H, ZTH), nWt = cdiv(W, 32);
     const size_t lds = (size_t)27 * ZPL * sizeof(float);
-    auto kern = Ci <= 32 ? conv3d_co1_fwd_mfma_kernel<true> : conv3d_co1_fwd_mfma_kernel<false>;
+    auto kern = conv3d_co1_fwd_mfma_kernel<false>;  // (Ci > 32 here: up to 32 channels run on classif_head.hip's kernel, above)
     int rc = allow_lds(kern, lds, who);
     if (rc != MODE_OK) return rc;
     hipLaunchKernelGGL(kern, dim3(B * nDc * nHt * nWt), dim3(NT), lds, st, x, w, y, B, Ci, D, H, W, nDc, nHt, nWt);

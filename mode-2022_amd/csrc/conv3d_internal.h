@@ -9,6 +9,10 @@ namespace mode {
 // taps as the GEMM-N dimension (weight gradient) or the GEMM-K dimension (input gradient).
 int conv3d_co1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who);
 
+// classif_head.hip: the same forward for Ci <= 32 and samples below 2^30 elements on the kernel of the fused classifier head (every
+// request of the plane loop unconditional and in a fixed order, a position group's fragments re-requested as soon as its MFMAs are issued)
+int conv3d_co1_fwd_small(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who);
+
 // gx (B,Ci,D,H,W) = input gradient for gy (B,1,D,H,W); overwrites gx.
 int conv3d_co1_bwd_data(const float* gy, const float* w, float* gx, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who);
 

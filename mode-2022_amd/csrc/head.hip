@@ -12,6 +12,8 @@
 // touch a low-resolution node (kernel 2).  No atomics.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int NT = 256;
@@ -374,6 +376,155 @@ __global__ __launch_bounds__(NT) void head_bwd_cols_kernel(const float* __restri
   gL[idx] = sum;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward with the per-pixel pass and the ROW half of the separable (h, w) transpose in ONE kernel (round 5).  The two-kernel form wrote
+// G = (B, D4, H, W) -- 201 MB per head at the benchmark shape -- and read it back to form the row sums R = (B, D4, H, W4): 0.157 ms of a
+// 0.26 ms head backward were that round trip.  Here a block owns ONE image row (W <= 512 threads, one per pixel), keeps the 48 node
+// gradients of every pixel in registers (a block is at most 512 threads: two waves per SIMD), and passes them through LDS 16 nodes at a time so that the threads can re-read them along w:
+// R[k][w4] = sum_w ww(w, w4) G[k][w] over the <= 12 pixels of a node's support.  G never exists; the column half (head_bwd_cols_kernel)
+// is unchanged.  LOSS: the upstream gradient is not read from memory but formed from the forward's own prediction and the ground truth --
+// the masked smooth-L1 of train_disparity.py:151-158: g = weight * [gt == gt] * clamp(pred - gt, -1, 1) * (*scale) -- so that the
+// loss chain between the head and the optimizer needs no elementwise launches.
+constexpr int HR_KC = 16;   // nodes per LDS pass
+constexpr int HR_MAXS = 12;  // pixels in the support of a low-resolution node (x4 up-sampling: 8-9)
+
+template <int D4, bool LOSS>
+__global__ __launch_bounds__(512) void head_bwd_pixrows_kernel(const float* __restrict__ L, const float* __restrict__ gpred,
+                                                                const float* __restrict__ pred, const float* __restrict__ gt, float weight,
+                                                                const float* __restrict__ scale, float* __restrict__ R, HDims d) {
+  using C = HeadConst<D4>;
+  extern __shared__ __attribute__((aligned(16))) float gl[];  // [HR_KC][pitch], element w of a row at w + (w >> 2): the stride-4 reads of
+  const int pitch = d.W + (d.W >> 2) + 1;                      // neighbouring nodes then fall on different banks
+  const int w = threadIdx.x;
+  const int h = blockIdx.x % d.H, b = blockIdx.x / d.H;
+  const bool live = w < d.W;
+  float A[D4], Bc[D4];
+  float gscale = 0.f, p = 0.f;
+  if (live) {
+    float a[D4];
+    fill_column_regs<D4>(L + (long long)b * D4 * d.H4 * d.W4, d, h, w, a);
+#pragma unroll
+    for (int k = 0; k < D4; ++k) A[k] = Bc[k] = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < C::D; ++dd) {
+      const float l = C::ld(dd);
+      const int k0 = C::d0(dd), k1 = C::d1(dd);
+      const float e = __builtin_amdgcn_exp2f((1.f - l) * a[k0] + l * a[k1]);
+      if (k1 != k0) {
+        A[k0] = fmaf(1.f - l, e, A[k0]);
+        Bc[k0] = fmaf((1.f - l) * (float)(dd - 4 * k0), e, Bc[k0]);
+        A[k1] = fmaf(l, e, A[k1]);
+        Bc[k1] = fmaf(l * (float)(dd - 4 * k1), e, Bc[k1]);
+      } else {
+        A[k0] += e;
+        Bc[k0] = fmaf((float)(dd - 4 * k0), e, Bc[k0]);
+      }
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < D4; ++k) {
+      s0 += A[k];
+      s1 += fmaf((float)(4 * k), A[k], Bc[k]);
+    }
+    p = s1 / s0;
+    const long long pix = ((long long)b * d.H + h) * d.W + w;
+    float g;
+    if (LOSS) {
+      const float t = gt[pix];
+      const float df = pred[pix] - t;  // the forward's own value: the gradient of the loss that was reported
+      g = (t == t) ? weight * fminf(fmaxf(df, -1.f), 1.f) * scale[0] : 0.f;  // NaN ground truth = masked out (train_disparity.py:195)
+    } else {
+      g = gpred[pix];
+    }
+    gscale = g / s0;
+  }
+  // this thread's output nodes: w4 = threadIdx.x % W4 for the node rows kq, kq + nkq, ... of a pass (host: blockDim.x % W4 == 0)
+  const int w4 = threadIdx.x % d.W4, kq = threadIdx.x / d.W4, nkq = blockDim.x / d.W4;
+  const int wlo = d.sw > 0.f ? max(0, (int)floorf((float)(w4 - 1) / d.sw) - 1) : 0;
+  const int whi = d.sw > 0.f ? min(d.W - 1, (int)ceilf((float)(w4 + 1) / d.sw) + 1) : d.W - 1;
+  float ww[HR_MAXS];
+#pragma unroll
+  for (int i = 0; i < HR_MAXS; ++i) {
+    const int wq = min(wlo + i, d.W - 1);
+    int w0, w1;
+    float lw;
+    src_index(wq, d.sw, d.W4, w0, w1, lw);
+    ww[i] = (wlo + i <= whi) ? (w0 == w4 ? 1.f - lw : 0.f) + (w1 == w4 ? lw : 0.f) : 0.f;  // exactly 0 outside the support
+  }
+  float* Rb = R + (((long long)b * D4) * d.H + h) * d.W4 + w4;
+  const long long rplane = (long long)d.H * d.W4;
+#pragma unroll
+  for (int k0 = 0; k0 < D4; k0 += HR_KC) {
+    if (live) {
+#pragma unroll
+      for (int kk = 0; kk < HR_KC; ++kk)
+        if (k0 + kk < D4) gl[kk * pitch + w + (w >> 2)] = gscale * (Bc[k0 + kk] - (p - (float)(4 * (k0 + kk))) * A[k0 + kk]);
+    }
+    __syncthreads();
+    for (int kk = kq; kk < HR_KC && k0 + kk < D4; kk += nkq) {
+      const float* row = gl + kk * pitch;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < HR_MAXS; ++i) {
+        const int wq = min(wlo + i, d.W - 1);
+        sum = fmaf(ww[i], row[wq + (wq >> 2)], sum);
+      }
+      Rb[(long long)(k0 + kk) * rplane] = sum;
+    }
+    __syncthreads();
+  }
+}
+
+// Masked smooth-L1 of up to three predictions against one ground truth (train_disparity.py:151-158):
+//   out[0] = (*scale) * sum_i weight_i * sum_pix [gt == gt] * smooth_l1(pred_i - gt),   smooth_l1(x) = 0.5 x^2 (|x| < 1), |x| - 0.5 otherwise
+// two launches with a fixed summation order (per-thread runs, a block tree, then one block over the block sums in double).
+__global__ __launch_bounds__(NT) void smooth_l1_partial_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                               const float* __restrict__ p2, const float* __restrict__ gt, float w0, float w1,
+                                                               float w2, long long n, float* __restrict__ partial) {
+  __shared__ float sh[NT / 64];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+    const float t = gt[i];
+    if (t == t) {
+      auto sl1 = [&](float v) {
+        const float ax = fabsf(v - t);
+        return ax < 1.f ? 0.5f * ax * ax : ax - 0.5f;
+      };
+      float v = w0 * sl1(p0[i]);
+      if (p1) v += w1 * sl1(p1[i]);
+      if (p2) v += w2 * sl1(p2[i]);
+      s += v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = sh[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) v += sh[i];
+    partial[blockIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(NT) void smooth_l1_final_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ scale,
+                                                             float* __restrict__ out) {
+  __shared__ double sh[NT / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += NT) s += (double)partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = sh[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) v += sh[i];
+    out[0] = (float)(v * (double)scale[0]);
+  }
+}
+
 template <int D4>
 int launch_fwd_fast(const float* logits, float* pred, float* conf, const HDims& d, hipStream_t st) {
   const long long npix = (long long)d.B * d.H * d.W;
@@ -393,6 +544,23 @@ int launch_bwd_fast(const float* logits, const float* gpred, float* ws, const HD
   const long long npix = (long long)d.B * d.H * d.W;
   hipLaunchKernelGGL(head_bwd_pix_fast_kernel<D4>, dim3(mode::cdiv(npix, NT)), dim3(NT), 0, st, logits, gpred, ws, d);
   return mode::check_launch("mode_head_bwd(pixels)");
+}
+
+// one block per image row: W <= 512 pixels (8 waves: the 48-node kernel needs 2 waves per SIMD = 256 registers; wider rows take the
+// two-kernel form), a whole number of node rows per pass of the block's threads
+bool pixrows_fits(const HDims& d) {
+  const int nt = ((d.W + 63) / 64) * 64;
+  return d.W <= 512 && d.W4 <= d.W && nt % d.W4 == 0 && (long long)d.B * d.H < (1ll << 31) &&
+         (size_t)HR_KC * (d.W + (d.W >> 2) + 1) * sizeof(float) <= 64 * 1024;
+}
+
+template <int D4, bool LOSS>
+int launch_bwd_pixrows(const float* logits, const float* gpred, const float* pred, const float* gt, float weight, const float* scale,
+                       float* R, const HDims& d, hipStream_t st) {
+  const int nt = ((d.W + 63) / 64) * 64;
+  const size_t lds = (size_t)HR_KC * (d.W + (d.W >> 2) + 1) * sizeof(float);
+  hipLaunchKernelGGL((head_bwd_pixrows_kernel<D4, LOSS>), dim3(d.B * d.H), dim3(nt), lds, st, logits, gpred, pred, gt, weight, scale, R, d);
+  return mode::check_launch("mode_head_bwd(pixels + rows)");
 }
 
 // the compile-time instantiations: D4 = maxdisp / 4 of the configurations in use (16 ... 256 disparities)
@@ -454,6 +622,16 @@ extern "C" int mode_head_bwd(const float* logits, const float* gpred, float* glo
   hipStream_t st = mode::as_stream(stream);
   const long long npix = (long long)B * H * W;
   bool fast = false;
+  if (head_fast(d) && pixrows_fits(d)) {  // per-pixel pass and row sums in one kernel, then the column sums
+    float* R = workspace;
+#define X(N) if (D4 == N) rc = launch_bwd_pixrows<N, false>(logits, gpred, nullptr, nullptr, 0.f, nullptr, R, d, st);
+    MODE_HEAD_FAST_D4(X)
+#undef X
+    if (rc != MODE_OK) return rc;
+    const long long n = (long long)B * D4 * H4 * W4;
+    hipLaunchKernelGGL(head_bwd_cols_kernel, dim3(mode::cdiv(n, NT)), dim3(NT), 0, st, R, glogits, d);
+    return mode::check_launch("mode_head_bwd(columns)");
+  }
   if (head_fast(d)) {
 #define X(N) if (D4 == N) { rc = launch_bwd_fast<N>(logits, gpred, workspace, d, st); fast = true; }
     MODE_HEAD_FAST_D4(X)
@@ -478,4 +656,50 @@ extern "C" int mode_head_bwd(const float* logits, const float* gpred, float* glo
   const long long n = (long long)B * D4 * H4 * W4;
   hipLaunchKernelGGL(head_bwd_gather_kernel, dim3(mode::cdiv(n, NT)), dim3(NT), 0, st, workspace, glogits, d);
   return mode::check_launch("mode_head_bwd(gather)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The loss of the training step next to the head (train_disparity.py:151-158): see include/mode_hip.h.
+extern "C" size_t mode_smooth_l1_workspace_bytes(long long n) {
+  if (n <= 0) return 0;
+  return (size_t)std::min<long long>((n + NT - 1) / NT, 4LL * kNumCU) * sizeof(float);
+}
+
+extern "C" int mode_smooth_l1_masked(const float* pred0, const float* pred1, const float* pred2, const float* gt, float w0, float w1,
+                                     float w2, const float* scale, float* out, float* workspace, long long n, mode_stream_t stream) {
+  MODE_REQUIRE(n > 0, MODE_ERR_BAD_ARG, "mode_smooth_l1_masked: non-positive size");
+  MODE_REQUIRE(pred0 && gt && scale && out && workspace && (pred1 || !pred2), MODE_ERR_BAD_ARG, "mode_smooth_l1_masked: null pointer");
+  const int blocks = (int)(mode_smooth_l1_workspace_bytes(n) / sizeof(float));
+  hipStream_t st = mode::as_stream(stream);
+  hipLaunchKernelGGL(smooth_l1_partial_kernel, dim3(blocks), dim3(NT), 0, st, pred0, pred1, pred2, gt, w0, w1, w2, n, workspace);
+  hipLaunchKernelGGL(smooth_l1_final_kernel, dim3(1), dim3(NT), 0, st, workspace, blocks, scale, out);
+  return mode::check_launch("mode_smooth_l1_masked");
+}
+
+extern "C" int mode_head_bwd_loss(const float* logits, const float* pred, const float* gt, float weight, const float* scale, float* glogits,
+                                  float* workspace, int B, int D4, int H4, int W4, int D, int H, int W, mode_stream_t stream) {
+  HDims d;
+  int rc = make_hdims(d, B, D4, H4, W4, D, H, W, "mode_head_bwd_loss");
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return MODE_OK;
+  MODE_REQUIRE(logits && pred && gt && scale && glogits, MODE_ERR_BAD_ARG, "mode_head_bwd_loss: null pointer");
+  MODE_REQUIRE(workspace, MODE_ERR_WORKSPACE, "mode_head_bwd_loss: workspace required");
+  MODE_REQUIRE(head_fast(d) && pixrows_fits(d), MODE_ERR_UNSUPPORTED,
+               "mode_head_bwd_loss: needs D = 4 * D4 with D4 in {4, 8, 12, 16, 48, 64}, W <= 512 and W4 dividing the row's thread count "
+               "(mode_head_loss_supported); form the gradient of the loss and call mode_head_bwd otherwise");
+  hipStream_t st = mode::as_stream(stream);
+  float* R = workspace;
+#define X(N) if (D4 == N) rc = launch_bwd_pixrows<N, true>(logits, nullptr, pred, gt, weight, scale, R, d, st);
+  MODE_HEAD_FAST_D4(X)
+#undef X
+  if (rc != MODE_OK) return rc;
+  const long long n = (long long)B * D4 * H4 * W4;
+  hipLaunchKernelGGL(head_bwd_cols_kernel, dim3(mode::cdiv(n, NT)), dim3(NT), 0, st, R, glogits, d);
+  return mode::check_launch("mode_head_bwd_loss(columns)");
+}
+
+extern "C" int mode_head_loss_supported(int B, int D4, int H4, int W4, int D, int H, int W) {
+  HDims d;
+  if (B <= 0 || make_hdims(d, B, D4, H4, W4, D, H, W, "mode_head_loss_supported") != MODE_OK) return 0;
+  return head_fast(d) && pixrows_fits(d) ? 1 : 0;
 }

@@ -106,12 +106,19 @@ SIGNATURES = {
     'mode_head_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr]),
     'mode_head_bwd_workspace_bytes': (_c_size, [_c_int] * 4),
     'mode_head_bwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_smooth_l1_workspace_bytes': (_c_size, [ctypes.c_longlong]),
+    'mode_smooth_l1_masked': (_c_int, [_c_ptr] * 4 + [ctypes.c_float] * 3 + [_c_ptr] * 3 + [ctypes.c_longlong, _c_ptr]),
+    'mode_head_loss_supported': (_c_int, [_c_int] * 7),
+    'mode_head_bwd_loss': (_c_int, [_c_ptr] * 3 + [ctypes.c_float] + [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr]),
     'mode_disp2depth': (_c_int, [_c_ptr] * 2 + [_c_int] * 2 + [ctypes.c_float, _c_ptr]),
     'mode_grid_sample_border': (_c_int, [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr]),
     'mode_depth_view_trans_workspace_bytes': (_c_size, [_c_int] * 2),
     'mode_depth_view_trans': (_c_int, [_c_ptr] * 8 + [_c_int] * 2 + [_c_ptr]),
     'mode_depth_view_project': (_c_int, [_c_ptr] * 6 + [_c_int] * 2 + [_c_ptr]),
     'mode_zbuffer': (_c_int, [_c_ptr] * 6 + [ctypes.c_longlong, _c_ptr]),
+    'mode_classif_workspace_bytes': (_c_size, [_c_int] * 5),
+    'mode_classif_train_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float] * 2 + [_c_ptr] * 8 + [_c_int] * 5 + [_c_ptr]),
+    'mode_classif_train_bwd': (_c_int, [_c_ptr] * 13 + [_c_int] + [_c_ptr] + [_c_int] * 5 + [_c_ptr]),
     'mode_bn_workspace_bytes': (_c_size, [_c_int]),
     'mode_bn_train_fwd': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 6 + [_c_int] * 2 +
                           [ctypes.c_longlong, _c_int, _c_ptr]),
@@ -120,7 +127,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 19  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 21  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

@@ -33,6 +33,25 @@ def _deps_mtime():
   return max(os.path.getmtime(h) for h in hs)
 
 
+def _flags_changed():
+  """True (and the stamp rewritten) when the objects in csrc/obj were compiled with other flags than today's -- e.g. after a debug build
+  with MODE_HIP_DEFINES: the mtime test alone would call that library up to date."""
+  import hashlib
+  stamp = os.path.join(OBJ, 'flags.sha')
+  want = hashlib.sha256('\0'.join([HIPCC] + FLAGS).encode()).hexdigest()
+  try:
+    with open(stamp) as f:
+      have = f.read().strip()
+  except OSError:
+    have = None
+  if have == want:
+    return False
+  with open(stamp, 'w') as f:
+    f.write(want)
+  # no stamp yet but objects present: they predate the stamp and were built by an unknown command line -- rebuild once
+  return have is not None or any(f.endswith('.o') for f in os.listdir(OBJ))
+
+
 def _compile(src, force):
   obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
   if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
@@ -48,6 +67,7 @@ def _compile(src, force):
 
 def build(force=False, verbose=True):
   os.makedirs(OBJ, exist_ok=True)
+  force = force or _flags_changed()
   srcs = sources()
   with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
     results = list(ex.map(lambda s: _compile(s, force), srcs))

@@ -1405,6 +1405,70 @@ def head(logits, size):
   return HeadFunction.apply(logits, size)
 
 
+# ------------------------------------------------------------------------------------ the three heads + the training loss, fused
+# train_disparity.py:151-158: loss = 0.5 sl1(pred1[mask], gt[mask]) + 0.7 sl1(pred2[mask], ...) + sl1(pred3[mask], ...), smooth-L1 with
+# mean reduction over the valid pixels.  As torch ops on the three (B, 1, H, W) maps that is ~25 small elementwise launches forward
+# and as many backward; here the loss is two tiny launches (mode_smooth_l1_masked) and its gradient is formed inside the head's
+# backward kernel from the forward's own prediction (mode_head_bwd_loss): nothing elementwise between the heads and the optimizer.
+def head_loss_supported(logits, size):
+  B, one, D4, H4, W4 = logits.shape
+  D, H, W = size
+  return (logits.is_cuda and logits.dtype == torch.float32 and one == 1 and
+          lib().mode_head_loss_supported(B, D4, H4, W4, D, H, W) == 1)
+
+
+class HeadLossFunction(torch.autograd.Function):
+  """(loss, pred1, pred2, pred3) = f(cost1, cost2, cost3, gt, scale): pred_i = head(cost_i), loss = scale * sum_i w_i * sum over the
+  pixels with a ground truth (gt == gt) of smooth_l1(pred_i - gt).  `scale` is a device scalar (1 / number of valid pixels over all
+  ranks: data_parallel.global_valid_count).  The predictions are returned for inspection and carry no gradient."""
+
+  @staticmethod
+  def forward(ctx, c1, c2, c3, gt, scale, weights, size):
+    costs = [c.contiguous() for c in (c1, c2, c3)]
+    gt = gt.contiguous()
+    require_gpu(*costs, gt, scale)
+    require_f32c(*costs, gt)
+    scale = scale.reshape(1).to(torch.float32)
+    preds = [head_fwd(c, size) for c in costs]
+    if tuple(gt.shape) != tuple(preds[0].shape):
+      raise RuntimeError('head_loss: ground truth %s does not match the predictions %s' % (tuple(gt.shape), tuple(preds[0].shape)))
+    n = gt.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=gt.device)
+    with torch.cuda.device_of(gt), profiling.region('smooth_l1_masked', 4 * 4 * n, 0, gt.device):
+      ws = torch.empty(max(lib().mode_smooth_l1_workspace_bytes(n) // 4, 1), dtype=torch.float32, device=gt.device)
+      check(lib().mode_smooth_l1_masked(ptr(preds[0]), ptr(preds[1]), ptr(preds[2]), ptr(gt), float(weights[0]), float(weights[1]),
+                                        float(weights[2]), ptr(scale), ptr(loss), ptr(ws), n, stream_of(gt)), 'mode_smooth_l1_masked')
+    ctx.save_for_backward(*costs, *preds, gt, scale)
+    ctx.weights, ctx.size = tuple(float(w) for w in weights), tuple(size)
+    ctx.mark_non_differentiable(*preds)
+    return (loss.reshape(()),) + tuple(preds)
+
+  @staticmethod
+  def backward(ctx, gloss, *unused):
+    c1, c2, c3, p1, p2, p3, gt, scale = ctx.saved_tensors
+    sg = (scale * gloss.reshape(1)).contiguous()  # upstream gradient of the loss folded into the scale (one 1-element launch)
+    D, H, W = ctx.size
+    grads = []
+    for c, p, wt, need in zip((c1, c2, c3), (p1, p2, p3), ctx.weights, ctx.needs_input_grad[:3]):
+      if not need:
+        grads.append(None)
+        continue
+      B, _, D4, H4, W4 = c.shape
+      gl = torch.empty_like(c)
+      with torch.cuda.device_of(c), profiling.region('head_bwd', 4 * (2 * c.numel() + 2 * p.numel()), 0, c.device):
+        ws = torch.empty(max(lib().mode_head_bwd_workspace_bytes(B, D4, H, W) // 4, 1), dtype=torch.float32, device=c.device)
+        check(lib().mode_head_bwd_loss(ptr(c), ptr(p), ptr(gt), wt, ptr(sg), ptr(gl), ptr(ws), B, D4, H4, W4, D, H, W, stream_of(c)),
+              'mode_head_bwd_loss')
+      grads.append(gl)
+    return grads[0], grads[1], grads[2], None, None, None, None
+
+
+def head_loss(costs, size, gt, scale, weights=(0.5, 0.7, 1.0)):
+  """costs = (cost1, cost2, cost3) (B, 1, D/4, H/4, W/4) each -> (loss, (pred1, pred2, pred3)); head_loss_supported(costs[0], size)."""
+  out = HeadLossFunction.apply(costs[0], costs[1], costs[2], gt, scale, tuple(weights), tuple(size))
+  return out[0], tuple(out[1:])
+
+
 # ------------------------------------------------------------------------------------ BatchNorm (+ add) (+ ReLU)
 def _tag_bn(name, y):
   """Profiling label with the tensor shape (like the convolution labels), e.g. bn_train_fwd[2x32 48x256x128]."""
@@ -1413,6 +1477,15 @@ def _tag_bn(name, y):
 
 def _bn_ws(C, device):
   return torch.empty(lib().mode_bn_workspace_bytes(C) // 4, dtype=torch.float32, device=device)
+
+
+def _written_by_kernel(*tensors):
+  """The training BatchNorm kernels update running_mean / running_var / num_batches_tracked through raw pointers; torch must see those
+  writes like any in-place op: the version counters move (host-side only, no launch), so that everything keyed on them -- autograd's
+  saved-tensor checks, the packed-weight cache of the eval forward (_eval_wpack) -- notices."""
+  live = [t for t in tensors if t is not None]
+  if live:
+    torch.autograd.graph.increment_version(live)
 
 
 def _bcs(t):
@@ -1458,6 +1531,7 @@ class BnActFunction(torch.autograd.Function):
       else:
         ws = _bn_ws(C * groups, y.device)
         check(lib().mode_bn_train_fwd(*common, ptr(ws), B, C, S, groups, stream_of(y)), 'mode_bn_train_fwd')
+    _written_by_kernel(running_mean, running_var, num_batches_tracked)
     ctx.save_for_backward(y, out if (relu and not from_y) else None, gamma, beta, mean, invstd, coef)
     ctx.relu, ctx.has_add, ctx.groups = bool(relu), add is not None, groups
     return out
@@ -1529,6 +1603,86 @@ def bn_act(bn, y, add=None, relu=False, groups=1):
   return bn_eval(y, add, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
 
 
+# ------------------------------------------------------------------------------------ classifier head in training, fused
+# classifN = Sequential(convbn_3d(32, 32), ReLU, Conv3d(32, 1)) (mode_disparity.py:76-80): from the first convolution's output on --
+# BatchNorm (batch statistics) + ReLU + the 32 -> 1 convolution + the residual add of mode_disparity.py:128-129 -- as ONE operator whose
+# activated intermediate never reaches HBM (csrc/classif_head.hip: 5 passes over the 403 MB tensor per head and step instead of 13).
+CLASSIF_FUSED = True  # bench.py --no-fused-classif measures the composition of separate operators
+
+
+def classif_fused_supported(y, bn, conv):
+  """y = output of the first convolution; bn = its BatchNorm3d (training mode); conv = the single-channel Conv3d behind the ReLU."""
+  return (CLASSIF_FUSED and y.is_cuda and y.dtype == torch.float32 and y.dim() == 5 and y.shape[0] > 0 and y.shape[1] <= 32 and
+          bn.training and bn.momentum is not None and bn.weight is not None and bn.bias is not None and
+          type(conv) is torch.nn.Conv3d and conv.out_channels == 1 and conv.in_channels == y.shape[1] and conv.bias is None and
+          tuple(conv.kernel_size) == (3, 3, 3) and tuple(conv.stride) == (1, 1, 1) and tuple(conv.padding) == (1, 1, 1) and
+          tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and
+          y.shape[1] * y.shape[2] * y.shape[3] * y.shape[4] < 2**30)
+
+
+class ClassifHeadFunction(torch.autograd.Function):
+  """cost = conv3d(relu(batch_norm_train(y)), w) [+ add]; running statistics updated in place (torch semantics)."""
+
+  @staticmethod
+  def forward(ctx, y, w, gamma, beta, add, running_mean, running_var, momentum, eps, num_batches_tracked):
+    require_gpu(y, w, gamma, beta, add)
+    y, w = y.contiguous(), w.contiguous()
+    add = add.contiguous() if add is not None else None
+    require_f32c(y, w, gamma, beta)
+    B, C, D, H, W = y.shape
+    cost = torch.empty((B, 1, D, H, W), dtype=y.dtype, device=y.device)
+    if add is not None:
+      require_f32c(add)
+      if tuple(add.shape) != tuple(cost.shape):
+        raise RuntimeError('classifier head: residual %s does not match the output %s' % (tuple(add.shape), tuple(cost.shape)))
+    saved = torch.empty((4, C), dtype=torch.float32, device=y.device)  # mean, invstd, scale, shift
+    with torch.cuda.device_of(y), profiling.region(_tag3('classif_fwd', C, 1, 1, D, H, W), 4 * (2 * y.numel() + cost.numel() * (2 if add is not None else 1)),
+                                                   2 * cost.numel() * C * 27, y.device):
+      ws = torch.empty(max(lib().mode_classif_workspace_bytes(B, C, D, H, W) // 4, 1), dtype=torch.float32, device=y.device)
+      check(lib().mode_classif_train_fwd(ptr(y), ptr(gamma), ptr(beta), ptr(running_mean) if running_mean is not None else None,
+                                         ptr(running_var) if running_var is not None else None,
+                                         ptr(num_batches_tracked) if num_batches_tracked is not None else None, float(momentum), float(eps),
+                                         ptr(w), ptr(add) if add is not None else None, ptr(cost), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
+                                         ptr(saved[3]), ptr(ws), B, C, D, H, W, stream_of(y)), 'mode_classif_train_fwd')
+    _written_by_kernel(running_mean, running_var, num_batches_tracked)
+    ctx.save_for_backward(y, w, gamma, beta, saved)
+    ctx.has_add = add is not None
+    return cost
+
+  @staticmethod
+  def backward(ctx, gcost):
+    y, w, gamma, beta, saved = ctx.saved_tensors
+    gcost = gcost.contiguous()
+    B, C, D, H, W = y.shape
+    gy = torch.empty_like(y)
+    sink_w = grad_sink(w) if ctx.needs_input_grad[1] else None
+    sink_g, sink_b = grad_sink(gamma), grad_sink(beta)
+    fused = sink_w is not None and sink_g is not None and sink_b is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+    gw = sink_w if fused else torch.empty_like(w)
+    ggamma = sink_g if fused else torch.empty_like(gamma)
+    gbeta = sink_b if fused else torch.empty_like(beta)
+    with torch.cuda.device_of(y), profiling.region(_tag3('classif_bwd', C, 1, 1, D, H, W), 4 * (3 * y.numel() + 4 * gcost.numel()),
+                                                   2 * 3 * gcost.numel() * C * 27, y.device):
+      ws = torch.empty(max(lib().mode_classif_workspace_bytes(B, C, D, H, W) // 4, 1), dtype=torch.float32, device=y.device)
+      check(lib().mode_classif_train_bwd(ptr(gcost), ptr(y), ptr(w), ptr(gamma), ptr(beta), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
+                                         ptr(saved[3]), ptr(gy), ptr(gw), ptr(ggamma), ptr(gbeta), int(fused), ptr(ws), B, C, D, H, W,
+                                         stream_of(y)), 'mode_classif_train_bwd')
+    if fused:
+      gw = ggamma = gbeta = None
+    return gy, gw, ggamma, gbeta, (gcost if ctx.has_add else None), None, None, None, None, None
+
+
+def classif_head_train(y, bn, conv, add=None):
+  """relu(bn(y)) -> conv (32 -> 1) [+ add] in training mode, fused (classif_fused_supported(y, bn, conv) must hold)."""
+  update = bn.training and bn.track_running_stats
+  nbt = bn.num_batches_tracked if update else None
+  if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+    nbt.add_(1)
+    nbt = None
+  return ClassifHeadFunction.apply(y, conv.weight, bn.weight, bn.bias, add, bn.running_mean if update else None,
+                                   bn.running_var if update else None, bn.momentum, bn.eps, nbt)
+
+
 # ------------------------------------------------------------------------------------ eval mode: convolution + folded BatchNorm
 # In inference every convbn / convbn_3d / sphereConvbn block (models/submodule.py:15-22, 61-74) is ONE launch: the BatchNorm
 # scale goes into the packed weights, shift / residual add / ReLU into the store of the convolution kernel (the *_bn entry points
@@ -1545,8 +1699,11 @@ def bn_foldable(bn, y_like=None):
 # launches, 0.65 ms of the 10.3 ms eval forward at one pair (profiles/r04_eval_b1_kernel_stats.txt).  In eval mode the weights do not
 # change between calls, so the *_bn_eval operators keep the workspace ON THE BatchNorm MODULE of the layer (it dies with the model:
 # no stale hit through a recycled address), keyed on the entry, the arithmetic and (data_ptr, _version) of the weight and of the four
-# BatchNorm tensors -- an optimizer step, load_state_dict or running-statistics update bumps a version and the next call repacks.  On
-# a hit the entry runs under mode_weight_pack_reuse(1) (include/mode_hip.h) and skips its pack kernels.
+# BatchNorm tensors -- an optimizer step, load_state_dict or running-statistics update bumps a version and the next call repacks (the
+# library's own training kernels write the running statistics through raw pointers and bump the counters themselves: _written_by_kernel).
+# Writes through `.data` are invisible to the counters: invalidate_eval_packs(module) after those.  On a hit the entry runs under
+# mode_weight_pack_reuse(1) (include/mode_hip.h) and skips its pack kernels.  A hipGraph captured from a forward that hit the cache
+# replays WITHOUT pack kernels: GraphedStep records the versions the hits relied on and refuses to replay once one has moved.
 EVAL_PACK_CACHE = True
 
 
@@ -1565,10 +1722,35 @@ class _PackReuse(object):
     return False
 
 
+_pack_tls = threading.local()
+
+
+def frozen_packs_begin():
+  """Start recording which (tensor, version) pairs the packed-weight cache vouches for on this thread (graph_step.GraphedStep calls this
+  around a capture): a captured eval forward that HITS the cache has no pack kernels in its graph -- its replays read the workspaces as
+  they were at capture time, so they are only valid while those versions stand."""
+  _pack_tls.log = []
+
+
+def frozen_packs_end():
+  log, _pack_tls.log = getattr(_pack_tls, 'log', None) or [], None
+  return log
+
+
+def invalidate_eval_packs(module):
+  """Drop every packed-weight workspace kept under `module`.  Needed only after writes torch cannot see -- `param.data.copy_()`,
+  `.data.mul_()`, raw-pointer writes from foreign code -- which do not move a version counter; optimizer steps, load_state_dict, in-place
+  torch ops and this library's own training kernels are noticed without it."""
+  for m in module.modules():
+    m.__dict__.pop('_mode_hip_packed', None)
+
+
 def _eval_wpack(bn, tag, w, nfloats, device):
   """(workspace, context manager to run the entry under): a kept workspace + pack reuse on a hit, a fresh one otherwise."""
   capturing = torch.cuda.is_current_stream_capturing()
-  if not EVAL_PACK_CACHE or bn is None:
+  # replicas of nn.DataParallel share the original module's __dict__ entries (a shallow copy) but hold freshly broadcast parameters at
+  # recycled addresses with version 0: no cache for them (train_disparity.py:264-265 only ever runs replicas in training anyway)
+  if not EVAL_PACK_CACHE or bn is None or getattr(bn, '_is_replica', False):
     return torch.empty(nfloats, dtype=torch.float32, device=device), _PackReuse(False)
   tens = (w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
   key = (tag, CONV_ARITH, nfloats, str(device), tuple(w.shape)) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tens)
@@ -1577,6 +1759,9 @@ def _eval_wpack(bn, tag, w, nfloats, device):
   if wp is not None:
     if capturing:  # a live graph now reads this workspace: it stays for the lifetime of the layer
       bn.__dict__.setdefault('_mode_hip_packed_pinned', []).append(wp)
+      log = getattr(_pack_tls, 'log', None)
+      if log is not None:
+        log.extend((t, t._version) for t in tens if t is not None)
     return wp, _PackReuse(True)
   wp = torch.empty(nfloats, dtype=torch.float32, device=device)
   if not capturing:  # (memory of a capture belongs to the graph's pool: not kept)

@@ -22,8 +22,19 @@ The graph's nodes hold the raw addresses of everything the kernels were launched
 mode_hip.functional (sampling tables, plans, adjoints).  Those caches are bounded LRUs; an entry they hand out while a capture is active
 is pinned (functional._LRU) and never evicted, so a live graph cannot be left pointing at freed tables however many other geometries
 the process touches afterwards.
+
+Fixed-weights contract of captured INFERENCE.  An eval-mode forward keeps the packed (BatchNorm-folded) weights of every layer between
+calls (functional._eval_wpack).  The warm-up above fills that cache, so the captured forward hits it and its graph contains NO pack
+kernels: a replay computes with the packs of capture time.  That is what makes a replayed eval forward cheaper than an eager one
+(0.65 ms of 10.3 at one pair), and it is only valid while the weights stand: the capture records (tensor, version) of everything the
+hits vouched for, and replay() raises once any of them has been written by torch (optimizer step, load_state_dict, in-place op) or by
+this library's training kernels; `stale()` tells without raising.  Writes through `.data` or foreign raw pointers move no version:
+call functional.invalidate_eval_packs(model) and capture again after those.  A captured TRAINING step packs inside the graph and is
+not affected.
 """
 import torch
+
+from . import functional
 
 
 class GraphedStep(object):
@@ -42,8 +53,13 @@ class GraphedStep(object):
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
     self.graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.graph, pool=pool):
-      self.outputs = fn()
+    functional.frozen_packs_begin()
+    try:
+      with torch.cuda.graph(self.graph, pool=pool):
+        self.outputs = fn()
+    finally:
+      # (tensor, version) pairs whose packed copies the captured kernels read WITHOUT repacking (see the contract above)
+      self.frozen = functional.frozen_packs_end()
     torch.cuda.synchronize(dev)
 
   def load(self, *tensors):
@@ -51,6 +67,13 @@ class GraphedStep(object):
     for dst, src in zip(self.static_inputs, tensors):
       dst.copy_(src, non_blocking=True)
 
+  def stale(self):
+    """True when a weight / BatchNorm tensor whose PACKED copy the graph reads has been written since the capture."""
+    return any(t._version != v for t, v in self.frozen)
+
   def replay(self):
+    if self.frozen and self.stale():
+      raise RuntimeError('GraphedStep: the weights of an eval-mode layer changed after this graph was captured; the graph reads the '
+                         'packed copies of capture time -- capture a new GraphedStep (see the fixed-weights contract in graph_step.py)')
     self.graph.replay()
     return self.outputs

@@ -65,6 +65,18 @@ def _shape_check(input, position, grad_output, weight, kH, kW, sH, sW, pH, pW, d
   return Ho, Wo
 
 
+def _computes_in_fp32(name, input):
+  """The reference dispatches its kernels with AT_DISPATCH_FLOATING_TYPES_AND_HALF (sphere_conv_cuda_kernel.cu:273, 367): double, float
+  and half tensors are accepted, anything else raises.  The gfx950 kernels are fp32: float64 and float16 tensors are converted on the
+  way in and the results converted back into the caller's buffers (float64 callers therefore get fp32 accuracy -- INTEGRATION.md says
+  so; float16 callers get MORE than the reference's half arithmetic).  Returns True when such a conversion is needed."""
+  if input.dtype == torch.float32:
+    return False
+  if input.dtype in (torch.float64, torch.float16):
+    return True
+  raise RuntimeError('"%s" not implemented for \'%s\'' % (name, str(input.dtype).replace('torch.', '')))  # (the text of AT_DISPATCH's error)
+
+
 def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, columns, kernel_h, kernel_w, stride_h, stride_w,
                              pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *, keep_transposed=None):
   """The 17 positional arguments of the reference op.  Keyword-only extension: pass a list as keep_transposed and the
@@ -74,6 +86,14 @@ def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, column
                         dilation_w, group)
   if tuple(output.shape) != (input.size(0), weight.size(0), Ho, Wo):
     raise RuntimeError('output has shape %s, expected %s' % (tuple(output.shape), (input.size(0), weight.size(0), Ho, Wo)))
+  if _computes_in_fp32('sphere_conv_forward_cuda', input):
+    out32 = torch.empty(output.shape, dtype=torch.float32, device=input.device)
+    sphere_conv_forward_cuda(input.float(), weight.float().contiguous(), None, None, position.float(), out32, None, kernel_h, kernel_w,
+                             stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, False)
+    output.copy_(out32)
+    if has_bias:
+      output += bias.view(1, -1, 1, 1)
+    return
   xt = _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group, return_transposed=True)
   if keep_transposed is not None and xt is not None:
     keep_transposed.append(xt)
@@ -89,6 +109,20 @@ def sphere_conv_backward_cuda(input, weight, bias, ones, position, columns, grad
   input_transposed = the plane-transposed copy of `input` kept from the forward (see sphere_conv_forward_cuda)."""
   _shape_check(input, position, grad_output, grad_weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
                dilation_w, group)
+  if _computes_in_fp32('sphere_conv_backward_cuda', input):
+    gi32 = torch.empty(grad_input.shape, dtype=torch.float32, device=input.device)
+    gw32 = torch.zeros(grad_weight.shape, dtype=torch.float32, device=input.device)
+    sphere_conv_backward_cuda(input.float(), weight.float().contiguous(), None, None, position.float(), None, gi32, gw32, None,
+                              grad_output.float(), kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, False,
+                              overwrite_grad_input=True)
+    if overwrite_grad_input:
+      grad_input.copy_(gi32)
+    else:
+      grad_input += gi32.to(grad_input.dtype)
+    grad_weight += gw32.to(grad_weight.dtype)
+    if has_bias:
+      grad_bias += grad_output.sum((0, 2, 3))
+    return
   gy = grad_output.contiguous()
   pos = position.contiguous()
   # one plane-transposed copy of grad_output serves both gradients (windowed weight gradient, transposed adjoint gather)

@@ -108,6 +108,43 @@ class ModeDisparity(nn.Module):
         m.bias.data.zero_()
 
   def forward(self, left, right):
+    cost1, cost2, cost3 = self._logits(left, right)
+    size = (self.maxdisp, left.size(2), left.size(3))
+    if self.training:
+      return stage3d.head(cost1, size), stage3d.head(cost2, size), stage3d.head(cost3, size)
+    if self.out_conf:
+      return stage3d.head(cost3, size, with_confidence=True)
+    return stage3d.head(cost3, size)
+
+  def forward_loss(self, left, right, disp_true, count=None, weights=(0.5, 0.7, 1.0)):
+    """The body of the reference's training iteration between zero_grad() and backward() in one call (train_disparity.py:150-158):
+        output1, output2, output3 = model(imgL, imgR)
+        loss = 0.5 * smooth_l1(output1[mask], disp_true[mask]) + 0.7 * smooth_l1(output2[mask], ...) + smooth_l1(output3[mask], ...)
+    with mask = the pixels that have a ground truth (NaN = none, train_disparity.py:195) and mean reduction over them.  An extension
+    (the reference has no such method): returns (loss, (pred1, pred2, pred3)) -- the same numbers as forward() + those lines, with the
+    loss and its gradient formed next to the soft-argmin heads (HF.head_loss) instead of by ~50 elementwise launches.  `count` = the number
+    of valid pixels as a 0-d device tensor when it is known already (data_parallel.global_valid_count: the GLOBAL count when the batch is
+    sharded over ranks); `disp_true` (B, 1, H, W) or (B, H, W) with NaN where there is no ground truth."""
+    if not self.training:
+      raise RuntimeError('forward_loss() is the training step; call the module itself for inference')
+    costs = self._logits(left, right)
+    size = (self.maxdisp, left.size(2), left.size(3))
+    gt = disp_true.reshape(left.size(0), 1, left.size(2), left.size(3))
+    if count is None:
+      count = (~torch.isnan(gt)).sum().to(torch.float32).clamp(min=1)
+    if HF.head_loss_supported(costs[0], size):
+      return HF.head_loss(costs, size, gt, count.reciprocal(), weights)
+    preds = tuple(stage3d.head(c, size) for c in costs)
+    mask = ~torch.isnan(gt)
+    gt0 = torch.nan_to_num(gt)
+    loss = 0
+    for wgt, o in zip(weights, preds):
+      per = F.smooth_l1_loss(o, gt0, reduction='none')
+      loss = loss + wgt * torch.where(mask, per, torch.zeros((), dtype=per.dtype, device=per.device)).sum() / count
+    return loss, tuple(p.detach() for p in preds)
+
+  def _logits(self, left, right):
+    """Everything up to the three classifier outputs cost1, cost2, cost3 (B, 1, D/4, H/4, W/4) (mode_disparity.py:98-129)."""
     if self.pair_extractor and left.shape == right.shape and not _cumulative_bn(self.feature_extraction):
       # One pass of the shared extractor over [left; right] instead of two: same arithmetic per sample, BatchNorm statistics
       # still per image set (stage3d.bn_groups), twice the work per kernel launch -- the extractor's kernels are small at the
@@ -145,12 +182,6 @@ class ModeDisparity(nn.Module):
     out3, pre3, post3 = self.dres4(out2, pre1[1], post2, residual=c0[3])  # pre1 (not pre2), as in the reference (:124)
 
     cost1 = stage3d.classify(self.classif1, out1)
-    cost2 = stage3d.classify(self.classif2, out2) + cost1
-    cost3 = stage3d.classify(self.classif3, out3) + cost2
-
-    size = (self.maxdisp, left.size(2), left.size(3))
-    if self.training:
-      return stage3d.head(cost1, size), stage3d.head(cost2, size), stage3d.head(cost3, size)
-    if self.out_conf:
-      return stage3d.head(cost3, size, with_confidence=True)
-    return stage3d.head(cost3, size)
+    cost2 = stage3d.classify(self.classif2, out2, add=cost1)  # = classif2(out2) + cost1 (reference :128)
+    cost3 = stage3d.classify(self.classif3, out3, add=cost2)
+    return cost1, cost2, cost3

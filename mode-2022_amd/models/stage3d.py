@@ -149,9 +149,21 @@ def bn_act_torch(bn, y, add=None, relu=False):
   return F.relu(y, inplace=True) if relu else y
 
 
-def classify(seq, x):
-  """classifN = Sequential(convbn_3d, ReLU, Conv3d(32->1)) (mode_disparity.py:76-80)."""
-  return conv3(seq[2], conv_bn(seq[0], x, relu=True))
+def classify(seq, x, *, add=None):
+  """classifN = Sequential(convbn_3d, ReLU, Conv3d(32->1)) (mode_disparity.py:76-80).  The keyword-only `add` is the residual the
+  reference adds right after the call (`cost2 = classif2(out2) + cost1`, mode_disparity.py:128-129).  Training: BatchNorm + ReLU +
+  the single-channel convolution + the add as one operator behind the first convolution (HF.classif_head_train); the activated
+  tensor between the two convolutions is never written."""
+  conv0, bn = seq[0][0], seq[0][1]
+  if (x.is_cuda and bn.training and torch.is_grad_enabled() and current_bn_groups() == 1 and _hip_kind(conv0, x) == 'conv1' and
+      conv0.out_channels > 1):
+    y = conv3(conv0, x)
+    if HF.classif_fused_supported(y, bn, seq[2]):
+      return HF.classif_head_train(y, bn, seq[2], add)
+    cost = conv3(seq[2], bn_act(bn, y, None, True))
+  else:
+    cost = conv3(seq[2], conv_bn(seq[0], x, relu=True))
+  return cost if add is None else cost + add
 
 
 def head(cost, size, with_confidence=False):

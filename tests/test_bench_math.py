@@ -81,15 +81,20 @@ def test_roofline_block_names_the_dominant_device_kernel():
 
 def test_kernel_of_names_device_kernels_that_really_ran():
   """kernel_of() must name the device kernel a label's launches run on -- every name it returns for the labels of a recorded
-  bench line is a kernel of the rocprofv3 --kernel-trace --stats file recorded with the same build (profiles/r04end_*), in both the
+  bench line is a kernel of the rocprofv3 --kernel-trace --stats file recorded with the same build (the newest profiles/r05*_ pair), in both the
   split and the fp32 pricing of the label (the real predicate, mode_hip's host-side *_supported queries: no GPU needed)."""
   import csv
   import json
   import os
   prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-  with open(os.path.join(prof, 'r04end_bench.json')) as f:
+  # the newest recorded pair (bench line, kernel stats of the same build): profiles/<tag>_bench.json + <tag>_rocprofv3_kernel_stats_*.csv
+  tags = sorted(f[:-len('_bench.json')] for f in os.listdir(prof) if f.endswith('_bench.json') and
+                os.path.exists(os.path.join(prof, f[:-len('_bench.json')] + '_rocprofv3_kernel_stats_bench_graph_steps2.csv')))
+  tag = tags[-1]
+  assert tag >= 'r05', tag
+  with open(os.path.join(prof, tag + '_bench.json')) as f:
     labels = list(json.load(f)['kernels'])
-  with open(os.path.join(prof, 'r04end_rocprofv3_kernel_stats_bench_graph_steps2.csv')) as f:
+  with open(os.path.join(prof, tag + '_rocprofv3_kernel_stats_bench_graph_steps2.csv')) as f:
     ran = [row['Name'] for row in csv.DictReader(f)]
   assert len(labels) > 60 and len(ran) > 60
   missing = []

@@ -374,6 +374,54 @@ def test_sphere_conv_layer4_full_size():
   assert torch.equal(y2, 2 * y)
 
 
+@pytest.mark.parametrize('B,D4,H4,W4', [(2, 4, 16, 8), (1, 12, 8, 16), (2, 48, 12, 32)])
+def test_head_loss_fused_equals_the_torch_composition(B, D4, H4, W4):
+  """HF.head_loss (mode_smooth_l1_masked + mode_head_bwd_loss: the masked smooth-L1 of train_disparity.py:151-158 formed next to the
+  heads) against the same loss written with torch ops on the three predictions of HF.head: value and the gradient of every logit."""
+  import torch.nn.functional as F
+  D, H, W = 4 * D4, 4 * H4, 4 * W4
+  costs = [(_rand((B, 1, D4, H4, W4), 70 + i) * 2).to(DEV).requires_grad_(True) for i in range(3)]
+  gt = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(5)) * (D / 2)
+  gt[torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(6)) < 0.1] = float('nan')
+  gt[0, 0, :2, :5] = 3 * D  # |pred - gt| > 1: the linear branch of the smooth-L1
+  gt = gt.to(DEV)
+  assert HF.head_loss_supported(costs[0], (D, H, W))
+  count = (~torch.isnan(gt)).sum().float()
+  loss, preds = HF.head_loss(costs, (D, H, W), gt, count.reciprocal())
+  loss.backward()
+  got = [c.grad.clone() for c in costs]
+  for c in costs:
+    c.grad = None
+  mask = ~torch.isnan(gt)
+  ref = 0
+  for wgt, c, p in zip((0.5, 0.7, 1.0), costs, preds):
+    o = HF.head(c, (D, H, W))
+    assert torch.equal(o.detach(), p) and not p.requires_grad
+    ref = ref + wgt * F.smooth_l1_loss(o[mask], gt[mask])
+  ref.backward()
+  assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+  for g, c in zip(got, costs):
+    err = float((g - c.grad).abs().max())
+    assert err <= 2e-6 * max(1e-6, float(c.grad.abs().max())) + 1e-12, err
+
+
+def test_head_backward_takes_the_two_kernel_form_beyond_512_columns():
+  """Rows wider than one 512-thread block (configs[4]: W = 1024) keep the per-pixel kernel + the row kernel; both forms agree."""
+  B, D4, H4, W4 = 1, 4, 4, 160
+  D, H, W = 16, 16, 640
+  logits = (_rand((B, 1, D4, H4, W4), 80) * 2).to(DEV).requires_grad_(True)
+  assert not HF.head_loss_supported(logits, (D, H, W))
+  go = _rand((B, 1, H, W), 81).to(DEV)
+  HF.head(logits, (D, H, W)).backward(go)
+  wide = logits.grad.clone()
+  # the same columns as two independent halves of 320 <= 512 pixels would need different interpolation weights: compare with autograd of the
+  # torch composition instead
+  import plain_ops
+  l2 = logits.detach().clone().requires_grad_(True)
+  plain_ops.head(l2, (D, H, W)).backward(go)
+  assert float((wide - l2.grad).abs().max()) <= 2e-5 * max(1.0, float(l2.grad.abs().max()))
+
+
 def test_native_seam_signature():
   """The reference's 17/20-argument pybind entry points (sphere_conv_cuda.cpp:339-345) work as documented."""
   from models.basic.spherical_conv import sphere_conv_cuda as ext
@@ -391,6 +439,33 @@ def test_native_seam_signature():
   assert (gb.cpu() - gy.sum((0, 2, 3))).abs().max() < 1e-3
   with pytest.raises(RuntimeError, match='invalid number of input planes'):
     ext.sphere_conv_forward_cuda(xd[:, :3].contiguous(), wd, bias, None, pd, out, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, False)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-4), (torch.float16, 2e-2)])
+def test_native_seam_takes_the_references_dtypes(dtype, tol):
+  """AT_DISPATCH_FLOATING_TYPES_AND_HALF (sphere_conv_cuda_kernel.cu:273, 367): double and half tensors are accepted at the native seam
+  (computed in fp32, converted back into the caller's buffers) and through SphereConvFunction; other dtypes raise like AT_DISPATCH."""
+  from models.basic.spherical_conv import sphere_conv_cuda as ext
+  from models.basic.spherical_conv.sphere_conv import sphere_conv
+  pos, x, w, gy = _sphere_case('Cassini', 32, 16, 2, 4, 8, 1, 1, 33)
+  xd, wd, pd, gyd = x.to(DEV, dtype), w.to(DEV, dtype), pos.to(DEV), gy.to(DEV, dtype)
+  out = torch.empty(2, 8, 32, 16, device=DEV, dtype=dtype)
+  ext.sphere_conv_forward_cuda(xd, wd, None, None, pd, out, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, False)
+  ref = sphere_conv_ref.forward(x, pos, w, (1, 1), (1, 1), (1, 1), 1)
+  assert out.dtype == dtype and (out.cpu().float() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+  gi, gw = torch.zeros_like(xd), torch.ones_like(wd)  # (accumulated into: the ones must still be there)
+  ext.sphere_conv_backward_cuda(xd, wd, None, None, pd, None, gi, gw, None, gyd, 3, 3, 1, 1, 1, 1, 1, 1, 1, False)
+  gx_ref, gw_ref = sphere_conv_ref.backward(x, pos, w, gy, (1, 1), (1, 1), (1, 1), 1)
+  assert (gi.cpu().float() - gx_ref).abs().max() < tol * max(1.0, float(gx_ref.abs().max()))
+  assert (gw.cpu().float() - 1 - gw_ref).abs().max() < 10 * tol * max(1.0, float(gw_ref.abs().max()))
+  xa, wa = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+  y = sphere_conv(xa, pd, wa, None, 1, 1, 1, 1)
+  y.backward(gyd)
+  assert y.dtype == dtype and xa.grad.dtype == dtype and wa.grad.dtype == dtype
+  assert (xa.grad.cpu().float() - gx_ref).abs().max() < tol * max(1.0, float(gx_ref.abs().max()))
+  with pytest.raises(RuntimeError, match='not implemented for'):
+    ext.sphere_conv_forward_cuda(xd.to(torch.bfloat16), wd.to(torch.bfloat16), None, None, pd, out.to(torch.bfloat16), None, 3, 3, 1, 1, 1, 1, 1, 1,
+                                 1, False)
 
 
 # ------------------------------------------------------------------ 3x3x3 convolution (a10-a12)

@@ -510,6 +510,93 @@ def test_under_nn_dataparallel_like_the_reference_call_sites():
   models.ModeDisparity(32, 'Sphere', 128, 64, 'Cassini').load_state_dict({k[len('module.'):]: v for k, v in sd.items()})
 
 
+def test_forward_loss_equals_forward_plus_the_references_loss_lines(golden):
+  """ModeDisparity.forward_loss (loss + gradient formed next to the heads) against forward() followed by the loss of
+  train_disparity.py:151-158 written with torch ops: same predictions (bit for bit), same loss, same gradient of every parameter."""
+  import torch.nn.functional as F
+  z = golden('model_tiny.npz')
+  net, left, right, gt, _ = _setup(z)
+  net.train()
+  state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+  mask = ~torch.isnan(gt)
+  o = net(left, right)
+  ref = 0.5 * F.smooth_l1_loss(o[0][mask], gt[mask]) + 0.7 * F.smooth_l1_loss(o[1][mask], gt[mask]) + F.smooth_l1_loss(o[2][mask], gt[mask])
+  ref.backward()
+  want = {k: p.grad.clone() for k, p in net.named_parameters()}
+  net.zero_grad()
+  with torch.no_grad():
+    for k, v in net.state_dict().items():
+      v.copy_(state[k])
+  loss, preds = net.forward_loss(left, right, gt)
+  loss.backward()
+  for a, b in zip(o, preds):
+    assert torch.equal(a.detach(), b)
+  assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+  num = sum(float(((p.grad - want[k]).double()**2).sum()) for k, p in net.named_parameters())
+  den = sum(float((want[k].double()**2).sum()) for k in want)
+  print('forward_loss vs forward + torch loss: whole-network gradient relative L2 %.3e' % (num / den)**0.5)
+  assert (num / den)**0.5 <= 1e-5
+  net.eval()
+  with pytest.raises(RuntimeError, match='training step'):
+    net.forward_loss(left, right, gt)
+
+
+def test_eval_pack_cache_notices_the_librarys_own_training_kernels(golden, monkeypatch):
+  """the training BatchNorm kernels write running_mean / running_var through raw pointers.  Eval, then a train-mode forward
+  under no_grad (BatchNorm re-estimation: only the running statistics change), then eval again: the second eval must repack -- it equals
+  the forward with the cache switched off and differs from the first."""
+  from mode_hip import functional as HF
+  z = golden('model_tiny.npz')
+  net, left, right, _, _ = _setup(z, bn_from_fixture=True)
+
+  def ev(cache):
+    monkeypatch.setattr(HF, 'EVAL_PACK_CACHE', cache)
+    net.eval()
+    with torch.no_grad():
+      return net(left, right).clone()
+
+  y0 = ev(True)
+  v0 = net.dres0[0][1].running_mean._version
+  net.train()
+  with torch.no_grad():
+    net(left, right)
+  assert net.dres0[0][1].running_mean._version > v0 and net.classif1[0][1].running_var._version > 0  # (plain BatchNorm pass and the fused head)
+  y1 = ev(True)
+  assert torch.equal(y1, ev(False))
+  assert not torch.equal(y1, y0)
+  # writes torch cannot see need the explicit call
+  net.dres2.conv1[0][0].weight.data.mul_(1.05)
+  stale = ev(True)
+  HF.invalidate_eval_packs(net)
+  fresh = ev(True)
+  assert torch.equal(fresh, ev(False)) and not torch.equal(fresh, stale)
+
+
+def test_captured_eval_forward_refuses_to_replay_on_changed_weights(golden):
+  """a GraphedStep captured from an eval forward that hit the packed-weight cache replays without pack kernels; it records the
+  versions it relied on and raises once a weight has been written (an optimizer step, load_state_dict, an in-place op)."""
+  from mode_hip.graph_step import GraphedStep
+  z = golden('model_tiny.npz')
+  net, left, right, _, _ = _setup(z, bn_from_fixture=True)
+  net.eval()
+
+  def fwd():
+    with torch.no_grad():
+      return net(left, right)
+
+  want = fwd().clone()
+  gs = GraphedStep(fwd, (left, right), warmup=1)
+  assert gs.frozen and not gs.stale()
+  assert torch.equal(gs.replay(), want)
+  with torch.no_grad():
+    net.dres3.conv2[0].weight.mul_(1.01)
+  assert gs.stale()
+  with pytest.raises(RuntimeError, match='changed after this graph was captured'):
+    gs.replay()
+  gs2 = GraphedStep(fwd, (left, right), warmup=1)
+  assert torch.equal(gs2.replay(), fwd())
+
+
 def test_eval_forward_keeps_packed_weights_and_notices_changes(golden, monkeypatch):
   """Inference keeps the packed weights of a layer on its BatchNorm module (functional._eval_wpack) and skips the pack kernels on later
   calls: the kept forward equals the repacking one bit for bit, the second call really reuses (mode_weight_pack_reuse), and an

@@ -303,3 +303,17 @@ def test_erp_tables_are_planned_through_their_transpose():
     assert post is not None and torch.equal(post, cas)
     assert HF.sphere_plan(post, 3, 3)[1] == HF.sphere_plan(cas, 3, 3)[1]
     assert HF.sphere_native_t(cas, 3, 3) is None and HF.sphere_uses_transposed_copies(cas, 3, 3) and not HF.sphere_uses_transposed_copies(erp, 3, 3)
+
+
+def test_build_notices_changed_compile_flags(tmp_path, monkeypatch):
+  """objects compiled with other flags (a MODE_HIP_DEFINES debug build) must not be taken for up to date."""
+  from mode_hip import build as hb
+  monkeypatch.setattr(hb, 'OBJ', str(tmp_path))
+  assert hb._flags_changed() is False  # empty directory: nothing to distrust, stamp written
+  assert hb._flags_changed() is False
+  monkeypatch.setattr(hb, 'FLAGS', hb.FLAGS + ['-DMODE_TAPTIME'])
+  assert hb._flags_changed() is True
+  assert hb._flags_changed() is False
+  os.remove(os.path.join(str(tmp_path), 'flags.sha'))
+  open(os.path.join(str(tmp_path), 'x.o'), 'w').close()
+  assert hb._flags_changed() is True  # objects of unknown origin

@@ -250,3 +250,39 @@ def test_tapwise_conv_oracle_equals_torch_conv3d(B, Ci, Co, D, H, W, stride):
   assert (conv_ref.conv3d_bwd_data(gy, w.detach(), x.shape, stride) - x.grad).abs().max() < 1e-12
   wt = torch.randn(Ci, Co, 3, 3, 3, generator=g, dtype=torch.float64)
   assert (conv_ref.deconv3d_fwd(x.detach(), wt) - F.conv_transpose3d(x.detach(), wt, None, 2, 1, 1)).abs().max() < 1e-12
+
+
+def test_three_training_steps_of_the_oracle_follow_the_imported_reference(golden):
+  """model_steps_tiny.npz (tests/golden/make_golden_steps.py): three iterations of the reference's own loop body (train_disparity.py:147-161,
+  Adam lr 1e-3).  The CPU restatement, stepped by the same optimizer, reproduces the losses, the BatchNorm running statistics after step 3
+  and the parameter update -- the fixture the GPU tier (tests/test_gpu_steps.py) then holds the product's graph-replayed step to."""
+  z = golden('model_steps_tiny.npz')
+  maxdisp, H, W, B, seed, K = [int(v) for v in z['cfg']]
+  P = recipe.recipe_state_wc(recipe.load_manifest(), seed)
+  names = [str(n) for n in z['names']]
+  for k in names:
+    P[k].requires_grad_(True)
+  p0 = {k: P[k].detach().clone().double() for k in names}
+  left, right = recipe.recipe_images(B, H, W, seed + 1)
+  gt = recipe.recipe_disparity_smooth(B, H, W, seed + 2, maxdisp)
+  mask = ~torch.isnan(gt)
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+  opt = torch.optim.Adam([P[k] for k in names], lr=1e-3, betas=(0.9, 0.999))
+  for step in range(K):
+    opt.zero_grad()
+    loss = mode_ref.training_loss(mode_ref.mode_disparity(P, left, right, maxdisp, pos, True), gt, mask)
+    loss.backward()
+    opt.step()
+    assert abs(float(loss.detach()) - z['loss'][step]) <= (2e-5 if step == 0 else 2e-4) * z['loss'][step], (step, float(loss.detach()), z['loss'][step])
+  for key in z.files:
+    if key.startswith('bn/'):
+      want = z[key].astype(np.float64)
+      assert np.abs(P[key[3:]].double().numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), key
+  rel = []
+  for i, k in enumerate(names):
+    d = (P[k].detach().double() - p0[k]).reshape(-1).numpy()
+    proj = recipe.projection_signs(seed, i, d.size, z['dproj'].shape[1]).astype(np.float64) @ d
+    rel.append((float(((proj - z['dproj'][i])**2).mean()) / max(z['dnorm'][i]**2, 1e-30))**0.5)
+  rel = np.array(rel)
+  print('relative L2 of the parameter update per tensor: median %.3e, max %.3e' % (np.median(rel), rel.max()))
+  assert np.median(rel) <= 2e-2 and rel.max() <= 0.5
