@@ -191,15 +191,19 @@ def kernel_of(label, conv_arith, on_split=None):
     return 'sum_n_kernel'  # (N-ary sum of the gradients that meet at a fan-out, functional.FanOutFunction)
   if name in ('head_fwd', 'head_bwd'):
     # one thread per pixel with the logit column in registers when maxdisp/4 is one of the instantiated depths (csrc/head.hip)
-    m = re.search(r'\[(\d+)x', label)
+    m = re.search(r'\[(\d+)x(\d+)x(\d+)\]', label)  # [D4 x H x W] of the full-resolution output
     fast = (not m) or int(m.group(1)) in (4, 8, 12, 16, 48, 64)
     if name == 'head_fwd':
       return 'head_fwd_fast_kernel' if fast else 'head_fwd_kernel'
+    if fast and ((not m) or int(m.group(3)) <= 512):  # one block per image row: per-pixel pass and row sums in one kernel
+      return 'head_bwd_pixrows_kernel+head_bwd_cols_kernel'
     return ('head_bwd_pix_fast_kernel' if fast else 'head_bwd_pix_kernel') + '+head_bwd_rows_kernel+head_bwd_cols_kernel'
   if name == 'classif_fwd':
     return 'bn_stats_kernel+classif_fwd_kernel'
-  if name == 'classif_bwd':
-    return 'classif_bww_kernel+classif_bwd_apply_kernel'
+  if name == 'classif_bwd':  # (rows that are multiples of 16 bytes: the 16-byte-access kernels of csrc/classif_head.hip)
+    return 'classif_bww2_kernel+classif_bwd_reduce_kernel+classif_bwd_apply2_kernel'
+  if name == 'smooth_l1_masked':
+    return 'smooth_l1_partial_kernel+smooth_l1_final_kernel'
   return {'bn_train_fwd': 'bn_stats_kernel+bn_apply_kernel', 'bn_train_bwd': 'bn_bwd_stats_kernel+bn_bwd_apply_kernel',
           'bn_eval_fwd': 'bn_eval_kernel',
           'cost_volume_fwd': 'cost_volume_fwd_v4', 'cost_volume_bwd': 'cost_volume_bwd_v4',

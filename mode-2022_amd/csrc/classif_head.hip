@@ -37,7 +37,9 @@ constexpr int ZTH = 16, ZIH = ZTH + 2, ZIW = 34, ZPL = ZIH * ZIW;
 constexpr int ZDC = 12;
 static_assert(ZIH + 2 == 4 * 5, "18 row groups + 36 halo-column positions in 2 groups = 5 groups per wave");
 
-template <bool BNRELU>  // false: the plain single-channel convolution (mode_conv3d_fwd with Co = 1, Ci <= 32: eval mode, other callers)
+// BNRELU false: the plain single-channel convolution (mode_conv3d_fwd with Co = 1, Ci <= 32: eval mode, other callers).
+// C32: exactly 32 channels (the network's heads): request addresses without vector arithmetic, see below; otherwise Ci <= 32, clamped.
+template <bool BNRELU, bool C32>
 __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ add, float* __restrict__ y, int B, int Ci, int D,
@@ -58,11 +60,15 @@ __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restr
   const float* xb = x + (long long)b * Ci * DHW;
 
   if (BNRELU && tid < 32) coefl[tid] = tid < Ci ? make_float2(scale[tid], shift[tid]) : make_float2(0.f, 0.f);
+  // K-step ks of the MFMA chain contracts the channel pair (ks, ks + 16): lanes 0..31 supply channel ks, lanes 32..63 channel ks + 16.
+  // (Any pairing works as long as A and B agree; with this one the channel offset of a request is ks * D*H*W for the WHOLE wave, i.e. it
+  // goes into the scalar base of the load and costs no vector instruction: the pairing (2 ks, 2 ks + 1) needed a multiply-add per request,
+  // 160 of the ~700 vector instructions a wave issued per plane beside its 80 MFMAs.)
   float a0[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    const int c = 2 * ks + kh;
-    a0[ks] = (j < 27 && c < Ci) ? w[c * 27 + j] : 0.f;
+    const int c = ks + 16 * kh;
+    a0[ks] = (j < 27 && c < Ci) ? w[min(c, Ci - 1) * 27 + min(j, 26)] : 0.f;
   }
   int poff[5], pz[5];
   bool pok[5];
@@ -87,19 +93,31 @@ __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restr
     poff[g5] = pok[g5] ? gh * W + gw : 0;
     pz[g5] = in ? row * ZIW + zc : -1;
   }
+  if (C32) {  // the upper half-wave's channels start 16 planes further
+#pragma unroll
+    for (int g5 = 0; g5 < 5; ++g5) poff[g5] += (int)((unsigned)(16 * kh) * (unsigned)DHW);
+  }
   const int wx = tid & 31, hq = tid >> 5;
   float om1[2] = {0.f, 0.f}, o0[2] = {0.f, 0.f};
 
   float bv[5][16];
   auto load_group = [&](int dz, int g5) {
     const float* xp = xb + (long long)dz * HW;
-    unsigned dhw = (unsigned)DHW;
-    asm volatile("" : "+s"(dhw));  // opaque: the 80 lane offsets are recomputed per plane, not kept live across the loop
-    // UNCONDITIONAL loads: positions outside the volume read voxel 0 (poff = 0) and are zeroed by a select before the MFMA, channels
-    // beyond Ci read channel Ci - 1 against a zero weight (a0).  A condition in the address (`ok ? off : 0` with a short-circuit &&) made
-    // every one of the 80 loads its own exec-masked basic block, and the vmcnt bookkeeping across those blocks degenerated to vmcnt(0).
+    // UNCONDITIONAL loads: positions outside the volume read voxel 0 of the half-wave's first channel and are zeroed by a select before
+    // the MFMA, channels beyond Ci read a lower channel against a zero weight (a0).  A condition in the address (`ok ? off : 0` with a
+    // short-circuit &&) made every one of the 80 loads its own exec-masked basic block, and the vmcnt bookkeeping across those blocks
+    // degenerated to vmcnt(0).  Address = wave-uniform base (plane, K-step channel) + this lane's 32-bit position offset.
+    if (C32) {
+      const unsigned pbyte = (unsigned)poff[g5] << 2;  // (byte offset: the scalar-base + 32-bit-lane-offset form of global_load)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bv[g5][ks] = xp[(unsigned)poff[g5] + (unsigned)min(2 * ks + kh, Ci - 1) * dhw];
+      for (int ks = 0; ks < 16; ++ks)
+        bv[g5][ks] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp + (long long)ks * DHW) + pbyte);
+    } else {
+      unsigned dhw = (unsigned)DHW;
+      asm volatile("" : "+s"(dhw));  // opaque: the 80 lane offsets are recomputed per plane, not kept live across the loop
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bv[g5][ks] = xp[(unsigned)poff[g5] + (unsigned)min(ks + 16 * kh, Ci - 1) * dhw];
+    }
   };
   // The planes this unit reads: dlo - 1 .. dhi, clipped to the volume (a plane outside it contributes nothing).  Every iteration issues
   // the SAME sequence of memory instructions -- the vector-memory counter is in-order and its waits are static counts, so one conditional
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restr
     // with all 80 requests behind the last MFMA a plane was a load phase (bandwidth share of the CU: ~16k cycles for both workgroups'
     // 156 KB) followed by a matrix phase (~10k), 30k in all.  (The last iteration re-requests its own plane: L2 hits, results unused.)
     f32x16 acc[5];
-    int co = kh;
+    int co = 16 * kh;
     const int dnext = min(dz + 1, dend);
 #pragma unroll
     for (int g5 = 0; g5 < 5; ++g5) {
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restr
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (BNRELU) {
-          const float2 cf = coefl[co + 2 * ks];
+          const float2 cf = coefl[co + ks];
           float a = __builtin_fmaf(bv[g5][ks], cf.x, cf.y);  // the BatchNorm apply pass's own expression (bn_act.hip)
           asm("" : "+v"(a));  // keeps neighbouring elements from being SLP-packed into v_pk_fma_f32 (does not overlap with MFMAs)
           acc[g5] = mfma32(a0[ks], pok[g5] ? relu_nan(a) : 0.f, acc[g5]);
@@ -174,7 +192,10 @@ __global__ __launch_bounds__(NT, 2) void classif_fwd_kernel(const float* __restr
       for (int kd = 0; kd < 3; ++kd) {
         float v = 0.f;
 #pragma unroll
-        for (int k9 = 0; k9 < 9; ++k9) v += zp[(kd * 9 + k9) * ZPL + (k9 / 3) * ZIW + (k9 % 3)];
+        for (int k9 = 0; k9 < 9; ++k9) {
+          v += zp[(kd * 9 + k9) * ZPL + (k9 / 3) * ZIW + (k9 % 3)];
+          asm volatile("" : "+v"(v));  // (the six chains of a thread stay scalar: no v_pk_add_f32)
+        }
         s[kd][o] = v;
       }
     }
@@ -287,7 +308,9 @@ __global__ __launch_bounds__(NT) void classif_bww_kernel(const float* __restrict
   float* pb = part + (long long)s * 2048;
   for (int idx = tid; idx < 2048; idx += NT) {
     const float* r = red + (idx >> 10) * 4096 + (idx & 1023);
-    pb[idx] = (r[0] + r[1024]) + (r[2048] + r[3072]);
+    float lo = r[0] + r[1024], hi = r[2048] + r[3072];
+    asm volatile("" : "+v"(lo), "+v"(hi));  // (keeps the unrolled iterations from being packed into v_pk_add_f32)
+    pb[idx] = lo + hi;
   }
 }
 
@@ -406,7 +429,9 @@ __global__ __launch_bounds__(NT) void classif_bww2_kernel(const float* __restric
   float* pb = part + (long long)s * 2048;
   for (int idx = tid; idx < 2048; idx += NT) {
     const float* r = red + (idx >> 10) * 4096 + (idx & 1023);
-    pb[idx] = (r[0] + r[1024]) + (r[2048] + r[3072]);
+    float lo = r[0] + r[1024], hi = r[2048] + r[3072];
+    asm volatile("" : "+v"(lo), "+v"(hi));  // (keeps the unrolled iterations from being packed into v_pk_add_f32)
+    pb[idx] = lo + hi;
   }
 }
 
@@ -553,10 +578,17 @@ __global__ __launch_bounds__(NT) void classif_bwd_apply_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) yv[r] = yb[ic * DHW + sp[r]];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float g = __builtin_fmaf(yv[r], k0.x, k0.y) > 0.f ? acc[r][q] : 0.f;
-      const float v = k0.z * g + k0.w * yv[r] + Cc;
-      if (rok[r] && i < Ci) gxb[i * DHW + sp[r]] = v;
+    for (int r = 0; r < 4; ++r) {  // (scalar chains with opaque intermediates: no packed fp32 on freshly loaded values, see the 16-byte kernel)
+      float yr = yv[r];
+      asm volatile("" : "+v"(yr));
+      float t = __builtin_fmaf(yr, k0.x, k0.y);
+      asm volatile("" : "+v"(t));
+      const float g = t > 0.f ? acc[r][q] : 0.f;
+      float v = __builtin_fmaf(k0.w, yr, Cc);
+      asm volatile("" : "+v"(v));
+      float res = __builtin_fmaf(k0.z, g, v);
+      asm volatile("" : "+v"(res));
+      if (rok[r] && i < Ci) gxb[i * DHW + sp[r]] = res;
     }
   }
 }
@@ -652,13 +684,23 @@ __global__ __launch_bounds__(NT) void classif_bwd_apply2_kernel(const float* __r
     const float4 k0 = *reinterpret_cast<const float4*>(ctab + ic * 8);
     const float Cc = ctab[ic * 8 + 4];
     const float ye[4] = {yv[q].x, yv[q].y, yv[q].z, yv[q].w};
+    // Scalar chains, every intermediate opaque: left alone the SLP vectoriser packs neighbouring elements into v_pk_fma_f32 with op_sel
+    // on the register pairs a 16-byte load has just written.  Packed fp32 does not overlap with the other waves' MFMAs on this SIMD
+    //  -- and on freshly loaded pairs it is the instruction shape behind round 4's non-repeatable adjoint kernel:
+    // with it this kernel gave different bits in 1 of 11 steps when a second process shared the GPU (tests/test_gpu_repeat.py).
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float g = __builtin_fmaf(ye[r], k0.x, k0.y) > 0.f ? acc[r][q] : 0.f;
-      float v = __builtin_fmaf(k0.w, ye[r], Cc);
-      asm("" : "+v"(v));  // scalar chains: packed fp32 (v_pk_fma_f32) does not overlap with the other waves' MFMAs on this SIMD
-      o[r] = __builtin_fmaf(k0.z, g, v);
+      float yr = ye[r];
+      asm volatile("" : "+v"(yr));
+      float t = __builtin_fmaf(yr, k0.x, k0.y);
+      asm volatile("" : "+v"(t));
+      const float g = t > 0.f ? acc[r][q] : 0.f;
+      float v = __builtin_fmaf(k0.w, yr, Cc);
+      asm volatile("" : "+v"(v));
+      float res = __builtin_fmaf(k0.z, g, v);
+      asm volatile("" : "+v"(res));
+      o[r] = res;
     }
     if (vok && i < Ci) *reinterpret_cast<float4*>(gxb + (unsigned)i * (unsigned)DHW + sp) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -708,10 +750,10 @@ extern "C" int mode_classif_train_fwd(const float* y, const float* gamma, const 
   if (rc != MODE_OK) return rc;
   const int nDc = mode::cdiv(D, ZDC), nHt = mode::cdiv(H, ZTH), nWt = mode::cdiv(W, 32);
   const size_t lds = (size_t)27 * ZPL * sizeof(float) + 32 * sizeof(float2);
-  rc = mode::allow_lds(classif_fwd_kernel<true>, lds, who);
+  auto kern = C == 32 ? classif_fwd_kernel<true, true> : classif_fwd_kernel<true, false>;
+  rc = mode::allow_lds(kern, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(classif_fwd_kernel<true>, dim3(B * nDc * nHt * nWt), dim3(NT), lds, st, y, w, save_scale, save_shift, add, cost, B, C, D, H,
-                     W, nDc, nHt, nWt);
+  hipLaunchKernelGGL(kern, dim3(B * nDc * nHt * nWt), dim3(NT), lds, st, y, w, save_scale, save_shift, add, cost, B, C, D, H, W, nDc, nHt, nWt);
   return mode::check_launch(who);
 }
 
@@ -719,10 +761,10 @@ extern "C" int mode_classif_train_fwd(const float* y, const float* gamma, const 
 int mode::conv3d_co1_fwd_small(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, hipStream_t st, const char* who) {
   const int nDc = mode::cdiv(D, ZDC), nHt = mode::cdiv(H, ZTH), nWt = mode::cdiv(W, 32);
   const size_t lds = (size_t)27 * ZPL * sizeof(float) + 32 * sizeof(float2);
-  int rc = mode::allow_lds(classif_fwd_kernel<false>, lds, who);
+  auto kern = Ci == 32 ? classif_fwd_kernel<false, true> : classif_fwd_kernel<false, false>;
+  int rc = mode::allow_lds(kern, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(classif_fwd_kernel<false>, dim3(B * nDc * nHt * nWt), dim3(NT), lds, st, x, w, nullptr, nullptr, nullptr, y, B, Ci, D, H, W,
-                     nDc, nHt, nWt);
+  hipLaunchKernelGGL(kern, dim3(B * nDc * nHt * nWt), dim3(NT), lds, st, x, w, nullptr, nullptr, nullptr, y, B, Ci, D, H, W, nDc, nHt, nWt);
   return mode::check_launch(who);
 }
 

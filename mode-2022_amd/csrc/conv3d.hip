@@ -468,6 +468,13 @@ __global__ __launch_bounds__(NT, EPI ? 2 : 1) void deconv3d_kernel(const float* 
 
   float* yb = y + (long long)b * d.Co * oDHW;
   const int qd = d0 + dz, qh = h0 + hy, qw = w0 + (lane & 31);
+  // the folded-BatchNorm shifts of this lane's 16 output channels, once: read inside the store loop (`epi.shift` may alias y as far as
+  // the compiler knows) every store waited for a load of its own -- 64 serialised L2 round trips per lane and tile (round 5, ISA scan)
+  float shv[16];
+  if (EPI) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) shv[q] = epi.shift[min(mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), d.Co - 1)];
+  }
   if (qd < d.D && qh < d.H && qw < d.W) {
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
@@ -480,24 +487,33 @@ __global__ __launch_bounds__(NT, EPI ? 2 : 1) void deconv3d_kernel(const float* 
         float2 res[16];
         if (EPI) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int o = min(mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), d.Co - 1);
-            res[q] = epi.add ? *reinterpret_cast<const float2*>(epi.add + (long long)b * d.Co * oDHW + o * oDHW + sp) : make_float2(0.f, 0.f);
+          for (int q = 0; q < 16; ++q) res[q] = make_float2(0.f, 0.f);
+          if (epi.add) {  // (one uniform test around the 16 loads, not one per load)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int o = min(mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), d.Co - 1);
+              res[q] = *reinterpret_cast<const float2*>(epi.add + (long long)b * d.Co * oDHW + o * oDHW + sp);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        auto emit = [&](int q) {
           const int o = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          if (o < d.Co) {
-            float2 v = make_float2(acc[pd][ph][0][q], acc[pd][ph][1][q]);
-            if (EPI) {  // torch's order: (convolution * scale + shift) + residual, then ReLU
-              const float sh = epi.shift[o];
-              v = make_float2((v.x + sh) + res[q].x, (v.y + sh) + res[q].y);
-              if (epi.relu) v = make_float2(relu_nan(v.x), relu_nan(v.y));
-            }
-            *reinterpret_cast<float2*>(yb + o * oDHW + sp) = v;
+          float2 v = make_float2(acc[pd][ph][0][q], acc[pd][ph][1][q]);
+          if (EPI) {  // torch's order: (convolution * scale + shift) + residual, then ReLU
+            const float sh = shv[q];
+            v = make_float2((v.x + sh) + res[q].x, (v.y + sh) + res[q].y);
+            if (epi.relu) v = make_float2(relu_nan(v.x), relu_nan(v.y));
           }
+          *reinterpret_cast<float2*>(yb + o * oDHW + sp) = v;
+        };
+        if (mt * 32 + 32 <= d.Co) {  // a full tile of output channels (uniform): 16 stores in one block -- with a test per channel every
+#pragma unroll                        // store was its own basic block behind a vmcnt(0), i.e. behind the store in front of it
+          for (int q = 0; q < 16; ++q) emit(q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5) < d.Co) emit(q);
         }
         if (EPI) __builtin_amdgcn_sched_barrier(0);
       }

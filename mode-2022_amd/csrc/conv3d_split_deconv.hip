@@ -18,6 +18,8 @@
 // 1 live in different waves and are stored one float each.
 #include "common.h"
 
+#include <type_traits>
+
 #include "conv3d_internal.h"
 
 namespace {
@@ -193,6 +195,10 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   for (int r = 0; r < 2; ++r) rowpos[r] = (2 * rp + r) * IW + (lane & 31);
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
   const uint4* wpm = wp + m * mstride + set * (7 * 192);
+  // (Round 5 also measured the request order "weight fragments a whole chunk ahead, the staging loads of chunk g + 2 at the end of chunk
+  // g" -- no wait of a chunk then reaches past the weights it needs, where the in-order vector-memory counter otherwise drags the HBM
+  // staging loads into a wait for an L2 weight fragment: same-box A/B 0.341-0.353 against 0.343-0.350 ms at 64 -> 32, 0.080 against
+  // 0.077 ms at 64 -> 64 (tools/experiments/deconv_ab.sh): not what bounds the kernel, not kept.)
   uint4 aring[7][3];  // slot = pair of the set; fetched three pairs ahead
   auto load_a = [&](int i, int ch) {
     const uint4* wq = wpm + ((long long)ch * NPAIR + i) * 192 + lane;
@@ -214,6 +220,12 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   }
   __syncthreads();
 
+  // The chunk loop exists TWICE, once per class set, and a wave enters the copy of its set: with `if (set == 0) ... else ...` INSIDE one loop
+  // the two paths use different accumulators (3 against 5 classes), the register allocator gave them different homes, and the join behind
+  // the branch paid for it with 117 v_accvgpr_write + 91 v_accvgpr_mov + 64 v_accvgpr_read per chunk and wave -- 272 of the loop's 446
+  // vector instructions beside its 84 MFMAs (round 5, tools/isa_mix.py).  Both copies execute the same barriers in the same order.
+  auto run = [&](auto set_tag) {
+  constexpr int SET = decltype(set_tag)::value;
   int ch = 0, k_tile = 0;
   for (int g = 0; g < G; ++g) {
     const uint4* src = sm + (g & 1) * BUF;
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     }                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-    if (set == 0)
+    if constexpr (SET == 0)
       {  // classes 0, 6, 7
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -291,22 +303,24 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
         if (gh < d.H && gw < d.W) {
           // running pointers, advanced by whole channel planes and made opaque after every step (left to itself the compiler computes
           // all store addresses of the two rows up front: ~200 registers next to the accumulators)
-          float* yb = y + ((long long)b * d.Co + m * 32 + 4 * half) * oDHW + (long long)(2 * d0) * oHW + (long long)(2 * gh) * oW + 2 * gw;
+          // (running OFFSETS from y, opaque after every step -- not running pointers: an opaque pointer loses its address space and the
+          // stores become flat_store, which count on both memory counters and made every chunk's first wait a vmcnt(0))
+          const long long yb = ((long long)b * d.Co + m * 32 + 4 * half) * oDHW + (long long)(2 * d0) * oHW + (long long)(2 * gh) * oW + 2 * gw;
           // set 0: class 0 -> (0,0,0) one float; classes 6, 7 -> (1,1,.) float2.  set 1: class 1 -> (0,0,1); 2, 3 -> (0,1,.); 4, 5 -> (1,0,.)
-          float* y1 = yb + (set == 0 ? 0 : 1);
-          float* y2a = yb + (set == 0 ? oHW + oW : oW);
-          float* y2b = yb + oHW;  // (set 1 only)
+          long long y1 = yb + (SET == 0 ? 0 : 1);
+          long long y2a = yb + (SET == 0 ? oHW + oW : oW);
+          long long y2b = yb + oHW;  // (set 1 only)
 #pragma unroll
           for (int qq = 0; qq < 16; ++qq) {
             const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
             asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
             if (o < d.Co) {
-              *y1 = acc[r][0][qq];
-              if (set == 0) {
-                *reinterpret_cast<float2*>(y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+              y[y1] = acc[r][0][qq];
+              if (SET == 0) {
+                *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
               } else {
-                *reinterpret_cast<float2*>(y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
-                *reinterpret_cast<float2*>(y2b) = make_float2(acc[r][3][qq], acc[r][4][qq]);
+                *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+                *reinterpret_cast<float2*>(y + y2b) = make_float2(acc[r][3][qq], acc[r][4][qq]);
               }
             }
             const long long step = ((qq & 3) == 3 ? 5 : 1) * oDHW;
@@ -323,6 +337,11 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     ch = ch_next;
     lds_barrier();
   }
+  };
+  if (set == 0)
+    run(std::integral_constant<int, 0>{});
+  else
+    run(std::integral_constant<int, 1>{});
 }
 
 }  // namespace

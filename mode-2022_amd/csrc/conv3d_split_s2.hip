@@ -115,7 +115,14 @@ __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of 
 // chunk's MFMAs (into registers), but their split + LDS stores form a phase of their own between two barriers -- which overlaps with
 // the MFMA phase of the CU's other workgroup.  With only 84 MFMAs per wave and chunk the staging arithmetic does not fit under them
 // (the stride-1 kernel has 336), and one wave per SIMD has nothing else to run while it waits.
-template <bool PHASED>
+// EPI: the eval-mode epilogue (folded BatchNorm shift, residual, ReLU) as its own instantiation.  As a run-time test inside the store loop
+// (`if (epi.shift) v = apply_epi(...)`: loads through a pointer that may alias y) it made the TRAINING kernel's epilogue 32 serialised
+// "LDS read -> wait -> store" round trips per lane and tile.
+// (Round 5 also tried the request order that pays in the transposed kernel -- weight fragments a whole chunk ahead, the staging loads of
+// chunk g + 2 issued in the commit phase of chunk g, so that no wait of a matrix phase reaches past its weights: 254 registers with 4
+// spilled, and a same-box A/B of 0.392-0.398 against 0.401-0.408 ms at 32 -> 64 and 0.087-0.090 against 0.083-0.085 ms at 64 -> 64:
+// not kept.)
+template <bool PHASED, bool EPI>
 __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                              float* __restrict__ y, S2Dims d, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [PHASED ? 1 : 2][3][PIECE], then the reduction area
@@ -299,14 +306,47 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
           const int gh = h0 + r;
           if (d0 < d.Do && gh < d.Ho && gw < d.Wo) {
             float* yb = y + (long long)b * d.Co * oDHW + d0 * oHW + (long long)gh * d.Wo + gw;
+            // eval mode: folded BatchNorm shift (+ residual) (+ ReLU); the shifts and residual values of HALF a row (8 channels) are
+            // requested together ahead of its stores (read next to the stores -- `shift` / `add` may alias y -- every store waited for two
+            // loads; a whole row at once spilled 34 registers at the two workgroups per CU this kernel runs at)
 #pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-              const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-              if (o < d.Co) {
-                float v = acc[r][qq] + red[(r * 16 + qq) * 64 + lane];
-                if (epi.shift) v = apply_epi(epi, v, o, (yb - y) + o * oDHW);  // eval mode: folded BatchNorm shift (+ residual) (+ ReLU)
-                yb[o * oDHW] = v;
+            for (int hq = 0; hq < 2; ++hq) {
+              float other[8];  // the odd-pair wave's sums of this half row: all 8 reads in flight before the first is used
+#pragma unroll
+              for (int q8 = 0; q8 < 8; ++q8) other[q8] = red[(r * 16 + 8 * hq + q8) * 64 + lane];
+              float shv[8], res[8];
+              if (EPI) {
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                  const int qq = 8 * hq + q8;
+                  const int o = min(m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
+                  shv[q8] = epi.shift[o];
+                  res[q8] = 0.f;
+                }
+                if (epi.add) {
+#pragma unroll
+                  for (int q8 = 0; q8 < 8; ++q8) {
+                    const int qq = 8 * hq + q8;
+                    const int o = min(m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
+                    res[q8] = epi.add[(yb - y) + o * oDHW];
+                  }
+                }
+                __builtin_amdgcn_sched_barrier(0);
               }
+#pragma unroll
+              for (int q8 = 0; q8 < 8; ++q8) {
+                const int qq = 8 * hq + q8;
+                const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+                if (o < d.Co) {
+                  float v = acc[r][qq] + other[q8];
+                  if (EPI) {
+                    v = (v + shv[q8]) + res[q8];
+                    v = epi.relu ? relu_nan(v) : v;
+                  }
+                  yb[o * oDHW] = v;
+                }
+              }
+              if (EPI) __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
@@ -353,9 +393,10 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
                      bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
   const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   constexpr size_t LDS1 = (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 65 536 B: two workgroups per CU
-  int rc = mode::allow_lds(conv3d_s2_split_kernel<true>, LDS1, who);
+  auto kern = epi.shift ? conv3d_s2_split_kernel<true, true> : conv3d_s2_split_kernel<true, false>;
+  int rc = mode::allow_lds(kern, LDS1, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_s2_split_kernel<true>, dim3(2 * kNumCU), dim3(NT), LDS1, st, x, reinterpret_cast<const uint4*>(wpack), y, d, epi);
+  hipLaunchKernelGGL(kern, dim3(2 * kNumCU), dim3(NT), LDS1, st, x, reinterpret_cast<const uint4*>(wpack), y, d, epi);
   return mode::check_launch(who);
 }
 

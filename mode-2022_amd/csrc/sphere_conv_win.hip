@@ -278,26 +278,40 @@ __device__ __forceinline__ void fwd_tile(const float* __restrict__ x, const floa
     const int cmax = d.Cog - mg * 128;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
-      float res[16];  // eval mode: the residual of this output tile, requested ahead of its stores (see sphere_fwd_split_kernel)
+      // eval mode: the shifts and the residual of this output tile, requested together ahead of its stores (see sphere_fwd_split_kernel)
+      float res[16], shv[16];
       if (EPI) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
-          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+          shv[r] = epi.shift[g * d.Cog + mg * 128 + co];
+          res[r] = 0.f;
+        }
+        if (epi.add) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+            res[r] = epi.add[(yb - y) + (long long)co * HW];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      auto emit = [&](int r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cmax) {
-          if (EPI) {  // folded BatchNorm shift (+ residual) (+ ReLU) on the way out
-            const float v = (acc[m][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
-            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
-          } else {
-            yb[(long long)co * HW] = acc[m][r];
-          }
+        if (EPI) {  // folded BatchNorm shift (+ residual) (+ ReLU) on the way out
+          const float v = (acc[m][r] + shv[r]) + res[r];
+          yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
+        } else {
+          yb[(long long)co * HW] = acc[m][r];
         }
+      };
+      if (m * 32 + 32 <= cmax) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) emit(r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < cmax) emit(r);
       }
       if (EPI) __builtin_amdgcn_sched_barrier(0);
     }
@@ -1209,26 +1223,41 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
     const int cmax = d.Cog - mg * 128;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
-      float res[16];
+      // (eval mode: the 16 shifts and the 16 residual values of this M-tile are requested TOGETHER ahead of its stores, under one uniform
+      // test each: read inside the store loop every store waited for a load of its own -- see sphere_fwd_split_kernel's epilogue)
+      float res[16], shv[16];
       if (EPI) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
-          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+          shv[r] = epi.shift[g * d.Cog + mg * 128 + co];
+          res[r] = 0.f;
+        }
+        if (epi.add) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+            res[r] = epi.add[(yb - y) + (long long)co * HW];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      auto emit = [&](int r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cmax) {
-          if (EPI) {
-            const float v = (acc[m][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
-            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
-          } else {
-            yb[(long long)co * HW] = acc[m][r];
-          }
+        if (EPI) {
+          const float v = (acc[m][r] + shv[r]) + res[r];
+          yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
+        } else {
+          yb[(long long)co * HW] = acc[m][r];
         }
+      };
+      if (m * 32 + 32 <= cmax) {  // (uniform) a full M-tile: no test per store
+#pragma unroll
+        for (int r = 0; r < 16; ++r) emit(r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < cmax) emit(r);
       }
       if (EPI) __builtin_amdgcn_sched_barrier(0);
     }
@@ -1545,6 +1574,15 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   // D[i = o][j = pixel of group gset + gi]
   const int hh = h0 + (wave / TW) * 32 + (lane & 31);
   const int cmax = d.Cog - mg * 128;
+  // eval mode: the 16 folded-BatchNorm shifts of this lane's output channels, ONCE (the same for the four pixel groups): read inside the
+  // store loop every store waited for a load of its own -- `shift` may alias y as far as the compiler knows (round 5, ISA scan: 256
+  // `s_waitcnt vmcnt(0)` in this kernel)
+  float shv[16];
+  if (EPI) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) shv[r] = epi.shift[g * d.Cog + mg * 128 + min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1)];
+  }
+  const bool full_m = m * 32 + 32 <= cmax;  // (uniform per wave) every channel of this M-tile exists: no test per store
 #pragma unroll
   for (int gi = 0; gi < 4; ++gi) {
     const int ww = w0 + gi;
@@ -1555,23 +1593,32 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       float res[16];
       if (EPI) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
-          res[r] = epi.add ? epi.add[(yb - y) + (long long)co * HW] : 0.f;
+        for (int r = 0; r < 16; ++r) res[r] = 0.f;
+        if (epi.add) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cmax - 1);
+            res[r] = epi.add[(yb - y) + (long long)co * HW];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      auto emit = [&](int r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cmax) {
-          if (EPI) {
-            const float v = (acc[gi][r] + epi.shift[g * d.Cog + mg * 128 + co]) + res[r];
-            yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
-          } else {
-            yb[(long long)co * HW] = acc[gi][r];
-          }
+        if (EPI) {
+          const float v = (acc[gi][r] + shv[r]) + res[r];
+          yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
+        } else {
+          yb[(long long)co * HW] = acc[gi][r];
         }
+      };
+      if (full_m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) emit(r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < cmax) emit(r);
       }
       if (EPI) __builtin_amdgcn_sched_barrier(0);
     }

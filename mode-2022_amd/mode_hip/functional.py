@@ -1352,6 +1352,11 @@ def deconv3d(x, w):
 
 
 # ------------------------------------------------------------------------------------ fused soft-argmin head
+def _tag_head(name, D4, H, W):
+  """Profiling label with the shape, e.g. head_bwd[48x1024x512] (nodes along the disparity axis x output height x output width)."""
+  return '%s[%dx%dx%d]' % (name, D4, H, W) if profiling.ENABLED else name
+
+
 def head_fwd(logits, size, with_confidence=False):
   """logits (B,1,D4,H4,W4) -> pred (B,1,H,W) [, conf (B,1,H,W)] for size = (D,H,W).
   Replaces mode_disparity.py:131-152 (+ :157-183 for the confidence map)."""
@@ -1365,7 +1370,7 @@ def head_fwd(logits, size, with_confidence=False):
   pred = torch.empty((B, 1, H, W), dtype=logits.dtype, device=logits.device)
   conf = torch.empty_like(pred) if with_confidence else None
   nbytes = 4 * (logits.numel() + pred.numel() * (2 if with_confidence else 1))
-  with torch.cuda.device_of(logits), profiling.region('head_fwd', nbytes, 0, logits.device):
+  with torch.cuda.device_of(logits), profiling.region(_tag_head('head_fwd', D4, H, W), nbytes, 0, logits.device):
     check(lib().mode_head_fwd(ptr(logits), ptr(pred), ptr(conf) if conf is not None else None, B, D4, H4, W4, D, H, W,
                               stream_of(logits)), 'mode_head_fwd')
   return (pred, conf) if with_confidence else pred
@@ -1379,7 +1384,7 @@ def head_bwd(logits, gpred, size):
   D, H, W = size
   gl = torch.empty_like(logits)
   nbytes = 4 * (2 * logits.numel() + gpred.numel())
-  with torch.cuda.device_of(logits), profiling.region('head_bwd', nbytes, 0, logits.device):
+  with torch.cuda.device_of(logits), profiling.region(_tag_head('head_bwd', D4, H, W), nbytes, 0, logits.device):
     n = lib().mode_head_bwd_workspace_bytes(B, D4, H, W)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=logits.device)
     check(lib().mode_head_bwd(ptr(logits), ptr(gpred), ptr(gl), ptr(ws), B, D4, H4, W4, D, H, W, stream_of(logits)),
@@ -1455,7 +1460,7 @@ class HeadLossFunction(torch.autograd.Function):
         continue
       B, _, D4, H4, W4 = c.shape
       gl = torch.empty_like(c)
-      with torch.cuda.device_of(c), profiling.region('head_bwd', 4 * (2 * c.numel() + 2 * p.numel()), 0, c.device):
+      with torch.cuda.device_of(c), profiling.region(_tag_head('head_bwd', D4, H, W), 4 * (2 * c.numel() + 2 * p.numel()), 0, c.device):
         ws = torch.empty(max(lib().mode_head_bwd_workspace_bytes(B, D4, H, W) // 4, 1), dtype=torch.float32, device=c.device)
         check(lib().mode_head_bwd_loss(ptr(c), ptr(p), ptr(gt), wt, ptr(sg), ptr(gl), ptr(ws), B, D4, H4, W4, D, H, W, stream_of(c)),
               'mode_head_bwd_loss')

@@ -37,8 +37,11 @@ def timed(fn, reps=5):
   return min(ts), out
 
 
-for name, fwd in (('fused', lambda: HF.classif_head_train(y, bn, conv, add)),
-                  ('unfused', lambda: HF.conv3d(HF.bn_act(bn, y, None, True), conv.weight, 1) + add)):
+VARIANTS = (('fused', lambda: HF.classif_head_train(y, bn, conv, add)),
+            ('unfused', lambda: HF.conv3d(HF.bn_act(bn, y, None, True), conv.weight, 1) + add))
+for name, fwd in VARIANTS:
+  if len(sys.argv) > 1 and name not in sys.argv[1:]:
+    continue
   for _ in range(2):
     fwd().backward(go)
   y.grad = None
