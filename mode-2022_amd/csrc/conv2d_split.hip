@@ -185,7 +185,10 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   constexpr bool ADD_AHEAD = EPI == 2 && MT * R * 16 <= 64;
   float shiftv[MT][16], addv[ADD_AHEAD ? MT : 1][ADD_AHEAD ? R : 1][16];
   const float relu_floor = (EPI && epi.relu) ? 0.f : -__builtin_inff();
-  if (EPI) {
+  // (the variant with the residual in its epilogue has no registers left for 32 shifts: kept across the tap loop they were spilled, and
+  // every store of the epilogue waited for its reload; it requests them with the residual values instead)
+  constexpr bool SHIFT_LATE = EPI == 2 && !ADD_AHEAD;
+  if (EPI && !SHIFT_LATE) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -289,18 +292,40 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
         if (gh < d.H && gw < d.W) {
           const int sp = gh * d.W + gw;
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m) {
+            // (where the residual values were not fetched ahead: the 16 of this row and channel block requested together in front of its
+            // stores -- read next to each store, `add` may alias y for all the compiler knows, every load waited for the store before it;
+            // a block wholly inside the layer's channels stores without a test per channel)
+            float res[16], shl[16];
+            if (EPI == 2 && !ADD_AHEAD) {
+              const float* ap = epi.add + (long long)b * d.Co * HWi + sp;
+              int mo = d.o0 + m * 32 + 4 * half;  // opaque: or the shift requests are hoisted out of the tile loop again (and spilled)
+              asm volatile("" : "+v"(mo));
 #pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-              const int o = d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-              if (o < d.Co) {
-                const long long idx = (long long)o * HWi + sp;
-                float v = acc[m][r][qq];
-                if (EPI) v += shiftv[m][qq];
-                if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : epi.add[(long long)b * d.Co * HWi + idx];
-                yb[idx] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+              for (int qq = 0; qq < 16; ++qq) {
+                const int oc = min(mo + (qq & 3) + 8 * (qq >> 2), d.Co - 1);
+                shl[qq] = epi.shift[oc];
+                res[qq] = ap[(long long)oc * HWi];
               }
+              __builtin_amdgcn_sched_barrier(0);
             }
+            auto emit = [&](int qq) {
+              const int o = d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              float v = acc[m][r][qq];
+              if (EPI) v += SHIFT_LATE ? shl[qq] : shiftv[m][qq];
+              if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : res[qq];
+              yb[(long long)o * HWi + sp] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+            };
+            if (d.o0 + m * 32 + 32 <= d.Co) {
+#pragma unroll
+              for (int qq = 0; qq < 16; ++qq) emit(qq);
+            } else {
+#pragma unroll
+              for (int qq = 0; qq < 16; ++qq)
+                if (d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half < d.Co) emit(qq);
+            }
+            if (EPI == 2 && !ADD_AHEAD) __builtin_amdgcn_sched_barrier(0);
+          }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][r] = (f32x16){0};

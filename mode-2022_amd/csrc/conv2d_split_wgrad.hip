@@ -216,18 +216,20 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
         const int ks = i / 3, kh = i % 3;
         // the next group under this one (branch-free; beyond the unit's last group it stages rows nobody reads): loads under the
         // first K-step, split + stores under the second
+        // (the next stage's fragment reads in front of the commits' LDS stores -- see conv3d_split_wgrad.hip)
+        if (i + 1 < 6) read_stage(i + 1);
         if (i < 3) {
 #pragma unroll
           for (int k = 3 * i; k < 3 * i + 3; ++k) load_x(k, h0 - DIL + 8);
 #pragma unroll
           for (int k = (GIT * i) / 3; k < (GIT * (i + 1)) / 3; ++k) load_g(k, h0 + 4);
-        } else {
+          __builtin_amdgcn_sched_barrier(0);  // in front of this stage's MFMAs (the group pattern below has no slot for them and put them
+        } else {                              // behind its 18 MFMAs: a third less lead to the commit three stages later)
 #pragma unroll
           for (int k = 3 * (i - 3); k < 3 * (i - 3) + 3; ++k) commit_x(k, h0 - DIL + 8, sfront);
 #pragma unroll
           for (int k = (GIT * (i - 3)) / 3; k < (GIT * (i - 2)) / 3; ++k) commit_g(k, h0 + 4, gbuf ^ 1);
         }
-        if (i + 1 < 6) read_stage(i + 1);
         uint4 bq[3][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -260,8 +262,9 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 18; ++j) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -272,6 +272,32 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
       for (int qq = 0; qq < 16; ++qq) shiftv[m][qq] = epi.shift[min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1)];
   }
+  // (EPI == 2) per tile, not per chunk: the element offset of this lane's pixel of row r inside channel 0 of the tile's sample (a cached
+  // dummy element for pixels outside the volume), and once per kernel the channel part of the 16 offsets -- a request is one 32-bit add
+  // on a uniform base.  (Computed in every chunk, with the tile's coordinates and 64-bit offsets, this took ~100 vector instructions at
+  // the top of each chunk and the registers that made the variant spill: 13 reloads, each behind an s_waitcnt vmcnt(0).)
+  unsigned ep_off[R], ep_chan[MT][16];
+  int ep_b = 0;
+  auto ep_tile = [&](int k) {
+    int b, d0, h0, w0;
+    tile_of(k, b, d0, h0, w0);
+    ep_b = __builtin_amdgcn_readfirstlane(b);  // uniform: the sample's base stays in scalar registers
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = wave * R + r;
+      const int gd = d0 + row / TH, gh = h0 + row % TH, gw = w0 + (lane & 31);
+      const unsigned ok = (unsigned)(gd < d.D) & (unsigned)(gh < d.H) & (unsigned)(gw < d.W);
+      ep_off[r] = ok ? (unsigned)(gd * (int)HW + gh * d.W + gw) : (unsigned)(lane & 31);
+    }
+  };
+  if (EPI == 2) {
+    ep_tile(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq)
+        ep_chan[m][qq] = (unsigned)min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1) * (unsigned)DHW;
+  }
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
 
   // weight fragments: a ring of 7 tap pairs, fetched 6 pairs ahead (their loads queue behind the 48 staging loads of a chunk)
@@ -305,20 +331,14 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     // the chunk staged under this one; after the last chunk it is staged once more into the idle buffer, which keeps the loop body
     // free of branches (a branch would pin the staging code to one spot instead of letting it spread between the MFMAs)
     stage_begin(min(g + 1, G - 1));
-    int ep_off[R];  // (EPI == 2) element offset of this lane's pixel of row r inside the output sample, or of a dummy element
+    // (EPI == 2) where this chunk's residual requests go: the tile's pixels in its last chunk, a cached dummy row in the others
+    unsigned ep_cur[R];
     const float* ep_base = epi.add;
     if (EPI == 2) {
-      int b, d0, h0, w0;
-      tile_of(k_tile, b, d0, h0, w0);
       const bool last = ch == d.NCHUNK - 1;
-      ep_base = epi.add + (last ? (long long)b * d.Co * DHW : 0);
+      ep_base = epi.add + (long long)(last ? ep_b : 0) * d.Co * DHW;  // (a select of the index, not of the product: no branch here)
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = wave * R + r;
-        const int gd = d0 + row / TH, gh = h0 + row % TH, gw = w0 + (lane & 31);
-        const unsigned ok = (unsigned)last & (unsigned)(gd < d.D) & (unsigned)(gh < d.H) & (unsigned)(gw < d.W);
-        ep_off[r] = ok ? (int)(gd * HW + (long long)gh * d.W + gw) : -1;
-      }
+      for (int r = 0; r < R; ++r) ep_cur[r] = last ? ep_off[r] : (unsigned)(lane & 31);
     }
     uint4 bq[2][R][3];
 #pragma unroll
@@ -348,10 +368,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int qq = 8 * (pair & 1); qq < 8 * (pair & 1) + 8; ++qq) {
-            const int o = min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
-            addv[m][r][qq] = ep_base[ep_off[r] >= 0 ? (long long)o * DHW + ep_off[r] : (lane & 31)];
-          }
+          for (int qq = 8 * (pair & 1); qq < 8 * (pair & 1) + 8; ++qq) addv[m][r][qq] = ep_base[ep_cur[r] + ep_chan[m][qq]];
       }
       if (pair >= NPAIR - KIT) {
         stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 0);
@@ -412,6 +429,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
         for (int m = 0; m < MT; ++m) acc[m][r] = (f32x16){0};
       }
       ++k_tile;
+      if (EPI == 2) ep_tile(min(k_tile, max(mine - 1, 0)));
     }
     ch = ch_next;
     lds_barrier();
@@ -503,6 +521,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.NCHUNK = cdiv(K, 8);
   MODE_REQUIRE(conv3d_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the split kernel", who,
                rows, K);
+  MODE_REQUIRE((long long)rows * D * H * W < (1ll << 31), MODE_ERR_UNSUPPORTED, "%s: a sample of the output has 2^31 elements or more", who);
   d.nWt = cdiv(W, 32);
   d.nHt = cdiv(H, TH);
   d.nDt = cdiv(D, TD);

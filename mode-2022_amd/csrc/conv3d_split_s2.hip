@@ -301,6 +301,8 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
         int b, d0, h0, w0;
         tile_of(k_tile, b, d0, h0, w0);
         const int gw = w0 + (lane & 31);
+        int mo = m * 32 + 4 * half;  // opaque: the 16 clamped channel offsets derived from it are loop invariants the compiler otherwise
+        if (EPI) asm volatile("" : "+v"(mo));  // keeps in registers across the chunk loop (34 spilled registers)
 #pragma unroll
         for (int r = 0; r < TH; ++r) {
           const int gh = h0 + r;
@@ -309,34 +311,35 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
             // eval mode: folded BatchNorm shift (+ residual) (+ ReLU); the shifts and residual values of HALF a row (8 channels) are
             // requested together ahead of its stores (read next to the stores -- `shift` / `add` may alias y -- every store waited for two
             // loads; a whole row at once spilled 34 registers at the two workgroups per CU this kernel runs at)
+            constexpr int HB = EPI ? 4 : 8;  // channels per batch
 #pragma unroll
-            for (int hq = 0; hq < 2; ++hq) {
-              float other[8];  // the odd-pair wave's sums of this half row: all 8 reads in flight before the first is used
+            for (int hq = 0; hq < 16 / HB; ++hq) {
+              float other[HB];  // the odd-pair wave's sums of this half row: all 8 reads in flight before the first is used
 #pragma unroll
-              for (int q8 = 0; q8 < 8; ++q8) other[q8] = red[(r * 16 + 8 * hq + q8) * 64 + lane];
-              float shv[8], res[8];
+              for (int q8 = 0; q8 < HB; ++q8) other[q8] = red[(r * 16 + HB * hq + q8) * 64 + lane];
+              float shv[HB], res[HB];
               if (EPI) {
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) {
-                  const int qq = 8 * hq + q8;
-                  const int o = min(m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
+                for (int q8 = 0; q8 < HB; ++q8) {
+                  const int qq = HB * hq + q8;
+                  const int o = min(mo + (qq & 3) + 8 * (qq >> 2), d.Co - 1);
                   shv[q8] = epi.shift[o];
                   res[q8] = 0.f;
                 }
                 if (epi.add) {
 #pragma unroll
-                  for (int q8 = 0; q8 < 8; ++q8) {
-                    const int qq = 8 * hq + q8;
-                    const int o = min(m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
+                  for (int q8 = 0; q8 < HB; ++q8) {
+                    const int qq = HB * hq + q8;
+                    const int o = min(mo + (qq & 3) + 8 * (qq >> 2), d.Co - 1);
                     res[q8] = epi.add[(yb - y) + o * oDHW];
                   }
                 }
                 __builtin_amdgcn_sched_barrier(0);
               }
 #pragma unroll
-              for (int q8 = 0; q8 < 8; ++q8) {
-                const int qq = 8 * hq + q8;
-                const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              for (int q8 = 0; q8 < HB; ++q8) {
+                const int qq = HB * hq + q8;
+                const int o = mo + (qq & 3) + 8 * (qq >> 2);
                 if (o < d.Co) {
                   float v = acc[r][qq] + other[q8];
                   if (EPI) {

@@ -52,12 +52,13 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 __device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
   // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
   // instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
+  // One of the pair as a subtraction, the other as fma(-1, piece, value) (the same exact difference): two different operations are not
+  // packed, and no empty asm statement is needed to keep them apart -- the scheduler's group pattern places plain VALU instructions
+  // under the MFMAs, an inline-asm node in a chain it left (with everything behind it) for the end of the K-step.
   p1 = pack2(a, b);
-  float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
-  asm("" : "+v"(ra), "+v"(rb));
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p1 & 0xffff0000u), b);
   p2 = pack2(ra, rb);
-  float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
-  asm("" : "+v"(sa), "+v"(sb));
+  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p2 & 0xffff0000u), rb);
   p3 = pack2(sa, sb);
 }
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
@@ -246,11 +247,16 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
           for (int k = 0; k < 5; ++k) load_x(k, dd + 2);
 #pragma unroll
           for (int k = 0; k < GIT; ++k) load_g(k, dd + 1);
-        }
+          __builtin_amdgcn_sched_barrier(0);  // (in front of this K-step's MFMAs: left to the group pattern below, which has no slot for
+        }                                     // them, the requests were placed behind its 42 MFMAs -- half the lead to their commit)
         if (ks == 1) {
 #pragma unroll
           for (int k = 5; k < XIT; ++k) load_x(k, dd + 2);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        // (the next K-step's fragment reads in front of the commits: behind them in program order they could not be placed ahead of the
+        // commits' LDS stores -- the compiler does not know the buffers are different -- and ended up, with the stores, behind the MFMAs)
+        if (ks + 1 < 2 * WTH) read_raw(ks + 1, (ks + 1) & 1);
         if (ks == 2) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) commit_x(k, dd + 2);
@@ -263,7 +269,6 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 #pragma unroll
           for (int k = GIT / 2; k < GIT; ++k) commit_g(k, dd + 1);
         }
-        if (ks + 1 < 2 * WTH) read_raw(ks + 1, (ks + 1) & 1);
         // the fragment of tap kw is elements kw .. kw + 7 of the 10: one v_perm_b32 per dword with the byte selector of the shift (an
         // MFMA operand is an even-aligned register quadruple: "dwords 1..4" is not addressable as such)
         uint4 a[3], bq[7][3];
@@ -296,8 +301,9 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 42; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -1697,11 +1697,14 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     return it;
   };
   // x window staging exactly as in sphere_bww_win_kernel
-  const int xcol = d.sh == 1 ? tid >> 6 : tid & (WC - 1), xrow = d.sh == 1 ? tid & 63 : tid >> 3;
-  const bool xrow_ok = xrow < WRP;
+  // (staging coordinates recomputed from an opaque copy of the thread index where they are used -- see issue_gy)
   float pxw[BW_NXW];
   bool pxw_ok = false;
   auto issue_xw = [&](const Item& it, int part) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int xcol = d.sh == 1 ? t_ >> 6 : t_ & (WC - 1), xrow = d.sh == 1 ? t_ & 63 : t_ >> 3;
+    const bool xrow_ok = xrow < WRP;
     pxw_ok = xrow_ok && it.cbase + xcol < d.W;
     const int grow = (it.rbase + (xrow_ok ? xrow : 0)) % d.H;
     const float* xg = x + ((long long)it.b * d.Ci + (long long)g * d.Cig + (long long)cg * BW_CG) * HW +
@@ -1710,7 +1713,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     for (int c = 0; c < BW_NXW; ++c) pxw[c] = xg[(long long)min(part * BW_NXW + c, cmax - 1) * HW];
   };
   auto commit_xw = [&](float* xwdst, int part) {
-    if (xrow_ok) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int xcol = d.sh == 1 ? t_ >> 6 : t_ & (WC - 1), xrow = d.sh == 1 ? t_ & 63 : t_ >> 3;
+    if (xrow < WRP) {
       float* dst = xwdst + xcol * WRP + xrow;
 #pragma unroll
       for (int c = 0; c < BW_NXW; ++c) dst[(part * BW_NXW + c) * BW_CP] = (pxw_ok && part * BW_NXW + c < cmax) ? pxw[c] : 0.f;
@@ -1718,7 +1724,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
   };
   // gy is requested TWO columns ahead (a column lasts ~1.5 us, less than a trip to HBM under load: with one column of lead the
   // commit between the two barriers waited for it -- measured 0.08 ms of a 0.36 ms call), into two register sets
-  const int gpp = tid & 15, go0 = tid >> 4;
+  const int gpp_ = tid & 15, go0_ = tid >> 4;
+  const int gpp = gpp_, go0 = go0_;
   struct GyPF {
     float g0[4], g1[4];
     unsigned ok;  // bit 2u: first pixel of pair real, bit 2u + 1: second
@@ -1728,6 +1735,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
   float4 prw0, prw1, prw8;
   int pro0, pro1, pro8;
   auto issue_gy = [&](const Item& it, int wc, GyPF& pf) {
+    // (gpp / go0 through an opaque copy: the row and the four clamped channel offsets derived from them are loop invariants, and kept
+    // across the column loop they were the registers the allocator spilled -- every column began with two scratch reloads, each behind an
+    // s_waitcnt vmcnt(0) that also drained the gy requested for the column after next.  Recomputed here they cost ~12 instructions.)
+    int gpp = gpp_, go0 = go0_;
+    asm volatile("" : "+v"(gpp), "+v"(go0));
     const int h = it.h0 + 2 * gpp, w = it.w0 + wc;
     const bool ok0 = h < d.H && w < d.W, ok1 = h + 1 < d.H && w < d.W;
     const float* gyb0 = gy + ((long long)it.b * d.Co + (long long)g * d.Cog + (long long)mg * 128) * HW +
@@ -1856,13 +1868,13 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       const bool have_next = !last_col || more_items;
       const float4 rw1 = prw1, rw8 = prw8;
       const int ro1 = pro1, ro8 = pro8;
-      // gy of the column after next (its register set held this column's gy, committed at the end of the previous column)
-      if (wc < 2)
-        issue_gy(cur, wc + 2, gpf[wc & 1]);
-      else if (more_items)
-        issue_gy(nxt, wc - 2, gpf[wc & 1]);
-      if (have_next) issue_rec(last_col ? nxt : cur, last_col ? 0 : wc + 1);
-      if (more_items) issue_xw(nxt, wc);
+      // Requests in the order they are consumed (vmcnt retires in order): the next item's window part (committed at the end of this
+      // column), the next column's records, and last the gy of the column after next (its register set held this column's gy, committed
+      // at the end of the previous column) -- requested first, the window commit's wait drained it too.  All unconditional (`nxt` is
+      // the current item again when there is no next one): a request under a branch turns the waits behind it into vmcnt(0).
+      issue_xw(nxt, wc);
+      issue_rec(last_col ? nxt : cur, last_col ? 0 : wc + 1);
+      issue_gy(wc < 2 ? cur : nxt, wc < 2 ? wc + 2 : wc - 2, gpf[wc & 1]);
       __builtin_amdgcn_sched_barrier(0);
 
       uint4 a[4][3], b1[3], b8[3];
