@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 21 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 22 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -386,6 +386,12 @@ int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilo
 int mode_deconv3d_split_supported(int Cin, int Cout);
 int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpack, int B, int Cin, int D, int H, int W, int Cout,
                             mode_stream_t stream);
+/* The same with the folded eval-mode BatchNorm (+ residual) (+ ReLU) epilogue of mode_deconv3d_fwd_bn (convbn_3d around the
+ * ConvTranspose3d of hourglass conv5 / conv6 in eval mode, mode_disparity.py:23-25, 38-45): whole 32-channel output tiles
+ * (mode_deconv3d_split_bn_supported(Cin, Cout) == 1); wpack >= mode_conv3d_wpack_bytes(Cin, Cout). */
+int mode_deconv3d_split_bn_supported(int Cin, int Cout);
+int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin, int D,
+                               int H, int W, int Cout, mode_stream_t stream);
 int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                   mode_stream_t stream);
 /* The weight gradient of the stride-2 convolution on the split-bf16 kernel of csrc/conv3d_split_wgrad_s2.hip (the gradients cuDNN

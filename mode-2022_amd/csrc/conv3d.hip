@@ -642,6 +642,17 @@ extern "C" int mode_deconv3d_fwd_split(const float* x, const float* w, float* y,
   return mode::deconv3d_split(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who);
 }
 
+extern "C" int mode_deconv3d_split_bn_supported(int Cin, int Cout) { return mode::deconv3d_split_bn_supported(Cin, Cout) ? 1 : 0; }
+
+extern "C" int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin,
+                                          int D, int H, int W, int Cout, mode_stream_t stream) {
+  const char* who = "mode_deconv3d_fwd_split_bn";
+  int rc = check_conv_args(x, w, y, wpack, B, Cin, D, H, W, Cout, 1, who);
+  if (rc == MODE_OK) rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  return mode::deconv3d_split(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who, bn);
+}
+
 extern "C" int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,
                                           int Co, mode_stream_t stream) {
   const char* who = "mode_conv3d_bwd_data_split";

@@ -76,8 +76,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
 
 // wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of W[c = ch*8 + j][o = m*32 + (lane & 31)]
 // [tap = pair_tap(pair, lane >> 5)], j = 0..7, from the (K, Co, 27) weight of the transposed convolution; zero for the empty tap, o >= Co, c >= K
-__global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __restrict__ wp, int K, int Co, int MTr, int NCHUNK) {
+// fold: output channel o scaled by the folded BatchNorm scale, the shifts written to the floats at wp + 3 * total (eval mode)
+__global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __restrict__ wp, int K, int Co, int MTr, int NCHUNK, int fold,
+                                      mode_bn_epilogue bn) {
   const long long total = (long long)MTr * NCHUNK * NPAIR * 64;
+  if (fold && blockIdx.x == 0) {
+    float* shifts = reinterpret_cast<float*>(wp + total * 3);
+    for (int o = threadIdx.x; o < Co; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     long long r = idx >> 6;
@@ -92,6 +98,7 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
     for (int j = 0; j < 8; ++j) {
       const int c = ch * 8 + j;
       v[j] = (o < Co && c < K && tap >= 0) ? w[((long long)c * Co + o) * 27 + tap] : 0.f;
+      if (fold && o < Co) v[j] *= fold_scale(bn, o);
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -105,9 +112,11 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
 
 // MT = output-channel tiles per launch.  MT = 2 (33..64 output channels): waves = 2 tiles x 2 class sets on a tile of 2 rows;
 // MT = 1: waves = 2 class sets x 2 row pairs on a tile of 4 rows.  One low-resolution depth plane per tile (+ its halo plane).
-template <int MT>
+// EPI: the eval-mode epilogue (folded-BatchNorm shift, optional residual, optional ReLU) as its own instantiation; needs whole 32-channel
+// output tiles (Co % 32 == 0: no test per channel between the batched requests and their stores).
+template <int MT, bool EPI>
 __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                                float* __restrict__ y, DcDims d) {
+                                                                float* __restrict__ y, DcDims d, Epi epi) {
   constexpr int TH = 4 / MT, IH = TH + 1;
   constexpr int ITEMS = 2 * IH * IW;
   static_assert(ITEMS <= PIECE, "tile does not fit the staging map");
@@ -195,6 +204,11 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   for (int r = 0; r < 2; ++r) rowpos[r] = (2 * rp + r) * IW + (lane & 31);
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
   const uint4* wpm = wp + m * mstride + set * (7 * 192);
+  float shv[16];  // (EPI) the folded shifts of this lane's 16 output channels, once per kernel
+  if (EPI) {
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) shv[qq] = epi.shift[m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half];
+  }
   // (Round 5 also measured the request order "weight fragments a whole chunk ahead, the staging loads of chunk g + 2 at the end of chunk
   // g" -- no wait of a chunk then reaches past the weights it needs, where the in-order vector-memory counter otherwise drags the HBM
   // staging loads into a wait for an L2 weight fragment: same-box A/B 0.341-0.353 against 0.343-0.350 ms at 64 -> 32, 0.080 against
@@ -310,23 +324,71 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
           long long y1 = yb + (SET == 0 ? 0 : 1);
           long long y2a = yb + (SET == 0 ? oHW + oW : oW);
           long long y2b = yb + oHW;  // (set 1 only)
+          if constexpr (!EPI) {
 #pragma unroll
-          for (int qq = 0; qq < 16; ++qq) {
-            const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-            asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
-            if (o < d.Co) {
-              y[y1] = acc[r][0][qq];
-              if (SET == 0) {
-                *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
-              } else {
-                *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
-                *reinterpret_cast<float2*>(y + y2b) = make_float2(acc[r][3][qq], acc[r][4][qq]);
+            for (int qq = 0; qq < 16; ++qq) {
+              const int o = m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
+              asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
+              if (o < d.Co) {
+                y[y1] = acc[r][0][qq];
+                if (SET == 0) {
+                  *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+                } else {
+                  *reinterpret_cast<float2*>(y + y2a) = make_float2(acc[r][1][qq], acc[r][2][qq]);
+                  *reinterpret_cast<float2*>(y + y2b) = make_float2(acc[r][3][qq], acc[r][4][qq]);
+                }
               }
+              const long long step = ((qq & 3) == 3 ? 5 : 1) * oDHW;
+              y1 += step;
+              y2a += step;
+              y2b += step;
             }
-            const long long step = ((qq & 3) == 3 ? 5 : 1) * oDHW;
-            y1 += step;
-            y2a += step;
-            y2b += step;
+          } else {
+            // eval: (sum + shift) + residual, ReLU as torch computes it; the residual values of FOUR channels (up to 20 floats) are
+            // requested together ahead of their stores (`add` may alias y for all the compiler knows: a load next to each store waits
+            // for the store in front of it)
+            const bool has_add = epi.add != nullptr;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              float r1[4];
+              float2 r2a[4], r2b[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                r1[i] = 0.f;
+                r2a[i] = r2b[i] = make_float2(0.f, 0.f);
+              }
+              if (has_add) {
+                long long a1 = y1, a2a = y2a, a2b = y2b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  asm volatile("" : "+v"(a1), "+v"(a2a), "+v"(a2b));
+                  r1[i] = epi.add[a1];
+                  r2a[i] = *reinterpret_cast<const float2*>(epi.add + a2a);
+                  if (SET == 1) r2b[i] = *reinterpret_cast<const float2*>(epi.add + a2b);
+                  a1 += oDHW;
+                  a2a += oDHW;
+                  a2b += oDHW;
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int qq = 4 * q4 + i;
+                asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
+                auto fin = [&](float v, float res) {
+                  v = (v + shv[qq]) + res;
+                  return epi.relu ? relu_nan(v) : v;
+                };
+                y[y1] = fin(acc[r][0][qq], r1[i]);
+                *reinterpret_cast<float2*>(y + y2a) = make_float2(fin(acc[r][1][qq], r2a[i].x), fin(acc[r][2][qq], r2a[i].y));
+                if (SET == 1) *reinterpret_cast<float2*>(y + y2b) = make_float2(fin(acc[r][3][qq], r2b[i].x), fin(acc[r][4][qq], r2b[i].y));
+                const long long step = (i == 3 ? 5 : 1) * oDHW;
+                y1 += step;
+                y2a += step;
+                y2b += step;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
 #pragma unroll
@@ -348,14 +410,20 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
 
 namespace mode {
 
-size_t deconv3d_split_wpack_floats(int K, int Co) { return (size_t)cdiv(Co, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4; }
+size_t deconv3d_split_wpack_floats(int K, int Co) {  // (+ the folded BatchNorm shifts behind the fragments)
+  return (size_t)cdiv(Co, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4 + 32 * (size_t)cdiv(Co, 32);
+}
+
+bool deconv3d_split_bn_supported(int K, int Co) { return deconv3d_split_supported(K, Co) && Co % 32 == 0; }
 
 bool deconv3d_split_supported(int K, int Co) { return Co > 1 && Co <= 64 && K > 0 && K % 8 == 0; }
 
 // x (B, K, D, H, W), w (K, Co, 27) -> y (B, Co, 2D, 2H, 2W)
 int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int Co, int D, int H, int W, hipStream_t st,
-                   const char* who) {
+                   const char* who, const mode_bn_epilogue* bn) {
   MODE_REQUIRE(deconv3d_split_supported(K, Co), MODE_ERR_UNSUPPORTED, "%s: %d output / %d input channels not supported by the split kernel", who, Co, K);
+  MODE_REQUIRE(!bn || deconv3d_split_bn_supported(K, Co), MODE_ERR_UNSUPPORTED, "%s: the folded-BatchNorm epilogue needs whole 32-channel output tiles, got %d",
+               who, Co);
   MODE_REQUIRE((long long)D * H * W * 8 * std::max(Co, 8) < (1ll << 31) && (long long)D * H * W < (1ll << 27), MODE_ERR_UNSUPPORTED,
                "%s: volume beyond the 32-bit offsets of the split kernel", who);
   DcDims d;
@@ -365,17 +433,24 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
   d.NCHUNK = cdiv(K, 8);
   d.ntiles = B * D * d.nHt * d.nWt;
   const long long npack = (long long)MTr * d.NCHUNK * NPAIR * 64;
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK);
+  if (mode::pack_needed())
+    hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK,
+                       bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
+  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  const uint4* wq = reinterpret_cast<const uint4*>(wpack);
   int rc;
-  if (MTr == 2) {
-    rc = mode::allow_lds(deconv3d_split_kernel<2>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(deconv3d_split_kernel<2>, dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
-  } else {
-    rc = mode::allow_lds(deconv3d_split_kernel<1>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(deconv3d_split_kernel<1>, dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, reinterpret_cast<const uint4*>(wpack), y, d);
+#define MODE_DC_LAUNCH(MTV, EPIV)                                                                                     \
+  {                                                                                                                   \
+    rc = mode::allow_lds(deconv3d_split_kernel<MTV, EPIV>, LDS_BYTES, who);                                           \
+    if (rc != MODE_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((deconv3d_split_kernel<MTV, EPIV>), dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, wq, y, d, epi);  \
   }
+  if (MTr == 2) {
+    if (bn) MODE_DC_LAUNCH(2, true) else MODE_DC_LAUNCH(2, false)
+  } else {
+    if (bn) MODE_DC_LAUNCH(1, true) else MODE_DC_LAUNCH(1, false)
+  }
+#undef MODE_DC_LAUNCH
   return mode::check_launch(who);
 }
 

@@ -1830,12 +1830,18 @@ def deconv3d_bn_eval(x, w, bn, add=None, relu=False):
   e, keep = _epilogue(bn, add, relu, y)
   flops = 2 * x.numel() * Cout * 27
   with torch.cuda.device_of(x), profiling.region('deconv3d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
-    # (fp32 kernel: the split kernel with this epilogue was measured and is no faster at one pair -- its epilogue walks one pointer per
-    # parity class, and the residual's loads cannot be batched behind its stores)
-    with reuse:
-      check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
-            'mode_deconv3d_fwd_bn')
+    if CONV_ARITH == 'bf16x6' and lib().mode_deconv3d_split_bn_supported(Cin, Cout) == 1 and _deconv_split_fits(D * H * W, Cout):
+      # (round 5: the split kernel with its own epilogue instantiation -- residual values of four channels requested ahead of their
+      # stores; round 3 had measured it no faster than the fp32 kernel with one load next to every store)
+      wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_split_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
+      with reuse:
+        check(lib().mode_deconv3d_fwd_split_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
+              'mode_deconv3d_fwd_split_bn')
+    else:
+      wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
+      with reuse:
+        check(lib().mode_deconv3d_fwd_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
+              'mode_deconv3d_fwd_bn')
   return y
 
 

@@ -927,7 +927,8 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
       add = _rand(tuple(want.shape), 94).to(DEV) if with_add else None
       got = HF.conv3d_bn_eval(x, w, bn, stride, add, relu)
       assert (got.double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (ci, co, stride)
-    for (cin, cout) in ((24, 40), (64, 32), (12, 40)):  # two output tiles, one (hourglass conv6), channels off the split kernel's grid
+    for (cin, cout) in ((24, 40), (64, 32), (64, 64), (12, 40)):  # two output tiles (fp32 kernel), hourglass conv6 and conv5 (in bf16x6 mode the
+      # split kernel's own epilogue, mode_deconv3d_fwd_split_bn), channels off the split kernel's grid
       x, w = _rand((2, cin, 3, 5, 34), 95).to(DEV), _rand((cin, cout, 3, 3, 3), 96, 0.1).to(DEV)
       bn = _eval_bn(cout, 97)
       want = F.conv_transpose3d(x.cpu().double(), w.cpu().double(), None, 2, 1, 1).to(DEV)
