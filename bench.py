@@ -171,8 +171,8 @@ def kernel_of(label, conv_arith, on_split=None):
     return 'conv3d_bwd_weight_ring_kernel' if stride == 1 else 'conv3d_bwd_weight_s2_kernel'
   if name == 'deconv3d_fwd':
     return 'deconv3d_split_kernel' if conv_arith == 'bf16x6' else 'deconv3d_kernel'
-  if name == 'deconv3d_bn_eval':
-    return 'deconv3d_kernel'
+  if name == 'deconv3d_bn_eval':  # (the model's 64 -> 64 / 64 -> 32 layers: whole output tiles, the split kernel's own epilogue instantiation)
+    return 'deconv3d_split_kernel' if conv_arith == 'bf16x6' else 'deconv3d_kernel'
   if name in ('conv2d_fwd', 'conv2d_bwd_data', 'conv2d_bn_eval'):
     return 'conv2d_split_kernel' if split else 'conv2d_kernel'
   if name == 'conv2d_bwd_weight':

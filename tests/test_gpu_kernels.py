@@ -920,7 +920,8 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
   convolution -> fp64 eval BatchNorm (+ add) (+ ReLU), under torch.no_grad (the fused form is inference only)."""
   import torch.nn.functional as F
   with torch.no_grad():
-    for (ci, co, stride) in ((8, 32, 1), (20, 40, 1), (16, 24, 2), (32, 64, 2)):  # (the last one: the stride-2 split kernel in bf16x6 mode)
+    for (ci, co, stride) in ((8, 32, 1), (20, 40, 1), (64, 64, 1), (16, 24, 2), (32, 64, 2)):  # (64 -> 64: two output blocks of the split
+      # kernel, the residual prefetch of the second starts at channel 32; the last one: the stride-2 split kernel in bf16x6 mode)
       x, w = _rand((2, ci, 6, 10, 36), 91).to(DEV), _rand((co, ci, 3, 3, 3), 92, 0.1).to(DEV)
       bn = _eval_bn(co, 93)
       want = F.conv3d(x.cpu().double(), w.cpu().double(), None, stride, 1).to(DEV)

@@ -317,3 +317,28 @@ def test_build_notices_changed_compile_flags(tmp_path, monkeypatch):
   os.remove(os.path.join(str(tmp_path), 'flags.sha'))
   open(os.path.join(str(tmp_path), 'x.o'), 'w').close()
   assert hb._flags_changed() is True  # objects of unknown origin
+
+
+def test_isa_loops_reads_a_listing(tmp_path, monkeypatch, capsys):
+  """tools/isa_loops.py on a hand-written listing: it finds the loop with the MFMAs, the vmcnt(0) among its waits, the scratch reload, and
+  the run of vector instructions in front of the second MFMA."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('isa_loops', os.path.join(os.path.dirname(__file__), '..', 'tools', 'isa_loops.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  body = ['_Z6kernelPf:                            ; @_Z6kernelPf', '\ts_load_dwordx2 s[0:1], s[4:5], 0x0', '.LBB0_1:                 ; =>This Inner Loop Header: Depth=1',
+          '\tglobal_load_dword v1, v0, s[0:1]', '\tglobal_load_dword v2, v0, s[0:1] offset:4', '\ts_waitcnt vmcnt(1)',
+          '\tv_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:11], a[0:15]'] + ['\tv_add_f32_e32 v3, v3, v1'] * 10 + \
+         ['\tscratch_load_dword v9, off, off offset:8', '\ts_waitcnt vmcnt(0)', '\tv_mfma_f32_32x32x16_bf16 a[16:31], v[4:7], v[8:11], a[16:31]',
+          '\ts_barrier', '\ts_cbranch_scc1 .LBB0_1', '\ts_endpgm', '.Lfunc_end0:']
+  (tmp_path / 'k.s').write_text('\n'.join(body) + '\n')
+  monkeypatch.setattr(mod, 'ASM', str(tmp_path))
+  mod.scan('')
+  out = capsys.readouterr().out
+  assert 'mfma    2' in out and 'vmcnt(0)  1 of   2 waits' in out and 'loads   3' in out and 'scratch  1' in out
+  mod.timeline('kernel')
+  assert '0:Lx2 0:w1 1:L 1:w0 2:B' in capsys.readouterr().out
+  mod.bursts('kernel')
+  assert '(1, (10, 0, 1, 1))' in capsys.readouterr().out
+  mod.chains('kernel')
+  assert '[(2, 2)]' in capsys.readouterr().out
