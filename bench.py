@@ -66,6 +66,8 @@ def parse():
                   help="initial weights: 'recipe' = tests/golden/recipe.py state (SURVEY 8c/8d), 'torch' = the constructor's random init under torch.manual_seed(0)")
   ap.add_argument('--no-fused-loss', action='store_true',
                   help='A/B: the loss of train_disparity.py:151-158 as torch ops on the three predictions instead of ModeDisparity.forward_loss')
+  ap.add_argument('--no-grad-carriers', action='store_true',
+                  help="A/B: autograd's own pairwise accumulation for the tensors with two consumers (functional.GRAD_CARRIERS = False)")
   ap.add_argument('--no-fused-classif', action='store_true',
                   help='A/B: the classifier heads as separate BatchNorm / 32->1 convolution operators (functional.CLASSIF_FUSED = False)')
   ap.add_argument('--no-collective-self-test', action='store_true', help='skip the world-size-1 RCCL all-reduce self-test after the timed region')
@@ -493,6 +495,7 @@ def main():
   HF.set_conv_arith(args.conv_arith)
   HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
   HF.CLASSIF_FUSED = not args.no_fused_classif
+  HF.GRAD_CARRIERS = not args.no_grad_carriers
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)

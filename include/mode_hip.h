@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 22 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 23 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -389,6 +389,13 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
 /* The same with the folded eval-mode BatchNorm (+ residual) (+ ReLU) epilogue of mode_deconv3d_fwd_bn (convbn_3d around the
  * ConvTranspose3d of hourglass conv5 / conv6 in eval mode, mode_disparity.py:23-25, 38-45): whole 32-channel output tiles
  * (mode_deconv3d_split_bn_supported(Cin, Cout) == 1); wpack >= mode_conv3d_wpack_bytes(Cin, Cout). */
+/* The input gradient of a stride-1 / stride-2 convolution on the split kernels with a gradient that is already there added in the
+ * store: gx = conv^T(gy) + acc, bit for bit the sum autograd would form with a separate pass (x has a second consumer whose gradient
+ * came first: a residual skip, a classifier head).  acc has gx's shape and must not alias it; stride 2: whole 32-channel tiles of gx
+ * (mode_conv3d_bwd_data_split_acc_supported(Ci, Co, stride) == 1), even D, H, W. */
+int mode_conv3d_bwd_data_split_acc_supported(int Ci, int Co, int stride);
+int mode_conv3d_bwd_data_split_acc(const float* gy, const float* w, const float* acc, float* gx, float* wpack, int B, int Ci, int D, int H,
+                                   int W, int Co, int stride, mode_stream_t stream);
 int mode_deconv3d_split_bn_supported(int Cin, int Cout);
 int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin, int D,
                                int H, int W, int Cout, mode_stream_t stream);

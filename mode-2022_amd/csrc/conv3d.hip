@@ -631,6 +631,25 @@ extern "C" int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, fl
   return mode::deconv3d_split(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), who);
 }
 
+// The two input gradients with a gradient that is already there added in the store: gx = conv^T(gy) + acc (acc must not alias gx).
+extern "C" int mode_conv3d_bwd_data_split_acc_supported(int Ci, int Co, int stride) {
+  if (Ci <= 0 || Co <= 0) return 0;
+  if (stride == 1) return mode::conv3d_split_supported(Co, Ci) ? 1 : 0;
+  return (stride == 2 && mode::deconv3d_split_bn_supported(Co, Ci)) ? 1 : 0;
+}
+
+extern "C" int mode_conv3d_bwd_data_split_acc(const float* gy, const float* w, const float* acc, float* gx, float* wpack, int B, int Ci, int D,
+                                              int H, int W, int Co, int stride, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_data_split_acc";
+  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, stride, who, stride == 2);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE(acc && acc != gx, MODE_ERR_BAD_ARG, "%s: acc must be a tensor of gx's shape that is not gx", who);
+  if (stride == 1) return mode::conv3d_s1_split(gy, w, gx, wpack, B, Co, Ci, D, H, W, 1, mode::as_stream(stream), who, nullptr, nullptr, acc);
+  MODE_REQUIRE(stride == 2 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MODE_ERR_UNSUPPORTED, "%s: stride 1, or stride 2 with even input sizes (got stride %d, %dx%dx%d)",
+               who, stride, D, H, W);
+  return mode::deconv3d_split(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), who, nullptr, acc);
+}
+
 // ConvTranspose3d k3 s2 p1 op1 on the same kernel: x (B, Cin, D, H, W), w (Cin, Cout, 27) -> y (B, Cout, 2D, 2H, 2W).
 extern "C" int mode_deconv3d_split_supported(int Cin, int Cout) { return mode::deconv3d_split_supported(Cin, Cout) ? 1 : 0; }
 

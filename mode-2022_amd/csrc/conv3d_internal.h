@@ -29,7 +29,8 @@ size_t conv3d_split_wpack_floats(int K, int rows);
 // partial pairs per channel + the pivots of the shifted sums (layout: conv3d_split_kernel, EPI 3).
 int conv3d_split_stat_partials();
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr);
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr, const float* acc_in = nullptr);
+// (acc_in: y = conv(x) + acc_in -- a gradient that is already there added in the store, instead of a separate pass; not with bn / stats)
 
 // conv3d_split_s2.hip: the stride-2 forward (= input gradient of the transposed convolution) on the same arithmetic; rows = output
 // channels (33..64), K = reduction channels (multiple of 8); w is (rows, K, 27); wpack >= conv3d_s2_split_wpack_floats(K, rows).
@@ -44,7 +45,8 @@ bool deconv3d_split_supported(int K, int Co);
 bool deconv3d_split_bn_supported(int K, int Co);  // with the folded-BatchNorm epilogue: whole 32-channel output tiles
 size_t deconv3d_split_wpack_floats(int K, int Co);
 int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int Co, int D, int H, int W, hipStream_t st,
-                   const char* who, const mode_bn_epilogue* bn = nullptr);  // bn: optional folded-BatchNorm epilogue (eval mode)
+                   const char* who, const mode_bn_epilogue* bn = nullptr, const float* acc_in = nullptr);
+// bn: optional folded-BatchNorm epilogue (eval mode); acc_in: y = deconv(x) + acc_in (whole 32-channel output tiles, not with bn)
 
 // conv3d_split_wgrad.hip: split-K partials of the stride-1 weight gradient on the split-bf16 matrix path, written in the layout of
 // conv3d.hip's weight-gradient kernels (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.

@@ -84,8 +84,8 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
   const long long total = (long long)MT * NCHUNK * NPAIR * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * 3);
-    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold_shift(bn, o);
-  }
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold == 1 ? fold_shift(bn, o) : 0.f;  // (fold 2: zero shifts, no scale --
+  }                                                                                                       // the accumulate form)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     long long r = idx >> 6;
@@ -102,7 +102,7 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
       v[j] = 0.f;
       if (o < rows && c < K && tap < 27)
         v[j] = flip == 0 ? w[((long long)o * K + c) * 27 + tap] : w[((long long)c * rows + o) * 27 + (26 - tap)];
-      if (fold && o < rows) v[j] *= fold_scale(bn, o);
+      if (fold == 1 && o < rows) v[j] *= fold_scale(bn, o);
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -514,7 +514,8 @@ bool conv3d_split_supported(int K, int rows) { return rows > 1 && rows <= 64 && 
 int conv3d_split_stat_partials() { return kNumCU; }  // partial pairs per channel that the statistics epilogue writes
 
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats) {
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* acc_in) {
+  MODE_REQUIRE(!(acc_in && (bn || stats)), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue and no statistics", who);
   SDims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.MT = cdiv(rows, 32);
@@ -528,8 +529,13 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
   if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
-                     d.NCHUNK, flip, bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
-  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+                     d.NCHUNK, flip, bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue());
+  Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  if (acc_in) {  // y = conv(x) + acc_in: the residual epilogue with zero shifts ((v + 0) + a is a + v exactly)
+    epi.shift = wpack + npack * 3 * 4;
+    epi.add = acc_in;
+    epi.relu = 0;
+  }
   // 32 output channels per workgroup: the second half of a 64-channel layer stages the input a second time, which at 6 / 16 of the
   // matrix rate still beats the fp32 kernel with two output tiles (64 -> 64 at 24 x 128 x 64: 0.41 ms against 0.70); the halves are
   // the y-slices of ONE launch

@@ -82,7 +82,7 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
   const long long total = (long long)MTr * NCHUNK * NPAIR * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * 3);
-    for (int o = threadIdx.x; o < Co; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+    for (int o = threadIdx.x; o < Co; o += blockDim.x) shifts[o] = fold == 1 ? fold_shift(bn, o) : 0.f;  // (fold 2: the accumulate form)
   }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -98,7 +98,7 @@ __global__ void pack_w3d_deconv_split(const float* __restrict__ w, uint4* __rest
     for (int j = 0; j < 8; ++j) {
       const int c = ch * 8 + j;
       v[j] = (o < Co && c < K && tap >= 0) ? w[((long long)c * Co + o) * 27 + tap] : 0.f;
-      if (fold && o < Co) v[j] *= fold_scale(bn, o);
+      if (fold == 1 && o < Co) v[j] *= fold_scale(bn, o);
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -420,10 +420,11 @@ bool deconv3d_split_supported(int K, int Co) { return Co > 1 && Co <= 64 && K > 
 
 // x (B, K, D, H, W), w (K, Co, 27) -> y (B, Co, 2D, 2H, 2W)
 int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int Co, int D, int H, int W, hipStream_t st,
-                   const char* who, const mode_bn_epilogue* bn) {
+                   const char* who, const mode_bn_epilogue* bn, const float* acc_in) {
+  MODE_REQUIRE(!(acc_in && bn), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue", who);
   MODE_REQUIRE(deconv3d_split_supported(K, Co), MODE_ERR_UNSUPPORTED, "%s: %d output / %d input channels not supported by the split kernel", who, Co, K);
-  MODE_REQUIRE(!bn || deconv3d_split_bn_supported(K, Co), MODE_ERR_UNSUPPORTED, "%s: the folded-BatchNorm epilogue needs whole 32-channel output tiles, got %d",
-               who, Co);
+  MODE_REQUIRE(!(bn || acc_in) || deconv3d_split_bn_supported(K, Co), MODE_ERR_UNSUPPORTED,
+               "%s: the epilogue forms need whole 32-channel output tiles, got %d", who, Co);
   MODE_REQUIRE((long long)D * H * W * 8 * std::max(Co, 8) < (1ll << 31) && (long long)D * H * W < (1ll << 27), MODE_ERR_UNSUPPORTED,
                "%s: volume beyond the 32-bit offsets of the split kernel", who);
   DcDims d;
@@ -435,8 +436,14 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
   const long long npack = (long long)MTr * d.NCHUNK * NPAIR * 64;
   if (mode::pack_needed())
     hipLaunchKernelGGL(pack_w3d_deconv_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), K, Co, MTr, d.NCHUNK,
-                       bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
-  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+                       bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue());
+  Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  if (acc_in) {  // y = deconv(x) + acc_in: the residual epilogue with zero shifts
+    epi.shift = wpack + npack * 3 * 4;
+    epi.add = acc_in;
+    epi.relu = 0;
+  }
+  const bool with_epi = bn || acc_in;
   const uint4* wq = reinterpret_cast<const uint4*>(wpack);
   int rc;
 #define MODE_DC_LAUNCH(MTV, EPIV)                                                                                     \
@@ -446,9 +453,9 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
     hipLaunchKernelGGL((deconv3d_split_kernel<MTV, EPIV>), dim3(kNumCU), dim3(NT), LDS_BYTES, st, x, wq, y, d, epi);  \
   }
   if (MTr == 2) {
-    if (bn) MODE_DC_LAUNCH(2, true) else MODE_DC_LAUNCH(2, false)
+    if (with_epi) MODE_DC_LAUNCH(2, true) else MODE_DC_LAUNCH(2, false)
   } else {
-    if (bn) MODE_DC_LAUNCH(1, true) else MODE_DC_LAUNCH(1, false)
+    if (with_epi) MODE_DC_LAUNCH(1, true) else MODE_DC_LAUNCH(1, false)
   }
 #undef MODE_DC_LAUNCH
   return mode::check_launch(who);

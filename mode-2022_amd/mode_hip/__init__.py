@@ -97,6 +97,8 @@ SIGNATURES = {
     'mode_deconv3d_split_supported': (_c_int, [_c_int] * 2),
     'mode_deconv3d_fwd_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_deconv3d_split_bn_supported': (_c_int, [_c_int] * 2),
+    'mode_conv3d_bwd_data_split_acc_supported': (_c_int, [_c_int] * 3),
+    'mode_conv3d_bwd_data_split_acc': (_c_int, [_c_ptr] * 5 + [_c_int] * 7 + [_c_ptr]),
     'mode_deconv3d_fwd_split_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
@@ -129,7 +131,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 22  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 23  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

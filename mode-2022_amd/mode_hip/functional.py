@@ -1097,6 +1097,43 @@ class FanOutFunction(torch.autograd.Function):
     return (live[0] if len(live) == 1 else sum_n(live)), None
 
 
+# A tensor with exactly TWO consumers whose gradients autograd would add in a separate pass (read two tensors, write one): the consumer
+# whose backward runs first leaves its gradient in the carrier and reports None, the second adds it inside the kernel that produces its
+# own (mode_conv3d_bwd_data_split_acc: one extra read in the store instead of three passes) -- the same fp32 sum, bit for bit.  Both
+# consumers register in their forward (arm); a gradient is only left behind when both did.  Consumers that cannot add in their kernel
+# (the BatchNorm backward that owns a residual skip's gradient) can still be the first.  Assumes what this model guarantees: when the
+# gradient of the shared tensor is needed, both backwards run in the same pass.
+GRAD_CARRIERS = True  # bench.py --no-grad-carriers measures autograd's own accumulation
+
+
+class GradCarrier(object):
+  __slots__ = ('armed', 'grad')
+
+  def __init__(self):
+    self.armed = 0
+    self.grad = None
+
+  def arm(self, needs_grad):
+    if needs_grad:
+      self.armed += 1
+
+  def take(self):
+    g, self.grad = self.grad, None
+    return g
+
+  def leave(self, g):
+    """First of the two backwards: True when g was left for the other one (report None to autograd), False to return it as usual."""
+    if self.armed == 2 and g is not None:
+      self.grad = g
+      return True
+    return False
+
+
+def grad_carrier(x):
+  """A carrier for tensor x, or None when nothing would be gained (no gradient needed, CPU tensor, switched off)."""
+  return GradCarrier() if (GRAD_CARRIERS and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad) else None
+
+
 def fan_out(x, n):
   if n <= 1 or not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad):
     return (x,) * max(n, 1)
@@ -1172,8 +1209,9 @@ def conv3d_fwd(x, w, stride=1):
   return y
 
 
-def conv3d_bwd_data(gy, w, in_shape, stride=1):
-  """gradient w.r.t. the input of conv3d_fwd; in_shape = x.shape."""
+def conv3d_bwd_data(gy, w, in_shape, stride=1, acc=None):
+  """gradient w.r.t. the input of conv3d_fwd; in_shape = x.shape.  acc: a gradient of the same tensor that is already there -- the sum
+  is returned (added in the kernel's store on the split path, by a separate pass elsewhere)."""
   require_gpu(gy, w)
   gy, w = gy.contiguous(), w.contiguous()
   require_f32c(gy, w)
@@ -1181,6 +1219,18 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1):
   Co = w.shape[0]
   gx = torch.empty((B, Ci, D, H, W), dtype=gy.dtype, device=gy.device)
   flops = 2 * gy.numel() * Ci * 27
+  if acc is not None:
+    acc = acc.contiguous()
+    s2_ok = stride == 2 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and _deconv_split_fits(D * H * W // 8, Ci)
+    if (tuple(acc.shape) == tuple(gx.shape) and acc.dtype == gx.dtype and CONV_ARITH == 'bf16x6' and (stride == 1 or s2_ok) and
+        lib().mode_conv3d_bwd_data_split_acc_supported(Ci, Co, stride) == 1):
+      with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
+                                                      4 * (2 * gx.numel() + gy.numel() + w.numel()), flops, gy.device):
+        wp = _wpack3d(Ci, Co, gy.device)
+        check(lib().mode_conv3d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
+              'mode_conv3d_bwd_data_split_acc')
+      return gx
+    return conv3d_bwd_data(gy, w, in_shape, stride).add_(acc)
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                   4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
@@ -1247,22 +1297,28 @@ class Conv3dFunction(torch.autograd.Function):
   """k3 p1 convolution (stride 1|2) on the HIP kernels; autograd of F.conv3d(x, w, None, stride, 1)."""
 
   @staticmethod
-  def forward(ctx, x, w, stride):
+  def forward(ctx, x, w, stride, carrier=None):
     ctx.save_for_backward(x, w)
     ctx.stride = stride
+    ctx.carrier = carrier  # GradCarrier of x (x has one other consumer), or None
     return conv3d_fwd(x, w, stride)
 
   @staticmethod
   def backward(ctx, gy):
     x, w = ctx.saved_tensors
-    gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
+    gx = None
+    if ctx.needs_input_grad[0]:
+      prev = ctx.carrier.take() if ctx.carrier is not None else None  # the other consumer's gradient, when it came first
+      gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride, acc=prev)
+      if prev is None and ctx.carrier is not None and ctx.carrier.leave(gx):
+        gx = None  # first of the two: the other consumer's backward returns the sum
     gw = None
     if ctx.needs_input_grad[1]:
       sink = grad_sink(w)
       gw = conv3d_bwd_weight(gy, x, ctx.stride, into=sink)
       if sink is not None:
         gw = None
-    return gx, gw, None
+    return gx, gw, None, None
 
 
 class Deconv3dFunction(torch.autograd.Function):
@@ -1287,8 +1343,10 @@ class Deconv3dFunction(torch.autograd.Function):
     return gx, gw
 
 
-def conv3d(x, w, stride=1):
-  return Conv3dFunction.apply(x, w, stride)
+def conv3d(x, w, stride=1, carrier=None):
+  if carrier is not None:
+    carrier.arm(x.requires_grad and torch.is_grad_enabled())
+  return Conv3dFunction.apply(x, w, stride, carrier)
 
 
 # BatchNorm statistics in the epilogue of the stride-1 split 3-D convolution (training) instead of a statistics pass over its output.
@@ -1508,7 +1566,9 @@ class BnActFunction(torch.autograd.Function):
   """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
 
   @staticmethod
-  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1, prestats_ws=None):
+  def forward(ctx, y, add, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1, prestats_ws=None,
+              add_carrier=None):
+    ctx.add_carrier = add_carrier  # GradCarrier of `add` (the skip tensor has one other consumer), or None
     require_gpu(y, add, gamma, beta)
     y = y.contiguous()
     add = add.contiguous() if add is not None else None
@@ -1564,7 +1624,13 @@ class BnActFunction(torch.autograd.Function):
       ggamma = gbeta = None
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
-    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None, None
+    if gadd is not None and ctx.add_carrier is not None:
+      prev = ctx.add_carrier.take()
+      if prev is not None:
+        gadd = gadd + prev  # (the other consumer came first: this backward cannot add inside its kernel)
+      elif ctx.add_carrier.leave(gadd):
+        gadd = None  # the skip's other consumer adds it inside its input-gradient kernel
+    return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None, None, None
 
 
 def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
@@ -1581,7 +1647,7 @@ def bn_eval(y, add, gamma, beta, running_mean, running_var, eps, relu):
   return out
 
 
-def bn_act(bn, y, add=None, relu=False, groups=1):
+def bn_act(bn, y, add=None, relu=False, groups=1, add_carrier=None):
   """groups > 1: batch statistics per group of B / groups consecutive samples, as `groups` consecutive calls would take them.
   nn.BatchNorm2d/3d `bn` applied to y, then the optional residual add and ReLU, in one fused pass (two in training).
   Same state handling as nn.BatchNorm: train mode uses batch statistics and updates running_mean / running_var /
@@ -1598,8 +1664,10 @@ def bn_act(bn, y, add=None, relu=False, groups=1):
       if momentum is None:
         momentum = 1.0 / float(nbt)
       nbt = None
+    if add_carrier is not None:
+      add_carrier.arm(add is not None and add.requires_grad and torch.is_grad_enabled())
     return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
-                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt, groups)
+                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt, groups, None, add_carrier)
   if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
     # eval-mode BN inside a graph that needs gradients: rare (the reference never does it); vendor ops keep autograd correct
     out = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)

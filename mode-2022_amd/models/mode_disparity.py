@@ -36,12 +36,13 @@ class hourglass(nn.Module):
     self.conv6 = nn.Sequential(nn.ConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
                                nn.BatchNorm3d(inplanes))
 
-  def forward(self, x, presqu, postsqu, *, residual=None, pre_consumers=1):
+  def forward(self, x, presqu, postsqu, *, residual=None, pre_consumers=1, x_carrier=None):
     """Reference signature (x, presqu, postsqu).  The keyword-only `residual` is added to the output inside the last fused
     BatchNorm pass; the reference adds cost0 right after the call (mode_disparity.py:119, 122, 125).  `pre_consumers`: how many times
     the caller uses the returned `pre` (dres2's is the presqu of both later hourglasses): with more than one, `pre` comes back as a
     tuple of that many aliases whose gradients are summed together with the internal ones in one pass (functional.fan_out)."""
-    out = stage3d.conv_bn(self.conv1[0], x, relu=True)  # 1/4 -> 1/8
+    # (x_carrier: x has one other consumer, HF.GradCarrier; None outside GPU training)
+    out = stage3d.conv_bn(self.conv1[0], x, relu=True) if x_carrier is None else stage3d.conv_bn(self.conv1[0], x, relu=True, x_carrier=x_carrier)  # 1/4 -> 1/8
     pre = stage3d.conv_bn(self.conv2, out, relu=True, add=postsqu)  # relu(bn(conv) [+ postsqu])
     inner = 1 + (1 if presqu is None else 0)  # conv3, and conv5's skip when no presqu is given
     alias = HF.fan_out(pre, inner + pre_consumers) if inner + pre_consumers > 2 else (pre,) * (inner + pre_consumers)
@@ -171,17 +172,29 @@ class ModeDisparity(nn.Module):
       cost = HF.cost_volume(ref_fea, tgt_fea, self.maxdisp // 4)  # (B, 64, D/4, H/4, W/4), one kernel
       cost0 = stage3d.conv_bn(self.dres0[0], cost, relu=True)
     cost0 = stage3d.conv_bn(self.dres0[2], cost0, relu=True)
-    t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
-    cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
+    # Tensors with exactly two consumers -- dres1's input (its first convolution and its skip), out1 and out2 (a classifier head and the
+    # next hourglass): the gradient that arrives first is added inside the kernel that produces the second (HF.GradCarrier) instead of
+    # by a pass of autograd's over the 403 MB tensors.  The forward is unchanged.
+    car = HF.grad_carrier(cost0)
+    if car is None:
+      t = stage3d.conv_bn(self.dres1[0], cost0, relu=True)
+      cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0)
+    else:
+      t = stage3d.conv_bn(self.dres1[0], cost0, relu=True, x_carrier=car)
+      cost0 = stage3d.conv_bn(self.dres1[2], t, add=cost0, add_carrier=car)
 
     # cost0 has four consumers (the input of dres2 and the three residual adds), pre1 four (two inside dres2, the presqu of dres3 and
     # dres4): their gradients are summed in one pass each instead of pairwise by autograd (HF.fan_out; the forward is unchanged)
     c0 = HF.fan_out(cost0, 4)
     out1, pre1, post1 = self.dres2(c0[0], None, None, residual=c0[1], pre_consumers=2)  # out1 = hourglass(...) + cost0
-    out2, pre2, post2 = self.dres3(out1, pre1[0], post1, residual=c0[2])
-    out3, pre3, post3 = self.dres4(out2, pre1[1], post2, residual=c0[3])  # pre1 (not pre2), as in the reference (:124)
+    car1 = HF.grad_carrier(out1)
+    kw1 = {} if car1 is None else {'x_carrier': car1}
+    out2, pre2, post2 = self.dres3(out1, pre1[0], post1, residual=c0[2], **kw1)
+    car2 = HF.grad_carrier(out2)
+    kw2 = {} if car2 is None else {'x_carrier': car2}
+    out3, pre3, post3 = self.dres4(out2, pre1[1], post2, residual=c0[3], **kw2)  # pre1 (not pre2), as in the reference (:124)
 
-    cost1 = stage3d.classify(self.classif1, out1)
-    cost2 = stage3d.classify(self.classif2, out2, add=cost1)  # = classif2(out2) + cost1 (reference :128)
+    cost1 = stage3d.classify(self.classif1, out1, **kw1)
+    cost2 = stage3d.classify(self.classif2, out2, add=cost1, **kw2)  # = classif2(out2) + cost1 (reference :128)
     cost3 = stage3d.classify(self.classif3, out3, add=cost2)
     return cost1, cost2, cost3

@@ -33,15 +33,16 @@ def _hip_kind(conv, x):
   return None
 
 
-def conv3(conv, x):
-  """One Conv3d / ConvTranspose3d layer."""
+def conv3(conv, x, carrier=None):
+  """One Conv3d / ConvTranspose3d layer.  carrier: the HF.GradCarrier of x when x has exactly one other consumer (honoured by the 3-D
+  convolutions; every other layer kind leaves it unarmed, and autograd adds the two gradients as usual)."""
   if not x.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')  # same refusal as the reference's native op
   kind = _hip_kind(conv, x)
   if kind == 'conv1':
-    return HF.conv3d(x, conv.weight, 1)
+    return HF.conv3d(x, conv.weight, 1, carrier)
   if kind == 'conv2':
-    return HF.conv3d(x, conv.weight, 2)
+    return HF.conv3d(x, conv.weight, 2, carrier)
   if kind == 'deconv':
     return HF.deconv3d(x, conv.weight)
   if type(conv) is nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and \
@@ -65,7 +66,7 @@ def conv3(conv, x):
   return conv(x)
 
 
-def conv_bn(seq, x, relu=False, add=None):
+def conv_bn(seq, x, relu=False, add=None, x_carrier=None, add_carrier=None):
   """seq = Sequential(Conv2d | SphereConv | Conv3d | ConvTranspose3d, BatchNorm): y = bn(conv(x)) [+ add] [relu]
   (convbn / convbn_3d / sphereConvbn submodule.py:15-22, 61-74; transposed form mode_disparity.py:23, 25).
   Inference (eval mode, no autograd): ONE launch per layer -- the BatchNorm is folded into the convolution kernel (scale into the
@@ -79,7 +80,9 @@ def conv_bn(seq, x, relu=False, add=None):
       torch.is_grad_enabled() and HF.conv3d_stats_supported(x, conv.weight, bn)):
     # training, stride-1 3-D layer on the split kernel: the BatchNorm statistics come out of the convolution's epilogue
     return HF.conv3d_bn_train(x, conv.weight, bn, add, relu)
-  return bn_act(bn, conv3(conv, x), add, relu)
+  # x_carrier / add_carrier: gradient carriers of x and of the skip tensor (HF.GradCarrier; training only, None otherwise)
+  y = conv3(conv, x) if x_carrier is None else conv3(conv, x, x_carrier)
+  return bn_act(bn, y, add, relu) if add_carrier is None else bn_act(bn, y, add, relu, add_carrier)
 
 
 def _conv_bn_folded(conv, bn, x, add, relu):
@@ -128,13 +131,13 @@ def bn_groups(n):
     _tls.bn_groups = prev
 
 
-def bn_act(bn, y, add=None, relu=False):
+def bn_act(bn, y, add=None, relu=False, add_carrier=None):
   """BatchNorm + optional residual add + optional ReLU: one fused HIP pass (two in training)."""
   if not y.is_cuda:
     raise NotImplementedError('Only support cuda tensor!')
   if not HF.bn_supported(y):  # (other dtypes, B * C beyond the grid limit): the torch module itself, on the GPU
     return bn_act_torch(bn, y, add, relu)
-  return HF.bn_act(bn, y, add, relu, groups=current_bn_groups() if bn.training else 1)
+  return HF.bn_act(bn, y, add, relu, groups=current_bn_groups() if bn.training else 1, add_carrier=add_carrier)
 
 
 def bn_act_torch(bn, y, add=None, relu=False):
@@ -149,7 +152,7 @@ def bn_act_torch(bn, y, add=None, relu=False):
   return F.relu(y, inplace=True) if relu else y
 
 
-def classify(seq, x, *, add=None):
+def classify(seq, x, *, add=None, x_carrier=None):
   """classifN = Sequential(convbn_3d, ReLU, Conv3d(32->1)) (mode_disparity.py:76-80).  The keyword-only `add` is the residual the
   reference adds right after the call (`cost2 = classif2(out2) + cost1`, mode_disparity.py:128-129).  Training: BatchNorm + ReLU +
   the single-channel convolution + the add as one operator behind the first convolution (HF.classif_head_train); the activated
@@ -157,12 +160,12 @@ def classify(seq, x, *, add=None):
   conv0, bn = seq[0][0], seq[0][1]
   if (x.is_cuda and bn.training and torch.is_grad_enabled() and current_bn_groups() == 1 and _hip_kind(conv0, x) == 'conv1' and
       conv0.out_channels > 1):
-    y = conv3(conv0, x)
+    y = conv3(conv0, x) if x_carrier is None else conv3(conv0, x, x_carrier)
     if HF.classif_fused_supported(y, bn, seq[2]):
       return HF.classif_head_train(y, bn, seq[2], add)
     cost = conv3(seq[2], bn_act(bn, y, None, True))
   else:
-    cost = conv3(seq[2], conv_bn(seq[0], x, relu=True))
+    cost = conv3(seq[2], conv_bn(seq[0], x, relu=True) if x_carrier is None else conv_bn(seq[0], x, relu=True, x_carrier=x_carrier))
   return cost if add is None else cost + add
 
 

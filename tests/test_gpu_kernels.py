@@ -937,6 +937,25 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
       assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (cin, cout)
 
 
+def test_conv3d_input_gradient_with_a_gradient_already_there(arith):
+  """conv3d_bwd_data(..., acc=g): the sum of the input gradient and g, added in the store of the split kernels
+  (mode_conv3d_bwd_data_split_acc; stride 1: the residual epilogue of conv3d_split_kernel, stride 2: of deconv3d_split_kernel, both
+  with zero shifts) -- bit for bit what a separate add gives; shapes the accumulate form does not take (channels off the 32-tile,
+  odd volumes, fp32-MFMA mode) go through that separate add."""
+  for (ci, co, stride, shape) in ((32, 32, 1, (2, 6, 10, 36)), (64, 64, 1, (1, 4, 9, 33)), (32, 64, 2, (2, 6, 10, 36)), (64, 64, 2, (1, 4, 8, 34)),
+                                  (24, 40, 1, (1, 4, 6, 34)), (40, 24, 2, (1, 4, 6, 34))):
+    B, D, H, W = shape
+    w = _rand((co, ci, 3, 3, 3), 401, 0.1).to(DEV)
+    do, ho, wo = ((D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
+    gy = _rand((B, co, do, ho, wo), 402).to(DEV)
+    acc = _rand((B, ci, D, H, W), 403).to(DEV)
+    plain = HF.conv3d_bwd_data(gy, w, (B, ci, D, H, W), stride)
+    keep = acc.clone()
+    got = HF.conv3d_bwd_data(gy, w, (B, ci, D, H, W), stride, acc=acc)
+    assert torch.equal(got, plain + acc), (ci, co, stride, float((got - (plain + acc)).abs().max()))
+    assert torch.equal(acc, keep) and got.data_ptr() != acc.data_ptr()
+
+
 @pytest.mark.parametrize('relu', [True, False])
 def test_folded_epilogues_propagate_nan_like_torch(relu, arith):
   """A NaN activation stays NaN through conv + folded BatchNorm (+ ReLU) in BOTH arithmetics -- torch.relu(NaN) is NaN, and the

@@ -221,6 +221,44 @@ def test_gradient_sinks_match_autograd_accumulation():
   assert not any(hasattr(p, '_mode_grad_sink') for p in net.parameters())
 
 
+def test_gradient_carriers_give_autograds_sums_bit_for_bit(monkeypatch):
+  """HF.GradCarrier: dres1's input, out1 and out2 have two consumers each; the gradient that arrives first is added inside the kernel
+  that produces the second (mode_conv3d_bwd_data_split_acc) instead of by autograd.  a + b is b + a in fp32 and (v + 0) + a is a + v:
+  every parameter gradient equals the plain route's bit for bit, also in a second backward on the same graph; and the kernels with
+  the add in their store really ran (3 per backward)."""
+  from mode_hip import functional as HF
+  net, left, right, gt = _tiny_net(11)
+  calls = []
+  real = HF.conv3d_bwd_data
+
+  def spy(gy, w, in_shape, stride=1, acc=None):
+    calls.append((stride, acc is not None))
+    return real(gy, w, in_shape, stride, acc)
+
+  monkeypatch.setattr(HF, 'conv3d_bwd_data', spy)
+  grads = {}
+  for on in (False, True):
+    monkeypatch.setattr(HF, 'GRAD_CARRIERS', on)
+    net.zero_grad(set_to_none=True)
+    del calls[:]
+    torch.manual_seed(0)
+    loss = _loss(net, left, right, gt)
+    loss.backward(retain_graph=True)
+    grads[on] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    n_acc = sum(1 for c in calls if c[1])
+    assert n_acc == (3 if on else 0), calls
+    if on:
+      assert sorted(c[0] for c in calls if c[1]) == [1, 2, 2]  # dres1's first convolution; the stride-2 convolutions of dres3 / dres4
+      net.zero_grad(set_to_none=True)
+      del calls[:]
+      loss.backward()  # the same graph again: the carriers are empty after the first pass and work the same way
+      assert sum(1 for c in calls if c[1]) == 3
+      for k, p in net.named_parameters():
+        assert torch.equal(p.grad, grads[True][k]), k
+  for k in grads[False]:
+    assert torch.equal(grads[False][k], grads[True][k]), k
+
+
 def test_graph_replay_matches_eager():
   """mode_hip.graph_step.GraphedStep: forward + loss + backward captured into one hipGraph and replayed; same loss and
   gradients as the eager step on the same weights, and new inputs are picked up through the static tensors."""
