@@ -344,51 +344,49 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
               y2b += step;
             }
           } else {
-            // eval: (sum + shift) + residual, ReLU as torch computes it; the residual values of FOUR channels (up to 20 floats) are
-            // requested together ahead of their stores (`add` may alias y for all the compiler knows: a load next to each store waits
-            // for the store in front of it)
+            // eval / accumulate: (sum + shift) + residual, ReLU as torch computes it.  The residual values of a ROW (16 channels, up to 80
+            // floats: the fragment and staging registers of the tap loop are free here) are requested together ahead of its stores --
+            // one round trip per row; `add` may alias y for all the compiler knows, and a load next to each store waits for the store in
+            // front of it (in batches of four channels: four round trips per row, 192 -> NNN us at 64 -> 32 / 24 x 128 x 64)
             const bool has_add = epi.add != nullptr;
+            float r1[16];
+            float2 r2a[16], r2b[16];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              float r1[4];
-              float2 r2a[4], r2b[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                r1[i] = 0.f;
-                r2a[i] = r2b[i] = make_float2(0.f, 0.f);
-              }
-              if (has_add) {
-                long long a1 = y1, a2a = y2a, a2b = y2b;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  asm volatile("" : "+v"(a1), "+v"(a2a), "+v"(a2b));
-                  r1[i] = epi.add[a1];
-                  r2a[i] = *reinterpret_cast<const float2*>(epi.add + a2a);
-                  if (SET == 1) r2b[i] = *reinterpret_cast<const float2*>(epi.add + a2b);
-                  a1 += oDHW;
-                  a2a += oDHW;
-                  a2b += oDHW;
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int qq = 4 * q4 + i;
-                asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
-                auto fin = [&](float v, float res) {
-                  v = (v + shv[qq]) + res;
-                  return epi.relu ? relu_nan(v) : v;
-                };
-                y[y1] = fin(acc[r][0][qq], r1[i]);
-                *reinterpret_cast<float2*>(y + y2a) = make_float2(fin(acc[r][1][qq], r2a[i].x), fin(acc[r][2][qq], r2a[i].y));
-                if (SET == 1) *reinterpret_cast<float2*>(y + y2b) = make_float2(fin(acc[r][3][qq], r2b[i].x), fin(acc[r][4][qq], r2b[i].y));
-                const long long step = (i == 3 ? 5 : 1) * oDHW;
-                y1 += step;
-                y2a += step;
-                y2b += step;
-              }
-              __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 16; ++i) {
+              r1[i] = 0.f;
+              r2a[i] = r2b[i] = make_float2(0.f, 0.f);
             }
+            if (has_add) {
+              long long a1 = y1, a2a = y2a, a2b = y2b;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                asm volatile("" : "+v"(a1), "+v"(a2a), "+v"(a2b));
+                r1[i] = epi.add[a1];
+                r2a[i] = *reinterpret_cast<const float2*>(epi.add + a2a);
+                if (SET == 1) r2b[i] = *reinterpret_cast<const float2*>(epi.add + a2b);
+                const long long step = ((i & 3) == 3 ? 5 : 1) * oDHW;
+                a1 += step;
+                a2a += step;
+                a2b += step;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
+              auto fin = [&](float v, float res) {
+                v = (v + shv[qq]) + res;
+                return epi.relu ? relu_nan(v) : v;
+              };
+              y[y1] = fin(acc[r][0][qq], r1[qq]);
+              *reinterpret_cast<float2*>(y + y2a) = make_float2(fin(acc[r][1][qq], r2a[qq].x), fin(acc[r][2][qq], r2a[qq].y));
+              if (SET == 1) *reinterpret_cast<float2*>(y + y2b) = make_float2(fin(acc[r][3][qq], r2b[qq].x), fin(acc[r][4][qq], r2b[qq].y));
+              const long long step = ((qq & 3) == 3 ? 5 : 1) * oDHW;
+              y1 += step;
+              y2a += step;
+              y2b += step;
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
 #pragma unroll

@@ -1308,9 +1308,10 @@ class Conv3dFunction(torch.autograd.Function):
     x, w = ctx.saved_tensors
     gx = None
     if ctx.needs_input_grad[0]:
-      prev = ctx.carrier.take() if ctx.carrier is not None else None  # the other consumer's gradient, when it came first
+      carrier = getattr(ctx, 'carrier', None)  # (Conv3dStatsFunction shares this backward and has none)
+      prev = carrier.take() if carrier is not None else None  # the other consumer's gradient, when it came first
       gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride, acc=prev)
-      if prev is None and ctx.carrier is not None and ctx.carrier.leave(gx):
+      if prev is None and carrier is not None and carrier.leave(gx):
         gx = None  # first of the two: the other consumer's backward returns the sum
     gw = None
     if ctx.needs_input_grad[1]:
@@ -1389,7 +1390,7 @@ class Conv3dStatsFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, gy):
-    return Conv3dFunction.backward(ctx, gy)
+    return Conv3dFunction.backward(ctx, gy)[:3]  # (x, w, ws)
 
 
 def conv3d_bn_train(x, conv_weight, bn, add=None, relu=False):

@@ -140,8 +140,9 @@ def bn_act(bn, y, add=None, relu=False, add_carrier=None):
   return HF.bn_act(bn, y, add, relu, groups=current_bn_groups() if bn.training else 1, add_carrier=add_carrier)
 
 
-def bn_act_torch(bn, y, add=None, relu=False):
-  """The same layer as separate torch ops; only reached for tensor shapes the fused kernels do not take."""
+def bn_act_torch(bn, y, add=None, relu=False, add_carrier=None):
+  """The same layer as separate torch ops; only reached for tensor shapes the fused kernels do not take.  (add_carrier is left unarmed:
+  autograd adds the skip's gradient as usual.)"""
   groups = current_bn_groups()
   if groups > 1 and bn.training:  # group after group, like consecutive calls
     y = torch.cat([bn(part) for part in y.chunk(groups, 0)], 0)

@@ -427,7 +427,7 @@ def test_fast_paths_together_match_the_plain_composition(monkeypatch):
     net.pair_extractor = net.fold_cost_volume = net.feature_extraction.transposed_chain = fast
     if not fast:  # the regular 3x3 layers as the torch modules they are (vendor library)
       own = st.conv3
-      monkeypatch.setattr(st, 'conv3', lambda conv, x: conv(x) if type(conv) is torch.nn.Conv2d else own(conv, x))
+      monkeypatch.setattr(st, 'conv3', lambda conv, x, *carrier: conv(x) if type(conv) is torch.nn.Conv2d else own(conv, x, *carrier))
     preds = net(left.to(DEV), right.to(DEV))
     g = gt.to(DEV)
     loss = mode_ref.training_loss(preds, g, ~torch.isnan(g))

@@ -1,5 +1,11 @@
 #!/bin/bash
-# same-box A/B of two builds of the library on the transposed / stride-2 kernels: tools/experiments/libmode_hip_<variant>.so
+# same-box A/B of two builds of the library on the transposed / stride-2 kernels.  The two builds are NOT in the repository: build the
+# library from the two source states to compare and copy each mode-2022_amd/mode_hip/libmode_hip.so to
+# tools/experiments/libmode_hip_new.so / libmode_hip_dcold.so (*.so is git-ignored) before sending the tree to the GPU box.  The script swaps
+# them in turn under the product's name (new, old, new, old) and restores `new` at the end.
+for v in new dcold; do
+  [ -f tools/experiments/libmode_hip_$v.so ] || { echo "tools/experiments/libmode_hip_$v.so is missing (see the header of this script)"; exit 2; }
+done
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for v in new dcold new dcold; do
