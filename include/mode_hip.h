@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 23 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 24 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -423,6 +423,11 @@ int mode_conv2d_fwd_split(const float* x, const float* w, const mode_bn_epilogue
                           int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
                                mode_stream_t stream);
+/* The same with a gradient of the same tensor that is already there added in the store (gx = conv^T(gy) + acc, bit for bit autograd's
+ * sum; acc has gx's shape and must not alias it): the input of a residual block of the extractor has two consumers, its first
+ * convolution and the skip (models/submodule.py:36-46, 110-118).  Same predicate as mode_conv2d_bwd_data_split. */
+int mode_conv2d_bwd_data_split_acc(const float* gy, const float* w, const float* acc, float* gx, float* wpack, int B, int Ci, int H, int W,
+                                   int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                                  int dilation, int accumulate, mode_stream_t stream); /* arguments / workspace: mode_conv2d_bwd_weight */
 

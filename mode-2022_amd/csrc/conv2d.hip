@@ -275,6 +275,14 @@ extern "C" int mode_conv2d_bwd_data_split(const float* gy, const float* w, float
   return mode::conv2d_split_run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data_split", nullptr);
 }
 
+// gx = conv^T(gy) + acc: a gradient of the same tensor that is already there, added in the store (acc must not alias gx)
+extern "C" int mode_conv2d_bwd_data_split_acc(const float* gy, const float* w, const float* acc, float* gx, float* wpack, int B, int Ci, int H,
+                                              int W, int Co, int dilation, mode_stream_t stream) {
+  MODE_REQUIRE(acc, MODE_ERR_BAD_ARG, "mode_conv2d_bwd_data_split_acc: null acc");
+  return mode::conv2d_split_run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data_split_acc", nullptr,
+                                acc);
+}
+
 extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
                                mode_stream_t stream) {
   return run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd");

@@ -72,7 +72,7 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
   const long long total = (long long)MT * NCHUNK * 9 * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * 3);
-    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold_shift(bn, o);
+    for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold == 1 ? fold_shift(bn, o) : 0.f;  // (fold 2: the accumulate form)
   }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -88,7 +88,7 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
       const int c = ch * 16 + 8 * (lane >> 5) + j;
       v[j] = 0.f;
       if (o < rows && c < K) v[j] = flip ? w[((long long)c * rows + o) * 9 + 8 - tap] : w[((long long)o * K + c) * 9 + tap];
-      if (fold && o < rows) v[j] *= fold_scale(bn, o);
+      if (fold == 1 && o < rows) v[j] *= fold_scale(bn, o);
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
@@ -381,8 +381,10 @@ bool conv2d_split_supported(int K, int rows, int dilation) {
 
 // rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels; flip 0 / 1 as pack_w2d_split
 int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
-                     hipStream_t st, const char* who, const mode_bn_epilogue* bn) {
+                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in) {
   MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE(!(acc_in && bn), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue", who);
+  MODE_REQUIRE(!acc_in || acc_in != y, MODE_ERR_BAD_ARG, "%s: acc must not be the output tensor", who);
   MODE_REQUIRE(conv2d_split_supported(K, rows, dilation), MODE_ERR_UNSUPPORTED,
                "%s: %d output / %d reduction channels, dilation %d not covered by the split kernel", who, rows, K, dilation);
   MODE_REQUIRE((long long)std::max(K, rows) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
@@ -395,9 +397,14 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
   const int MT = cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
   uint4* wp = reinterpret_cast<uint4*>(wpack);
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : 0,
+  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : acc_in ? 2 : 0,
                      bn ? *bn : mode_bn_epilogue());
-  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  if (acc_in) {  // y = conv(x) + acc_in: the residual epilogue with zero shifts ((v + 0) + a is a + v exactly)
+    epi.shift = wpack + npack * 3 * 4;
+    epi.add = acc_in;
+    epi.relu = 0;
+  }
   // two output-channel tiles per launch (64 channels); 128-channel layers run as two launches
   for (int m = 0; m < MT; m += 2) {
     d.o0 = 32 * m;

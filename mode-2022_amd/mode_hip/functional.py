@@ -190,8 +190,24 @@ def conv2d_fwd(x, w, dilation=1):
   return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation)
 
 
-def conv2d_bwd_data(gy, w, dilation=1):
-  return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation)
+def conv2d_bwd_data(gy, w, dilation=1, acc=None):
+  """acc: a gradient of the same tensor that is already there; the sum is returned (added in the split kernel's store where it runs)."""
+  if acc is None:
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation)
+  require_gpu(gy, w, acc)
+  acc = acc.contiguous()
+  require_f32c(gy, w, acc)
+  B, _, H, W = gy.shape
+  Co, Ci = w.shape[:2]
+  if not (CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 1) == 1 and tuple(acc.shape) == (B, Ci, H, W)):
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, Ci, dilation).add_(acc)
+  gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device)
+  with torch.cuda.device_of(gy), profiling.region('conv2d_bwd_data[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED else 'conv2d_bwd_data',
+                                                  4 * (gy.numel() + 2 * gx.numel() + w.numel()), 2 * B * H * W * Ci * Co * 9, gy.device):
+    wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=gy.device)
+    check(lib().mode_conv2d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(gy)),
+          'mode_conv2d_bwd_data_split_acc')
+  return gx
 
 
 class Conv2d3x3Function(torch.autograd.Function):
@@ -200,9 +216,10 @@ class Conv2d3x3Function(torch.autograd.Function):
   faster (_conv2d_own), else on the vendor library's fp32 Winograd."""
 
   @staticmethod
-  def forward(ctx, x, w, dilation):
+  def forward(ctx, x, w, dilation, carrier=None):
     ctx.save_for_backward(x, w)
     ctx.dilation = dilation
+    ctx.carrier = carrier  # GradCarrier of x (x has one other consumer: the skip of its residual block), or None
     ctx.own = _conv2d_own(x, w)
     if ctx.own:
       return conv2d_fwd(x, w.contiguous(), dilation)
@@ -216,22 +233,29 @@ class Conv2d3x3Function(torch.autograd.Function):
     gy = gy.contiguous()
     gx = None
     if ctx.needs_input_grad[0]:
+      prev = ctx.carrier.take() if ctx.carrier is not None else None  # the skip's gradient, when it came first (it always does)
       if ctx.own:
-        gx = conv2d_bwd_data(gy, w.contiguous(), dil)
+        gx = conv2d_bwd_data(gy, w.contiguous(), dil, acc=prev)
       else:
         gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
+        if prev is not None:
+          gx = gx.add_(prev)
+      if prev is None and ctx.carrier is not None and ctx.carrier.leave(gx):
+        gx = None
     gw = None
     if ctx.needs_input_grad[1]:
       sink = grad_sink(w)
       gw = conv2d_bwd_weight(gy, x.contiguous(), dil, into=sink)
       if sink is not None:
         gw = None
-    return gx, gw, None
+    return gx, gw, None, None
 
 
-def conv2d_3x3(x, w, dilation=1):
+def conv2d_3x3(x, w, dilation=1, carrier=None):
   """Callers check conv2d_wgrad_supported(x, w) first (models/stage3d.conv3 does)."""
-  return Conv2d3x3Function.apply(x, w, dilation)
+  if carrier is not None:
+    carrier.arm(x.requires_grad and torch.is_grad_enabled())
+  return Conv2d3x3Function.apply(x, w, dilation, carrier)
 
 
 # ------------------------------------------------------------------------------------ cost volume + dres0[0][0], fused

@@ -51,7 +51,7 @@ def conv3(conv, x, carrier=None):
     # regular stride-1 3x3 layer of the 2-D extractor: own kernels (csrc/conv2d.hip, conv2d_wgrad.hip)
     if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
       if HF.conv2d_wgrad_supported(x, conv.weight):
-        return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0])
+        return HF.conv2d_3x3(x.contiguous(), conv.weight, conv.dilation[0], carrier)
     elif HF._conv2d_own(x, conv.weight):
       return HF.conv2d_fwd(x.contiguous(), conv.weight.detach().contiguous(), conv.dilation[0])
   if type(conv) is nn.Conv2d and HF.conv2d_3x3_s2_supported(x, conv) and torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):

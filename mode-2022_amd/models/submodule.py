@@ -68,6 +68,13 @@ class _ResidualBlock(nn.Module):
   def _residual(self, x, final_relu):
     """conv-bn-relu, conv-bn, + shortcut [, relu]: the second BatchNorm, the add and the ReLU are one fused pass
     (the reference runs bn, `out += x` and relu as three kernels)."""
+    # identity skip: x has two consumers, conv1 and the add behind conv2's BatchNorm -- the skip's gradient (which the BatchNorm backward
+    # produces first) is added inside conv1's input-gradient kernel instead of by a pass of autograd's (HF.GradCarrier; regular 3x3
+    # layers on the split kernels -- a spherical conv1 leaves the carrier unarmed and nothing changes)
+    car = stage3d.HF.grad_carrier(x) if self.downsample is None and isinstance(self.conv1[0][0], nn.Conv2d) else None
+    if car is not None:
+      out = stage3d.conv_bn(self.conv1[0], x, relu=True, x_carrier=car)
+      return stage3d.conv_bn(self.conv2, out, relu=final_relu, add=x, add_carrier=car)
     out = stage3d.conv_bn(self.conv1[0], x, relu=True)
     shortcut = x if self.downsample is None else stage3d.conv_bn(self.downsample, x)
     return stage3d.conv_bn(self.conv2, out, relu=final_relu, add=shortcut)

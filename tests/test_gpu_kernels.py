@@ -954,6 +954,14 @@ def test_conv3d_input_gradient_with_a_gradient_already_there(arith):
     got = HF.conv3d_bwd_data(gy, w, (B, ci, D, H, W), stride, acc=acc)
     assert torch.equal(got, plain + acc), (ci, co, stride, float((got - (plain + acc)).abs().max()))
     assert torch.equal(acc, keep) and got.data_ptr() != acc.data_ptr()
+  for (ci, co, dil, shape) in ((64, 64, 1, (2, 20, 36)), (32, 64, 2, (1, 9, 33)), (128, 128, 1, (1, 17, 40)), (24, 40, 1, (1, 8, 34))):
+    B, H, W = shape  # (mode_conv2d_bwd_data_split_acc; the last one: channels off the split kernel's grid)
+    w = _rand((co, ci, 3, 3), 411, 0.1).to(DEV)
+    gy = _rand((B, co, H, W), 412).to(DEV)
+    acc = _rand((B, ci, H, W), 413).to(DEV)
+    plain = HF.conv2d_bwd_data(gy, w, dil)
+    got = HF.conv2d_bwd_data(gy, w, dil, acc=acc)
+    assert torch.equal(got, plain + acc), (ci, co, dil, float((got - (plain + acc)).abs().max()))
 
 
 @pytest.mark.parametrize('relu', [True, False])

@@ -228,31 +228,42 @@ def test_gradient_carriers_give_autograds_sums_bit_for_bit(monkeypatch):
   the add in their store really ran (3 per backward)."""
   from mode_hip import functional as HF
   net, left, right, gt = _tiny_net(11)
-  calls = []
-  real = HF.conv3d_bwd_data
+  calls, calls2d = [], []
+  real, real2d = HF.conv3d_bwd_data, HF.conv2d_bwd_data
 
   def spy(gy, w, in_shape, stride=1, acc=None):
     calls.append((stride, acc is not None))
     return real(gy, w, in_shape, stride, acc)
 
+  def spy2d(gy, w, dilation=1, acc=None):
+    calls2d.append(acc is not None)
+    return real2d(gy, w, dilation, acc)
+
   monkeypatch.setattr(HF, 'conv3d_bwd_data', spy)
+  monkeypatch.setattr(HF, 'conv2d_bwd_data', spy2d)
   grads = {}
   for on in (False, True):
     monkeypatch.setattr(HF, 'GRAD_CARRIERS', on)
     net.zero_grad(set_to_none=True)
-    del calls[:]
+    del calls[:], calls2d[:]
     torch.manual_seed(0)
     loss = _loss(net, left, right, gt)
     loss.backward(retain_graph=True)
     grads[on] = {k: p.grad.clone() for k, p in net.named_parameters()}
     n_acc = sum(1 for c in calls if c[1])
     assert n_acc == (3 if on else 0), calls
+    # the extractor's regular residual blocks with an identity skip, once per pass of the paired extractor
+    n2d = sum(1 for c in calls2d if c)
+    blocks = [m for m in net.feature_extraction.modules() if hasattr(m, '_residual') and m.downsample is None and
+              isinstance(m.conv1[0][0], torch.nn.Conv2d)]
+    print('identity-skip regular blocks: %d, input gradients with the skip added in the kernel: %d' % (len(blocks), n2d))
+    assert n2d == (len(blocks) if on else 0) and len(blocks) >= 10, (n2d, len(blocks), len(calls2d))
     if on:
       assert sorted(c[0] for c in calls if c[1]) == [1, 2, 2]  # dres1's first convolution; the stride-2 convolutions of dres3 / dres4
       net.zero_grad(set_to_none=True)
-      del calls[:]
+      del calls[:], calls2d[:]
       loss.backward()  # the same graph again: the carriers are empty after the first pass and work the same way
-      assert sum(1 for c in calls if c[1]) == 3
+      assert sum(1 for c in calls if c[1]) == 3 and sum(1 for c in calls2d if c) == len(blocks)
       for k, p in net.named_parameters():
         assert torch.equal(p.grad, grads[True][k]), k
   for k in grads[False]:
