@@ -64,6 +64,7 @@ def _run_convbn_relu_chain(seq, x):
 
 class _ResidualBlock(nn.Module):
   expansion = 1
+  input_shared = False  # True: the block's input has consumers outside the block (plain attribute, not state)
 
   def _residual(self, x, final_relu):
     """conv-bn-relu, conv-bn, + shortcut [, relu]: the second BatchNorm, the add and the ReLU are one fused pass
@@ -71,7 +72,9 @@ class _ResidualBlock(nn.Module):
     # identity skip: x has two consumers, conv1 and the add behind conv2's BatchNorm -- the skip's gradient (which the BatchNorm backward
     # produces first) is added inside conv1's input-gradient kernel instead of by a pass of autograd's (HF.GradCarrier; regular 3x3
     # layers on the split kernels -- a spherical conv1 leaves the carrier unarmed and nothing changes)
-    car = stage3d.HF.grad_carrier(x) if self.downsample is None and isinstance(self.conv1[0][0], nn.Conv2d) else None
+    # (not when x is also used outside the block -- `input_shared`, set by the extractor for layer3[0], whose input is concatenated into
+    # the output as well: with three consumers the carrier would change the association of autograd's sum)
+    car = stage3d.HF.grad_carrier(x) if (self.downsample is None and not self.input_shared and isinstance(self.conv1[0][0], nn.Conv2d)) else None
     if car is not None:
       out = stage3d.conv_bn(self.conv1[0], x, relu=True, x_carrier=car)
       return stage3d.conv_bn(self.conv2, out, relu=final_relu, add=x, add_carrier=car)
@@ -152,6 +155,7 @@ class sphere_feature_extraction(nn.Module):
     self.layer2 = self._make_layer(RegularBasicBlock, h2, w2, sphereType, 64, 64, 8, 2, 1, 1)
     self.layer3 = self._make_layer(RegularBasicBlock, h4, w4, sphereType, 64, 64, 4, 1, 1, 2)
     self.layer4 = self._make_layer(SphereBasicBlock, h4, w4, sphereType, 64, 128, 8, 1, 1, 1)
+    self.layer3[0].input_shared = True  # layer2's output also goes into the concatenation of forward()
     self.lastconv = nn.Sequential(convbn(256, 128, 1, 1, 0, 1), nn.ReLU(inplace=True), convbn(128, 128, 3, 1, 1, 1),
                                   nn.ReLU(inplace=True), convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True))
 
