@@ -37,16 +37,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NT = 256;
+#ifndef MODE_SPLIT_NT
+#define MODE_SPLIT_NT 256  // (512: two waves per SIMD, two rows each -- measured in round 5)
+#endif
+constexpr int NT = MODE_SPLIT_NT;
 constexpr int TD = 2, TH = 8, ID = TD + 2, IH = TH + 2, IW = 34;
 constexpr int ROWS = ID * IH;           // 40 haloed rows
 constexpr int ITEMS = ROWS * IW;        // 1 360 positions per chunk
-constexpr int KIT = (ITEMS + 256 - 1) / 256;  // 6 positions per thread
-constexpr int PIECE = KIT * 256;        // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
+constexpr int KIT = (ITEMS + NT - 1) / NT;    // 6 positions per thread
+constexpr int PIECE = KIT * NT;         // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
 constexpr int BUF = 3 * PIECE;          // uint4 per buffer
 constexpr int NPAIR = 14;
 constexpr int WAHEAD = 6;  // weight fragments are loaded this many tap pairs ahead (3 measured the same, r03w)
-constexpr int R = TD * TH / 4;          // 4 output rows per matrix wave
+constexpr int R = TD * TH / (NT / 64);  // 4 output rows per matrix wave
 constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
 
 struct SDims {
