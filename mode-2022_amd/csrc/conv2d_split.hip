@@ -195,6 +195,30 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
       for (int qq = 0; qq < 16; ++qq) shiftv[m][qq] = epi.shift[min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1)];
   }
 
+  // (ADD_AHEAD) per tile, not per chunk: the element offset of this lane's pixel of row r inside channel 0 of the tile's sample (a cached
+  // dummy element for pixels outside the image), and once per kernel the channel part of the 16 offsets -- a request is one 32-bit add on
+  // a uniform base (conv3d_split.hip, DESIGN 3s: computed per chunk this was ~100 vector instructions at every chunk's top)
+  unsigned ep_off[ADD_AHEAD ? R : 1], ep_chan[ADD_AHEAD ? MT : 1][16];
+  int ep_b = 0;
+  auto ep_tile = [&](int k) {
+    int b, h0, w0;
+    tile_of(k, b, h0, w0);
+    ep_b = __builtin_amdgcn_readfirstlane(b);
+#pragma unroll
+    for (int r = 0; r < (ADD_AHEAD ? R : 1); ++r) {
+      const int gh = h0 + wave * R + r, gw = w0 + (lane & 31);
+      ep_off[r] = (gh < d.H && gw < d.W) ? (unsigned)(gh * d.W + gw) : (unsigned)(lane & 31);
+    }
+  };
+  if (ADD_AHEAD) {
+    ep_tile(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq)
+        ep_chan[m][qq] = (unsigned)min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1) * (unsigned)HWi;
+  }
+
   // weight fragments: ring of 3 taps, fetched 2 taps ahead
   uint4 aring[3][MT][3];
   auto load_a = [&](int slot3, int ch, int tap) {
@@ -221,19 +245,13 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
     const uint4* src = sm + (g & 1) * BUF;
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
     stage_begin(min(g + 1, G - 1));  // (after the last chunk: once more into the idle buffer -- keeps the body free of branches)
-    int ep_off[R];
+    unsigned ep_cur[ADD_AHEAD ? R : 1];  // where this chunk's residual requests go: the tile's pixels in its last chunk, a cached dummy row else
     const float* ep_base = epi.add;
     if (ADD_AHEAD) {
-      int b, h0, w0;
-      tile_of(k_tile, b, h0, w0);
       const bool last = ch == d.NCHUNK - 1;
-      ep_base = epi.add + (last ? (long long)b * d.Co * HWi : 0);
+      ep_base = epi.add + (long long)(last ? ep_b : 0) * d.Co * HWi;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int gh = h0 + wave * R + r, gw = w0 + (lane & 31);
-        const unsigned ok = (unsigned)last & (unsigned)(gh < d.H) & (unsigned)(gw < d.W);
-        ep_off[r] = ok ? gh * d.W + gw : -1;
-      }
+      for (int r = 0; r < R; ++r) ep_cur[r] = last ? ep_off[r] : (unsigned)(lane & 31);
     }
     uint4 bq[2][R][3];
 #pragma unroll
@@ -257,10 +275,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
       if (ADD_AHEAD && tap >= 9 - 2 * R * MT && tap < 9) {  // 8 residual values under each of the last 2 * R * MT taps
         const int i = tap - (9 - 2 * R * MT), m = i / (2 * R), r = (i / 2) % R;
 #pragma unroll
-        for (int qq = 8 * (i & 1); qq < 8 * (i & 1) + 8; ++qq) {
-          const int o = min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1);
-          addv[m][r][qq] = ep_base[ep_off[r] >= 0 ? (long long)o * HWi + ep_off[r] : (lane & 31)];
-        }
+        for (int qq = 8 * (i & 1); qq < 8 * (i & 1) + 8; ++qq) addv[m][r][qq] = ep_base[ep_cur[r] + ep_chan[m][qq]];
       }
       if (tap >= 9 - KIT) stage_commit((g + 1) & 1, tap - (9 - KIT));
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
@@ -331,6 +346,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
         for (int m = 0; m < MT; ++m) acc[m][r] = (f32x16){0};
       }
       ++k_tile;
+      if (ADD_AHEAD) ep_tile(min(k_tile, max(mine - 1, 0)));
     }
     ch = ch_next;
     lds_barrier();
