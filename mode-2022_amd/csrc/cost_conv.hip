@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int NT = 128;
+constexpr int NTB = 256;  // the backward assembly: two halves of 128 threads share the columns
 
 // grid = B*Co*H blocks; LDS = 9*(W+2) + 9*W floats.  R, T: (B, 9*Co, H, W) with channel = t*Co + o.
 // EPI: eval-mode BatchNorm (+ ReLU) of dres0[0] applied to the assembled value on its way out (scale and shift of channel o from
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float*
 // first version staged them one dependent load at a time and took 0.62 ms; the 18 sums themselves are cheap): the three kd of
 // one kw share a pass over the column for gR, and the (kd, kw) with the same kd - kw share a pass over the diagonal for gT.
 // Sums over d ascending: deterministic.
-__global__ __launch_bounds__(NT) void cost_conv_assemble_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gR,
+__global__ __launch_bounds__(NTB) void cost_conv_assemble_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gR,
                                                                     float* __restrict__ gT, int B, int Co, int D, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int S = W + 4;
@@ -92,37 +93,43 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_bwd_kernel(const float*
   const float* gb = gout + (((long long)b * Co + o) * D) * HW + (long long)h * W;
   if ((W & 3) == 0 && (reinterpret_cast<size_t>(gout) & 15) == 0) {
     const int W4 = W >> 2, total = D * W4;
-    for (int base = 0; base < total; base += NT * 8) {
+    for (int base = 0; base < total; base += NTB * 8) {
       float4 v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int idx = base + j * NT + threadIdx.x;
+        const int idx = base + j * NTB + threadIdx.x;
         const int d = idx / W4, w4 = idx - d * W4;
         v[j] = *reinterpret_cast<const float4*>(gb + (idx < total ? (long long)d * HW + w4 * 4 : 0));
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int idx = base + j * NT + threadIdx.x;
+        const int idx = base + j * NTB + threadIdx.x;
         const int d = idx / W4, w4 = idx - d * W4;
         if (idx < total) *reinterpret_cast<float4*>(gl + d * S + w4 * 4) = v[j];
       }
     }
   } else {
-    for (int idx = threadIdx.x; idx < D * W; idx += NT) {
+    for (int idx = threadIdx.x; idx < D * W; idx += NTB) {
       const int d = idx / W, w = idx - d * W;
       gl[d * S + w] = gb[(long long)d * HW + w];
     }
   }
-  for (int i = threadIdx.x; i < 4 * (D + 1); i += NT) sm[(i >> 2) * S + (i & 3)] = 0.f;  // the pads: sm[0..3] and behind every row
+  for (int i = threadIdx.x; i < 4 * (D + 1); i += NTB) sm[(i >> 2) * S + (i & 3)] = 0.f;  // the pads: sm[0..3] and behind every row
   __syncthreads();
-  for (int x = threadIdx.x; x < W; x += NT) {
+  // Two halves of the block share a column x: the first takes gR and the diagonal delta = -2, the second the diagonals -1 .. 2 (192
+  // LDS reads each instead of 384 in one thread; every (kd, kw) sum belongs to exactly one of them).  The d loops are unrolled by 8: as
+  // rolled loops every read waited for its own round trip to the LDS (0.41 ms per launch against 0.08 ms of HBM time for the 403 MB).
+  const int part = threadIdx.x / (NTB / 2);
+  for (int x = threadIdx.x % (NTB / 2); x < W; x += NTB / 2) {
     const long long dst = (((long long)b * 9) * Co + o) * HW + (long long)h * W + x;
     const long long tstride = (long long)Co * HW;
     // gR: one pass over column x - kw + 1 for the three kd
+    if (part == 0) {
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const float* col = gl + (x - kw + 1);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
       for (int d = 0; d < D; ++d) {
         const float v = col[d * S];
         // d' = d + kd - 1 must lie in [0, D) and be <= x
@@ -134,12 +141,15 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_bwd_kernel(const float*
       gR[dst + (1 * 3 + kw) * tstride] = s1;
       gR[dst + (2 * 3 + kw) * tstride] = s2;
     }
+    }
     // gT: one pass over the diagonal w = x + d + delta for every (kd, kw) with kd - kw = delta
     float st[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) st[t] = 0.f;
 #pragma unroll
     for (int delta = -2; delta <= 2; ++delta) {
+      if ((delta == -2) != (part == 0)) continue;  // (uniform per half of the block)
+#pragma unroll 8
       for (int d = 0; d < D; ++d) {
         const int w = x + d + delta;
         const float v = (w >= -1 && w <= W) ? gl[d * S + w] : 0.f;
@@ -153,7 +163,10 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_bwd_kernel(const float*
       }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) gT[dst + t * tstride] = st[t];
+    for (int t = 0; t < 9; ++t) {
+      const int delta = t / 3 - t % 3;  // kd - kw
+      if ((delta == -2) == (part == 0)) gT[dst + t * tstride] = st[t];
+    }
   }
 }
 
@@ -206,6 +219,6 @@ extern "C" int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* 
   MODE_REQUIRE(lds <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: D x W = %d x %d too large for the row buffer", who, D, W);
   rc = mode::allow_lds(cost_conv_assemble_bwd_kernel, lds, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(cost_conv_assemble_bwd_kernel, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), gout, gR, gT, B, Co, D, H, W);
+  hipLaunchKernelGGL(cost_conv_assemble_bwd_kernel, dim3(B * Co * H), dim3(NTB), lds, mode::as_stream(stream), gout, gR, gT, B, Co, D, H, W);
   return mode::check_launch(who);
 }
