@@ -41,12 +41,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MODE_SPLIT_NT 256  // (512: two waves per SIMD, two rows each -- measured in round 5)
 #endif
 constexpr int NT = MODE_SPLIT_NT;
+#ifndef MODE_SPLIT_F16
+#define MODE_SPLIT_F16 0  // (1: experiment of round 5 -- two fp16 pieces and three MFMAs per product instead of three bf16 pieces and six)
+#endif
+constexpr int NP = MODE_SPLIT_F16 ? 2 : 3;      // pieces per fp32 value
+constexpr int NTERM = MODE_SPLIT_F16 ? 3 : 6;   // MFMAs per product
 constexpr int TD = 2, TH = 8, ID = TD + 2, IH = TH + 2, IW = 34;
 constexpr int ROWS = ID * IH;           // 40 haloed rows
 constexpr int ITEMS = ROWS * IW;        // 1 360 positions per chunk
 constexpr int KIT = (ITEMS + NT - 1) / NT;    // 6 positions per thread
 constexpr int PIECE = KIT * NT;         // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
-constexpr int BUF = 3 * PIECE;          // uint4 per buffer
+constexpr int BUF = NP * PIECE;          // uint4 per buffer
 constexpr int NPAIR = 14;
 constexpr int WAHEAD = 6;  // weight fragments are loaded this many tap pairs ahead (3 measured the same, r03w)
 constexpr int R = TD * TH / (NT / 64);  // 4 output rows per matrix wave
@@ -65,6 +70,20 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+#if MODE_SPLIT_F16
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// (a, b) -> two packed fp16 pairs (v_cvt_pk_f16_f32, round to nearest even: the remainder a - a1 is exact in fp32, the second piece's
+// rounding unbiased -- with round-toward-zero pieces the 2^-22 residue of every product has one sign); p3 unused
+__device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  const f32x2 v = {a, b};
+  const f16x2 h1 = __builtin_convertvector(v, f16x2);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+  const f32x2 r = {a - (float)h1[0], __builtin_fmaf(-1.f, (float)h1[1], b)};
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  p3 = 0;
+}
+#else
 // (a, b) -> the three packed bf16 pairs; the remainders are exact in fp32
 __device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
   // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
@@ -77,6 +96,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t&
   asm("" : "+v"(sa), "+v"(sb));
   p3 = pack2(sa, sb);
 }
+#endif
 
 // wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of Wsrc(o = m*32 + (lane & 31), c = ch*8 + j,
 // tap = 2 * pair + (lane >> 5)), j = 0..7; zero for tap 27, o >= rows, c >= K.  flip / fold as pack_w3d (conv3d.hip): flip 0 forward
@@ -86,7 +106,7 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
                                int fold, mode_bn_epilogue bn) {
   const long long total = (long long)MT * NCHUNK * NPAIR * 64;
   if (fold && blockIdx.x == 0) {
-    float* shifts = reinterpret_cast<float*>(wp + total * 3);
+    float* shifts = reinterpret_cast<float*>(wp + total * NP);
     for (int o = threadIdx.x; o < rows; o += blockDim.x) shifts[o] = fold == 1 ? fold_shift(bn, o) : 0.f;  // (fold 2: zero shifts, no scale --
   }                                                                                                       // the accumulate form)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -110,10 +130,10 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
-    uint4* dst = wp + (idx - lane) * 3 + lane;
+    uint4* dst = wp + (idx - lane) * NP + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    if (NP == 3) dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
   }
 }
 
@@ -122,7 +142,11 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+#if MODE_SPLIT_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of a tap inside the haloed tile
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   // 64-channel layer used to be two launches; as one, the tail of the first block's tiles overlaps with the second block, and at the
   // small volumes -- 96 tiles at 12 x 64 x 32 -- both blocks run side by side on CUs that sat idle)
   d.o0 += 32 * MT * (int)blockIdx.y;
-  wp += (long long)blockIdx.y * MT * d.NCHUNK * NPAIR * 192;
+  wp += (long long)blockIdx.y * MT * d.NCHUNK * NPAIR * (64 * NP);
 
   // this workgroup's tiles: XCD x = blockIdx % 8 owns a contiguous tile range, its workgroups take every nwx-th tile of it
   const int nwx = gridDim.x / kNumXCD;
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   };
   // split position k of the loaded chunk and write its three pieces into buffer `buf`, in two halves (one per tap pair):
   // half 0 splits channels 0..3, half 1 channels 4..7 and stores.  Branch-free: the code sits between the MFMAs of a pair.
-  uint32_t sq[3][4];
+  uint32_t sq[3][4];  // (NP pieces used)
   auto stage_commit = [&](int buf, int k, int h) {
     const bool ok = (okmask >> k) & 1;
 #pragma unroll
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     if (h == 1) {
       uint4* dst = sm + buf * BUF + tid + k * NT;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[p * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
+      for (int p = 0; p < NP; ++p) dst[p * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
     }
   };
 
@@ -301,16 +325,16 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
       for (int qq = 0; qq < 16; ++qq)
         ep_chan[m][qq] = (unsigned)min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1) * (unsigned)DHW;
   }
-  const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
+  const long long mstride = (long long)d.NCHUNK * NPAIR * (64 * NP);
 
   // weight fragments: a ring of 7 tap pairs, fetched 6 pairs ahead (their loads queue behind the 48 staging loads of a chunk)
-  uint4 aring[7][MT][3];
+  uint4 aring[7][MT][NP];
   auto load_a = [&](int slot7, int ch, int pair) {
-    const uint4* wq = wp + ((long long)ch * NPAIR + pair) * 192 + lane;
+    const uint4* wq = wp + ((long long)ch * NPAIR + pair) * (64 * NP) + lane;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) aring[slot7][m][p] = wq[m * mstride + p * 64];
+      for (int p = 0; p < NP; ++p) aring[slot7][m][p] = wq[m * mstride + p * 64];
   };
 
   if (G > 0) {
@@ -343,11 +367,11 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < R; ++r) ep_cur[r] = last ? ep_off[r] : (unsigned)(lane & 31);
     }
-    uint4 bq[2][R][3];
+    uint4 bq[2][R][NP];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? tap_off(1) : tap_off(0))];
+      for (int p = 0; p < NP; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? tap_off(1) : tap_off(0))];
 #pragma unroll
     for (int pair = 0; pair < NPAIR; ++pair) {
       // fragments of the next pair (the empty second half of the last pair reads tap 26 again: finite data under zero weights)
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bq[(pair + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];
+          for (int p = 0; p < NP; ++p) bq[(pair + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];
       }
       // weights 6 pairs ahead, into the slot the previous pair has left
       if (pair + WAHEAD < NPAIR)
@@ -381,20 +405,26 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
       acc[m][r] = mfma_bf16(aring[pair % 7][m][PA], bq[pair & 1][r][PB], acc[m][r]);
+#if MODE_SPLIT_F16
+      MODE_SPLIT_TERM(1, 0)
+      MODE_SPLIT_TERM(0, 1)
+      MODE_SPLIT_TERM(0, 0)
+#else
       MODE_SPLIT_TERM(2, 0)
       MODE_SPLIT_TERM(0, 2)
       MODE_SPLIT_TERM(1, 1)
       MODE_SPLIT_TERM(1, 0)
       MODE_SPLIT_TERM(0, 1)
       MODE_SPLIT_TERM(0, 0)
+#endif
 #undef MODE_SPLIT_TERM
       // one MFMA, then up to 3 vector-ALU instructions and one fragment read, 24 times: spreads the staging arithmetic and the
       // next pair's reads over the matrix instructions (5 single-issue slots fit under one 32x32x16 MFMA)
 #pragma unroll
-      for (int i = 0; i < MT * R * 6; ++i) {
+      for (int i = 0; i < MT * R * NTERM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MODE_SPLIT_F16 ? 6 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MODE_SPLIT_F16 ? 2 : 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -533,9 +563,9 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
   if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
                      d.NCHUNK, flip, bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue());
-  Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  Epi epi = make_epi(bn, wpack + npack * NP * 4);
   if (acc_in) {  // y = conv(x) + acc_in: the residual epilogue with zero shifts ((v + 0) + a is a + v exactly)
-    epi.shift = wpack + npack * 3 * 4;
+    epi.shift = wpack + npack * NP * 4;
     epi.add = acc_in;
     epi.relu = 0;
   }
