@@ -30,7 +30,15 @@ import torch.nn.functional as F  # noqa: E402
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense; a split-bf16 fp32 product costs six bf16 MFMAs (csrc/conv3d_split.hip)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense (bf16 and fp16 alike); a split-bf16 fp32 product costs six bf16 MFMAs (csrc/conv3d_split.hip)
+# The stride-1 3-D layers in training run on TWO fp16 pieces and three MFMAs per product (functional.CONV3D_S1_F16): their
+# labels are priced against the dense peak / 3.  Set from --no-conv3d-f16 in main().
+CONV3D_S1_F16 = True
+
+
+def _on_f16_path(label):
+  import re
+  return bool(CONV3D_S1_F16 and re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight)\[(\d+)->(\d+) s1 ', label) and not re.search(r'->1 ', label))
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
                 'classif_fwd': 'hbm', 'classif_bwd': 'hbm'}
@@ -66,6 +74,9 @@ def parse():
                   help="initial weights: 'recipe' = tests/golden/recipe.py state (SURVEY 8c/8d), 'torch' = the constructor's random init under torch.manual_seed(0)")
   ap.add_argument('--no-fused-loss', action='store_true',
                   help='A/B: the loss of train_disparity.py:151-158 as torch ops on the three predictions instead of ModeDisparity.forward_loss')
+  ap.add_argument('--no-conv3d-f16', action='store_true',
+                  help='A/B: the stride-1 3-D layers of the training step on three bf16 pieces / six MFMAs per product like every other split '
+                       'kernel, instead of two fp16 pieces / three MFMAs with a power-of-two scale per operand tensor (functional.CONV3D_S1_F16)')
   ap.add_argument('--no-grad-carriers', action='store_true',
                   help="A/B: autograd's own pairwise accumulation for the tensors with two consumers (functional.GRAD_CARRIERS = False)")
   ap.add_argument('--no-fused-classif', action='store_true',
@@ -132,6 +143,8 @@ def label_peak(label, conv_arith, on_split=None):
   if KERNEL_BOUND.get(label.split('[')[0], 'mfma') == 'hbm':
     return 'hbm', HBM_PEAK_GBPS, 'GB/s'
   split = conv_arith == 'bf16x6' and (on_split if on_split is not None else _on_split_path)(label)
+  if split and _on_f16_path(label):
+    return 'mfma', MFMA_BF16_PEAK_TFLOPS / 3.0, 'TFLOP/s'  # two fp16 pieces: three MFMAs per fp32 product
   return 'mfma', (MFMA_BF16_PEAK_TFLOPS / 6.0 if split else MFMA_F32_PEAK_TFLOPS), 'TFLOP/s'
 
 
@@ -163,6 +176,8 @@ def kernel_of(label, conv_arith, on_split=None):
     if split and stride == 2:
       return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
+      if _on_f16_path(label):
+        return 'conv3d_split_kernel<1,0,true>'  # (<1,2,true> where a gradient is added in the store)
       return 'conv3d_split_kernel<1,0>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1>'  # (<1,2> with a residual)
     return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
   if name == 'conv3d_bwd_weight':
@@ -496,6 +511,8 @@ def main():
   HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
   HF.CLASSIF_FUSED = not args.no_fused_classif
   HF.GRAD_CARRIERS = not args.no_grad_carriers
+  global CONV3D_S1_F16
+  CONV3D_S1_F16 = HF.CONV3D_S1_F16 = not args.no_conv3d_f16 and args.conv_arith == 'bf16x6'
 
   torch.backends.cudnn.benchmark = bool(args.vendor_autotune)
   torch.manual_seed(0)
@@ -662,7 +679,9 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32' if args.conv_arith == 'f32' else ('f32 (3x3x3, 3x3 and spherical convolution layers incl. gradients: fp32 operands split exactly into 3 bf16 '
-                                                            'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l)'),
+                                                            'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l' +
+                                                            ('; the stride-1 3x3x3 layers of the training step: 2 fp16 pieces with a power-of-two scale '
+                                                             'per operand tensor, 3 fp16 MFMAs per product, DESIGN.md 3u)' if CONV3D_S1_F16 else ')')),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,

@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 24 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 25 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -389,6 +389,21 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
 /* The same with the folded eval-mode BatchNorm (+ residual) (+ ReLU) epilogue of mode_deconv3d_fwd_bn (convbn_3d around the
  * ConvTranspose3d of hourglass conv5 / conv6 in eval mode, mode_disparity.py:23-25, 38-45): whole 32-channel output tiles
  * (mode_deconv3d_split_bn_supported(Cin, Cout) == 1); wpack >= mode_conv3d_wpack_bytes(Cin, Cout). */
+/* EXPERIMENTAL arithmetic of the stride-1 3x3x3 layers (nn.Conv3d of convbn_3d, models/submodule.py:20-22; functional.CONV_ARITH =
+ * 'f16x3', off by default): fp32 operands split into TWO fp16 pieces, three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones
+ * (2^-22 per product; 30-35 % faster).  fp16's range is narrow, so each operand is scaled by a power of two that brings its tensor's
+ * largest magnitude to [2^14, 2^15): amax_* = DEVICE floats, one per operand, filled by mode_abs_max (an order-independent maximum
+ * over bit patterns; no host synchronisation, graph-capturable; a tensor's maximum can be computed once and passed to every call that
+ * reads the tensor).  Elements more than ~2^17 below their tensor's maximum lose relative precision -- DESIGN.md section 6.
+ * mode_conv3d_bwd_data_split_f16: acc may be NULL.  mode_conv3d_bwd_weight_split_f16: other arguments and workspace as
+ * mode_conv3d_bwd_weight_split. */
+int mode_abs_max(const float* x, long long n, float* out_device_scalar, mode_stream_t stream);
+int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B, int Ci,
+                              int D, int H, int W, int Co, mode_stream_t stream);
+int mode_conv3d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
+                                   float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream);
+int mode_conv3d_bwd_weight_split_f16(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace,
+                                     int B, int Ci, int D, int H, int W, int Co, int accumulate, mode_stream_t stream);
 /* The input gradient of a stride-1 / stride-2 convolution on the split kernels with a gradient that is already there added in the
  * store: gx = conv^T(gy) + acc, bit for bit the sum autograd would form with a separate pass (x has a second consumer whose gradient
  * came first: a residual skip, a classifier head).  acc has gx's shape and must not alias it; stride 2: whole 32-channel tiles of gx

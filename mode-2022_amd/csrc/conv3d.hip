@@ -631,6 +631,31 @@ extern "C" int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, fl
   return mode::deconv3d_split(gy, w, gx, wpack, B, Co, Ci, D / 2, H / 2, W / 2, mode::as_stream(stream), who);
 }
 
+// ---- the stride-1 layer on the two-piece fp16 arithmetic (three MFMAs per product; csrc/conv3d_split.hip).  amax_*: device floats, the
+// largest magnitude of each operand (mode_abs_max), read by the kernels themselves: no host synchronisation.
+extern "C" int mode_abs_max(const float* x, long long n, float* out, mode_stream_t stream) {
+  return mode::abs_max(x, n, out, mode::as_stream(stream), "mode_abs_max");
+}
+
+extern "C" int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B,
+                                         int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_fwd_split_f16";
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 1, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE(amax_x && amax_w, MODE_ERR_BAD_ARG, "%s: null operand maximum", who);
+  return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, nullptr, nullptr, nullptr, amax_x, amax_w);
+}
+
+// gx = conv^T(gy) [+ acc]; amax_g = max |gy|, amax_w = max |w|
+extern "C" int mode_conv3d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
+                                              float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_bwd_data_split_f16";
+  int rc = check_conv_args(gy, w, gx, wpack, B, Ci, D, H, W, Co, 1, who);
+  if (rc != MODE_OK || B == 0) return rc;
+  MODE_REQUIRE(amax_g && amax_w && acc != gx, MODE_ERR_BAD_ARG, "%s: null operand maximum, or acc is the output tensor", who);
+  return mode::conv3d_s1_split(gy, w, gx, wpack, B, Co, Ci, D, H, W, 1, mode::as_stream(stream), who, nullptr, nullptr, acc, amax_g, amax_w);
+}
+
 // The two input gradients with a gradient that is already there added in the store: gx = conv^T(gy) + acc (acc must not alias gx).
 extern "C" int mode_conv3d_bwd_data_split_acc_supported(int Ci, int Co, int stride) {
   if (Ci <= 0 || Co <= 0) return 0;
@@ -1341,9 +1366,23 @@ extern "C" int mode_conv3d_bwd_weight(const float* gy, const float* x, float* gw
   return mode::check_launch("mode_conv3d_bwd_weight(reduce)");
 }
 
+static int bwd_weight_split(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace, int B, int Ci,
+                            int D, int H, int W, int Co, int accumulate, mode_stream_t stream, const char* who);
+
 extern "C" int mode_conv3d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int D, int H,
                                             int W, int Co, int accumulate, mode_stream_t stream) {
-  const char* who = "mode_conv3d_bwd_weight_split";
+  return bwd_weight_split(gy, x, nullptr, nullptr, gw, workspace, B, Ci, D, H, W, Co, accumulate, stream, "mode_conv3d_bwd_weight_split");
+}
+
+// The same on the two-piece fp16 arithmetic (mode_conv3d_fwd_split_f16): amax_g / amax_x = device floats max |gy| / max |x|
+extern "C" int mode_conv3d_bwd_weight_split_f16(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace,
+                                                int B, int Ci, int D, int H, int W, int Co, int accumulate, mode_stream_t stream) {
+  MODE_REQUIRE(amax_g && amax_x, MODE_ERR_BAD_ARG, "mode_conv3d_bwd_weight_split_f16: null operand maximum");
+  return bwd_weight_split(gy, x, amax_g, amax_x, gw, workspace, B, Ci, D, H, W, Co, accumulate, stream, "mode_conv3d_bwd_weight_split_f16");
+}
+
+static int bwd_weight_split(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace, int B, int Ci,
+                            int D, int H, int W, int Co, int accumulate, mode_stream_t stream, const char* who) {
   int rc = check_conv_args(gy, x, gw, workspace, B, Ci, D, H, W, Co, 1, who);
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(mode_conv3d_split_supported(Ci, Co, 1, 2) == 1 && (long long)std::max(Ci, Co) * D * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED,
@@ -1367,7 +1406,7 @@ extern "C" int mode_conv3d_bwd_weight_split(const float* gy, const float* x, flo
   q.units = B * d.nHt * d.nWt * q.nDc;
   if (S > q.units) S = q.units;
   q.S = d.S = S;  // (<= the S of make_wdims, which sized the workspace)
-  rc = mode::conv3d_bww_split_launch(gy, x, workspace, q, st, who);
+  rc = mode::conv3d_bww_split_launch(gy, x, workspace, q, st, who, amax_g, amax_x);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(reduce_gw3d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 27 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv3d_bwd_weight_split(reduce)");

@@ -29,8 +29,14 @@ size_t conv3d_split_wpack_floats(int K, int rows);
 // partial pairs per channel + the pivots of the shifted sums (layout: conv3d_split_kernel, EPI 3).
 int conv3d_split_stat_partials();
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr, const float* acc_in = nullptr);
-// (acc_in: y = conv(x) + acc_in -- a gradient that is already there added in the store, instead of a separate pass; not with bn / stats)
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr, const float* acc_in = nullptr,
+                    const float* amax_x = nullptr, const float* amax_w = nullptr);
+// (acc_in: y = conv(x) + acc_in -- a gradient that is already there added in the store, instead of a separate pass; not with bn / stats.
+//  amax_x / amax_w: device floats max |x|, max |w| (both or neither) -> the two-piece fp16 arithmetic (three MFMAs per product) with
+//  power-of-two scales; not with bn / stats)
+
+// out[0] (device) = the largest magnitude in x[0..n): the scale source of the fp16 arithmetic (order-independent, graph-capturable)
+int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who);
 
 // conv3d_split_s2.hip: the stride-2 forward (= input gradient of the transposed convolution) on the same arithmetic; rows = output
 // channels (33..64), K = reduction channels (multiple of 8); w is (rows, K, 27); wpack >= conv3d_s2_split_wpack_floats(K, rows).
@@ -55,7 +61,8 @@ struct WgradSplitDims {
   int nWt, nHt, nDc, ring_dc, units;  // units = B * nHt * nWt * nDc work units of ring_dc depths x 2 rows x 32 voxels
   int S, MTo, MTc;                    // workgroups along the split-K axis, 32-channel blocks of gy / x
 };
-int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who);
+int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who,
+                            const float* amax_g = nullptr, const float* amax_x = nullptr);  // device floats max |gy|, max |x| -> fp16 arithmetic
 
 // conv3d_split_wgrad_s2.hip: the same for the stride-2 convolution (x at D x H x W, gy at Do x Ho x Wo = half of it; even D, H and
 // W a multiple of 8); a workgroup owns BOTH 32-row blocks of a 64-channel gy block (grid y = cdiv(MTo, 2)).

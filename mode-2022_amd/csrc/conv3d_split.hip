@@ -41,21 +41,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MODE_SPLIT_NT 256  // (512: two waves per SIMD, two rows each -- measured in round 5)
 #endif
 constexpr int NT = MODE_SPLIT_NT;
-#ifndef MODE_SPLIT_F16
-#define MODE_SPLIT_F16 0  // (1: experiment of round 5 -- two fp16 pieces and three MFMAs per product instead of three bf16 pieces and six)
-#endif
-constexpr int NP = MODE_SPLIT_F16 ? 2 : 3;      // pieces per fp32 value
-constexpr int NTERM = MODE_SPLIT_F16 ? 3 : 6;   // MFMAs per product
+// Two arithmetics (template parameter F16 of the kernels below):
+//   false  three bf16 pieces per fp32 value, six MFMAs per product (the product arithmetic: 24 mantissa bits for every element);
+//   true   two fp16 pieces (v_cvt_pk_f16_f32, round to nearest even; the remainder a - a1 is exact in fp32), three MFMAs per product
+//          (a1b1, a1b2, a2b1: 2^-22 per product).  fp16's range is narrow: both operands are multiplied by a power of two that brings
+//          their tensor's largest magnitude (a device scalar the caller provides: mode_abs_max) to [2^14, 2^15), and the accumulators by
+//          the inverse -- all exact.  Elements more than ~2^17 below their tensor's maximum lose relative precision.
+template <bool F16> struct Arith {
+  static constexpr int NP = F16 ? 2 : 3;     // pieces per fp32 value
+  static constexpr int NTERM = F16 ? 3 : 6;  // MFMAs per product
+};
 constexpr int TD = 2, TH = 8, ID = TD + 2, IH = TH + 2, IW = 34;
 constexpr int ROWS = ID * IH;           // 40 haloed rows
 constexpr int ITEMS = ROWS * IW;        // 1 360 positions per chunk
 constexpr int KIT = (ITEMS + NT - 1) / NT;    // 6 positions per thread
 constexpr int PIECE = KIT * NT;         // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
-constexpr int BUF = NP * PIECE;          // uint4 per buffer
+template <bool F16> constexpr int buf_of() { return Arith<F16>::NP * PIECE; }  // uint4 per buffer
 constexpr int NPAIR = 14;
 constexpr int WAHEAD = 6;  // weight fragments are loaded this many tap pairs ahead (3 measured the same, r03w)
 constexpr int R = TD * TH / (NT / 64);  // 4 output rows per matrix wave
-constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(uint4);  // 147 456 B
+template <bool F16> constexpr size_t lds_bytes() { return 2 * (size_t)buf_of<F16>() * sizeof(uint4); }  // 147 456 B (98 304 B)
 
 struct SDims {
   int B, K, Co, D, H, W;  // K = reduction channels of this GEMM, Co = its output channels
@@ -70,40 +75,48 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-#if MODE_SPLIT_F16
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// (a, b) -> two packed fp16 pairs (v_cvt_pk_f16_f32, round to nearest even: the remainder a - a1 is exact in fp32, the second piece's
-// rounding unbiased -- with round-toward-zero pieces the 2^-22 residue of every product has one sign); p3 unused
+// (a, b) -> the packed pieces of the pair; the remainders are exact in fp32
+template <bool F16>
 __device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  const f32x2 v = {a, b};
-  const f16x2 h1 = __builtin_convertvector(v, f16x2);
-  p1 = __builtin_bit_cast(uint32_t, h1);
-  const f32x2 r = {a - (float)h1[0], __builtin_fmaf(-1.f, (float)h1[1], b)};
-  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-  p3 = 0;
+  if constexpr (F16) {
+    const f32x2 v = {a, b};
+    const f16x2 h1 = __builtin_convertvector(v, f16x2);
+    p1 = __builtin_bit_cast(uint32_t, h1);
+    const f32x2 r = {a - (float)h1[0], __builtin_fmaf(-1.f, (float)h1[1], b)};
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+    p3 = 0;
+  } else {
+    // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
+    // instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
+    p1 = pack2(a, b);
+    float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    asm("" : "+v"(ra), "+v"(rb));
+    p2 = pack2(ra, rb);
+    float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+    asm("" : "+v"(sa), "+v"(sb));
+    p3 = pack2(sa, sb);
+  }
 }
-#else
-// (a, b) -> the three packed bf16 pairs; the remainders are exact in fp32
-__device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
-  // instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
-  p1 = pack2(a, b);
-  float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
-  asm("" : "+v"(ra), "+v"(rb));
-  p2 = pack2(ra, rb);
-  float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
-  asm("" : "+v"(sa), "+v"(sb));
-  p3 = pack2(sa, sb);
+
+// 2^(14 - floor(log2 m)) for the largest magnitude m of a tensor (m * scale in [2^14, 2^15)); 1 for m = 0; magnitudes below 2^-63 are
+// treated as 2^-63 (the tensor is zero for every purpose); Inf / NaN maxima give a finite scale and propagate through the products
+__device__ __forceinline__ float f16_scale_of(float m) {
+  const unsigned e = min(max((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu, 64u), 254u);
+  return m == 0.f ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
 }
-#endif
 
 // wp[(((m * NCHUNK + ch) * NPAIR + pair) * 3 + piece) * 64 + lane] = 8 bf16: piece of Wsrc(o = m*32 + (lane & 31), c = ch*8 + j,
 // tap = 2 * pair + (lane >> 5)), j = 0..7; zero for tap 27, o >= rows, c >= K.  flip / fold as pack_w3d (conv3d.hip): flip 0 forward
 // (w is (rows, K, 27)), flip 1 backward-data (w is (K, rows, 27), taps mirrored); fold: row o scaled by the folded BatchNorm scale
 // and the shifts written to the floats at wp + total.
+// F16: the values are multiplied by the weight tensor's power-of-two scale (amax_w[0] = its largest magnitude) before the split.
+template <bool F16>
 __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip,
-                               int fold, mode_bn_epilogue bn) {
+                               int fold, mode_bn_epilogue bn, const float* __restrict__ amax_w) {
+  constexpr int NP = Arith<F16>::NP;
+  const float sw = F16 ? f16_scale_of(amax_w[0]) : 1.f;
   const long long total = (long long)MT * NCHUNK * NPAIR * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * NP);
@@ -126,10 +139,11 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
       if (o < rows && c < K && tap < 27)
         v[j] = flip == 0 ? w[((long long)o * K + c) * 27 + tap] : w[((long long)c * rows + o) * 27 + (26 - tap)];
       if (fold == 1 && o < rows) v[j] *= fold_scale(bn, o);
+      if (F16) v[j] *= sw;
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    for (int j = 0; j < 4; ++j) split2<F16>(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
     uint4* dst = wp + (idx - lane) * NP + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -141,12 +155,12 @@ __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ 
 // fragments already requested for the next chunk and for the output stores of a finished tile.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
-#if MODE_SPLIT_F16
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-#else
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 __host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of a tap inside the haloed tile
@@ -178,10 +192,15 @@ __global__ __launch_bounds__(64) void first_voxel_kernel(const float* __restrict
   if (lane == 0) pivot[o] = acc;
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool F16 = false>
 __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                           float* __restrict__ y, SDims d, Epi epi, float* __restrict__ stats,
-                                                          const float* __restrict__ stat_pivot) {
+                                                          const float* __restrict__ stat_pivot, const float* __restrict__ amax_x,
+                                                          const float* __restrict__ amax_w) {
+  constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16>();
+  // (F16) x is multiplied by sx when it is staged, the weights by sw when they are packed, the sums by 1 / (sx sw) when they are stored
+  const float sx = F16 ? f16_scale_of(amax_x[0]) : 1.f;
+  const float unscale = F16 ? (1.f / sx) * (1.f / f16_scale_of(amax_w[0])) : 1.f;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][ITEMS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // grid.y = the 32 * MT-channel output blocks of the layer: every y-slice is the persistent grid described above on ITS block (a
@@ -257,7 +276,14 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   auto stage_commit = [&](int buf, int k, int h) {
     const bool ok = (okmask >> k) & 1;
 #pragma unroll
-    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(ok ? raw[k][2 * j] : 0.f, ok ? raw[k][2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+    for (int j = 2 * h; j < 2 * h + 2; ++j) {
+      float v0 = ok ? raw[k][2 * j] : 0.f, v1 = ok ? raw[k][2 * j + 1] : 0.f;
+      if (F16) {
+        v0 *= sx;
+        v1 *= sx;
+      }
+      split2<F16>(v0, v1, sq[0][j], sq[1][j], sq[2][j]);
+    }
     if (h == 1) {
       uint4* dst = sm + buf * BUF + tid + k * NT;
 #pragma unroll
@@ -404,27 +430,27 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
       // smallest terms first; consecutive MFMAs go to different accumulators
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
-      acc[m][r] = mfma_bf16(aring[pair % 7][m][PA], bq[pair & 1][r][PB], acc[m][r]);
-#if MODE_SPLIT_F16
-      MODE_SPLIT_TERM(1, 0)
-      MODE_SPLIT_TERM(0, 1)
-      MODE_SPLIT_TERM(0, 0)
-#else
-      MODE_SPLIT_TERM(2, 0)
-      MODE_SPLIT_TERM(0, 2)
-      MODE_SPLIT_TERM(1, 1)
-      MODE_SPLIT_TERM(1, 0)
-      MODE_SPLIT_TERM(0, 1)
-      MODE_SPLIT_TERM(0, 0)
-#endif
+      acc[m][r] = mfma_split<F16>(aring[pair % 7][m][PA], bq[pair & 1][r][PB], acc[m][r]);
+      if constexpr (F16) {
+        MODE_SPLIT_TERM(1, 0)
+        MODE_SPLIT_TERM(0, 1)
+        MODE_SPLIT_TERM(0, 0)
+      } else {
+        MODE_SPLIT_TERM(2, 0)
+        MODE_SPLIT_TERM(0, 2)
+        MODE_SPLIT_TERM(1, 1)
+        MODE_SPLIT_TERM(1, 0)
+        MODE_SPLIT_TERM(0, 1)
+        MODE_SPLIT_TERM(0, 0)
+      }
 #undef MODE_SPLIT_TERM
       // one MFMA, then up to 3 vector-ALU instructions and one fragment read, 24 times: spreads the staging arithmetic and the
       // next pair's reads over the matrix instructions (5 single-issue slots fit under one 32x32x16 MFMA)
 #pragma unroll
       for (int i = 0; i < MT * R * NTERM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, MODE_SPLIT_F16 ? 6 : 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MODE_SPLIT_F16 ? 2 : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 6 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -447,6 +473,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
               if (o < d.Co) {
                 const long long idx = o * DHW + sp;
                 float v = acc[m][r][qq];
+                if (F16) v *= unscale;
                 if (EPI == 1 || EPI == 2) v += shiftv[m][qq];
                 if (EPI == 2) v += addv[m][r][qq];
                 if (EPI == 3) {
@@ -507,36 +534,72 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 
 template <int MT>
 int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblocks, hipStream_t st, const char* who, Epi epi,
-                 float* stats = nullptr, const float* stat_pivot = nullptr) {
+                 float* stats = nullptr, const float* stat_pivot = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr) {
   const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
-  if (stats) {
-    int rc = mode::allow_lds(conv3d_split_kernel<MT, 3>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 3>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, stats, stat_pivot);
-    return mode::check_launch(who);
+#define MODE_SPLIT_LAUNCH(EPIV, F16V, STATS, PIVOT)                                                                          \
+  {                                                                                                                          \
+    int rc = mode::allow_lds(conv3d_split_kernel<MT, EPIV, F16V>, lds_bytes<F16V>(), who);                                   \
+    if (rc != MODE_OK) return rc;                                                                                            \
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, EPIV, F16V>), dim3(grid, nblocks), dim3(NT), lds_bytes<F16V>(), st, x, wp, y, d, epi, \
+                       STATS, PIVOT, amax_x, amax_w);                                                                        \
+    return mode::check_launch(who);                                                                                          \
   }
-  if (epi.shift && epi.add) {
-    int rc = mode::allow_lds(conv3d_split_kernel<MT, 2>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 2>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
-    return mode::check_launch(who);
+  if (amax_x) {  // the two-piece fp16 arithmetic: plain store and the accumulate form (training)
+    MODE_REQUIRE(!stats && (!epi.shift || epi.add), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no BatchNorm epilogues", who);
+    if (epi.shift && epi.add) MODE_SPLIT_LAUNCH(2, true, nullptr, nullptr)
+    MODE_SPLIT_LAUNCH(0, true, nullptr, nullptr)
   }
-  if (epi.shift) {
-    int rc = mode::allow_lds(conv3d_split_kernel<MT, 1>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, 1>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
-    return mode::check_launch(who);
+  if (stats) MODE_SPLIT_LAUNCH(3, false, stats, stat_pivot)
+  if (epi.shift && epi.add) MODE_SPLIT_LAUNCH(2, false, nullptr, nullptr)
+  if (epi.shift) MODE_SPLIT_LAUNCH(1, false, nullptr, nullptr)
+  MODE_SPLIT_LAUNCH(0, false, nullptr, nullptr)
+#undef MODE_SPLIT_LAUNCH
+}
+
+// out[0] = the largest FINITE |x[i]| as an unsigned maximum over the bit patterns of the magnitudes (order-independent: the same bits
+// however the blocks are scheduled).  Inf and NaN elements do not take part: the scale has to fit the finite data, and a non-finite
+// element then stays non-finite through scaling, split and MFMA -- inside its own receptive field only, as in the bf16 arithmetic.
+__device__ __forceinline__ unsigned finite_mag(unsigned bits) {
+  const unsigned v = bits & 0x7fffffffu;
+  return v < 0x7f800000u ? v : 0u;
+}
+__global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four 16-byte requests in flight per lane (one at a time: 3.4 TB/s)
+    const uint4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    m = max(max(m, finite_mag(v0.x)), max(max(finite_mag(v0.y), finite_mag(v0.z)), finite_mag(v0.w)));
+    m = max(max(m, finite_mag(v1.x)), max(max(finite_mag(v1.y), finite_mag(v1.z)), finite_mag(v1.w)));
+    m = max(max(m, finite_mag(v2.x)), max(max(finite_mag(v2.y), finite_mag(v2.z)), finite_mag(v2.w)));
+    m = max(max(m, finite_mag(v3.x)), max(max(finite_mag(v3.y), finite_mag(v3.z)), finite_mag(v3.w)));
   }
-  int rc = mode::allow_lds(conv3d_split_kernel<MT, 0>, LDS_BYTES, who);
-  if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL((conv3d_split_kernel<MT, 0>), dim3(grid, nblocks), dim3(NT), LDS_BYTES, st, x, wp, y, d, epi, nullptr, nullptr);
-  return mode::check_launch(who);
+  for (; i < n4; i += stride) {
+    const uint4 v = x4[i];
+    m = max(max(m, finite_mag(v.x)), max(max(finite_mag(v.y), finite_mag(v.z)), finite_mag(v.w)));
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    m = max(m, finite_mag(__builtin_bit_cast(unsigned, x[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 }  // namespace
 
 namespace mode {
+
+int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who) {
+  MODE_REQUIRE(n >= 0 && out && (n == 0 || x), MODE_ERR_BAD_ARG, "%s: bad argument", who);
+  MODE_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, MODE_ERR_BAD_ARG, "%s: the tensor must be 16-byte aligned", who);
+  int rc = mode::fill_words(out, 0u, 1, st, who);
+  if (rc != MODE_OK || n == 0) return rc;
+  const int blocks = (int)std::min<long long>(cdiv(n, 256 * 16), 16 * kNumCU);
+  hipLaunchKernelGGL(abs_max_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out));
+  return mode::check_launch(who);
+}
 
 size_t conv3d_split_wpack_floats(int K, int rows) {
   return (size_t)cdiv(rows, 32) * cdiv(K, 8) * NPAIR * 3 * 64 * 4 + 32 * (size_t)cdiv(rows, 32);
@@ -547,8 +610,12 @@ bool conv3d_split_supported(int K, int rows) { return rows > 1 && rows <= 64 && 
 int conv3d_split_stat_partials() { return kNumCU; }  // partial pairs per channel that the statistics epilogue writes
 
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
-                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* acc_in) {
+                    hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* acc_in, const float* amax_x,
+                    const float* amax_w) {
+  const float* absmax = amax_x;  // (non-null: the fp16 arithmetic)
+  MODE_REQUIRE((amax_x == nullptr) == (amax_w == nullptr), MODE_ERR_BAD_ARG, "%s: both operand maxima, or neither", who);
   MODE_REQUIRE(!(acc_in && (bn || stats)), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue and no statistics", who);
+  MODE_REQUIRE(!(absmax && (bn || stats)), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no BatchNorm epilogue and no statistics", who);
   SDims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.MT = cdiv(rows, 32);
@@ -561,8 +628,15 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.nDt = cdiv(D, TD);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT,
-                     d.NCHUNK, flip, bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue());
+  const int NP = absmax ? 2 : 3;
+  if (mode::pack_needed()) {
+    if (absmax)
+      hipLaunchKernelGGL(pack_w3d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT, d.NCHUNK,
+                         flip, acc_in ? 2 : 0, mode_bn_epilogue(), amax_w);
+    else
+      hipLaunchKernelGGL(pack_w3d_split<false>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT, d.NCHUNK,
+                         flip, bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue(), nullptr);
+  }
   Epi epi = make_epi(bn, wpack + npack * NP * 4);
   if (acc_in) {  // y = conv(x) + acc_in: the residual epilogue with zero shifts ((v + 0) + a is a + v exactly)
     epi.shift = wpack + npack * NP * 4;
@@ -578,7 +652,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
     hipLaunchKernelGGL(first_voxel_kernel, dim3(rows), dim3(64), 0, st, x, w, pivot, K, rows, D, H, W);
     return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, stats, pivot);
   }
-  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi);
+  return launch_split<1>(x, wpack, y, d, d.MT, st, who, epi, nullptr, nullptr, amax_x, amax_w);
 }
 
 }  // namespace mode

@@ -49,25 +49,53 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// F16: two fp16 pieces (round to nearest even), three MFMAs per product -- the experimental arithmetic of conv3d_split.hip (its header);
+// the operands arrive scaled by a power of two, the sums leave scaled back.
+template <bool F16>
 __device__ __forceinline__ void split2(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
-  // instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
-  // One of the pair as a subtraction, the other as fma(-1, piece, value) (the same exact difference): two different operations are not
-  // packed, and no empty asm statement is needed to keep them apart -- the scheduler's group pattern places plain VALU instructions
-  // under the MFMAs, an inline-asm node in a chain it left (with everything behind it) for the end of the K-step.
-  p1 = pack2(a, b);
-  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p1 & 0xffff0000u), b);
-  p2 = pack2(ra, rb);
-  const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p2 & 0xffff0000u), rb);
-  p3 = pack2(sa, sb);
+  if constexpr (F16) {
+    const f32x2 v = {a, b};
+    const f16x2 h1 = __builtin_convertvector(v, f16x2);
+    p1 = __builtin_bit_cast(uint32_t, h1);
+    const f32x2 r = {a - (float)h1[0], __builtin_fmaf(-1.f, (float)h1[1], b)};
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+    p3 = 0;
+  } else {
+    // (the subtractions of a pair stay scalar: packed into v_pk_add_f32 each costs ~9 cycles of the MATRIX pipe -- packed fp32
+    // instructions do not overlap with MFMAs on gfx950, plain ones do; tools/experiments/mfma_op_cost.hip)
+    // One of the pair as a subtraction, the other as fma(-1, piece, value) (the same exact difference): two different operations are not
+    // packed, and no empty asm statement is needed to keep them apart -- the scheduler's group pattern places plain VALU instructions
+    // under the MFMAs, an inline-asm node in a chain it left (with everything behind it) for the end of the K-step.
+    p1 = pack2(a, b);
+    const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p1 & 0xffff0000u), b);
+    p2 = pack2(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = __builtin_fmaf(-1.f, __builtin_bit_cast(float, p2 & 0xffff0000u), rb);
+    p3 = pack2(sa, sb);
+  }
 }
-__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ float f16_scale_of(float m) {  // as in conv3d_split.hip: m * scale in [2^14, 2^15)
+  const unsigned e = min(max((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu, 64u), 254u);
+  return m == 0.f ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <bool F16>
 __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                              float* __restrict__ part, mode::WgradSplitDims d) {
+                                                              float* __restrict__ part, mode::WgradSplitDims d,
+                                                              const float* __restrict__ amax_g, const float* __restrict__ amax_x) {
+  constexpr int NP = F16 ? 2 : 3;  // pieces (the LDS layout keeps room for three)
+  // (F16) amax_g / amax_x = max |gy| / max |x|: both operands scaled when staged, the sums scaled back when written
+  const float sg = F16 ? f16_scale_of(amax_g[0]) : 1.f, sx = F16 ? f16_scale_of(amax_x[0]) : 1.f;
+  const float unscale = F16 ? (1.f / sg) * (1.f / sx) : 1.f;
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   uint16_t* xl = lds;          // [32 c][3 pieces][4 planes][4 rows][40]
   uint16_t* gl = lds + XALL;   // [2 buffers][32 o][3 pieces][2 rows][32]
@@ -162,11 +190,16 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
   auto commit_x = [&](int k, int z) {
     const unsigned zok = (unsigned)((unsigned)z < (unsigned)d.D);
     uint32_t p1, p2, p3;
-    split2((zok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, (zok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f, p1, p2, p3);
+    float v0 = (zok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, v1 = (zok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f;
+    if (F16) {
+      v0 *= sx;
+      v1 *= sx;
+    }
+    split2<F16>(v0, v1, p1, p2, p3);
     uint32_t* dst = reinterpret_cast<uint32_t*>(xl + xdst[k] + ((z + 4) & 3) * XPLANE);
     dst[0] = p1;  // (threads beyond the last item repeat it: same address, same value -- no conditional store in the MFMA stream)
     dst[XPIECE / 2] = p2;
-    dst[XPIECE] = p3;
+    if (!F16) dst[XPIECE] = p3;
   };
   auto load_g = [&](int k, int z) {
     const unsigned zo = 4u * (unsigned)(min(z, d.D - 1) * HWi);
@@ -176,11 +209,16 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
   auto commit_g = [&](int k, int z) {
     const unsigned zok = (unsigned)(z < d.D);
     uint32_t p1, p2, p3;
-    split2((zok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, (zok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f, p1, p2, p3);
+    float v0 = (zok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, v1 = (zok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f;
+    if (F16) {
+      v0 *= sg;
+      v1 *= sg;
+    }
+    split2<F16>(v0, v1, p1, p2, p3);
     uint32_t* dst = reinterpret_cast<uint32_t*>(gl + gdst[k] + (z & 1) * GBUF);
     dst[0] = p1;
     dst[GPIECE / 2] = p2;
-    dst[GPIECE] = p3;
+    if (!F16) dst[GPIECE] = p3;
   };
 
   for (int u = xcd_remap(s, d.S); u < d.units; u += d.S) {
@@ -221,12 +259,12 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
       // per piece the gy fragment, and for each of the three (kd, kh) groups of this wave (slots 0-2, 3-5, 6) dwords 0..4 of an
       // aligned group of 10 x elements, fetched as ds_read_b128 + ds_read_b64 (dword-wide LDS reads of 32 channel lanes 964 dwords
       // apart would be 4-way bank conflicts).
-      uint4 ra[2][3], rlo[2][3][3];
-      uint2 rhi[2][3][3];
+      uint4 ra[2][NP], rlo[2][3][NP];
+      uint2 rhi[2][3][NP];
       auto read_raw = [&](int ks, int set) {
         const int row = ks / 2, w16 = 16 * (ks % 2);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           ra[set][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + p * GPIECE + row * 32 + w16, 16));
 #pragma unroll
           for (int g = 0; g < 3; ++g) {
@@ -271,9 +309,9 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
         }
         // the fragment of tap kw is elements kw .. kw + 7 of the 10: one v_perm_b32 per dword with the byte selector of the shift (an
         // MFMA operand is an even-aligned register quadruple: "dwords 1..4" is not addressable as such)
-        uint4 a[3], bq[7][3];
+        uint4 a[NP], bq[7][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           a[p] = ra[ks & 1][p];
 #pragma unroll
           for (int t7 = 0; t7 < 7; ++t7) {
@@ -290,20 +328,26 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
         }
         // smallest terms first; consecutive MFMAs go to different accumulators
 #define MODE_SPLIT_TERM(ACC, PA, PB) \
-  _Pragma("unroll") for (int t7 = 0; t7 < 7; ++t7) ACC[t7] = mfma_bf16(a[PA], bq[t7][PB], ACC[t7]);
-        MODE_SPLIT_TERM(acs, 2, 0)
-        MODE_SPLIT_TERM(acs, 0, 2)
-        MODE_SPLIT_TERM(acs, 1, 1)
-        MODE_SPLIT_TERM(acs, 1, 0)
-        MODE_SPLIT_TERM(acs, 0, 1)
-        MODE_SPLIT_TERM(acc, 0, 0)
+  _Pragma("unroll") for (int t7 = 0; t7 < 7; ++t7) ACC[t7] = mfma_split<F16>(a[PA], bq[t7][PB], ACC[t7]);
+        if constexpr (F16) {
+          MODE_SPLIT_TERM(acs, 1, 0)
+          MODE_SPLIT_TERM(acs, 0, 1)
+          MODE_SPLIT_TERM(acc, 0, 0)
+        } else {
+          MODE_SPLIT_TERM(acs, 2, 0)
+          MODE_SPLIT_TERM(acs, 0, 2)
+          MODE_SPLIT_TERM(acs, 1, 1)
+          MODE_SPLIT_TERM(acs, 1, 0)
+          MODE_SPLIT_TERM(acs, 0, 1)
+          MODE_SPLIT_TERM(acc, 0, 0)
+        }
 #undef MODE_SPLIT_TERM
 #pragma unroll
-        for (int i = 0; i < 42; ++i) {
+        for (int i = 0; i < (F16 ? 21 : 42); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 9 : 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, F16 ? 2 : 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -319,7 +363,7 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-        pb[tap * 1024 + i * 32 + (lane & 31)] = acc[t7][q] + acs[t7][q];
+        pb[tap * 1024 + i * 32 + (lane & 31)] = F16 ? (acc[t7][q] + acs[t7][q]) * unscale : acc[t7][q] + acs[t7][q];
       }
     }
   }
@@ -329,10 +373,17 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 
 namespace mode {
 
-int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who) {
-  int rc = allow_lds(conv3d_bww_split_kernel, LDS_BYTES, who);
+int conv3d_bww_split_launch(const float* gy, const float* x, float* part, const WgradSplitDims& d, hipStream_t st, const char* who,
+                            const float* amax_g, const float* amax_x) {
+  if (amax_g) {  // the two-piece fp16 arithmetic
+    int rc = allow_lds(conv3d_bww_split_kernel<true>, LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(conv3d_bww_split_kernel<true>, dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d, amax_g, amax_x);
+    return check_launch(who);
+  }
+  int rc = allow_lds(conv3d_bww_split_kernel<false>, LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(conv3d_bww_split_kernel, dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d);
+  hipLaunchKernelGGL(conv3d_bww_split_kernel<false>, dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d, nullptr, nullptr);
   return check_launch(who);
 }
 

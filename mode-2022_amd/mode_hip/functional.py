@@ -1209,8 +1209,29 @@ def _tag3(name, ci, co, stride, d, h, w):
   return '%s[%d->%d s%d %dx%dx%d]' % (name, ci, co, stride, d, h, w) if profiling.ENABLED else name
 
 
-def conv3d_fwd(x, w, stride=1):
-  """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,Do,Ho,Wo); k3 p1, stride 1|2, no bias (convbn_3d, submodule.py:20-22)."""
+# EXPERIMENTAL (round 5, off by default; bench.py --conv3d-f16): the stride-1 3-D layers' forward and input gradient on TWO fp16 pieces
+# and three MFMAs per product (mode_conv3d_*_split_f16; 30-35 % faster kernels) -- each operand scaled by a power of two taken from its
+# tensor's largest magnitude (mode_abs_max: one more pass over the activation operand per call).  Elements far below their tensor's
+# maximum lose relative precision: not the product arithmetic until the float64 tests say it may be.
+CONV3D_S1_F16 = True
+
+
+def abs_max(t):
+  """Device scalar: the largest magnitude in t (mode_abs_max; no host synchronisation).  A tensor's maximum is computed once and handed
+  to every kernel that reads the tensor (the forward's x again in the weight gradient, gy in both gradients)."""
+  out = torch.empty(1, dtype=torch.float32, device=t.device)
+  check(lib().mode_abs_max(ptr(t), t.numel(), ptr(out), stream_of(t)), 'mode_abs_max')
+  return out
+
+
+def conv3d_s1_f16(ci, co, which):
+  """True when the stride-1 layer ci -> co runs its forward (which 0) / input gradient (1) / weight gradient (2) on the fp16 arithmetic."""
+  return CONV3D_S1_F16 and _split3d(ci, co, 1, which)
+
+
+def conv3d_fwd(x, w, stride=1, amax=None):
+  """x (B,Ci,D,H,W), w (Co,Ci,3,3,3) -> (B,Co,Do,Ho,Wo); k3 p1, stride 1|2, no bias (convbn_3d, submodule.py:20-22).
+  amax = (max |x|, max |w|) device scalars when the caller has them (fp16 arithmetic only; computed here otherwise)."""
   require_gpu(x, w)
   x, w = x.contiguous(), w.contiguous()
   require_f32c(x, w)
@@ -1226,6 +1247,10 @@ def conv3d_fwd(x, w, stride=1):
     if _split3d(Ci, Co, stride, False) and stride == 2 and D * H * W < 2**27:
       check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
             'mode_conv3d_fwd_s2_split')
+    elif _split3d(Ci, Co, stride, False) and stride == 1 and CONV3D_S1_F16:
+      ax, aw = amax if amax is not None else (abs_max(x), abs_max(w))
+      check(lib().mode_conv3d_fwd_split_f16(ptr(x), ptr(w), ptr(ax), ptr(aw), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+            'mode_conv3d_fwd_split_f16')
     elif _split3d(Ci, Co, stride, False) and stride == 1:
       check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)), 'mode_conv3d_fwd_split')
     else:
@@ -1233,7 +1258,7 @@ def conv3d_fwd(x, w, stride=1):
   return y
 
 
-def conv3d_bwd_data(gy, w, in_shape, stride=1, acc=None):
+def conv3d_bwd_data(gy, w, in_shape, stride=1, acc=None, amax=None):
   """gradient w.r.t. the input of conv3d_fwd; in_shape = x.shape.  acc: a gradient of the same tensor that is already there -- the sum
   is returned (added in the kernel's store on the split path, by a separate pass elsewhere)."""
   require_gpu(gy, w)
@@ -1251,16 +1276,25 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1, acc=None):
       with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                       4 * (2 * gx.numel() + gy.numel() + w.numel()), flops, gy.device):
         wp = _wpack3d(Ci, Co, gy.device)
-        check(lib().mode_conv3d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
-              'mode_conv3d_bwd_data_split_acc')
+        if stride == 1 and CONV3D_S1_F16:
+          ag, aw = amax if amax is not None else (abs_max(gy), abs_max(w))
+          check(lib().mode_conv3d_bwd_data_split_f16(ptr(gy), ptr(w), ptr(ag), ptr(aw), ptr(acc), ptr(gx), ptr(wp), B, Ci, D, H, W, Co,
+                                                     stream_of(gy)), 'mode_conv3d_bwd_data_split_f16')
+        else:
+          check(lib().mode_conv3d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stride, stream_of(gy)),
+                'mode_conv3d_bwd_data_split_acc')
       return gx
-    return conv3d_bwd_data(gy, w, in_shape, stride).add_(acc)
+    return conv3d_bwd_data(gy, w, in_shape, stride, amax=amax).add_(acc)
   with torch.cuda.device_of(gy), profiling.region(_tag3('conv3d_bwd_data', Ci, Co, stride, D, H, W),
                                                   4 * (gx.numel() + gy.numel() + w.numel()), flops, gy.device):
     wp = _wpack3d(Ci, Co, gy.device)
     if stride == 2 and _split3d(Ci, Co, stride, True) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and _deconv_split_fits(D * H * W // 8, Ci):
       check(lib().mode_conv3d_bwd_data_s2_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
             'mode_conv3d_bwd_data_s2_split')
+    elif stride == 1 and _split3d(Ci, Co, stride, True) and CONV3D_S1_F16:
+      ag, aw = amax if amax is not None else (abs_max(gy), abs_max(w))
+      check(lib().mode_conv3d_bwd_data_split_f16(ptr(gy), ptr(w), ptr(ag), ptr(aw), None, ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
+            'mode_conv3d_bwd_data_split_f16')
     elif stride == 1 and _split3d(Ci, Co, stride, True):
       check(lib().mode_conv3d_bwd_data_split(ptr(gy), ptr(w), ptr(gx), ptr(wp), B, Ci, D, H, W, Co, stream_of(gy)),
             'mode_conv3d_bwd_data_split')
@@ -1270,8 +1304,9 @@ def conv3d_bwd_data(gy, w, in_shape, stride=1, acc=None):
   return gx
 
 
-def conv3d_bwd_weight(gy, x, stride=1, into=None):
-  """gW (Co,Ci,3,3,3) = sum gy[o, q] * x[c, stride*q + k - 1]; returned, or ADDED to `into` when given."""
+def conv3d_bwd_weight(gy, x, stride=1, into=None, amax=None):
+  """gW (Co,Ci,3,3,3) = sum gy[o, q] * x[c, stride*q + k - 1]; returned, or ADDED to `into` when given.
+  amax = (max |gy|, max |x|) device scalars when the caller has them (fp16 arithmetic only)."""
   require_gpu(gy, x)
   gy, x = gy.contiguous(), x.contiguous()
   require_f32c(gy, x)
@@ -1288,6 +1323,10 @@ def conv3d_bwd_weight(gy, x, stride=1, into=None):
     if stride == 2 and _split3d(Ci, Co, 2, 2) and D % 2 == 0 and H % 2 == 0 and W % 8 == 0 and 32 * D * H * W < 2**29:
       check(lib().mode_conv3d_bwd_weight_s2_split(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None), stream_of(gy)),
             'mode_conv3d_bwd_weight_s2_split')
+    elif stride == 1 and _split3d(Ci, Co, stride, 2) and max(Ci, Co) * D * H * W < 2**29 and CONV3D_S1_F16:
+      ag, ax = amax if amax is not None else (abs_max(gy), abs_max(x))
+      check(lib().mode_conv3d_bwd_weight_split_f16(ptr(gy), ptr(x), ptr(ag), ptr(ax), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None),
+                                                   stream_of(gy)), 'mode_conv3d_bwd_weight_split_f16')
     elif stride == 1 and _split3d(Ci, Co, stride, 2) and max(Ci, Co) * D * H * W < 2**29:
       check(lib().mode_conv3d_bwd_weight_split(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, D, H, W, Co, int(into is not None), stream_of(gy)),
             'mode_conv3d_bwd_weight_split')
@@ -1325,22 +1364,30 @@ class Conv3dFunction(torch.autograd.Function):
     ctx.save_for_backward(x, w)
     ctx.stride = stride
     ctx.carrier = carrier  # GradCarrier of x (x has one other consumer), or None
-    return conv3d_fwd(x, w, stride)
+    ctx.amax = None
+    if stride == 1 and x.is_cuda and CONV3D_S1_F16 and _split3d(x.shape[1], w.shape[0], 1, False):
+      ctx.amax = (abs_max(x.contiguous()), abs_max(w.contiguous()))  # (max |x|, max |w|): the backward reads both tensors again
+    return conv3d_fwd(x, w, stride, amax=ctx.amax)
 
   @staticmethod
   def backward(ctx, gy):
     x, w = ctx.saved_tensors
     gx = None
+    fwd_amax = getattr(ctx, 'amax', None)
+    ag = None
+    if fwd_amax is not None:  # fp16 arithmetic: gy's maximum once, for both gradients
+      gy = gy.contiguous()
+      ag = abs_max(gy)
     if ctx.needs_input_grad[0]:
       carrier = getattr(ctx, 'carrier', None)  # (Conv3dStatsFunction shares this backward and has none)
       prev = carrier.take() if carrier is not None else None  # the other consumer's gradient, when it came first
-      gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride, acc=prev)
+      gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride, acc=prev, amax=(ag, fwd_amax[1]) if ag is not None else None)
       if prev is None and carrier is not None and carrier.leave(gx):
         gx = None  # first of the two: the other consumer's backward returns the sum
     gw = None
     if ctx.needs_input_grad[1]:
       sink = grad_sink(w)
-      gw = conv3d_bwd_weight(gy, x, ctx.stride, into=sink)
+      gw = conv3d_bwd_weight(gy, x, ctx.stride, into=sink, amax=(ag, fwd_amax[0]) if ag is not None else None)
       if sink is not None:
         gw = None
     return gx, gw, None, None

@@ -15,6 +15,7 @@ for p in (ROOT, GOLDEN, PKG):
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+  config.addinivalue_line('markers', 'f16_pricing: tests/test_bench_math.py -- keeps the two-piece fp16 pricing of the stride-1 3-D labels')
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1,5 +1,15 @@
 """CPU: the arithmetic of bench.py's `roofline` / `targets` block (no GPU, no native call: the split-path predicate is injected)."""
+import pytest
+
 import bench
+
+
+@pytest.fixture(autouse=True)
+def _three_piece_pricing(request, monkeypatch):
+  """The hand-computed numbers below are for the three-piece bf16 arithmetic on every split label (bench.py --no-conv3d-f16); the test
+  of the two-piece fp16 pricing of the stride-1 3-D labels opts out."""
+  if 'f16_pricing' not in request.keywords:
+    monkeypatch.setattr(bench, 'CONV3D_S1_F16', False)
 
 
 def _kern():
@@ -19,6 +29,28 @@ def _kern():
 
 def _split(label):
   return ' s1 ' in label and label.startswith('conv3d')
+
+
+@pytest.mark.f16_pricing
+def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
+  """functional.CONV3D_S1_F16 (the default): forward and both gradients of the stride-1 3-D layers run on two fp16 pieces, three MFMAs
+  per product -- priced against 2500 / 3, named after the kernel's third template argument; the classifier's single-channel layer,
+  the stride-2 layers and the eval label keep their pipes."""
+  monkeypatch.setattr(bench, 'CONV3D_S1_F16', True)
+  for name in ('conv3d_fwd', 'conv3d_bwd_data', 'conv3d_bwd_weight'):
+    assert bench.label_peak(name + '[32->32 s1 48x256x128]', 'bf16x6', _split) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
+  assert bench.label_peak('conv3d_fwd[32->32 s1 48x256x128]', 'f32', _split) == ('mfma', 157.3, 'TFLOP/s')
+  assert bench.label_peak('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  assert bench.label_peak('conv3d_fwd[32->64 s2 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true>'
+  assert bench.kernel_of('conv3d_bwd_data[64->64 s1 24x128x64]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true>'
+  assert bench.kernel_of('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1>'
+  assert bench.kernel_of('conv3d_bwd_weight[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_bww_split_kernel'
+  k = _kern()
+  f = bench.blended_mfma_fraction(k, 'bf16x6', _split)
+  need = (12 + 6) * 173.95e9 / (2500e12 / 3) + 6 * 43.5e9 / 157.3e12
+  took = (12 * 0.80 + 6 * 0.95 + 6 * 0.44) * 1e-3
+  assert abs(f - need / took) < 1e-12
 
 
 def test_each_label_is_priced_against_the_pipe_it_runs_on():

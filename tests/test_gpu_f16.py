@@ -1,0 +1,103 @@
+"""GPU (-m gpu): the stride-1 3x3x3 layers on the two-piece fp16 arithmetic (functional.CONV3D_S1_F16; csrc/conv3d_split.hip,
+conv3d_split_wgrad.hip: two fp16 pieces per fp32 value, three v_mfma_f32_32x32x16_f16 per product, a power-of-two scale per operand
+tensor from mode_abs_max).
+
+The claim under test: with the scale it is an fp32-grade convolution wherever the three-piece bf16 arithmetic is -- forward, input
+gradient (also with a gradient added in the store) and weight gradient are held to the SAME bound against float64 as the bf16 path
+(2^-22 * sqrt(terms) * 8 of the largest exact output), on unit-variance data, on rows spanning six decades, on gradient-sized data
+(x 1e-7: without the scale fp16 returns noise there) and next to one outlier of 1e4; and to twice the bf16 path's own error plus that
+bound's tenth.  mode_abs_max is an order-independent maximum: the same bits in every call."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mode_hip
+from mode_hip import functional as HF
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+  assert torch.cuda.is_available(), 'GPU tests need a GPU'
+  mode_hip.lib()
+
+
+@pytest.fixture
+def f16_switch():
+  keep = HF.CONV3D_S1_F16
+  HF.set_conv_arith('bf16x6')
+  yield
+  HF.CONV3D_S1_F16 = keep
+
+
+def _rand(shape, seed, scale=1.0):
+  return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)).to(DEV)
+
+
+CASES = ['unit variance', 'six decades along a row', 'gradient-sized', 'one outlier']
+
+
+def _case(name, ci, shape, seed):
+  x = _rand((shape[0], ci) + shape[1:], seed)
+  if name == 'six decades along a row':
+    x = torch.relu(x) * torch.logspace(0, -6, shape[-1], device=DEV)
+  elif name == 'gradient-sized':
+    x = x * 1e-7
+  elif name == 'one outlier':
+    x[0, 1, 1, 2, 3] = 1e4
+  return x
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('ci,co,shape', [(32, 32, (2, 6, 20, 40)), (64, 64, (1, 5, 9, 33))])
+def test_f16_arithmetic_is_an_fp32_convolution(case, ci, co, shape, f16_switch):
+  x = _case(case, ci, shape, 501)
+  w = _rand((co, ci, 3, 3, 3), 502, 0.05)
+  gy = _case(case, co, shape, 503)
+  acc = _rand(tuple(x.shape), 504) * float(x.abs().max()) * 0.1
+  xd, wd, gd = x.double().cpu(), w.double().cpu(), gy.double().cpu()
+  want = {'forward': F.conv3d(xd, wd, None, 1, 1), 'input gradient': torch.nn.grad.conv3d_input(x.shape, wd, gd, 1, 1),
+          'weight gradient': torch.nn.grad.conv3d_weight(xd, w.shape, gd, 1, 1)}
+  want['input gradient + acc'] = want['input gradient'] + acc.double().cpu()
+  terms = {'forward': ci * 27, 'input gradient': co * 27, 'input gradient + acc': co * 27, 'weight gradient': x.numel() // ci}
+  got = {}
+  for f16 in (False, True):
+    HF.CONV3D_S1_F16 = f16
+    got[f16] = {'forward': HF.conv3d_fwd(x, w, 1), 'input gradient': HF.conv3d_bwd_data(gy, w, x.shape, 1),
+                'input gradient + acc': HF.conv3d_bwd_data(gy, w, x.shape, 1, acc=acc), 'weight gradient': HF.conv3d_bwd_weight(gy, x, 1)}
+  for k in want:
+    scale = float(want[k].abs().max())
+    bound = 2.0**-22 * terms[k]**0.5 * 8 * scale
+    e16 = float((got[True][k].double().cpu() - want[k]).abs().max())
+    eb = float((got[False][k].double().cpu() - want[k]).abs().max())
+    print('%-22s %-24s f16x3 %.2e  bf16x6 %.2e  bound %.2e' % (case, k, e16, eb, bound))
+    assert e16 <= bound, (case, k, e16, bound)
+    assert e16 <= 2 * eb + bound / 10, (case, k, e16, eb)
+    assert torch.isfinite(got[True][k]).all()
+
+
+def test_abs_max_is_exact_and_order_independent():
+  x = _rand((3, 1000003), 601)
+  x[1, 77] = -123.5
+  m = [float(HF.abs_max(x)) for _ in range(3)]
+  assert m == [123.5] * 3
+  assert float(HF.abs_max(torch.zeros(5, device=DEV))) == 0.0
+  y = x.clone()
+  y[2, 5] = float('nan')
+  y[0, 9] = float('inf')
+  assert float(HF.abs_max(y)) == 123.5  # the largest FINITE magnitude: the scale has to fit the finite data
+
+
+def test_f16_layers_propagate_nan_and_inf_like_the_bf16_ones(f16_switch):
+  x = _rand((1, 32, 4, 8, 32), 701)
+  w = _rand((32, 32, 3, 3, 3), 702, 0.05)
+  x[0, 3, 2, 4, 7] = float('nan')
+  for f16 in (False, True):
+    HF.CONV3D_S1_F16 = f16
+    y = HF.conv3d_fwd(x, w, 1)
+    near = y[0, :, 1:4, 3:6, 6:9]
+    assert bool(torch.isnan(near).all()), f16  # every output within one tap of the NaN input is NaN ...
+    assert int(torch.isnan(y).sum()) == near.numel() and not bool(torch.isinf(y).any()), f16  # ... and no other output is touched

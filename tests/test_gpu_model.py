@@ -231,9 +231,9 @@ def test_gradient_carriers_give_autograds_sums_bit_for_bit(monkeypatch):
   calls, calls2d = [], []
   real, real2d = HF.conv3d_bwd_data, HF.conv2d_bwd_data
 
-  def spy(gy, w, in_shape, stride=1, acc=None):
+  def spy(gy, w, in_shape, stride=1, acc=None, **kw):
     calls.append((stride, acc is not None))
-    return real(gy, w, in_shape, stride, acc)
+    return real(gy, w, in_shape, stride, acc, **kw)
 
   def spy2d(gy, w, dilation=1, acc=None):
     calls2d.append(acc is not None)
