@@ -150,10 +150,12 @@ struct BnCoefArgs {
   int groups;    // statistics groups (TRAIN)
   int Bg;        // samples per group
   const float* pivot;  // (TRAIN) per (group, channel) pivot of the shifted sums; null: the first element of the group's first sample
+  unsigned* amax;      // optional: atomicMax of the bit patterns of the finite |out| values (the scale source of the fp16 convolutions)
 };
 
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
-template <bool RELU, bool ADD, bool TRAIN>
+// AMAX: also leaves the largest finite |out| in *k.amax (its own instantiation: the untracked passes keep their registers and occupancy)
+template <bool RELU, bool ADD, bool TRAIN, bool AMAX = false>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ add, BnCoefArgs k,
                                                       float* __restrict__ out, int C, long long S) {
   __shared__ double shd[2 * NW];
@@ -227,6 +229,17 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     }
     return v;
   };
+  // (k.amax) the largest finite magnitude this thread writes: the consumer's fp16 scale comes out of this pass instead of one of its own
+  unsigned mx = 0;
+  constexpr bool track = AMAX;
+  auto mag = [](float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f) & 0x7fffffffu;
+    return u < 0x7f800000u ? u : 0u;
+  };
+  auto put = [&](float4* dst, float4 v) {
+    if (track) mx = max(max(mx, mag(v.x)), max(max(mag(v.y), mag(v.z)), mag(v.w)));
+    *dst = v;
+  };
   const long long st = (long long)gridDim.x * NT;
   long long i = (long long)blockIdx.x * NT + threadIdx.x;
   for (; i + 3 * st < S4; i += 4 * st) {
@@ -235,18 +248,26 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     if (ADD) {
       a0 = ap[i]; a1 = ap[i + st]; a2 = ap[i + 2 * st]; a3 = ap[i + 3 * st];
     }
-    op[i] = one(v0, a0);
-    op[i + st] = one(v1, a1);
-    op[i + 2 * st] = one(v2, a2);
-    op[i + 3 * st] = one(v3, a3);
+    put(op + i, one(v0, a0));
+    put(op + i + st, one(v1, a1));
+    put(op + i + 2 * st, one(v2, a2));
+    put(op + i + 3 * st, one(v3, a3));
   }
-  for (; i < S4; i += st) op[i] = one(yp[i], ADD ? ap[i] : yp[i]);
+  for (; i < S4; i += st) put(op + i, one(yp[i], ADD ? ap[i] : yp[i]));
   for (long long i = (S4 << 2) + (long long)blockIdx.x * NT + threadIdx.x; i < S; i += (long long)gridDim.x * NT) {  // scalar path (S % 4 != 0)
       float v = __builtin_fmaf(y[base + i], sc, sh);
       if (ADD) v += add[base + i];
       if (RELU) v = relu_nan(v);
+      if (track) mx = max(mx, mag(v));
       out[base + i] = v;
     }
+  if (track) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+    // (tens of thousands of waves, one address: an atomic per wave serialises in the L2 -- measured 3 x the pass's time.  The value only
+    // grows, so a wave whose maximum is not above what is already there has nothing to add; a stale read costs one spare atomic.)
+    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(k.amax, __ATOMIC_RELAXED)) atomicMax(k.amax, mx);
+  }
 }
 
 // Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y).
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
 //   Cc = A*(mean*invstd*dgamma - sum(g))/count
 // derived by every block from the partial sums; the block (chunk 0, sample 0) of each channel stores (or, with
 // `accumulate`, adds into) ggamma / gbeta.
-template <int RELU, bool GADD>
+template <int RELU, bool GADD, bool AMAX = false>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ gout, const float* __restrict__ y,
                                                           const float* __restrict__ out, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, const float* __restrict__ partial,
@@ -325,9 +346,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ save_invstd, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int accumulate, int nsplit, double count,
                                                           int groups, int Bg, float* __restrict__ gy, float* __restrict__ gadd, int C,
-                                                          long long S) {
+                                                          long long S, unsigned* __restrict__ amax) {
   __shared__ double shd[2 * NW];
   __shared__ float coef[3];
+  unsigned mx = 0;  // (amax) the largest finite |gy| this thread writes: the scale source of the fp16 convolution gradients that read gy
+  auto mag = [](float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f) & 0x7fffffffu;
+    return u < 0x7f800000u ? u : 0u;
+  };
   const int bc = blockIdx.y;
   const int c = bc % C;
   const int grp = (bc / C) / Bg;
@@ -388,6 +414,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     r.y = A * g.y + Bc * v.y + Cc;
     r.z = A * g.z + Bc * v.z + Cc;
     r.w = A * g.w + Bc * v.w + Cc;
+    if (AMAX) mx = max(max(mx, mag(r.x)), max(max(mag(r.y), mag(r.z)), mag(r.w)));
     gyp[i] = r;
   };
   const long long st = (long long)gridDim.x * NT;
@@ -410,8 +437,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
       if (RELU == 1) g = out[base + i] > 0.f ? g : 0.f;
       if (RELU == 2) g = __builtin_fmaf(y[base + i], msc, msh) > 0.f ? g : 0.f;
       if (GADD) gadd[base + i] = g;
-      gy[base + i] = A * g + Bc * y[base + i] + Cc;
+      const float r = A * g + Bc * y[base + i] + Cc;
+      if (AMAX) mx = max(mx, mag(r));
+      gy[base + i] = r;
     }
+  if (AMAX) {  // (one address: see bn_apply_kernel)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, mx);
+  }
 }
 
 int pick_nsplit(int C, long long S) {
@@ -464,6 +498,15 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
                              int C, long long S, int groups, int prestats, mode_stream_t stream);
 
+// The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of this thread also leaves the largest finite |out| in *device_scalar
+// (the bit pattern of a non-negative float; zeroed by that call): the power-of-two scale of an fp16-arithmetic consumer
+// (mode_conv3d_fwd_split_f16) without a pass of its own over the tensor.  One-shot: cleared by the call that uses it.
+static thread_local float* g_next_out_absmax = nullptr;
+extern "C" void mode_bn_next_out_absmax(float* device_scalar) { g_next_out_absmax = device_scalar; }
+// the same for the NEXT mode_bn_train_bwd call and its `gy` (the gradient the convolution in front of the BatchNorm reads twice)
+static thread_local float* g_next_gy_absmax = nullptr;
+extern "C" void mode_bn_next_gy_absmax(float* device_scalar) { g_next_gy_absmax = device_scalar; }
+
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                  float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
@@ -498,13 +541,28 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   // the apply pass re-reads the pivot of the shifted sums from y while other blocks of the same launch write `out`
   MODE_REQUIRE(out != y, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: in-place operation (out == y) is not supported");
   hipStream_t st = mode::as_stream(stream);
+  float* amax = g_next_out_absmax;
+  g_next_out_absmax = nullptr;
+  if (amax) {
+    rc = mode::fill_words(amax, 0u, 1, st, "mode_bn_train_fwd");
+    if (rc != MODE_OK) return rc;
+  }
   const int nsplit = prestats > 0 ? prestats : pick_nsplit(C * groups, S);
   if (prestats <= 0) hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit,
-               (double)(B / groups) * (double)S, groups, B / groups, prestats > 0 ? workspace + 2LL * C * nsplit : nullptr};
+               (double)(B / groups) * (double)S, groups, B / groups, prestats > 0 ? workspace + 2LL * C * nsplit : nullptr,
+               reinterpret_cast<unsigned*>(amax)};
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
+  if (amax) {
+    if (relu) {
+      if (add) return launch_apply(bn_apply_kernel<true, true, true, true>, BC, S, st, who, y, add, k, out, C, S);
+      return launch_apply(bn_apply_kernel<true, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
+    }
+    if (add) return launch_apply(bn_apply_kernel<false, true, true, true>, BC, S, st, who, y, add, k, out, C, S);
+    return launch_apply(bn_apply_kernel<false, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
+  }
   if (relu) {
     if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
     return launch_apply(bn_apply_kernel<true, false, true>, BC, S, st, who, y, y, k, out, C, S);
@@ -612,9 +670,19 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
   const double count = (double)(B / groups) * (double)S;
+  float* amax = g_next_gy_absmax;  // (mode_bn_next_gy_absmax: one-shot)
+  g_next_gy_absmax = nullptr;
+  if (amax) {
+    int frc = mode::fill_words(amax, 0u, 1, st, who);
+    if (frc != MODE_OK) return frc;
+  }
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
-  launch_apply(bn_bwd_apply_kernel<M, G>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean, save_invstd, ggamma, \
-               gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S)
+  (amax ? launch_apply(bn_bwd_apply_kernel<M, G, true>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,    \
+                       save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
+                       reinterpret_cast<unsigned*>(amax))                                                                             \
+        : launch_apply(bn_bwd_apply_kernel<M, G, false>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,   \
+                       save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
+                       (unsigned*)nullptr))
   if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
   if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
   return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);

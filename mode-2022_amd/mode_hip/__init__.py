@@ -100,6 +100,8 @@ SIGNATURES = {
     'mode_deconv3d_split_bn_supported': (_c_int, [_c_int] * 2),
     'mode_conv3d_bwd_data_split_acc_supported': (_c_int, [_c_int] * 3),
     'mode_abs_max': (_c_int, [_c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr]),
+    'mode_bn_next_out_absmax': (None, [_c_ptr]),
+    'mode_bn_next_gy_absmax': (None, [_c_ptr]),
     'mode_conv3d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),
@@ -136,7 +138,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 25  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 26  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

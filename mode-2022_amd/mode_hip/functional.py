@@ -1366,7 +1366,8 @@ class Conv3dFunction(torch.autograd.Function):
     ctx.carrier = carrier  # GradCarrier of x (x has one other consumer), or None
     ctx.amax = None
     if stride == 1 and x.is_cuda and CONV3D_S1_F16 and _split3d(x.shape[1], w.shape[0], 1, False):
-      ctx.amax = (abs_max(x.contiguous()), abs_max(w.contiguous()))  # (max |x|, max |w|): the backward reads both tensors again
+      ax = known_abs_max(x)  # left by the BatchNorm pass that wrote x, where there is one
+      ctx.amax = (ax if ax is not None else abs_max(x.contiguous()), abs_max(w.contiguous()))  # the backward reads both tensors again
     return conv3d_fwd(x, w, stride, amax=ctx.amax)
 
   @staticmethod
@@ -1376,8 +1377,10 @@ class Conv3dFunction(torch.autograd.Function):
     fwd_amax = getattr(ctx, 'amax', None)
     ag = None
     if fwd_amax is not None:  # fp16 arithmetic: gy's maximum once, for both gradients
+      ag = known_abs_max(gy)  # left by the BatchNorm backward that wrote gy, where that is where gy comes from
       gy = gy.contiguous()
-      ag = abs_max(gy)
+      if ag is None:
+        ag = abs_max(gy)
     if ctx.needs_input_grad[0]:
       carrier = getattr(ctx, 'carrier', None)  # (Conv3dStatsFunction shares this backward and has none)
       prev = carrier.take() if carrier is not None else None  # the other consumer's gradient, when it came first
@@ -1634,6 +1637,15 @@ def bn_supported(y):
   return y.is_cuda and y.dtype == torch.float32 and B * C < 65536 and B > 0  # (any S: rows that are not multiples of 16 bytes take the kernels' scalar path)
 
 
+_bn_tls = threading.local()  # out_amax: the device scalar the last BnActFunction.forward of this thread asked its kernel to fill
+
+
+def known_abs_max(t):
+  """The largest-magnitude scalar the producer of t left next to it (BatchNorm's apply pass, bn_act), if t has not been written since."""
+  tag = getattr(t, '_mode_amax', None)
+  return tag[0] if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() else None
+
+
 class BnActFunction(torch.autograd.Function):
   """out = relu?(batch_norm_train(y) [+ add]); running statistics updated in place (torch semantics)."""
 
@@ -1660,6 +1672,11 @@ class BnActFunction(torch.autograd.Function):
                 ptr(running_var) if running_var is not None else None, ptr(num_batches_tracked) if num_batches_tracked is not None else None,
                 float(momentum), float(eps), int(relu), ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None,
                 ptr(coef[1]) if from_y else None)
+      _bn_tls.out_amax = None
+      if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
+        # the 3-D stack's activations feed stride-1 convolutions on the fp16 arithmetic: their maximum comes out of this pass
+        _bn_tls.out_amax = torch.empty(1, dtype=torch.float32, device=y.device)
+        lib().mode_bn_next_out_absmax(ptr(_bn_tls.out_amax))
       if prestats_ws is not None:  # the producing convolution left the statistics in the workspace (conv3d_bn_train): no statistics pass
         if groups != 1:
           raise RuntimeError('BatchNorm with precomputed statistics takes one statistics group')
@@ -1686,13 +1703,19 @@ class BnActFunction(torch.autograd.Function):
     ggamma = sink_g if fused else torch.empty_like(gamma)
     gbeta = sink_b if fused else torch.empty_like(gamma)
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
+    gy_amax = None
+    if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
+      gy_amax = torch.empty(1, dtype=torch.float32, device=y.device)  # the convolution in front reads gy in both of its gradients
+      lib().mode_bn_next_gy_absmax(ptr(gy_amax))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * ctx.groups, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
                                     ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
                                     ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
                                     int(fused), ptr(ws), B, C, S, ctx.groups, stream_of(y)), 'mode_bn_train_bwd')
-    if fused:
+    if gy_amax is not None:
+      gy._mode_amax = (gy_amax, gy._version, gy.data_ptr())  # (survives the engine's hand-over when the tensor's Python object does;
+    if fused:                                               #  Conv3dFunction.backward computes the maximum itself otherwise)
       ggamma = gbeta = None
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
@@ -1738,8 +1761,13 @@ def bn_act(bn, y, add=None, relu=False, groups=1, add_carrier=None):
       nbt = None
     if add_carrier is not None:
       add_carrier.arm(add is not None and add.requires_grad and torch.is_grad_enabled())
-    return BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
-                               momentum if momentum is not None else 0.0, bn.eps, relu, nbt, groups, None, add_carrier)
+    out = BnActFunction.apply(y, add, bn.weight, bn.bias, bn.running_mean if update else None, bn.running_var if update else None,
+                              momentum if momentum is not None else 0.0, bn.eps, relu, nbt, groups, None, add_carrier)
+    am = getattr(_bn_tls, 'out_amax', None)
+    if am is not None:
+      _bn_tls.out_amax = None
+      out._mode_amax = (am, out._version, out.data_ptr())  # (a later in-place write to `out` invalidates it: known_abs_max checks)
+    return out
   if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
     # eval-mode BN inside a graph that needs gradients: rare (the reference never does it); vendor ops keep autograd correct
     out = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
