@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 26 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 27 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -523,8 +523,11 @@ int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, cons
                       float* workspace, int B, int C, long long S, int groups, mode_stream_t stream);
 
 /* The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of the calling thread also leaves the largest finite |out| in
- * *device_scalar (zeroed by that call; same convention as mode_abs_max): the operand maximum of an fp16-arithmetic consumer
- * (mode_conv3d_fwd_split_f16) comes out of the pass that writes the tensor.  One-shot. */
+ * device_scalar[0] (same convention as mode_abs_max): the operand maximum of an fp16-arithmetic consumer (mode_conv3d_fwd_split_f16)
+ * comes out of the pass that writes the tensor.  `device_scalar` points at MODE_BN_ABSMAX_FLOATS floats: word 0 is the result, the
+ * rest is the pass's scratch (its blocks collect the maximum in 128 words of different cache lines, a one-block kernel folds them);
+ * the call zeroes all of it.  One-shot. */
+#define MODE_BN_ABSMAX_FLOATS 2064
 void mode_bn_next_out_absmax(float* device_scalar);
 /* The same for the NEXT mode_bn_train_bwd call and the gradient `gy` it writes (read by both gradients of the convolution in front). */
 void mode_bn_next_gy_absmax(float* device_scalar);

@@ -153,6 +153,41 @@ struct BnCoefArgs {
   unsigned* amax;      // optional: atomicMax of the bit patterns of the finite |out| values (the scale source of the fp16 convolutions)
 };
 
+// The tracked maximum of a pass.  `amax` points at MODE_BN_ABSMAX_FLOATS words (zeroed by the entry): word 0 is the result, the
+// AMAX_SLOTS words at 16 * (1 + s) collect it.  One address for the whole launch does not work: tens of thousands of waves end within
+// microseconds of each other, and their requests to ONE word -- the atomics, and just as much the loads that guard them -- queue up
+// behind each other at the memory side (device scope: not served by the per-XCD L2s): an atomic per wave was 3 x the pass's time, a
+// guarded one still +60 % on the 403 MB layers.  So: one request per BLOCK (its waves meet in LDS), spread over 128 words of 128
+// different cache lines, and a one-block kernel behind the pass that folds them into word 0.
+constexpr int AMAX_SLOTS = 128;
+static_assert(MODE_BN_ABSMAX_FLOATS == 16 * (1 + AMAX_SLOTS), "include/mode_hip.h and bn_act.hip disagree about the maximum's buffer");
+__device__ __forceinline__ void amax_block_commit(unsigned mx, unsigned* amax, unsigned* sh /* [NW] */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = max(mx, sh[w]);
+    unsigned* slot = amax + 16 * (1 + (int)((blockIdx.y * gridDim.x + blockIdx.x) % AMAX_SLOTS));
+    // (the value only grows: a block whose maximum is not above what is already there has nothing to add; a stale read costs one spare atomic)
+    if (mx > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mx);
+  }
+}
+__global__ __launch_bounds__(AMAX_SLOTS) void amax_fold_kernel(unsigned* __restrict__ amax) {
+  __shared__ unsigned sh[AMAX_SLOTS / 64];
+  unsigned mx = amax[16 * (1 + threadIdx.x)];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < AMAX_SLOTS / 64; ++w) mx = max(mx, sh[w]);
+    amax[0] = mx;
+  }
+}
+
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
 // AMAX: also leaves the largest finite |out| in *k.amax (its own instantiation: the untracked passes keep their registers and occupancy)
 template <bool RELU, bool ADD, bool TRAIN, bool AMAX = false>
@@ -261,13 +296,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       if (track) mx = max(mx, mag(v));
       out[base + i] = v;
     }
-  if (track) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-    // (tens of thousands of waves, one address: an atomic per wave serialises in the L2 -- measured 3 x the pass's time.  The value only
-    // grows, so a wave whose maximum is not above what is already there has nothing to add; a stale read costs one spare atomic.)
-    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(k.amax, __ATOMIC_RELAXED)) atomicMax(k.amax, mx);
-  }
+  if (track) amax_block_commit(mx, k.amax, reinterpret_cast<unsigned*>(shd));  // (shd: read for the last time in front of the barrier above)
 }
 
 // Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y).
@@ -441,11 +470,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
       if (AMAX) mx = max(mx, mag(r));
       gy[base + i] = r;
     }
-  if (AMAX) {  // (one address: see bn_apply_kernel)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, mx);
-  }
+  if (AMAX) amax_block_commit(mx, amax, reinterpret_cast<unsigned*>(shd));
 }
 
 int pick_nsplit(int C, long long S) {
@@ -498,8 +523,9 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
                              int C, long long S, int groups, int prestats, mode_stream_t stream);
 
-// The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of this thread also leaves the largest finite |out| in *device_scalar
-// (the bit pattern of a non-negative float; zeroed by that call): the power-of-two scale of an fp16-arithmetic consumer
+// The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of this thread also leaves the largest finite |out| in device_scalar[0]
+// (the bit pattern of a non-negative float; the buffer -- MODE_BN_ABSMAX_FLOATS words, the rest is the pass's scratch -- is zeroed by
+// that call): the power-of-two scale of an fp16-arithmetic consumer
 // (mode_conv3d_fwd_split_f16) without a pass of its own over the tensor.  One-shot: cleared by the call that uses it.
 static thread_local float* g_next_out_absmax = nullptr;
 extern "C" void mode_bn_next_out_absmax(float* device_scalar) { g_next_out_absmax = device_scalar; }
@@ -544,7 +570,7 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   float* amax = g_next_out_absmax;
   g_next_out_absmax = nullptr;
   if (amax) {
-    rc = mode::fill_words(amax, 0u, 1, st, "mode_bn_train_fwd");
+    rc = mode::fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, "mode_bn_train_fwd");
     if (rc != MODE_OK) return rc;
   }
   const int nsplit = prestats > 0 ? prestats : pick_nsplit(C * groups, S);
@@ -556,12 +582,15 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   const int BC = B * C;
   const char* who = "mode_bn_train_fwd";
   if (amax) {
-    if (relu) {
-      if (add) return launch_apply(bn_apply_kernel<true, true, true, true>, BC, S, st, who, y, add, k, out, C, S);
-      return launch_apply(bn_apply_kernel<true, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
-    }
-    if (add) return launch_apply(bn_apply_kernel<false, true, true, true>, BC, S, st, who, y, add, k, out, C, S);
-    return launch_apply(bn_apply_kernel<false, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
+    if (relu)
+      rc = add ? launch_apply(bn_apply_kernel<true, true, true, true>, BC, S, st, who, y, add, k, out, C, S)
+               : launch_apply(bn_apply_kernel<true, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
+    else
+      rc = add ? launch_apply(bn_apply_kernel<false, true, true, true>, BC, S, st, who, y, add, k, out, C, S)
+               : launch_apply(bn_apply_kernel<false, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
+    return mode::check_launch(who);
   }
   if (relu) {
     if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
@@ -673,9 +702,14 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   float* amax = g_next_gy_absmax;  // (mode_bn_next_gy_absmax: one-shot)
   g_next_gy_absmax = nullptr;
   if (amax) {
-    int frc = mode::fill_words(amax, 0u, 1, st, who);
+    int frc = mode::fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, who);
     if (frc != MODE_OK) return frc;
   }
+  auto fold = [&](int arc) {
+    if (arc != MODE_OK || !amax) return arc;
+    hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
+    return mode::check_launch(who);
+  };
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
   (amax ? launch_apply(bn_bwd_apply_kernel<M, G, true>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,    \
                        save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
@@ -683,9 +717,9 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
         : launch_apply(bn_bwd_apply_kernel<M, G, false>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,   \
                        save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
                        (unsigned*)nullptr))
-  if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
-  if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
-  return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);
+  if (mode == 0) return fold(gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false));
+  if (mode == 1) return fold(gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false));
+  return fold(gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false));
 #undef MODE_BN_BWD_APPLY
 }
 

@@ -138,7 +138,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 26  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 27  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

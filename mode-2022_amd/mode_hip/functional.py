@@ -1637,6 +1637,7 @@ def bn_supported(y):
   return y.is_cuda and y.dtype == torch.float32 and B * C < 65536 and B > 0  # (any S: rows that are not multiples of 16 bytes take the kernels' scalar path)
 
 
+BN_ABSMAX_FLOATS = 2064  # MODE_BN_ABSMAX_FLOATS of include/mode_hip.h: the buffer mode_bn_next_*_absmax points the pass at
 _bn_tls = threading.local()  # out_amax: the device scalar the last BnActFunction.forward of this thread asked its kernel to fill
 
 
@@ -1675,8 +1676,9 @@ class BnActFunction(torch.autograd.Function):
       _bn_tls.out_amax = None
       if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
         # the 3-D stack's activations feed stride-1 convolutions on the fp16 arithmetic: their maximum comes out of this pass
-        _bn_tls.out_amax = torch.empty(1, dtype=torch.float32, device=y.device)
-        lib().mode_bn_next_out_absmax(ptr(_bn_tls.out_amax))
+        buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)  # word 0: the result; the rest: the pass's scratch
+        _bn_tls.out_amax = buf[:1]
+        lib().mode_bn_next_out_absmax(ptr(buf))
       if prestats_ws is not None:  # the producing convolution left the statistics in the workspace (conv3d_bn_train): no statistics pass
         if groups != 1:
           raise RuntimeError('BatchNorm with precomputed statistics takes one statistics group')
@@ -1705,8 +1707,9 @@ class BnActFunction(torch.autograd.Function):
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
     gy_amax = None
     if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
-      gy_amax = torch.empty(1, dtype=torch.float32, device=y.device)  # the convolution in front reads gy in both of its gradients
-      lib().mode_bn_next_gy_absmax(ptr(gy_amax))
+      buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
+      gy_amax = buf[:1]  # the convolution in front reads gy in both of its gradients
+      lib().mode_bn_next_gy_absmax(ptr(buf))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * ctx.groups, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
