@@ -529,7 +529,8 @@ int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, cons
  * the call zeroes all of it.  One-shot. */
 #define MODE_BN_ABSMAX_FLOATS 2064
 void mode_bn_next_out_absmax(float* device_scalar);
-/* The same for the NEXT mode_bn_train_bwd call and the gradient `gy` it writes (read by both gradients of the convolution in front). */
+/* The same for the NEXT mode_bn_train_bwd or mode_classif_train_bwd call and the gradient `gy` it writes (read by both gradients of the
+ * convolution in front). */
 void mode_bn_next_gy_absmax(float* device_scalar);
 
 int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,

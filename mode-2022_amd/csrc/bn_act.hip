@@ -49,11 +49,14 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [2 *
 // per-call BatchNorm statistics: two groups.
 // grid = (nsplit, C, G).  partial[((g*C + c)*nsplit + split)*2 + {0,1}] = sum(y), sum(y*y) over this block's share of (b, s).
 __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int B, int C,
-                                                      long long S, int nsplit) {
+                                                      long long S, int nsplit, unsigned* __restrict__ zero) {
   __shared__ float sh[2 * NW];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
+  // (the buffer of the apply pass's tracked maximum, if there is one, is zeroed here: a launch of its own costs 5 us in front of every pass)
+  if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < MODE_BN_ABSMAX_FLOATS; i += NT) zero[i] = 0u;
   const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   // Shifted sums: everything is accumulated relative to a pivot -- the first element of the group's first sample of this channel
   // (bn_pivot, re-read by the finalisation) -- so that var = E[(y-K)^2] - E[y-K]^2 does not cancel when |mean| >> std
@@ -153,29 +156,8 @@ struct BnCoefArgs {
   unsigned* amax;      // optional: atomicMax of the bit patterns of the finite |out| values (the scale source of the fp16 convolutions)
 };
 
-// The tracked maximum of a pass.  `amax` points at MODE_BN_ABSMAX_FLOATS words (zeroed by the entry): word 0 is the result, the
-// AMAX_SLOTS words at 16 * (1 + s) collect it.  One address for the whole launch does not work: tens of thousands of waves end within
-// microseconds of each other, and their requests to ONE word -- the atomics, and just as much the loads that guard them -- queue up
-// behind each other at the memory side (device scope: not served by the per-XCD L2s): an atomic per wave was 3 x the pass's time, a
-// guarded one still +60 % on the 403 MB layers.  So: one request per BLOCK (its waves meet in LDS), spread over 128 words of 128
-// different cache lines, and a one-block kernel behind the pass that folds them into word 0.
-constexpr int AMAX_SLOTS = 128;
-static_assert(MODE_BN_ABSMAX_FLOATS == 16 * (1 + AMAX_SLOTS), "include/mode_hip.h and bn_act.hip disagree about the maximum's buffer");
-__device__ __forceinline__ void amax_block_commit(unsigned mx, unsigned* amax, unsigned* sh /* [NW] */) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < NW; ++w) mx = max(mx, sh[w]);
-    unsigned* slot = amax + 16 * (1 + (int)((blockIdx.y * gridDim.x + blockIdx.x) % AMAX_SLOTS));
-    // (the value only grows: a block whose maximum is not above what is already there has nothing to add; a stale read costs one spare atomic)
-    if (mx > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mx);
-  }
-}
-__global__ __launch_bounds__(AMAX_SLOTS) void amax_fold_kernel(unsigned* __restrict__ amax) {
-  __shared__ unsigned sh[AMAX_SLOTS / 64];
+__global__ __launch_bounds__(mode::ABSMAX_SLOTS) void amax_fold_kernel(unsigned* __restrict__ amax) {
+  __shared__ unsigned sh[mode::ABSMAX_SLOTS / 64];
   unsigned mx = amax[16 * (1 + threadIdx.x)];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
@@ -183,7 +165,7 @@ __global__ __launch_bounds__(AMAX_SLOTS) void amax_fold_kernel(unsigned* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 1; w < AMAX_SLOTS / 64; ++w) mx = max(mx, sh[w]);
+    for (int w = 1; w < mode::ABSMAX_SLOTS / 64; ++w) mx = max(mx, sh[w]);
     amax[0] = mx;
   }
 }
@@ -296,7 +278,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       if (track) mx = max(mx, mag(v));
       out[base + i] = v;
     }
-  if (track) amax_block_commit(mx, k.amax, reinterpret_cast<unsigned*>(shd));  // (shd: read for the last time in front of the barrier above)
+  if (track) mode::absmax_block_commit(mx, k.amax, reinterpret_cast<unsigned*>(shd));  // (shd: read for the last time in front of the barrier above)
 }
 
 // Backward reduce: g = RELU ? (out > 0 ? gout : 0) : gout;  partial = sum(g), sum(g*y).
@@ -306,11 +288,14 @@ template <int RELU>
 __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ gout, const float* __restrict__ y,
                                                           const float* __restrict__ out, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, float* __restrict__ partial, int B, int C,
-                                                          long long S, int nsplit) {
+                                                          long long S, int nsplit, unsigned* __restrict__ zero) {
   __shared__ float sh[2 * NW];
   const int c = blockIdx.y, split = blockIdx.x;
   const int Bg = B / gridDim.z, b0 = blockIdx.z * Bg;
   const long long prow = (long long)blockIdx.z * C + c;
+  // (the buffer of the apply pass's tracked maximum, if there is one, is zeroed here: a launch of its own costs 5 us in front of every pass)
+  if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < MODE_BN_ABSMAX_FLOATS; i += NT) zero[i] = 0u;
   const float msc = RELU == 2 ? mscale[prow] : 0.f, msh = RELU == 2 ? mshift[prow] : 0.f;
   const long long S4 = (S & 3) ? 0 : (S >> 2);  // rows that are not multiples of 16 bytes: the scalar loop below takes the whole row
   float s0 = 0.f, s1 = 0.f;
@@ -470,7 +455,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
       if (AMAX) mx = max(mx, mag(r));
       gy[base + i] = r;
     }
-  if (AMAX) amax_block_commit(mx, amax, reinterpret_cast<unsigned*>(shd));
+  if (AMAX) mode::absmax_block_commit(mx, amax, reinterpret_cast<unsigned*>(shd));
 }
 
 int pick_nsplit(int C, long long S) {
@@ -513,6 +498,14 @@ int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who,
 
 }  // namespace
 
+namespace mode {
+int absmax_begin(float* amax, hipStream_t st, const char* who) { return fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, who); }
+int absmax_fold(float* amax, hipStream_t st, const char* who) {
+  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(ABSMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
+  return check_launch(who);
+}
+}  // namespace mode
+
 // workspace (floats): per-block partial sums, up to 1024 pairs per (group, channel); C = channels x groups
 extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 2048 * sizeof(float) : 0; }
 
@@ -532,6 +525,11 @@ extern "C" void mode_bn_next_out_absmax(float* device_scalar) { g_next_out_absma
 // the same for the NEXT mode_bn_train_bwd call and its `gy` (the gradient the convolution in front of the BatchNorm reads twice)
 static thread_local float* g_next_gy_absmax = nullptr;
 extern "C" void mode_bn_next_gy_absmax(float* device_scalar) { g_next_gy_absmax = device_scalar; }
+float* mode::take_next_gy_absmax() {
+  float* p = g_next_gy_absmax;
+  g_next_gy_absmax = nullptr;
+  return p;
+}
 
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
@@ -555,6 +553,8 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
                              float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
                              int C, long long S, int groups, int prestats, mode_stream_t stream) {
+  float* amax = g_next_out_absmax;  // (mode_bn_next_out_absmax: one-shot, whatever this call returns)
+  g_next_out_absmax = nullptr;
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
@@ -567,14 +567,13 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
   // the apply pass re-reads the pivot of the shifted sums from y while other blocks of the same launch write `out`
   MODE_REQUIRE(out != y, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: in-place operation (out == y) is not supported");
   hipStream_t st = mode::as_stream(stream);
-  float* amax = g_next_out_absmax;
-  g_next_out_absmax = nullptr;
-  if (amax) {
-    rc = mode::fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, "mode_bn_train_fwd");
+  if (amax && prestats > 0) {  // (no statistics pass to zero the maximum's buffer on the way)
+    rc = mode::absmax_begin(amax, st, "mode_bn_train_fwd");
     if (rc != MODE_OK) return rc;
   }
   const int nsplit = prestats > 0 ? prestats : pick_nsplit(C * groups, S);
-  if (prestats <= 0) hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  if (prestats <= 0)
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, groups), dim3(NT), 0, st, y, workspace, B, C, S, nsplit, reinterpret_cast<unsigned*>(amax));
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit,
                (double)(B / groups) * (double)S, groups, B / groups, prestats > 0 ? workspace + 2LL * C * nsplit : nullptr,
@@ -589,8 +588,7 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
       rc = add ? launch_apply(bn_apply_kernel<false, true, true, true>, BC, S, st, who, y, add, k, out, C, S)
                : launch_apply(bn_apply_kernel<false, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
     if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
-    return mode::check_launch(who);
+    return mode::absmax_fold(amax, st, who);
   }
   if (relu) {
     if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
@@ -639,7 +637,7 @@ int mode::bn_train_coefficients(const float* y, const float* gamma, const float*
   MODE_REQUIRE(aligned_rows(y, S) && aligned16(workspace), MODE_ERR_UNSUPPORTED, "%s: unaligned buffer", who);
   MODE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MODE_ERR_BAD_ARG, "%s: running stats must come in pairs", who);
   const int nsplit = pick_nsplit(C, S);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, 1), dim3(NT), 0, st, y, workspace, B, C, S, nsplit);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C, 1), dim3(NT), 0, st, y, workspace, B, C, S, nsplit, (unsigned*)nullptr);
   BnCoefArgs k{workspace, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, save_scale, save_shift,
                momentum, eps, nsplit, (double)B * (double)S, 1, B, nullptr};
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(NT), 0, st, y, k, C, S);
@@ -672,6 +670,7 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
                                  const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                                  float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, long long S,
                                  int groups, mode_stream_t stream) {
+  float* amax = mode::take_next_gy_absmax();  // (mode_bn_next_gy_absmax: one-shot, whatever this call returns)
   int rc = check_bn(B, C, S, "mode_bn_train_bwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");
@@ -690,26 +689,17 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   // mask source: the forward output when given (mandatory if a residual was added before the ReLU), else y and the coefficients
   const int mode = !relu ? 0 : (out ? 1 : 2);
   const float* o = out ? out : y;
+  unsigned* zero = reinterpret_cast<unsigned*>(amax);  // (the maximum's buffer is zeroed by the statistics pass)
   if (mode == 0)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<0>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, zero);
   else if (mode == 1)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, zero);
   else
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<2>, dim3(nsplit, C, groups), dim3(NT), 0, st, gout, y, o, save_scale, save_shift, partial, B, C, S, nsplit, zero);
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
   const double count = (double)(B / groups) * (double)S;
-  float* amax = g_next_gy_absmax;  // (mode_bn_next_gy_absmax: one-shot)
-  g_next_gy_absmax = nullptr;
-  if (amax) {
-    int frc = mode::fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, who);
-    if (frc != MODE_OK) return frc;
-  }
-  auto fold = [&](int arc) {
-    if (arc != MODE_OK || !amax) return arc;
-    hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
-    return mode::check_launch(who);
-  };
+  auto fold = [&](int arc) { return (arc != MODE_OK || !amax) ? arc : mode::absmax_fold(amax, st, who); };
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
   (amax ? launch_apply(bn_bwd_apply_kernel<M, G, true>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,    \
                        save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \

@@ -13,4 +13,38 @@ int bn_train_coefficients(const float* y, const float* gamma, const float* beta,
                           float* save_scale, float* save_shift, float* workspace, int B, int C, long long S, hipStream_t st,
                           const char* who);
 
+// ---- a pass that also leaves the largest finite magnitude it writes (mode_bn_next_out_absmax / mode_bn_next_gy_absmax) --------------
+// `amax` points at MODE_BN_ABSMAX_FLOATS words, all zero when the pass starts: word 0 is the result, the ABSMAX_SLOTS words at
+// 16 * (1 + s) collect it.  One address for the whole launch does not work: tens of thousands of waves end within microseconds of each
+// other, and their requests to ONE word -- the atomics, and just as much the loads that guard them -- queue up behind each other at the
+// memory side (device scope: not served by the per-XCD L2s): an atomic per wave was 3 x a BatchNorm pass's time, a guarded one still
+// +60 % on the 403 MB layers.  So: one request per BLOCK (its waves meet in LDS), spread over 128 words of 128 different cache lines,
+// and a one-block kernel behind the pass (absmax_fold) that folds them into word 0.
+constexpr int ABSMAX_SLOTS = 128;
+static_assert(MODE_BN_ABSMAX_FLOATS == 16 * (1 + ABSMAX_SLOTS), "include/mode_hip.h and bn_internal.h disagree about the maximum's buffer");
+
+// bit pattern of |f| when f is finite, else 0 (the scale of an fp16 consumer fits the finite data; NaN / Inf stay where they are)
+__device__ __forceinline__ unsigned absmax_mag(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f) & 0x7fffffffu;
+  return u < 0x7f800000u ? u : 0u;
+}
+// every thread of the block calls this once, behind its last store; sh: blockDim.x / 64 words of LDS nobody reads any more
+__device__ __forceinline__ void absmax_block_commit(unsigned mx, unsigned* amax, unsigned* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = max(mx, sh[w]);
+    unsigned* slot = amax + 16 * (1 + (int)((blockIdx.y * gridDim.x + blockIdx.x) % ABSMAX_SLOTS));
+    // (the value only grows: a block whose maximum is not above what is already there has nothing to add; a stale read costs one spare atomic)
+    if (mx > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mx);
+  }
+}
+// the one-shot pointer of mode_bn_next_gy_absmax (null when none was left); clears it
+float* take_next_gy_absmax();
+// zero the buffer in front of the pass / fold the slots into word 0 behind it
+int absmax_begin(float* amax, hipStream_t st, const char* who);
+int absmax_fold(float* amax, hipStream_t st, const char* who);
+
 }  // namespace mode

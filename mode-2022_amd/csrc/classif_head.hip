@@ -597,12 +597,13 @@ __global__ __launch_bounds__(NT) void classif_bwd_apply_kernel(const float* __re
 // columns and the N index of its four accumulators is interleaved, accumulator r = positions 4 j + r: a lane then holds FOUR CONSECUTIVE
 // voxels of each of its 16 channels, i.e. one 16-byte load of y and one 16-byte store of dL/dy per channel (64 + 64 dword accesses in the
 // kernel above), a wave instruction covers 2 channels x 512 contiguous bytes, and all 16 loads of a lane are requested before the MFMAs.
-template <int TC>
+// AMAX: also leaves the largest finite |dL/dy| it writes (bn_internal.h): the scale of the fp16 convolution gradients that read it.
+template <int TC, bool AMAX = false>
 __global__ __launch_bounds__(NT) void classif_bwd_apply2_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                                 const float* __restrict__ y, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float4* __restrict__ coef,
                                                                 float* __restrict__ gx, int B, int Ci, int D, int H, int W, int nHt,
-                                                                int nWt) {
+                                                                int nWt, unsigned* __restrict__ amax) {
   constexpr int WR = 128 / TC, TRW = 4 * WR, GWD = TC + 2, GHT = TRW + 2, GPL2 = GHT * GWD;
   __shared__ float tile[3 * GPL2];
   __shared__ __attribute__((aligned(16))) float ctab[32 * 8];  // per channel: sc, sh, A, Bc | Cc
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(NT) void classif_bwd_apply2_kernel(const float* __r
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
+  unsigned mx = 0;
   f32x16 acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = (f32x16){0};
@@ -702,7 +704,14 @@ __global__ __launch_bounds__(NT) void classif_bwd_apply2_kernel(const float* __r
       asm volatile("" : "+v"(res));
       o[r] = res;
     }
-    if (vok && i < Ci) *reinterpret_cast<float4*>(gxb + (unsigned)i * (unsigned)DHW + sp) = make_float4(o[0], o[1], o[2], o[3]);
+    if (vok && i < Ci) {
+      *reinterpret_cast<float4*>(gxb + (unsigned)i * (unsigned)DHW + sp) = make_float4(o[0], o[1], o[2], o[3]);
+      if (AMAX) mx = max(max(mx, mode::absmax_mag(o[0])), max(max(mode::absmax_mag(o[1]), mode::absmax_mag(o[2])), mode::absmax_mag(o[3])));
+    }
+  }
+  if (AMAX) {
+    __syncthreads();  // (the tile is read for the last time by the MFMAs above)
+    mode::absmax_block_commit(mx, amax, reinterpret_cast<unsigned*>(tile));
   }
 }
 
@@ -773,6 +782,7 @@ extern "C" int mode_classif_train_bwd(const float* gcost, const float* y, const 
                                       float* gy, float* gw, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
                                       int D, int H, int W, mode_stream_t stream) {
   const char* who = "mode_classif_train_bwd";
+  float* amax = mode::take_next_gy_absmax();  // (mode_bn_next_gy_absmax: this IS a BatchNorm backward; one-shot, whatever this call returns)
   int rc = check_classif(who, B, C, D, H, W);
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(gcost && y && w && gamma && beta && save_mean && save_invstd && save_scale && save_shift && gy && gw && ggamma && gbeta && workspace,
@@ -781,6 +791,10 @@ extern "C" int mode_classif_train_bwd(const float* gcost, const float* y, const 
   hipStream_t st = mode::as_stream(stream);
   // rows that are multiples of 16 bytes (and 16-byte aligned tensors): the kernels built on 16-byte accesses; anything else: the dword forms
   const bool fast = W % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+  if (amax && fast) {
+    rc = mode::absmax_begin(amax, st, who);
+    if (rc != MODE_OK) return rc;
+  }
   const int nHt = mode::cdiv(H, GTH), nWt = mode::cdiv(W, 32);
   const int T = fast ? classif_tiles(B, D, H, W) : B * D * nHt * nWt;
   const int S = classif_splits(T, fast ? 3 : 4);  // (classif_bww2_kernel: 144 registers, three workgroups per CU)
@@ -808,16 +822,29 @@ extern "C" int mode_classif_train_bwd(const float* gcost, const float* y, const 
     const int TC = tile_cols(W), TRW = 4 * (128 / TC);
     const int nHa = mode::cdiv(H, TRW), nWa = mode::cdiv(W, TC);
     const dim3 grid(B * D * nHa * nWa);
-    if (TC == 128)
-      hipLaunchKernelGGL(classif_bwd_apply2_kernel<128>, grid, dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D, H, W, nHa, nWa);
-    else if (TC == 64)
-      hipLaunchKernelGGL(classif_bwd_apply2_kernel<64>, grid, dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D, H, W, nHa, nWa);
-    else
-      hipLaunchKernelGGL(classif_bwd_apply2_kernel<32>, grid, dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D, H, W, nHa, nWa);
-    return mode::check_launch(who);
+    unsigned* am = reinterpret_cast<unsigned*>(amax);
+#define MODE_CLASSIF_APPLY2(TCV)                                                                                                          \
+  if (amax)                                                                                                                                \
+    hipLaunchKernelGGL((classif_bwd_apply2_kernel<TCV, true>), grid, dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D, H, \
+                       W, nHa, nWa, am);                                                                                                   \
+  else                                                                                                                                     \
+    hipLaunchKernelGGL((classif_bwd_apply2_kernel<TCV, false>), grid, dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D, H, \
+                       W, nHa, nWa, am);
+    if (TC == 128) {
+      MODE_CLASSIF_APPLY2(128)
+    } else if (TC == 64) {
+      MODE_CLASSIF_APPLY2(64)
+    } else {
+      MODE_CLASSIF_APPLY2(32)
+    }
+#undef MODE_CLASSIF_APPLY2
+    rc = mode::check_launch(who);
+    return (rc != MODE_OK || !amax) ? rc : mode::absmax_fold(amax, st, who);
   }
   const int nDt = mode::cdiv(D, BTD), nHt2 = mode::cdiv(H, BTH);
   hipLaunchKernelGGL(classif_bwd_apply_kernel, dim3(B * nDt * nHt2 * nWt), dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D,
                      H, W, nDt, nHt2, nWt);
-  return mode::check_launch(who);
+  rc = mode::check_launch(who);
+  // (rows that are not multiples of 16 bytes: the maximum that was asked for comes from a pass of its own)
+  return (rc != MODE_OK || !amax) ? rc : mode::abs_max(gy, (long long)B * C * D * H * W, amax, st, who);
 }

@@ -584,8 +584,15 @@ __global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ 
     m = max(m, finite_mag(__builtin_bit_cast(unsigned, x[i])));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  // (one address for thousands of waves: only a wave whose maximum is above what is already there adds anything -- bn_act.hip)
-  if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+  // (one address for the whole launch: one request per block, and only from a block whose maximum is above what is already there --
+  // bn_internal.h has the measurements, and the slotted form the passes over the large tensors use)
+  __shared__ unsigned sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(m, sh[1]), max(sh[2], sh[3]));
+    if (m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+  }
 }
 
 }  // namespace

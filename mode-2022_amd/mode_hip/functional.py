@@ -1840,9 +1840,16 @@ class ClassifHeadFunction(torch.autograd.Function):
     with torch.cuda.device_of(y), profiling.region(_tag3('classif_bwd', C, 1, 1, D, H, W), 4 * (3 * y.numel() + 4 * gcost.numel()),
                                                    2 * 3 * gcost.numel() * C * 27, y.device):
       ws = torch.empty(max(lib().mode_classif_workspace_bytes(B, C, D, H, W) // 4, 1), dtype=torch.float32, device=y.device)
+      gy_amax = None
+      if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6':  # the 32 -> 32 convolution in front reads gy in both of its gradients (BnActFunction.backward)
+        buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
+        gy_amax = buf[:1]
+        lib().mode_bn_next_gy_absmax(ptr(buf))
       check(lib().mode_classif_train_bwd(ptr(gcost), ptr(y), ptr(w), ptr(gamma), ptr(beta), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
                                          ptr(saved[3]), ptr(gy), ptr(gw), ptr(ggamma), ptr(gbeta), int(fused), ptr(ws), B, C, D, H, W,
                                          stream_of(y)), 'mode_classif_train_bwd')
+      if gy_amax is not None:
+        gy._mode_amax = (gy_amax, gy._version, gy.data_ptr())
     if fused:
       gw = ggamma = gbeta = None
     return gy, gw, ggamma, gbeta, (gcost if ctx.has_add else None), None, None, None, None, None

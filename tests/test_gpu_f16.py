@@ -149,3 +149,23 @@ def test_maxima_come_from_the_batchnorm_passes_in_a_conv_bn_chain(f16_switch, mo
   out.square().mean().backward()
   print('maximum passes over gradient tensors in the backward: %d (2 without the BatchNorm backward\'s)' % len(big))
   assert len(big) <= 1, big  # the last BatchNorm's gy is tagged; at most the loss gradient path is not
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 6, 32, 64), (1, 32, 5, 11, 37), (2, 32, 3, 40, 132)])
+def test_classifier_backward_leaves_its_gradients_maximum(f16_switch, shape):
+  """The fused classifier head's backward (mode_classif_train_bwd) writes the gradient the 32 -> 32 convolution in front reads twice: its
+  maximum comes out of that pass (16-byte rows: tracked in the kernel, one request per block into 128 slots, folded; other rows: a pass
+  of its own) -- exactly mode_abs_max of the gradient, three times in a row (the slots are zeroed by every call)."""
+  HF.CONV3D_S1_F16 = True
+  B, C, D, H, W = shape
+  bn = torch.nn.BatchNorm3d(C).to(DEV).train()
+  conv = torch.nn.Conv3d(C, 1, 3, padding=1, bias=False).to(DEV)
+  for rep in range(3):
+    y = (_rand(shape, 811 + rep) * 1.3 + 0.2).requires_grad_(True)
+    seen = []
+    y.register_hook(lambda g: seen.append((HF.known_abs_max(g), g.detach().clone())))
+    assert HF.classif_fused_supported(y, bn, conv)
+    cost = HF.classif_head_train(y, bn, conv, None)
+    cost.backward(_rand(cost.shape, 821 + rep, 10.0**(rep - 1)))
+    (am, g), = seen
+    assert am is not None and float(am) == float(g.abs().max()) == float(HF.abs_max(g)), (shape, rep)
