@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 27 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 28 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -179,6 +179,14 @@ int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w
 int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack,
                                 const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh,
                                 int Kw, int groups, int transposed, mode_stream_t stream);
+
+/* The plain (no epilogue) call of a TRAINING step with the small-window tiles on the two-piece fp16 arithmetic of the stride-1 3-D layers
+ * (two fp16 pieces per value, three MFMAs per product, a power-of-two scale per operand): amax_x / amax_w = device scalars
+ * holding the largest finite magnitude of x and of w (mode_abs_max, or mode_bn_next_out_absmax of the pass that wrote x).  The
+ * tall-window tiles next to the poles keep three bf16 pieces.  Ci / groups % 16 != 0: the call above with bn = NULL. */
+int mode_sphere_conv_fwd_win_split_f16(const float* x, const float* pos, const float* w, const float* amax_x, const float* amax_w, float* y,
+                                       float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W,
+                                       int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream);
 
 /* `transposed` != 0: x and y are stored plane-transposed, (B, C, W, H) contiguous, i.e. with the h axis contiguous
  * (mode_transpose_planes converts).  For the Cassini tables of the network h is the shift-invariant longitude axis, and in
@@ -392,12 +400,12 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
 /* EXPERIMENTAL arithmetic of the stride-1 3x3x3 layers (nn.Conv3d of convbn_3d, models/submodule.py:20-22; functional.CONV_ARITH =
  * 'f16x3', off by default): fp32 operands split into TWO fp16 pieces, three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones
  * (2^-22 per product; 30-35 % faster).  fp16's range is narrow, so each operand is scaled by a power of two that brings its tensor's
- * largest magnitude to [2^14, 2^15): amax_* = DEVICE floats, one per operand, filled by mode_abs_max (an order-independent maximum
- * over bit patterns; no host synchronisation, graph-capturable; a tensor's maximum can be computed once and passed to every call that
- * reads the tensor).  Elements more than ~2^17 below their tensor's maximum lose relative precision -- DESIGN.md section 6.
+ * largest magnitude to [2^14, 2^15): amax_* = DEVICE buffers of MODE_BN_ABSMAX_FLOATS floats, one per operand (layout: see
+ * mode_bn_next_out_absmax below), filled by mode_abs_max (an order-independent maximum over bit patterns; no host synchronisation,
+ * graph-capturable; a tensor's maximum can be computed once and passed to every call that reads the tensor).  Elements more than ~2^17 below their tensor's maximum lose relative precision -- DESIGN.md section 6.
  * mode_conv3d_bwd_data_split_f16: acc may be NULL.  mode_conv3d_bwd_weight_split_f16: other arguments and workspace as
  * mode_conv3d_bwd_weight_split. */
-int mode_abs_max(const float* x, long long n, float* out_device_scalar, mode_stream_t stream);
+int mode_abs_max(const float* x, long long n, float* out_device_buffer, mode_stream_t stream);
 int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B, int Ci,
                               int D, int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
@@ -522,11 +530,12 @@ int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, cons
                       float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
                       float* workspace, int B, int C, long long S, int groups, mode_stream_t stream);
 
-/* The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of the calling thread also leaves the largest finite |out| in
- * device_scalar[0] (same convention as mode_abs_max): the operand maximum of an fp16-arithmetic consumer (mode_conv3d_fwd_split_f16)
- * comes out of the pass that writes the tensor.  `device_scalar` points at MODE_BN_ABSMAX_FLOATS floats: word 0 is the result, the
- * rest is the pass's scratch (its blocks collect the maximum in 128 words of different cache lines, a one-block kernel folds them);
- * the call zeroes all of it.  One-shot. */
+/* A tensor's largest finite magnitude, as the fp16-arithmetic entries (mode_conv3d_*_split_f16, mode_sphere_conv_fwd_win_split_f16) take
+ * it: a device buffer of MODE_BN_ABSMAX_FLOATS floats whose MAXIMUM is the value -- word 0 and 128 words of 128 different cache lines,
+ * everything else zero (the blocks of the producing pass each add to one of them: one word for a whole launch serialises at the memory
+ * side; the consumers' waves read all 129).  mode_abs_max fills such a buffer with a pass over the tensor; the two calls below make the
+ * NEXT BatchNorm call of the calling thread fill one on the way: the operand maximum comes out of the pass that writes the tensor.
+ * Either zeroes the whole buffer first.  One-shot. */
 #define MODE_BN_ABSMAX_FLOATS 2064
 void mode_bn_next_out_absmax(float* device_scalar);
 /* The same for the NEXT mode_bn_train_bwd or mode_classif_train_bwd call and the gradient `gy` it writes (read by both gradients of the

@@ -156,20 +156,6 @@ struct BnCoefArgs {
   unsigned* amax;      // optional: atomicMax of the bit patterns of the finite |out| values (the scale source of the fp16 convolutions)
 };
 
-__global__ __launch_bounds__(mode::ABSMAX_SLOTS) void amax_fold_kernel(unsigned* __restrict__ amax) {
-  __shared__ unsigned sh[mode::ABSMAX_SLOTS / 64];
-  unsigned mx = amax[16 * (1 + threadIdx.x)];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < mode::ABSMAX_SLOTS / 64; ++w) mx = max(mx, sh[w]);
-    amax[0] = mx;
-  }
-}
-
 // grid = (chunks, B*C): out = y*scale[c] + shift[c] (+ add) (relu)
 // AMAX: also leaves the largest finite |out| in *k.amax (its own instantiation: the untracked passes keep their registers and occupancy)
 template <bool RELU, bool ADD, bool TRAIN, bool AMAX = false>
@@ -500,10 +486,6 @@ int launch_apply(K kernel, int BC, long long S, hipStream_t st, const char* who,
 
 namespace mode {
 int absmax_begin(float* amax, hipStream_t st, const char* who) { return fill_words(amax, 0u, MODE_BN_ABSMAX_FLOATS, st, who); }
-int absmax_fold(float* amax, hipStream_t st, const char* who) {
-  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(ABSMAX_SLOTS), 0, st, reinterpret_cast<unsigned*>(amax));
-  return check_launch(who);
-}
 }  // namespace mode
 
 // workspace (floats): per-block partial sums, up to 1024 pairs per (group, channel); C = channels x groups
@@ -587,8 +569,7 @@ static int bn_train_fwd_impl(const float* y, const float* add, const float* gamm
     else
       rc = add ? launch_apply(bn_apply_kernel<false, true, true, true>, BC, S, st, who, y, add, k, out, C, S)
                : launch_apply(bn_apply_kernel<false, false, true, true>, BC, S, st, who, y, y, k, out, C, S);
-    if (rc != MODE_OK) return rc;
-    return mode::absmax_fold(amax, st, who);
+    return rc;
   }
   if (relu) {
     if (add) return launch_apply(bn_apply_kernel<true, true, true>, BC, S, st, who, y, add, k, out, C, S);
@@ -699,7 +680,6 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
   const int BC = B * C;
   const char* who = "mode_bn_train_bwd";
   const double count = (double)(B / groups) * (double)S;
-  auto fold = [&](int arc) { return (arc != MODE_OK || !amax) ? arc : mode::absmax_fold(amax, st, who); };
 #define MODE_BN_BWD_APPLY(M, G)                                                                                                         \
   (amax ? launch_apply(bn_bwd_apply_kernel<M, G, true>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,    \
                        save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
@@ -707,9 +687,9 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
         : launch_apply(bn_bwd_apply_kernel<M, G, false>, BC, S, st, who, gout, y, o, save_scale, save_shift, partial, gamma, save_mean,   \
                        save_invstd, ggamma, gbeta, accumulate, nsplit, count, groups, B / groups, gy, (G) ? gadd : gy, C, S,            \
                        (unsigned*)nullptr))
-  if (mode == 0) return fold(gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false));
-  if (mode == 1) return fold(gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false));
-  return fold(gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false));
+  if (mode == 0) return gadd ? MODE_BN_BWD_APPLY(0, true) : MODE_BN_BWD_APPLY(0, false);
+  if (mode == 1) return gadd ? MODE_BN_BWD_APPLY(1, true) : MODE_BN_BWD_APPLY(1, false);
+  return gadd ? MODE_BN_BWD_APPLY(2, true) : MODE_BN_BWD_APPLY(2, false);
 #undef MODE_BN_BWD_APPLY
 }
 

@@ -13,13 +13,15 @@ int bn_train_coefficients(const float* y, const float* gamma, const float* beta,
                           float* save_scale, float* save_shift, float* workspace, int B, int C, long long S, hipStream_t st,
                           const char* who);
 
-// ---- a pass that also leaves the largest finite magnitude it writes (mode_bn_next_out_absmax / mode_bn_next_gy_absmax) --------------
-// `amax` points at MODE_BN_ABSMAX_FLOATS words, all zero when the pass starts: word 0 is the result, the ABSMAX_SLOTS words at
-// 16 * (1 + s) collect it.  One address for the whole launch does not work: tens of thousands of waves end within microseconds of each
-// other, and their requests to ONE word -- the atomics, and just as much the loads that guard them -- queue up behind each other at the
-// memory side (device scope: not served by the per-XCD L2s): an atomic per wave was 3 x a BatchNorm pass's time, a guarded one still
-// +60 % on the 403 MB layers.  So: one request per BLOCK (its waves meet in LDS), spread over 128 words of 128 different cache lines,
-// and a one-block kernel behind the pass (absmax_fold) that folds them into word 0.
+// ---- the largest finite magnitude of a tensor, as its fp16-arithmetic consumers read it (mode_abs_max, mode_bn_next_out_absmax,
+// mode_bn_next_gy_absmax) ---------------------------------------------------------------------------------------------------------------
+// `amax` points at MODE_BN_ABSMAX_FLOATS words, all zero when the producing pass starts; the value is the maximum over word 0 and the
+// ABSMAX_SLOTS words at 16 * (1 + s) (bit patterns of non-negative floats: an unsigned maximum).  One address for the whole launch does
+// not work: tens of thousands of waves end within microseconds of each other, and their requests to ONE word -- the atomics, and just as
+// much the loads that guard them -- queue up behind each other at the memory side (device scope: not served by the per-XCD L2s): an atomic
+// per wave was 3 x a BatchNorm pass's time, a guarded one still +60 % on the 403 MB layers.  So: one request per BLOCK (its waves meet
+// in LDS), spread over 128 words of 128 different cache lines.  Nobody folds them: a kernel of its own behind every pass was 5 us x 100
+// per step; every wave of a consumer reads the 129 words itself (two loads per lane and a wave reduction, once per kernel).
 constexpr int ABSMAX_SLOTS = 128;
 static_assert(MODE_BN_ABSMAX_FLOATS == 16 * (1 + ABSMAX_SLOTS), "include/mode_hip.h and bn_internal.h disagree about the maximum's buffer");
 
@@ -41,10 +43,18 @@ __device__ __forceinline__ void absmax_block_commit(unsigned mx, unsigned* amax,
     if (mx > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mx);
   }
 }
+// what a consumer does with the pointer: every lane of a FULL wave calls it (kernel prologue) and gets the maximum
+__device__ __forceinline__ float absmax_load(const float* amax) {
+  const unsigned* u = reinterpret_cast<const unsigned*>(amax);
+  const int lane = threadIdx.x & 63;
+  unsigned mx = max(max(u[16 * (1 + lane)], u[16 * (1 + lane + 64)]), u[0]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+  return __builtin_bit_cast(float, mx);
+}
 // the one-shot pointer of mode_bn_next_gy_absmax (null when none was left); clears it
 float* take_next_gy_absmax();
-// zero the buffer in front of the pass / fold the slots into word 0 behind it
+// zero the buffer in front of the pass (where no kernel of the pass does it on the way)
 int absmax_begin(float* amax, hipStream_t st, const char* who);
-int absmax_fold(float* amax, hipStream_t st, const char* who);
 
 }  // namespace mode

@@ -838,8 +838,7 @@ extern "C" int mode_classif_train_bwd(const float* gcost, const float* y, const 
       MODE_CLASSIF_APPLY2(32)
     }
 #undef MODE_CLASSIF_APPLY2
-    rc = mode::check_launch(who);
-    return (rc != MODE_OK || !amax) ? rc : mode::absmax_fold(amax, st, who);
+    return mode::check_launch(who);
   }
   const int nDt = mode::cdiv(D, BTD), nHt2 = mode::cdiv(H, BTH);
   hipLaunchKernelGGL(classif_bwd_apply_kernel, dim3(B * nDt * nHt2 * nWt), dim3(NT), 0, st, gcost, w, y, save_scale, save_shift, coef, gy, B, C, D,

@@ -28,6 +28,7 @@
 // Weights are split and packed once per launch ([m][chunk][pair][piece][lane] uint4, L2-resident).
 #include "common.h"
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -116,7 +117,7 @@ template <bool F16>
 __global__ void pack_w3d_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip,
                                int fold, mode_bn_epilogue bn, const float* __restrict__ amax_w) {
   constexpr int NP = Arith<F16>::NP;
-  const float sw = F16 ? f16_scale_of(amax_w[0]) : 1.f;
+  const float sw = F16 ? f16_scale_of(mode::absmax_load(amax_w)) : 1.f;
   const long long total = (long long)MT * NCHUNK * NPAIR * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * NP);
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
                                                           const float* __restrict__ amax_w) {
   constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16>();
   // (F16) x is multiplied by sx when it is staged, the weights by sw when they are packed, the sums by 1 / (sx sw) when they are stored
-  const float sx = F16 ? f16_scale_of(amax_x[0]) : 1.f;
-  const float unscale = F16 ? (1.f / sx) * (1.f / f16_scale_of(amax_w[0])) : 1.f;
+  const float sx = F16 ? f16_scale_of(mode::absmax_load(amax_x)) : 1.f;
+  const float unscale = F16 ? (1.f / sx) * (1.f / f16_scale_of(mode::absmax_load(amax_w))) : 1.f;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3][ITEMS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // grid.y = the 32 * MT-channel output blocks of the layer: every y-slice is the persistent grid described above on ITS block (a
@@ -584,15 +585,9 @@ __global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ 
     m = max(m, finite_mag(__builtin_bit_cast(unsigned, x[i])));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  // (one address for the whole launch: one request per block, and only from a block whose maximum is above what is already there --
-  // bn_internal.h has the measurements, and the slotted form the passes over the large tensors use)
+  // (one request per block, into one of 128 words of different cache lines: bn_internal.h has the layout and the measurements)
   __shared__ unsigned sh[4];
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(m, sh[1]), max(sh[2], sh[3]));
-    if (m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
-  }
+  mode::absmax_block_commit(m, out, sh);
 }
 
 }  // namespace
@@ -602,7 +597,7 @@ namespace mode {
 int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who) {
   MODE_REQUIRE(n >= 0 && out && (n == 0 || x), MODE_ERR_BAD_ARG, "%s: bad argument", who);
   MODE_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, MODE_ERR_BAD_ARG, "%s: the tensor must be 16-byte aligned", who);
-  int rc = mode::fill_words(out, 0u, 1, st, who);
+  int rc = mode::fill_words(out, 0u, MODE_BN_ABSMAX_FLOATS, st, who);
   if (rc != MODE_OK || n == 0) return rc;
   const int blocks = (int)std::min<long long>(cdiv(n, 256 * 16), 16 * kNumCU);
   hipLaunchKernelGGL(abs_max_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out));

@@ -21,6 +21,7 @@
 //     depth, one wave per SIMD.
 #include "common.h"
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
                                                               const float* __restrict__ amax_g, const float* __restrict__ amax_x) {
   constexpr int NP = F16 ? 2 : 3;  // pieces (the LDS layout keeps room for three)
   // (F16) amax_g / amax_x = max |gy| / max |x|: both operands scaled when staged, the sums scaled back when written
-  const float sg = F16 ? f16_scale_of(amax_g[0]) : 1.f, sx = F16 ? f16_scale_of(amax_x[0]) : 1.f;
+  const float sg = F16 ? f16_scale_of(mode::absmax_load(amax_g)) : 1.f, sx = F16 ? f16_scale_of(mode::absmax_load(amax_x)) : 1.f;
   const float unscale = F16 ? (1.f / sg) * (1.f / sx) : 1.f;
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   uint16_t* xl = lds;          // [32 c][3 pieces][4 planes][4 rows][40]

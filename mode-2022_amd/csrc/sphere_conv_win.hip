@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "bn_internal.h"
 #include "sphere_internal.h"
 #include "sphere_tap.h"
 
@@ -822,9 +823,36 @@ __device__ __forceinline__ f32x16 sp_mfma(uint4 a, uint4 b, f32x16 c) {
 }
 __device__ __forceinline__ void sp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- the two-piece fp16 arithmetic of conv3d_split.hip for the small-window tiles of the TRAINING forward: two fp16 pieces
+// per value (v_cvt_pk_f16_f32, round to nearest even; the remainder is exact in fp32), three v_mfma_f32_32x32x16_f16 per product
+// (lo x hi, hi x hi, hi x lo).  Both operands are multiplied by a power of two that brings their tensor's largest finite magnitude (a
+// device scalar from the caller) to [2^14, 2^15); the sampled operand gets it through its four bilinear weights, once per tile.
+typedef _Float16 sp_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float sp_f16_scale_of(float m) {  // as in conv3d_split.hip: m * scale in [2^14, 2^15)
+  const unsigned e = min(max((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu, 64u), 254u);
+  return m == 0.f ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ void sp_split2_f16(float a, float b, uint32_t& p1, uint32_t& p2) {
+  const sp_f32x2 v = {a, b};
+  const sp_f16x2 h1 = __builtin_convertvector(v, sp_f16x2);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+  float ra = a - (float)h1[0], rb = b - (float)h1[1];
+  asm("" : "+v"(ra), "+v"(rb));  // (scalar subtractions: see sp_split2)
+  const sp_f32x2 r = {ra, rb};
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, sp_f16x2));
+}
+__device__ __forceinline__ f32x16 sp_mfma_f16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sp_f16x8, a), __builtin_bit_cast(sp_f16x8, b), c, 0, 0, 0);
+}
+
 // wps[(((((g*MG + mg)*NCH16 + ch)*KT + tap)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[g*Cog + mg*128 + m*32 + (lane&31)]
 // [ch*16 + 8*(lane>>5) + j][tap], j = 0..7 (scaled by the folded BatchNorm scale when fold != 0; the shifts are the ones pack_w_win wrote)
-__global__ void pack_w_win_split(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16, int fold, mode_bn_epilogue bn) {
+// F16: two fp16 pieces of w * (the weight tensor's power-of-two scale, from amax_w[0]) in the places of pieces 0 and 1 (no fold)
+template <bool F16>
+__global__ void pack_w_win_split(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16, int fold, mode_bn_epilogue bn,
+                                 const float* __restrict__ amax_w) {
+  const float sw = F16 ? sp_f16_scale_of(mode::absmax_load(amax_w)) : 1.f;
   const long long total = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -846,11 +874,19 @@ __global__ void pack_w_win_split(const float* __restrict__ w, uint4* __restrict_
       if (co < d.Cog && c < d.Cig) {
         v[j] = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
         if (fold) v[j] *= fold_scale(bn, g * d.Cog + co);
+        if (F16) v[j] *= sw;
       }
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (F16) {
+        sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+        q3[j] = 0u;
+      } else {
+        sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      }
+    }
     uint4* dst = wps + (idx - lane) * 3 + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -1265,11 +1301,16 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   MODE_STAMP(3)
 }
 
-template <bool EPI>
+// F16 (training forward, no epilogue): the small-window tiles on two fp16 pieces and three MFMAs per product -- a tap is 12 slots
+// instead of 24, and the split of a sampled value 3 instructions instead of 5.5; the tall-window tiles keep the three bf16 pieces
+// (their fragments `wpt` are packed unscaled).
+template <bool EPI, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                     const uint4* __restrict__ wps, const uint4* __restrict__ wpt,
                                                                     float* __restrict__ y, WinDims d, int NCH16,
-                                                                    const int4* __restrict__ tiles, Epi epi) {
+                                                                    const int4* __restrict__ tiles, Epi epi,
+                                                                    const float* __restrict__ amax_x, const float* __restrict__ amax_w) {
+  static_assert(!(EPI && F16), "the fp16 arithmetic has no folded-BatchNorm epilogue");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WRP = WR_SMALL, CP = SP_CP;
   uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [3][8 pixel groups][3 pieces][64 lanes]
@@ -1293,6 +1334,11 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   const int h = h0 + (wave / TW) * 32 + (lane & 31), w = w0 + (wave % TW);  // the pixel this lane SAMPLES
   const bool pix_ok = h < d.H && w < d.W;
   const long long HW = (long long)d.H * d.W;
+  float sx = 1.f, unscale = 1.f;
+  if (F16) {
+    sx = sp_f16_scale_of(mode::absmax_load(amax_x));
+    unscale = (1.f / sx) * (1.f / sp_f16_scale_of(mode::absmax_load(amax_w)));
+  }
 
   int roff[KT];
   float4 rw[KT];
@@ -1380,12 +1426,17 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       asm("" : "+v"(v[c]));  // (opaque, not volatile -- a volatile asm pins the schedule: keeps the chains of two channels from being packed pairwise -- 24 v_mov + 24 v_pk_*)
     }
     uint32_t q1[4], q2[4], q3[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
     uint4* dst = op + (wave * 3) * 64 + lane;
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    }
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
   };
   auto sample = [&](const float* win, int k, uint4* op) {
     float raw[8][4];
@@ -1402,9 +1453,10 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   const int m = wave % TW, gset = (wave / TW) * 4;  // output tile and first pixel group of the MATRIX role
   const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;  // uniform; + p * 64 + lane per fragment
   const int nsteps = NCH16 * KT;
+  constexpr int NPC = F16 ? 2 : 3;  // pieces per value
   uint4 acur[3], anxt[3];  // weight fragments of this tap and of the next one (requested at the top of a tap, one tap ahead)
 #pragma unroll
-  for (int p = 0; p < 3; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
+  for (int p = 0; p < NPC; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
 
   // prologue: window of chunk 0, operand of tap 0
 #pragma unroll
@@ -1421,7 +1473,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
     const int lc = c0 - cbase;
     const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
     roff[k] = (dead || !pix_ok) ? 0 : lc * WRP + lr;
-    rw[k] = wt;
+    // (F16: the operand's power-of-two scale rides on the four weights -- sx * (sum of w_i x_i) bit for bit, no instruction per sample)
+    rw[k] = F16 ? make_float4(wt.x * sx, wt.y * sx, wt.z * sx, wt.w * sx) : wt;
   }
   MODE_STAMP(5)
 #pragma unroll
@@ -1458,6 +1511,89 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   }
   MODE_STAMP(1)
 #define MODE_SB __builtin_amdgcn_sched_barrier(0);
+  if constexpr (F16) {
+    // ---- 12 slots: lo x hi (piece 1 of the weights against piece 0 of the operand), hi x hi, hi x lo.  The second half batch of window
+    // words has registers of its own (the third piece's are free) and is requested at the top of the tap; the next tap's first half batch
+    // and its piece-0 fragments in slot 8, when the combines have consumed this tap's.
+#define MODE_MFH(PA, B, gi) acc[gi] = sp_mfma_f16(acur[PA], B[gi], acc[gi]); asm volatile("" :: "v"(acc[gi]));
+    float raw2[4][4];
+    for (int ch = 0; ch < NCH16; ++ch) {
+      float* cur = smem + (ch & 1) * SP_WIN;
+      float* nxt = smem + ((ch + 1) & 1) * SP_WIN;
+      const int chn = ch + 1 < NCH16 ? ch + 1 : ch;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int step = ch * KT + k;
+        const int nstep = step + 1 < nsteps ? step + 1 : nsteps - 1;
+        const int ks = (k + 2) % KT;
+        const float* wsrc = k + 2 < KT ? cur : nxt;
+        const uint4* fcur = fragbase + (k % 3) * SP_OP;
+        const uint4* fnxt = fragbase + ((k + 1) % 3) * SP_OP;
+        uint4* opw = opbuf + ((k + 2) % 3) * SP_OP + (wave * 3) * 64 + lane;
+        const float4 tw = rw[ks];
+        const float* wp_ = wsrc + half * 8 * CP + roff[ks];
+        const float* wpn_ = (k + 3 < KT ? cur : nxt) + half * 8 * CP + roff[(k + 3) % KT];
+        auto combine = [&](int c, float (&rr)[4][4]) {  // (one fma chain per value, kept scalar: see sp_split2)
+          v[c] = __builtin_fmaf(tw.w, rr[c & 3][3], __builtin_fmaf(tw.z, rr[c & 3][2], __builtin_fmaf(tw.y, rr[c & 3][1], tw.x * rr[c & 3][0])));
+          asm("" : "+v"(v[c]));
+        };
+        auto hsplit = [&](int j) { sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]); };
+#pragma unroll
+        for (int p = 0; p < 2; ++p) anxt[p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float* q = wp_ + (4 + c) * CP;
+          raw2[c][0] = q[0];
+          raw2[c][1] = q[WRP];
+          raw2[c][2] = q[1];
+          raw2[c][3] = q[WRP + 1];
+        }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b1[gi] = fcur[(gi * 3 + 1) * 64];
+        MODE_SB
+        MODE_MFH(0, b0, 0) combine(0, raw); MODE_SB
+        MODE_MFH(0, b0, 1) combine(1, raw); MODE_SB
+        MODE_MFH(0, b0, 2) combine(2, raw); MODE_SB
+        MODE_MFH(0, b0, 3) combine(3, raw); MODE_SB
+        MODE_MFH(1, b0, 0) hsplit(0); MODE_SB
+        MODE_MFH(1, b0, 1) hsplit(1); combine(4, raw2); MODE_SB
+        MODE_MFH(1, b0, 2) combine(5, raw2); combine(6, raw2); MODE_SB
+        MODE_MFH(1, b0, 3) combine(7, raw2); MODE_SB
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b0n[gi] = fnxt[(gi * 3 + 0) * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float* q = wpn_ + c * CP;
+          raw[c][0] = q[0];
+          raw[c][1] = q[WRP];
+          raw[c][2] = q[1];
+          raw[c][3] = q[WRP + 1];
+        }
+        MODE_SB
+        MODE_MFH(0, b1, 0) hsplit(2); MODE_SB
+        MODE_MFH(0, b1, 1) hsplit(3); MODE_SB
+        opw[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        opw[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if (k < 4) {
+          issue(chn, 2 * k, 2 * k);
+          issue(chn, 2 * k + 1, 2 * k + 1);
+        }
+        MODE_SB
+        MODE_MFH(0, b1, 2) MODE_SB
+        if (k >= STAGE_LAG && k < 4 + STAGE_LAG) commit(chn, 2 * (k - STAGE_LAG), 2 * (k - STAGE_LAG), nxt);
+        MODE_SB
+        MODE_MFH(0, b1, 3) MODE_SB
+        if (k >= STAGE_LAG && k < 4 + STAGE_LAG) commit(chn, 2 * (k - STAGE_LAG) + 1, 2 * (k - STAGE_LAG) + 1, nxt);
+        MODE_SB
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acur[p] = anxt[p];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b0[gi] = b0n[gi];
+        sp_lds_barrier();
+      }
+    }
+#undef MODE_MFH
+  } else {
 #define MODE_MF(PA, B, gi) acc[gi] = sp_mfma(acur[PA], B[gi], acc[gi]);
 
   for (int ch = 0; ch < NCH16; ++ch) {
@@ -1567,8 +1703,9 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
       sp_lds_barrier();
     }
   }
-#undef MODE_SB
 #undef MODE_MF
+  }
+#undef MODE_SB
   MODE_STAMP(2)
 
   // D[i = o][j = pixel of group gset + gi]
@@ -1609,7 +1746,7 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
           const float v = (acc[gi][r] + shv[r]) + res[r];
           yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
         } else {
-          yb[(long long)co * HW] = acc[gi][r];
+          yb[(long long)co * HW] = F16 ? acc[gi][r] * unscale : acc[gi][r];
         }
       };
       if (full_m) {
@@ -2257,9 +2394,13 @@ int fwd_win_launch(const float* x, const float* pos, float* y, const float* wpac
 
 static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const float* w, float* y, float* wpack, const int32_t* tiles,
                                     int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
-                                    int transposed, mode_stream_t stream, const mode_bn_epilogue* bn, int split = 0) {
+                                    int transposed, mode_stream_t stream, const mode_bn_epilogue* bn, int split = 0,
+                                    const float* amax_x = nullptr, const float* amax_w = nullptr) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_fwd_win");
+  MODE_REQUIRE((amax_x == nullptr) == (amax_w == nullptr) && !(amax_x && bn), MODE_ERR_BAD_ARG,
+               "mode_sphere_conv_fwd_win: the fp16 arithmetic takes both operand maxima and no BatchNorm epilogue");
+  const bool f16 = amax_x != nullptr;
   if (rc != MODE_OK) return rc;
   if (transposed) {
     d.sh = 1;
@@ -2285,8 +2426,13 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     const int NCH16 = d.Cig / SP_CCH;
     uint4* wps = reinterpret_cast<uint4*>(wpack + ((npack + d.Co + 3) / 4) * 4);
     const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
-    if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
-                       bn ? *bn : mode_bn_epilogue());
+    if (mode::pack_needed()) {
+      if (f16)
+        hipLaunchKernelGGL(pack_w_win_split<true>, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, 0, mode_bn_epilogue(), amax_w);
+      else
+        hipLaunchKernelGGL(pack_w_win_split<false>, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, bn ? 1 : 0,
+                           bn ? *bn : mode_bn_epilogue(), (const float*)nullptr);
+    }
     uint4* wpt = wps + nsplit * 3;  // fragments of the tall-window tiles: K = 8 channels x 2 taps
     if (n_mid + n_wrap > 0) {
       const long long ntall = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
@@ -2311,12 +2457,17 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
       rc = mode::allow_lds(sphere_fwd_split_kernel<true>, lds, "mode_sphere_conv_fwd_win_split");
       if (rc != MODE_OK) return rc;
       hipLaunchKernelGGL(sphere_fwd_split_kernel<true>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wpt, y, d, NCH16, tl,
-                         epi);
+                         epi, amax_x, amax_w);
+    } else if (f16) {
+      rc = mode::allow_lds(sphere_fwd_split_kernel<false, true>, lds, "mode_sphere_conv_fwd_win_split");
+      if (rc != MODE_OK) return rc;
+      hipLaunchKernelGGL((sphere_fwd_split_kernel<false, true>), dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wpt, y, d, NCH16,
+                         tl, epi, amax_x, amax_w);
     } else {
       rc = mode::allow_lds(sphere_fwd_split_kernel<false>, lds, "mode_sphere_conv_fwd_win_split");
       if (rc != MODE_OK) return rc;
       hipLaunchKernelGGL(sphere_fwd_split_kernel<false>, dim3(n_all, B, d.G * d.MG), dim3(NTHREADS), lds, st, x, pos, wps, wpt, y, d, NCH16, tl,
-                         epi);
+                         epi, amax_x, amax_w);
     }
     return mode::check_launch("mode_sphere_conv_fwd_win_split");
   }
@@ -2372,6 +2523,17 @@ extern "C" int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, 
   }
   return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream, bn,
                                   1);
+}
+
+// The training forward with the small-window tiles on the two-piece fp16 arithmetic: amax_x / amax_w = device scalars holding the largest
+// finite magnitude of x and of w (mode_abs_max, or the BatchNorm pass that wrote x).  Same results contract as the split-bf16 entry.
+extern "C" int mode_sphere_conv_fwd_win_split_f16(const float* x, const float* pos, const float* w, const float* amax_x, const float* amax_w,
+                                                  float* y, float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B,
+                                                  int Ci, int H, int W, int Co, int Kh, int Kw, int groups, int transposed,
+                                                  mode_stream_t stream) {
+  MODE_REQUIRE(amax_x && amax_w, MODE_ERR_BAD_ARG, "mode_sphere_conv_fwd_win_split_f16: null maximum");
+  return sphere_conv_fwd_win_impl(x, pos, w, y, wpack, tiles, n_small, n_mid, n_wrap, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream,
+                                  nullptr, 1, amax_x, amax_w);
 }
 
 extern "C" int mode_sphere_conv_fwd_win_bn(const float* x, const float* pos, const float* w, const mode_bn_epilogue* bn, float* y,

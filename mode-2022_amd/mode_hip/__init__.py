@@ -59,6 +59,7 @@ SIGNATURES = {
     'mode_sphere_conv_fwd_bn': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_fwd_win_bn': (_c_int, [_c_ptr] * 7 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_fwd_win_split': (_c_int, [_c_ptr] * 7 + [_c_int] * 12 + [_c_ptr]),
+    'mode_sphere_conv_fwd_win_split_f16': (_c_int, [_c_ptr] * 8 + [_c_int] * 12 + [_c_ptr]),
     'mode_cost_volume_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_volume_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_conv2d_wpack_bytes': (_c_size, [_c_int] * 2),
@@ -138,7 +139,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 27  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 28  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

@@ -408,9 +408,21 @@ def sphere_plan(pos, kh, kw):
     return plan
 
 
-def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
+SPHERE_FWD_F16 = True  # the small-window tiles of a TRAINING forward on two fp16 pieces / three MFMAs per product (bf16x6 only)
+
+
+def _sphere_f16_maxima(x, w, f16):
+  """(max |x|, max |w|) device scalars for the fp16 arithmetic of the windowed forward, or None when it does not apply."""
+  if not (f16 and SPHERE_FWD_F16 and CONV_ARITH == 'bf16x6' and w.shape[1] % 16 == 0):  # (16 input channels per MFMA: the split kernel's layers)
+    return None
+  ax = known_abs_max(x)  # left by the BatchNorm pass that wrote x, where there is one
+  return (ax if ax is not None else abs_max(x), abs_max(w))
+
+
+def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False, f16=False):
   """Writes `out` (B,Co,Ho,Wo) in place.  Replaces sphere_conv_forward_cuda (sphere_conv_cuda.cpp:129-210).
-  return_transposed: return the plane-transposed copy of x the windowed kernel used (None if it did not run) instead of out."""
+  return_transposed: return the plane-transposed copy of x the windowed kernel used (None if it did not run) instead of out.
+  f16: the caller is a training step (SphereConvFunction with a gradient to compute): the windowed kernel may use the fp16 arithmetic."""
   require_gpu(x, pos, w, out)
   require_f32c(x, pos, w, out)
   _check_pos(pos, x, w.shape[2], w.shape[3])
@@ -429,7 +441,7 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
     if not _plan_usable(plan):
       post = sphere_native_t(pos, w.shape[2], w.shape[3])  # ERP-like table: the `_t` operator on the NCHW tensors themselves
       if post is not None and sphere_t_supported(post, w, x.shape[0], groups):
-        sphere_conv_fwd_t(x, post, w, out, groups)
+        sphere_conv_fwd_t(x, post, w, out, groups, f16=f16)
         return None if return_transposed else out
   with torch.cuda.device_of(x), profiling.region(_tag2('sphere_conv_fwd', w, x), nbytes, flops, x.device):
     if plan is not None:
@@ -437,12 +449,13 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
       tiles, (n0, n1, n2) = plan[:2]
       wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
       xt = None
+      amax = _sphere_f16_maxima(x, w, f16)
       if SPHERE_LAYOUT == 'transposed':
         xt, yt = transpose_planes(x), torch.empty((B, Co, W, H), dtype=x.dtype, device=x.device)
-        _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x))
+        _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(x), amax)
         transpose_planes(yt, out)
       else:
-        _sphere_fwd_win(ptr(x), pos, w, None, ptr(out), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 0, stream_of(x))
+        _sphere_fwd_win(ptr(x), pos, w, None, ptr(out), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 0, stream_of(x), amax)
     else:
       xt = None
       wp = _wpack(w, groups)
@@ -450,10 +463,14 @@ def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False):
   return xt if return_transposed else out
 
 
-def _sphere_fwd_win(xp, pos, w, e, yp, wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream):
+def _sphere_fwd_win(xp, pos, w, e, yp, wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream, amax=None):
   """Windowed spherical forward (optional folded-BatchNorm epilogue `e`): the small-window tiles on the split-bf16 kernel when
-  CONV_ARITH says so (the library falls back to the fp32 kernels by itself when the channel count does not fit)."""
-  if CONV_ARITH == 'bf16x6':
+  CONV_ARITH says so (the library falls back to the fp32 kernels by itself when the channel count does not fit).
+  amax = (max |x|, max |w|) device scalars: the fp16 arithmetic (_sphere_f16_maxima; no epilogue)."""
+  if amax is not None and e is None and CONV_ARITH == 'bf16x6':
+    check(lib().mode_sphere_conv_fwd_win_split_f16(xp, ptr(pos), ptr(w), ptr(amax[0]), ptr(amax[1]), yp, ptr(wp), ptr(tiles), n0, n1, n2, B, Ci, H,
+                                                   W, Co, Kh, Kw, groups, transposed, stream), 'mode_sphere_conv_fwd_win_split_f16')
+  elif CONV_ARITH == 'bf16x6':
     check(lib().mode_sphere_conv_fwd_win_split(xp, ptr(pos), ptr(w), ctypes.byref(e) if e is not None else None, yp, ptr(wp), ptr(tiles), n0, n1,
                                                n2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream), 'mode_sphere_conv_fwd_win_split')
   elif e is not None:
@@ -647,7 +664,7 @@ def sphere_t_supported(pos, w, B, groups):
   return sum(plan[1]) * B * groups * (-(-(w.shape[0] // groups) // 128)) >= SPHERE_FWD_MIN_WG
 
 
-def sphere_conv_fwd_t(xt, pos, w, yt, groups):
+def sphere_conv_fwd_t(xt, pos, w, yt, groups, f16=False):
   """yt (B,Co,W,H) = spherical convolution of xt (B,Ci,W,H), both plane-transposed; stride 1, 3x3 taps."""
   require_gpu(xt, pos, w, yt)
   require_f32c(xt, pos, w, yt)
@@ -659,7 +676,8 @@ def sphere_conv_fwd_t(xt, pos, w, yt, groups):
   nbytes = 4 * (xt.numel() + yt.numel() + pos.numel() + w.numel())
   with torch.cuda.device_of(xt), profiling.region('sphere_conv_fwd[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, xt.device):
     wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
-    _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(xt))
+    _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(xt),
+                    _sphere_f16_maxima(xt, w, f16))
   return yt
 
 
@@ -1216,12 +1234,21 @@ def _tag3(name, ci, co, stride, d, h, w):
 CONV3D_S1_F16 = True
 
 
+BN_ABSMAX_FLOATS = 2064  # MODE_BN_ABSMAX_FLOATS of include/mode_hip.h: the buffer a tensor's maximum lives in
+
+
 def abs_max(t):
-  """Device scalar: the largest magnitude in t (mode_abs_max; no host synchronisation).  A tensor's maximum is computed once and handed
-  to every kernel that reads the tensor (the forward's x again in the weight gradient, gy in both gradients)."""
-  out = torch.empty(1, dtype=torch.float32, device=t.device)
+  """The largest finite magnitude in t as the fp16-arithmetic kernels take it (mode_abs_max; no host synchronisation): a device buffer
+  of BN_ABSMAX_FLOATS floats whose maximum is the value (abs_max_value reads it on the host).  A tensor's maximum is computed once and
+  handed to every kernel that reads the tensor (the forward's x again in the weight gradient, gy in both gradients)."""
+  out = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=t.device)
   check(lib().mode_abs_max(ptr(t), t.numel(), ptr(out), stream_of(t)), 'mode_abs_max')
   return out
+
+
+def abs_max_value(buf):
+  """Host value of a maximum buffer (abs_max, known_abs_max): its entries are non-negative floats, the value is their maximum.  Synchronises."""
+  return float(buf.max())
 
 
 def conv3d_s1_f16(ci, co, which):
@@ -1637,7 +1664,6 @@ def bn_supported(y):
   return y.is_cuda and y.dtype == torch.float32 and B * C < 65536 and B > 0  # (any S: rows that are not multiples of 16 bytes take the kernels' scalar path)
 
 
-BN_ABSMAX_FLOATS = 2064  # MODE_BN_ABSMAX_FLOATS of include/mode_hip.h: the buffer mode_bn_next_*_absmax points the pass at
 _bn_tls = threading.local()  # out_amax: the device scalar the last BnActFunction.forward of this thread asked its kernel to fill
 
 
@@ -1674,11 +1700,11 @@ class BnActFunction(torch.autograd.Function):
                 float(momentum), float(eps), int(relu), ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None,
                 ptr(coef[1]) if from_y else None)
       _bn_tls.out_amax = None
-      if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
-        # the 3-D stack's activations feed stride-1 convolutions on the fp16 arithmetic: their maximum comes out of this pass
-        buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)  # word 0: the result; the rest: the pass's scratch
-        _bn_tls.out_amax = buf[:1]
-        lib().mode_bn_next_out_absmax(ptr(buf))
+      if CONV_ARITH == 'bf16x6' and ((CONV3D_S1_F16 and y.dim() == 5) or (SPHERE_FWD_F16 and y.dim() == 4 and C % 16 == 0)):
+        # the 3-D stack's activations feed stride-1 convolutions on the fp16 arithmetic, the extractor's the spherical layers: their
+        # maximum comes out of this pass
+        _bn_tls.out_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
+        lib().mode_bn_next_out_absmax(ptr(_bn_tls.out_amax))
       if prestats_ws is not None:  # the producing convolution left the statistics in the workspace (conv3d_bn_train): no statistics pass
         if groups != 1:
           raise RuntimeError('BatchNorm with precomputed statistics takes one statistics group')
@@ -1707,9 +1733,8 @@ class BnActFunction(torch.autograd.Function):
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
     gy_amax = None
     if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
-      buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
-      gy_amax = buf[:1]  # the convolution in front reads gy in both of its gradients
-      lib().mode_bn_next_gy_absmax(ptr(buf))
+      gy_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)  # the convolution in front reads gy in both of its gradients
+      lib().mode_bn_next_gy_absmax(ptr(gy_amax))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * ctx.groups, y.device)
       check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
@@ -1842,9 +1867,8 @@ class ClassifHeadFunction(torch.autograd.Function):
       ws = torch.empty(max(lib().mode_classif_workspace_bytes(B, C, D, H, W) // 4, 1), dtype=torch.float32, device=y.device)
       gy_amax = None
       if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6':  # the 32 -> 32 convolution in front reads gy in both of its gradients (BnActFunction.backward)
-        buf = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
-        gy_amax = buf[:1]
-        lib().mode_bn_next_gy_absmax(ptr(buf))
+        gy_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
+        lib().mode_bn_next_gy_absmax(ptr(gy_amax))
       check(lib().mode_classif_train_bwd(ptr(gcost), ptr(y), ptr(w), ptr(gamma), ptr(beta), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
                                          ptr(saved[3]), ptr(gy), ptr(gw), ptr(ggamma), ptr(gbeta), int(fused), ptr(ws), B, C, D, H, W,
                                          stream_of(y)), 'mode_classif_train_bwd')

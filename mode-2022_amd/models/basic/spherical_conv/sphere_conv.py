@@ -27,7 +27,9 @@ class SphereConvFunction(Function):
   """autograd glue; same argument list and error behaviour as sphere_conv.py:16-114."""
 
   @staticmethod
-  def forward(ctx, input, position, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+  def forward(ctx, input, position, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, training=False):
+    # (training: an extension, set by SphereConv.forward when gradients are being recorded -- ctx.needs_input_grad is also set under
+    # no_grad -- and passed on to sphere_conv_forward_cuda: the arithmetic of the training step, DESIGN 3v)
     if input is not None and input.dim() != 4:
       raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
     ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
@@ -47,7 +49,7 @@ class SphereConvFunction(Function):
     keep = [] if ctx.needs_input_grad[2] else None  # only the weight gradient uses it
     sphere_conv_cuda.sphere_conv_forward_cuda(input, weight, bias, None, position, output, None, kh, kw, ctx.stride[0],
                                               ctx.stride[1], ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1],
-                                              groups, ctx.has_bias, keep_transposed=keep)
+                                              groups, ctx.has_bias, keep_transposed=keep, training=bool(training))
     ctx.input_t = keep[0] if keep else None
     return output
 
@@ -68,7 +70,7 @@ class SphereConvFunction(Function):
                                                grad_output, kh, kw, ctx.stride[0], ctx.stride[1], ctx.padding[0], ctx.padding[1],
                                                ctx.dilation[0], ctx.dilation[1], ctx.groups, ctx.has_bias,
                                                overwrite_grad_input=True, input_transposed=ctx.input_t)
-    return grad_input, None, (None if sink is not None else grad_weight), (grad_bias if ctx.has_bias else None), None, None, None, None
+    return grad_input, None, (None if sink is not None else grad_weight), (grad_bias if ctx.has_bias else None), None, None, None, None, None
 
   @staticmethod
   def _output_size(input, weight, padding, dilation, stride):
@@ -124,12 +126,12 @@ class SphereConvTransposedFunction(Function):
   """SphereConvFunction for stride 1, 3x3 taps, no bias, on plane-transposed input and output."""
 
   @staticmethod
-  def forward(ctx, input_t, position, weight, groups):
+  def forward(ctx, input_t, position, weight, groups, training=False):
     input_t = input_t.contiguous()
     weight = weight.contiguous()
     B, _, W, H = input_t.shape
     output_t = input_t.new_empty((B, weight.size(0), W, H))
-    _F.sphere_conv_fwd_t(input_t, position, weight, output_t, groups)
+    _F.sphere_conv_fwd_t(input_t, position, weight, output_t, groups, f16=bool(training))  # (a training step: DESIGN 3v)
     ctx.save_for_backward(input_t, position, weight)
     ctx.groups = groups
     return output_t
@@ -149,7 +151,7 @@ class SphereConvTransposedFunction(Function):
       gw = sink if sink is not None else torch.zeros_like(weight)
       _F.sphere_conv_bwd_weight_t(gyt, position, input_t, gw, ctx.groups)
       grad_weight = None if sink is not None else gw
-    return grad_input_t, None, grad_weight, None
+    return grad_input_t, None, grad_weight, None, None
 
 # All layers of one network share a handful of geometries (16 identical tables in ModeDisparity): build each
 # table once per process and upload it once per device, instead of per layer (reference) and per call (:240).
@@ -267,12 +269,13 @@ class SphereConv(nn.Module):
     return t
 
   def forward(self, x):
+    training = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)  # gradients are being recorded
     if getattr(_tls, 'transposed', False):
       if not self.supports_transposed_io(x.shape[0], x.device):
         raise RuntimeError('SphereConv: this layer cannot run on plane-transposed storage (see supports_transposed_io)')
-      return SphereConvTransposedFunction.apply(x, self.position_on(x.device), self.weight, self.groups)
+      return SphereConvTransposedFunction.apply(x, self.position_on(x.device), self.weight, self.groups, training)
     return sphere_conv(x, self.position_on(x.device), self.weight, self.bias, self.stride, self.padding, self.dilation,
-                       self.groups)
+                       self.groups, training)
 
   def forward_bn(self, x, bn, add=None, relu=False):
     """Inference only (an extension; the reference has no counterpart): relu?(bn(self(x)) [+ add]) with `bn` in eval mode as ONE

@@ -78,10 +78,11 @@ def _computes_in_fp32(name, input):
 
 
 def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, columns, kernel_h, kernel_w, stride_h, stride_w,
-                             pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *, keep_transposed=None):
+                             pad_h, pad_w, dilation_h, dilation_w, group, has_bias, *, keep_transposed=None, training=False):
   """The 17 positional arguments of the reference op.  Keyword-only extension: pass a list as keep_transposed and the
   plane-transposed copy of `input` that the windowed kernel made (if it ran) is appended to it, for
-  sphere_conv_backward_cuda(input_transposed=...)."""
+  sphere_conv_backward_cuda(input_transposed=...).  training=True (SphereConvFunction with a gradient to compute) lets the windowed
+  kernel use the two-piece fp16 arithmetic of the training step (functional.SPHERE_FWD_F16); an inference call keeps three bf16 pieces."""
   Ho, Wo = _shape_check(input, position, None, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
                         dilation_w, group)
   if tuple(output.shape) != (input.size(0), weight.size(0), Ho, Wo):
@@ -94,7 +95,8 @@ def sphere_conv_forward_cuda(input, weight, bias, ones, position, output, column
     if has_bias:
       output += bias.view(1, -1, 1, 1)
     return
-  xt = _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group, return_transposed=True)
+  xt = _F.sphere_conv_fwd(input.contiguous(), position.contiguous(), weight, output, (stride_h, stride_w), group, return_transposed=True,
+                          f16=training)
   if keep_transposed is not None and xt is not None:
     keep_transposed.append(xt)
   if has_bias:

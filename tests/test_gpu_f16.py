@@ -82,13 +82,13 @@ def test_f16_arithmetic_is_an_fp32_convolution(case, ci, co, shape, f16_switch):
 def test_abs_max_is_exact_and_order_independent():
   x = _rand((3, 1000003), 601)
   x[1, 77] = -123.5
-  m = [float(HF.abs_max(x)) for _ in range(3)]
+  m = [HF.abs_max_value(HF.abs_max(x)) for _ in range(3)]
   assert m == [123.5] * 3
-  assert float(HF.abs_max(torch.zeros(5, device=DEV))) == 0.0
+  assert HF.abs_max_value(HF.abs_max(torch.zeros(5, device=DEV))) == 0.0
   y = x.clone()
   y[2, 5] = float('nan')
   y[0, 9] = float('inf')
-  assert float(HF.abs_max(y)) == 123.5  # the largest FINITE magnitude: the scale has to fit the finite data
+  assert HF.abs_max_value(HF.abs_max(y)) == 123.5  # the largest FINITE magnitude: the scale has to fit the finite data
 
 
 def test_f16_layers_propagate_nan_and_inf_like_the_bf16_ones(f16_switch):
@@ -114,7 +114,7 @@ def test_batchnorm_pass_leaves_its_outputs_maximum(f16_switch):
   for relu, a in ((True, None), (False, add), (True, add), (False, None)):
     out = HF.bn_act(bn, y, a, relu)
     am = HF.known_abs_max(out)
-    assert am is not None and float(am) == float(out.abs().max()) == float(HF.abs_max(out)), (relu, a is not None)
+    assert am is not None and HF.abs_max_value(am) == float(out.abs().max()) == HF.abs_max_value(HF.abs_max(out)), (relu, a is not None)
   w = _rand((32, 32, 3, 3, 3), 803, 0.05)
   with_tag = HF.conv3d(out, w, 1)
   plain = out.clone()
@@ -122,7 +122,10 @@ def test_batchnorm_pass_leaves_its_outputs_maximum(f16_switch):
   assert torch.equal(with_tag, HF.conv3d(plain, w, 1))
   out.mul_(2.0)
   assert HF.known_abs_max(out) is None  # written since: the tag is stale and ignored
-  assert HF.known_abs_max(HF.bn_act(torch.nn.BatchNorm2d(8).to(DEV).train(), _rand((2, 8, 6, 40), 804), None, True)) is None  # 3-D stack only
+  assert HF.known_abs_max(HF.bn_act(torch.nn.BatchNorm2d(8).to(DEV).train(), _rand((2, 8, 6, 40), 804), None, True)) is None  # (no fp16 consumer)
+  out2 = HF.bn_act(torch.nn.BatchNorm2d(32).to(DEV).train(), _rand((4, 32, 24, 40), 805), None, True)  # (the extractor: spherical layers)
+  am2 = HF.known_abs_max(out2)
+  assert (am2 is not None) == HF.SPHERE_FWD_F16 and (am2 is None or HF.abs_max_value(am2) == float(out2.abs().max()))
 
 
 def test_maxima_come_from_the_batchnorm_passes_in_a_conv_bn_chain(f16_switch, monkeypatch):
@@ -168,4 +171,79 @@ def test_classifier_backward_leaves_its_gradients_maximum(f16_switch, shape):
     cost = HF.classif_head_train(y, bn, conv, None)
     cost.backward(_rand(cost.shape, 821 + rep, 10.0**(rep - 1)))
     (am, g), = seen
-    assert am is not None and float(am) == float(g.abs().max()) == float(HF.abs_max(g)), (shape, rep)
+    assert am is not None and HF.abs_max_value(am) == float(g.abs().max()) == HF.abs_max_value(HF.abs_max(g)), (shape, rep)
+
+
+# ------------------------------------------------------------------------------------------------ the spherical forward (a7)
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups', [(128, 256, 2, 128, 128, 1), (128, 256, 2, 64, 128, 1), (128, 256, 1, 32, 48, 2), (128, 256, 2, 16, 40, 1)])
+@pytest.mark.parametrize('case', ['unit variance', 'gradient-sized', 'one outlier'])
+def test_sphere_forward_on_two_fp16_pieces_against_float64(ih, iw, B, ci, co, groups, case, f16_switch):
+  """mode_sphere_conv_fwd_win_split_f16: the small-window tiles of the windowed spherical forward on two fp16 pieces and three MFMAs per
+  product (the tall-window tiles next to the poles keep three bf16 pieces), against the float64 oracle (oracle/sphere_conv_ref.py) on a
+  Cassini grid -- held to the bound of the three-piece path (2^-22 sqrt(terms) 8 of the largest output) and to twice that path's own
+  error plus a tenth of the bound; the same bits in every call; an inference call (f16 = False) keeps the three-piece bits."""
+  from oracle import mode_ref, sphere_conv_ref
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  ih, iw = pos.shape[2:]  # (Cassini: the stored image is (W, H))
+  x = _rand((B, ci, ih, iw), 901)
+  w = _rand((co, ci // groups, 3, 3), 902, 0.05)
+  if case == 'gradient-sized':
+    x = x * 1e-7
+  if case == 'one outlier':
+    x[0, 0, ih // 2, iw // 2] = 1e4
+  want = sphere_conv_ref.forward(x.cpu().double(), pos, w.cpu().double(), (1, 1), (1, 1), (1, 1), groups)
+  pd = pos.to(DEV)
+  assert HF.sphere_plan(pd, 3, 3) is not None
+  keep = HF.SPHERE_FWD_F16
+  try:
+    HF.SPHERE_FWD_F16 = True
+    got = HF.sphere_conv_fwd(x, pd, w, torch.empty((B, co, ih, iw), device=DEV), (1, 1), groups, f16=True)
+    again = HF.sphere_conv_fwd(x, pd, w, torch.empty((B, co, ih, iw), device=DEV), (1, 1), groups, f16=True)
+    plain = HF.sphere_conv_fwd(x, pd, w, torch.empty((B, co, ih, iw), device=DEV), (1, 1), groups)
+    HF.SPHERE_FWD_F16 = False
+    three = HF.sphere_conv_fwd(x, pd, w, torch.empty((B, co, ih, iw), device=DEV), (1, 1), groups, f16=True)
+  finally:
+    HF.SPHERE_FWD_F16 = keep
+  bound = 2.0**-22 * np.sqrt(9 * ci // groups) * 8 * float(want.abs().max())
+  e16 = float((got.cpu().double() - want).abs().max())
+  e3 = float((three.cpu().double() - want).abs().max())
+  print('sphere_conv_fwd %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (max |y| %.3g)' %
+        (ci, co, ih, iw, B, groups, case, e16, e3, bound, float(want.abs().max())))
+  assert e16 <= bound and e16 <= 2 * e3 + 0.1 * bound
+  assert torch.equal(got, again), 'not deterministic'
+  assert torch.equal(plain, three), 'an inference call must not change'
+  if ci // groups % 16 == 0:
+    assert not torch.equal(got, three), 'the fp16 kernel did not run'
+
+
+def test_sphere_training_forward_uses_the_batchnorm_tag_or_a_pass(f16_switch, monkeypatch):
+  """SphereConvFunction asks for the fp16 arithmetic only when there is a gradient to compute; the result is the same with the maximum
+  from a pass and from a producer's tag."""
+  from models.basic import SphereConv
+  conv = SphereConv(128, 256, 'Cassini', 32, 32, 3, 1, 1, 1, 1, False).to(DEV)
+  H, W = conv.position.shape[2:]
+  x = _rand((2, 32, H, W), 911)
+  calls = []
+  keep = HF.SPHERE_FWD_F16
+  try:
+    HF.SPHERE_FWD_F16 = True
+    spy_lib = HF.lib()
+
+    class Spy(object):
+      def __getattr__(self, name):
+        f = getattr(spy_lib, name)
+        if name == 'mode_sphere_conv_fwd_win_split_f16':
+          def g(*a):
+            calls.append(name)
+            return f(*a)
+          return g
+        return f
+    monkeypatch.setattr(HF, 'lib', lambda: Spy())
+    with torch.no_grad():
+      y_eval = conv(x)
+    assert not calls
+    y_train = conv(x.clone().requires_grad_(True))
+    assert calls == ['mode_sphere_conv_fwd_win_split_f16']
+    assert float((y_train - y_eval).abs().max()) <= 1e-4 * float(y_eval.abs().max())
+  finally:
+    HF.SPHERE_FWD_F16 = keep
