@@ -154,6 +154,12 @@ int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int groups);
 int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles, int n_tiles,
                                         const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2, const float* rec_w2, int B,
                                         int Ci, int H, int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream);
+/* The same on the two-piece fp16 arithmetic of mode_sphere_conv_fwd_win_split_f16 (a backward pass is a training step): amax_g / amax_w =
+ * the maximum buffers (MODE_BN_ABSMAX_FLOATS floats; mode_abs_max, mode_bn_next_gy_absmax) of gy and of w. */
+int mode_sphere_conv_bwd_data_win_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, float* gx, float* wpack,
+                                            const int32_t* tiles, int n_tiles, const int32_t* rec_off, const float* rec_w,
+                                            const int32_t* rec_off2, const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh,
+                                            int Kw, int groups, int transposed, mode_stream_t stream);
 
 /* Windowed forward (csrc/sphere_conv_win.hip): same result as mode_sphere_conv_fwd for stride 1 and 3x3 taps, ~2x faster on
  * tables whose samples are spatially compact (the gnomonic tables of the network).  The caller plans the table once on the HOST:

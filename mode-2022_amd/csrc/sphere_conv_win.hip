@@ -2843,11 +2843,14 @@ constexpr int AJ_PIX = TH * TW;  // 256 pixels per tile = 8 waves x 32 lanes
 // NS = 4: every adjoint list of the tile has at most four entries; NS = 6: up to six (the columns around the equator, where the
 // sampling positions of neighbouring output columns straddle a pixel boundary): slots 4 and 5 come from a second record array, read
 // when the tap is sampled (one tile in sixteen: not worth prefetch registers in a kernel at 249 VGPRs).
-template <int NS>
+// F16: the two-piece fp16 arithmetic of the training forward (sphere_fwd_split_kernel<false, true>): sx = the power-of-two scale of gy
+// (on the record's weights when a record becomes current), unscale = 1 / (sx * the weights' scale) on the accumulators.
+template <int NS, bool F16>
 __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, const uint4* __restrict__ wps, float* __restrict__ gx,
                                               const WinDims& d /* roles swapped: Ci = gy channels */, int NCH16, const int4 t,
                                               const int4* __restrict__ rec_off, const float4* __restrict__ rec_w,
-                                              const int2* __restrict__ rec_off2, const float2* __restrict__ rec_w2, float* smem) {
+                                              const int2* __restrict__ rec_off2, const float2* __restrict__ rec_w2, float* smem,
+                                              float sx, float unscale) {
   constexpr int WRP = WR_SMALL, CP = SP_CP;
   uint4* opbuf = reinterpret_cast<uint4*>(smem + SP_WIN_FLOATS);  // [3][8 pixel groups][3 pieces][64 lanes]
   const int h0 = t.x, w0 = t.y, rbase = t.z, cbase = t.w & 0xffff;
@@ -2880,6 +2883,13 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
       w2 = rwp2[kk * AJ_PIX + l];
     }
   };
+  // (F16) the operand's power-of-two scale rides on the record's weights: sx * (sum of w_i g_i) bit for bit
+  auto scaled = [&](float4& w4, float2& w2) {
+    if (F16) {
+      w4 = make_float4(w4.x * sx, w4.y * sx, w4.z * sx, w4.w * sx);
+      if (NS == 6) w2 = make_float2(w2.x * sx, w2.y * sx);
+    }
+  };
   int4 o_p0, o_p1, o_use, o_next;
   float4 w_p0, w_p1, w_use, w_next;
   int2 o2_p0, o2_p1, o2_use, o2_next;
@@ -2887,6 +2897,9 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   record(0, o_p0, w_p0, o2_p0, w2_p0);
   record(1, o_p1, w_p1, o2_p1, w2_p1);
   record(2, o_use, w_use, o2_use, w2_use);
+  scaled(w_p0, w2_p0);
+  scaled(w_p1, w2_p1);
+  scaled(w_use, w2_use);
 
   // every window word that may be read is finite: the staging stores write all rows and columns of both windows; what they never write
   // is the pad word behind each channel, the slack behind the two buffers, and -- during the first chunk -- the head of the second
@@ -2952,12 +2965,17 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
       asm("" : "+v"(v[c]));  // (keeps the chains of two channels from being SLP-packed pairwise, see sphere_fwd_split_kernel)
     }
     uint32_t q1[4], q2[4], q3[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
     uint4* dst = op + (wave * 3) * 64 + lane;
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    }
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    dst[128] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
   };
 
   f32x16 acc[4];
@@ -2968,9 +2986,10 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   const int m = wave % TW, gset = (wave / TW) * 4;
   const uint4* wpa = wps + ((long long)(g * d.MG + mg) * NCH16) * KT * MTW * 192 + m * 192;
   const int nsteps = NCH16 * KT;
+  constexpr int NPC = F16 ? 2 : 3;  // pieces per value
   uint4 acur[3], anxt[3];  // weight fragments of this tap and of the next one
 #pragma unroll
-  for (int p = 0; p < 3; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
+  for (int p = 0; p < NPC; ++p) acur[p] = wpa[(unsigned)(p * 64 + lane)];
 
 #pragma unroll
   for (int ph = 0; ph < 8; ++ph) issue(0, ph, ph);
@@ -3006,6 +3025,103 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
   };
   words(smem, o_use, o2_use, 0);
 #define MODE_SB __builtin_amdgcn_sched_barrier(0);
+  if constexpr (F16) {
+    // ---- 12 slots, as in sphere_fwd_split_kernel<false, true>: hi x hi, lo x hi, hi x lo; the second half batch of window words in
+    // registers of its own, requested at the top of the tap.  (The empty asm behind each MFMA pins it to its slot: without a consumer in
+    // the slot the compiler sinks the first eight below all their sched_barriers, to where their operands' registers are assembled.)
+#define MODE_MFH(PA, B, gi) acc[gi] = sp_mfma_f16(acur[PA], B[gi], acc[gi]); asm volatile("" :: "v"(acc[gi]));
+    float raw2[4][NS];
+    // Three record sets, the record of sampled tap s in set s % 3, requested FOUR taps ahead (at the top of tap s - 6 ... i.e. under tap
+    // k the record of tap k + 4 is requested and the one of tap k + 3 becomes current in slot 8): requested one tap ahead as in the
+    // three-piece loop it would be the newest request when slot 8 needs it -- a vmcnt(0) that also drains the window staging loads
+    // of the previous tap, which have two taps to arrive.
+    int4 ro[3];
+    float4 rwt[3];
+    int2 ro2[3];
+    float2 rwt2[3];
+    ro[2] = o_use; rwt[2] = w_use; ro2[2] = o2_use; rwt2[2] = w2_use;  // (already scaled)
+    record(3, ro[0], rwt[0], ro2[0], rwt2[0]);
+    for (int ch = 0; ch < NCH16; ++ch) {
+      float* cur = smem + (ch & 1) * SP_WIN;
+      float* nxt = smem + ((ch + 1) & 1) * SP_WIN;
+      const int chn = ch + 1 < NCH16 ? ch + 1 : ch;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int step = ch * KT + k;
+        const int nstep = step + 1 < nsteps ? step + 1 : nsteps - 1;
+        const float* wsrc = k + 2 < KT ? cur : nxt;
+        const float* wsrcn = k + 3 < KT ? cur : nxt;
+        const uint4* fcur = fragbase + (k % 3) * SP_OP;
+        const uint4* fnxt = fragbase + ((k + 1) % 3) * SP_OP;
+        uint4* opw = opbuf + ((k + 2) % 3) * SP_OP + (wave * 3) * 64 + lane;
+        const int su = (k + 2) % 3, sn = (k + 3) % 3, sl = (k + 4) % 3;  // sets: current, next, the one being requested
+        auto combine = [&](int c, float (&rr)[4][NS]) {
+          const float4 tw = rwt[su];
+          float t = __builtin_fmaf(tw.w, rr[c & 3][3], __builtin_fmaf(tw.z, rr[c & 3][2], __builtin_fmaf(tw.y, rr[c & 3][1], tw.x * rr[c & 3][0])));
+          if (NS == 6) t = __builtin_fmaf(rwt2[su].y, rr[c & 3][NS - 1], __builtin_fmaf(rwt2[su].x, rr[c & 3][NS - 2], t));
+          v[c] = t;
+          asm("" : "+v"(v[c]));
+        };
+        auto hsplit = [&](int j) { sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]); };
+#pragma unroll
+        for (int p = 0; p < 2; ++p) anxt[p] = (wpa + (long long)nstep * MTW * 192)[(unsigned)(p * 64 + lane)];
+        record((k + 4) % KT, ro[sl], rwt[sl], ro2[sl], rwt2[sl]);
+        {
+          const float* p = wsrc + half * 8 * CP;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float* q = p + (4 + c) * CP;
+            raw2[c][0] = q[ro[su].x];
+            raw2[c][1] = q[ro[su].y];
+            raw2[c][2] = q[ro[su].z];
+            raw2[c][3] = q[ro[su].w];
+            if (NS == 6) {
+              raw2[c][4] = q[ro2[su].x];
+              raw2[c][5] = q[ro2[su].y];
+            }
+          }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b1[gi] = fcur[(gi * 3 + 1) * 64];
+        MODE_SB
+        MODE_MFH(0, b0, 0) combine(0, raw); MODE_SB
+        MODE_MFH(0, b0, 1) combine(1, raw); MODE_SB
+        MODE_MFH(0, b0, 2) combine(2, raw); MODE_SB
+        MODE_MFH(0, b0, 3) combine(3, raw); MODE_SB
+        MODE_MFH(1, b0, 0) hsplit(0); MODE_SB
+        MODE_MFH(1, b0, 1) hsplit(1); combine(4, raw2); MODE_SB
+        MODE_MFH(1, b0, 2) combine(5, raw2); combine(6, raw2); MODE_SB
+        MODE_MFH(1, b0, 3) combine(7, raw2); MODE_SB
+        // the record of the tap sampled under the NEXT tap becomes current; its first half batch of window words is requested here
+        scaled(rwt[sn], rwt2[sn]);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b0n[gi] = fnxt[(gi * 3 + 0) * 64];
+        words(wsrcn, ro[sn], ro2[sn], 0);
+        MODE_SB
+        MODE_MFH(0, b1, 0) hsplit(2); MODE_SB
+        MODE_MFH(0, b1, 1) hsplit(3); MODE_SB
+        opw[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        opw[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if (k < 4) {
+          issue(chn, 2 * k, 2 * k);
+          issue(chn, 2 * k + 1, 2 * k + 1);
+        }
+        MODE_SB
+        MODE_MFH(0, b1, 2) MODE_SB
+        if (k >= LAG && k < 4 + LAG) commit(chn, 2 * (k - LAG), 2 * (k - LAG), nxt);
+        MODE_SB
+        MODE_MFH(0, b1, 3) MODE_SB
+        if (k >= LAG && k < 4 + LAG) commit(chn, 2 * (k - LAG) + 1, 2 * (k - LAG) + 1, nxt);
+        MODE_SB
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acur[p] = anxt[p];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) b0[gi] = b0n[gi];
+        sp_lds_barrier();
+      }
+    }
+#undef MODE_MFH
+  } else {
 #define MODE_MF(PA, B, gi) acc[gi] = sp_mfma(acur[PA], B[gi], acc[gi]);
 
   for (int ch = 0; ch < NCH16; ++ch) {
@@ -3105,8 +3221,9 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
       sp_lds_barrier();
     }
   }
-#undef MODE_SB
 #undef MODE_MF
+  }
+#undef MODE_SB
 
   // D[i = c][j = pixel of group gset + gi]: written (this kernel owns every element of its tiles)
   const int hh = h0 + (wave / TW) * 32 + (lane & 31);
@@ -3119,29 +3236,38 @@ __device__ __forceinline__ void bwd_data_tile(const float* __restrict__ gy, cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cmax) yb[(long long)co * HW] = acc[gi][r];
+        if (co < cmax) yb[(long long)co * HW] = F16 ? acc[gi][r] * unscale : acc[gi][r];
       }
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(NTHREADS) void sphere_bwd_data_split_kernel(const float* __restrict__ gy, const uint4* __restrict__ wps,
                                                                          float* __restrict__ gx, WinDims d, int NCH16,
                                                                          const int4* __restrict__ tiles, const int4* __restrict__ rec_off,
                                                                          const float4* __restrict__ rec_w, const int2* __restrict__ rec_off2,
-                                                                         const float2* __restrict__ rec_w2) {
+                                                                         const float2* __restrict__ rec_w2, const float* __restrict__ amax_g,
+                                                                         const float* __restrict__ amax_w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float sx = 1.f, unscale = 1.f;
+  if (F16) {
+    sx = sp_f16_scale_of(mode::absmax_load(amax_g));
+    unscale = (1.f / sx) * (1.f / sp_f16_scale_of(mode::absmax_load(amax_w)));
+  }
   const int4 t = tiles[blockIdx.x];
   if ((t.w >> 16) == 0)
-    bwd_data_tile<4>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem);
+    bwd_data_tile<4, F16>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem, sx, unscale);
   else
-    bwd_data_tile<6>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem);
+    bwd_data_tile<6, F16>(gy, wps, gx, d, NCH16, t, rec_off, rec_w, rec_off2, rec_w2, smem, sx, unscale);
 }
 
 // wps[(((((g*MG + mg)*NCH16 + ch)*KT + tap)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[o = g*Cog' + ch*16 + 8*(lane>>5) + j]
 // [c = mg*128 + m*32 + (lane&31)][tap] -- the transposed weight: rows of this GEMM are the INPUT channels c of the layer, its reduction
 // runs over the output channels o.  `d` carries the swapped roles (d.Cog = input channels per group, d.Cig = output channels per group).
-__global__ void pack_w_win_split_t(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16) {
+template <bool F16>
+__global__ void pack_w_win_split_t(const float* __restrict__ w, uint4* __restrict__ wps, WinDims d, int NCH16, const float* __restrict__ amax_w) {
+  const float sw = F16 ? sp_f16_scale_of(mode::absmax_load(amax_w)) : 1.f;
   const long long total = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -3160,10 +3286,18 @@ __global__ void pack_w_win_split_t(const float* __restrict__ w, uint4* __restric
     for (int j = 0; j < 8; ++j) {
       const int o = ch * SP_CCH + 8 * (lane >> 5) + j;  // reduction index = output channel of the layer (within the group)
       v[j] = (c < d.Cog && o < d.Cig) ? w[((long long)(g * d.Cig + o) * d.Cog + c) * KT + tap] : 0.f;
+      if (F16) v[j] *= sw;
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (F16) {
+        sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+        q3[j] = 0u;
+      } else {
+        sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      }
+    }
     uint4* dst = wps + (idx - lane) * 3 + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -3329,11 +3463,10 @@ extern "C" int mode_sphere_conv_bwd_data_win_supported(int Ci, int Co, int group
 
 // gx (written, not added to) on the n_tiles good tiles of the adjoint plan; `transposed`: gy and gx are plane-transposed (B, C, W, H).
 // The caller runs mode_sphere_conv_bwd_data_adj_list on the plan's bad tiles.
-extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles,
-                                                   int n_tiles, const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2,
-                                                   const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
-                                                   int transposed, mode_stream_t stream) {
-  const char* who = "mode_sphere_conv_bwd_data_win_split";
+static int sphere_bwd_data_win_split(const char* who, const float* gy, const float* w, const float* amax_g, const float* amax_w, float* gx,
+                                     float* wpack, const int32_t* tiles, int n_tiles, const int32_t* rec_off, const float* rec_w,
+                                     const int32_t* rec_off2, const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh, int Kw,
+                                     int groups, int transposed, mode_stream_t stream) {
   WinDims d;
   int rc = make_win_dims(d, B, Co, H, W, Ci, Kh, Kw, groups, who);  // roles swapped: this GEMM reduces over the layer's output channels
   if (rc != MODE_OK) return rc;
@@ -3351,13 +3484,43 @@ extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float*
   const int NCH16 = d.Cig / SP_CCH;
   uint4* wps = reinterpret_cast<uint4*>(wpack);
   const long long nsplit = (long long)d.G * d.MG * NCH16 * KT * MTW * 64;
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split_t, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16);
-  rc = mode::allow_lds(sphere_bwd_data_split_kernel, SP3_LDS_BYTES, who);
+  if (amax_g) {
+    if (mode::pack_needed())
+      hipLaunchKernelGGL(pack_w_win_split_t<true>, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, amax_w);
+    rc = mode::allow_lds(sphere_bwd_data_split_kernel<true>, SP3_LDS_BYTES, who);
+    if (rc != MODE_OK) return rc;
+    hipLaunchKernelGGL(sphere_bwd_data_split_kernel<true>, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP3_LDS_BYTES, st, gy, wps, gx, d, NCH16,
+                       reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w),
+                       reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2), amax_g, amax_w);
+    return mode::check_launch(who);
+  }
+  if (mode::pack_needed())
+    hipLaunchKernelGGL(pack_w_win_split_t<false>, dim3(mode::cdiv(nsplit, 256)), dim3(256), 0, st, w, wps, d, NCH16, (const float*)nullptr);
+  rc = mode::allow_lds(sphere_bwd_data_split_kernel<false>, SP3_LDS_BYTES, who);
   if (rc != MODE_OK) return rc;
-  hipLaunchKernelGGL(sphere_bwd_data_split_kernel, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP3_LDS_BYTES, st, gy, wps, gx, d, NCH16,
+  hipLaunchKernelGGL(sphere_bwd_data_split_kernel<false>, dim3(n_tiles, B, d.G * d.MG), dim3(NTHREADS), SP3_LDS_BYTES, st, gy, wps, gx, d, NCH16,
                      reinterpret_cast<const int4*>(tiles), reinterpret_cast<const int4*>(rec_off), reinterpret_cast<const float4*>(rec_w),
-                     reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2));
+                     reinterpret_cast<const int2*>(rec_off2), reinterpret_cast<const float2*>(rec_w2), (const float*)nullptr,
+                     (const float*)nullptr);
   return mode::check_launch(who);
+}
+
+extern "C" int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* gx, float* wpack, const int32_t* tiles,
+                                                   int n_tiles, const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2,
+                                                   const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups,
+                                                   int transposed, mode_stream_t stream) {
+  return sphere_bwd_data_win_split("mode_sphere_conv_bwd_data_win_split", gy, w, nullptr, nullptr, gx, wpack, tiles, n_tiles, rec_off, rec_w,
+                                   rec_off2, rec_w2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream);
+}
+
+// The same on the two-piece fp16 arithmetic (mode_sphere_conv_fwd_win_split_f16): amax_g / amax_w = the maximum buffers of gy and of w.
+extern "C" int mode_sphere_conv_bwd_data_win_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, float* gx,
+                                                       float* wpack, const int32_t* tiles, int n_tiles, const int32_t* rec_off,
+                                                       const float* rec_w, const int32_t* rec_off2, const float* rec_w2, int B, int Ci, int H,
+                                                       int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream) {
+  MODE_REQUIRE(amax_g && amax_w, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_data_win_split_f16: null maximum");
+  return sphere_bwd_data_win_split("mode_sphere_conv_bwd_data_win_split_f16", gy, w, amax_g, amax_w, gx, wpack, tiles, n_tiles, rec_off, rec_w,
+                                   rec_off2, rec_w2, B, Ci, H, W, Co, Kh, Kw, groups, transposed, stream);
 }
 
 #ifdef MODE_TAPTIME

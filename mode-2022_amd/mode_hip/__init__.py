@@ -39,6 +39,7 @@ SIGNATURES = {
     'mode_sphere_conv_bwd_data_win_wpack_bytes': (_c_size, [_c_int] * 5),
     'mode_sphere_conv_bwd_data_win_supported': (_c_int, [_c_int] * 3),
     'mode_sphere_conv_bwd_data_win_split': (_c_int, [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr]),
+    'mode_sphere_conv_bwd_data_win_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] + [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr]),
     'mode_sphere_plan_max_tiles': (_c_size, [_c_int] * 2),
     'mode_sphere_plan_build': (_c_int, [_c_ptr] + [_c_int] * 4 + [_c_ptr] * 2),
     'mode_sphere_conv_win_wpack_bytes': (_c_size, [_c_int] * 5),

@@ -411,12 +411,24 @@ def sphere_plan(pos, kh, kw):
 SPHERE_FWD_F16 = True  # the small-window tiles of a TRAINING forward on two fp16 pieces / three MFMAs per product (bf16x6 only)
 
 
+SPHERE_BWD_F16 = True  # ... and the windowed input gradient (the adjoint on the same kernel structure)
+
+
+def _tagged_abs_max(t):
+  """The maximum buffer of t: the producer's tag (BatchNorm passes), an earlier call's (a weight is read by the forward and by the input
+  gradient of its layer), or a pass -- whose result is left as the tag (known_abs_max drops it when t is written)."""
+  am = known_abs_max(t)
+  if am is None:
+    am = abs_max(t)
+    t._mode_amax = (am, t._version, t.data_ptr())
+  return am
+
+
 def _sphere_f16_maxima(x, w, f16):
-  """(max |x|, max |w|) device scalars for the fp16 arithmetic of the windowed forward, or None when it does not apply."""
+  """(max |x|, max |w|) buffers for the fp16 arithmetic of the windowed forward, or None when it does not apply."""
   if not (f16 and SPHERE_FWD_F16 and CONV_ARITH == 'bf16x6' and w.shape[1] % 16 == 0):  # (16 input channels per MFMA: the split kernel's layers)
     return None
-  ax = known_abs_max(x)  # left by the BatchNorm pass that wrote x, where there is one
-  return (ax if ax is not None else abs_max(x), abs_max(w))
+  return (_tagged_abs_max(x), _tagged_abs_max(w))
 
 
 def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False, f16=False):
@@ -743,9 +755,14 @@ def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
     if aplan is not None:
       tiles, ng, rec_off, rec_w, bad_ids, nbad, rec_off2, rec_w2 = aplan
       wps = torch.empty(lib().mode_sphere_conv_bwd_data_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
-      check(lib().mode_sphere_conv_bwd_data_win_split(ptr(gyt), ptr(w), ptr(gxt), ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w),
-                                                      ptr(rec_off2), ptr(rec_w2), B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)),
-            'mode_sphere_conv_bwd_data_win_split')
+      if SPHERE_BWD_F16:  # (a backward pass is a training step: the two-piece fp16 arithmetic)
+        check(lib().mode_sphere_conv_bwd_data_win_split_f16(ptr(gyt), ptr(w), ptr(_tagged_abs_max(gyt)), ptr(_tagged_abs_max(w)), ptr(gxt),
+                                                            ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w), ptr(rec_off2), ptr(rec_w2), B, Ci,
+                                                            H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)), 'mode_sphere_conv_bwd_data_win_split_f16')
+      else:
+        check(lib().mode_sphere_conv_bwd_data_win_split(ptr(gyt), ptr(w), ptr(gxt), ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w),
+                                                        ptr(rec_off2), ptr(rec_w2), B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)),
+              'mode_sphere_conv_bwd_data_win_split')
       if nbad:  # the tiles next to the poles and the few columns with more than four sources per tap: gather kernel on a tile list
         check(lib().mode_sphere_conv_bwd_data_adj_list(ptr(gyt), ptr(w), ptr(gxt), ptr(wp), ptr(rowptr), ptr(entries), B, Ci, W, H, Co,
                                                        Kh, Kw, W, H, groups, 0, ptr(bad_ids), nbad, stream_of(gyt)),
@@ -1732,7 +1749,7 @@ class BnActFunction(torch.autograd.Function):
     gbeta = sink_b if fused else torch.empty_like(gamma)
     nbytes = 4 * y.numel() * (2 * (2 + (1 if out is not None else 0)) + 1 + (1 if need_gadd else 0))
     gy_amax = None
-    if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6' and y.dim() == 5:
+    if CONV_ARITH == 'bf16x6' and ((CONV3D_S1_F16 and y.dim() == 5) or (SPHERE_BWD_F16 and y.dim() == 4 and C % 16 == 0)):
       gy_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)  # the convolution in front reads gy in both of its gradients
       lib().mode_bn_next_gy_absmax(ptr(gy_amax))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):

@@ -247,3 +247,48 @@ def test_sphere_training_forward_uses_the_batchnorm_tag_or_a_pass(f16_switch, mo
     assert float((y_train - y_eval).abs().max()) <= 1e-4 * float(y_eval.abs().max())
   finally:
     HF.SPHERE_FWD_F16 = keep
+
+
+# (the float64 oracle of the adjoint takes a minute per call at 128 -> 128 on the GPU box's host: the data cases run on the small layer)
+@pytest.mark.parametrize('ih,iw,B,ci,co,groups,case', [(128, 256, 2, 128, 128, 1, 'unit variance'), (128, 256, 1, 48, 32, 2, 'unit variance'),
+                                                        (128, 256, 1, 48, 32, 2, 'gradient-sized'), (128, 256, 1, 48, 32, 2, 'one outlier')])
+def test_sphere_input_gradient_on_two_fp16_pieces_against_float64(ih, iw, B, ci, co, groups, case, f16_switch, monkeypatch):
+  """mode_sphere_conv_bwd_data_win_split_f16 (the windowed adjoint on two fp16 pieces; the tiles next to the poles stay on the gather
+  kernel) against the float64 oracle (oracle/sphere_conv_ref.py: cu:293-356 + cpp:275-315 restated): the bound of the three-piece path,
+  and twice that path's own error plus a tenth of the bound; the same bits in every call; the weight's maximum is computed once."""
+  from oracle import mode_ref, sphere_conv_ref
+  monkeypatch.setattr(HF, 'SPHERE_BWD_SPLIT_MIN_WG', 0)
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  w = _rand((co, ci // groups, 3, 3), 921, (2.0 / (9 * ci // groups))**0.5)
+  gy = _rand((B, co, H, W), 922)
+  if case == 'gradient-sized':
+    gy = gy * 1e-7
+  if case == 'one outlier':
+    gy[0, 0, H // 2, W // 2] = 1e4
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  want, _ = sphere_conv_ref.backward(torch.zeros((B, ci, H, W), dtype=torch.float64), pos, w.cpu().double(), gy.cpu().double(), (1, 1), (1, 1),
+                                     (1, 1), groups)
+  pd = pos.to(DEV)
+  gyt = HF.transpose_planes(gy)
+  calls = []
+  real = HF.abs_max
+  monkeypatch.setattr(HF, 'abs_max', lambda t: (calls.append(tuple(t.shape)), real(t))[1])
+  keep = HF.SPHERE_BWD_F16
+  try:
+    HF.SPHERE_BWD_F16 = True
+    got = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups))
+    again = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups))
+    HF.SPHERE_BWD_F16 = False
+    three = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups))
+  finally:
+    HF.SPHERE_BWD_F16 = keep
+  assert sorted(calls) == sorted([tuple(gyt.shape), tuple(w.shape)]), calls  # one pass per tensor, reused by the second call
+  bound = 2.0**-22 * np.sqrt(9 * co // groups) * 8 * float(want.abs().max())
+  e16 = float((got.cpu().double() - want).abs().max())
+  e3 = float((three.cpu().double() - want).abs().max())
+  print('sphere_conv_bwd_data %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (max |gx| %.3g)' %
+        (ci, co, ih, iw, B, groups, case, e16, e3, bound, float(want.abs().max())))
+  assert e16 <= bound and e16 <= 2 * e3 + 0.1 * bound
+  assert torch.equal(got, again), 'not deterministic'
+  assert not torch.equal(got, three), 'the fp16 kernel did not run'
