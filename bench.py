@@ -34,7 +34,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense (bf16 and fp16 alike); a split-bf16 fp32
 # The stride-1 3-D layers in training run on TWO fp16 pieces and three MFMAs per product (functional.CONV3D_S1_F16): their
 # labels are priced against the dense peak / 3.  Set from --no-conv3d-f16 in main().
 CONV3D_S1_F16 = True
-# ... and so do the windowed spherical forward and input gradient of the training step (functional.SPHERE_FWD_F16 / SPHERE_BWD_F16).
+# ... and so do the windowed spherical forward and both of its gradients in the training step (functional.SPHERE_FWD_F16 / SPHERE_BWD_F16).
 # Set from --no-sphere-f16.
 SPHERE_FWD_F16 = True
 
@@ -43,7 +43,7 @@ def _on_f16_path(label):
   import re
   if CONV3D_S1_F16 and re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight)\[(\d+)->(\d+) s1 ', label) and not re.search(r'->1 ', label):
     return True
-  m = re.match(r'sphere_conv_(fwd|bwd_data)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
+  m = re.match(r'sphere_conv_(fwd|bwd_data|bwd_weight)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
   return bool(SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0)
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
@@ -84,7 +84,7 @@ def parse():
                   help='A/B: the stride-1 3-D layers of the training step on three bf16 pieces / six MFMAs per product like every other split '
                        'kernel, instead of two fp16 pieces / three MFMAs with a power-of-two scale per operand tensor (functional.CONV3D_S1_F16)')
   ap.add_argument('--no-sphere-f16', action='store_true',
-                  help='A/B: the windowed spherical forward and input gradient of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
+                  help='A/B: the windowed spherical forward and gradients of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
   ap.add_argument('--no-grad-carriers', action='store_true',
                   help="A/B: autograd's own pairwise accumulation for the tensors with two consumers (functional.GRAD_CARRIERS = False)")
   ap.add_argument('--no-fused-classif', action='store_true',
@@ -692,7 +692,7 @@ def main():
                                                             'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l' +
                                                             ('; the stride-1 3x3x3 layers of the training step: 2 fp16 pieces with a power-of-two scale '
                                                              'per operand tensor, 3 fp16 MFMAs per product, DESIGN.md 3u' +
-                                                             ('; so do the windowed spherical forward and input gradient, 3v)' if SPHERE_FWD_F16 else ')')
+                                                             ('; so do the windowed spherical forward and both of its gradients, 3v)' if SPHERE_FWD_F16 else ')')
                                                              if CONV3D_S1_F16 else ')')),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),

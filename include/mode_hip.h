@@ -237,6 +237,15 @@ int mode_sphere_conv_bwd_weight_win_split(const float* gy, const float* pos, con
                                           int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t,
                                           const float* x_t, mode_stream_t stream);
 
+/* ... and with those tiles on the two-piece fp16 arithmetic of mode_sphere_conv_fwd_win_split_f16: amax_g / amax_x = the maximum buffers
+ * (MODE_BN_ABSMAX_FLOATS floats) of gy and of x.  The polar items keep three bf16 pieces. */
+int mode_sphere_conv_bwd_weight_win_split_f16(const float* gy, const float* pos, const float* x, const float* amax_g, const float* amax_x,
+                                              float* gw, float* workspace, const int32_t* tiles, int n_small, int n_mid, int n_wrap,
+                                              const float* rec_w, const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels,
+                                              const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
+                                              int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t,
+                                              const float* x_t, mode_stream_t stream);
+
 int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                     const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
                                     const int32_t* rec_off, const int32_t* rest_pixels, int n_rest_pixels, const int32_t* pitems,

@@ -1786,11 +1786,22 @@ constexpr int BS_SCR = 32 * BS_SCRP;           // floats of one wave's transposi
 constexpr int BS_X2 = ((2 * BW_XW + 3) / 4) * 4;  // both x windows, rounded so that the gy buffer behind them is 16-byte aligned
 constexpr int BS_LDS_DWORDS = BS_X2 + BS_GYB + 8 * BS_SCR;
 
+// F16: the two-piece fp16 arithmetic of the other two spherical kernels (3v): gy is scaled by its tensor's power of two when a column is
+// committed, the sampled operand through its four bilinear weights, the partial sums by the inverse of both; 12 MFMAs per K-step.
+template <bool F16>
 __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                      float* __restrict__ part, WinDims d, const int4* __restrict__ tiles,
                                                                      const float4* __restrict__ rec_w, const int* __restrict__ rec_off,
-                                                                     int ntiles, int S) {
+                                                                     int ntiles, int S, const float* __restrict__ amax_g,
+                                                                     const float* __restrict__ amax_x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float sg = 1.f, sx = 1.f, unscale = 1.f;
+  if (F16) {
+    sg = sp_f16_scale_of(mode::absmax_load(amax_g));
+    sx = sp_f16_scale_of(mode::absmax_load(amax_x));
+    unscale = (1.f / sg) * (1.f / sx);
+  }
+  constexpr int NPC = F16 ? 2 : 3;  // pieces per value
   uint32_t* gyb = reinterpret_cast<uint32_t*>(smem + BS_X2);  // [3][128][BS_GP]
   constexpr int WRP = BW_WR, CP = BW_CP;
   const int s = blockIdx.x, cg = blockIdx.y;
@@ -1907,17 +1918,21 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     for (int u = 0; u < 4; ++u) {
       const float a = (pf.ok >> (2 * u) & 1u) ? pf.g0[u] : 0.f, b2 = (pf.ok >> (2 * u + 1) & 1u) ? pf.g1[u] : 0.f;
       uint32_t p1, p2, p3;
-      sp_split2(a, b2, p1, p2, p3);
       uint32_t* dst = gyb + (go0 + 32 * u) * BS_GP + gpp;
+      if constexpr (F16) {
+        sp_split2_f16(a * sg, b2 * sg, p1, p2);
+      } else {
+        sp_split2(a, b2, p1, p2, p3);
+        dst[2 * 128 * BS_GP] = p3;
+      }
       dst[0] = p1;
       dst[128 * BS_GP] = p2;
-      dst[2 * 128 * BS_GP] = p3;
     }
   };
   // B fragment of one K-step: sample this lane's pixel for 8 channels, transpose through the scratch, split this lane's channel.
   // No wait between the scratch stores and loads: the LDS serves the instructions of one wave in order, and the compiler keeps
   // may-aliasing LDS accesses in program order -- an explicit s_waitcnt here would pin the whole sample in front of the MFMAs.
-  auto sample = [&](const float* xw, const float4 w4, const int ro, uint4 (&bf)[3]) {
+  auto sample = [&](const float* xw, const float4 w4_, const int ro, uint4 (&bf)[3]) {
     const float* xb = xw + (8 * sq) * CP + ro;
     float v[8], r_[8][4];
     // (all 32 window words requested before the first is used: as one loop the compiler issued every read right in front of its
@@ -1931,6 +1946,8 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       r_[c][3] = q[WRP + 1];
     }
     __builtin_amdgcn_sched_barrier(0);
+    // (F16: the operand's power-of-two scale rides on the four weights)
+    const float4 w4 = F16 ? make_float4(w4_.x * sx, w4_.y * sx, w4_.z * sx, w4_.w * sx) : w4_;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       v[c] = __builtin_fmaf(w4.w, r_[c][3], __builtin_fmaf(w4.z, r_[c][2], __builtin_fmaf(w4.y, r_[c][1], w4.x * r_[c][0])));
@@ -1944,11 +1961,16 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
 #pragma unroll
     for (int i = 0; i < 8; ++i) t8[i] = sr[i];
     uint32_t q1[4], q2[4], q3[4];
+    if constexpr (F16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sp_split2(t8[2 * i], t8[2 * i + 1], q1[i], q2[i], q3[i]);
+      for (int i = 0; i < 4; ++i) sp_split2_f16(t8[2 * i], t8[2 * i + 1], q1[i], q2[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sp_split2(t8[2 * i], t8[2 * i + 1], q1[i], q2[i], q3[i]);
+      bf[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    }
     bf[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     bf[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    bf[2] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
   };
   // A fragments (gy, lane = o, 8 consecutive pixels) of the four o-tiles for K-step ks
   auto load_a = [&](int ks, uint4 (&a)[4][3]) {
@@ -1956,28 +1978,36 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
     for (int m = 0; m < 4; ++m) {
       const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m * 32 + j) * BS_GP + 8 * ks + 4 * half);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[m][p] = ga[p * (128 * BS_GP / 4)];
+      for (int p = 0; p < NPC; ++p) a[m][p] = ga[p * (128 * BS_GP / 4)];
     }
   };
-  // the 24 MFMAs of one K-step of this wave's tap: smallest terms first, consecutive MFMAs on different accumulators
+  // the 24 (F16: 12) MFMAs of one K-step of this wave's tap: smallest terms first, consecutive MFMAs on different accumulators
   auto mma24 = [&](const uint4 (&a)[4][3], const uint4 (&bf)[3]) {
-#define MODE_BS_TERM(PA, PB) _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = sp_mfma(a[m][PA], bf[PB], acc[m]);
-    MODE_BS_TERM(2, 0)
-    MODE_BS_TERM(0, 2)
-    MODE_BS_TERM(1, 1)
-    MODE_BS_TERM(1, 0)
-    MODE_BS_TERM(0, 1)
-    MODE_BS_TERM(0, 0)
+    if constexpr (F16) {
+#define MODE_BS_TERM(PA, PB) _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = sp_mfma_f16(a[m][PA], bf[PB], acc[m]);
+      MODE_BS_TERM(1, 0)
+      MODE_BS_TERM(0, 1)
+      MODE_BS_TERM(0, 0)
 #undef MODE_BS_TERM
+    } else {
+#define MODE_BS_TERM(PA, PB) _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = sp_mfma(a[m][PA], bf[PB], acc[m]);
+      MODE_BS_TERM(2, 0)
+      MODE_BS_TERM(0, 2)
+      MODE_BS_TERM(1, 1)
+      MODE_BS_TERM(1, 0)
+      MODE_BS_TERM(0, 1)
+      MODE_BS_TERM(0, 0)
+#undef MODE_BS_TERM
+    }
   };
-  // one MFMA, then up to 4 vector-ALU instructions and 3 LDS instructions, n times: spreads a sample (and the next fragment reads)
-  // over the matrix instructions issued beside it
-#define MODE_BS_SPREAD(n)                                  \
-  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     \
-  }                                                        \
+  // one MFMA, then up to 4 (F16: 7) vector-ALU instructions and 3 (F16: 4) LDS instructions, n times: spreads a sample (and the next
+  // fragment reads) over the matrix instructions issued beside it -- half the MFMAs carry a sample that is three quarters of the work
+#define MODE_BS_SPREAD(n)                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < (F16 ? (n) / 2 : (n)); ++i_) { \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
+    __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 7 : 4, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 4 : 3, 0);     \
+  }                                                                  \
   __builtin_amdgcn_sched_barrier(0);
 
   Item cur = item_of(s);
@@ -2028,13 +2058,20 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
       // tap 8: o-tile m8, K-step ks8
       {
         const uint4* ga = reinterpret_cast<const uint4*>(gyb + (m8 * 32 + j) * BS_GP + 8 * ks8 + 4 * half);
-        const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4], a3 = ga[2 * (128 * BS_GP / 4)];
-        acc8 = sp_mfma(a3, b8[0], acc8);
-        acc8 = sp_mfma(a1, b8[2], acc8);
-        acc8 = sp_mfma(a2, b8[1], acc8);
-        acc8 = sp_mfma(a2, b8[0], acc8);
-        acc8 = sp_mfma(a1, b8[1], acc8);
-        acc8 = sp_mfma(a1, b8[0], acc8);
+        const uint4 a1 = ga[0], a2 = ga[128 * BS_GP / 4];
+        if constexpr (F16) {
+          acc8 = sp_mfma_f16(a2, b8[0], acc8);
+          acc8 = sp_mfma_f16(a1, b8[1], acc8);
+          acc8 = sp_mfma_f16(a1, b8[0], acc8);
+        } else {
+          const uint4 a3 = ga[2 * (128 * BS_GP / 4)];
+          acc8 = sp_mfma(a3, b8[0], acc8);
+          acc8 = sp_mfma(a1, b8[2], acc8);
+          acc8 = sp_mfma(a2, b8[1], acc8);
+          acc8 = sp_mfma(a2, b8[0], acc8);
+          acc8 = sp_mfma(a1, b8[1], acc8);
+          acc8 = sp_mfma(a1, b8[0], acc8);
+        }
       }
       if (more_items) commit_xw(smem + (xbuf ^ 1) * BW_XW, wc);  // the other window buffer: nobody reads it now
 
@@ -2056,18 +2093,18 @@ __global__ __launch_bounds__(NTHREADS) void sphere_bww_split_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      pb[((long long)wave * 128 + o) * BW_CG + j] = acc[m][r];
+      pb[((long long)wave * 128 + o) * BW_CG + j] = F16 ? acc[m][r] * unscale : acc[m][r];
     }
   // tap 8: o-tile m8 = the share of K-step 0 (waves 0..3) + the share of K-step 1 (waves 4..7), added in that order through LDS
   float* red = smem;  // [128 o][32 c]; the item loop ended with a barrier
   if (wave < 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] = acc8[r];
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] = F16 ? acc8[r] * unscale : acc8[r];
   }
   __syncthreads();
   if (wave >= 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] += acc8[r];
+    for (int r = 0; r < 16; ++r) red[(m8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BW_CG + j] += F16 ? acc8[r] * unscale : acc8[r];
   }
   __syncthreads();
   for (int i = tid; i < 128 * BW_CG; i += NTHREADS) pb[(long long)8 * 128 * BW_CG + i] = red[i];
@@ -2705,7 +2742,7 @@ static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x
                                int n_small, int n_mid, int n_wrap, const float* rec_w, const int32_t* rec_off, const int32_t* rest_pixels,
                                int n_rest_pixels, const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
                                int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
-                               mode_stream_t stream, int split);
+                               mode_stream_t stream, int split, const float* amax_g = nullptr, const float* amax_x = nullptr);
 
 extern "C" int mode_sphere_conv_bwd_weight_win(const float* gy, const float* pos, const float* x, float* gw, float* workspace,
                                                const int32_t* tiles, int n_small, int n_mid, int n_wrap, const float* rec_w,
@@ -2729,13 +2766,28 @@ extern "C" int mode_sphere_conv_bwd_weight_win_split(const float* gy, const floa
                              prec_w, prec_off, n_polar_items, B, Ci, H, W, Co, Kh, Kw, groups, gy_t, x_t, stream, 1);
 }
 
+// The split call with the compact-window tiles on the two-piece fp16 arithmetic (3v): amax_g / amax_x = the maximum buffers of gy and x
+// (the polar items keep three bf16 pieces; their partial sums go through the same reduction).
+extern "C" int mode_sphere_conv_bwd_weight_win_split_f16(const float* gy, const float* pos, const float* x, const float* amax_g,
+                                                         const float* amax_x, float* gw, float* workspace, const int32_t* tiles, int n_small,
+                                                         int n_mid, int n_wrap, const float* rec_w, const int32_t* rec_off,
+                                                         const int32_t* rest_pixels, int n_rest_pixels, const int32_t* pitems,
+                                                         const float* prec_w, const int32_t* prec_off, int n_polar_items, int B, int Ci, int H,
+                                                         int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
+                                                         mode_stream_t stream) {
+  MODE_REQUIRE(amax_g && amax_x, MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win_split_f16: null maximum");
+  return bwd_weight_win_impl(gy, pos, x, gw, workspace, tiles, n_small, n_mid, n_wrap, rec_w, rec_off, rest_pixels, n_rest_pixels, pitems,
+                             prec_w, prec_off, n_polar_items, B, Ci, H, W, Co, Kh, Kw, groups, gy_t, x_t, stream, 1, amax_g, amax_x);
+}
+
 static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x, float* gw, float* workspace, const int32_t* tiles,
                                int n_small, int n_mid, int n_wrap, const float* rec_w, const int32_t* rec_off, const int32_t* rest_pixels,
                                int n_rest_pixels, const int32_t* pitems, const float* prec_w, const int32_t* prec_off, int n_polar_items,
                                int B, int Ci, int H, int W, int Co, int Kh, int Kw, int groups, const float* gy_t, const float* x_t,
-                               mode_stream_t stream, int split) {
+                               mode_stream_t stream, int split, const float* amax_g, const float* amax_x) {
   WinDims d;
   int rc = make_win_dims(d, B, Ci, H, W, Co, Kh, Kw, groups, "mode_sphere_conv_bwd_weight_win");
+  MODE_REQUIRE((amax_g == nullptr) == (amax_x == nullptr), MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: both operand maxima, or neither");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE((gy_t == nullptr) == (x_t == nullptr), MODE_ERR_BAD_ARG, "mode_sphere_conv_bwd_weight_win: gy_t and x_t come together");
   if (gy_t) {
@@ -2761,10 +2813,19 @@ static int bwd_weight_win_impl(const float* gy, const float* pos, const float* x
     S = bww_win_splits(d, n_small);
     if (split) {
       const size_t lds = (size_t)BS_LDS_DWORDS * sizeof(float);
-      rc = mode::allow_lds(sphere_bww_split_kernel, lds, "mode_sphere_conv_bwd_weight_win_split");
-      if (rc != MODE_OK) return rc;
-      hipLaunchKernelGGL(sphere_bww_split_kernel, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
-                         reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S);
+      if (amax_g) {
+        rc = mode::allow_lds(sphere_bww_split_kernel<true>, lds, "mode_sphere_conv_bwd_weight_win_split");
+        if (rc != MODE_OK) return rc;
+        hipLaunchKernelGGL(sphere_bww_split_kernel<true>, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
+                           reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S,
+                           amax_g, amax_x);
+      } else {
+        rc = mode::allow_lds(sphere_bww_split_kernel<false>, lds, "mode_sphere_conv_bwd_weight_win_split");
+        if (rc != MODE_OK) return rc;
+        hipLaunchKernelGGL(sphere_bww_split_kernel<false>, dim3(S, NCG, d.G * d.MG), dim3(NTHREADS), lds, st, gys, xs, workspace, d,
+                           reinterpret_cast<const int4*>(tiles) + n_wrap + n_mid, reinterpret_cast<const float4*>(rec_w), rec_off, n_small, S,
+                           amax_g, amax_x);
+      }
     } else {
       const size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
       rc = mode::allow_lds(sphere_bww_win_kernel, lds, "mode_sphere_conv_bwd_weight_win");

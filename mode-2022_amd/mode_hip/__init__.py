@@ -55,6 +55,8 @@ SIGNATURES = {
                                         [_c_ptr] * 3),
     'mode_sphere_conv_bwd_weight_win_split': (_c_int, [_c_ptr] * 6 + [_c_int] * 3 + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 9 +
                                               [_c_ptr] * 3),
+    'mode_sphere_conv_bwd_weight_win_split_f16': (_c_int, [_c_ptr] * 8 + [_c_int] * 3 + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 9 +
+                                                  [_c_ptr] * 3),
     'mode_sphere_conv_bwd_weight_workspace_bytes': (_c_size, [_c_int] * 8),
     'mode_sphere_conv_bwd_weight': (_c_int, [_c_ptr] * 5 + [_c_int] * 12 + [_c_ptr]),
     'mode_sphere_conv_fwd_bn': (_c_int, [_c_ptr] * 6 + [_c_int] * 12 + [_c_ptr]),

@@ -610,6 +610,19 @@ SPHERE_BWD_WEIGHT_SPLIT = True  # compact-window tiles of the weight gradient on
 
 def _bww_win_entry():
   return 'mode_sphere_conv_bwd_weight_win_split' if (CONV_ARITH == 'bf16x6' and SPHERE_BWD_WEIGHT_SPLIT) else 'mode_sphere_conv_bwd_weight_win'
+
+
+def _bww_f16_maxima(gy, x, gy_src=None, x_src=None):
+  """(max |gy|, max |x|) buffers for the fp16 arithmetic of the windowed weight gradient (mode_sphere_conv_bwd_weight_win_split_f16), or
+  None when it does not apply.  gy_src / x_src: the tensors the given ones are plane-transposed copies of (same values, maybe tagged)."""
+  if not (SPHERE_BWD_F16 and CONV_ARITH == 'bf16x6' and SPHERE_BWD_WEIGHT_SPLIT):
+    return None
+  def of(t, src):
+    am = known_abs_max(t)
+    if am is None and src is not None and src is not t:
+      am = known_abs_max(src)
+    return am if am is not None else _tagged_abs_max(t)
+  return (of(gy, gy_src), of(x, x_src))
 SPHERE_BWD_WEIGHT = 'window'  # 'window' (where the table allows) | 'gather'
 
 
@@ -647,7 +660,10 @@ def sphere_conv_bwd_weight(gy, pos, x, gw, stride, groups, x_transposed=None, gy
         gyt = gy_transposed if gy_transposed is not None and tuple(gy_transposed.shape) == (B, Co, Wo, Ho) else transpose_planes(gy)
         xt = x_transposed if x_transposed is not None and tuple(x_transposed.shape) == (B, Ci, W, H) else transpose_planes(x)
       entry = _bww_win_entry()
-      check(getattr(lib(), entry)(ptr(gy), ptr(pos), ptr(x), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
+      amax = _bww_f16_maxima(gyt if gyt is not None else gy, xt if xt is not None else x, gy, x)
+      if amax is not None:
+        entry, amax = entry + '_f16', (ptr(amax[0]), ptr(amax[1]))
+      check(getattr(lib(), entry)(ptr(gy), ptr(pos), ptr(x), *(amax or ()), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w),
                                   ptr(rec_off), ptr(rest), nrest, ptr(pitems) if npol else None, ptr(prw) if npol else None,
                                   ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, G,
                                   ptr(gyt) if gyt is not None else None, ptr(xt) if xt is not None else None,
@@ -789,7 +805,10 @@ def sphere_conv_bwd_weight_t(gyt, pos, xt, gw, groups):
     n = lib().mode_sphere_conv_bwd_weight_win_workspace_bytes(B, Ci, H, W, Co, Kh, Kw, groups, n0, 0, npol)
     ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=gyt.device)
     entry = _bww_win_entry()
-    check(getattr(lib(), entry)(None, ptr(pos), None, ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w), ptr(rec_off),
+    amax = _bww_f16_maxima(gyt, xt)
+    if amax is not None:
+      entry, amax = entry + '_f16', (ptr(amax[0]), ptr(amax[1]))
+    check(getattr(lib(), entry)(None, ptr(pos), None, *(amax or ()), ptr(gw), ptr(ws), ptr(tiles), n0, n1, n2, ptr(rec_w), ptr(rec_off),
                                 ptr(rest), 0, ptr(pitems) if npol else None, ptr(prw) if npol else None,
                                 ptr(pro) if npol else None, npol, B, Ci, H, W, Co, Kh, Kw, groups, ptr(gyt), ptr(xt),
                                 stream_of(gyt)), entry)

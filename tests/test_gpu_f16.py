@@ -292,3 +292,45 @@ def test_sphere_input_gradient_on_two_fp16_pieces_against_float64(ih, iw, B, ci,
   assert e16 <= bound and e16 <= 2 * e3 + 0.1 * bound
   assert torch.equal(got, again), 'not deterministic'
   assert not torch.equal(got, three), 'the fp16 kernel did not run'
+
+
+@pytest.mark.parametrize('case', ['unit variance', 'gradient-sized', 'one outlier'])
+def test_sphere_weight_gradient_on_two_fp16_pieces_against_float64(case, f16_switch):
+  """mode_sphere_conv_bwd_weight_win_split_f16 (compact-window tiles on two fp16 pieces; polar items on three bf16 pieces) against the
+  float64 oracle on a 128 x 64 Cassini grid with groups: the three-piece path's bound (1e-5 of the largest entry), twice its own error
+  plus a tenth of the bound, the same bits in every call, adds to gw."""
+  from oracle import mode_ref, sphere_conv_ref
+  ih, iw, B, ci, co, groups = 64, 128, 2, 64, 64, 2
+  pos = mode_ref.sphere_position(ih, iw, 'Cassini').contiguous()
+  H, W = pos.shape[2:]
+  x = _rand((B, ci, H, W), 931)
+  gy = _rand((B, co, H, W), 932)
+  if case == 'gradient-sized':
+    gy = gy * 1e-7
+  if case == 'one outlier':
+    gy[0, 3, H // 2, W // 2] = 1e4
+    x[1, 5, H // 3, W // 3] = -3e3
+  torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+  _, want = sphere_conv_ref.backward(x.cpu().double(), pos, torch.zeros((co, ci // groups, 3, 3), dtype=torch.float64), gy.cpu().double(),
+                                     (1, 1), (1, 1), (1, 1), groups)
+  pd = pos.to(DEV)
+  xt, gyt = HF.transpose_planes(x), HF.transpose_planes(gy)
+  keep = HF.SPHERE_BWD_F16
+  try:
+    HF.SPHERE_BWD_F16 = True
+    got = HF.sphere_conv_bwd_weight_t(gyt, pd, xt, torch.zeros((co, ci // groups, 3, 3), device=DEV), groups)
+    again = HF.sphere_conv_bwd_weight_t(gyt, pd, xt, torch.zeros((co, ci // groups, 3, 3), device=DEV), groups)
+    twice = HF.sphere_conv_bwd_weight_t(gyt, pd, xt, got.clone(), groups)
+    HF.SPHERE_BWD_F16 = False
+    three = HF.sphere_conv_bwd_weight_t(gyt, pd, xt, torch.zeros((co, ci // groups, 3, 3), device=DEV), groups)
+  finally:
+    HF.SPHERE_BWD_F16 = keep
+  scale = float(want.abs().max())
+  e16 = float((got.cpu().double() - want).abs().max())
+  e3 = float((three.cpu().double() - want).abs().max())
+  print('sphere_conv_bwd_weight %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (|gw| <= %.3g)' %
+        (ci, co, ih, iw, B, groups, case, e16, e3, 1e-5 * scale, scale))
+  assert e16 <= 1e-5 * scale and e16 <= 2 * e3 + 1e-6 * scale
+  assert torch.equal(got, again), 'not deterministic'
+  assert float((twice.cpu().double() - 2 * want).abs().max()) <= 2e-5 * scale, 'adds to gw'
+  assert not torch.equal(got, three), 'the fp16 kernel did not run'
