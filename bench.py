@@ -37,6 +37,7 @@ CONV3D_S1_F16 = True
 # ... and so do the windowed spherical forward and both of its gradients in the training step (functional.SPHERE_FWD_F16 / SPHERE_BWD_F16).
 # Set from --no-sphere-f16.
 SPHERE_FWD_F16 = True
+CONV2D_F16 = True  # (functional.CONV2D_F16: forward and input gradient of the extractor's stride-1 3 x 3 layers; --no-conv2d-f16)
 
 
 def _on_f16_path(label):
@@ -44,7 +45,9 @@ def _on_f16_path(label):
   if CONV3D_S1_F16 and re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight)\[(\d+)->(\d+) s1 ', label) and not re.search(r'->1 ', label):
     return True
   m = re.match(r'sphere_conv_(fwd|bwd_data|bwd_weight)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
-  return bool(SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0)
+  if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
+    return True
+  return bool(CONV2D_F16 and re.match(r'conv2d_(fwd|bwd_data)\[', label))  # (where they are on the split path at all: label_peak asks that first)
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
                 'classif_fwd': 'hbm', 'classif_bwd': 'hbm'}
@@ -85,6 +88,8 @@ def parse():
                        'kernel, instead of two fp16 pieces / three MFMAs with a power-of-two scale per operand tensor (functional.CONV3D_S1_F16)')
   ap.add_argument('--no-sphere-f16', action='store_true',
                   help='A/B: the windowed spherical forward and gradients of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
+  ap.add_argument('--no-conv2d-f16', action='store_true',
+                  help='A/B: forward and input gradient of the stride-1 3 x 3 layers of the training step on three bf16 pieces (functional.CONV2D_F16 = False)')
   ap.add_argument('--no-grad-carriers', action='store_true',
                   help="A/B: autograd's own pairwise accumulation for the tensors with two consumers (functional.GRAD_CARRIERS = False)")
   ap.add_argument('--no-fused-classif', action='store_true',
@@ -519,7 +524,9 @@ def main():
   HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
   HF.CLASSIF_FUSED = not args.no_fused_classif
   HF.GRAD_CARRIERS = not args.no_grad_carriers
-  global CONV3D_S1_F16, SPHERE_FWD_F16
+  global CONV3D_S1_F16, SPHERE_FWD_F16, CONV2D_F16
+  HF.CONV2D_F16 = not args.no_conv2d_f16
+  CONV2D_F16 = HF.CONV2D_F16 and args.conv_arith == 'bf16x6' and args.mode == 'train'
   CONV3D_S1_F16 = HF.CONV3D_S1_F16 = not args.no_conv3d_f16 and args.conv_arith == 'bf16x6'
   HF.SPHERE_FWD_F16 = HF.SPHERE_BWD_F16 = not args.no_sphere_f16
   SPHERE_FWD_F16 = HF.SPHERE_FWD_F16 and args.conv_arith == 'bf16x6' and args.mode == 'train'
@@ -692,7 +699,7 @@ def main():
                                                             'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l' +
                                                             ('; the stride-1 3x3x3 layers of the training step: 2 fp16 pieces with a power-of-two scale '
                                                              'per operand tensor, 3 fp16 MFMAs per product, DESIGN.md 3u' +
-                                                             ('; so do the windowed spherical forward and both of its gradients, 3v)' if SPHERE_FWD_F16 else ')')
+                                                             ('; so do the windowed spherical forward and both of its gradients' + (' and forward / input gradient of the 3x3 layers' if CONV2D_F16 else '') + ', 3v)' if SPHERE_FWD_F16 else ')')
                                                              if CONV3D_S1_F16 else ')')),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),

@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 28 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 29 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -466,6 +466,14 @@ int mode_conv2d_bwd_data_split(const float* gy, const float* w, float* gx, float
  * convolution and the skip (models/submodule.py:36-46, 110-118).  Same predicate as mode_conv2d_bwd_data_split. */
 int mode_conv2d_bwd_data_split_acc(const float* gy, const float* w, const float* acc, float* gx, float* wpack, int B, int Ci, int H, int W,
                                    int Co, int dilation, mode_stream_t stream);
+/* mode_conv2d_fwd_split / mode_conv2d_bwd_data_split(_acc) of a TRAINING step on the two-piece fp16 arithmetic of the stride-1 3-D layers
+ * (two fp16 pieces per value, three MFMAs per product, a power-of-two scale per operand): amax_* = the maximum buffers
+ * (MODE_BN_ABSMAX_FLOATS floats: mode_abs_max, mode_bn_next_out_absmax, mode_bn_next_gy_absmax) of the activation / gradient and of the
+ * weight.  Same predicate (mode_conv2d_split_supported) and workspace; acc may be NULL. */
+int mode_conv2d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B, int Ci,
+                              int H, int W, int Co, int dilation, mode_stream_t stream);
+int mode_conv2d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
+                                   float* wpack, int B, int Ci, int H, int W, int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                                  int dilation, int accumulate, mode_stream_t stream); /* arguments / workspace: mode_conv2d_bwd_weight */
 

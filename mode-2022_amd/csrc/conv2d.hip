@@ -283,6 +283,23 @@ extern "C" int mode_conv2d_bwd_data_split_acc(const float* gy, const float* w, c
                                 acc);
 }
 
+// The two calls of a TRAINING step on the two-piece fp16 arithmetic (conv3d_split.hip): amax_* = the maximum buffers
+// (MODE_BN_ABSMAX_FLOATS floats) of the activation / gradient and of the weight; acc may be NULL.
+extern "C" int mode_conv2d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B,
+                                         int Ci, int H, int W, int Co, int dilation, mode_stream_t stream) {
+  MODE_REQUIRE(amax_x && amax_w, MODE_ERR_BAD_ARG, "mode_conv2d_fwd_split_f16: null maximum");
+  return mode::conv2d_split_run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd_split_f16", nullptr,
+                                nullptr, amax_x, amax_w);
+}
+
+extern "C" int mode_conv2d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc,
+                                              float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                                              mode_stream_t stream) {
+  MODE_REQUIRE(amax_g && amax_w, MODE_ERR_BAD_ARG, "mode_conv2d_bwd_data_split_f16: null maximum");
+  return mode::conv2d_split_run(gy, w, gx, wpack, B, Co, Ci, H, W, dilation, 1, mode::as_stream(stream), "mode_conv2d_bwd_data_split_f16", nullptr,
+                                acc, amax_g, amax_w);
+}
+
 extern "C" int mode_conv2d_fwd(const float* x, const float* w, float* y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
                                mode_stream_t stream) {
   return run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), "mode_conv2d_fwd");

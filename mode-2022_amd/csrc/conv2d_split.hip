@@ -14,6 +14,7 @@
 // chunk stream across tile boundaries, LDS-only barrier: as in conv3d_split.hip.
 #include "common.h"
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -63,12 +64,34 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// ---- F16: the two-piece fp16 arithmetic of conv3d_split.hip for the training step's 3 x 3 layers: two fp16 pieces per value,
+// three v_mfma_f32_32x32x16_f16 per product (lo x hi, hi x lo, hi x hi), a power-of-two scale per operand tensor from its maximum buffer
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float f16_scale_of(float m) {  // as in conv3d_split.hip: m * scale in [2^14, 2^15)
+  const unsigned e = min(max((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu, 64u), 254u);
+  return m == 0.f ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ void split2_f16(float a, float b, uint32_t& p1, uint32_t& p2) {
+  const f32x2 v = {a, b};
+  const f16x2 h1 = __builtin_convertvector(v, f16x2);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+  float ra = a - (float)h1[0], rb = b - (float)h1[1];
+  asm("" : "+v"(ra), "+v"(rb));
+  const f32x2 r = {ra, rb};
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 // wp[(((m * NCHUNK + ch) * 9 + tap) * 3 + piece) * 64 + lane] = 8 bf16: piece of Wsrc(o = m*32 + (lane & 31), c = ch*16 + 8 * (lane >> 5)
 // + j, tap), j = 0..7; zero for o >= rows, c >= K.  flip 0: Wsrc = w[o][c][tap] (forward, w is (rows, K, 9)); flip 1: w[c][o][8 - tap]
 // (input gradient, w is (K, rows, 9)); fold: row o scaled by the folded BatchNorm scale, shifts written behind the fragments.
+template <bool F16>
 __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int K, int MT, int NCHUNK, int flip, int fold,
-                               mode_bn_epilogue bn) {
+                               mode_bn_epilogue bn, const float* __restrict__ amax_w) {
+  const float sw = F16 ? f16_scale_of(mode::absmax_load(amax_w)) : 1.f;
   const long long total = (long long)MT * NCHUNK * 9 * 64;
   if (fold && blockIdx.x == 0) {
     float* shifts = reinterpret_cast<float*>(wp + total * 3);
@@ -89,10 +112,18 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
       v[j] = 0.f;
       if (o < rows && c < K) v[j] = flip ? w[((long long)c * rows + o) * 9 + 8 - tap] : w[((long long)o * K + c) * 9 + tap];
       if (fold == 1 && o < rows) v[j] *= fold_scale(bn, o);
+      if (F16) v[j] *= sw;
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (F16) {
+        split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+        q3[j] = 0u;
+      } else {
+        split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      }
+    }
     uint4* dst = wp + (idx - lane) * 3 + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -101,9 +132,19 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
 }
 
 // EPI: 0 plain store; 1 folded-BatchNorm shift (+ ReLU); 2 shift + residual add (+ ReLU)
-template <int MT, int TH, int DIL, int EPI>
+// F16 (EPI 0 and 2 -- the training step): two fp16 pieces, three MFMAs per product; x is scaled when a tile is staged, the accumulators
+// unscaled in front of the epilogue's additions.  The LDS and weight-fragment layouts keep room for three pieces.
+template <int MT, int TH, int DIL, int EPI, bool F16 = false>
 __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, float* __restrict__ y,
-                                                          S2Dims d, Epi epi) {
+                                                          S2Dims d, Epi epi, const float* __restrict__ amax_x,
+                                                          const float* __restrict__ amax_w) {
+  static_assert(!(F16 && EPI == 1), "the fp16 arithmetic has no folded-BatchNorm epilogue");
+  constexpr int NP = F16 ? 2 : 3;  // pieces per value
+  float sx = 1.f, unscale = 1.f;
+  if (F16) {
+    sx = f16_scale_of(mode::absmax_load(amax_x));
+    unscale = (1.f / sx) * (1.f / f16_scale_of(mode::absmax_load(amax_w)));
+  }
   using G2 = Geo2<TH, DIL>;
   constexpr int R = G2::R, IW = G2::IW, ITEMS = G2::ITEMS, KIT = G2::KIT, PIECE = G2::PIECE, BUF = G2::BUF;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3 pieces][2 octets][PIECE]
@@ -164,10 +205,15 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
     for (int oct = 0; oct < 2; ++oct) {
       uint32_t sq[3][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        split2(ok ? raw[k][8 * oct + 2 * j] : 0.f, ok ? raw[k][8 * oct + 2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = ok ? raw[k][8 * oct + 2 * j] : 0.f, v1 = ok ? raw[k][8 * oct + 2 * j + 1] : 0.f;
+        if constexpr (F16)
+          split2_f16(v0 * sx, v1 * sx, sq[0][j], sq[1][j]);
+        else
+          split2(v0, v1, sq[0][j], sq[1][j], sq[2][j]);
+      }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[(2 * p + oct) * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
+      for (int p = 0; p < NP; ++p) dst[(2 * p + oct) * PIECE] = make_uint4(sq[p][0], sq[p][1], sq[p][2], sq[p][3]);
     }
   };
 
@@ -226,7 +272,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) aring[slot3][m][p] = wq[m * mstride + p * 64];
+      for (int p = 0; p < NP; ++p) aring[slot3][m][p] = wq[m * mstride + p * 64];
   };
 
   if (G > 0) {
@@ -257,7 +303,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bq[0][r][p] = src[2 * p * PIECE + rowpos[r]];
+      for (int p = 0; p < NP; ++p) bq[0][r][p] = src[2 * p * PIECE + rowpos[r]];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) {
@@ -265,7 +311,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bq[(tap + 1) & 1][r][p] = src[2 * p * PIECE + rowpos[r] + toff];
+          for (int p = 0; p < NP; ++p) bq[(tap + 1) & 1][r][p] = src[2 * p * PIECE + rowpos[r] + toff];
       }
       if (tap + 2 < 9)
         load_a((tap + 2) % 3, ch, tap + 2);
@@ -278,21 +324,32 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
         for (int qq = 8 * (i & 1); qq < 8 * (i & 1) + 8; ++qq) addv[m][r][qq] = ep_base[ep_cur[r] + ep_chan[m][qq]];
       }
       if (tap >= 9 - KIT) stage_commit((g + 1) & 1, tap - (9 - KIT));
+      if constexpr (F16) {
+#define MODE_SPLIT_TERM(PA, PB)                                                      \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
+      acc[m][r] = mfma_f16(aring[tap % 3][m][PA], bq[tap & 1][r][PB], acc[m][r]);
+        MODE_SPLIT_TERM(1, 0)
+        MODE_SPLIT_TERM(0, 1)
+        MODE_SPLIT_TERM(0, 0)
+#undef MODE_SPLIT_TERM
+      } else {
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
       acc[m][r] = mfma_bf16(aring[tap % 3][m][PA], bq[tap & 1][r][PB], acc[m][r]);
-      MODE_SPLIT_TERM(2, 0)
-      MODE_SPLIT_TERM(0, 2)
-      MODE_SPLIT_TERM(1, 1)
-      MODE_SPLIT_TERM(1, 0)
-      MODE_SPLIT_TERM(0, 1)
-      MODE_SPLIT_TERM(0, 0)
+        MODE_SPLIT_TERM(2, 0)
+        MODE_SPLIT_TERM(0, 2)
+        MODE_SPLIT_TERM(1, 1)
+        MODE_SPLIT_TERM(1, 0)
+        MODE_SPLIT_TERM(0, 1)
+        MODE_SPLIT_TERM(0, 0)
 #undef MODE_SPLIT_TERM
+      }
+      // (F16: half the MFMAs carry two thirds of the staging work -- twice the vector and LDS instructions beside each)
 #pragma unroll
-      for (int i = 0; i < MT * R * 6; ++i) {
+      for (int i = 0; i < MT * R * (F16 ? 3 : 6); ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, MT * R <= 4 ? 5 : 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (MT * R <= 4 ? 5 : 3) * (F16 ? 2 : 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -326,7 +383,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
             }
             auto emit = [&](int qq) {
               const int o = d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half;
-              float v = acc[m][r][qq];
+              float v = F16 ? acc[m][r][qq] * unscale : acc[m][r][qq];
               if (EPI) v += SHIFT_LATE ? shl[qq] : shiftv[m][qq];
               if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : res[qq];
               yb[(long long)o * HWi + sp] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
@@ -354,33 +411,36 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 }
 
 template <int MT, int TH, int DIL>
-int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st, const char* who, Epi epi) {
+int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st, const char* who, Epi epi, const float* amax_x,
+            const float* amax_w) {
   constexpr size_t LDS = Geo2<TH, DIL>::LDS_BYTES;
   d.nHt = mode::cdiv(d.H, TH);
   d.ntiles = d.B * d.nHt * d.nWt;
   const int grid = kNumCU;
-  if (epi.shift && epi.add) {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 2>, LDS, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 2>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
-  } else if (epi.shift) {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 1>, LDS, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 1>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
-  } else {
-    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, 0>, LDS, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, 0>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi);
+#define MODE_C2D_LAUNCH(EPIV, F16V)                                                                                                  \
+  {                                                                                                                                  \
+    int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, EPIV, F16V>, LDS, who);                                                \
+    if (rc != MODE_OK) return rc;                                                                                                    \
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, EPIV, F16V>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi, amax_x, amax_w); \
   }
+  if (epi.shift && epi.add) {
+    if (amax_x) MODE_C2D_LAUNCH(2, true) else MODE_C2D_LAUNCH(2, false)
+  } else if (epi.shift) {
+    MODE_C2D_LAUNCH(1, false)
+  } else {
+    if (amax_x) MODE_C2D_LAUNCH(0, true) else MODE_C2D_LAUNCH(0, false)
+  }
+#undef MODE_C2D_LAUNCH
   return mode::check_launch(who);
 }
 
 template <int MT>
-int launch_tile(const float* x, const uint4* wp, float* y, const S2Dims& d, int dilation, hipStream_t st, const char* who, Epi epi) {
+int launch_tile(const float* x, const uint4* wp, float* y, const S2Dims& d, int dilation, hipStream_t st, const char* who, Epi epi,
+                const float* ax, const float* aw) {
   // 16-row tiles unless that leaves fewer than two tiles per CU (a workgroup's first chunk is staged un-overlapped)
   const bool big = (long long)d.B * mode::cdiv(d.H, 16) * d.nWt >= 2 * kNumCU;
-  if (dilation == 1) return big ? launch2<MT, 16, 1>(x, wp, y, d, st, who, epi) : launch2<MT, 8, 1>(x, wp, y, d, st, who, epi);
-  return big ? launch2<MT, 16, 2>(x, wp, y, d, st, who, epi) : launch2<MT, 8, 2>(x, wp, y, d, st, who, epi);
+  if (dilation == 1) return big ? launch2<MT, 16, 1>(x, wp, y, d, st, who, epi, ax, aw) : launch2<MT, 8, 1>(x, wp, y, d, st, who, epi, ax, aw);
+  return big ? launch2<MT, 16, 2>(x, wp, y, d, st, who, epi, ax, aw) : launch2<MT, 8, 2>(x, wp, y, d, st, who, epi, ax, aw);
 }
 
 }  // namespace
@@ -397,8 +457,11 @@ bool conv2d_split_supported(int K, int rows, int dilation) {
 
 // rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels; flip 0 / 1 as pack_w2d_split
 int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
-                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in) {
+                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in, const float* amax_x,
+                     const float* amax_w) {
   MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
+  MODE_REQUIRE((amax_x == nullptr) == (amax_w == nullptr) && !(amax_x && bn), MODE_ERR_BAD_ARG,
+               "%s: the fp16 arithmetic takes both operand maxima and no BatchNorm epilogue", who);
   MODE_REQUIRE(!(acc_in && bn), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue", who);
   MODE_REQUIRE(!acc_in || acc_in != y, MODE_ERR_BAD_ARG, "%s: acc must not be the output tensor", who);
   MODE_REQUIRE(conv2d_split_supported(K, rows, dilation), MODE_ERR_UNSUPPORTED,
@@ -413,8 +476,14 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
   const int MT = cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
   uint4* wp = reinterpret_cast<uint4*>(wpack);
-  if (mode::pack_needed()) hipLaunchKernelGGL(pack_w2d_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, bn ? 1 : acc_in ? 2 : 0,
-                     bn ? *bn : mode_bn_epilogue());
+  if (mode::pack_needed()) {
+    if (amax_x)
+      hipLaunchKernelGGL(pack_w2d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, acc_in ? 2 : 0,
+                         mode_bn_epilogue(), amax_w);
+    else
+      hipLaunchKernelGGL(pack_w2d_split<false>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip,
+                         bn ? 1 : acc_in ? 2 : 0, bn ? *bn : mode_bn_epilogue(), (const float*)nullptr);
+  }
   Epi epi = make_epi(bn, wpack + npack * 3 * 4);
   if (acc_in) {  // y = conv(x) + acc_in: the residual epilogue with zero shifts ((v + 0) + a is a + v exactly)
     epi.shift = wpack + npack * 3 * 4;
@@ -426,7 +495,8 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
     d.o0 = 32 * m;
     const uint4* wpm = wp + (long long)m * d.NCHUNK * 9 * 192;
     int rc;
-    rc = m + 1 < MT ? launch_tile<2>(x, wpm, y, d, dilation, st, who, epi) : launch_tile<1>(x, wpm, y, d, dilation, st, who, epi);
+    rc = m + 1 < MT ? launch_tile<2>(x, wpm, y, d, dilation, st, who, epi, amax_x, amax_w)
+                    : launch_tile<1>(x, wpm, y, d, dilation, st, who, epi, amax_x, amax_w);
     if (rc != MODE_OK) return rc;
   }
   return MODE_OK;

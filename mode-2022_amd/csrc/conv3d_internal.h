@@ -78,7 +78,8 @@ int conv3d_bww_s2_split_launch(const float* gy, const float* x, float* part, con
 bool conv2d_split_supported(int K, int rows, int dilation);
 size_t conv2d_split_wpack_floats(int K, int rows);
 int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
-                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in = nullptr);  // acc_in: y = conv(x) + acc_in
+                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in = nullptr,
+                     const float* amax_x = nullptr, const float* amax_w = nullptr);  // (maxima: the two-piece fp16 arithmetic)  // acc_in: y = conv(x) + acc_in
 
 // conv2d_split_wgrad.hip: split-K partials of the 3x3 Conv2d weight gradient on the split-bf16 path, in the layout of conv2d_wgrad.hip
 // (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.

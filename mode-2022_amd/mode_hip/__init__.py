@@ -95,6 +95,8 @@ SIGNATURES = {
     'mode_conv2d_fwd_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data_split_acc': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv2d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv2d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_split_supported': (_c_int, [_c_int] * 4),
     'mode_conv3d_fwd_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
@@ -142,7 +144,7 @@ SIGNATURES = {
                           [ctypes.c_longlong, _c_int, _c_ptr]),
 }
 
-ABI_VERSION = 28  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 29  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

@@ -162,7 +162,14 @@ def conv2d_wgrad_supported(x, w):
   return max(w.shape[0], w.shape[1]) * x.shape[2] * x.shape[3] < 2**29
 
 
-def _conv2d_run(entry, name, src, w, out_channels, dilation):
+CONV2D_F16 = True  # forward and input gradient of the 3 x 3 layers of a TRAINING step on two fp16 pieces / three MFMAs per product
+
+
+def _conv2d_f16(f16):
+  return bool(f16) and CONV2D_F16 and CONV_ARITH == 'bf16x6'
+
+
+def _conv2d_run(entry, name, src, w, out_channels, dilation, f16=False):
   require_gpu(src, w)
   require_f32c(src, w)
   B, _, H, W = src.shape
@@ -175,7 +182,15 @@ def _conv2d_run(entry, name, src, w, out_channels, dilation):
     wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=src.device)
     which = int(entry == 'mode_conv2d_bwd_data')
     if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, which) == 1:
-      if which:
+      if _conv2d_f16(f16):
+        am = (ptr(_tagged_abs_max(src)), ptr(_tagged_abs_max(w)))
+        if which:
+          check(lib().mode_conv2d_bwd_data_split_f16(ptr(src), ptr(w), am[0], am[1], None, ptr(out), ptr(wp), B, Ci, H, W, Co, dilation,
+                                                     stream_of(src)), 'mode_conv2d_bwd_data_split_f16')
+        else:
+          check(lib().mode_conv2d_fwd_split_f16(ptr(src), ptr(w), am[0], am[1], ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)),
+                'mode_conv2d_fwd_split_f16')
+      elif which:
         check(lib().mode_conv2d_bwd_data_split(ptr(src), ptr(w), ptr(out), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(src)),
               'mode_conv2d_bwd_data_split')
       else:
@@ -186,27 +201,33 @@ def _conv2d_run(entry, name, src, w, out_channels, dilation):
   return out
 
 
-def conv2d_fwd(x, w, dilation=1):
-  return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation)
+def conv2d_fwd(x, w, dilation=1, f16=False):
+  """f16: the caller is a training step (Conv2d3x3Function with gradients being recorded): the split kernel may use the fp16 arithmetic."""
+  return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation, f16)
 
 
-def conv2d_bwd_data(gy, w, dilation=1, acc=None):
-  """acc: a gradient of the same tensor that is already there; the sum is returned (added in the split kernel's store where it runs)."""
+def conv2d_bwd_data(gy, w, dilation=1, acc=None, f16=True):
+  """acc: a gradient of the same tensor that is already there; the sum is returned (added in the split kernel's store where it runs).
+  (A backward pass is a training step: the fp16 arithmetic where CONV2D_F16 says so.)"""
   if acc is None:
-    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation)
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation, f16)
   require_gpu(gy, w, acc)
   acc = acc.contiguous()
   require_f32c(gy, w, acc)
   B, _, H, W = gy.shape
   Co, Ci = w.shape[:2]
   if not (CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 1) == 1 and tuple(acc.shape) == (B, Ci, H, W)):
-    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, Ci, dilation).add_(acc)
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, Ci, dilation, f16).add_(acc)
   gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device)
   with torch.cuda.device_of(gy), profiling.region('conv2d_bwd_data[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED else 'conv2d_bwd_data',
                                                   4 * (gy.numel() + 2 * gx.numel() + w.numel()), 2 * B * H * W * Ci * Co * 9, gy.device):
     wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=gy.device)
-    check(lib().mode_conv2d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(gy)),
-          'mode_conv2d_bwd_data_split_acc')
+    if _conv2d_f16(f16):
+      check(lib().mode_conv2d_bwd_data_split_f16(ptr(gy), ptr(w), ptr(_tagged_abs_max(gy)), ptr(_tagged_abs_max(w)), ptr(acc), ptr(gx), ptr(wp),
+                                                 B, Ci, H, W, Co, dilation, stream_of(gy)), 'mode_conv2d_bwd_data_split_f16')
+    else:
+      check(lib().mode_conv2d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(gy)),
+            'mode_conv2d_bwd_data_split_acc')
   return gx
 
 
@@ -216,13 +237,13 @@ class Conv2d3x3Function(torch.autograd.Function):
   faster (_conv2d_own), else on the vendor library's fp32 Winograd."""
 
   @staticmethod
-  def forward(ctx, x, w, dilation, carrier=None):
+  def forward(ctx, x, w, dilation, carrier=None, training=False):
     ctx.save_for_backward(x, w)
     ctx.dilation = dilation
     ctx.carrier = carrier  # GradCarrier of x (x has one other consumer: the skip of its residual block), or None
     ctx.own = _conv2d_own(x, w)
     if ctx.own:
-      return conv2d_fwd(x, w.contiguous(), dilation)
+      return conv2d_fwd(x, w.contiguous(), dilation, f16=training)  # (training: gradients are being recorded -- set by conv2d_3x3)
     return torch.nn.functional.conv2d(x, w, None, 1, dilation, dilation)
 
   @staticmethod
@@ -248,14 +269,14 @@ class Conv2d3x3Function(torch.autograd.Function):
       gw = conv2d_bwd_weight(gy, x.contiguous(), dil, into=sink)
       if sink is not None:
         gw = None
-    return gx, gw, None, None
+    return gx, gw, None, None, None
 
 
 def conv2d_3x3(x, w, dilation=1, carrier=None):
   """Callers check conv2d_wgrad_supported(x, w) first (models/stage3d.conv3 does)."""
   if carrier is not None:
     carrier.arm(x.requires_grad and torch.is_grad_enabled())
-  return Conv2d3x3Function.apply(x, w, dilation, carrier)
+  return Conv2d3x3Function.apply(x, w, dilation, carrier, torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
 
 
 # ------------------------------------------------------------------------------------ cost volume + dres0[0][0], fused

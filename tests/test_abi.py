@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 28
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 29
 
 
 def test_argument_validation_without_gpu():

@@ -334,3 +334,51 @@ def test_sphere_weight_gradient_on_two_fp16_pieces_against_float64(case, f16_swi
   assert torch.equal(got, again), 'not deterministic'
   assert float((twice.cpu().double() - 2 * want).abs().max()) <= 2e-5 * scale, 'adds to gw'
   assert not torch.equal(got, three), 'the fp16 kernel did not run'
+
+
+# ------------------------------------------------------------------------------------------------ the extractor's 3 x 3 layers
+@pytest.mark.parametrize('B,Ci,Co,H,W,dil', [(2, 32, 32, 40, 70, 1), (1, 64, 128, 33, 64, 1), (2, 128, 128, 24, 48, 2), (1, 16, 40, 9, 31, 2)])
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_on_two_fp16_pieces_against_float64(B, Ci, Co, H, W, dil, case, f16_switch):
+  """mode_conv2d_fwd_split_f16 / mode_conv2d_bwd_data_split_f16 (the stride-1 3 x 3 layers of the extractor in a training step) against
+  torch's float64 convolution: the three-piece path's bound (2^-22 sqrt(terms) 8 of the largest output) and twice its own error plus a
+  tenth of the bound; a gradient that is already there is added in the store bit for bit; deterministic; inference calls unchanged."""
+  x = _rand((B, Ci, H, W), 941)
+  w = _rand((Co, Ci, 3, 3), 942, 0.05)
+  gy = _rand((B, Co, H, W), 943)
+  if case == 'six decades along a row':
+    x = x * torch.logspace(-3, 3, W, device=DEV).view(1, 1, 1, W)
+    gy = gy * torch.logspace(3, -3, W, device=DEV).view(1, 1, 1, W)
+  if case == 'gradient-sized':
+    x, gy = x * 1e-7, gy * 1e-7
+  if case == 'one outlier':
+    x[0, 0, H // 2, W // 2] = 1e4
+    gy[0, 1, H // 3, W // 3] = -1e4
+  xa = x.double().requires_grad_(True)
+  want = F.conv2d(xa, w.double(), None, 1, dil, dil)
+  want.backward(gy.double())
+  want, want_gx = want.detach(), xa.grad
+  keep = HF.CONV2D_F16
+  try:
+    HF.CONV2D_F16 = True
+    y = HF.conv2d_fwd(x, w, dil, f16=True)
+    y_inf = HF.conv2d_fwd(x, w, dil)
+    gx = HF.conv2d_bwd_data(gy, w, dil)
+    acc = _rand((B, Ci, H, W), 944, float(want_gx.abs().max()))
+    gx_acc = HF.conv2d_bwd_data(gy, w, dil, acc=acc)
+    again = (HF.conv2d_fwd(x, w, dil, f16=True), HF.conv2d_bwd_data(gy, w, dil))
+    HF.CONV2D_F16 = False
+    y3, gx3 = HF.conv2d_fwd(x, w, dil, f16=True), HF.conv2d_bwd_data(gy, w, dil)
+  finally:
+    HF.CONV2D_F16 = keep
+  for which, (name, got, three, ref, terms) in enumerate((('fwd', y, y3, want, 9 * Ci), ('bwd_data', gx, gx3, want_gx, 9 * Co))):
+    bound = 2.0**-22 * np.sqrt(terms) * 8 * float(ref.abs().max())
+    e16, e3 = float((got.double() - ref).abs().max()), float((three.double() - ref).abs().max())
+    print('conv2d %s %s [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e' % (name, (B, Ci, Co, H, W, dil), case, e16, e3, bound))
+    assert e16 <= bound and e16 <= 2 * e3 + 0.1 * bound, (name, case)
+    # (16 reduction channels per MFMA: a gradient over 40 output channels stays on the fp32 kernel in both arithmetics)
+    on_split = mode_hip.lib().mode_conv2d_split_supported(Ci, Co, dil, which) == 1
+    assert torch.equal(got, three) != on_split, 'the fp16 kernel did not run'
+  assert torch.equal(y_inf, y3), 'an inference call must not change'
+  assert torch.equal(gx_acc, gx + acc), 'the accumulate form adds in the store, bit for bit'
+  assert torch.equal(y, again[0]) and torch.equal(gx, again[1]), 'not deterministic'
