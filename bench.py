@@ -47,7 +47,7 @@ def _on_f16_path(label):
   m = re.match(r'sphere_conv_(fwd|bwd_data|bwd_weight)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
   if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
     return True
-  return bool(CONV2D_F16 and re.match(r'conv2d_(fwd|bwd_data)\[', label))  # (where they are on the split path at all: label_peak asks that first)
+  return bool(CONV2D_F16 and re.match(r'conv2d_(fwd|bwd_data|bwd_weight)\[', label))  # (where they are on the split path at all: label_peak asks that first)
 KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
                 'classif_fwd': 'hbm', 'classif_bwd': 'hbm'}
@@ -89,7 +89,7 @@ def parse():
   ap.add_argument('--no-sphere-f16', action='store_true',
                   help='A/B: the windowed spherical forward and gradients of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
   ap.add_argument('--no-conv2d-f16', action='store_true',
-                  help='A/B: forward and input gradient of the stride-1 3 x 3 layers of the training step on three bf16 pieces (functional.CONV2D_F16 = False)')
+                  help='A/B: the stride-1 3 x 3 layers of the training step (forward and both gradients) on three bf16 pieces (functional.CONV2D_F16 = False)')
   ap.add_argument('--no-grad-carriers', action='store_true',
                   help="A/B: autograd's own pairwise accumulation for the tensors with two consumers (functional.GRAD_CARRIERS = False)")
   ap.add_argument('--no-fused-classif', action='store_true',
@@ -699,7 +699,7 @@ def main():
                                                             'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l' +
                                                             ('; the stride-1 3x3x3 layers of the training step: 2 fp16 pieces with a power-of-two scale '
                                                              'per operand tensor, 3 fp16 MFMAs per product, DESIGN.md 3u' +
-                                                             ('; so do the windowed spherical forward and both of its gradients' + (' and forward / input gradient of the 3x3 layers' if CONV2D_F16 else '') + ', 3v)' if SPHERE_FWD_F16 else ')')
+                                                             ('; so do the windowed spherical forward and both of its gradients' + (' and the 3x3 layers of the extractor' if CONV2D_F16 else '') + ', 3v)' if SPHERE_FWD_F16 else ')')
                                                              if CONV3D_S1_F16 else ')')),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),

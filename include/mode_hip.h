@@ -475,7 +475,10 @@ int mode_conv2d_fwd_split_f16(const float* x, const float* w, const float* amax_
 int mode_conv2d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
                                    float* wpack, int B, int Ci, int H, int W, int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
-                                 int dilation, int accumulate, mode_stream_t stream); /* arguments / workspace: mode_conv2d_bwd_weight */
+                                 int dilation, int accumulate, mode_stream_t stream);
+/* ... on the two-piece fp16 arithmetic (mode_conv2d_fwd_split_f16): amax_g / amax_x = the maximum buffers of gy and of x. */
+int mode_conv2d_bwd_weight_split_f16(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace,
+                                     int B, int Ci, int H, int W, int Co, int dilation, int accumulate, mode_stream_t stream); /* arguments / workspace: mode_conv2d_bwd_weight */
 
 size_t mode_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int D, int H, int W, int Co, int stride);
 

@@ -15,6 +15,7 @@
 // with the fp32 kernel (conv2d_wgrad.hip).
 #include "common.h"
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -57,10 +58,38 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ---- F16: the two-piece fp16 arithmetic of conv3d_split_wgrad.hip: both operands scaled by their tensor's power of two
+// when staged, three v_mfma_f32_32x32x16_f16 per product, the block's sums unscaled when they are written
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float f16_scale_of(float m) {  // as in conv3d_split.hip: m * scale in [2^14, 2^15)
+  const unsigned e = min(max((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu, 64u), 254u);
+  return m == 0.f ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ void split2_f16(float a, float b, uint32_t& p1, uint32_t& p2) {
+  const f32x2 v = {a, b};
+  const f16x2 h1 = __builtin_convertvector(v, f16x2);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+  float ra = a - (float)h1[0], rb = b - (float)h1[1];
+  asm("" : "+v"(ra), "+v"(rb));
+  const f32x2 r = {ra, rb};
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
-template <int DIL>
+template <int DIL, bool F16>
 __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                              float* __restrict__ part, mode::Wgrad2SplitDims d) {
+                                                              float* __restrict__ part, mode::Wgrad2SplitDims d,
+                                                              const float* __restrict__ amax_g, const float* __restrict__ amax_x) {
+  constexpr int NPC = F16 ? 2 : 3;                     // pieces per value
+  float sg = 1.f, sx = 1.f, unscale = 1.f;
+  if (F16) {
+    sg = f16_scale_of(mode::absmax_load(amax_g));
+    sx = f16_scale_of(mode::absmax_load(amax_x));
+    unscale = (1.f / sg) * (1.f / sx);
+  }
   constexpr int NP = (32 + 2 * DIL) / 2;               // pixel pairs per staged x row
   constexpr int XIT = (32 * 4 * NP + NT - 1) / NT;     // 9 pairs of 4 x rows per thread
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -132,13 +161,18 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
   auto commit_x = [&](int k, int r0, int slot0) {
     const unsigned rok = (unsigned)((unsigned)(r0 + x_row[k]) < (unsigned)d.H);
     uint32_t p1, p2, p3;
-    split2((rok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, (rok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f, p1, p2, p3);
+    const float v0 = (rok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, v1 = (rok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f;
     int sl = slot0 + x_row[k];
     sl = sl >= RING ? sl - RING : sl;
     uint32_t* dst = reinterpret_cast<uint32_t*>(xl + xdst[k] + sl * XROWP);
+    if constexpr (F16) {
+      split2_f16(v0 * sx, v1 * sx, p1, p2);
+    } else {
+      split2(v0, v1, p1, p2, p3);
+      dst[XPIECE] = p3;
+    }
     dst[0] = p1;  // (threads beyond the last item repeat it: same address, same value)
     dst[XPIECE / 2] = p2;
-    dst[XPIECE] = p3;
   };
   auto load_g = [&](int k, int r0) {
     const unsigned ro = 4u * (unsigned)(min(r0 + g_row[k], d.H - 1) * d.W);
@@ -148,11 +182,16 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
   auto commit_g = [&](int k, int r0, int buf) {
     const unsigned rok = (unsigned)(r0 + g_row[k] < d.H);
     uint32_t p1, p2, p3;
-    split2((rok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, (rok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f, p1, p2, p3);
+    const float v0 = (rok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, v1 = (rok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f;
     uint32_t* dst = reinterpret_cast<uint32_t*>(gl + buf * GBUF + gdst[k]);
+    if constexpr (F16) {
+      split2_f16(v0 * sg, v1 * sg, p1, p2);
+    } else {
+      split2(v0, v1, p1, p2, p3);
+      dst[GPIECE] = p3;
+    }
     dst[0] = p1;
     dst[GPIECE / 2] = p2;
-    dst[GPIECE] = p3;
   };
 
   for (int u = xcd_remap(s, d.S); u < d.units; u += d.S) {
@@ -203,7 +242,7 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
       auto read_stage = [&](int i) {
         const int ks = i / 3, kh = i % 3;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPC; ++p) {
           if (kh == 0) ra[ks][p] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ga + p * GPIECE + 16 * ks, 16));
           const uint32_t* src = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(xl + xrow[kh] + p * XPIECE + 16 * ks, 16));
           rlo[i & 1][p] = *reinterpret_cast<const uint4*>(src);
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
         }
         uint4 bq[3][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPC; ++p) {
           const uint4 lo = rlo[i & 1][p];
           const uint2 hi = rhi[i & 1][p];
           const uint32_t dw[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
@@ -250,21 +289,31 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
             }
           }
         }
+        if constexpr (F16) {
+#define MODE_SPLIT_TERM(PA, PB) \
+  _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) acc[3 * kh + kw] = mfma_f16(ra[ks][PA], bq[kw][PB], acc[3 * kh + kw]);
+          MODE_SPLIT_TERM(1, 0)
+          MODE_SPLIT_TERM(0, 1)
+          MODE_SPLIT_TERM(0, 0)
+#undef MODE_SPLIT_TERM
+        } else {
 #define MODE_SPLIT_TERM(PA, PB) \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) acc[3 * kh + kw] = mfma_bf16(ra[ks][PA], bq[kw][PB], acc[3 * kh + kw]);
-        MODE_SPLIT_TERM(2, 0)
-        MODE_SPLIT_TERM(0, 2)
-        MODE_SPLIT_TERM(1, 1)
-        MODE_SPLIT_TERM(1, 0)
-        MODE_SPLIT_TERM(0, 1)
-        MODE_SPLIT_TERM(0, 0)
+          MODE_SPLIT_TERM(2, 0)
+          MODE_SPLIT_TERM(0, 2)
+          MODE_SPLIT_TERM(1, 1)
+          MODE_SPLIT_TERM(1, 0)
+          MODE_SPLIT_TERM(0, 1)
+          MODE_SPLIT_TERM(0, 0)
 #undef MODE_SPLIT_TERM
+        }
+        // (F16: half the MFMAs carry two thirds of the staging work of a stage)
 #pragma unroll
-        for (int j = 0; j < 18; ++j) {
+        for (int j = 0; j < (F16 ? 9 : 18); ++j) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 12 : 7, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, F16 ? 3 : 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -291,7 +340,7 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
         const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
         const float v = ((acc[tap][q] + sums[tap * 1024 + q * 64 + lane]) + sums[(9 + tap) * 1024 + q * 64 + lane]) +
                         sums[(18 + tap) * 1024 + q * 64 + lane];
-        pb[tap * 1024 + i * 32 + (lane & 31)] = v;
+        pb[tap * 1024 + i * 32 + (lane & 31)] = F16 ? v * unscale : v;
       }
   }
 }
@@ -301,16 +350,20 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
 namespace mode {
 
 int conv2d_bww_split_launch(const float* gy, const float* x, float* part, const Wgrad2SplitDims& d, int dilation, hipStream_t st,
-                            const char* who) {
-  if (dilation == 1) {
-    int rc = allow_lds(conv2d_bww_split_kernel<1>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(conv2d_bww_split_kernel<1>, dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d);
-  } else {
-    int rc = allow_lds(conv2d_bww_split_kernel<2>, LDS_BYTES, who);
-    if (rc != MODE_OK) return rc;
-    hipLaunchKernelGGL(conv2d_bww_split_kernel<2>, dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d);
+                            const char* who, const float* amax_g, const float* amax_x) {
+#define MODE_C2W_LAUNCH(DILV, F16V)                                                                                              \
+  {                                                                                                                              \
+    int rc = allow_lds(conv2d_bww_split_kernel<DILV, F16V>, LDS_BYTES, who);                                                     \
+    if (rc != MODE_OK) return rc;                                                                                                \
+    hipLaunchKernelGGL((conv2d_bww_split_kernel<DILV, F16V>), dim3(d.S, d.MTo, d.MTc), dim3(NT), LDS_BYTES, st, gy, x, part, d, amax_g, \
+                       amax_x);                                                                                                  \
   }
+  if (dilation == 1) {
+    if (amax_g) MODE_C2W_LAUNCH(1, true) else MODE_C2W_LAUNCH(1, false)
+  } else {
+    if (amax_g) MODE_C2W_LAUNCH(2, true) else MODE_C2W_LAUNCH(2, false)
+  }
+#undef MODE_C2W_LAUNCH
   return check_launch(who);
 }
 

@@ -279,9 +279,26 @@ extern "C" int mode_conv2d_bwd_weight(const float* gy, const float* x, float* gw
   return mode::check_launch("mode_conv2d_bwd_weight(reduce)");
 }
 
+static int conv2d_bwd_weight_split(const char* who, const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw,
+                                   float* workspace, int B, int Ci, int H, int W, int Co, int dilation, int accumulate, mode_stream_t stream);
+
 extern "C" int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                                             int dilation, int accumulate, mode_stream_t stream) {
-  const char* who = "mode_conv2d_bwd_weight_split";
+  return conv2d_bwd_weight_split("mode_conv2d_bwd_weight_split", gy, x, nullptr, nullptr, gw, workspace, B, Ci, H, W, Co, dilation, accumulate,
+                                 stream);
+}
+
+// The same on the two-piece fp16 arithmetic (mode_conv2d_fwd_split_f16): amax_g / amax_x = the maximum buffers of gy and of x.
+extern "C" int mode_conv2d_bwd_weight_split_f16(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw,
+                                                float* workspace, int B, int Ci, int H, int W, int Co, int dilation, int accumulate,
+                                                mode_stream_t stream) {
+  MODE_REQUIRE(amax_g && amax_x, MODE_ERR_BAD_ARG, "mode_conv2d_bwd_weight_split_f16: null maximum");
+  return conv2d_bwd_weight_split("mode_conv2d_bwd_weight_split_f16", gy, x, amax_g, amax_x, gw, workspace, B, Ci, H, W, Co, dilation, accumulate,
+                                 stream);
+}
+
+static int conv2d_bwd_weight_split(const char* who, const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw,
+                                   float* workspace, int B, int Ci, int H, int W, int Co, int dilation, int accumulate, mode_stream_t stream) {
   MODE_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
   MODE_REQUIRE(dilation == 1 || dilation == 2, MODE_ERR_UNSUPPORTED, "%s: dilation %d not implemented (1 or 2)", who, dilation);
   MODE_REQUIRE((long long)std::max(Ci, Co) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
@@ -308,7 +325,7 @@ extern "C" int mode_conv2d_bwd_weight_split(const float* gy, const float* x, flo
   if (S > q.units) S = q.units;
   if (S > d.S) S = d.S;  // never more slices than the workspace query assumed
   q.S = d.S = S;
-  int rc = mode::conv2d_bww_split_launch(gy, x, workspace, q, dilation, st, who);
+  int rc = mode::conv2d_bww_split_launch(gy, x, workspace, q, dilation, st, who, amax_g, amax_x);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(reduce_gw2d, dim3(mode::cdiv((long long)d.MTo * d.MTc * 9 * 1024, 32)), dim3(256), 0, st, workspace, gw, d, accumulate);
   return mode::check_launch("mode_conv2d_bwd_weight_split(reduce)");

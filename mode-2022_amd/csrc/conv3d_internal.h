@@ -89,6 +89,6 @@ struct Wgrad2SplitDims {
   int S, MTo, MTc;
 };
 int conv2d_bww_split_launch(const float* gy, const float* x, float* part, const Wgrad2SplitDims& d, int dilation, hipStream_t st,
-                            const char* who);
+                            const char* who, const float* amax_g = nullptr, const float* amax_x = nullptr);
 
 }  // namespace mode

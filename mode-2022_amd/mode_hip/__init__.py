@@ -98,6 +98,7 @@ SIGNATURES = {
     'mode_conv2d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
+    'mode_conv2d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_split_supported': (_c_int, [_c_int] * 4),
     'mode_conv3d_fwd_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_fwd_s2_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),

@@ -140,7 +140,10 @@ def conv2d_bwd_weight(gy, x, dilation=1, into=None):
                                                  else 'conv2d_bwd_weight', nbytes, flops, x.device):
     ws = torch.empty(max(lib().mode_conv2d_bwd_weight_workspace_bytes(B, Ci, H, W, Co) // 4, 1), dtype=torch.float32, device=x.device)
     entry = 'mode_conv2d_bwd_weight_split' if CONV_ARITH == 'bf16x6' else 'mode_conv2d_bwd_weight'  # (any channel counts: masked blocks)
-    check(getattr(lib(), entry)(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, H, W, Co, dilation, 1 if into is not None else 0, stream_of(x)),
+    am = ()
+    if _conv2d_f16(True):  # (a weight gradient is a training step: the two-piece fp16 arithmetic)
+      entry, am = entry + '_f16', (ptr(_tagged_abs_max(gy)), ptr(_tagged_abs_max(x)))
+    check(getattr(lib(), entry)(ptr(gy), ptr(x), *am, ptr(gw), ptr(ws), B, Ci, H, W, Co, dilation, 1 if into is not None else 0, stream_of(x)),
           entry)
   return gw
 

@@ -52,7 +52,7 @@ def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
   monkeypatch.setattr(bench, 'CONV2D_F16', True)  # (functional.CONV2D_F16: the extractor's 3 x 3 layers, forward and input gradient)
   assert bench.label_peak('conv2d_fwd[64->64 d1 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('conv2d_bwd_data[128->128 d2 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
-  assert bench.label_peak('conv2d_bwd_weight[128->128 d2 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  assert bench.label_peak('conv2d_bwd_weight[128->128 d2 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('conv2d_bn_eval[64->64 d1 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
   assert bench.label_peak('sphere_conv_fwd[32->288 256x128]', 'bf16x6', lambda l: False)[1] == 157.3  # (the integer-table layers: gather kernels)
   assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true>'

@@ -369,8 +369,21 @@ def test_conv2d_on_two_fp16_pieces_against_float64(B, Ci, Co, H, W, dil, case, f
     again = (HF.conv2d_fwd(x, w, dil, f16=True), HF.conv2d_bwd_data(gy, w, dil))
     HF.CONV2D_F16 = False
     y3, gx3 = HF.conv2d_fwd(x, w, dil, f16=True), HF.conv2d_bwd_data(gy, w, dil)
+    gw3 = HF.conv2d_bwd_weight(gy, x, dil)
+    HF.CONV2D_F16 = True
+    gw = HF.conv2d_bwd_weight(gy, x, dil)
+    gw_again = HF.conv2d_bwd_weight(gy, x, dil)
+    gw_into = HF.conv2d_bwd_weight(gy, x, dil, into=torch.ones_like(gw))
   finally:
     HF.CONV2D_F16 = keep
+  wa = torch.zeros((Co, Ci, 3, 3), dtype=torch.float64, device=DEV, requires_grad=True)
+  F.conv2d(x.double(), wa, None, 1, dil, dil).backward(gy.double())
+  scale = float(wa.grad.abs().max())
+  ew, ew3 = float((gw.double() - wa.grad).abs().max()), float((gw3.double() - wa.grad).abs().max())
+  print('conv2d bwd_weight %s [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e' % ((B, Ci, Co, H, W, dil), case, ew, ew3, 2e-5 * scale))
+  assert ew <= 2e-5 * scale and ew <= 2 * ew3 + 2e-6 * scale
+  assert torch.equal(gw, gw_again) and not torch.equal(gw, gw3)
+  assert float((gw_into - (gw + 1.0)).abs().max()) <= 1e-5 * max(1.0, scale), 'accumulating form'
   for which, (name, got, three, ref, terms) in enumerate((('fwd', y, y3, want, 9 * Ci), ('bwd_data', gx, gx3, want_gx, 9 * Co))):
     bound = 2.0**-22 * np.sqrt(terms) * 8 * float(ref.abs().max())
     e16, e3 = float((got.double() - ref).abs().max()), float((three.double() - ref).abs().max())
