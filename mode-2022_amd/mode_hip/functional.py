@@ -172,7 +172,7 @@ def _conv2d_f16(f16):
   return bool(f16) and CONV2D_F16 and CONV_ARITH == 'bf16x6'
 
 
-def _conv2d_run(entry, name, src, w, out_channels, dilation, f16=False):
+def _conv2d_run(entry, name, src, w, out_channels, dilation, f16=False, w_amax=None, amax_out=None):
   require_gpu(src, w)
   require_f32c(src, w)
   B, _, H, W = src.shape
@@ -186,7 +186,10 @@ def _conv2d_run(entry, name, src, w, out_channels, dilation, f16=False):
     which = int(entry == 'mode_conv2d_bwd_data')
     if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, which) == 1:
       if _conv2d_f16(f16):
-        am = (ptr(_tagged_abs_max(src)), ptr(_tagged_abs_max(w)))
+        aw = _weight_abs_max(w, w_amax)
+        if amax_out is not None:
+          amax_out.append(aw)
+        am = (ptr(_tagged_abs_max(src)), ptr(aw))
         if which:
           check(lib().mode_conv2d_bwd_data_split_f16(ptr(src), ptr(w), am[0], am[1], None, ptr(out), ptr(wp), B, Ci, H, W, Co, dilation,
                                                      stream_of(src)), 'mode_conv2d_bwd_data_split_f16')
@@ -204,29 +207,30 @@ def _conv2d_run(entry, name, src, w, out_channels, dilation, f16=False):
   return out
 
 
-def conv2d_fwd(x, w, dilation=1, f16=False):
-  """f16: the caller is a training step (Conv2d3x3Function with gradients being recorded): the split kernel may use the fp16 arithmetic."""
-  return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation, f16)
+def conv2d_fwd(x, w, dilation=1, f16=False, amax_out=None):
+  """f16: the caller is a training step (Conv2d3x3Function with gradients being recorded): the split kernel may use the fp16 arithmetic;
+  amax_out: a list that receives the weight's maximum buffer when it did (for the layer's backward)."""
+  return _conv2d_run('mode_conv2d_fwd', 'conv2d_fwd', x, w, w.shape[0], dilation, f16, amax_out=amax_out)
 
 
-def conv2d_bwd_data(gy, w, dilation=1, acc=None, f16=True):
+def conv2d_bwd_data(gy, w, dilation=1, acc=None, f16=True, w_amax=None):
   """acc: a gradient of the same tensor that is already there; the sum is returned (added in the split kernel's store where it runs).
-  (A backward pass is a training step: the fp16 arithmetic where CONV2D_F16 says so.)"""
+  (A backward pass is a training step: the fp16 arithmetic where CONV2D_F16 says so; w_amax: the weight's maximum from the forward.)"""
   if acc is None:
-    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation, f16)
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, w.shape[1], dilation, f16, w_amax=w_amax)
   require_gpu(gy, w, acc)
   acc = acc.contiguous()
   require_f32c(gy, w, acc)
   B, _, H, W = gy.shape
   Co, Ci = w.shape[:2]
   if not (CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 1) == 1 and tuple(acc.shape) == (B, Ci, H, W)):
-    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, Ci, dilation, f16).add_(acc)
+    return _conv2d_run('mode_conv2d_bwd_data', 'conv2d_bwd_data', gy, w, Ci, dilation, f16, w_amax=w_amax).add_(acc)
   gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device)
   with torch.cuda.device_of(gy), profiling.region('conv2d_bwd_data[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED else 'conv2d_bwd_data',
                                                   4 * (gy.numel() + 2 * gx.numel() + w.numel()), 2 * B * H * W * Ci * Co * 9, gy.device):
     wp = torch.empty(lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, dtype=torch.float32, device=gy.device)
     if _conv2d_f16(f16):
-      check(lib().mode_conv2d_bwd_data_split_f16(ptr(gy), ptr(w), ptr(_tagged_abs_max(gy)), ptr(_tagged_abs_max(w)), ptr(acc), ptr(gx), ptr(wp),
+      check(lib().mode_conv2d_bwd_data_split_f16(ptr(gy), ptr(w), ptr(_tagged_abs_max(gy)), ptr(_weight_abs_max(w, w_amax)), ptr(acc), ptr(gx), ptr(wp),
                                                  B, Ci, H, W, Co, dilation, stream_of(gy)), 'mode_conv2d_bwd_data_split_f16')
     else:
       check(lib().mode_conv2d_bwd_data_split_acc(ptr(gy), ptr(w), ptr(acc), ptr(gx), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(gy)),
@@ -245,8 +249,12 @@ class Conv2d3x3Function(torch.autograd.Function):
     ctx.dilation = dilation
     ctx.carrier = carrier  # GradCarrier of x (x has one other consumer: the skip of its residual block), or None
     ctx.own = _conv2d_own(x, w)
+    ctx.w_amax = None  # the weight's maximum buffer, when the forward ran on the fp16 arithmetic: the input gradient reads the same weight
     if ctx.own:
-      return conv2d_fwd(x, w.contiguous(), dilation, f16=training)  # (training: gradients are being recorded -- set by conv2d_3x3)
+      keep = []
+      y = conv2d_fwd(x, w.contiguous(), dilation, f16=training, amax_out=keep)  # (training: gradients are being recorded -- set by conv2d_3x3)
+      ctx.w_amax = keep[0] if keep else None
+      return y
     return torch.nn.functional.conv2d(x, w, None, 1, dilation, dilation)
 
   @staticmethod
@@ -259,7 +267,7 @@ class Conv2d3x3Function(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       prev = ctx.carrier.take() if ctx.carrier is not None else None  # the skip's gradient, when it came first (it always does)
       if ctx.own:
-        gx = conv2d_bwd_data(gy, w.contiguous(), dil, acc=prev)
+        gx = conv2d_bwd_data(gy, w.contiguous(), dil, acc=prev, w_amax=ctx.w_amax)
       else:
         gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
         if prev is not None:
@@ -439,8 +447,8 @@ SPHERE_BWD_F16 = True  # ... and the windowed input gradient (the adjoint on the
 
 
 def _tagged_abs_max(t):
-  """The maximum buffer of t: the producer's tag (BatchNorm passes), an earlier call's (a weight is read by the forward and by the input
-  gradient of its layer), or a pass -- whose result is left as the tag (known_abs_max drops it when t is written)."""
+  """The maximum buffer of an ACTIVATION or GRADIENT t: the producer's tag (BatchNorm passes), an earlier call's, or a pass -- whose result
+  is left as the tag (known_abs_max drops it when t is written; a tensor that lives inside one step)."""
   am = known_abs_max(t)
   if am is None:
     am = abs_max(t)
@@ -448,11 +456,18 @@ def _tagged_abs_max(t):
   return am
 
 
+def _weight_abs_max(w, given=None):
+  """The maximum buffer of a WEIGHT: the one the layer's forward computed when the caller kept it (`given`: autograd functions carry it from
+  their forward to their backward, where the weight is the same tensor by autograd's own rules), else a pass.  Never cached on the
+  parameter: a write through `.data` moves no version counter, and a stale maximum of a weight that grew is an fp16 overflow."""
+  return given if given is not None else abs_max(w)
+
+
 def _sphere_f16_maxima(x, w, f16):
   """(max |x|, max |w|) buffers for the fp16 arithmetic of the windowed forward, or None when it does not apply."""
   if not (f16 and SPHERE_FWD_F16 and CONV_ARITH == 'bf16x6' and w.shape[1] % 16 == 0):  # (16 input channels per MFMA: the split kernel's layers)
     return None
-  return (_tagged_abs_max(x), _tagged_abs_max(w))
+  return (_tagged_abs_max(x), _weight_abs_max(w))
 
 
 def sphere_conv_fwd(x, pos, w, out, stride, groups, return_transposed=False, f16=False):
@@ -716,8 +731,9 @@ def sphere_t_supported(pos, w, B, groups):
   return sum(plan[1]) * B * groups * (-(-(w.shape[0] // groups) // 128)) >= SPHERE_FWD_MIN_WG
 
 
-def sphere_conv_fwd_t(xt, pos, w, yt, groups, f16=False):
-  """yt (B,Co,W,H) = spherical convolution of xt (B,Ci,W,H), both plane-transposed; stride 1, 3x3 taps."""
+def sphere_conv_fwd_t(xt, pos, w, yt, groups, f16=False, amax_out=None):
+  """yt (B,Co,W,H) = spherical convolution of xt (B,Ci,W,H), both plane-transposed; stride 1, 3x3 taps.
+  amax_out: a list that receives the (max |x|, max |w|) buffers when the fp16 arithmetic ran (for the layer's backward)."""
   require_gpu(xt, pos, w, yt)
   require_f32c(xt, pos, w, yt)
   B, Ci, W, H = xt.shape
@@ -728,8 +744,10 @@ def sphere_conv_fwd_t(xt, pos, w, yt, groups, f16=False):
   nbytes = 4 * (xt.numel() + yt.numel() + pos.numel() + w.numel())
   with torch.cuda.device_of(xt), profiling.region('sphere_conv_fwd[%d->%d %dx%d]' % (Ci, Co, H, W), nbytes, flops, xt.device):
     wp = torch.empty(lib().mode_sphere_conv_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
-    _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(xt),
-                    _sphere_f16_maxima(xt, w, f16))
+    amax = _sphere_f16_maxima(xt, w, f16)
+    if amax is not None and amax_out is not None:
+      amax_out.append(amax)
+    _sphere_fwd_win(ptr(xt), pos, w, None, ptr(yt), wp, tiles, n0, n1, n2, B, Ci, H, W, Co, Kh, Kw, groups, 1, stream_of(xt), amax)
   return yt
 
 
@@ -775,7 +793,7 @@ def sphere_adjplan(pos, kh, kw):
     return plan
 
 
-def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
+def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups, w_amax=None):
   """gxt (B,Ci,W,H) = input gradient for gyt (B,Co,W,H), both plane-transposed (written, not added to)."""
   require_gpu(gyt, pos, w, gxt)
   require_f32c(gyt, pos, w, gxt)
@@ -796,7 +814,7 @@ def sphere_conv_bwd_data_t(gyt, pos, w, gxt, groups):
       tiles, ng, rec_off, rec_w, bad_ids, nbad, rec_off2, rec_w2 = aplan
       wps = torch.empty(lib().mode_sphere_conv_bwd_data_win_wpack_bytes(Ci, Co, Kh, Kw, groups) // 4, dtype=torch.float32, device=w.device)
       if SPHERE_BWD_F16:  # (a backward pass is a training step: the two-piece fp16 arithmetic)
-        check(lib().mode_sphere_conv_bwd_data_win_split_f16(ptr(gyt), ptr(w), ptr(_tagged_abs_max(gyt)), ptr(_tagged_abs_max(w)), ptr(gxt),
+        check(lib().mode_sphere_conv_bwd_data_win_split_f16(ptr(gyt), ptr(w), ptr(_tagged_abs_max(gyt)), ptr(_weight_abs_max(w, w_amax)), ptr(gxt),
                                                             ptr(wps), ptr(tiles), ng, ptr(rec_off), ptr(rec_w), ptr(rec_off2), ptr(rec_w2), B, Ci,
                                                             H, W, Co, Kh, Kw, groups, 1, stream_of(gyt)), 'mode_sphere_conv_bwd_data_win_split_f16')
       else:

@@ -131,7 +131,9 @@ class SphereConvTransposedFunction(Function):
     weight = weight.contiguous()
     B, _, W, H = input_t.shape
     output_t = input_t.new_empty((B, weight.size(0), W, H))
-    _F.sphere_conv_fwd_t(input_t, position, weight, output_t, groups, f16=bool(training))  # (a training step: DESIGN 3v)
+    keep = []
+    _F.sphere_conv_fwd_t(input_t, position, weight, output_t, groups, f16=bool(training), amax_out=keep)  # (a training step: DESIGN 3v)
+    ctx.w_amax = keep[0][1] if keep else None  # the weight's maximum buffer: the input gradient reads the same weight
     ctx.save_for_backward(input_t, position, weight)
     ctx.groups = groups
     return output_t
@@ -144,7 +146,7 @@ class SphereConvTransposedFunction(Function):
     grad_input_t = None
     if ctx.needs_input_grad[0]:
       grad_input_t = torch.empty_like(input_t)
-      _F.sphere_conv_bwd_data_t(gyt, position, weight, grad_input_t, ctx.groups)
+      _F.sphere_conv_bwd_data_t(gyt, position, weight, grad_input_t, ctx.groups, w_amax=ctx.w_amax)
     grad_weight = None
     if ctx.needs_input_grad[2]:
       sink = _F.grad_sink(weight)

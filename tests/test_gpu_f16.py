@@ -283,7 +283,15 @@ def test_sphere_input_gradient_on_two_fp16_pieces_against_float64(ih, iw, B, ci,
     three = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups))
   finally:
     HF.SPHERE_BWD_F16 = keep
-  assert sorted(calls) == sorted([tuple(gyt.shape), tuple(w.shape)]), calls  # one pass per tensor, reused by the second call
+  # the gradient's maximum is computed once and stays with the tensor; the weight's is NOT cached on the parameter (a write through
+  # .data moves no version counter) -- autograd functions carry it from their forward to their backward instead (w_amax)
+  assert sorted(calls) == sorted([tuple(gyt.shape), tuple(w.shape), tuple(w.shape)]), calls
+  w.data.mul_(4096.0)  # (the hazard: a stale maximum here would overflow fp16)
+  big = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups))
+  w.data.mul_(1.0 / 4096.0)
+  assert torch.equal(big, got * 4096.0), 'a weight rescaled through .data'
+  carried = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups, w_amax=real(w)))
+  assert torch.equal(carried, got), 'the maximum handed over by the forward'
   bound = 2.0**-22 * np.sqrt(9 * co // groups) * 8 * float(want.abs().max())
   e16 = float((got.cpu().double() - want).abs().max())
   e3 = float((three.cpu().double() - want).abs().max())

@@ -235,9 +235,9 @@ def test_gradient_carriers_give_autograds_sums_bit_for_bit(monkeypatch):
     calls.append((stride, acc is not None))
     return real(gy, w, in_shape, stride, acc, **kw)
 
-  def spy2d(gy, w, dilation=1, acc=None):
+  def spy2d(gy, w, dilation=1, acc=None, **kw):
     calls2d.append(acc is not None)
-    return real2d(gy, w, dilation, acc)
+    return real2d(gy, w, dilation, acc, **kw)
 
   monkeypatch.setattr(HF, 'conv3d_bwd_data', spy)
   monkeypatch.setattr(HF, 'conv2d_bwd_data', spy2d)
