@@ -33,6 +33,19 @@ def test_abi_version():
   assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 29
 
 
+def test_maximum_buffer_size_matches_the_header():
+  """functional.BN_ABSMAX_FLOATS (what Python allocates for mode_abs_max / mode_bn_next_*_absmax) is the header's MODE_BN_ABSMAX_FLOATS (what the
+  kernels zero and read: 16 + 128 slots x 16 floats); the fp16 entries reject a missing maximum on the host."""
+  from mode_hip import functional as HF
+  src = open(os.path.join(ROOT, 'include', 'mode_hip.h')).read()
+  m = re.search(r'#define\s+MODE_BN_ABSMAX_FLOATS\s+(\d+)', src)
+  assert m and int(m.group(1)) == HF.BN_ABSMAX_FLOATS == 16 * (1 + 128)
+  lib = mode_hip.lib()
+  null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+  assert lib.mode_conv2d_fwd_split_f16(one, one, null, one, one, one, 1, 16, 8, 8, 16, 1, null) == -1 and b'maximum' in lib.mode_last_error()
+  assert lib.mode_conv2d_bwd_weight_split_f16(one, one, one, null, one, one, 1, 16, 8, 8, 16, 1, 0, null) == -1 and b'maximum' in lib.mode_last_error()
+
+
 def test_argument_validation_without_gpu():
   """Bad arguments are rejected on the host before any launch, with a message (reference: TORCH_CHECK)."""
   lib = mode_hip.lib()
