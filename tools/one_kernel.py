@@ -92,7 +92,7 @@ elif what.startswith('sphere'):
   w = m.weight.detach()
   if what == 'sphere_fwd_t':
     yt = torch.empty_like(xt)
-    run(lambda: HF.sphere_conv_fwd_t(xt, pos, w, yt, 1))
+    run(lambda: HF.sphere_conv_fwd_t(xt, pos, w, yt, 1, f16=True))  # (the arithmetic of a training step)
   elif what == 'sphere_bwd_data_t':
     gxt = torch.empty_like(xt)
     run(lambda: HF.sphere_conv_bwd_data_t(gyt, pos, w, gxt, 1))
