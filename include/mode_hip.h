@@ -188,8 +188,8 @@ int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, const float
 
 /* The plain (no epilogue) call of a TRAINING step with the small-window tiles on the two-piece fp16 arithmetic of the stride-1 3-D layers
  * (two fp16 pieces per value, three MFMAs per product, a power-of-two scale per operand): amax_x / amax_w = device scalars
- * holding the largest finite magnitude of x and of w (mode_abs_max, or mode_bn_next_out_absmax of the pass that wrote x).  The
- * tall-window tiles next to the poles keep three bf16 pieces.  Ci / groups % 16 != 0: the call above with bn = NULL. */
+ * holding the largest finite magnitude of x and of w (mode_abs_max, or mode_bn_next_out_absmax of the pass that wrote x).
+ * Ci / groups % 16 != 0: the call above with bn = NULL. */
 int mode_sphere_conv_fwd_win_split_f16(const float* x, const float* pos, const float* w, const float* amax_x, const float* amax_w, float* y,
                                        float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W,
                                        int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream);

@@ -907,7 +907,10 @@ constexpr int TP = 5;  // tap pairs of a 3 x 3 kernel
 
 // wpt[(((((g*MG + mg)*NCH + ch)*TP + pair)*MTW + m)*3 + piece)*64 + lane] = 8 bf16: piece of W[g*Cog + mg*128 + m*32 + (lane&31)]
 // [ch*8 + j][tap = 2 pair + (lane>>5)], j = 0..7 (zeros for tap 9; scaled by the folded BatchNorm scale when fold != 0)
-__global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __restrict__ wpt, WinDims d, int fold, mode_bn_epilogue bn) {
+template <bool F16>
+__global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __restrict__ wpt, WinDims d, int fold, mode_bn_epilogue bn,
+                                      const float* __restrict__ amax_w) {
+  const float sw = F16 ? sp_f16_scale_of(mode::absmax_load(amax_w)) : 1.f;
   const long long total = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -930,11 +933,19 @@ __global__ void pack_w_win_split_tall(const float* __restrict__ w, uint4* __rest
       if (tap < KT && co < d.Cog && c < d.Cig) {
         v[j] = w[((long long)(g * d.Cog + co) * d.Cig + c) * KT + tap];
         if (fold) v[j] *= fold_scale(bn, g * d.Cog + co);
+        if (F16) v[j] *= sw;
       }
     }
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (F16) {
+        sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]);
+        q3[j] = 0u;
+      } else {
+        sp_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+      }
+    }
     uint4* dst = wpt + (idx - lane) * 3 + lane;
     dst[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
     dst[64] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -952,10 +963,11 @@ __device__ unsigned long long g_taptime[8 * 8192];
 #define MODE_STAMPV(j, v)
 #endif
 // Template parameters as fwd_tile (window rows, double-buffered staging in NPH phases of NRB row passes).
-template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI>
+// F16: two fp16 pieces / three MFMAs per product (the small-window code of sphere_fwd_split_kernel<false, true>): a half step is 6 slots.
+template <int WR_T, bool PIPE, int NRB, int NPH, bool EPI, bool F16 = false>
 __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, const float* __restrict__ pos, const uint4* __restrict__ wpt,
                                                float* __restrict__ y, const WinDims& d, int h0, int w0, int rbase, int cbase, float* smem,
-                                               const Epi& epi) {
+                                               const Epi& epi, float sx = 1.f, float unscale = 1.f) {
   const int WRP = WR_T > 0 ? WR_T : d.wr;
   const int CP = chan_pitch(WRP);
   const int bufsz = CCH * CP;
@@ -990,7 +1002,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       const int lc = c0 - cbase;
       const bool dead = wt.x == 0.f && wt.y == 0.f && wt.z == 0.f && wt.w == 0.f;
       roff[p] = dead ? 0 : lc * WRP + lr;
-      rw[p] = wt;
+      rw[p] = F16 ? make_float4(wt.x * sx, wt.y * sx, wt.z * sx, wt.w * sx) : wt;  // (the operand's power-of-two scale rides on the weights)
     }
   }
   const int lds_floats = (PIPE ? 2 : 1) * bufsz + WRP + 8;
@@ -1096,6 +1108,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
     asm("" : "+v"(ra[j]), "+v"(rb[j]));
   };
   auto split_c = [&](int j) { q3[j] = sp_pack2(ra[j], rb[j]); };
+  auto hsplit = [&](int j) { sp_split2_f16(v[2 * j], v[2 * j + 1], q1[j], q2[j]); };
 
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph) {
@@ -1122,9 +1135,14 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   for (int c = 4; c < 8; ++c) comb(0, c);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    split_a(j);
-    split_b(j);
-    split_c(j);
+    if constexpr (F16) {
+      hsplit(j);
+      q3[j] = 0u;
+    } else {
+      split_a(j);
+      split_b(j);
+      split_c(j);
+    }
   }
   bq[0] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
   bq[1] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -1133,6 +1151,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   MODE_STAMP(1)
 #define MODE_SB __builtin_amdgcn_sched_barrier(0);
 #define MODE_TMF(PA, PB, m, t) acc[t] = sp_mfma(a_cur[m][PA], bq[PB], acc[t]);
+#define MODE_TMFH(PA, PB, m, t) acc[t] = sp_mfma_f16(a_cur[m][PA], bq[PB], acc[t]); asm volatile("" :: "v"(acc[t]));  // (pinned: see the small tiles)
 #ifdef MODE_TAPTIME
   unsigned long long tt_top = 0, tt_pre = 0, tt_post = __builtin_readcyclecounter(), ts_a = 0, ts_b = 0, ts_c = 0;
 #endif
@@ -1151,6 +1170,24 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
 #ifdef MODE_TAPTIME
       tt_top = __builtin_readcyclecounter();
 #endif
+      if constexpr (F16) {
+        // 6 slots: lo x hi, hi x lo, hi x hi for tiles 0 and 1; the rest of the step's LDS and sampling work between them as below
+        MODE_SB
+        MODE_TMFH(1, 0, 0, 0) if (p + 1 < TP) comb(pn, 0); MODE_SB
+        MODE_TMFH(1, 0, 1, 1) if (p + 1 < TP) comb(pn, 1); MODE_SB
+        MODE_TMFH(0, 1, 0, 0) if (p + 1 < TP) comb(pn, 2); wstore(step + 1); MODE_SB
+        MODE_TMFH(0, 1, 1, 1) if (p + 1 < TP) comb(pn, 3); wfetch(step + 2); MODE_SB
+        if (p + 1 < TP) load_half(cur, pn, 1);
+        if (p % PPP == 0 && p / PPP < NPH && more) issue(ch + 1, p / PPP);
+        if (p == TP - 1 && more) commit(ch + 1, NPH - 1, nxt);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a_nxt[0][q] = wcur[((2 + 0) * 3 + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a_nxt[1][q] = wcur[((2 + 1) * 3 + q) * 64];
+        MODE_SB
+        MODE_TMFH(0, 0, 0, 0) if (p + 1 < TP) { comb(pn, 4); comb(pn, 5); } MODE_SB
+        MODE_TMFH(0, 0, 1, 1) if (p + 1 < TP) { comb(pn, 6); comb(pn, 7); } MODE_SB
+      } else {
       MODE_SB
       MODE_TMF(2, 0, 0, 0) if (p + 1 < TP) comb(pn, 0); MODE_SB
       MODE_TMF(2, 0, 1, 1) if (p + 1 < TP) comb(pn, 1); MODE_SB
@@ -1174,6 +1211,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
       MODE_TMF(0, 1, 1, 1) if (p + 1 < TP) comb(pn, 7); MODE_SB
       MODE_TMF(0, 0, 0, 0) MODE_SB
       MODE_TMF(0, 0, 1, 1) MODE_SB
+      }
 #ifdef MODE_TAPTIME
       tt_pre = __builtin_readcyclecounter();
 #endif
@@ -1191,6 +1229,38 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
         for (int q = 0; q < 3; ++q) a_cur[m][q] = a_nxt[m][q];
       if (p + 1 == TP) load_half(more ? nxt : cur, 0, 0);  // (after the last chunk: any finite words, the fragment is not used)
       MODE_SB
+      if constexpr (F16) {
+        if (p + 1 < TP) {
+          MODE_TMFH(1, 0, 0, 2) hsplit(0); MODE_SB
+          MODE_TMFH(1, 0, 1, 3) hsplit(1); MODE_SB
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a_nxt[0][q] = wnx[(0 * 3 + q) * 64];
+          MODE_SB
+          MODE_TMFH(0, 1, 0, 2) hsplit(2); MODE_SB
+          MODE_TMFH(0, 1, 1, 3) hsplit(3); MODE_SB
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a_nxt[1][q] = wnx[(1 * 3 + q) * 64];
+          if (p + 2 < TP) load_half(cur, p + 2, 0);  // first half batch of the fragment built under the next step
+          MODE_SB
+          MODE_TMFH(0, 0, 0, 2) MODE_SB
+          MODE_TMFH(0, 0, 1, 3) MODE_SB
+        } else {  // the whole B fragment of the next chunk's first pair under these six MFMAs
+          MODE_TMFH(1, 0, 0, 2) comb(0, 0); comb(0, 1); MODE_SB
+          MODE_TMFH(1, 0, 1, 3) comb(0, 2); comb(0, 3); MODE_SB
+          load_half(more ? nxt : cur, 0, 1);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a_nxt[0][q] = wnx[(0 * 3 + q) * 64];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a_nxt[1][q] = wnx[(1 * 3 + q) * 64];
+          MODE_SB
+          MODE_TMFH(0, 1, 0, 2) MODE_SB
+          MODE_TMFH(0, 1, 1, 3) comb(0, 4); comb(0, 5); comb(0, 6); comb(0, 7); MODE_SB
+          load_half(more ? nxt : cur, 1, 0);  // (the fragment built under the next chunk's first step)
+          MODE_SB
+          MODE_TMFH(0, 0, 0, 2) hsplit(0); hsplit(1); MODE_SB
+          MODE_TMFH(0, 0, 1, 3) hsplit(2); hsplit(3); MODE_SB
+        }
+      } else
       if (p + 1 < TP) {
         MODE_TMF(2, 0, 0, 2) split_a(0); MODE_SB
         MODE_TMF(2, 0, 1, 3) split_b(0); MODE_SB
@@ -1247,6 +1317,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   }
 #undef MODE_SB
 #undef MODE_TMF
+#undef MODE_TMFH
   MODE_STAMP(2)
 #ifdef MODE_TAPTIME
   MODE_STAMPV(4, ts_a)
@@ -1284,7 +1355,7 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
           const float v = (acc[m][r] + shv[r]) + res[r];
           yb[(long long)co * HW] = epi.relu ? relu_nan(v) : v;
         } else {
-          yb[(long long)co * HW] = acc[m][r];
+          yb[(long long)co * HW] = F16 ? acc[m][r] * unscale : acc[m][r];
         }
       };
       if (m * 32 + 32 <= cmax) {  // (uniform) a full M-tile: no test per store
@@ -1301,9 +1372,8 @@ __device__ __forceinline__ void fwd_tile_split(const float* __restrict__ x, cons
   MODE_STAMP(3)
 }
 
-// F16 (training forward, no epilogue): the small-window tiles on two fp16 pieces and three MFMAs per product -- a tap is 12 slots
-// instead of 24, and the split of a sampled value 3 instructions instead of 5.5; the tall-window tiles keep the three bf16 pieces
-// (their fragments `wpt` are packed unscaled).
+// F16 (training forward, no epilogue): two fp16 pieces and three MFMAs per product -- a tap of the small-window tiles is 12 slots
+// instead of 24, and the split of a sampled value 3 instructions instead of 5.5; the tall-window tiles (fwd_tile_split<.., F16>) likewise.
 template <bool EPI, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                                     const uint4* __restrict__ wps, const uint4* __restrict__ wpt,
@@ -1320,11 +1390,23 @@ __global__ __launch_bounds__(NTHREADS) void sphere_fwd_split_kernel(const float*
   // 0.37 ms for the two launches against 0.26 for the old single one), on the same arithmetic since round 4 (fwd_tile_split)
   const int cls = t.w >> 16;
   if (cls == 1) {
-    fwd_tile_split<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    if constexpr (F16) {
+      const float sx_ = sp_f16_scale_of(mode::absmax_load(amax_x));
+      fwd_tile_split<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI, true>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi, sx_,
+                                                                              (1.f / sx_) * (1.f / sp_f16_scale_of(mode::absmax_load(amax_w))));
+    } else {
+      fwd_tile_split<WR_MID, true, (WR_MID + SROWS - 1) / SROWS, 2, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    }
     return;
   }
   if (cls != 0) {
-    fwd_tile_split<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    if constexpr (F16) {
+      const float sx_ = sp_f16_scale_of(mode::absmax_load(amax_x));
+      fwd_tile_split<0, true, WR_PIPE_MAX / SROWS, 4, EPI, true>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi, sx_,
+                                                                 (1.f / sx_) * (1.f / sp_f16_scale_of(mode::absmax_load(amax_w))));
+    } else {
+      fwd_tile_split<0, true, WR_PIPE_MAX / SROWS, 4, EPI>(x, pos, wpt, y, d, t.x, t.y, t.z, cbase, smem, epi);
+    }
     return;
   }
   MODE_STAMP(0)
@@ -2473,8 +2555,13 @@ static int sphere_conv_fwd_win_impl(const float* x, const float* pos, const floa
     uint4* wpt = wps + nsplit * 3;  // fragments of the tall-window tiles: K = 8 channels x 2 taps
     if (n_mid + n_wrap > 0) {
       const long long ntall = (long long)d.G * d.MG * d.NCH * TP * MTW * 64;
-      if (mode::pack_needed()) hipLaunchKernelGGL(pack_w_win_split_tall, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, bn ? 1 : 0,
-                         bn ? *bn : mode_bn_epilogue());
+      if (mode::pack_needed()) {
+        if (f16)
+          hipLaunchKernelGGL(pack_w_win_split_tall<true>, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, 0, mode_bn_epilogue(), amax_w);
+        else
+          hipLaunchKernelGGL(pack_w_win_split_tall<false>, dim3(mode::cdiv(ntall, 256)), dim3(256), 0, st, w, wpt, d, bn ? 1 : 0,
+                             bn ? *bn : mode_bn_epilogue(), (const float*)nullptr);
+      }
     }
     // one launch for all tiles; wrap-around tiles that cannot be double-buffered keep their own kernel
     const int4* tl = reinterpret_cast<const int4*>(tiles);
