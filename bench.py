@@ -257,6 +257,29 @@ def calibrated_traffic(label, batch, conv_arith, on_split=None):
   return None
 
 
+def dtype_string(conv_arith):
+  """The bench line's `dtype`: the NARROWEST product arithmetic of the timed step first (the driver keeps ~100 characters), then
+  where the wider ones are used.  Storage, accumulation, BatchNorm, head and optimizer are fp32 under every setting."""
+  if conv_arith == 'f32':
+    return 'fp32 storage/accumulate; products: fp32 MFMA everywhere (--conv-arith f32)'
+  parts = []
+  if CONV3D_S1_F16:
+    who = ['stride-1 3x3x3']
+    if SPHERE_FWD_F16:
+      who.append('spherical')
+    if CONV2D_F16:
+      who.append('3x3')
+    parts.append('fp32 storage/accumulate; products: 2xfp16 split (22-bit, per-tensor 2^k scale, 3 MFMAs) in the %s layers incl. '
+                 'gradients (DESIGN 3u/3v)' % ' / '.join(who))
+    parts.append('3xbf16 split (24-bit, 6 MFMAs) in the stride-2 / transposed 3x3x3 layers and the polar spherical tiles (3j-3l)')
+  else:
+    parts.append('fp32 storage/accumulate; products: 3xbf16 split (24-bit, 6 bf16 MFMAs) in the 3x3x3, 3x3 and spherical layers incl. '
+                 'gradients (DESIGN 3j-3l)')
+  parts.append('fp32 MFMA in the 32->1 heads, 1x1 and 7x7 layers')
+  return '; '.join(parts)
+
+
+
 def roofline_block(kern, conv_arith, batch, profile_steps, timed_over, on_split=None):
   """The bench line's `roofline` object.  The dominant kernel is the DEVICE KERNEL with the largest total time over all the layer
   shapes it serves -- the first row of `rocprofv3 --stats` for the same command -- priced against the pipe its launches run on:
@@ -695,12 +718,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.conv_arith == 'f32' else ('f32 (3x3x3, 3x3 and spherical convolution layers incl. gradients: fp32 operands split exactly into 3 bf16 '
-                                                            'pieces, 6 bf16 MFMAs per product, fp32 accumulate; DESIGN.md 3j-3l' +
-                                                            ('; the stride-1 3x3x3 layers of the training step: 2 fp16 pieces with a power-of-two scale '
-                                                             'per operand tensor, 3 fp16 MFMAs per product, DESIGN.md 3u' +
-                                                             ('; so do the windowed spherical forward and both of its gradients' + (' and the 3x3 layers of the extractor' if CONV2D_F16 else '') + ', 3v)' if SPHERE_FWD_F16 else ')')
-                                                             if CONV3D_S1_F16 else ')')),
+        'dtype': dtype_string(args.conv_arith),
         'data': 'synthetic',
         'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
         'per_gpu_value': pairs / elapsed / world,
@@ -752,7 +770,10 @@ def main():
       ch = [v for k, v in kern.items() if k.startswith(('classif_fwd', 'classif_bwd'))]
       if ch:
         out['targets']['classifier_heads_hbm_frac'] = round(sum(v['bytes'] for v in ch) / (sum(v['total_ms'] for v in ch) * 1e6) / HBM_PEAK_GBPS, 4)
-      out['roofline']['targets'] = out['targets']  # (also inside `roofline`, where the driver's parser keeps it)
+      out['roofline']['targets'] = out['targets']
+      for k, v in out['targets'].items():  # (and as scalar keys of `roofline`: the driver's parser keeps scalars, not nested objects)
+        if isinstance(v, (int, float)) or v is None:
+          out['roofline'][k] = v
       out['config']['vendor_guard'] = 'first eager step ran under mode_hip.no_vendor (%d aten ops seen, none of them vendor arithmetic)' % guard.seen
       out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
                             'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}

@@ -111,6 +111,17 @@ inline Epi make_epi(const mode_bn_epilogue* e, const float* shift) {
 // the packing kernels scale output channel o of the weights by fold_scale and write fold_shift(o) next to the packed weights.
 __device__ __forceinline__ float fold_scale(const mode_bn_epilogue& e, int o) { return e.gamma[o] / sqrtf(e.var[o] + e.eps); }
 __device__ __forceinline__ float fold_shift(const mode_bn_epilogue& e, int o) { return e.beta[o] - e.mean[o] * fold_scale(e, o); }
+// Buffer-addressed loads (a 128-bit descriptor in scalar registers + a 32-bit lane offset + a scalar offset): no 64-bit vector
+// address arithmetic per request, and a lane offset at or beyond `bytes` reads as ZERO -- the zero padding of a haloed tile costs one
+// select of the OFFSET per position instead of one select per loaded value.  The descriptor must be built from wave-uniform values.
+// kBufOOB is the offset of a lane that must read zero (bytes < 2^31 is the caller's contract).
+constexpr unsigned kBufOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned lane_off_bytes, unsigned scalar_off_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off_bytes, scalar_off_bytes, 0));
+}
 // ReLU as torch computes it: NaN stays NaN (fmaxf(NaN, 0) would return 0 and hide a diverged activation).
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 __device__ __forceinline__ float apply_epi(const Epi& e, float v, int o, long long idx) {

@@ -244,45 +244,79 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     poff[k] = pdz[k] * (int)HW + phy[k] * d.W + pwi[k];
   }
   float raw[KIT][8];
-  unsigned okmask = 0;
-  // Loads of the next chunk: unconditional, from clamped addresses, position k under tap pair k and split under pair k + 8 -- the
-  // workgroups run in lockstep, and 48 loads per thread issued at once by every CU arrive as one 20 MB burst that takes a whole
-  // chunk time to drain (measured: 0.92 ms per launch against 0.74 with the same loads served from cache).  No `&&` in here: the
-  // compiler turns a chain of short-circuit tests into nested branches, and a branch ends the region in which these instructions
-  // can move under the MFMAs.
-  const float* st_xc = x;
+  // Loads of the next chunk: unconditional, position k under tap pair k and split under pair k + 8 -- the workgroups run in lockstep,
+  // and 48 loads per thread issued at once by every CU arrive as one 20 MB burst that takes a whole chunk time to drain (measured:
+  // 0.92 ms per launch against 0.74 with the same loads served from cache).  No `&&` in here: the compiler turns a chain of
+  // short-circuit tests into nested branches, and a branch ends the region in which these instructions can move under the MFMAs.
+  // The requests are buffer loads (round 6): the chunk's 8 channel planes are one descriptor, a channel is a scalar offset, a
+  // position a 32-bit lane offset, and a position in the zero padding is an offset beyond the descriptor -- it reads as zero.  That
+  // took 48 64-bit vector adds and 54 selects out of a chunk's 168 MFMA gaps (fp16 arithmetic: 4.4 -> 3.3 other instructions per gap).
+  // The staging walks its tiles incrementally -- (sb, sd, sh, sw) in tile units, advanced by the workgroup's stride of nwx tiles with
+  // carries when the chunk index wraps: the division of a tile index by three runtime extents was ~110 scalar instructions per chunk
+  // in ONE gap.
+  int jw, jh, jd, jb, sw, sh, sd, sb, s_ch = 0;
+  {
+    int t = nwx;
+    jw = t % d.nWt;
+    t /= d.nWt;
+    jh = t % d.nHt;
+    t /= d.nHt;
+    jd = t % d.nDt;
+    jb = t / d.nDt;
+    t = t_begin + slot;
+    sw = t % d.nWt;
+    t /= d.nWt;
+    sh = t % d.nHt;
+    t /= d.nHt;
+    sd = t % d.nDt;
+    sb = t / d.nDt;
+  }
+  unsigned soff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) soff[c] = (unsigned)c * (unsigned)DHW * 4u;
+  __amdgpu_buffer_rsrc_t st_rs = buf_rsrc(x, 0);
   int st_base = 0, st_d0 = 0, st_h0 = 0, st_w0 = 0;
-  auto stage_begin = [&](int g) {  // scalar part: which tile / channels chunk g reads
-    int b;
-    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
-    tile_of(k_tile, b, st_d0, st_h0, st_w0);
-    st_xc = x + ((long long)b * d.K + ch * 8) * DHW;
+  auto stage_advance = [&](int step) {  // step = 1: the next chunk of this workgroup's stream; 0: stay (after the last one)
+    s_ch += step;
+    const int wrap = s_ch >= d.NCHUNK ? 1 : 0;
+    s_ch = wrap ? 0 : s_ch;
+    sw += wrap ? jw : 0;
+    int c = sw >= d.nWt ? 1 : 0;
+    sw -= c ? d.nWt : 0;
+    sh += (wrap ? jh : 0) + c;
+    c = sh >= d.nHt ? 1 : 0;
+    sh -= c ? d.nHt : 0;
+    sd += (wrap ? jd : 0) + c;
+    c = sd >= d.nDt ? 1 : 0;
+    sd -= c ? d.nDt : 0;
+    sb += (wrap ? jb : 0) + c;
+  };
+  auto stage_begin = [&]() {  // scalar part: which tile / channels the staged chunk reads
+    st_d0 = sd * TD;
+    st_h0 = sh * TH;
+    st_w0 = sw * 32;
+    st_rs = buf_rsrc(x + ((long long)sb * d.K + s_ch * 8) * DHW, (unsigned)DHW * 32u);
     st_base = (st_d0 - 1) * (int)HW + (st_h0 - 1) * d.W + (st_w0 - 1);
-    okmask = 0;
   };
   auto stage_load = [&](int k) {  // the 8 channel values of position k
     const unsigned ok = (unsigned)((unsigned)(st_d0 + pdz[k] - 1) < (unsigned)d.D) & (unsigned)((unsigned)(st_h0 + phy[k] - 1) < (unsigned)d.H) &
                         (unsigned)((unsigned)(st_w0 + pwi[k] - 1) < (unsigned)d.W);
-    okmask |= ok << k;
-    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) * 4u : kBufOOB;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float* xcc = st_xc + (long long)c * DHW;  // uniform base (scalar registers) + 32-bit lane offset: no 64-bit vector adds
-      raw[k][c] = xcc[off];                            // (K is a multiple of 8)
-    }
+    for (int c = 0; c < 8; ++c) raw[k][c] = buf_load_f32(st_rs, off, soff[c]);  // (K is a multiple of 8)
   };
   // split position k of the loaded chunk and write its three pieces into buffer `buf`, in two halves (one per tap pair):
   // half 0 splits channels 0..3, half 1 channels 4..7 and stores.  Branch-free: the code sits between the MFMAs of a pair.
   uint32_t sq[3][4];  // (NP pieces used)
   auto stage_commit = [&](int buf, int k, int h) {
-    const bool ok = (okmask >> k) & 1;
 #pragma unroll
     for (int j = 2 * h; j < 2 * h + 2; ++j) {
-      float v0 = ok ? raw[k][2 * j] : 0.f, v1 = ok ? raw[k][2 * j + 1] : 0.f;
+      float v0 = raw[k][2 * j], v1 = raw[k][2 * j + 1];
       if (F16) {
         v0 *= sx;
         v1 *= sx;
-      }
+      }  // (this file is compiled with -fno-slp-vectorize, build.py: as <2 x float> the pair's remainders lose v_fma_mix_f32 -- two
+         // v_cvt_f32_f16 more per pair -- and become packed fp32 instructions, which do not overlap with MFMAs)
       split2<F16>(v0, v1, sq[0][j], sq[1][j], sq[2][j]);
     }
     if (h == 1) {
@@ -365,7 +399,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   };
 
   if (G > 0) {
-    stage_begin(0);
+    stage_begin();
 #pragma unroll
     for (int k = 0; k < KIT; ++k) stage_load(k);
 #pragma unroll
@@ -384,7 +418,8 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
     // the chunk staged under this one; after the last chunk it is staged once more into the idle buffer, which keeps the loop body
     // free of branches (a branch would pin the staging code to one spot instead of letting it spread between the MFMAs)
-    stage_begin(min(g + 1, G - 1));
+    stage_advance(g + 1 < G ? 1 : 0);
+    stage_begin();
     // (EPI == 2) where this chunk's residual requests go: the tile's pixels in its last chunk, a cached dummy row in the others
     unsigned ep_cur[R];
     const float* ep_base = epi.add;
@@ -450,8 +485,13 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < MT * R * NTERM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 6 : 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (F16) {  // (half the MFMAs for the same staging: every gap also takes an LDS access of either kind and a load.  6 + 2 per
+          __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);  // gap let the scheduler fill the first gaps of a pair with 9-16
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // instructions and leave the last five empty)
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -33,41 +33,54 @@ def _deps_mtime():
   return max(os.path.getmtime(h) for h in hs)
 
 
-def _flags_changed():
-  """True (and the stamp rewritten) when the objects in csrc/obj were compiled with other flags than today's -- e.g. after a debug build
-  with MODE_HIP_DEFINES: the mtime test alone would call that library up to date."""
+# Per-file flags.  -fno-slp-vectorize for the MFMA kernels whose staging arithmetic sits between the matrix instructions: the SLP
+# vectoriser pairs their scalar fp32 operations into v_pk_*_f32, which do not overlap with MFMAs on gfx950, and as <2 x float> the
+# fp16 split's remainder loses v_fma_mix_f32.
+FILE_FLAGS = {
+    'conv3d_split.hip': ['-fno-slp-vectorize'],
+}
+
+
+def _flags_of(src):
+  return FLAGS + FILE_FLAGS.get(os.path.basename(src), [])
+
+
+def _flags_hash(src):
   import hashlib
-  stamp = os.path.join(OBJ, 'flags.sha')
-  want = hashlib.sha256('\0'.join([HIPCC] + FLAGS).encode()).hexdigest()
-  try:
-    with open(stamp) as f:
-      have = f.read().strip()
-  except OSError:
-    have = None
-  if have == want:
-    return False
-  with open(stamp, 'w') as f:
-    f.write(want)
-  # no stamp yet but objects present: they predate the stamp and were built by an unknown command line -- rebuild once
-  return have is not None or any(f.endswith('.o') for f in os.listdir(OBJ))
+  return hashlib.sha256('\0'.join([HIPCC] + _flags_of(src)).encode()).hexdigest()
+
+
+def _stamp(obj):
+  return obj + '.flags'
 
 
 def _compile(src, force):
+  """Compile one source if its object is missing, older than the source / a header, or was built with other flags (the flags hash
+  is stored PER OBJECT and written only after a successful compile: an interrupted build cannot leave a matching stamp beside
+  objects of the old flags)."""
   obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
-  if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
+  want = _flags_hash(src)
+  try:
+    with open(_stamp(obj)) as f:
+      have = f.read().strip()
+  except OSError:
+    have = None
+  if (not force and have == want and os.path.exists(obj) and
+      os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime())):
     return obj, False
-  cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+  cmd = [HIPCC] + _flags_of(src) + ['-c', src, '-o', obj]
   r = subprocess.run(cmd, capture_output=True, text=True)
   if r.returncode != 0:
     raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
   if r.stderr.strip():
     sys.stderr.write(r.stderr)
+  with open(_stamp(obj), 'w') as f:
+    f.write(want)
   return obj, True
 
 
 def build(force=False, verbose=True):
   os.makedirs(OBJ, exist_ok=True)
-  force = force or _flags_changed()
   srcs = sources()
   with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
     results = list(ex.map(lambda s: _compile(s, force), srcs))

@@ -307,17 +307,36 @@ def test_erp_tables_are_planned_through_their_transpose():
 
 
 def test_build_notices_changed_compile_flags(tmp_path, monkeypatch):
-  """objects compiled with other flags (a MODE_HIP_DEFINES debug build) must not be taken for up to date."""
+  """objects compiled with other flags (a MODE_HIP_DEFINES debug build, a per-file flag) must not be taken for up to
+  date, and a compile that fails after the flags changed must not leave a stamp that says they match: the flags hash is stored per
+  object and written only after that object compiled."""
+  import stat
   from mode_hip import build as hb
-  monkeypatch.setattr(hb, 'OBJ', str(tmp_path))
-  assert hb._flags_changed() is False  # empty directory: nothing to distrust, stamp written
-  assert hb._flags_changed() is False
+  src = tmp_path / 'k.hip'
+  src.write_text('// nothing')
+  fake = tmp_path / 'fakecc'
+  fake.write_text('#!/bin/sh\nfor a in "$@"; do [ "$a" = "-DFAIL" ] && exit 1; prev2="$prev"; prev="$a"; done\n: > "$prev"\n')
+  fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+  obj_dir = tmp_path / 'obj'
+  obj_dir.mkdir()
+  monkeypatch.setattr(hb, 'OBJ', str(obj_dir))
+  monkeypatch.setattr(hb, 'HIPCC', str(fake))
+  monkeypatch.setattr(hb, '_deps_mtime', lambda: 0.0)
+  obj, compiled = hb._compile(str(src), False)
+  assert compiled and os.path.exists(obj) and os.path.exists(obj + '.flags')
+  assert hb._compile(str(src), False) == (obj, False)  # up to date
   monkeypatch.setattr(hb, 'FLAGS', hb.FLAGS + ['-DMODE_TAPTIME'])
-  assert hb._flags_changed() is True
-  assert hb._flags_changed() is False
-  os.remove(os.path.join(str(tmp_path), 'flags.sha'))
-  open(os.path.join(str(tmp_path), 'x.o'), 'w').close()
-  assert hb._flags_changed() is True  # objects of unknown origin
+  assert hb._compile(str(src), False) == (obj, True)  # other flags: rebuilt
+  assert hb._compile(str(src), False) == (obj, False)
+  monkeypatch.setitem(hb.FILE_FLAGS, 'k.hip', ['-DX'])
+  assert hb._compile(str(src), False) == (obj, True)  # a per-file flag counts
+  monkeypatch.setitem(hb.FILE_FLAGS, 'k.hip', ['-DFAIL'])
+  with pytest.raises(RuntimeError):
+    hb._compile(str(src), False)
+  monkeypatch.setitem(hb.FILE_FLAGS, 'k.hip', ['-DX', '-DY'])
+  assert hb._compile(str(src), False) == (obj, True)  # the failed attempt left no matching stamp behind
+  os.remove(obj + '.flags')
+  assert hb._compile(str(src), False) == (obj, True)  # an object of unknown origin
 
 
 def test_isa_loops_reads_a_listing(tmp_path, monkeypatch, capsys):

@@ -6,6 +6,10 @@
 for v in new dcold; do
   [ -f tools/experiments/libmode_hip_$v.so ] || { echo "tools/experiments/libmode_hip_$v.so is missing (see the header of this script)"; exit 2; }
 done
+# the product library is swapped in place below: put it back on ANY exit, not only after a clean run
+cp mode-2022_amd/mode_hip/libmode_hip.so /tmp/libmode_hip_product_$$.so
+trap 'cp /tmp/libmode_hip_product_$$.so mode-2022_amd/mode_hip/libmode_hip.so; rm -f /tmp/libmode_hip_product_$$.so' EXIT
+trap 'exit 130' INT TERM
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for v in new dcold new dcold; do
@@ -33,4 +37,3 @@ for (ci, co, D, H, W) in ((32, 64, 48, 256, 128), (64, 64, 24, 128, 64)):
 print('$v', ' | '.join(out))
 PY
 done
-cp tools/experiments/libmode_hip_new.so mode-2022_amd/mode_hip/libmode_hip.so

@@ -9,6 +9,10 @@ cd $R
 for v in bf16x6 f16x3; do
   [ -f tools/experiments/libmode_hip_$v.so ] || { echo "tools/experiments/libmode_hip_$v.so is missing (see the header of this script)"; exit 2; }
 done
+# the product library is swapped in place below: put it back on ANY exit, not only after a clean run
+cp mode-2022_amd/mode_hip/libmode_hip.so /tmp/libmode_hip_product_$$.so
+trap 'cp /tmp/libmode_hip_product_$$.so mode-2022_amd/mode_hip/libmode_hip.so; rm -f /tmp/libmode_hip_product_$$.so' EXIT
+trap 'exit 130' INT TERM
 for v in bf16x6 f16x3 bf16x6 f16x3; do
   cp tools/experiments/libmode_hip_$v.so mode-2022_amd/mode_hip/libmode_hip.so
   python - <<PY
@@ -49,4 +53,3 @@ for name, scale in (('randn', None), ('6 decades', 6.0), ('gradient-sized (x 1e-
 print('$v', ' | '.join(out))
 PY
 done
-cp tools/experiments/libmode_hip_bf16x6.so mode-2022_amd/mode_hip/libmode_hip.so

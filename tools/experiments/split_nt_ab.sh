@@ -8,6 +8,10 @@ cd $R
 for v in nt256 nt512; do
   [ -f tools/experiments/libmode_hip_$v.so ] || { echo "tools/experiments/libmode_hip_$v.so is missing (see the header of this script)"; exit 2; }
 done
+# the product library is swapped in place below: put it back on ANY exit, not only after a clean run
+cp mode-2022_amd/mode_hip/libmode_hip.so /tmp/libmode_hip_product_$$.so
+trap 'cp /tmp/libmode_hip_product_$$.so mode-2022_amd/mode_hip/libmode_hip.so; rm -f /tmp/libmode_hip_product_$$.so' EXIT
+trap 'exit 130' INT TERM
 for v in nt256 nt512 nt256 nt512; do
   cp tools/experiments/libmode_hip_$v.so mode-2022_amd/mode_hip/libmode_hip.so
   python - <<PY
@@ -38,4 +42,3 @@ import torch
 a, b = torch.load('/tmp/split_nt_nt256.pt'), torch.load('/tmp/split_nt_nt512.pt')
 print('max |nt256 - nt512| =', float((a - b).abs().max()), 'of', float(a.abs().max()))
 PY
-cp tools/experiments/libmode_hip_nt256.so mode-2022_amd/mode_hip/libmode_hip.so
