@@ -177,36 +177,60 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
     poff[k] = phy[k] * d.W + pwi[k];
   }
   float raw[KIT][16];
-  unsigned okmask = 0;
-  const float* st_xc = x;
-  int st_base = 0, st_h0 = 0, st_w0 = 0;
-  auto stage_begin = [&](int g) {
-    int b;
-    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
-    tile_of(k_tile, b, st_h0, st_w0);
-    st_xc = x + ((long long)b * d.K + ch * 16) * HWi;
-    st_base = (st_h0 - DIL) * d.W + (st_w0 - DIL);
-    okmask = 0;
-  };
-  auto stage_load = [&](int k) {  // the 16 channel values of position k: unconditional, clamped address (no && : no branches)
-    const unsigned ok = (unsigned)((unsigned)(st_h0 + phy[k] - DIL) < (unsigned)d.H) & (unsigned)((unsigned)(st_w0 + pwi[k] - DIL) < (unsigned)d.W);
-    okmask |= ok << k;
-    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+  // Staging as in conv3d_split.hip (round 6): buffer loads -- the chunk's 16 channel planes are one descriptor, a channel a scalar
+  // offset, a position a 32-bit lane offset, a position in the zero padding an offset beyond the descriptor (reads as zero: no select
+  // per loaded value) -- and the tiles walked incrementally (sb, sh, sw in tile units, advanced by the workgroup's stride with carries
+  // when the chunk index wraps) instead of a division of the tile index per chunk (113 scalar instructions in one MFMA gap).
+  int jw, jh, jb, sw, sh, sb, s_ch = 0;
+  {
+    int t = nwx;
+    jw = t % d.nWt;
+    t /= d.nWt;
+    jh = t % d.nHt;
+    jb = t / d.nHt;
+    t = t_begin + slot;
+    sw = t % d.nWt;
+    t /= d.nWt;
+    sh = t % d.nHt;
+    sb = t / d.nHt;
+  }
+  unsigned soff[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float* xcc = st_xc + (long long)c * HWi;  // uniform base + 32-bit lane offset (K is a multiple of 16)
-      raw[k][c] = xcc[off];
-    }
+  for (int c = 0; c < 16; ++c) soff[c] = (unsigned)c * (unsigned)HWi * 4u;
+  __amdgpu_buffer_rsrc_t st_rs = buf_rsrc(x, 0);
+  int st_base = 0, st_h0 = 0, st_w0 = 0;
+  auto stage_advance = [&](int step) {  // step = 1: the next chunk of this workgroup's stream; 0: stay (after the last one)
+    s_ch += step;
+    const int wrap = s_ch >= d.NCHUNK ? 1 : 0;
+    s_ch = wrap ? 0 : s_ch;
+    sw += wrap ? jw : 0;
+    int c = sw >= d.nWt ? 1 : 0;
+    sw -= c ? d.nWt : 0;
+    sh += (wrap ? jh : 0) + c;
+    c = sh >= d.nHt ? 1 : 0;
+    sh -= c ? d.nHt : 0;
+    sb += (wrap ? jb : 0) + c;
+  };
+  auto stage_begin = [&]() {
+    st_h0 = sh * TH;
+    st_w0 = sw * 32;
+    st_rs = buf_rsrc(x + ((long long)sb * d.K + s_ch * 16) * HWi, (unsigned)HWi * 64u);  // (K is a multiple of 16)
+    st_base = (st_h0 - DIL) * d.W + (st_w0 - DIL);
+  };
+  auto stage_load = [&](int k) {  // the 16 channel values of position k: unconditional (no && : no branches)
+    const unsigned ok = (unsigned)((unsigned)(st_h0 + phy[k] - DIL) < (unsigned)d.H) & (unsigned)((unsigned)(st_w0 + pwi[k] - DIL) < (unsigned)d.W);
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) * 4u : kBufOOB;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) raw[k][c] = buf_load_f32(st_rs, off, soff[c]);
   };
   auto stage_commit = [&](int buf, int k) {
-    const bool ok = (okmask >> k) & 1;
     uint4* dst = sm + buf * BUF + tid + k * NT;
 #pragma unroll
     for (int oct = 0; oct < 2; ++oct) {
       uint32_t sq[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float v0 = ok ? raw[k][8 * oct + 2 * j] : 0.f, v1 = ok ? raw[k][8 * oct + 2 * j + 1] : 0.f;
+        const float v0 = raw[k][8 * oct + 2 * j], v1 = raw[k][8 * oct + 2 * j + 1];
         if constexpr (F16)
           split2_f16(v0 * sx, v1 * sx, sq[0][j], sq[1][j]);
         else
@@ -276,7 +300,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   };
 
   if (G > 0) {
-    stage_begin(0);
+    stage_begin();
 #pragma unroll
     for (int k = 0; k < KIT; ++k) stage_load(k);
 #pragma unroll
@@ -290,7 +314,8 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   for (int g = 0; g < G; ++g) {
     const uint4* src = sm + (g & 1) * BUF;
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
-    stage_begin(min(g + 1, G - 1));  // (after the last chunk: once more into the idle buffer -- keeps the body free of branches)
+    stage_advance(g + 1 < G ? 1 : 0);  // (after the last chunk: the same one once more into the idle buffer -- keeps the body free of branches)
+    stage_begin();
     unsigned ep_cur[ADD_AHEAD ? R : 1];  // where this chunk's residual requests go: the tile's pixels in its last chunk, a cached dummy row else
     const float* ep_base = epi.add;
     if (ADD_AHEAD) {
@@ -344,12 +369,25 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
         MODE_SPLIT_TERM(0, 0)
 #undef MODE_SPLIT_TERM
       }
-      // (F16: half the MFMAs carry two thirds of the staging work -- twice the vector and LDS instructions beside each)
+      // (F16: half the MFMAs carry two thirds of the staging work.  Per tap: 48 vector instructions of a position's split, R * NP
+      // fragment reads + 4 stores, 16 + MT * NP loads -- dealt evenly over the tap's MFMA gaps, every kind with its own slot: a generous
+      // allowance per gap let the scheduler fill a tap's first gaps with 6-16 instructions and leave the other two thirds empty)
+      if constexpr (F16) {
+        constexpr int NM = MT * R * 3;
 #pragma unroll
-      for (int i = 0; i < MT * R * (F16 ? 3 : 6); ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, (MT * R <= 4 ? 5 : 3) * (F16 ? 2 : 1), 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (48 + NM - 1) / NM + 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x080, (R * NP + 4 + NM - 1) / NM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, (16 + MT * NP + NM - 1) / NM, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT * R * 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, MT * R <= 4 ? 5 : 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

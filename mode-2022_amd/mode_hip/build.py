@@ -38,6 +38,7 @@ def _deps_mtime():
 # fp16 split's remainder loses v_fma_mix_f32.
 FILE_FLAGS = {
     'conv3d_split.hip': ['-fno-slp-vectorize'],
+    'conv2d_split.hip': ['-fno-slp-vectorize'],
 }
 
 
