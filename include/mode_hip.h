@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 29 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 30 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -155,7 +155,7 @@ int mode_sphere_conv_bwd_data_win_split(const float* gy, const float* w, float* 
                                         const int32_t* rec_off, const float* rec_w, const int32_t* rec_off2, const float* rec_w2, int B,
                                         int Ci, int H, int W, int Co, int Kh, int Kw, int groups, int transposed, mode_stream_t stream);
 /* The same on the two-piece fp16 arithmetic of mode_sphere_conv_fwd_win_split_f16 (a backward pass is a training step): amax_g / amax_w =
- * the maximum buffers (MODE_BN_ABSMAX_FLOATS floats; mode_abs_max, mode_bn_next_gy_absmax) of gy and of w. */
+ * the maximum buffers (MODE_BN_ABSMAX_FLOATS floats; mode_abs_max, mode_bn_train_bwd_amax) of gy and of w. */
 int mode_sphere_conv_bwd_data_win_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, float* gx, float* wpack,
                                             const int32_t* tiles, int n_tiles, const int32_t* rec_off, const float* rec_w,
                                             const int32_t* rec_off2, const float* rec_w2, int B, int Ci, int H, int W, int Co, int Kh,
@@ -188,7 +188,7 @@ int mode_sphere_conv_fwd_win_split(const float* x, const float* pos, const float
 
 /* The plain (no epilogue) call of a TRAINING step with the small-window tiles on the two-piece fp16 arithmetic of the stride-1 3-D layers
  * (two fp16 pieces per value, three MFMAs per product, a power-of-two scale per operand): amax_x / amax_w = device scalars
- * holding the largest finite magnitude of x and of w (mode_abs_max, or mode_bn_next_out_absmax of the pass that wrote x).
+ * holding the largest finite magnitude of x and of w (mode_abs_max, or mode_bn_train_fwd_amax of the pass that wrote x).
  * Ci / groups % 16 != 0: the call above with bn = NULL. */
 int mode_sphere_conv_fwd_win_split_f16(const float* x, const float* pos, const float* w, const float* amax_x, const float* amax_w, float* y,
                                        float* wpack, const int32_t* tiles, int n_small, int n_mid, int n_wrap, int B, int Ci, int H, int W,
@@ -412,12 +412,15 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
 /* The same with the folded eval-mode BatchNorm (+ residual) (+ ReLU) epilogue of mode_deconv3d_fwd_bn (convbn_3d around the
  * ConvTranspose3d of hourglass conv5 / conv6 in eval mode, mode_disparity.py:23-25, 38-45): whole 32-channel output tiles
  * (mode_deconv3d_split_bn_supported(Cin, Cout) == 1); wpack >= mode_conv3d_wpack_bytes(Cin, Cout). */
-/* EXPERIMENTAL arithmetic of the stride-1 3x3x3 layers (nn.Conv3d of convbn_3d, models/submodule.py:20-22; functional.CONV_ARITH =
- * 'f16x3', off by default): fp32 operands split into TWO fp16 pieces, three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones
- * (2^-22 per product; 30-35 % faster).  fp16's range is narrow, so each operand is scaled by a power of two that brings its tensor's
- * largest magnitude to [2^14, 2^15): amax_* = DEVICE buffers of MODE_BN_ABSMAX_FLOATS floats, one per operand (layout: see
- * mode_bn_next_out_absmax below), filled by mode_abs_max (an order-independent maximum over bit patterns; no host synchronisation,
- * graph-capturable; a tensor's maximum can be computed once and passed to every call that reads the tensor).  Elements more than ~2^17 below their tensor's maximum lose relative precision -- DESIGN.md section 6.
+/* The arithmetic of the stride-1 3x3x3 layers in a TRAINING step (nn.Conv3d of convbn_3d, models/submodule.py:20-22; the product
+ * default since round 5, functional.CONV3D_S1_F16): fp32 operands split into TWO fp16 pieces, three v_mfma_f32_32x32x16_f16 per product
+ * instead of six bf16 ones (2^-22 per product).  fp16's range is narrow, so each operand is scaled by a power of two that brings its
+ * tensor's largest finite magnitude to [2^14, 2^15): amax_* = DEVICE buffers of MODE_BN_ABSMAX_FLOATS floats, one per operand (layout:
+ * see MODE_BN_ABSMAX_FLOATS below), filled by mode_abs_max (an order-independent maximum over bit patterns; no host synchronisation,
+ * graph-capturable) or by the `_amax` BatchNorm entries that write the tensor; a tensor's maximum can be computed once and passed to
+ * every call that reads the tensor.  PRECISION CONTRACT: an element keeps 22 significant bits down to ~2^-17 of its tensor's maximum,
+ * fewer below that, none below ~2^-39 of it (it contributes less than 2^-17 of the tensor's scale to any sum either way; the three-piece
+ * bf16 entries keep 24 bits for every element) -- DESIGN.md 3u.
  * mode_conv3d_bwd_data_split_f16: acc may be NULL.  mode_conv3d_bwd_weight_split_f16: other arguments and workspace as
  * mode_conv3d_bwd_weight_split. */
 int mode_abs_max(const float* x, long long n, float* out_device_buffer, mode_stream_t stream);
@@ -455,7 +458,8 @@ int mode_conv3d_bwd_weight_split(const float* gy, const float* x, float* gw, flo
                                  int Co, int accumulate, mode_stream_t stream);
 
 /* The regular 3x3 Conv2d layers (stride 1, dilation 1 / 2) on the same split-bf16 path (csrc/conv2d_split.hip): reduction channels
- * a multiple of 16, <= 128 output channels of the GEMM; arguments and wpack as mode_conv2d_fwd / _bwd_data (+ optional epilogue). */
+ * a multiple of 16, <= 512 output channels of the GEMM (one launch per block of 64); arguments and wpack as mode_conv2d_fwd / _bwd_data
+ * (+ optional epilogue). */
 int mode_conv2d_split_supported(int Ci, int Co, int dilation, int which /* 0 forward, 1 input gradient */);
 int mode_conv2d_fwd_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci, int H, int W,
                           int Co, int dilation, mode_stream_t stream);
@@ -468,7 +472,7 @@ int mode_conv2d_bwd_data_split_acc(const float* gy, const float* w, const float*
                                    int Co, int dilation, mode_stream_t stream);
 /* mode_conv2d_fwd_split / mode_conv2d_bwd_data_split(_acc) of a TRAINING step on the two-piece fp16 arithmetic of the stride-1 3-D layers
  * (two fp16 pieces per value, three MFMAs per product, a power-of-two scale per operand): amax_* = the maximum buffers
- * (MODE_BN_ABSMAX_FLOATS floats: mode_abs_max, mode_bn_next_out_absmax, mode_bn_next_gy_absmax) of the activation / gradient and of the
+ * (MODE_BN_ABSMAX_FLOATS floats: mode_abs_max, mode_bn_train_fwd_amax, mode_bn_train_bwd_amax) of the activation / gradient and of the
  * weight.  Same predicate (mode_conv2d_split_supported) and workspace; acc may be NULL. */
 int mode_conv2d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B, int Ci,
                               int H, int W, int Co, int dilation, mode_stream_t stream);
@@ -559,14 +563,16 @@ int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, cons
 /* A tensor's largest finite magnitude, as the fp16-arithmetic entries (mode_conv3d_*_split_f16, mode_sphere_conv_fwd_win_split_f16) take
  * it: a device buffer of MODE_BN_ABSMAX_FLOATS floats whose MAXIMUM is the value -- word 0 and 128 words of 128 different cache lines,
  * everything else zero (the blocks of the producing pass each add to one of them: one word for a whole launch serialises at the memory
- * side; the consumers' waves read all 129).  mode_abs_max fills such a buffer with a pass over the tensor; the two calls below make the
- * NEXT BatchNorm call of the calling thread fill one on the way: the operand maximum comes out of the pass that writes the tensor.
- * Either zeroes the whole buffer first.  One-shot. */
+ * side; the consumers' waves read all 129).  mode_abs_max fills such a buffer with a pass over the tensor; the `_amax` entries below fill
+ * one on the way -- the operand maximum comes out of the pass that WRITES the tensor: mode_bn_train_fwd_amax (+ _prestats_amax) for `out`,
+ * mode_bn_train_bwd_amax and mode_classif_train_bwd_amax for the gradient `gy` (read by both gradients of the convolution in front).
+ * Same arguments as the plain entries plus the buffer (NULL = the plain call); the call zeroes the whole buffer first.  (ABI <= 29 had
+ * one-shot thread-local setters, mode_bn_next_out_absmax / mode_bn_next_gy_absmax, instead: removed.) */
 #define MODE_BN_ABSMAX_FLOATS 2064
-void mode_bn_next_out_absmax(float* device_scalar);
-/* The same for the NEXT mode_bn_train_bwd or mode_classif_train_bwd call and the gradient `gy` it writes (read by both gradients of the
- * convolution in front). */
-void mode_bn_next_gy_absmax(float* device_scalar);
+int mode_bn_train_fwd_amax(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                           float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B, int C,
+                           long long S, int groups, float* out_absmax, mode_stream_t stream);
 
 int mode_bn_eval_fwd(const float* y, const float* add, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int relu, float* out, int B, int C, long long S,
@@ -576,6 +582,10 @@ int mode_bn_train_bwd(const float* gout, const float* y, const float* out, const
                       const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                       float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
                       long long S, int groups, mode_stream_t stream);
+int mode_bn_train_bwd_amax(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
+                           const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
+                           float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
+                           long long S, int groups, float* gy_absmax, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier head of the 3-D regulariser in TRAINING (SURVEY a12 + a15):
@@ -604,6 +614,10 @@ int mode_classif_train_bwd(const float* gcost, const float* y, const float* w, c
                            const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift, float* gy,
                            float* gw, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, int D, int H, int W,
                            mode_stream_t stream);
+int mode_classif_train_bwd_amax(const float* gcost, const float* y, const float* w, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
+                                float* gy, float* gw, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, int D,
+                                int H, int W, float* gy_absmax /* may be NULL */, mode_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Export-stage geometry: what happens between the disparity network and the fusion network.
@@ -652,11 +666,42 @@ int mode_bn_train_fwd_prestats(const float* y, const float* add, const float* ga
                                float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int nsplit,
                                int B, int C, long long S, mode_stream_t stream);
+int mode_bn_train_fwd_prestats_amax(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                                    float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace,
+                                    int nsplit, int B, int C, long long S, float* out_absmax /* as mode_bn_train_fwd_amax */,
+                                    mode_stream_t stream);
 
 /* out = a + b [+ c [+ d]] (c, d may be NULL; fixed association): the gradient of a tensor with several consumers in ONE pass.
  * No reference counterpart as code: autograd's pairwise accumulation of the gradients of cost0 / pre1
  * (models/mode_disparity.py:119-125) is what it replaces.  n elements, 16-byte aligned buffers. */
 int mode_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, mode_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fusion network (models/mode_fusion.py:91-307, built as train_fusion.py:64): the layers that are neither a 3x3
+ * convolution (mode_conv2d_*) nor a BatchNorm (mode_bn_*).  csrc/fusion_ops.hip; all deterministic, fp32.
+ *
+ * mode_maxpool2x2_fwd / _bwd: nn.MaxPool2d(2, stride=2) (mode_fusion.py:146, :161, :190) over N = B * C planes (H, W) -> (H / 2, W / 2),
+ *   floor; picks like torch (scan order, a later value replaces the current one when it is greater or NaN); the backward recomputes
+ *   the choice from x (no index tensor) and writes all of gx (zeros where nothing was picked).
+ * mode_depth_to_space2 / mode_space_to_depth2: the rearrangement half of nn.ConvTranspose2d(Ci, Co, 2, 2) (mode_fusion.py:195, :212) --
+ *   kernel 2, stride 2: no overlapping taps, so the layer is ONE 1x1 convolution with 4 Co output channels (row 4 o + 2 i + j of the
+ *   weight's own (Ci, 4 Co) storage: mode_conv1x1_bwd_data on x with the weight as it lies) followed by
+ *       y[b, o, 2h+i, 2w+j] = relu?(scale[o] * y4[b, 4 o + 2 i + j, h, w] + shift[o])        (scale NULL = 1, shift NULL = 0)
+ *   with the bias (training) or the bias and the folded eval-mode BatchNorm (inference) as the per-channel affine.  The inverse
+ *   rearranges the output gradient for mode_conv1x1_fwd (input gradient) / mode_conv1x1_bwd_weight (weight gradient).
+ * mode_conv1x1_sigmoid_fwd / _bwd: nn.Conv2d(C, 1, 1, bias=True) + nn.Sigmoid (mode_fusion.py:228-229) over (B, C, S) planes, S % 4 == 0,
+ *   C <= 64: s = sigmoid(bias + sum_c w[c] x[b, c, :]).  bwd: gs = dL/ds -> gx (B, C, S) written (may be NULL), gw (C) and gbias (1, may be
+ *   NULL) written (accumulate = 0) or added to (accumulate = 1); workspace >= mode_conv1x1_sigmoid_bwd_workspace_bytes(B, S). */
+int mode_maxpool2x2_fwd(const float* x, float* y, long long N, int H, int W, mode_stream_t stream);
+int mode_maxpool2x2_bwd(const float* x, const float* gy, float* gx, long long N, int H, int W, mode_stream_t stream);
+int mode_depth_to_space2(const float* y4, const float* scale, const float* shift, float* y, int B, int Co, int H, int W, int relu,
+                         mode_stream_t stream);
+int mode_space_to_depth2(const float* gy, float* g4, int B, int Co, int H, int W, mode_stream_t stream);
+int mode_conv1x1_sigmoid_fwd(const float* x, const float* w, const float* bias, float* s, int B, int C, long long S, mode_stream_t stream);
+size_t mode_conv1x1_sigmoid_bwd_workspace_bytes(int B, long long S);
+int mode_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* s, const float* gs, float* gx, float* gw, float* gbias,
+                             int accumulate, float* workspace, int B, int C, long long S, mode_stream_t stream);
 
 #ifdef __cplusplus
 }

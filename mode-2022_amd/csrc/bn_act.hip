@@ -496,47 +496,60 @@ extern "C" size_t mode_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * 20
 static int bn_train_fwd_impl(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
-                             int C, long long S, int groups, int prestats, mode_stream_t stream);
+                             int C, long long S, int groups, int prestats, float* amax, mode_stream_t stream);
 
-// The NEXT mode_bn_train_fwd / mode_bn_train_fwd_prestats call of this thread also leaves the largest finite |out| in device_scalar[0]
-// (the bit pattern of a non-negative float; the buffer -- MODE_BN_ABSMAX_FLOATS words, the rest is the pass's scratch -- is zeroed by
-// that call): the power-of-two scale of an fp16-arithmetic consumer
-// (mode_conv3d_fwd_split_f16) without a pass of its own over the tensor.  One-shot: cleared by the call that uses it.
-static thread_local float* g_next_out_absmax = nullptr;
-extern "C" void mode_bn_next_out_absmax(float* device_scalar) { g_next_out_absmax = device_scalar; }
-// the same for the NEXT mode_bn_train_bwd call and its `gy` (the gradient the convolution in front of the BatchNorm reads twice)
-static thread_local float* g_next_gy_absmax = nullptr;
-extern "C" void mode_bn_next_gy_absmax(float* device_scalar) { g_next_gy_absmax = device_scalar; }
-float* mode::take_next_gy_absmax() {
-  float* p = g_next_gy_absmax;
-  g_next_gy_absmax = nullptr;
-  return p;
-}
-
+// The `_amax` entries also leave the largest finite magnitude of the tensor they write in `out_absmax` / `gy_absmax` (a device buffer of
+// MODE_BN_ABSMAX_FLOATS floats whose maximum is the value; zeroed by the call): the power-of-two scale of an fp16-arithmetic consumer
+// (mode_conv3d_fwd_split_f16, ...) comes out of the pass that writes the operand, without a pass of its own over the tensor.  NULL:
+// the plain call.  (Rounds 5: one-shot thread-local setters in front of the plain calls -- state between two calls that no binder
+// other than the Python one could be expected to get right; ABI 30 made it a parameter.)
 extern "C" int mode_bn_train_fwd(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                                  float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
                                  int C, long long S, int groups, mode_stream_t stream) {
   return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
-                           save_invstd, save_scale, save_shift, workspace, B, C, S, groups, 0, stream);
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, groups, 0, nullptr, stream);
+}
+
+extern "C" int mode_bn_train_fwd_amax(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
+                                      float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
+                                      int C, long long S, int groups, float* out_absmax, mode_stream_t stream) {
+  return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, groups, 0, out_absmax, stream);
+}
+
+static int check_nsplit(int nsplit) {
+  // the C pivots sit behind the 2 * C * nsplit partial sums in a workspace of C * 2048 floats: at most 1023 pairs per channel
+  MODE_REQUIRE(nsplit > 0 && nsplit <= 1023, MODE_ERR_BAD_ARG, "mode_bn_train_fwd_prestats: %d partial pairs per channel (1..1023)", nsplit);
+  return MODE_OK;
 }
 
 extern "C" int mode_bn_train_fwd_prestats(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                                           float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
                                           float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
                                           float* workspace, int nsplit, int B, int C, long long S, mode_stream_t stream) {
-  // the C pivots sit behind the 2 * C * nsplit partial sums in a workspace of C * 2048 floats: at most 1023 pairs per channel
-  MODE_REQUIRE(nsplit > 0 && nsplit <= 1023, MODE_ERR_BAD_ARG, "mode_bn_train_fwd_prestats: %d partial pairs per channel (1..1023)", nsplit);
+  int rc = check_nsplit(nsplit);
+  if (rc != MODE_OK) return rc;
   return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
-                           save_invstd, save_scale, save_shift, workspace, B, C, S, 1, nsplit, stream);
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, 1, nsplit, nullptr, stream);
+}
+
+extern "C" int mode_bn_train_fwd_prestats_amax(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
+                                               float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
+                                               float* out, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                               float* workspace, int nsplit, int B, int C, long long S, float* out_absmax,
+                                               mode_stream_t stream) {
+  int rc = check_nsplit(nsplit);
+  if (rc != MODE_OK) return rc;
+  return bn_train_fwd_impl(y, add, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, out, save_mean,
+                           save_invstd, save_scale, save_shift, workspace, B, C, S, 1, nsplit, out_absmax, stream);
 }
 
 static int bn_train_fwd_impl(const float* y, const float* add, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* out,
                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift, float* workspace, int B,
-                             int C, long long S, int groups, int prestats, mode_stream_t stream) {
-  float* amax = g_next_out_absmax;  // (mode_bn_next_out_absmax: one-shot, whatever this call returns)
-  g_next_out_absmax = nullptr;
+                             int C, long long S, int groups, int prestats, float* amax, mode_stream_t stream) {
   int rc = check_bn(B, C, S, "mode_bn_train_fwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_fwd: empty batch has no statistics");
@@ -651,7 +664,15 @@ extern "C" int mode_bn_train_bwd(const float* gout, const float* y, const float*
                                  const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
                                  float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C, long long S,
                                  int groups, mode_stream_t stream) {
-  float* amax = mode::take_next_gy_absmax();  // (mode_bn_next_gy_absmax: one-shot, whatever this call returns)
+  return mode_bn_train_bwd_amax(gout, y, out, gamma, save_mean, save_invstd, save_scale, save_shift, relu, gy, gadd, ggamma, gbeta,
+                                accumulate, workspace, B, C, S, groups, nullptr, stream);
+}
+
+extern "C" int mode_bn_train_bwd_amax(const float* gout, const float* y, const float* out, const float* gamma, const float* save_mean,
+                                      const float* save_invstd, const float* save_scale, const float* save_shift, int relu, float* gy,
+                                      float* gadd, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
+                                      long long S, int groups, float* gy_absmax, mode_stream_t stream) {
+  float* amax = gy_absmax;
   int rc = check_bn(B, C, S, "mode_bn_train_bwd");
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(B > 0, MODE_ERR_BAD_ARG, "mode_bn_train_bwd: empty batch");

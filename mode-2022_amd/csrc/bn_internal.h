@@ -13,8 +13,8 @@ int bn_train_coefficients(const float* y, const float* gamma, const float* beta,
                           float* save_scale, float* save_shift, float* workspace, int B, int C, long long S, hipStream_t st,
                           const char* who);
 
-// ---- the largest finite magnitude of a tensor, as its fp16-arithmetic consumers read it (mode_abs_max, mode_bn_next_out_absmax,
-// mode_bn_next_gy_absmax) ---------------------------------------------------------------------------------------------------------------
+// ---- the largest finite magnitude of a tensor, as its fp16-arithmetic consumers read it (mode_abs_max, the out_absmax / gy_absmax
+// arguments of the `_amax` entries) ---------------------------------------------------------------------------------------------------------------
 // `amax` points at MODE_BN_ABSMAX_FLOATS words, all zero when the producing pass starts; the value is the maximum over word 0 and the
 // ABSMAX_SLOTS words at 16 * (1 + s) (bit patterns of non-negative floats: an unsigned maximum).  One address for the whole launch does
 // not work: tens of thousands of waves end within microseconds of each other, and their requests to ONE word -- the atomics, and just as
@@ -52,8 +52,6 @@ __device__ __forceinline__ float absmax_load(const float* amax) {
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
   return __builtin_bit_cast(float, mx);
 }
-// the one-shot pointer of mode_bn_next_gy_absmax (null when none was left); clears it
-float* take_next_gy_absmax();
 // zero the buffer in front of the pass (where no kernel of the pass does it on the way)
 int absmax_begin(float* amax, hipStream_t st, const char* who);
 

@@ -781,8 +781,18 @@ extern "C" int mode_classif_train_bwd(const float* gcost, const float* y, const 
                                       const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
                                       float* gy, float* gw, float* ggamma, float* gbeta, int accumulate, float* workspace, int B, int C,
                                       int D, int H, int W, mode_stream_t stream) {
+  return mode_classif_train_bwd_amax(gcost, y, w, gamma, beta, save_mean, save_invstd, save_scale, save_shift, gy, gw, ggamma, gbeta,
+                                     accumulate, workspace, B, C, D, H, W, nullptr, stream);
+}
+
+// ... and leaves the largest finite |gy| in gy_absmax (MODE_BN_ABSMAX_FLOATS floats, may be NULL): this IS a BatchNorm backward, and the
+// 32 -> 32 convolution in front reads gy in both of its gradients (mode_bn_train_bwd_amax has the contract)
+extern "C" int mode_classif_train_bwd_amax(const float* gcost, const float* y, const float* w, const float* gamma, const float* beta,
+                                           const float* save_mean, const float* save_invstd, const float* save_scale,
+                                           const float* save_shift, float* gy, float* gw, float* ggamma, float* gbeta, int accumulate,
+                                           float* workspace, int B, int C, int D, int H, int W, float* gy_absmax, mode_stream_t stream) {
   const char* who = "mode_classif_train_bwd";
-  float* amax = mode::take_next_gy_absmax();  // (mode_bn_next_gy_absmax: this IS a BatchNorm backward; one-shot, whatever this call returns)
+  float* amax = gy_absmax;
   int rc = check_classif(who, B, C, D, H, W);
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(gcost && y && w && gamma && beta && save_mean && save_invstd && save_scale && save_shift && gy && gw && ggamma && gbeta && workspace,

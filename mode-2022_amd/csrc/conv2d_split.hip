@@ -490,7 +490,8 @@ size_t conv2d_split_wpack_floats(int K, int rows) {
 }
 
 bool conv2d_split_supported(int K, int rows, int dilation) {
-  return rows > 1 && rows <= 128 && K % 16 == 0 && (dilation == 1 || dilation == 2);
+  // (any number of 64-channel output blocks: one launch each; 512 covers the fusion network's 256-channel bottleneck with room)
+  return rows > 1 && rows <= 512 && K % 16 == 0 && (dilation == 1 || dilation == 2);
 }
 
 // rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels; flip 0 / 1 as pack_w2d_split

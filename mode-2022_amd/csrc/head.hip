@@ -23,7 +23,7 @@ struct HDims {
   float sd, sh, sw;  // align_corners scales (in-1)/(out-1)
 };
 
-__device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, int& i1, float& l1) {
+__host__ __device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, int& i1, float& l1) {
   // area_pixel_compute_source_index(align_corners=True) + the index/lambda computation of upsample_*linear
   const float s = scale * (float)o;
   i0 = (int)s;
@@ -548,10 +548,30 @@ int launch_bwd_fast(const float* logits, const float* gpred, float* ws, const HD
 
 // one block per image row: W <= 512 pixels (8 waves: the 48-node kernel needs 2 waves per SIMD = 256 registers; wider rows take the
 // two-kernel form), a whole number of node rows per pass of the block's threads
+// ... and every pixel that contributes to a low-resolution node along w lies within the HR_MAXS pixels from the node's `wlo` that the
+// kernel sums (the same wlo and the same src_index, in the same float arithmetic).  At the x4 up-sampling of the model a node's support
+// is 8-9 pixels; at a wider ratio (W = 512 over W4 = 64: ~18) the kernel would silently drop contributions -- such shapes
+// take the two-kernel form, whose row kernel loops over the whole support.
+bool pixrows_support_fits(const HDims& d) {
+  if (!(d.sw > 0.f)) return d.W <= HR_MAXS;
+  for (int w = 0; w < d.W; ++w) {
+    int w0, w1;
+    float lw;
+    src_index(w, d.sw, d.W4, w0, w1, lw);
+    const int nodes[2] = {w0, w1};
+    const float wt[2] = {1.f - lw, lw};
+    for (int j = 0; j < 2; ++j) {
+      if (wt[j] == 0.f) continue;
+      const int wlo = std::max(0, (int)floorf((float)(nodes[j] - 1) / d.sw) - 1);
+      if (w < wlo || w - wlo >= HR_MAXS) return false;
+    }
+  }
+  return true;
+}
 bool pixrows_fits(const HDims& d) {
   const int nt = ((d.W + 63) / 64) * 64;
   return d.W <= 512 && d.W4 <= d.W && nt % d.W4 == 0 && (long long)d.B * d.H < (1ll << 31) &&
-         (size_t)HR_KC * (d.W + (d.W >> 2) + 1) * sizeof(float) <= 64 * 1024;
+         (size_t)HR_KC * (d.W + (d.W >> 2) + 1) * sizeof(float) <= 64 * 1024 && pixrows_support_fits(d);
 }
 
 template <int D4, bool LOSS>

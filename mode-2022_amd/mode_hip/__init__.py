@@ -107,8 +107,6 @@ SIGNATURES = {
     'mode_deconv3d_split_bn_supported': (_c_int, [_c_int] * 2),
     'mode_conv3d_bwd_data_split_acc_supported': (_c_int, [_c_int] * 3),
     'mode_abs_max': (_c_int, [_c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr]),
-    'mode_bn_next_out_absmax': (None, [_c_ptr]),
-    'mode_bn_next_gy_absmax': (None, [_c_ptr]),
     'mode_conv3d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),
@@ -143,9 +141,25 @@ SIGNATURES = {
     'mode_bn_eval_fwd': (_c_int, [_c_ptr] * 6 + [ctypes.c_float, _c_int] + [_c_ptr] + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
     'mode_bn_train_bwd': (_c_int, [_c_ptr] * 8 + [_c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] + [_c_int] * 2 +
                           [ctypes.c_longlong, _c_int, _c_ptr]),
+    # the `_amax` entries: the plain entry's arguments + the maximum's buffer in front of the stream (ABI 30)
+    'mode_bn_train_fwd_amax': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 6 + [_c_int] * 2 +
+                               [ctypes.c_longlong, _c_int, _c_ptr, _c_ptr]),
+    'mode_bn_train_fwd_prestats_amax': (_c_int, [_c_ptr] * 7 + [ctypes.c_float] * 2 + [_c_int] + [_c_ptr] * 6 + [_c_int] * 3 +
+                                        [ctypes.c_longlong, _c_ptr, _c_ptr]),
+    'mode_bn_train_bwd_amax': (_c_int, [_c_ptr] * 8 + [_c_int] + [_c_ptr] * 4 + [_c_int] + [_c_ptr] + [_c_int] * 2 +
+                               [ctypes.c_longlong, _c_int, _c_ptr, _c_ptr]),
+    'mode_classif_train_bwd_amax': (_c_int, [_c_ptr] * 13 + [_c_int] + [_c_ptr] + [_c_int] * 5 + [_c_ptr, _c_ptr]),
+    # fusion network (csrc/fusion_ops.hip)
+    'mode_maxpool2x2_fwd': (_c_int, [_c_ptr] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr]),
+    'mode_maxpool2x2_bwd': (_c_int, [_c_ptr] * 3 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr]),
+    'mode_depth_to_space2': (_c_int, [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr]),
+    'mode_space_to_depth2': (_c_int, [_c_ptr] * 2 + [_c_int] * 4 + [_c_ptr]),
+    'mode_conv1x1_sigmoid_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
+    'mode_conv1x1_sigmoid_bwd_workspace_bytes': (_c_size, [_c_int, ctypes.c_longlong]),
+    'mode_conv1x1_sigmoid_bwd': (_c_int, [_c_ptr] * 7 + [_c_int] + [_c_ptr] + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
 }
 
-ABI_VERSION = 29  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 30  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

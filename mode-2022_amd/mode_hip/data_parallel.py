@@ -39,8 +39,20 @@ class GradAllReducer(object):
     """Identical replicas at step 0 (DataParallel re-broadcasts every step; once is enough)."""
     if self.world == 1:
       return
+    # ONE message per dtype instead of ~480 per-tensor broadcasts (83 weights + 80 x 5 BatchNorm entries; the 8-rank launch's start-up
+    # was hundreds of small collectives): the state is packed into a flat buffer, broadcast, and copied back.  fp32 tensors -- all the
+    # parameters and running statistics -- go as one 22 MB message, the int64 batch counters as a second, tiny one.
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-      dist.broadcast(t.data, src, group=self.group)
+      by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+    for (dtype, device), ts in by_dtype.items():
+      flat = torch.cat([t.reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1).clone()
+      dist.broadcast(flat, src, group=self.group)
+      off = 0
+      for t in ts:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    self.broadcast_messages = len(by_dtype)
 
   def zero_grad(self):
     self.flat.zero_()

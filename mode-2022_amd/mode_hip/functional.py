@@ -156,8 +156,12 @@ def _conv2d_own(x, w):
   (tools/microbench.py --only conv2d): 90-130 TFLOP/s against the vendor's 80-112 at every shape of the extractor, half
   resolution included, and the fusion network's full-resolution layers (1024 x 512: 32.2 -> 31.9 ms per training step); larger
   images stay on the vendor library (untested territory for the tile choice)."""
-  return (x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and w.shape[0] <= 128 and w.shape[1] <= 128 and
-          max(w.shape[0], w.shape[1]) * x.shape[2] * x.shape[3] < 2**29)
+  co, ci = int(w.shape[0]), int(w.shape[1])
+  # the fp32 kernels take up to 128 channels on either side; wider layers (the fusion network's 256-channel bottleneck) need the split
+  # kernels in both directions (forward: reduction ci, input gradient: reduction co -- multiples of 16)
+  wide_ok = CONV_ARITH == 'bf16x6' and ci % 16 == 0 and co % 16 == 0 and max(ci, co) <= 512
+  return (x.shape[2] * x.shape[3] <= CONV2D_OWN_MAX_PIXELS and ((co <= 128 and ci <= 128) or wide_ok) and
+          max(co, ci) * x.shape[2] * x.shape[3] < 2**29)
 
 
 def conv2d_wgrad_supported(x, w):
@@ -265,14 +269,14 @@ class Conv2d3x3Function(torch.autograd.Function):
     gy = gy.contiguous()
     gx = None
     if ctx.needs_input_grad[0]:
-      prev = ctx.carrier.take() if ctx.carrier is not None else None  # the skip's gradient, when it came first (it always does)
+      prev = ctx.carrier.take(ctx) if ctx.carrier is not None else None  # the skip's gradient, when it came first (it always does)
       if ctx.own:
         gx = conv2d_bwd_data(gy, w.contiguous(), dil, acc=prev, w_amax=ctx.w_amax)
       else:
         gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0]
         if prev is not None:
           gx = gx.add_(prev)
-      if prev is None and ctx.carrier is not None and ctx.carrier.leave(gx):
+      if prev is None and ctx.carrier is not None and ctx.carrier.leave(gx, ctx):
         gx = None
     gw = None
     if ctx.needs_input_grad[1]:
@@ -1221,32 +1225,54 @@ class FanOutFunction(torch.autograd.Function):
 # whose backward runs first leaves its gradient in the carrier and reports None, the second adds it inside the kernel that produces its
 # own (mode_conv3d_bwd_data_split_acc: one extra read in the store instead of three passes) -- the same fp32 sum, bit for bit.  Both
 # consumers register in their forward (arm); a gradient is only left behind when both did.  Consumers that cannot add in their kernel
-# (the BatchNorm backward that owns a residual skip's gradient) can still be the first.  Assumes what this model guarantees: when the
-# gradient of the shared tensor is needed, both backwards run in the same pass.
+# (the BatchNorm backward that owns a residual skip's gradient) can still be the first.
+# The hand-off relies on both backwards running in the same pass -- what this model's training step guarantees -- and CHECKS it (ADVICE
+# r5): the consumer that leaves a gradient queues a callback for the end of that backward pass; a gradient still parked then means the
+# partner never ran (backward(inputs=...), autograd.grad on a sub-graph): the pass has reported None for a gradient it dropped, and
+# the callback raises instead of letting a wrong gradient through (and un-parks the tensor, up to 403 MB).  A gradient left over from a
+# pass that died before its callbacks ran is recognised by its owner -- the same consumer asking first again -- and dropped.
 GRAD_CARRIERS = True  # bench.py --no-grad-carriers measures autograd's own accumulation
 
 
 class GradCarrier(object):
-  __slots__ = ('armed', 'grad')
+  __slots__ = ('armed', 'grad', 'owner')
 
   def __init__(self):
     self.armed = 0
     self.grad = None
+    self.owner = None
 
   def arm(self, needs_grad):
     if needs_grad:
       self.armed += 1
 
-  def take(self):
-    g, self.grad = self.grad, None
+  def take(self, who=None):
+    """The partner's gradient when it came first, else None.  `who` identifies the asking consumer (its autograd ctx): a gradient it
+    parked itself is a leftover of an earlier, aborted pass -- dropped, not added."""
+    g, owner = self.grad, self.owner
+    self.grad = self.owner = None
+    if g is not None and who is not None and owner is who:
+      return None
     return g
 
-  def leave(self, g):
+  def leave(self, g, who=None):
     """First of the two backwards: True when g was left for the other one (report None to autograd), False to return it as usual."""
     if self.armed == 2 and g is not None:
-      self.grad = g
+      self.grad, self.owner = g, who
+      try:
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+      except RuntimeError:  # (not inside a backward pass: nothing to check against; behave like autograd)
+        self.grad = self.owner = None
+        return False
       return True
     return False
+
+  def _end_of_pass(self):
+    if self.grad is not None:
+      self.grad = self.owner = None
+      raise RuntimeError('mode_hip GradCarrier: one of the two consumers of a shared tensor ran its backward and the other did not '
+                         '(backward(inputs=...) / autograd.grad on a sub-graph?): the gradient of the shared tensor would be incomplete. '
+                         'Set mode_hip.functional.GRAD_CARRIERS = False for partial backward passes.')
 
 
 def grad_carrier(x):
@@ -1305,10 +1331,11 @@ def _tag3(name, ci, co, stride, d, h, w):
   return '%s[%d->%d s%d %dx%dx%d]' % (name, ci, co, stride, d, h, w) if profiling.ENABLED else name
 
 
-# EXPERIMENTAL (round 5, off by default; bench.py --conv3d-f16): the stride-1 3-D layers' forward and input gradient on TWO fp16 pieces
-# and three MFMAs per product (mode_conv3d_*_split_f16; 30-35 % faster kernels) -- each operand scaled by a power of two taken from its
-# tensor's largest magnitude (mode_abs_max: one more pass over the activation operand per call).  Elements far below their tensor's
-# maximum lose relative precision: not the product arithmetic until the float64 tests say it may be.
+# The stride-1 3-D layers of a TRAINING step run on TWO fp16 pieces and three MFMAs per product (mode_conv3d_*_split_f16; the
+# product default since round 5, `bench.py --no-conv3d-f16` is the A/B): each operand scaled by a power of two taken from its tensor's
+# largest finite magnitude -- left by the BatchNorm pass that wrote the tensor (the `_amax` entries), or by mode_abs_max.
+# Precision contract (include/mode_hip.h): an element keeps 22 significant bits down to ~2^-17 of its tensor's maximum, fewer below,
+# none below ~2^-39 of it; three bf16 pieces (CONV3D_S1_F16 = False, and every inference call) keep 24 bits for every element.
 CONV3D_S1_F16 = True
 
 
@@ -1488,9 +1515,9 @@ class Conv3dFunction(torch.autograd.Function):
         ag = abs_max(gy)
     if ctx.needs_input_grad[0]:
       carrier = getattr(ctx, 'carrier', None)  # (Conv3dStatsFunction shares this backward and has none)
-      prev = carrier.take() if carrier is not None else None  # the other consumer's gradient, when it came first
+      prev = carrier.take(ctx) if carrier is not None else None  # the other consumer's gradient, when it came first
       gx = conv3d_bwd_data(gy, w, x.shape, ctx.stride, acc=prev, amax=(ag, fwd_amax[1]) if ag is not None else None)
-      if prev is None and carrier is not None and carrier.leave(gx):
+      if prev is None and carrier is not None and carrier.leave(gx, ctx):
         gx = None  # first of the two: the other consumer's backward returns the sum
     gw = None
     if ctx.needs_input_grad[1]:
@@ -1729,6 +1756,27 @@ def _written_by_kernel(*tensors):
   live = [t for t in tensors if t is not None]
   if live:
     torch.autograd.graph.increment_version(live)
+    log = getattr(_bn_tls, 'written_log', None)
+    if log is not None:  # a capture is recording: the REPLAYS write these tensors too, through the same raw pointers (GraphedStep.replay)
+      log.extend(live)
+
+
+def written_log_begin():
+  """Start recording (on this thread) the tensors the library's kernels write through raw pointers -- BatchNorm running statistics and
+  batch counters; graph_step.GraphedStep calls this around a capture: every replay of the graph writes them again, with no Python in
+  between to move their version counters, so replay() moves them (the packed-weight cache of the eval forward and
+  GraphedStep.stale() of a captured inference otherwise miss a BatchNorm recalibration run as replayed training steps)."""
+  _bn_tls.written_log = []
+
+
+def written_log_end():
+  log, _bn_tls.written_log = getattr(_bn_tls, 'written_log', None) or [], None
+  seen, out = set(), []
+  for t in log:
+    if id(t) not in seen:
+      seen.add(id(t))
+      out.append(t)
+  return out
 
 
 def _bcs(t):
@@ -1777,20 +1825,21 @@ class BnActFunction(torch.autograd.Function):
                 ptr(running_var) if running_var is not None else None, ptr(num_batches_tracked) if num_batches_tracked is not None else None,
                 float(momentum), float(eps), int(relu), ptr(out), ptr(mean), ptr(invstd), ptr(coef[0]) if from_y else None,
                 ptr(coef[1]) if from_y else None)
-      _bn_tls.out_amax = None
+      _bn_tls.out_amax = out_amax = None
       if CONV_ARITH == 'bf16x6' and ((CONV3D_S1_F16 and y.dim() == 5) or (SPHERE_FWD_F16 and y.dim() == 4 and C % 16 == 0)):
         # the 3-D stack's activations feed stride-1 convolutions on the fp16 arithmetic, the extractor's the spherical layers: their
-        # maximum comes out of this pass
-        _bn_tls.out_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
-        lib().mode_bn_next_out_absmax(ptr(_bn_tls.out_amax))
+        # maximum comes out of this pass (the `_amax` entries; bn_act tags `out` with the buffer)
+        _bn_tls.out_amax = out_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
       if prestats_ws is not None:  # the producing convolution left the statistics in the workspace (conv3d_bn_train): no statistics pass
         if groups != 1:
           raise RuntimeError('BatchNorm with precomputed statistics takes one statistics group')
-        check(lib().mode_bn_train_fwd_prestats(*common, ptr(prestats_ws), lib().mode_conv3d_fwd_split_stats_partials(), B, C, S, stream_of(y)),
-              'mode_bn_train_fwd_prestats')
+        check(lib().mode_bn_train_fwd_prestats_amax(*common, ptr(prestats_ws), lib().mode_conv3d_fwd_split_stats_partials(), B, C, S,
+                                                    ptr(out_amax) if out_amax is not None else None, stream_of(y)),
+              'mode_bn_train_fwd_prestats_amax')
       else:
         ws = _bn_ws(C * groups, y.device)
-        check(lib().mode_bn_train_fwd(*common, ptr(ws), B, C, S, groups, stream_of(y)), 'mode_bn_train_fwd')
+        check(lib().mode_bn_train_fwd_amax(*common, ptr(ws), B, C, S, groups, ptr(out_amax) if out_amax is not None else None, stream_of(y)),
+              'mode_bn_train_fwd_amax')
     _written_by_kernel(running_mean, running_var, num_batches_tracked)
     ctx.save_for_backward(y, out if (relu and not from_y) else None, gamma, beta, mean, invstd, coef)
     ctx.relu, ctx.has_add, ctx.groups = bool(relu), add is not None, groups
@@ -1812,13 +1861,13 @@ class BnActFunction(torch.autograd.Function):
     gy_amax = None
     if CONV_ARITH == 'bf16x6' and ((CONV3D_S1_F16 and y.dim() == 5) or (SPHERE_BWD_F16 and y.dim() == 4 and C % 16 == 0)):
       gy_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)  # the convolution in front reads gy in both of its gradients
-      lib().mode_bn_next_gy_absmax(ptr(gy_amax))
     with torch.cuda.device_of(y), profiling.region(_tag_bn('bn_train_bwd', y), nbytes, 0, y.device):
       ws = _bn_ws(C * ctx.groups, y.device)
-      check(lib().mode_bn_train_bwd(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
-                                    ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
-                                    ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
-                                    int(fused), ptr(ws), B, C, S, ctx.groups, stream_of(y)), 'mode_bn_train_bwd')
+      check(lib().mode_bn_train_bwd_amax(ptr(gout), ptr(y), ptr(out) if out is not None else None, ptr(gamma), ptr(mean), ptr(invstd),
+                                         ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None, int(ctx.relu),
+                                         ptr(gy), ptr(gadd) if gadd is not None else None, ptr(ggamma), ptr(gbeta),
+                                         int(fused), ptr(ws), B, C, S, ctx.groups, ptr(gy_amax) if gy_amax is not None else None,
+                                         stream_of(y)), 'mode_bn_train_bwd_amax')
     if gy_amax is not None:
       gy._mode_amax = (gy_amax, gy._version, gy.data_ptr())  # (survives the engine's hand-over when the tensor's Python object does;
     if fused:                                               #  Conv3dFunction.backward computes the maximum itself otherwise)
@@ -1826,10 +1875,10 @@ class BnActFunction(torch.autograd.Function):
     if ctx.has_add and not ctx.relu:
       gadd = gout  # the add passes the gradient through unchanged
     if gadd is not None and ctx.add_carrier is not None:
-      prev = ctx.add_carrier.take()
+      prev = ctx.add_carrier.take(ctx)
       if prev is not None:
         gadd = gadd + prev  # (the other consumer came first: this backward cannot add inside its kernel)
-      elif ctx.add_carrier.leave(gadd):
+      elif ctx.add_carrier.leave(gadd, ctx):
         gadd = None  # the skip's other consumer adds it inside its input-gradient kernel
     return gy, gadd, ggamma, gbeta, None, None, None, None, None, None, None, None, None
 
@@ -1946,10 +1995,9 @@ class ClassifHeadFunction(torch.autograd.Function):
       gy_amax = None
       if CONV3D_S1_F16 and CONV_ARITH == 'bf16x6':  # the 32 -> 32 convolution in front reads gy in both of its gradients (BnActFunction.backward)
         gy_amax = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=y.device)
-        lib().mode_bn_next_gy_absmax(ptr(gy_amax))
-      check(lib().mode_classif_train_bwd(ptr(gcost), ptr(y), ptr(w), ptr(gamma), ptr(beta), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
-                                         ptr(saved[3]), ptr(gy), ptr(gw), ptr(ggamma), ptr(gbeta), int(fused), ptr(ws), B, C, D, H, W,
-                                         stream_of(y)), 'mode_classif_train_bwd')
+      check(lib().mode_classif_train_bwd_amax(ptr(gcost), ptr(y), ptr(w), ptr(gamma), ptr(beta), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]),
+                                              ptr(saved[3]), ptr(gy), ptr(gw), ptr(ggamma), ptr(gbeta), int(fused), ptr(ws), B, C, D, H, W,
+                                              ptr(gy_amax) if gy_amax is not None else None, stream_of(y)), 'mode_classif_train_bwd_amax')
       if gy_amax is not None:
         gy._mode_amax = (gy_amax, gy._version, gy.data_ptr())
     if fused:
@@ -1966,6 +2014,182 @@ def classif_head_train(y, bn, conv, add=None):
     nbt = None
   return ClassifHeadFunction.apply(y, conv.weight, bn.weight, bn.bias, add, bn.running_mean if update else None,
                                    bn.running_var if update else None, bn.momentum, bn.eps, nbt)
+
+
+# ------------------------------------------------------------------------------------ fusion network: pooling, 2x2 transposed conv, head
+class MaxPool2x2Function(torch.autograd.Function):
+  """nn.MaxPool2d(2, stride=2) (mode_fusion.py:146, :161, :190) on csrc/fusion_ops.hip; the backward recomputes the picks from x."""
+
+  @staticmethod
+  def forward(ctx, x):
+    require_gpu(x)
+    x = x.contiguous()
+    require_f32c(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device_of(x), profiling.region('maxpool2x2_fwd', 4 * (x.numel() + y.numel()), 0, x.device):
+      check(lib().mode_maxpool2x2_fwd(ptr(x), ptr(y), B * C, H, W, stream_of(x)), 'mode_maxpool2x2_fwd')
+    ctx.save_for_backward(x)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    with torch.cuda.device_of(x), profiling.region('maxpool2x2_bwd', 4 * (2 * x.numel() + gy.numel()), 0, x.device):
+      check(lib().mode_maxpool2x2_bwd(ptr(x), ptr(gy), ptr(gx), B * C, H, W, stream_of(x)), 'mode_maxpool2x2_bwd')
+    return gx
+
+
+def maxpool2x2_supported(x, pool):
+  ks = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size,) * 2
+  st = pool.stride if isinstance(pool.stride, tuple) else (pool.stride,) * 2
+  pad = pool.padding if isinstance(pool.padding, tuple) else (pool.padding,) * 2
+  dil = pool.dilation if isinstance(pool.dilation, tuple) else (pool.dilation,) * 2
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and ks == (2, 2) and st == (2, 2) and pad == (0, 0) and dil == (1, 1) and
+          not pool.ceil_mode and not pool.return_indices and x.shape[2] >= 2 and x.shape[3] >= 2)
+
+
+def maxpool2x2(x):
+  return MaxPool2x2Function.apply(x)
+
+
+def _deconv2x2_gemm(x, w):
+  """y4 (B, 4 Co, H, W) = the 1x1 convolution half of ConvTranspose2d(Ci, Co, 2, 2): row 4 o + 2 i + j of the weight's own (Ci, 4 Co)
+  storage -- mode_conv1x1_bwd_data reads a (rows-of-the-reduction, output) weight exactly as w lies."""
+  B, Ci, H, W = x.shape
+  R = w.shape[1] * 4
+  y4 = torch.empty((B, R, H, W), dtype=x.dtype, device=x.device)
+  with torch.cuda.device_of(x), profiling.region(_tag1('deconv2x2_gemm', Ci, R, 1, H, W), 4 * (x.numel() + y4.numel() + w.numel()),
+                                                 2 * y4.numel() * Ci, x.device):
+    wp = torch.empty(lib().mode_conv1x1_wpack_bytes(R, Ci) // 4, dtype=torch.float32, device=x.device)
+    check(lib().mode_conv1x1_bwd_data(ptr(x), ptr(w), ptr(y4), ptr(wp), B, R, H, W, Ci, 1, stream_of(x)), 'mode_conv1x1_bwd_data')
+  return y4
+
+
+def _depth_to_space2(y4, scale, shift, relu):
+  B, R, H, W = y4.shape
+  Co = R // 4
+  y = torch.empty((B, Co, 2 * H, 2 * W), dtype=y4.dtype, device=y4.device)
+  with torch.cuda.device_of(y4), profiling.region('depth_to_space2', 8 * y4.numel(), 0, y4.device):
+    check(lib().mode_depth_to_space2(ptr(y4), ptr(scale) if scale is not None else None, ptr(shift) if shift is not None else None, ptr(y),
+                                     B, Co, H, W, int(relu), stream_of(y4)), 'mode_depth_to_space2')
+  return y
+
+
+def deconv2x2_supported(x, conv):
+  """nn.ConvTranspose2d(Ci, Co, 2, 2) of the fusion decoder (mode_fusion.py:195, :212): kernel 2, stride 2, no padding; the 1x1 GEMM's
+  weight gradient loads 16-byte row pieces (W % 4 == 0)."""
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv) is torch.nn.ConvTranspose2d and conv.kernel_size == (2, 2) and
+          conv.stride == (2, 2) and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and
+          x.shape[3] % 4 == 0 and 4 * max(conv.in_channels, conv.out_channels) * x.shape[2] * x.shape[3] < 2**31)
+
+
+class Deconv2x2Function(torch.autograd.Function):
+  """y = conv_transpose2d(x, w (Ci, Co, 2, 2), bias, stride 2): the 1x1 GEMM on csrc/conv1x1.hip + the rearrangement of fusion_ops.hip."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias):
+    require_gpu(x, w)
+    x, w = x.contiguous(), w.contiguous()
+    require_f32c(x, w)
+    ctx.save_for_backward(x, w)
+    ctx.has_bias = bias is not None
+    return _depth_to_space2(_deconv2x2_gemm(x, w), None, bias.contiguous() if bias is not None else None, False)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, Ci, H, W = x.shape
+    Co = w.shape[1]
+    R = 4 * Co
+    g4 = torch.empty((B, R, H, W), dtype=gy.dtype, device=gy.device)
+    with torch.cuda.device_of(gy), profiling.region('space_to_depth2', 8 * gy.numel(), 0, gy.device):
+      check(lib().mode_space_to_depth2(ptr(gy), ptr(g4), B, Co, H, W, stream_of(gy)), 'mode_space_to_depth2')
+    gx = gw = gb = None
+    if ctx.needs_input_grad[0]:  # gx[b, c, q] = sum_r w[c][r] g4[b, r, q]: a 1x1 convolution R -> Ci with the weight as it lies
+      gx = torch.empty_like(x)
+      with torch.cuda.device_of(x), profiling.region(_tag1('deconv2x2_bwd_data', R, Ci, 1, H, W), 4 * (gx.numel() + g4.numel() + w.numel()),
+                                                     2 * g4.numel() * Ci, x.device):
+        wp = torch.empty(lib().mode_conv1x1_wpack_bytes(R, Ci) // 4, dtype=torch.float32, device=x.device)
+        check(lib().mode_conv1x1_fwd(ptr(g4), ptr(w), ptr(gx), ptr(wp), B, R, H, W, Ci, 1, stream_of(x)), 'mode_conv1x1_fwd')
+    if ctx.needs_input_grad[1]:  # gw[c][r] = sum x[b, c, q] g4[b, r, q]: the 1x1 weight gradient with "gy" := x, "x" := g4
+      sink = grad_sink(w)
+      gw = sink if sink is not None else torch.empty_like(w)
+      with torch.cuda.device_of(x), profiling.region(_tag1('deconv2x2_bwd_weight', R, Ci, 1, H, W), 4 * (x.numel() + g4.numel() + w.numel()),
+                                                     2 * g4.numel() * Ci, x.device):
+        ws = torch.empty(max(lib().mode_conv1x1_bwd_weight_workspace_bytes(B, R, H, W, Ci, 1) // 4, 1), dtype=torch.float32, device=x.device)
+        check(lib().mode_conv1x1_bwd_weight(ptr(x), ptr(g4), ptr(gw), ptr(ws), B, R, H, W, Ci, 1, int(sink is not None), stream_of(x)),
+              'mode_conv1x1_bwd_weight')
+      if sink is not None:
+        gw = None
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+      gb = gy.sum((0, 2, 3))
+    return gx, gw, gb
+
+
+def deconv2x2(x, conv):
+  return Deconv2x2Function.apply(x, conv.weight, conv.bias)
+
+
+def deconv2x2_bn_eval(x, conv, bn, relu):
+  """relu?(eval-mode bn(conv_transpose2d(x))) in two launches: the 1x1 GEMM, then the rearrangement with bias and BatchNorm folded into
+  its per-channel affine (C-element vectors, formed on the device)."""
+  x, w = x.contiguous(), conv.weight.detach().contiguous()
+  require_gpu(x, w)
+  require_f32c(x, w)
+  scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+  bias = conv.bias.detach() if conv.bias is not None else torch.zeros_like(bn.running_mean)
+  shift = (bias - bn.running_mean) * scale + bn.bias.detach()
+  return _depth_to_space2(_deconv2x2_gemm(x, w), scale.contiguous(), shift.contiguous(), relu)
+
+
+def conv1x1_sigmoid_supported(x, conv):
+  """nn.Conv2d(C, 1, 1, bias=True) + nn.Sigmoid, the last two layers of the fusion network (mode_fusion.py:228-229)."""
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and
+          conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.out_channels == 1 and conv.in_channels <= 64 and
+          (x.shape[2] * x.shape[3]) % 4 == 0)
+
+
+class Conv1x1SigmoidFunction(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, w, bias):
+    require_gpu(x, w)
+    x, w = x.contiguous(), w.contiguous()
+    require_f32c(x, w)
+    B, C, H, W = x.shape
+    s = torch.empty((B, 1, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device_of(x), profiling.region('conv1x1_sigmoid_fwd', 4 * (x.numel() + s.numel()), 2 * x.numel(), x.device):
+      check(lib().mode_conv1x1_sigmoid_fwd(ptr(x), ptr(w), ptr(bias) if bias is not None else None, ptr(s), B, C, H * W, stream_of(x)),
+            'mode_conv1x1_sigmoid_fwd')
+    ctx.save_for_backward(x, w, s)
+    ctx.has_bias = bias is not None
+    return s
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gs):
+    x, w, s = ctx.saved_tensors
+    gs = gs.contiguous()
+    B, C, H, W = x.shape
+    gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    gw = torch.empty_like(w)
+    gb = torch.empty(1, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+    with torch.cuda.device_of(x), profiling.region('conv1x1_sigmoid_bwd', 4 * (3 * x.numel() + 2 * s.numel()), 4 * x.numel(), x.device):
+      ws = torch.empty(max(lib().mode_conv1x1_sigmoid_bwd_workspace_bytes(B, H * W) // 4, 1), dtype=torch.float32, device=x.device)
+      check(lib().mode_conv1x1_sigmoid_bwd(ptr(x), ptr(w), ptr(s), ptr(gs), ptr(gx) if gx is not None else None, ptr(gw),
+                                           ptr(gb) if gb is not None else None, 0, ptr(ws), B, C, H * W, stream_of(x)), 'mode_conv1x1_sigmoid_bwd')
+    return gx, gw if ctx.needs_input_grad[1] else None, gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+
+
+def conv1x1_sigmoid(x, conv):
+  return Conv1x1SigmoidFunction.apply(x, conv.weight, conv.bias)
 
 
 # ------------------------------------------------------------------------------------ eval mode: convolution + folded BatchNorm

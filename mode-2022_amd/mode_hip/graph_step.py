@@ -28,7 +28,8 @@ calls (functional._eval_wpack).  The warm-up above fills that cache, so the capt
 kernels: a replay computes with the packs of capture time.  That is what makes a replayed eval forward cheaper than an eager one
 (0.65 ms of 10.3 at one pair), and it is only valid while the weights stand: the capture records (tensor, version) of everything the
 hits vouched for, and replay() raises once any of them has been written by torch (optimizer step, load_state_dict, in-place op) or by
-this library's training kernels; `stale()` tells without raising.  Writes through `.data` or foreign raw pointers move no version:
+this library's training kernels -- launched eagerly or by a replayed training graph, whose replay() moves the version counters of the
+BatchNorm state it writes; `stale()` tells without raising.  Writes through `.data` or foreign raw pointers move no version:
 call functional.invalidate_eval_packs(model) and capture again after those.  A captured TRAINING step packs inside the graph and is
 not affected.
 """
@@ -54,12 +55,15 @@ class GraphedStep(object):
     torch.cuda.synchronize(dev)
     self.graph = torch.cuda.CUDAGraph()
     functional.frozen_packs_begin()
+    functional.written_log_begin()
     try:
       with torch.cuda.graph(self.graph, pool=pool):
         self.outputs = fn()
     finally:
       # (tensor, version) pairs whose packed copies the captured kernels read WITHOUT repacking (see the contract above)
       self.frozen = functional.frozen_packs_end()
+      # tensors the captured kernels write through raw pointers (BatchNorm running statistics): every replay writes them again
+      self.written = functional.written_log_end()
     torch.cuda.synchronize(dev)
 
   def load(self, *tensors):
@@ -76,4 +80,6 @@ class GraphedStep(object):
       raise RuntimeError('GraphedStep: the weights of an eval-mode layer changed after this graph was captured; the graph reads the '
                          'packed copies of capture time -- capture a new GraphedStep (see the fixed-weights contract in graph_step.py)')
     self.graph.replay()
+    if self.written:  # what the eager step does after every BatchNorm launch (functional._written_by_kernel): host-side only
+      torch.autograd.graph.increment_version(self.written)
     return self.outputs

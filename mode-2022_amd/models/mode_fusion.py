@@ -6,15 +6,19 @@ reference: ``ModeFusion(maxdepth, channels, inplanes)`` (mode_fusion.py:286-307,
 (:269-283) and ``depth_regression`` (:255-265).
 
 The network is a 2D U-Net of 3x3 ``Conv2d -> BatchNorm2d -> ReLU`` pairs with max-pooling on the way down and 2x2 transposed
-convolutions on the way up.  The convolutions, poolings and the final sigmoid are vendor (MIOpen / ATen) ops; every
-``BatchNorm2d (+ ReLU)`` runs on the fused HIP kernels of the disparity stage (``stage3d.bn_act`` -> ``mode_bn_train_fwd`` /
-``mode_bn_eval_fwd`` / ``mode_bn_train_bwd``: two passes over the activation in training, one in eval, instead of the three
-to five of the unfused ops), which is where a fp32 network of this shape spends the time that is not convolution.
+convolutions on the way up.  Since round 6 every layer runs on the hand-written kernels (no MIOpen / rocBLAS call in its forward or
+backward; ``tests/test_fusion.py`` runs it under the no-vendor guard): the 3x3 convolutions on the disparity stage's ``conv2d``
+kernels (split-bf16 matrix path; the 12-channel input layers on the fp32 MFMA kernel; inference folds the BatchNorm into the
+convolution), every ``BatchNorm2d (+ ReLU)`` on the fused BatchNorm kernels, max-pooling / the rearrangement half of the 2x2
+transposed convolutions / the sigmoid head on ``csrc/fusion_ops.hip``, the GEMM half of the transposed convolutions on
+``csrc/conv1x1.hip``.  What is left to ATen is data movement (``cat``) and the final multiplication by ``maxdepth``.
 CPU tensors raise NotImplementedError like the rest of the package: there is no CPU path."""
 import math
 
 import torch
 import torch.nn as nn
+
+from mode_hip import functional as HF
 
 from . import stage3d
 
@@ -27,7 +31,10 @@ def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
 
 
 def _run(module, x):
-  """Evaluate a (nested) Sequential, fusing every BatchNorm2d with the ReLU that follows it (if any) into one kernel."""
+  """Evaluate a (nested) Sequential on the hand-written kernels: convbn (+ ReLU) as stage3d.conv_bn (training: convolution kernel +
+  the fused BatchNorm passes; inference: ONE launch, BatchNorm folded into the convolution), max-pooling, the 2x2 transposed
+  convolution with its BatchNorm + ReLU, and the single-channel head with its sigmoid (csrc/fusion_ops.hip).  Host tensors keep the
+  torch modules (the CPU wiring tests)."""
   if isinstance(module, BasicBlock):
     return module(x)
   if not isinstance(module, nn.Sequential):
@@ -36,15 +43,28 @@ def _run(module, x):
   i = 0
   while i < len(items):
     m = items[i]
+    nxt = items[i + 1] if i + 1 < len(items) else None
     if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d):
-      relu = i + 1 < len(items) and isinstance(items[i + 1], nn.ReLU)  # convbn (+ ReLU)
-      # (stride-1 3x3 layers: own conv2d kernels, csrc/conv2d*.hip; host tensors keep torch's convolution for the wiring tests)
-      x = stage3d.bn_act(m[1], stage3d.conv3(m[0], x) if x.is_cuda else m[0](x), None, relu)
+      relu = isinstance(nxt, nn.ReLU)  # convbn (+ ReLU)
+      x = stage3d.conv_bn(m, x, relu=relu) if x.is_cuda else stage3d.bn_act(m[1], m[0](x), None, relu)
       i += 2 if relu else 1
+    elif isinstance(m, nn.ConvTranspose2d) and isinstance(nxt, nn.BatchNorm2d) and x.is_cuda and HF.deconv2x2_supported(x, m):
+      relu = i + 2 < len(items) and isinstance(items[i + 2], nn.ReLU)  # ConvTranspose2d -> BatchNorm2d -> ReLU (mode_fusion.py:195-197)
+      if HF.bn_foldable(nxt):
+        x = HF.deconv2x2_bn_eval(x, m, nxt, relu)
+      else:
+        x = stage3d.bn_act(nxt, HF.deconv2x2(x, m), None, relu)
+      i += 3 if relu else 2
     elif isinstance(m, nn.BatchNorm2d):
-      relu = i + 1 < len(items) and isinstance(items[i + 1], nn.ReLU)  # ConvTranspose2d -> BatchNorm2d -> ReLU
+      relu = isinstance(nxt, nn.ReLU)
       x = stage3d.bn_act(m, x, None, relu)
       i += 2 if relu else 1
+    elif isinstance(m, nn.MaxPool2d) and x.is_cuda and HF.maxpool2x2_supported(x, m):
+      x = HF.maxpool2x2(x)
+      i += 1
+    elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.Sigmoid) and x.is_cuda and HF.conv1x1_sigmoid_supported(x, m):
+      x = HF.conv1x1_sigmoid(x, m)  # Conv2d(planes, 1, 1, bias=True) + Sigmoid (mode_fusion.py:228-229)
+      i += 2
     else:
       x = _run(m, x)
       i += 1

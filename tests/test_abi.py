@@ -30,11 +30,11 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 29
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 30
 
 
 def test_maximum_buffer_size_matches_the_header():
-  """functional.BN_ABSMAX_FLOATS (what Python allocates for mode_abs_max / mode_bn_next_*_absmax) is the header's MODE_BN_ABSMAX_FLOATS (what the
+  """functional.BN_ABSMAX_FLOATS (what Python allocates for mode_abs_max / the `_amax` BatchNorm entries) is the header's MODE_BN_ABSMAX_FLOATS (what the
   kernels zero and read: 16 + 128 slots x 16 floats); the fp16 entries reject a missing maximum on the host."""
   from mode_hip import functional as HF
   src = open(os.path.join(ROOT, 'include', 'mode_hip.h')).read()
@@ -204,6 +204,22 @@ def test_bn_train_fwd_refuses_in_place_operation():
   a, b = ctypes.c_void_p(4096), ctypes.c_void_p(8192)
   rc = lib.mode_bn_train_fwd(a, None, b, b, None, None, None, 0.1, 1e-5, 1, a, b, b, None, None, b, 2, 4, 64, 1, None)
   assert rc == -1 and b'in-place' in lib.mode_last_error()
+
+
+def test_no_state_between_calls_in_the_abi():
+  """the maximum of a tensor a BatchNorm pass writes is requested through a PARAMETER of the `_amax` entries, not through a
+  one-shot setter in front of the plain call -- the header's own convention (no mutable state between calls) holds for every entry."""
+  lib = mode_hip.lib()
+  for gone in ('mode_bn_next_out_absmax', 'mode_bn_next_gy_absmax'):
+    assert not hasattr(lib, gone), gone
+  src = open(os.path.join(ROOT, 'mode-2022_amd', 'csrc', 'bn_act.hip')).read() + open(os.path.join(ROOT, 'mode-2022_amd', 'csrc', 'classif_head.hip')).read()
+  assert 'thread_local' not in src
+  # the `_amax` entries check their arguments like the plain ones (host-side, no launch): in-place is refused with a maximum buffer too
+  a, b = ctypes.c_void_p(4096), ctypes.c_void_p(8192)
+  rc = lib.mode_bn_train_fwd_amax(a, None, b, b, None, None, None, 0.1, 1e-5, 1, a, b, b, None, None, b, 2, 4, 64, 1, b, None)
+  assert rc == -1 and b'in-place' in lib.mode_last_error()
+  rc = lib.mode_bn_train_bwd_amax(None, a, None, b, b, b, None, None, 0, a, None, b, b, 0, b, 2, 4, 64, 1, b, None)
+  assert rc == -1 and b'null pointer' in lib.mode_last_error()
 
 
 def test_table_caches_are_bounded():

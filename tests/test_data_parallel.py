@@ -48,6 +48,20 @@ def _worker(rank, world, port, out):
         p.add_(1.0)
   red = data_parallel.GradAllReducer(net)
   red.broadcast_parameters(net)
+  # one message per dtype (fp32 state, int64 counters), not one per tensor: a module with BatchNorm state
+  def bn_net():
+    torch.manual_seed(4)
+    return nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4), nn.Conv2d(4, 2, 1), nn.BatchNorm2d(2))
+  m = bn_net()
+  if rank == 1:
+    with torch.no_grad():
+      for t in list(m.parameters()) + list(m.buffers()):
+        t.add_(3)
+  r2 = data_parallel.GradAllReducer(m)
+  r2.broadcast_parameters(m)
+  assert r2.broadcast_messages == 2
+  for a, b in zip(list(m.parameters()) + list(m.buffers()), list(bn_net().parameters()) + list(bn_net().buffers())):
+    assert torch.equal(a, b) and a.dtype == b.dtype, rank
   x, gt = _data()
   xs, gts = x[rank * 2:rank * 2 + 2], gt[rank * 2:rank * 2 + 2]
   mask = ~torch.isnan(gts)

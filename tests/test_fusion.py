@@ -102,8 +102,11 @@ def test_gpu_fusion_train_and_eval(golden):
     print('%s: |gpu-truth64| max %.2e mean %.2e; reference itself max %.2e mean %.2e' % (name, err.max(), err.mean(), ref_err.max(), ref_err.mean()))
     assert err.max() <= max(1e-4, 3 * ref_err.max()) and err.mean() <= max(1e-6, 2 * ref_err.mean())
 
+  from mode_hip import no_vendor
   net.train()
-  pred = net(dd, cc, rr)
+  with no_vendor.no_vendor_arithmetic() as guard:  # the whole forward on the hand-written kernels
+    pred = net(dd, cc, rr)
+  assert guard.seen > 0
   check('train', pred.detach().cpu().numpy().astype(np.float64), z['train/pred'], z['truth64/train_pred'])
   loss = fusion_ref.training_loss(pred, gt.to(dev), maxdepth)
   assert abs(float(loss) - float(z['train/loss'])) < 1e-4 * float(z['train/loss'])
@@ -118,8 +121,9 @@ def test_gpu_fusion_train_and_eval(golden):
       a = sd_after[k[3:]].cpu().numpy()
       assert np.abs(a - z[k]).max() <= 1e-4 * max(1.0, np.abs(z[k]).max()), k
   net.eval()
-  with torch.no_grad():
-    check('eval', net(dd, cc, rr).cpu().numpy().astype(np.float64), z['eval/pred'], z['truth64/eval_pred'])
+  with torch.no_grad(), no_vendor.no_vendor_arithmetic():
+    out = net(dd, cc, rr)
+  check('eval', out.cpu().numpy().astype(np.float64), z['eval/pred'], z['truth64/eval_pred'])
 
 
 @pytest.mark.gpu
@@ -132,7 +136,106 @@ def test_gpu_fusion_full_size_step():
   confs = [torch.rand(1, 1, 1024, 512, generator=g).to(dev) for _ in range(6)]
   rgbs = [torch.rand(1, 3, 1024, 512, generator=g).to(dev) for _ in range(4)]
   gt = (torch.rand(1, 1024, 512, generator=g) * 60).to(dev)
-  pred = net(depthes, confs, rgbs)
+  from mode_hip import no_vendor
+  with no_vendor.no_vendor_arithmetic():
+    pred = net(depthes, confs, rgbs)
   assert pred.shape == (1, 1, 1024, 512) and float(pred.min()) >= 0 and float(pred.max()) <= 1000
-  fusion_ref.training_loss(pred, gt, 1000).backward()
+  with no_vendor.no_vendor_arithmetic() as guard:  # the backward too (the dispatch mode travels to autograd's device thread)
+    fusion_ref.training_loss(pred, gt, 1000).backward()
+  assert guard.seen > 0
   assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+  # inference at the same size (BASELINE configs[4] names the forward): BatchNorm folded, still no vendor arithmetic
+  net.eval()
+  with torch.no_grad(), no_vendor.no_vendor_arithmetic():
+    out = net(depthes, confs, rgbs)
+  assert out.shape == (1, 1, 1024, 512) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 5, 8, 12), (1, 3, 9, 7), (2, 4, 16, 32), (1, 2, 2, 2)])
+def test_gpu_maxpool2x2_is_torchs(shape):
+  """mode_maxpool2x2_fwd / _bwd against torch's max_pool2d on the CPU: values, and the gradient's routing (ties go to the first element
+  in scan order, NaN wins), odd sizes (floor), bit for bit."""
+  from mode_hip import functional as HF
+  import torch.nn.functional as F
+  g = torch.Generator().manual_seed(3)
+  x = torch.randn(*shape, generator=g)
+  x[0, 0, :2, :2] = 1.5  # a tie
+  if shape[2] >= 4:
+    x[0, 1, 2, 3] = float('nan')
+  xr = x.clone().requires_grad_(True)
+  y_ref = F.max_pool2d(xr, 2, 2)
+  go = torch.randn(*y_ref.shape, generator=g)
+  y_ref.backward(go)
+  xd = x.to('cuda:0').requires_grad_(True)
+  y = HF.maxpool2x2(xd)
+  y.backward(go.to('cuda:0'))
+  assert torch.equal(y.detach().cpu().nan_to_num(nan=7.0), y_ref.detach().nan_to_num(nan=7.0))
+  assert torch.equal(xd.grad.cpu(), xr.grad)
+  pool = torch.nn.MaxPool2d(2, stride=2)
+  assert HF.maxpool2x2_supported(xd, pool) and not HF.maxpool2x2_supported(xd, torch.nn.MaxPool2d(3, stride=2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 8, 6, 8), (1, 64, 32, 16, 12), (1, 256, 128, 8, 4)])
+def test_gpu_deconv2x2_against_float64(B, Ci, Co, H, W):
+  """ConvTranspose2d(Ci, Co, 2, 2) as the 1x1 GEMM of csrc/conv1x1.hip + the rearrangement of csrc/fusion_ops.hip: forward, input
+  gradient, weight gradient, bias gradient against torch's float64 on the CPU; the eval form with the BatchNorm folded in."""
+  from mode_hip import functional as HF
+  torch.manual_seed(5)
+  conv = torch.nn.ConvTranspose2d(Ci, Co, 2, 2)
+  x = torch.randn(B, Ci, H, W)
+  go = torch.randn(B, Co, 2 * H, 2 * W)
+  c64 = torch.nn.ConvTranspose2d(Ci, Co, 2, 2).double()
+  c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+  x64 = x.double().requires_grad_(True)
+  y64 = c64(x64)
+  y64.backward(go.double())
+  convd = conv.to('cuda:0')
+  xd = x.to('cuda:0').requires_grad_(True)
+  assert HF.deconv2x2_supported(xd, convd)
+  y = HF.deconv2x2(xd, convd)
+  y.backward(go.to('cuda:0'))
+  tol = 2e-6 * Ci ** 0.5
+  assert float((y.detach().cpu().double() - y64.detach()).abs().max()) <= tol * max(1.0, float(y64.abs().max()))
+  assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= 4 * tol * max(1.0, float(x64.grad.abs().max()))
+  gw64, gb64 = c64.weight.grad, c64.bias.grad
+  assert float((convd.weight.grad.cpu().double() - gw64).abs().max()) <= 2e-6 * (B * H * W) ** 0.5 * max(1.0, float(gw64.abs().max()))
+  assert float((convd.bias.grad.cpu().double() - gb64).abs().max()) <= 1e-5 * max(1.0, float(gb64.abs().max()))
+  bn = torch.nn.BatchNorm2d(Co)
+  with torch.no_grad():
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2.0)
+    bn.weight.uniform_(0.5, 1.5)
+    bn.bias.normal_()
+  bn.eval()
+  ref = torch.relu(bn.double()(y64.detach()))
+  bn = bn.float().to('cuda:0')
+  with torch.no_grad():
+    got = HF.deconv2x2_bn_eval(xd.detach(), convd, bn, True)
+  assert float((got.cpu().double() - ref).abs().max()) <= 4 * tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 8, 12), (1, 8, 6, 10), (1, 32, 64, 32)])
+def test_gpu_conv1x1_sigmoid_against_float64(B, C, H, W):
+  """Conv2d(C, 1, 1, bias=True) + Sigmoid in one pass (mode_conv1x1_sigmoid_fwd / _bwd) against torch's float64 on the CPU."""
+  from mode_hip import functional as HF
+  torch.manual_seed(6)
+  conv = torch.nn.Conv2d(C, 1, 1, bias=True)
+  x = torch.randn(B, C, H, W)
+  go = torch.randn(B, 1, H, W)
+  c64 = torch.nn.Conv2d(C, 1, 1, bias=True).double()
+  c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+  x64 = x.double().requires_grad_(True)
+  s64 = torch.sigmoid(c64(x64))
+  s64.backward(go.double())
+  convd = conv.to('cuda:0')
+  xd = x.to('cuda:0').requires_grad_(True)
+  assert HF.conv1x1_sigmoid_supported(xd, convd)
+  s = HF.conv1x1_sigmoid(xd, convd)
+  s.backward(go.to('cuda:0'))
+  assert float((s.detach().cpu().double() - s64.detach()).abs().max()) <= 2e-6
+  assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= 2e-6 * max(1.0, float(x64.grad.abs().max()))
+  assert float((convd.weight.grad.cpu().double() - c64.weight.grad).abs().max()) <= 1e-5 * max(1.0, float(c64.weight.grad.abs().max()))
+  assert float((convd.bias.grad.cpu().double() - c64.bias.grad).abs().max()) <= 1e-5 * max(1.0, float(c64.bias.grad.abs().max()))

@@ -104,7 +104,7 @@ def test_f16_layers_propagate_nan_and_inf_like_the_bf16_ones(f16_switch):
 
 
 def test_batchnorm_pass_leaves_its_outputs_maximum(f16_switch):
-  """The operand maximum of an fp16 convolution comes out of the BatchNorm pass that wrote the operand (mode_bn_next_out_absmax):
+  """The operand maximum of an fp16 convolution comes out of the BatchNorm pass that wrote the operand (mode_bn_train_fwd_amax):
   exactly mode_abs_max of the output, with and without ReLU / residual; dropped when the tensor is written again; and the convolution
   that follows gives the bits it gives with a maximum pass of its own."""
   HF.CONV3D_S1_F16 = True

@@ -422,6 +422,23 @@ def test_head_backward_takes_the_two_kernel_form_beyond_512_columns():
   assert float((wide - l2.grad).abs().max()) <= 2e-5 * max(1.0, float(l2.grad.abs().max()))
 
 
+@pytest.mark.parametrize('W4,W,one_kernel', [(8, 64, False), (16, 128, False), (64, 512, False), (100, 512, False), (32, 64, True), (16, 64, True)])
+def test_head_backward_with_an_upsampling_ratio_other_than_four(W4, W, one_kernel):
+  """the one-kernel backward sums at most 12 pixels per low-resolution node along w -- enough for the model's x4 up-sampling
+  (8-9), not for x8 (W = 512 over W4 = 64: ~18).  Such shapes must take the two-kernel form (mode_head_loss_supported says 0) and
+  give the right gradient through the public entry; x2 (32 -> 64) stays on the one-kernel form."""
+  import plain_ops
+  B, D4, H4 = 1, 4, 4
+  D, H = 16, 16
+  logits = (_rand((B, 1, D4, H4, W4), 90) * 2).to(DEV).requires_grad_(True)
+  assert HF.head_loss_supported(logits, (D, H, W)) == one_kernel
+  go = _rand((B, 1, H, W), 91).to(DEV)
+  HF.head(logits, (D, H, W)).backward(go)
+  l2 = logits.detach().clone().requires_grad_(True)
+  plain_ops.head(l2, (D, H, W)).backward(go)
+  assert float((logits.grad - l2.grad).abs().max()) <= 2e-5 * max(1.0, float(l2.grad.abs().max()))
+
+
 def test_native_seam_signature():
   """The reference's 17/20-argument pybind entry points (sphere_conv_cuda.cpp:339-345) work as documented."""
   from models.basic.spherical_conv import sphere_conv_cuda as ext

@@ -270,6 +270,30 @@ def test_gradient_carriers_give_autograds_sums_bit_for_bit(monkeypatch):
     assert torch.equal(grads[False][k], grads[True][k]), k
 
 
+def test_partial_backward_is_refused_not_silently_wrong(monkeypatch):
+  """a backward pass in which only ONE of the two consumers of a carried tensor runs (backward(inputs=[subset])) used to park
+  that consumer's gradient for good and hand a stale one to a later pass.  Now the pass raises at its end (the parked tensor is
+  released), and a full backward on the retained graph afterwards gives exactly the gradients of the carrier-less route."""
+  from mode_hip import functional as HF
+  net, left, right, gt = _tiny_net(12)
+  grads = {}
+  for on in (False, True):
+    monkeypatch.setattr(HF, 'GRAD_CARRIERS', on)
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(0)
+    loss = _loss(net, left, right, gt)
+    if on:
+      # gradients of the classifier heads' parameters only: the hourglass consumers of out1 / out2 / cost0 are cut off
+      subset = [p for k, p in net.named_parameters() if k.startswith('classif')]
+      with pytest.raises(RuntimeError, match='GradCarrier'):
+        loss.backward(inputs=subset, retain_graph=True)
+      net.zero_grad(set_to_none=True)
+    loss.backward()
+    grads[on] = {k: p.grad.clone() for k, p in net.named_parameters()}
+  for k in grads[False]:
+    assert torch.equal(grads[False][k], grads[True][k]), k
+
+
 def test_graph_replay_matches_eager():
   """mode_hip.graph_step.GraphedStep: forward + loss + backward captured into one hipGraph and replayed; same loss and
   gradients as the eager step on the same weights, and new inputs are picked up through the static tensors."""
@@ -644,6 +668,45 @@ def test_captured_eval_forward_refuses_to_replay_on_changed_weights(golden):
     gs.replay()
   gs2 = GraphedStep(fwd, (left, right), warmup=1)
   assert torch.equal(gs2.replay(), fwd())
+
+
+def test_replayed_training_moves_the_versions_of_the_batchnorm_state(golden):
+  """a REPLAYED training step updates running_mean / running_var through raw pointers with no Python in between; replay()
+  moves their version counters like the eager step does, so a BatchNorm recalibration run as graph replays (weights frozen) is seen by
+  the packed-weight cache of the eval forward and by a captured inference graph."""
+  from mode_hip.graph_step import GraphedStep
+  z = golden('model_tiny.npz')
+  net, left, right, _, _ = _setup(z, bn_from_fixture=True)
+  net.eval()
+
+  def fwd():
+    with torch.no_grad():
+      return net(left, right)
+
+  before = fwd().clone()
+  ev = GraphedStep(fwd, (left, right), warmup=1)
+  assert torch.equal(ev.replay(), before) and not ev.stale()
+  net.train()
+  for p in net.parameters():
+    p.requires_grad_(False)  # recalibration: only the running statistics move
+
+  def recal():
+    with torch.no_grad():
+      return net(left, right)[2]
+
+  tr = GraphedStep(recal, (left, right), warmup=1)
+  bn = net.dres2.conv1[0][1]
+  assert any(t is bn.running_mean for t in tr.written) and any(t is bn.running_var for t in tr.written)
+  v0, rm0 = bn.running_mean._version, bn.running_mean.clone()
+  tr.replay()
+  assert bn.running_mean._version > v0 and not torch.equal(bn.running_mean, rm0)
+  net.eval()
+  assert ev.stale()
+  with pytest.raises(RuntimeError, match='changed after this graph was captured'):
+    ev.replay()
+  after = fwd()  # the eager eval forward repacks with the recalibrated statistics
+  assert not torch.equal(after, before)
+  assert torch.equal(GraphedStep(fwd, (left, right), warmup=1).replay(), after)
 
 
 def test_eval_forward_keeps_packed_weights_and_notices_changes(golden, monkeypatch):

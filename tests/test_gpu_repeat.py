@@ -28,8 +28,7 @@ import op_trace
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_ONLY = ('_bytes', '_supported', '_build', '_plan_', '_max_', 'abi_version', 'last_error', 'debug_poison', 'adjplan', '_partials',
-             '_next_')  # (mode_bn_next_*_absmax set a thread-local pointer: no stream, no launch)
+HOST_ONLY = ('_bytes', '_supported', '_build', '_plan_', '_max_', 'abi_version', 'last_error', 'debug_poison', 'adjplan', '_partials')
 
 
 class PoisoningLib(object):

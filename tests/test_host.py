@@ -306,6 +306,52 @@ def test_erp_tables_are_planned_through_their_transpose():
     assert HF.sphere_native_t(cas, 3, 3) is None and HF.sphere_uses_transposed_copies(cas, 3, 3) and not HF.sphere_uses_transposed_copies(erp, 3, 3)
 
 
+def test_grad_carrier_checks_that_both_consumers_ran():
+  """functional.GradCarrier on a toy pair of autograd functions (CPU): a full backward adds the first consumer's gradient inside the
+  second; a backward that reaches only one consumer raises at its end and leaves nothing parked; a gradient left over from an aborted
+  pass is recognised by its owner and dropped."""
+  from mode_hip import functional as HF
+
+  class Twice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+      ctx.c = c
+      return x * 2
+
+    @staticmethod
+    def backward(ctx, g):
+      prev = ctx.c.take(ctx)
+      gx = g * 2
+      if prev is not None:
+        return gx + prev, None
+      if ctx.c.leave(gx, ctx):
+        return None, None
+      return gx, None
+
+  x = torch.ones(3, requires_grad=True)
+  c = HF.GradCarrier()
+  c.arm(True)
+  c.arm(True)
+  h = x * 1.0
+  y1, y2 = Twice.apply(h, c), Twice.apply(h, c)
+  (y1.sum() + y2.sum()).backward(retain_graph=True)
+  assert torch.equal(x.grad, torch.full((3,), 4.0)) and c.grad is None
+  x.grad = None
+  with pytest.raises(RuntimeError, match='GradCarrier'):
+    y1.sum().backward(retain_graph=True)
+  assert c.grad is None
+  x.grad = None
+  (y1.sum() + y2.sum()).backward(retain_graph=True)
+  assert torch.equal(x.grad, torch.full((3,), 4.0))
+  # a leftover whose owner asks first again (the pass that parked it died before its callbacks ran): dropped, not added
+  owner = object()
+  c.grad, c.owner = torch.full((3,), 100.0), owner
+  assert c.take(owner) is None and c.grad is None
+  c.grad, c.owner = torch.full((3,), 100.0), owner
+  assert c.take(object()) is not None  # the partner would take it
+  assert c.leave(torch.ones(3), owner) is False and c.grad is None  # outside a backward pass nothing is parked
+
+
 def test_build_notices_changed_compile_flags(tmp_path, monkeypatch):
   """objects compiled with other flags (a MODE_HIP_DEFINES debug build, a per-file flag) must not be taken for up to
   date, and a compile that fails after the flags changed must not leave a stamp that says they match: the flags hash is stored per
