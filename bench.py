@@ -48,7 +48,8 @@ def _on_f16_path(label):
   if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
     return True
   return bool(CONV2D_F16 and re.match(r'conv2d_(fwd|bwd_data|bwd_weight)\[', label))  # (where they are on the split path at all: label_peak asks that first)
-KERNEL_BOUND = {'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
+KERNEL_BOUND = {'maxpool2x2_fwd': 'hbm', 'maxpool2x2_bwd': 'hbm', 'depth_to_space2': 'hbm', 'space_to_depth2': 'hbm', 'conv1x1_sigmoid_fwd': 'hbm',
+                'conv1x1_sigmoid_bwd': 'hbm', 'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
                 'classif_fwd': 'hbm', 'classif_bwd': 'hbm'}
 
@@ -58,11 +59,12 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=5)
   ap.add_argument('--warmup', type=int, default=2)
-  ap.add_argument('--batch', type=int, default=2, help='pairs per GPU')
+  ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default 2; --mode fusion: frames per call, default 1)')
   ap.add_argument('--height', type=int, default=1024)
   ap.add_argument('--width', type=int, default=512)
   ap.add_argument('--maxdisp', type=int, default=192)
-  ap.add_argument('--mode', default='train', choices=['train', 'eval'])
+  ap.add_argument('--mode', default='train', choices=['train', 'eval', 'fusion'],
+                  help="'fusion': ModeFusion inference forward at --height x --width (the second half of BASELINE configs[4]; models/mode_fusion.py)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) run the CPU oracle timing and print its JSON')
   ap.add_argument('--cpu-baseline-timeout', type=int, default=420)
@@ -99,7 +101,10 @@ def parse():
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
                   '(RCCL refuses two ranks on the same device)')
-  return ap.parse_args()
+  args = ap.parse_args()
+  if args.batch is None:
+    args.batch = 1 if args.mode == 'fusion' else 2
+  return args
 
 
 def launch_ranks(args):
@@ -238,6 +243,10 @@ def kernel_of(label, conv_arith, on_split=None):
           'bn_eval_fwd': 'bn_eval_kernel',
           'cost_volume_fwd': 'cost_volume_fwd_v4', 'cost_volume_bwd': 'cost_volume_bwd_v4',
           'cost_conv_assemble_fwd': 'cost_conv_assemble_fwd_kernel', 'cost_conv_assemble_bwd': 'cost_conv_assemble_bwd_kernel',
+          'maxpool2x2_fwd': 'maxpool2_fwd_kernel', 'maxpool2x2_bwd': 'maxpool2_bwd_kernel', 'depth_to_space2': 'shuffle2_kernel',
+          'space_to_depth2': 'unshuffle2_kernel', 'conv1x1_sigmoid_fwd': 'head1_fwd_kernel',
+          'conv1x1_sigmoid_bwd': 'head1_bwd_kernel+head1_reduce_kernel', 'deconv2x2_gemm': 'conv1x1_kernel', 'deconv2x2_bwd_data': 'conv1x1_kernel',
+          'deconv2x2_bwd_weight': 'conv1x1_bww_kernel',
           'conv_stem_fwd': 'stem_fwd_kernel', 'conv_stem_bwd_weight': 'stem_bww_kernel', 'conv1x1_fwd': 'conv1x1_kernel',
           'conv1x1_bwd_data': 'conv1x1_kernel', 'conv1x1_bwd_weight': 'conv1x1_bww_kernel'}.get(name, name)
 
@@ -392,11 +401,53 @@ def cpu_baseline(args):
               'oracle/mode_ref.py on torch CPU' % (t_small, flop_ratio))
 
 
-def cpu_baseline_subprocess(args):
+def cpu_baseline_eval(args):
+  """The inference leg's baseline (BASELINE configs[1]): ONE eval forward of the CPU oracle at the bench size, no autograd."""
+  import recipe
+  from oracle import mode_ref
+  cores = usable_cores()
+  torch.set_num_threads(cores)
+  P = recipe.recipe_state(recipe.load_manifest(), 1)
+  pos = mode_ref.sphere_position(args.height // 4, args.width // 4, 'Cassini')
+  with torch.no_grad():
+    l0, r0 = recipe.recipe_images(1, 64, 32, 2)
+    mode_ref.mode_disparity(P, l0, r0, 16, mode_ref.sphere_position(16, 8, 'Cassini'), False)  # warm-up
+    left, right = recipe.recipe_images(1, args.height, args.width, 2)
+    t0 = time.time()
+    mode_ref.mode_disparity(P, left, right, args.maxdisp, pos, False)
+    t = time.time() - t0
+  return dict(value=1.0 / t, unit='pairs/s', cores=cores, kind='port',
+              sample='1 pair eval forward at Cassini %dx%d, D=%d, oracle/mode_ref.py on torch CPU, %.1f s' % (args.height, args.width, args.maxdisp, t))
+
+
+def cpu_baseline_fusion(args):
+  """The fusion leg's baseline: ONE inference forward of oracle/fusion_ref.py (plain torch CPU ops) at the bench size."""
+  from oracle import fusion_ref
+  import models
+  cores = usable_cores()
+  torch.set_num_threads(cores)
+  torch.manual_seed(0)
+  net = models.ModeFusion(1000, [32, 64, 128, 256], {'depth': 12, 'rgb': 12})
+  P = {k: v.detach() for k, v in net.state_dict().items()}
+  g = torch.Generator().manual_seed(1)
+  H, W = args.height, args.width
+  mk = lambda n, c, s: [torch.rand(1, c, H, W, generator=g) * s for _ in range(n)]  # noqa: E731
+  with torch.no_grad():
+    fusion_ref.mode_fusion(P, [t[:, :, :64, :32] for t in mk(6, 1, 50.0)], [t[:, :, :64, :32] for t in mk(6, 1, 1.0)],
+                           [t[:, :, :64, :32] for t in mk(4, 3, 1.0)], 1000.0, False)  # warm-up
+    d, c, r = mk(6, 1, 50.0), mk(6, 1, 1.0), mk(4, 3, 1.0)
+    t0 = time.time()
+    fusion_ref.mode_fusion(P, d, c, r, 1000.0, False)
+    t = time.time() - t0
+  return dict(value=1.0 / t, unit='frames/s', cores=cores, kind='port',
+              sample='1 inference forward of ModeFusion(1000,[32,64,128,256]) at %dx%d, oracle/fusion_ref.py on torch CPU, %.1f s' % (H, W, t))
+
+
+def cpu_baseline_subprocess(args, which='train'):
   """Run the CPU timing in a child process (never touches the GPU) so that a slow host cannot stall the bench line."""
   import subprocess
   cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--height', str(args.height), '--width', str(args.width),
-         '--maxdisp', str(args.maxdisp)]
+         '--maxdisp', str(args.maxdisp), '--mode', which]
   try:
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
     for line in reversed(r.stdout.strip().splitlines()):
@@ -518,11 +569,101 @@ def rccl_self_test(reducer, backend):
   return out
 
 
+def fusion_main(args):
+  """`--mode fusion`: inference forward of the fusion network as train_fusion.py:64 builds it -- ModeFusion(1000, [32, 64, 128, 256],
+  {'depth': 12, 'rgb': 12}) on 6 depth + 6 confidence maps and 4 RGB views of --height x --width (the second half of BASELINE
+  configs[4]) -- on ONE GPU, BatchNorm folded into the convolution kernels, hipGraph replay.  Same line format as the headline bench:
+  frames/s, the dominant kernel's roofline entry, the CPU oracle's time beside it."""
+  assert args.gpus == 1, 'the fusion leg is a one-GPU inference benchmark'
+  assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
+  dev = torch.device('cuda', 0)
+  torch.cuda.set_device(0)
+  import models
+  import mode_hip
+  mode_hip.lib()
+  from mode_hip import functional as HF, no_vendor, profiling
+  from mode_hip.graph_step import GraphedStep
+  HF.set_conv_arith(args.conv_arith)
+  B, H, W = args.batch, args.height, args.width  # (default: one frame per call, configs[4]'s share of a GPU)
+  torch.manual_seed(0)
+  net = models.ModeFusion(1000, [32, 64, 128, 256], {'depth': 12, 'rgb': 12}).to(dev)
+  g = torch.Generator().manual_seed(1)
+  depthes = [(torch.rand(B, 1, H, W, generator=g) * 50).to(dev) for _ in range(6)]
+  confs = [torch.rand(B, 1, H, W, generator=g).to(dev) for _ in range(6)]
+  rgbs = [torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(4)]
+  net.train()
+  with torch.no_grad():  # calibrate the running statistics (fresh ones would let the activations grow layer by layer)
+    for _ in range(2):
+      net(depthes, confs, rgbs)
+  net.eval()
+
+  def fwd():
+    with torch.no_grad():
+      return net(depthes, confs, rgbs)
+
+  with no_vendor.no_vendor_arithmetic() as guard:
+    out0 = fwd()
+  assert bool(torch.isfinite(out0).all())
+  for _ in range(args.warmup):
+    fwd()
+  torch.cuda.synchronize()
+  launch, run = 'hipGraph replay', None
+  try:
+    graphed = GraphedStep(fwd, tuple(depthes + confs + rgbs), warmup=1)
+    run = graphed.replay
+  except Exception as e:
+    sys.stderr.write('bench.py: fusion capture failed (%s); eager\n' % e)
+    launch, run = 'eager', fwd
+  run()
+  torch.cuda.synchronize()
+  t0 = time.time()
+  for _ in range(args.steps):
+    run()
+  torch.cuda.synchronize()
+  elapsed = time.time() - t0
+  kern = None
+  if not args.no_kernel_timing:
+    profiling.enable(True)
+    for _ in range(args.profile_steps):
+      fwd()
+    torch.cuda.synchronize()
+    kern = profiling.summary()
+    profiling.enable(False)
+  out = {
+      'metric': 'ModeFusion inference forward frames/sec (%dx%d, 6 depth+confidence views, 4 RGB)' % (W, H),
+      'value': B * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'fp32 storage/accumulate; products: 3xbf16 split (24-bit, 6 MFMAs) in the 3x3 layers with 16k input channels, fp32 MFMA in the '
+               '12-channel input layers and the 2x2 transposed convolutions' if args.conv_arith == 'bf16x6' else 'fp32 storage/accumulate; fp32 MFMA',
+      'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2),
+      'config': {'workload': 'ModeFusion(1000,[32,64,128,256],depth 12,rgb 12) eval forward, %d frame(s)/call, %dx%d (BASELINE configs[4], '
+                             'fusion half; train_fusion.py:64)' % (B, H, W),
+                 'global_batch': B, 'conv_arith': args.conv_arith, 'launch': launch, 'init': 'torch.manual_seed(0) constructor init, BatchNorm '
+                 'running statistics from two training-mode forwards',
+                 'vendor_guard': 'first forward ran under mode_hip.no_vendor (%d aten ops seen, none of them vendor arithmetic)' % guard.seen},
+  }
+  if kern:
+    out['roofline'] = roofline_block(kern, args.conv_arith, B, args.profile_steps, '%d eager forwards after the timed region' % args.profile_steps)
+    out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1), 'TFLOPs': round(v['TFLOPs'], 2)}
+                      for k, v in kern.items()}
+    conv = [v for k, v in kern.items() if k.startswith('conv2d_')]
+    if conv:
+      out['roofline']['conv3x3_mfma_frac'] = round(blended_mfma_fraction(kern, args.conv_arith, prefixes=('conv2d_',)), 4)
+      out['roofline']['conv3x3_ms_per_forward'] = round(sum(v['total_ms'] for v in conv) / max(args.profile_steps, 1), 3)
+  else:
+    out['roofline'] = None
+  if not args.no_cpu_baseline:
+    out['cpu_baseline'] = cpu_baseline_subprocess(args, 'fusion')
+  print(json.dumps(out))
+
+
 def main():
   args = parse()
   if args.cpu_baseline_only:
-    print(json.dumps(cpu_baseline(args)))
+    print(json.dumps({'train': cpu_baseline, 'eval': cpu_baseline_eval, 'fusion': cpu_baseline_fusion}[args.mode](args)))
     return
+  if args.mode == 'fusion':
+    return fusion_main(args)
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(launch_ranks(args))  # before anything touches the GPU in this process
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -780,6 +921,8 @@ def main():
     else:
       out['roofline'] = None
     if eval_b1 is not None:
+      if not args.no_cpu_baseline:  # (the inference leg's own baseline, one eval forward of the CPU oracle)
+        eval_b1['cpu_baseline'] = cpu_baseline_subprocess(args, 'eval')
       out['eval_b1'] = eval_b1
     if args.value_1gpu:
       out['scaling_vs_1gpu'] = {'value_1gpu': args.value_1gpu, 'efficiency': out['value'] / (world * args.value_1gpu)}

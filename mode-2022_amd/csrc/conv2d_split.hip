@@ -148,6 +148,10 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   using G2 = Geo2<TH, DIL>;
   constexpr int R = G2::R, IW = G2::IW, ITEMS = G2::ITEMS, KIT = G2::KIT, PIECE = G2::PIECE, BUF = G2::BUF;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];  // [2][3 pieces][2 octets][PIECE]
+  // grid.y = the 32 * MT-channel output blocks of the layer, every y-slice the persistent grid on ITS block (as in conv3d_split.hip): a
+  // 256-channel layer at 128 x 64 has 32 tiles per block -- one launch per block left seven CUs in eight idle
+  d.o0 += 32 * MT * (int)blockIdx.y;
+  wp += (long long)blockIdx.y * MT * d.NCHUNK * 9 * 192;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
 
   const int nwx = gridDim.x / kNumXCD;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
 
 template <int MT, int TH, int DIL>
 int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st, const char* who, Epi epi, const float* amax_x,
-            const float* amax_w) {
+            const float* amax_w, int nblocks) {
   constexpr size_t LDS = Geo2<TH, DIL>::LDS_BYTES;
   d.nHt = mode::cdiv(d.H, TH);
   d.ntiles = d.B * d.nHt * d.nWt;
@@ -459,7 +463,7 @@ int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st,
   {                                                                                                                                  \
     int rc = mode::allow_lds(conv2d_split_kernel<MT, TH, DIL, EPIV, F16V>, LDS, who);                                                \
     if (rc != MODE_OK) return rc;                                                                                                    \
-    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, EPIV, F16V>), dim3(grid), dim3(NT), LDS, st, x, wp, y, d, epi, amax_x, amax_w); \
+    hipLaunchKernelGGL((conv2d_split_kernel<MT, TH, DIL, EPIV, F16V>), dim3(grid, nblocks), dim3(NT), LDS, st, x, wp, y, d, epi, amax_x, amax_w); \
   }
   if (epi.shift && epi.add) {
     if (amax_x) MODE_C2D_LAUNCH(2, true) else MODE_C2D_LAUNCH(2, false)
@@ -474,11 +478,12 @@ int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st,
 
 template <int MT>
 int launch_tile(const float* x, const uint4* wp, float* y, const S2Dims& d, int dilation, hipStream_t st, const char* who, Epi epi,
-                const float* ax, const float* aw) {
+                const float* ax, const float* aw, int nblocks) {
   // 16-row tiles unless that leaves fewer than two tiles per CU (a workgroup's first chunk is staged un-overlapped)
-  const bool big = (long long)d.B * mode::cdiv(d.H, 16) * d.nWt >= 2 * kNumCU;
-  if (dilation == 1) return big ? launch2<MT, 16, 1>(x, wp, y, d, st, who, epi, ax, aw) : launch2<MT, 8, 1>(x, wp, y, d, st, who, epi, ax, aw);
-  return big ? launch2<MT, 16, 2>(x, wp, y, d, st, who, epi, ax, aw) : launch2<MT, 8, 2>(x, wp, y, d, st, who, epi, ax, aw);
+  const bool big = (long long)d.B * mode::cdiv(d.H, 16) * d.nWt * nblocks >= 2 * kNumCU;
+  if (dilation == 1)
+    return big ? launch2<MT, 16, 1>(x, wp, y, d, st, who, epi, ax, aw, nblocks) : launch2<MT, 8, 1>(x, wp, y, d, st, who, epi, ax, aw, nblocks);
+  return big ? launch2<MT, 16, 2>(x, wp, y, d, st, who, epi, ax, aw, nblocks) : launch2<MT, 8, 2>(x, wp, y, d, st, who, epi, ax, aw, nblocks);
 }
 
 }  // namespace
@@ -529,14 +534,16 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
     epi.add = acc_in;
     epi.relu = 0;
   }
-  // two output-channel tiles per launch (64 channels); 128-channel layers run as two launches
-  for (int m = 0; m < MT; m += 2) {
-    d.o0 = 32 * m;
-    const uint4* wpm = wp + (long long)m * d.NCHUNK * 9 * 192;
-    int rc;
-    rc = m + 1 < MT ? launch_tile<2>(x, wpm, y, d, dilation, st, who, epi, amax_x, amax_w)
-                    : launch_tile<1>(x, wpm, y, d, dilation, st, who, epi, amax_x, amax_w);
+  // two output-channel tiles per workgroup (64 channels); the layer's 64-channel blocks are the y-slices of ONE launch (round 6; a
+  // launch per block before), an odd 32-channel block at the end a launch of its own
+  d.o0 = 0;
+  if (MT >= 2) {
+    int rc = launch_tile<2>(x, wp, y, d, dilation, st, who, epi, amax_x, amax_w, MT / 2);
     if (rc != MODE_OK) return rc;
+  }
+  if (MT % 2) {
+    d.o0 = 32 * (MT - 1);
+    return launch_tile<1>(x, wp + (long long)(MT - 1) * d.NCHUNK * 9 * 192, y, d, dilation, st, who, epi, amax_x, amax_w, 1);
   }
   return MODE_OK;
 }
