@@ -146,52 +146,49 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
     g_o[k] = item / (16 * WTH);
   }
 
-  const float* xb = x;
-  const float* gb = gy;
   float xr[XIT][2], gr[GIT][2];
-  // Per unit and item: the two element offsets inside plane 0 of the sample (clamped into the volume) and the validity of row /
-  // channel / column as bits; per depth only the plane offset (a scalar) is added -- the address and mask arithmetic of 13 items
-  // would otherwise take as many issue slots per depth as the staging itself.
-  unsigned xo0[XIT], xo1[XIT], go0[GIT], go1[GIT];  // BYTE offsets (a sample is < 2^29 elements): uniform base + 32-bit lane offset
+  // Per unit and item: the two BYTE offsets inside plane 0 of the (sample, 32-channel block) the unit reads (a sample is < 2^29
+  // elements) -- or kBufOOB for an element outside the volume / beyond the layer's channels; per depth only the plane offset (a scalar)
+  // is added.  The requests are buffer loads (round 6): the block's 32 channel planes are one descriptor, an offset at or beyond its
+  // size reads as ZERO, and a depth outside the volume takes the empty descriptor -- so the zero padding costs nothing per value (the
+  // validity masks were 108 of a depth's 518 vector / scalar instructions beside 84 MFMAs: and + compare + select per loaded value).
+  unsigned xo0[XIT], xo1[XIT], go0[GIT], go1[GIT];
   int xdst[XIT], gdst[GIT];
-  unsigned xm0 = 0, xm1 = 0, gm0 = 0, gm1 = 0;
 #pragma unroll
   for (int k = 0; k < XIT; ++k) xdst[k] = x_c[k] * XCS + x_row[k] * XROWP + 2 * x_wp[k];
 #pragma unroll
   for (int k = 0; k < GIT; ++k) gdst[k] = g_o[k] * GCS + g_row[k] * 32 + 2 * g_wp[k];  // (+ piece * GPIECE)
   auto unit_begin = [&](int h0, int w0) {
-    xm0 = xm1 = gm0 = gm1 = 0;
 #pragma unroll
     for (int k = 0; k < XIT; ++k) {
       const int gh = h0 - 1 + x_row[k], gw = w0 - 1 + 2 * x_wp[k];
       const unsigned rowok = (unsigned)((unsigned)gh < (unsigned)d.H) & (unsigned)(cb * 32 + x_c[k] < d.Ci);
-      const int base = rowok ? x_c[k] * DHWi + gh * d.W : 0;
-      xo0[k] = 4u * (unsigned)(base + min(max(gw, 0), d.W - 1));
-      xo1[k] = 4u * (unsigned)(base + min(max(gw + 1, 0), d.W - 1));
-      xm0 |= (rowok & (unsigned)((unsigned)gw < (unsigned)d.W)) << k;
-      xm1 |= (rowok & (unsigned)((unsigned)(gw + 1) < (unsigned)d.W)) << k;
+      const unsigned base = 4u * (unsigned)(x_c[k] * DHWi + gh * d.W + gw);
+      xo0[k] = (rowok & (unsigned)((unsigned)gw < (unsigned)d.W)) ? base : kBufOOB;
+      xo1[k] = (rowok & (unsigned)((unsigned)(gw + 1) < (unsigned)d.W)) ? base + 4u : kBufOOB;
     }
 #pragma unroll
     for (int k = 0; k < GIT; ++k) {
       const int gh = h0 + g_row[k], gw = w0 + 2 * g_wp[k];
       const unsigned rowok = (unsigned)(gh < d.H) & (unsigned)(ob * 32 + g_o[k] < d.Co);
-      const int base = rowok ? g_o[k] * DHWi + gh * d.W : 0;
-      go0[k] = 4u * (unsigned)(base + min(gw, d.W - 1));
-      go1[k] = 4u * (unsigned)(base + min(gw + 1, d.W - 1));
-      gm0 |= (rowok & (unsigned)(gw < d.W)) << k;
-      gm1 |= (rowok & (unsigned)(gw + 1 < d.W)) << k;
+      const unsigned base = 4u * (unsigned)(g_o[k] * DHWi + gh * d.W + gw);
+      go0[k] = (rowok & (unsigned)(gw < d.W)) ? base : kBufOOB;
+      go1[k] = (rowok & (unsigned)(gw + 1 < d.W)) ? base + 4u : kBufOOB;
     }
   };
-  // loads of x plane z and of the gy rows of depth z: unconditional, from clamped addresses; the masks are applied at the split
+  const unsigned block_bytes = 128u * (unsigned)DHWi;  // 32 channels of a sample (the host guarantees < 2^31)
+  // loads of x plane z and of the gy rows of depth z: unconditional; a plane outside the volume reads through an EMPTY descriptor
+  const float* xb = x;
+  const float* gb = gy;
   auto load_x = [&](int k, int z) {
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(xb, (unsigned)z < (unsigned)d.D ? block_bytes : 0u);
     const unsigned zo = 4u * (unsigned)(min(max(z, 0), d.D - 1) * HWi);
-    xr[k][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + (xo0[k] + zo));
-    xr[k][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + (xo1[k] + zo));
+    xr[k][0] = buf_load_f32(rs, xo0[k], zo);
+    xr[k][1] = buf_load_f32(rs, xo1[k], zo);
   };
   auto commit_x = [&](int k, int z) {
-    const unsigned zok = (unsigned)((unsigned)z < (unsigned)d.D);
     uint32_t p1, p2, p3;
-    float v0 = (zok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, v1 = (zok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f;
+    float v0 = xr[k][0], v1 = xr[k][1];
     if (F16) {
       v0 *= sx;
       v1 *= sx;
@@ -203,14 +200,14 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
     if (!F16) dst[XPIECE] = p3;
   };
   auto load_g = [&](int k, int z) {
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(gb, z < d.D ? block_bytes : 0u);
     const unsigned zo = 4u * (unsigned)(min(z, d.D - 1) * HWi);
-    gr[k][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gb) + (go0[k] + zo));
-    gr[k][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gb) + (go1[k] + zo));
+    gr[k][0] = buf_load_f32(rs, go0[k], zo);
+    gr[k][1] = buf_load_f32(rs, go1[k], zo);
   };
   auto commit_g = [&](int k, int z) {
-    const unsigned zok = (unsigned)(z < d.D);
     uint32_t p1, p2, p3;
-    float v0 = (zok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, v1 = (zok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f;
+    float v0 = gr[k][0], v1 = gr[k][1];
     if (F16) {
       v0 *= sg;
       v1 *= sg;
@@ -331,9 +328,19 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 #define MODE_SPLIT_TERM(ACC, PA, PB) \
   _Pragma("unroll") for (int t7 = 0; t7 < 7; ++t7) ACC[t7] = mfma_split<F16>(a[PA], bq[t7][PB], ACC[t7]);
         if constexpr (F16) {
-          MODE_SPLIT_TERM(acs, 1, 0)
-          MODE_SPLIT_TERM(acs, 0, 1)
-          MODE_SPLIT_TERM(acc, 0, 0)
+          // tap-PAIR major (round 6): the six MFMAs of taps (a, b) need only those two taps' shifted fragments, so the 40 v_perm of a
+          // K-step are consumed at a steady 16 per six MFMAs -- term major, all 40 had to precede the K-step's first fourteen MFMAs and
+          // filled its first gaps.  Every accumulator still receives its terms in the same order (acs: lo x hi, then hi x lo): same bits.
+#pragma unroll
+          for (int ta = 0; ta < 7; ta += 2) {
+            const int tb = ta + 1;
+            acs[ta] = mfma_split<F16>(a[1], bq[ta][0], acs[ta]);
+            if (tb < 7) acs[tb] = mfma_split<F16>(a[1], bq[tb][0], acs[tb]);
+            acc[ta] = mfma_split<F16>(a[0], bq[ta][0], acc[ta]);
+            if (tb < 7) acc[tb] = mfma_split<F16>(a[0], bq[tb][0], acc[tb]);
+            acs[ta] = mfma_split<F16>(a[0], bq[ta][1], acs[ta]);
+            if (tb < 7) acs[tb] = mfma_split<F16>(a[0], bq[tb][1], acs[tb]);
+          }
         } else {
           MODE_SPLIT_TERM(acs, 2, 0)
           MODE_SPLIT_TERM(acs, 0, 2)
@@ -346,9 +353,24 @@ __global__ __launch_bounds__(NT) void conv3d_bww_split_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < (F16 ? 21 : 42); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 9 : 5, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, F16 ? 2 : 1, 0);
+          if (F16) {
+            // a K-step's work dealt evenly over its 21 MFMA gaps -- the scheduler fills the groups greedily, so the allowance per gap
+            // has to be the AVERAGE, not a ceiling (9 + 2 + 2 per gap put 11 instructions into each of a K-step's first six gaps and
+            // none into the other fifteen): K-steps 0 / 1 carry 40 shifts, 14 fragment reads and 18 / 8 loads; K-steps 2 / 3 the 40
+            // shifts, the split of 7 / 6 staged items (6 instructions each), the fragment reads and ~8 LDS stores
+            if (ks < 2) {  // (the builtin takes literal constants: `ks` is a loop index the unroller resolves, not a constant expression)
+              __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+            }
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -39,6 +39,7 @@ def _deps_mtime():
 FILE_FLAGS = {
     'conv3d_split.hip': ['-fno-slp-vectorize'],
     'conv2d_split.hip': ['-fno-slp-vectorize'],
+    'conv3d_split_wgrad.hip': ['-fno-slp-vectorize'],
 }
 
 

@@ -70,7 +70,9 @@ def test_f16_arithmetic_is_an_fp32_convolution(case, ci, co, shape, f16_switch):
                 'input gradient + acc': HF.conv3d_bwd_data(gy, w, x.shape, 1, acc=acc), 'weight gradient': HF.conv3d_bwd_weight(gy, x, 1)}
   for k in want:
     scale = float(want[k].abs().max())
-    bound = 2.0**-22 * terms[k]**0.5 * 8 * scale
+    # (round 6: the constants are ~10 x the errors the round-5 run recorded -- profiles/r05zl_pytest_gpu_output.txt:81-112 -- instead of
+    # 60-1000 x: a stale maximum or a wrong scale that costs 30 x accuracy must fail here)
+    bound = 2.0**-22 * terms[k]**0.5 * (0.2 if k == 'weight gradient' else 1.0) * scale
     e16 = float((got[True][k].double().cpu() - want[k]).abs().max())
     eb = float((got[False][k].double().cpu() - want[k]).abs().max())
     print('%-22s %-24s f16x3 %.2e  bf16x6 %.2e  bound %.2e' % (case, k, e16, eb, bound))
@@ -204,7 +206,7 @@ def test_sphere_forward_on_two_fp16_pieces_against_float64(ih, iw, B, ci, co, gr
     three = HF.sphere_conv_fwd(x, pd, w, torch.empty((B, co, ih, iw), device=DEV), (1, 1), groups, f16=True)
   finally:
     HF.SPHERE_FWD_F16 = keep
-  bound = 2.0**-22 * np.sqrt(9 * ci // groups) * 8 * float(want.abs().max())
+  bound = 2.0**-22 * np.sqrt(9 * ci // groups) * float(want.abs().max())  # (~9 x the recorded errors; was 8 x this)
   e16 = float((got.cpu().double() - want).abs().max())
   e3 = float((three.cpu().double() - want).abs().max())
   print('sphere_conv_fwd %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (max |y| %.3g)' %
@@ -292,7 +294,7 @@ def test_sphere_input_gradient_on_two_fp16_pieces_against_float64(ih, iw, B, ci,
   assert torch.equal(big, got * 4096.0), 'a weight rescaled through .data'
   carried = HF.transpose_planes(HF.sphere_conv_bwd_data_t(gyt, pd, w, torch.empty((B, ci, W, H), device=DEV), groups, w_amax=real(w)))
   assert torch.equal(carried, got), 'the maximum handed over by the forward'
-  bound = 2.0**-22 * np.sqrt(9 * co // groups) * 8 * float(want.abs().max())
+  bound = 2.0**-22 * np.sqrt(9 * co // groups) * float(want.abs().max())  # (~7 x the recorded errors; was 8 x this)
   e16 = float((got.cpu().double() - want).abs().max())
   e3 = float((three.cpu().double() - want).abs().max())
   print('sphere_conv_bwd_data %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (max |gx| %.3g)' %
@@ -337,8 +339,8 @@ def test_sphere_weight_gradient_on_two_fp16_pieces_against_float64(case, f16_swi
   e16 = float((got.cpu().double() - want).abs().max())
   e3 = float((three.cpu().double() - want).abs().max())
   print('sphere_conv_bwd_weight %d->%d %dx%d B=%d g=%d [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e (|gw| <= %.3g)' %
-        (ci, co, ih, iw, B, groups, case, e16, e3, 1e-5 * scale, scale))
-  assert e16 <= 1e-5 * scale and e16 <= 2 * e3 + 1e-6 * scale
+        (ci, co, ih, iw, B, groups, case, e16, e3, 3e-6 * scale, scale))
+  assert e16 <= 3e-6 * scale and e16 <= 2 * e3 + 3e-7 * scale  # (recorded: 2.9e-7 x scale; the bound was 1e-5)
   assert torch.equal(got, again), 'not deterministic'
   assert float((twice.cpu().double() - 2 * want).abs().max()) <= 2e-5 * scale, 'adds to gw'
   assert not torch.equal(got, three), 'the fp16 kernel did not run'
@@ -388,12 +390,12 @@ def test_conv2d_on_two_fp16_pieces_against_float64(B, Ci, Co, H, W, dil, case, f
   F.conv2d(x.double(), wa, None, 1, dil, dil).backward(gy.double())
   scale = float(wa.grad.abs().max())
   ew, ew3 = float((gw.double() - wa.grad).abs().max()), float((gw3.double() - wa.grad).abs().max())
-  print('conv2d bwd_weight %s [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e' % ((B, Ci, Co, H, W, dil), case, ew, ew3, 2e-5 * scale))
-  assert ew <= 2e-5 * scale and ew <= 2 * ew3 + 2e-6 * scale
+  print('conv2d bwd_weight %s [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e' % ((B, Ci, Co, H, W, dil), case, ew, ew3, 4e-6 * scale))
+  assert ew <= 4e-6 * scale and ew <= 2 * ew3 + 2e-6 * scale  # (recorded: <= 5.5e-7 x scale; test_gpu_split.py holds the bf16 path to 2e-5)
   assert torch.equal(gw, gw_again) and not torch.equal(gw, gw3)
   assert float((gw_into - (gw + 1.0)).abs().max()) <= 1e-5 * max(1.0, scale), 'accumulating form'
   for which, (name, got, three, ref, terms) in enumerate((('fwd', y, y3, want, 9 * Ci), ('bwd_data', gx, gx3, want_gx, 9 * Co))):
-    bound = 2.0**-22 * np.sqrt(terms) * 8 * float(ref.abs().max())
+    bound = 2.0**-22 * np.sqrt(terms) * float(ref.abs().max())  # (~10 x the recorded errors; was 8 x this)
     e16, e3 = float((got.double() - ref).abs().max()), float((three.double() - ref).abs().max())
     print('conv2d %s %s [%s]: two fp16 pieces %.3e | three bf16 pieces %.3e | bound %.3e' % (name, (B, Ci, Co, H, W, dil), case, e16, e3, bound))
     assert e16 <= bound and e16 <= 2 * e3 + 0.1 * bound, (name, case)
@@ -403,3 +405,57 @@ def test_conv2d_on_two_fp16_pieces_against_float64(B, Ci, Co, H, W, dil, case, f
   assert torch.equal(y_inf, y3), 'an inference call must not change'
   assert torch.equal(gx_acc, gx + acc), 'the accumulate form adds in the store, bit for bit'
   assert torch.equal(y, again[0]) and torch.equal(gx, again[1]), 'not deterministic'
+
+
+def test_whole_model_with_an_activation_tensor_spanning_2_to_the_20(f16_switch, monkeypatch):
+  """the per-tensor scale of the fp16 arithmetic costs small elements precision once a tensor spans more than ~2^17.  A whole
+  model that provokes exactly that: channel 0 of the first 3-D activation is made 2^20 x the others (its BatchNorm's gamma and beta
+  times 2^20) and its only consumer undoes it (its weights for that channel times 2^-20) -- powers of two, so the network is the SAME
+  function, and an fp32 evaluation is bit-for-bit unchanged.  The fp16 layers see a tensor spanning > 2^17 (asserted): the 31 ordinary
+  channels keep ~19 of their 22 bits in that one layer.  Held: all three predictions within the 1e-3 px of the north_star of the float64
+  oracle on the rescaled state, and within 2e-4 px of the model's own predictions on the plain state; printed next to the three-piece
+  bf16 arithmetic's figures."""
+  import recipe
+  import models
+  from oracle import mode_ref
+  maxdisp, H, W, B = 16, 64, 32, 2
+  plain = recipe.recipe_state_wc(recipe.load_manifest(), 21)
+  k = 2.0**20
+  scaled = {n: v.clone() for n, v in plain.items()}
+  scaled['dres0.0.1.weight'][0] *= k
+  scaled['dres0.0.1.bias'][0] *= k
+  scaled['dres0.2.0.weight'][:, 0] /= k
+  left, right = recipe.recipe_images(B, H, W, 22)
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+  P64 = {n: (v.double() if v.is_floating_point() else v.clone()) for n, v in scaled.items()}
+  with torch.no_grad():
+    want = [p.numpy() for p in mode_ref.mode_disparity(P64, left.double(), right.double(), maxdisp, pos, True)]
+  spans = []
+  real = HF.conv3d_fwd
+
+  def spy(x, w, stride=1, amax=None):
+    if stride == 1 and x.shape[1] == 32:
+      per_channel = x.abs().amax((0, 2, 3, 4))
+      spans.append(float(per_channel.max() / per_channel.median().clamp_min(1e-30)))
+    return real(x, w, stride, amax=amax)
+
+  monkeypatch.setattr(HF, 'conv3d_fwd', spy)
+  got = {}
+  for name, state, f16 in (('plain', plain, True), ('scaled', scaled, True), ('scaled bf16', scaled, False)):
+    HF.CONV3D_S1_F16 = f16
+    net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
+    net.load_state_dict({n: v.clone() for n, v in state.items()})
+    net.train()
+    del spans[:]
+    with torch.no_grad():
+      got[name] = [p.cpu().numpy().astype(np.float64) for p in net(left.to(DEV), right.to(DEV))]
+    if name != 'plain':
+      assert max(spans) > 2.0**17, spans
+    else:
+      assert max(spans) < 2.0**8, spans
+  for i in range(3):
+    e16 = np.abs(got['scaled'][i] - want[i]).max()
+    e3 = np.abs(got['scaled bf16'][i] - want[i]).max()
+    same = np.abs(got['scaled'][i] - got['plain'][i]).max()
+    print('pred%d: |fp16 pieces - float64| %.2e px   |bf16 pieces - float64| %.2e px   |scaled - plain state| %.2e px' % (i + 1, e16, e3, same))
+    assert e16 <= 1e-3 and e3 <= 1e-3 and same <= 2e-4
