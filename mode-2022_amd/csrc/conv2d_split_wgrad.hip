@@ -122,46 +122,48 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
   const float* xb = x;
   const float* gb = gy;
   float xr[XIT][2], gr[GIT][2];
-  unsigned xo0[XIT], xo1[XIT], go0[GIT], go1[GIT];  // byte offsets of the pair inside row 0 of the image (clamped columns)
+  // Byte offsets of the pair inside row 0 of the (image, 32-channel block) -- or kBufOOB for a column outside the image / a channel
+  // beyond the layer's.  The requests are buffer loads (round 6, as in conv3d_split_wgrad.hip): an offset at or beyond the descriptor's
+  // size reads as ZERO and a row outside the image takes the empty descriptor, so the zero padding needs no validity masks -- and +
+  // compare + select per loaded value were 170 of a group's ~520 vector instructions beside 54 MFMAs.
+  // (markers: an invalid column / channel and an invalid row each contribute kHalfOOB = 2^30 -- above every valid offset, which the host
+  // keeps below 2^30 -- so that their sum cannot wrap back into the block: a 32-bit kBufOOB + kBufOOB would be 0)
+  constexpr unsigned kHalfOOB = 0x40000000u;
+  unsigned xo0[XIT], xo1[XIT], go0[GIT], go1[GIT];
   int xdst[XIT], gdst[GIT];
-  unsigned xm0 = 0, xm1 = 0, gm0 = 0, gm1 = 0;      // column / channel validity bits
 #pragma unroll
   for (int k = 0; k < XIT; ++k) xdst[k] = x_c[k] * XCS + 2 * x_wp[k];
 #pragma unroll
   for (int k = 0; k < GIT; ++k) gdst[k] = g_o[k] * GCS + g_row[k] * 32 + 2 * g_wp[k];
-  auto unit_begin = [&](int w0) {
-    xm0 = xm1 = gm0 = gm1 = 0;
+  auto unit_begin = [&](int w0) {  // (the item's own row inside the staged group of four is part of the offset)
 #pragma unroll
     for (int k = 0; k < XIT; ++k) {
       const int gw = w0 - DIL + 2 * x_wp[k];
       const unsigned cok = (unsigned)(cb * 32 + x_c[k] < d.Ci);
-      const int base = cok ? x_c[k] * HWi : 0;
-      xo0[k] = 4u * (unsigned)(base + min(max(gw, 0), d.W - 1));
-      xo1[k] = 4u * (unsigned)(base + min(max(gw + 1, 0), d.W - 1));
-      xm0 |= (cok & (unsigned)((unsigned)gw < (unsigned)d.W)) << k;
-      xm1 |= (cok & (unsigned)((unsigned)(gw + 1) < (unsigned)d.W)) << k;
+      const unsigned base = 4u * (unsigned)(x_c[k] * HWi + x_row[k] * d.W + gw);
+      xo0[k] = (cok & (unsigned)((unsigned)gw < (unsigned)d.W)) ? base : kHalfOOB;
+      xo1[k] = (cok & (unsigned)((unsigned)(gw + 1) < (unsigned)d.W)) ? base + 4u : kHalfOOB;
     }
 #pragma unroll
     for (int k = 0; k < GIT; ++k) {
       const int gw = w0 + 2 * g_wp[k];
       const unsigned ook = (unsigned)(ob * 32 + g_o[k] < d.Co);
-      const int base = ook ? g_o[k] * HWi : 0;
-      go0[k] = 4u * (unsigned)(base + min(gw, d.W - 1));
-      go1[k] = 4u * (unsigned)(base + min(gw + 1, d.W - 1));
-      gm0 |= (ook & (unsigned)(gw < d.W)) << k;
-      gm1 |= (ook & (unsigned)(gw + 1 < d.W)) << k;
+      const unsigned base = 4u * (unsigned)(g_o[k] * HWi + g_row[k] * d.W + gw);
+      go0[k] = (ook & (unsigned)(gw < d.W)) ? base : kHalfOOB;
+      go1[k] = (ook & (unsigned)(gw + 1 < d.W)) ? base + 4u : kHalfOOB;
     }
   };
+  const unsigned block_bytes = 128u * (unsigned)HWi;  // 32 channel planes of an image (the host guarantees < 2^30)
   // x rows [r0, r0 + 4) of the image into ring slots (slot0 + row) % RING; gy rows [r0, r0 + 4) into buffer `buf`
   auto load_x = [&](int k, int r0) {
-    const unsigned ro = 4u * (unsigned)(min(max(r0 + x_row[k], 0), d.H - 1) * d.W);
-    xr[k][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + (xo0[k] + ro));
-    xr[k][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + (xo1[k] + ro));
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(xb, block_bytes);
+    const unsigned ro = (unsigned)(r0 + x_row[k]) < (unsigned)d.H ? (unsigned)(4 * r0 * d.W) : kHalfOOB;  // (r0 may be negative: the sum is not)
+    xr[k][0] = buf_load_f32(rs, xo0[k] + ro, 0);
+    xr[k][1] = buf_load_f32(rs, xo1[k] + ro, 0);
   };
   auto commit_x = [&](int k, int r0, int slot0) {
-    const unsigned rok = (unsigned)((unsigned)(r0 + x_row[k]) < (unsigned)d.H);
     uint32_t p1, p2, p3;
-    const float v0 = (rok & (xm0 >> k) & 1u) ? xr[k][0] : 0.f, v1 = (rok & (xm1 >> k) & 1u) ? xr[k][1] : 0.f;
+    const float v0 = xr[k][0], v1 = xr[k][1];
     int sl = slot0 + x_row[k];
     sl = sl >= RING ? sl - RING : sl;
     uint32_t* dst = reinterpret_cast<uint32_t*>(xl + xdst[k] + sl * XROWP);
@@ -175,14 +177,14 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
     dst[XPIECE / 2] = p2;
   };
   auto load_g = [&](int k, int r0) {
-    const unsigned ro = 4u * (unsigned)(min(r0 + g_row[k], d.H - 1) * d.W);
-    gr[k][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gb) + (go0[k] + ro));
-    gr[k][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gb) + (go1[k] + ro));
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(gb, block_bytes);
+    const unsigned ro = r0 + g_row[k] < d.H ? (unsigned)(4 * r0 * d.W) : kHalfOOB;
+    gr[k][0] = buf_load_f32(rs, go0[k] + ro, 0);
+    gr[k][1] = buf_load_f32(rs, go1[k] + ro, 0);
   };
   auto commit_g = [&](int k, int r0, int buf) {
-    const unsigned rok = (unsigned)(r0 + g_row[k] < d.H);
     uint32_t p1, p2, p3;
-    const float v0 = (rok & (gm0 >> k) & 1u) ? gr[k][0] : 0.f, v1 = (rok & (gm1 >> k) & 1u) ? gr[k][1] : 0.f;
+    const float v0 = gr[k][0], v1 = gr[k][1];
     uint32_t* dst = reinterpret_cast<uint32_t*>(gl + buf * GBUF + gdst[k]);
     if constexpr (F16) {
       split2_f16(v0 * sg, v1 * sg, p1, p2);
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
           for (int k = 3 * i; k < 3 * i + 3; ++k) load_x(k, h0 - DIL + 8);
 #pragma unroll
           for (int k = (GIT * i) / 3; k < (GIT * (i + 1)) / 3; ++k) load_g(k, h0 + 4);
-          __builtin_amdgcn_sched_barrier(0);  // in front of this stage's MFMAs (the group pattern below has no slot for them and put them
-        } else {                              // behind its 18 MFMAs: a third less lead to the commit three stages later)
+          if (!F16) __builtin_amdgcn_sched_barrier(0);  // in front of this stage's MFMAs (the bf16 group pattern below has no slot for
+        } else {                                        // them and put them behind its 18 MFMAs; the fp16 pattern deals them over the gaps)
 #pragma unroll
           for (int k = 3 * (i - 3); k < 3 * (i - 3) + 3; ++k) commit_x(k, h0 - DIL + 8, sfront);
 #pragma unroll
@@ -307,13 +309,25 @@ __global__ __launch_bounds__(NT) void conv2d_bww_split_kernel(const float* __res
           MODE_SPLIT_TERM(0, 0)
 #undef MODE_SPLIT_TERM
         }
-        // (F16: half the MFMAs carry two thirds of the staging work of a stage)
+        // (F16: half the MFMAs carry two thirds of the staging work of a stage -- ~50 vector instructions, ~12 loads (stages 0-2) or ~11
+        // LDS stores (stages 3-5) and 5 fragment reads beside 9 MFMAs: the allowance per gap is the stage's AVERAGE, the scheduler fills
+        // greedily -- 12 + 2 + 3 per gap put a stage's work into its first three gaps)
 #pragma unroll
         for (int j = 0; j < (F16 ? 9 : 18); ++j) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 12 : 7, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, F16 ? 3 : 2, 0);
+          if (F16) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            if (i < 3) {
+              __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+            }
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -40,6 +40,7 @@ FILE_FLAGS = {
     'conv3d_split.hip': ['-fno-slp-vectorize'],
     'conv2d_split.hip': ['-fno-slp-vectorize'],
     'conv3d_split_wgrad.hip': ['-fno-slp-vectorize'],
+    'conv2d_split_wgrad.hip': ['-fno-slp-vectorize'],
 }
 
 
