@@ -424,6 +424,10 @@ int mode_deconv3d_fwd_split(const float* x, const float* w, float* y, float* wpa
  * mode_conv3d_bwd_data_split_f16: acc may be NULL.  mode_conv3d_bwd_weight_split_f16: other arguments and workspace as
  * mode_conv3d_bwd_weight_split. */
 int mode_abs_max(const float* x, long long n, float* out_device_buffer, mode_stream_t stream);
+/* The same for n tensors in ONE launch (one workgroup per tensor: meant for the tens of small WEIGHT tensors of a model, whose maxima a
+ * training step needs before its first convolution): device_ptrs / device_sizes = DEVICE arrays of n tensor addresses / element counts,
+ * out = n consecutive maximum buffers (n * MODE_BN_ABSMAX_FLOATS floats), all written. */
+int mode_abs_max_batch(const float* const* device_ptrs, const long long* device_sizes, int n, float* out, mode_stream_t stream);
 int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B, int Ci,
                               int D, int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,

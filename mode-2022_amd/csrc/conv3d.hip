@@ -637,6 +637,10 @@ extern "C" int mode_abs_max(const float* x, long long n, float* out, mode_stream
   return mode::abs_max(x, n, out, mode::as_stream(stream), "mode_abs_max");
 }
 
+extern "C" int mode_abs_max_batch(const float* const* device_ptrs, const long long* device_sizes, int n, float* out, mode_stream_t stream) {
+  return mode::abs_max_batch(device_ptrs, device_sizes, n, out, mode::as_stream(stream), "mode_abs_max_batch");
+}
+
 extern "C" int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_x, const float* amax_w, float* y, float* wpack, int B,
                                          int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
   const char* who = "mode_conv3d_fwd_split_f16";

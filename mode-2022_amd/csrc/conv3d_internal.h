@@ -37,6 +37,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
 
 // out[0] (device) = the largest magnitude in x[0..n): the scale source of the fp16 arithmetic (order-independent, graph-capturable)
 int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who);
+int abs_max_batch(const float* const* ptrs, const long long* sizes, int n, float* out, hipStream_t st, const char* who);
 
 // conv3d_split_s2.hip: the stride-2 forward (= input gradient of the transposed convolution) on the same arithmetic; rows = output
 // channels (33..64), K = reduction channels (multiple of 8); w is (rows, K, 27); wpack >= conv3d_s2_split_wpack_floats(K, rows).

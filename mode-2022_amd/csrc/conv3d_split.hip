@@ -630,9 +630,48 @@ __global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ 
   mode::absmax_block_commit(m, out, sh);
 }
 
+// One block per tensor: out[j] (MODE_BN_ABSMAX_FLOATS words) = the maximum buffer of tensor j -- word 0 the value, everything else zero
+// (the layout's reading is "the maximum over word 0 and the 128 slots").  For the WEIGHTS of a model: tens of small tensors whose
+// maxima a training step needs before its first convolution -- one launch instead of a fill + a pass per tensor.
+__global__ __launch_bounds__(1024) void abs_max_batch_kernel(const float* const* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                             unsigned* __restrict__ out) {
+  const int j = blockIdx.x;
+  const float* x = ptrs[j];
+  const long long n = sizes[j];
+  unsigned m = 0;
+  long long i = threadIdx.x;
+  for (; i + 3072 < n; i += 4096) {  // four requests in flight per lane (the largest weights are ~150 k floats: one block each)
+    const float a = x[i], b = x[i + 1024], c = x[i + 2048], e = x[i + 3072];
+    m = max(max(m, finite_mag(__builtin_bit_cast(unsigned, a))), finite_mag(__builtin_bit_cast(unsigned, b)));
+    m = max(max(m, finite_mag(__builtin_bit_cast(unsigned, c))), finite_mag(__builtin_bit_cast(unsigned, e)));
+  }
+  for (; i < n; i += 1024) m = max(m, finite_mag(__builtin_bit_cast(unsigned, x[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned sh[16];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  unsigned* o = out + (long long)j * MODE_BN_ABSMAX_FLOATS;
+  for (int k = threadIdx.x + 1; k < MODE_BN_ABSMAX_FLOATS; k += 1024) o[k] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = max(r, sh[k]);
+    o[0] = r;
+  }
+}
+
 }  // namespace
 
 namespace mode {
+
+int abs_max_batch(const float* const* ptrs, const long long* sizes, int n, float* out, hipStream_t st, const char* who) {
+  MODE_REQUIRE(n >= 0, MODE_ERR_BAD_ARG, "%s: negative count", who);
+  if (n == 0) return MODE_OK;
+  MODE_REQUIRE(ptrs && sizes && out, MODE_ERR_BAD_ARG, "%s: null pointer", who);
+  hipLaunchKernelGGL(abs_max_batch_kernel, dim3(n), dim3(1024), 0, st, ptrs, sizes, reinterpret_cast<unsigned*>(out));
+  return mode::check_launch(who);
+}
 
 int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who) {
   MODE_REQUIRE(n >= 0 && out && (n == 0 || x), MODE_ERR_BAD_ARG, "%s: bad argument", who);

@@ -107,6 +107,7 @@ SIGNATURES = {
     'mode_deconv3d_split_bn_supported': (_c_int, [_c_int] * 2),
     'mode_conv3d_bwd_data_split_acc_supported': (_c_int, [_c_int] * 3),
     'mode_abs_max': (_c_int, [_c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr]),
+    'mode_abs_max_batch': (_c_int, [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'mode_conv3d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),

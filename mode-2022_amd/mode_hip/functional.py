@@ -462,9 +462,56 @@ def _tagged_abs_max(t):
 
 def _weight_abs_max(w, given=None):
   """The maximum buffer of a WEIGHT: the one the layer's forward computed when the caller kept it (`given`: autograd functions carry it from
-  their forward to their backward, where the weight is the same tensor by autograd's own rules), else a pass.  Never cached on the
-  parameter: a write through `.data` moves no version counter, and a stale maximum of a weight that grew is an fp16 overflow."""
-  return given if given is not None else abs_max(w)
+  their forward to their backward, where the weight is the same tensor by autograd's own rules), else the entry of the forward pass's
+  batched table (weight_maxima: all of a model's weights in one launch at the top of its forward), else a pass.  Never cached on the
+  parameter: a write through `.data` moves no version counter, and a stale maximum of a weight that grew is an fp16 overflow -- the
+  table lives for ONE forward pass and is computed inside it."""
+  if given is not None:
+    return given
+  table = getattr(_wmax_tls, 'table', None)
+  if table is not None:
+    hit = table.get(w.data_ptr())
+    if hit is not None and hit[1] == w._version and hit[2] == w.numel():
+      return hit[0]
+  return abs_max(w)
+
+
+_wmax_tls = threading.local()
+
+
+class weight_maxima(object):
+  """with weight_maxima(module): ...   Inside, the maximum buffers of ALL convolution weights of `module` come from ONE launch
+  (mode_abs_max_batch: one workgroup per tensor) issued on entry, instead of a zero fill + a pass per layer -- 63 + 63 launches of ~4.5 us
+  per training step of ModeDisparity (0.6 ms of 55).  Only while the fp16 arithmetic is on and gradients are being recorded; the
+  table of device pointers is kept on the module (rebuilt when a parameter's storage moved) so that the launch is graph-capturable."""
+
+  def __init__(self, module):
+    self.module = module
+    self.prev = None
+
+  def __enter__(self):
+    self.prev = getattr(_wmax_tls, 'table', None)
+    m = self.module
+    on = CONV_ARITH == 'bf16x6' and (CONV3D_S1_F16 or SPHERE_FWD_F16 or CONV2D_F16) and torch.is_grad_enabled() and m.training
+    ws = [p for p in m.parameters() if p.dim() >= 4 and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()] if on else []
+    if not ws:
+      _wmax_tls.table = None
+      return self
+    key = tuple(p.data_ptr() for p in ws)
+    cache = m.__dict__.get('_mode_wmax_cache')
+    if cache is None or cache[0] != key:
+      dev = ws[0].device
+      cache = (key, torch.tensor(key, dtype=torch.int64).to(dev), torch.tensor([p.numel() for p in ws], dtype=torch.int64).to(dev))
+      m.__dict__['_mode_wmax_cache'] = cache
+    out = torch.empty((len(ws), BN_ABSMAX_FLOATS), dtype=torch.float32, device=ws[0].device)
+    with torch.cuda.device_of(out), profiling.region('abs_max_batch', 4 * sum(p.numel() for p in ws), 0, out.device):
+      check(lib().mode_abs_max_batch(ptr(cache[1]), ptr(cache[2]), len(ws), ptr(out), stream_of(out)), 'mode_abs_max_batch')
+    _wmax_tls.table = {p.data_ptr(): (out[i], p._version, p.numel()) for i, p in enumerate(ws)}
+    return self
+
+  def __exit__(self, *exc):
+    _wmax_tls.table = self.prev
+    return False
 
 
 def _sphere_f16_maxima(x, w, f16):
@@ -1499,7 +1546,7 @@ class Conv3dFunction(torch.autograd.Function):
     ctx.amax = None
     if stride == 1 and x.is_cuda and CONV3D_S1_F16 and _split3d(x.shape[1], w.shape[0], 1, False):
       ax = known_abs_max(x)  # left by the BatchNorm pass that wrote x, where there is one
-      ctx.amax = (ax if ax is not None else abs_max(x.contiguous()), abs_max(w.contiguous()))  # the backward reads both tensors again
+      ctx.amax = (ax if ax is not None else abs_max(x.contiguous()), _weight_abs_max(w.contiguous()))  # the backward reads both tensors again
     return conv3d_fwd(x, w, stride, amax=ctx.amax)
 
   @staticmethod

@@ -146,6 +146,12 @@ class ModeDisparity(nn.Module):
 
   def _logits(self, left, right):
     """Everything up to the three classifier outputs cost1, cost2, cost3 (B, 1, D/4, H/4, W/4) (mode_disparity.py:98-129)."""
+    if left.is_cuda:
+      with HF.weight_maxima(self):  # (training on the fp16 arithmetic: every weight's maximum from one launch; a no-op otherwise)
+        return self._logits_body(left, right)
+    return self._logits_body(left, right)
+
+  def _logits_body(self, left, right):
     if self.pair_extractor and left.shape == right.shape and not _cumulative_bn(self.feature_extraction):
       # One pass of the shared extractor over [left; right] instead of two: same arithmetic per sample, BatchNorm statistics
       # still per image set (stage3d.bn_groups), twice the work per kernel launch -- the extractor's kernels are small at the

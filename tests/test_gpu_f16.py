@@ -459,3 +459,60 @@ def test_whole_model_with_an_activation_tensor_spanning_2_to_the_20(f16_switch, 
     same = np.abs(got['scaled'][i] - got['plain'][i]).max()
     print('pred%d: |fp16 pieces - float64| %.2e px   |bf16 pieces - float64| %.2e px   |scaled - plain state| %.2e px' % (i + 1, e16, e3, same))
     assert e16 <= 1e-3 and e3 <= 1e-3 and same <= 2e-4
+
+
+def test_weight_maxima_from_one_launch_are_the_per_layer_ones(f16_switch, monkeypatch):
+  """functional.weight_maxima: inside ModeDisparity.forward every convolution weight's maximum comes from ONE mode_abs_max_batch launch
+  instead of a fill + a pass per layer.  Same buffers' values, hence the same bits in every prediction and gradient as with the table
+  switched off; the per-tensor passes over weights disappear; a weight rescaled through `.data` between two steps (no version bump) is
+  picked up, because the table is computed inside each forward."""
+  import contextlib
+  import recipe
+  import models
+  maxdisp, H, W, B = 16, 64, 32, 2
+  net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
+  net.load_state_dict(recipe.recipe_state_wc(recipe.load_manifest(), 31))
+  net.train()
+  left, right = [t.to(DEV) for t in recipe.recipe_images(B, H, W, 32)]
+  weights = {p.data_ptr() for p in net.parameters() if p.dim() >= 4}
+  passes = []
+  real = HF.abs_max
+
+  def spy(t):
+    passes.append(t.data_ptr() in weights)
+    return real(t)
+
+  monkeypatch.setattr(HF, 'abs_max', spy)
+
+  def step():
+    net.zero_grad(set_to_none=True)
+    del passes[:]
+    preds = net(left, right)
+    sum(p.sum() * w for p, w in zip(preds, (0.5, 0.7, 1.0))).backward()
+    return [p.detach().clone() for p in preds] + [p.grad.clone() for p in net.parameters()], sum(passes)
+
+  batched, n_batched = step()
+
+  class Off(object):
+    def __init__(self, module):
+      pass
+
+    def __enter__(self):
+      return self
+
+    def __exit__(self, *a):
+      return False
+
+  monkeypatch.setattr(HF, 'weight_maxima', Off)
+  plain, n_plain = step()
+  # (one pass is left: a SLICE of dres0[0][0]'s weight that starts at the parameter's address -- cost_conv's tap products; its maximum is its own)
+  assert n_batched <= 2 and n_plain >= 40, (n_batched, n_plain)
+  for a, b in zip(batched, plain):
+    assert torch.equal(a, b)
+  monkeypatch.undo()
+  net.dres1[0][0].weight.data.mul_(64.0)  # 2^6: without a fresh maximum the scaled weight overflows fp16 (2^14 .. 2^15 -> 2^20)
+  after, _ = step()
+  assert all(bool(torch.isfinite(t).all()) for t in after)
+  with torch.no_grad():
+    v = HF.abs_max_value(HF.abs_max(net.dres1[0][0].weight))
+  assert v == float(net.dres1[0][0].weight.abs().max())
