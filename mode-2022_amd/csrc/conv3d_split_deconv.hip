@@ -161,32 +161,63 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     poff[k] = pdz[k] * (int)HW + phy[k] * d.W + pwx[k];
   }
   float raw[KIT][8];
-  unsigned okmask = 0;
-  const float* st_xc = x;
+  // Staging as in conv3d_split.hip since round 6: buffer loads -- the chunk's 8 channel planes one descriptor, a channel a
+  // scalar offset, a position beyond the volume an out-of-range lane offset that reads as zero -- and the tiles walked incrementally
+  // (sb, sd, sh, sw in tile units; the depth extent of a tile is one plane) instead of a division of the tile index per chunk.
+  int jw, jh, jd, jb, sw, sh, sd, sb, s_ch = 0;
+  {
+    int t = nwx;
+    jw = t % d.nWt;
+    t /= d.nWt;
+    jh = t % d.nHt;
+    t /= d.nHt;
+    jd = t % d.D;
+    jb = t / d.D;
+    t = t_begin + slot;
+    sw = t % d.nWt;
+    t /= d.nWt;
+    sh = t % d.nHt;
+    t /= d.nHt;
+    sd = t % d.D;
+    sb = t / d.D;
+  }
+  unsigned soff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) soff[c] = (unsigned)c * (unsigned)DHW * 4u;
+  __amdgpu_buffer_rsrc_t st_rs = buf_rsrc(x, 0);
   int st_base = 0, st_d0 = 0, st_h0 = 0, st_w0 = 0;
-  auto stage_begin = [&](int g) {
-    int b;
-    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
-    tile_of(k_tile, b, st_d0, st_h0, st_w0);
-    st_xc = x + ((long long)b * d.K + ch * 8) * DHW;
+  auto stage_advance = [&](int step) {
+    s_ch += step;
+    const int wrap = s_ch >= d.NCHUNK ? 1 : 0;
+    s_ch = wrap ? 0 : s_ch;
+    sw += wrap ? jw : 0;
+    int c = sw >= d.nWt ? 1 : 0;
+    sw -= c ? d.nWt : 0;
+    sh += (wrap ? jh : 0) + c;
+    c = sh >= d.nHt ? 1 : 0;
+    sh -= c ? d.nHt : 0;
+    sd += (wrap ? jd : 0) + c;
+    c = sd >= d.D ? 1 : 0;
+    sd -= c ? d.D : 0;
+    sb += (wrap ? jb : 0) + c;
+  };
+  auto stage_begin = [&]() {
+    st_d0 = sd;
+    st_h0 = sh * TH;
+    st_w0 = sw * 32;
+    st_rs = buf_rsrc(x + ((long long)sb * d.K + s_ch * 8) * DHW, (unsigned)DHW * 32u);
     st_base = st_d0 * (int)HW + st_h0 * d.W + st_w0;
-    okmask = 0;
   };
   auto stage_load = [&](int k) {
     const unsigned ok = (unsigned)(st_d0 + pdz[k] < d.D) & (unsigned)(st_h0 + phy[k] < d.H) & (unsigned)(st_w0 + pwx[k] < d.W);
-    okmask |= ok << k;
-    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) * 4u : kBufOOB;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float* xcc = st_xc + (long long)c * DHW;
-      raw[k][c] = xcc[off];
-    }
+    for (int c = 0; c < 8; ++c) raw[k][c] = buf_load_f32(st_rs, off, soff[c]);
   };
   uint32_t sq[3][4];
   auto stage_commit = [&](int buf, int k, int h) {
-    const bool ok = (okmask >> k) & 1;
 #pragma unroll
-    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(ok ? raw[k][2 * j] : 0.f, ok ? raw[k][2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(raw[k][2 * j], raw[k][2 * j + 1], sq[0][j], sq[1][j], sq[2][j]);
     if (h == 1) {
       uint4* dst = sm + buf * BUF + tid + k * NT;
 #pragma unroll
@@ -221,7 +252,7 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   };
 
   if (G > 0) {
-    stage_begin(0);
+    stage_begin();
 #pragma unroll
     for (int k = 0; k < KIT; ++k) stage_load(k);
 #pragma unroll
@@ -244,7 +275,8 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   for (int g = 0; g < G; ++g) {
     const uint4* src = sm + (g & 1) * BUF;
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
-    stage_begin(min(g + 1, G - 1));  // (after the last chunk it is staged once more into the idle buffer: no branch in the body)
+    stage_advance(g + 1 < G ? 1 : 0);  // (after the last chunk the same one is staged once more into the idle buffer: no branch in the body)
+    stage_begin();
     uint4 bq[2][2][3];
     // One tap pair of this wave's set (I, SLOT literal: every register array index is a compile-time constant): fragment reads of the
     // next pair, the weight fragments three pairs ahead, this pair's share of the staging, then 12 MFMAs -- smallest terms first, the

@@ -164,36 +164,64 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
     poff[k] = pdz[k] * (int)HW + phy[k] * d.W + pwx[k];
   }
   float raw[KIT][8];
-  unsigned okmask = 0;
-  const float* st_xc = x;
+  // Staging as in conv3d_split.hip since round 6: buffer loads -- the chunk's 8 channel planes one descriptor, a channel a
+  // scalar offset, a position in the zero padding an out-of-range lane offset that reads as zero -- and the tiles walked incrementally
+  // (sb, sd, sh, sw in OUTPUT-tile units) instead of a division of the tile index per chunk.
+  int jw, jh, jd, jb, sw, sh, sd, sb, s_ch = 0;
+  {
+    int t = nwx;
+    jw = t % d.nWt;
+    t /= d.nWt;
+    jh = t % d.nHt;
+    t /= d.nHt;
+    jd = t % d.nDt;
+    jb = t / d.nDt;
+    t = t_begin + slot;
+    sw = t % d.nWt;
+    t /= d.nWt;
+    sh = t % d.nHt;
+    t /= d.nHt;
+    sd = t % d.nDt;
+    sb = t / d.nDt;
+  }
+  unsigned soff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) soff[c] = (unsigned)c * (unsigned)DHW * 4u;
+  __amdgpu_buffer_rsrc_t st_rs = buf_rsrc(x, 0);
   int st_base = 0, st_d0 = 0, st_h0 = 0, st_w0 = 0;  // input coordinates of the haloed tile's first voxel
-  auto stage_begin = [&](int g) {
-    int b, od, oh, ow;
-    const int k_tile = g / d.NCHUNK, ch = g - k_tile * d.NCHUNK;
-    tile_of(k_tile, b, od, oh, ow);
-    st_d0 = 2 * od - 1;
-    st_h0 = 2 * oh - 1;
-    st_w0 = 2 * ow - 1;
-    st_xc = x + ((long long)b * d.K + ch * 8) * DHW;
+  auto stage_advance = [&](int step) {
+    s_ch += step;
+    const int wrap = s_ch >= d.NCHUNK ? 1 : 0;
+    s_ch = wrap ? 0 : s_ch;
+    sw += wrap ? jw : 0;
+    int c = sw >= d.nWt ? 1 : 0;
+    sw -= c ? d.nWt : 0;
+    sh += (wrap ? jh : 0) + c;
+    c = sh >= d.nHt ? 1 : 0;
+    sh -= c ? d.nHt : 0;
+    sd += (wrap ? jd : 0) + c;
+    c = sd >= d.nDt ? 1 : 0;
+    sd -= c ? d.nDt : 0;
+    sb += (wrap ? jb : 0) + c;
+  };
+  auto stage_begin = [&]() {
+    st_d0 = 2 * (sd * TD) - 1;
+    st_h0 = 2 * (sh * TH) - 1;
+    st_w0 = 2 * (sw * 32) - 1;
+    st_rs = buf_rsrc(x + ((long long)sb * d.K + s_ch * 8) * DHW, (unsigned)DHW * 32u);
     st_base = st_d0 * (int)HW + st_h0 * d.W + st_w0;
-    okmask = 0;
   };
   auto stage_load = [&](int k) {
     const unsigned ok = (unsigned)((unsigned)(st_d0 + pdz[k]) < (unsigned)d.D) & (unsigned)((unsigned)(st_h0 + phy[k]) < (unsigned)d.H) &
                         (unsigned)((unsigned)(st_w0 + pwx[k]) < (unsigned)d.W) & (unsigned)(pwx[k] < 2 * IWH - 1);
-    okmask |= ok << k;
-    const unsigned off = ok ? (unsigned)(st_base + poff[k]) : 0u;
+    const unsigned off = ok ? (unsigned)(st_base + poff[k]) * 4u : kBufOOB;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float* xcc = st_xc + (long long)c * DHW;
-      raw[k][c] = xcc[off];
-    }
+    for (int c = 0; c < 8; ++c) raw[k][c] = buf_load_f32(st_rs, off, soff[c]);
   };
   uint32_t sq[3][4];
   auto stage_commit = [&](int buf, int k, int h) {
-    const bool ok = (okmask >> k) & 1;
 #pragma unroll
-    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(ok ? raw[k][2 * j] : 0.f, ok ? raw[k][2 * j + 1] : 0.f, sq[0][j], sq[1][j], sq[2][j]);
+    for (int j = 2 * h; j < 2 * h + 2; ++j) split2(raw[k][2 * j], raw[k][2 * j + 1], sq[0][j], sq[1][j], sq[2][j]);
     if (h == 1) {
       uint4* dst = sm + buf * BUF + tid + k * NT;
 #pragma unroll
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
   };
 
   if (G > 0) {
-    stage_begin(0);
+    stage_begin();
 #pragma unroll
     for (int k = 0; k < KIT; ++k) stage_load(k);
 #pragma unroll
@@ -245,7 +273,8 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
   for (int g = 0; g < G; ++g) {
     const uint4* src = sm + (PHASED ? 0 : (g & 1) * BUF);
     const int ch_next = ch + 1 < d.NCHUNK ? ch + 1 : 0;
-    stage_begin(min(g + 1, G - 1));  // (after the last chunk it is staged once more into the idle buffer: no branch in the body)
+    stage_advance(g + 1 < G ? 1 : 0);  // (after the last chunk the same one is staged once more: no branch in the body)
+    stage_begin();
     uint4 bq[2][TH][3];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
@@ -384,7 +413,7 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
                     const char* who, const mode_bn_epilogue* bn) {
   MODE_REQUIRE(conv3d_s2_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the stride-2 split kernel",
                who, rows, K);
-  MODE_REQUIRE((long long)D * H * W < (1ll << 30) / 8, MODE_ERR_UNSUPPORTED, "%s: volume beyond the 32-bit lane offsets of the split kernel", who);
+  MODE_REQUIRE((long long)D * H * W < (1ll << 26), MODE_ERR_UNSUPPORTED, "%s: volume beyond the 32-bit lane offsets of the split kernel", who);  // (8 planes < 2^31 bytes)
   S2Dims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.Do = (D - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1;

@@ -1423,7 +1423,7 @@ def conv3d_fwd(x, w, stride=1, amax=None):
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_fwd', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
     wp = _wpack3d(Ci, Co, x.device)
-    if _split3d(Ci, Co, stride, False) and stride == 2 and D * H * W < 2**27:
+    if _split3d(Ci, Co, stride, False) and stride == 2 and D * H * W < 2**26:
       check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), None, ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
             'mode_conv3d_fwd_s2_split')
     elif _split3d(Ci, Co, stride, False) and stride == 1 and CONV3D_S1_F16:
@@ -2358,7 +2358,7 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
       with reuse:
         check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
               'mode_conv3d_fwd_split')
-    elif stride == 2 and _split3d(Ci, Co, stride, False) and D * H * W < 2**27:
+    elif stride == 2 and _split3d(Ci, Co, stride, False) and D * H * W < 2**26:
       wp, reuse = _eval_wpack(bn, 'conv3d_fwd_s2_split', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
       with reuse:
         check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
