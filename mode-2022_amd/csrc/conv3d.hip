@@ -401,8 +401,11 @@ __global__ __launch_bounds__(NT, EPI ? 2 : 1) void deconv3d_kernel(const float* 
   const int e_off = e_in ? (int)(e_gd * HW + e_gh * d.W) + w0 + 32 : 0;
   float vm[RPC], ve;
   auto issue = [&](int ch) {
-    const float* xc = xb + ((long long)ch * CCH + hwv) * DHW;
     const bool cok = ch * CCH + hwv < d.Ci;
+    // (a half-wave whose channel lies beyond Ci reads the chunk's FIRST channel instead -- the value is dropped in commit().  Round 6:
+    // the base used to include the missing channel itself, i.e. an address up to 7 planes past the end of the last sample -- harmless
+    // inside a cached allocation, a memory fault when x ended at the end of a mapping: the full GPU suite hit it once its order changed)
+    const float* xc = xb + ((long long)ch * CCH + (cok ? hwv : 0)) * DHW;
 #pragma unroll
     for (int j = 0; j < RPC; ++j) vm[j] = xc[(unsigned)(cok ? rowoff[j] : 0)];
     const bool eok = e_in && ch * CCH + e_c < d.Ci;

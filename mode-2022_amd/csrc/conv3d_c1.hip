@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_co1_fwd_mfma_kernel(const float*
             for (int ks = 0; ks < 16; ++ks) {
               const int c = cb * 32 + 2 * ks + kh;
               const bool ok = pok[g5] && c < Ci;
-              const float xv = xp[ok ? 2 * ks * DHW : 0];
+              const float xv = *(ok ? xp + 2 * ks * DHW : xb);  // (not xp[0]: xp itself may lie past the last channel / outside the plane)
               const float av = (j < 27 && c < Ci) ? w[c * 27 + j] : 0.f;
               acc[g5] = mfma32b(av, ok ? xv : 0.f, acc[g5]);
             }

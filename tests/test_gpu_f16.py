@@ -516,3 +516,33 @@ def test_weight_maxima_from_one_launch_are_the_per_layer_ones(f16_switch, monkey
   with torch.no_grad():
     v = HF.abs_max_value(HF.abs_max(net.dres1[0][0].weight))
   assert v == float(net.dres1[0][0].weight.abs().max())
+
+
+def test_precision_contract_of_small_elements(f16_switch):
+  """ADVICE r5 / include/mode_hip.h: the per-tensor scale keeps 22 significant bits for an element down to ~2^-17 of its tensor's
+  maximum and fewer below.  Measured per ELEMENT here, not against the largest output: input channel 1 is 2^-20 of channel 0, output
+  channel 0 reads only channel 1 -- its values are ~2^-20 of the tensor's and carry 22 - 3 = 19 bits on two fp16 pieces (relative error
+  of the output <= 2^-16 asserted: a sum of 27 terms) where three bf16 pieces keep all 24 (<= 2^-20); output channel 1, fed by the large
+  channel, is fp32-grade in both."""
+  torch.manual_seed(3)
+  B, C, D, H, W = 1, 32, 4, 12, 40
+  x = torch.randn(B, C, D, H, W, device=DEV)
+  x[:, 1] *= 2.0**-20
+  x[:, 2:] = 0
+  w = torch.zeros(C, C, 3, 3, 3, device=DEV)
+  w[0, 1] = torch.randn(3, 3, 3, device=DEV).abs() + 0.5  # positive: no cancellation, the relative error of a sum is that of its terms
+  w[1, 0] = torch.randn(3, 3, 3, device=DEV)
+  x[:, 1].abs_()
+  want = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+  rel = {}
+  for f16 in (True, False):
+    HF.CONV3D_S1_F16 = f16
+    got = HF.conv3d_fwd(x, w, 1).double().cpu()
+    small = ((got[:, 0] - want[:, 0]).abs() / want[:, 0].abs().clamp_min(1e-300)).max()
+    big = (got[:, 1] - want[:, 1]).abs().max() / want[:, 1].abs().max()
+    rel[f16] = (float(small), float(big))
+    print('%s: worst relative error of the small channel %.2e (2^%.1f), of the large one %.2e' %
+          ('two fp16 pieces ' if f16 else 'three bf16 pieces', small, np.log2(max(float(small), 1e-300)), big))
+  assert rel[True][0] <= 2.0**-16 and rel[False][0] <= 2.0**-20
+  assert rel[True][1] <= 2.0**-19 and rel[False][1] <= 2.0**-19
+  assert float(want[:, 0].abs().max()) < 2.0**-14 * float(want[:, 1].abs().max())

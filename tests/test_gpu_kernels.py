@@ -954,6 +954,47 @@ def test_folded_batchnorm_conv3d(relu, with_add, arith):
       assert (HF.deconv3d_bn_eval(x, w, bn, add, relu).double() - _unfused(bn, want, add, relu)).abs().max() < 1e-4, (cin, cout)
 
 
+def _at_the_end_of_its_own_mapping(t):
+  """A copy of t whose last byte is the last byte of a fresh device allocation: torch's caching allocator gives a request of >= 10 MB a
+  segment of its own (rounded to 2 MB), so a kernel that reads even one element past the tensor leaves the mapping -- inside a cached
+  block the same read lands in someone else's memory and nobody notices (round 6: a read seven planes past the last sample in the fp32
+  transposed kernel survived five rounds that way and took the whole suite down when the test order changed)."""
+  torch.cuda.empty_cache()
+  nbytes = t.numel() * 4
+  seg = 12 * 2**20
+  assert nbytes <= seg and nbytes % 4 == 0
+  raw = torch.empty(seg, dtype=torch.uint8, device=t.device)
+  view = raw[seg - nbytes:].view(torch.float32).view(t.shape)
+  view.copy_(t)
+  return view, raw
+
+
+def test_channel_tails_do_not_read_past_the_tensor(arith):
+  """Layers whose input channels do not fill the kernels' 8 / 16 / 32-channel chunks, with the input placed at the very end of a device
+  mapping: the chunk's missing channels must not be addressed at all.  (The values are checked by the other tests; here the kernels
+  only have to finish.)"""
+  with torch.no_grad():
+    for (cin, cout) in ((12, 40), (24, 40), (20, 8)):  # transposed, fp32 kernel (+ folded BatchNorm epilogue)
+      x, keep = _at_the_end_of_its_own_mapping(_rand((2, cin, 3, 5, 34), 95).to(DEV))
+      w = _rand((cin, cout, 3, 3, 3), 96, 0.1).to(DEV)
+      a = HF.deconv3d_bn_eval(x, w, _eval_bn(cout, 97), None, True)
+      b = HF.deconv3d_fwd(x, w)
+      assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    for (ci, co, stride) in ((20, 40, 1), (12, 24, 2), (36, 1, 1)):  # stride 1 / 2 and the single-channel head, fp32 kernels
+      x, keep = _at_the_end_of_its_own_mapping(_rand((2, ci, 6, 10, 36), 91).to(DEV))
+      w = _rand((co, ci, 3, 3, 3), 92, 0.1).to(DEV)
+      y = HF.conv3d_fwd(x, w, stride)
+      gw = HF.conv3d_bwd_weight(torch.ones_like(y), x, stride)
+      assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(gw).all())
+    for (ci, co) in ((12, 32), (20, 24)):  # 3 x 3 layers off the 16-channel grid (the fusion network's input layers)
+      x, keep = _at_the_end_of_its_own_mapping(_rand((2, ci, 20, 36), 81).to(DEV))
+      w = _rand((co, ci, 3, 3), 82, 0.1).to(DEV)
+      y = HF.conv2d_fwd(x, w, 1)
+      gw = HF.conv2d_bwd_weight(torch.ones_like(y), x, 1)
+      assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(gw).all())
+  torch.cuda.synchronize()
+
+
 def test_conv3d_input_gradient_with_a_gradient_already_there(arith):
   """conv3d_bwd_data(..., acc=g): the sum of the input gradient and g, added in the store of the split kernels
   (mode_conv3d_bwd_data_split_acc; stride 1: the residual epilogue of conv3d_split_kernel, stride 2: of deconv3d_split_kernel, both
