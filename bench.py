@@ -48,6 +48,20 @@ def _on_f16_path(label):
   if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
     return True
   return bool(CONV2D_F16 and re.match(r'conv2d_(fwd|bwd_data|bwd_weight)\[', label))  # (where they are on the split path at all: label_peak asks that first)
+TIMED_BATCH = 2  # (set by main: the layer labels carry no batch size)
+
+
+def _tall_tile(label):
+  """csrc/conv3d_split.hip, conv3d_s1_split: the plain-store fp16 instantiation runs a 2 x 16 x 32 output tile where H % 16 == 0 and the
+  2 x 8 x 32 tiling has at least four tiles per CU and output block -- another device kernel (<1,0,true,16>) in rocprofv3's table."""
+  import re
+  m = re.search(r' s1 (\d+)x(\d+)x(\d+)\]', label)
+  if not m or os.environ.get('MODE_SPLIT_TALL', '1')[:1] == '0':
+    return False
+  d, h, w = (int(v) for v in m.groups())
+  return h % 16 == 0 and TIMED_BATCH * ((d + 1) // 2) * (h // 8) * ((w + 31) // 32) >= 4 * 256
+
+
 KERNEL_BOUND = {'maxpool2x2_fwd': 'hbm', 'maxpool2x2_bwd': 'hbm', 'depth_to_space2': 'hbm', 'space_to_depth2': 'hbm', 'conv1x1_sigmoid_fwd': 'hbm',
                 'conv1x1_sigmoid_bwd': 'hbm', 'cost_volume_fwd': 'hbm', 'cost_volume_bwd': 'hbm', 'head_fwd': 'hbm', 'head_bwd': 'hbm', 'bn_train_fwd': 'hbm',
                 'bn_train_bwd': 'hbm', 'bn_eval_fwd': 'hbm', 'cost_conv_assemble_fwd': 'hbm', 'cost_conv_assemble_bwd': 'hbm',
@@ -104,6 +118,8 @@ def parse():
   args = ap.parse_args()
   if args.batch is None:
     args.batch = 1 if args.mode == 'fusion' else 2
+  global TIMED_BATCH
+  TIMED_BATCH = args.batch
   return args
 
 
@@ -194,9 +210,9 @@ def kernel_of(label, conv_arith, on_split=None):
     if split and stride == 2:
       return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
-      if _on_f16_path(label):
-        return 'conv3d_split_kernel<1,0,true>'  # (<1,2,true> where a gradient is added in the store)
-      return 'conv3d_split_kernel<1,0>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1>'  # (<1,2> with a residual)
+      if _on_f16_path(label):  # (<1,2,true,8> where a gradient is added in the store)
+        return 'conv3d_split_kernel<1,0,true,16>' if _tall_tile(label) else 'conv3d_split_kernel<1,0,true,8>'
+      return 'conv3d_split_kernel<1,0,false,8>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1,false,8>'  # (<1,2,false,8> with a residual)
     return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
   if name == 'conv3d_bwd_weight':
     if re.search(r'->1 ', label):
@@ -248,7 +264,8 @@ def kernel_of(label, conv_arith, on_split=None):
           'conv1x1_sigmoid_bwd': 'head1_bwd_kernel+head1_reduce_kernel', 'deconv2x2_gemm': 'conv1x1_kernel', 'deconv2x2_bwd_data': 'conv1x1_kernel',
           'deconv2x2_bwd_weight': 'conv1x1_bww_kernel',
           'conv_stem_fwd': 'stem_fwd_kernel', 'conv_stem_bwd_weight': 'stem_bww_kernel', 'conv1x1_fwd': 'conv1x1_kernel',
-          'conv1x1_bwd_data': 'conv1x1_kernel', 'conv1x1_bwd_weight': 'conv1x1_bww_kernel'}.get(name, name)
+          'conv1x1_bwd_data': 'conv1x1_kernel', 'conv1x1_bwd_weight': 'conv1x1_bww_kernel',
+          'abs_max': 'abs_max_kernel', 'abs_max_batch': 'abs_max_batch_kernel'}.get(name, name)
 
 
 def calibrated_traffic(label, batch, conv_arith, on_split=None):

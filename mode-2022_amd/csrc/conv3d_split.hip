@@ -52,22 +52,31 @@ template <bool F16> struct Arith {
   static constexpr int NP = F16 ? 2 : 3;     // pieces per fp32 value
   static constexpr int NTERM = F16 ? 3 : 6;  // MFMAs per product
 };
-constexpr int TD = 2, TH = 8, ID = TD + 2, IH = TH + 2, IW = 34;
-constexpr int ROWS = ID * IH;           // 40 haloed rows
-constexpr int ITEMS = ROWS * IW;        // 1 360 positions per chunk
-constexpr int KIT = (ITEMS + NT - 1) / NT;    // 6 positions per thread
-constexpr int PIECE = KIT * NT;         // 1 536: positions per piece incl. the unused tail, so that no staging store is conditional
-template <bool F16> constexpr int buf_of() { return Arith<F16>::NP * PIECE; }  // uint4 per buffer
+constexpr int TD = 2, ID = TD + 2, IW = 34;
+// Tile geometry for TH output rows per depth plane: 8 (every instantiation of rounds 2-5) or 16 (round 6, the fp16 plain-store
+// instantiation at volumes with enough tiles: twice the MFMAs per chunk for 1.8 x the staged positions and the same 28 weight
+// fragments -- 2.3 instead of 3.1 other instructions beside an MFMA; two 80 KB buffers are exactly the CU's 160 KB of LDS)
+template <int TH_>
+struct Geo {
+  static constexpr int TH = TH_, IH = TH_ + 2;
+  static constexpr int ROWS = ID * IH;                 // 40 (72) haloed rows
+  static constexpr int ITEMS = ROWS * IW;              // 1 360 (2 448) positions per chunk
+  static constexpr int KIT = (ITEMS + NT - 1) / NT;    // 6 (10) positions per thread
+  static constexpr int PIECE = KIT * NT;               // 1 536 (2 560): positions per piece incl. the unused tail, so that no staging store is conditional
+  static constexpr int R = TD * TH_ / (NT / 64);       // 4 (8) output rows per matrix wave
+  static constexpr int RB = R / 4;                     // blocks of four rows a tap pair is multiplied in
+};
+template <bool F16, int TH_ = 8> constexpr int buf_of() { return Arith<F16>::NP * Geo<TH_>::PIECE; }  // uint4 per buffer
 constexpr int NPAIR = 14;
 constexpr int WAHEAD = 6;  // weight fragments are loaded this many tap pairs ahead (3 measured the same, r03w)
-constexpr int R = TD * TH / (NT / 64);  // 4 output rows per matrix wave
-template <bool F16> constexpr size_t lds_bytes() { return 2 * (size_t)buf_of<F16>() * sizeof(uint4); }  // 147 456 B (98 304 B)
+template <bool F16, int TH_ = 8> constexpr size_t lds_bytes() { return 2 * (size_t)buf_of<F16, TH_>() * sizeof(uint4); }  // 147 456 B (98 304 B; 163 840 B)
 
 struct SDims {
   int B, K, Co, D, H, W;  // K = reduction channels of this GEMM, Co = its output channels
   int nWt, nHt, nDt;
   int MT, NCHUNK;
   int ntiles;
+  int TH;  // output rows per depth plane of a tile: 8, or 16 (Geo)
   int o0;  // first output channel of this launch (a layer with 33..64 output channels runs as two launches of 32)
 };
 
@@ -164,7 +173,7 @@ __device__ __forceinline__ f32x16 mfma_split(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__host__ __device__ constexpr int tap_off(int tap) {  // LDS position offset of a tap inside the haloed tile
+__host__ __device__ constexpr int tap_off(int tap, int IH) {  // LDS position offset of a tap inside the haloed tile
   return (tap / 9) * (IH * IW) + ((tap / 3) % 3) * IW + tap % 3;
 }
 
@@ -193,12 +202,15 @@ __global__ __launch_bounds__(64) void first_voxel_kernel(const float* __restrict
   if (lane == 0) pivot[o] = acc;
 }
 
-template <int MT, int EPI, bool F16 = false>
+template <int MT, int EPI, bool F16 = false, int TH_ = 8>
 __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                           float* __restrict__ y, SDims d, Epi epi, float* __restrict__ stats,
                                                           const float* __restrict__ stat_pivot, const float* __restrict__ amax_x,
                                                           const float* __restrict__ amax_w) {
-  constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16>();
+  constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16, TH_>();
+  using Ge = Geo<TH_>;
+  constexpr int TH = Ge::TH, IH = Ge::IH, ITEMS = Ge::ITEMS, KIT = Ge::KIT, PIECE = Ge::PIECE, R = Ge::R, RB = Ge::RB;
+  static_assert(EPI == 0 || TH_ == 8, "the tall tile exists for the plain store only");
   // (F16) x is multiplied by sx when it is staged, the weights by sw when they are packed, the sums by 1 / (sx sw) when they are stored
   const float sx = F16 ? f16_scale_of(mode::absmax_load(amax_x)) : 1.f;
   const float unscale = F16 ? (1.f / sx) * (1.f / f16_scale_of(mode::absmax_load(amax_w))) : 1.f;
@@ -429,29 +441,36 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < R; ++r) ep_cur[r] = last ? ep_off[r] : (unsigned)(lane & 31);
     }
-    uint4 bq[2][R][NP];
+    // A tap pair is multiplied in RB blocks of four rows (RB = 1: the 8-row tile, the loop of rounds 2-5; RB = 2: the 16-row tile -- the
+    // same weight fragment serves both blocks, the fragment registers stay those of four rows).  idx = pair * RB + block.
+    uint4 bq[2][4][NP];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? tap_off(1) : tap_off(0))];
+      for (int p = 0; p < NP; ++p) bq[0][r][p] = src[p * PIECE + rowpos[r] + (half ? tap_off(1, IH) : tap_off(0, IH))];
 #pragma unroll
-    for (int pair = 0; pair < NPAIR; ++pair) {
-      // fragments of the next pair (the empty second half of the last pair reads tap 26 again: finite data under zero weights)
-      if (pair + 1 < NPAIR) {
-        const int t0 = 2 * (pair + 1), t1 = t0 + 1 < 27 ? t0 + 1 : 26;
-        const int toff = half ? tap_off(t1) : tap_off(t0);
+    for (int idx = 0; idx < NPAIR * RB; ++idx) {
+      const int pair = idx / RB, rb = idx % RB;
+      // fragments of the next block (the empty second half of the last pair reads tap 26 again: finite data under zero weights)
+      if (idx + 1 < NPAIR * RB) {
+        const int npair = (idx + 1) / RB, nrb = (idx + 1) % RB;
+        const int t0 = 2 * npair, t1 = t0 + 1 < 27 ? t0 + 1 : 26;
+        const int toff = half ? tap_off(t1, IH) : tap_off(t0, IH);
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int p = 0; p < NP; ++p) bq[(pair + 1) & 1][r][p] = src[p * PIECE + rowpos[r] + toff];
+          for (int p = 0; p < NP; ++p) bq[(idx + 1) & 1][r][p] = src[p * PIECE + rowpos[4 * nrb + r] + toff];
       }
-      // weights 6 pairs ahead, into the slot the previous pair has left
-      if (pair + WAHEAD < NPAIR)
-        load_a((pair + WAHEAD) % 7, ch, pair + WAHEAD);
-      else
-        load_a((pair + WAHEAD) % 7, ch_next, pair + WAHEAD - NPAIR);
-      // the staging arithmetic sits under the last 6 pairs, one position each: the loads have had 8 pairs (~6 000 cycles) to land
-      if (pair < KIT) stage_load(pair);
+      if (rb == 0) {
+        // weights 6 pairs ahead, into the slot the previous pair has left
+        if (pair + WAHEAD < NPAIR)
+          load_a((pair + WAHEAD) % 7, ch, pair + WAHEAD);
+        else
+          load_a((pair + WAHEAD) % 7, ch_next, pair + WAHEAD - NPAIR);
+        // position k of the next chunk is requested under pair k and split under pair k + (NPAIR - KIT): 8 pairs (16-row tile: 4 pairs
+        // of twice the MFMAs) for the loads to land
+        if (pair < KIT) stage_load(pair);
+      }
       if (EPI == 2 && pair >= NPAIR - 2 * R) {  // residual values of one row, 8 of its 16 output channels, under each of the last 8 pairs
         const int r = (pair - (NPAIR - 2 * R)) / 2;
 #pragma unroll
@@ -459,14 +478,14 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 #pragma unroll
           for (int qq = 8 * (pair & 1); qq < 8 * (pair & 1) + 8; ++qq) addv[m][r][qq] = ep_base[ep_cur[r] + ep_chan[m][qq]];
       }
-      if (pair >= NPAIR - KIT) {
-        stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 0);
-        stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 1);
+      if (pair >= NPAIR - KIT) {  // (RB = 2: one half of the position's channels under each row block)
+        if (RB == 1 || rb == 0) stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 0);
+        if (RB == 1 || rb == 1) stage_commit((g + 1) & 1, pair - (NPAIR - KIT), 1);
       }
       // smallest terms first; consecutive MFMAs go to different accumulators
 #define MODE_SPLIT_TERM(PA, PB)                                                      \
-  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < R; ++r) \
-      acc[m][r] = mfma_split<F16>(aring[pair % 7][m][PA], bq[pair & 1][r][PB], acc[m][r]);
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int r = 0; r < 4; ++r) \
+      acc[m][4 * rb + r] = mfma_split<F16>(aring[pair % 7][m][PA], bq[idx & 1][r][PB], acc[m][4 * rb + r]);
       if constexpr (F16) {
         MODE_SPLIT_TERM(1, 0)
         MODE_SPLIT_TERM(0, 1)
@@ -483,7 +502,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
       // one MFMA, then up to 3 vector-ALU instructions and one fragment read, 24 times: spreads the staging arithmetic and the
       // next pair's reads over the matrix instructions (5 single-issue slots fit under one 32x32x16 MFMA)
 #pragma unroll
-      for (int i = 0; i < MT * R * NTERM; ++i) {
+      for (int i = 0; i < MT * 4 * NTERM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         if (F16) {  // (half the MFMAs for the same staging: every gap also takes an LDS access of either kind and a load.  6 + 2 per
@@ -578,17 +597,19 @@ int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblo
                  float* stats = nullptr, const float* stat_pivot = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr) {
   const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
-#define MODE_SPLIT_LAUNCH(EPIV, F16V, STATS, PIVOT)                                                                          \
+#define MODE_SPLIT_LAUNCH_TH(EPIV, F16V, THV, STATS, PIVOT)                                                                  \
   {                                                                                                                          \
-    int rc = mode::allow_lds(conv3d_split_kernel<MT, EPIV, F16V>, lds_bytes<F16V>(), who);                                   \
+    int rc = mode::allow_lds(conv3d_split_kernel<MT, EPIV, F16V, THV>, lds_bytes<F16V, THV>(), who);                         \
     if (rc != MODE_OK) return rc;                                                                                            \
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, EPIV, F16V>), dim3(grid, nblocks), dim3(NT), lds_bytes<F16V>(), st, x, wp, y, d, epi, \
-                       STATS, PIVOT, amax_x, amax_w);                                                                        \
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, EPIV, F16V, THV>), dim3(grid, nblocks), dim3(NT), (lds_bytes<F16V, THV>()), st, x, wp, y, d, \
+                       epi, STATS, PIVOT, amax_x, amax_w);                                                                   \
     return mode::check_launch(who);                                                                                          \
   }
+#define MODE_SPLIT_LAUNCH(EPIV, F16V, STATS, PIVOT) MODE_SPLIT_LAUNCH_TH(EPIV, F16V, 8, STATS, PIVOT)
   if (amax_x) {  // the two-piece fp16 arithmetic: plain store and the accumulate form (training)
     MODE_REQUIRE(!stats && (!epi.shift || epi.add), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no BatchNorm epilogues", who);
     if (epi.shift && epi.add) MODE_SPLIT_LAUNCH(2, true, nullptr, nullptr)
+    if (d.TH == 16) MODE_SPLIT_LAUNCH_TH(0, true, 16, nullptr, nullptr)
     MODE_SPLIT_LAUNCH(0, true, nullptr, nullptr)
   }
   if (stats) MODE_SPLIT_LAUNCH(3, false, stats, stat_pivot)
@@ -596,6 +617,7 @@ int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblo
   if (epi.shift) MODE_SPLIT_LAUNCH(1, false, nullptr, nullptr)
   MODE_SPLIT_LAUNCH(0, false, nullptr, nullptr)
 #undef MODE_SPLIT_LAUNCH
+#undef MODE_SPLIT_LAUNCH_TH
 }
 
 // out[0] = the largest FINITE |x[i]| as an unsigned maximum over the bit patterns of the magnitudes (order-independent: the same bits
@@ -705,8 +727,15 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   MODE_REQUIRE(conv3d_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the split kernel", who,
                rows, K);
   MODE_REQUIRE((long long)rows * D * H * W < (1ll << 31), MODE_ERR_UNSUPPORTED, "%s: a sample of the output has 2^31 elements or more", who);
+  // The 16-row tile: the plain-store fp16 instantiation, where the rows divide and the 8-row tiling has at least four rounds of
+  // tiles per output block (half as many tiles: fewer would leave CUs without one)
+  static const char* tall_env = getenv("MODE_SPLIT_TALL");  // (tuning override: 0 keeps the 8-row tile everywhere)
+  const bool tall_ok = !tall_env || tall_env[0] != '0';
+  d.TH = 8;
+  if (absmax && !acc_in && H % 16 == 0 && (long long)B * cdiv(D, TD) * (H / 8) * cdiv(W, 32) >= 4ll * kNumCU && tall_ok)
+    d.TH = 16;
   d.nWt = cdiv(W, 32);
-  d.nHt = cdiv(H, TH);
+  d.nHt = cdiv(H, d.TH);
   d.nDt = cdiv(D, TD);
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;

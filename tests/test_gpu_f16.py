@@ -81,6 +81,30 @@ def test_f16_arithmetic_is_an_fp32_convolution(case, ci, co, shape, f16_switch):
     assert torch.isfinite(got[True][k]).all()
 
 
+def test_the_16_row_tile_is_the_8_row_tile_bit_for_bit(f16_switch):
+  """Round 6: at volumes with >= 4 x 256 tiles and H % 16 == 0 the plain-store fp16 instantiation runs a 2 x 16 x 32 tile
+  (csrc/conv3d_split.hip, Geo<16>).  The order of every output's sum is that of the 8-row tile (chunks, tap pairs, terms), so the
+  results are the same bits: the accumulate form (residual epilogue, always the 8-row tile) with a zero addend is the witness.
+  Ragged W and odd D; forward and input gradient; and the fp32-grade bound against float64."""
+  HF.CONV3D_S1_F16 = True
+  shape = (1, 17, 64, 500)
+  x = _case('six decades along a row', 32, shape, 511)
+  w = _rand((32, 32, 3, 3, 3), 512, 0.05)
+  wf = w.flip(2, 3, 4).transpose(0, 1).contiguous()  # conv(x, w) as the input gradient of the flipped, transposed weights
+  y = HF.conv3d_fwd(x, w, 1)
+  y_as_grad = HF.conv3d_bwd_data(x, wf, x.shape, 1)
+  y8 = HF.conv3d_bwd_data(x, wf, x.shape, 1, acc=torch.zeros_like(x))
+  assert torch.equal(y_as_grad, y8)
+  want = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+  bound = 2.0**-22 * (32 * 27)**0.5 * float(want.abs().max())
+  for got in (y, y8):
+    err = float((got.double().cpu() - want).abs().max())
+    print('16-row tile: error %.2e, bound %.2e' % (err, bound))
+    assert err <= bound
+  # the forward packs the weights itself (no flip): same products, same order -> the same bits again
+  assert torch.equal(y, y8)
+
+
 def test_abs_max_is_exact_and_order_independent():
   x = _rand((3, 1000003), 601)
   x[1, 77] = -123.5
