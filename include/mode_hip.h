@@ -58,7 +58,7 @@ typedef struct mode_bn_epilogue {
 } mode_bn_epilogue;
 
 /* Version / diagnostics. */
-#define MODE_HIP_ABI_VERSION 30 /* bumped whenever a signature below changes */
+#define MODE_HIP_ABI_VERSION 31 /* bumped whenever a signature below changes */
 int mode_hip_abi_version(void);
 const char* mode_last_error(void);
 
@@ -432,6 +432,13 @@ int mode_conv3d_fwd_split_f16(const float* x, const float* w, const float* amax_
                               int D, int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
                                    float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream);
+/* INFERENCE on the same arithmetic (ABI 31): y = relu?(bn(conv3d(x, w)) [+ bn->add]) as mode_conv3d_fwd_split with a non-NULL epilogue, on
+ * two fp16 pieces.  The BatchNorm scale is folded into the weights before they are scaled and split: their maximum is the FOLDED weights',
+ * taken inside the call where they are packed and kept in wpack (same size as for mode_conv3d_fwd_split; mode_pack_reuse applies to it as
+ * to the packed weights).  In eval mode no BatchNorm pass writes the activations, so the kernel's epilogue leaves the maximum of what it
+ * stored in amax_y (MODE_BN_ABSMAX_FLOATS floats, zeroed and filled by the call): the next layer's amax_x. */
+int mode_conv3d_fwd_split_f16_bn(const float* x, const float* w, const float* amax_x, const mode_bn_epilogue* bn, float* y, float* amax_y,
+                                 float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream);
 int mode_conv3d_bwd_weight_split_f16(const float* gy, const float* x, const float* amax_g, const float* amax_x, float* gw, float* workspace,
                                      int B, int Ci, int D, int H, int W, int Co, int accumulate, mode_stream_t stream);
 /* The input gradient of a stride-1 / stride-2 convolution on the split kernels with a gradient that is already there added in the

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "conv3d_internal.h"
+#include "bn_internal.h"
 
 namespace {
 
@@ -651,6 +652,22 @@ extern "C" int mode_conv3d_fwd_split_f16(const float* x, const float* w, const f
   if (rc != MODE_OK || B == 0) return rc;
   MODE_REQUIRE(amax_x && amax_w, MODE_ERR_BAD_ARG, "%s: null operand maximum", who);
   return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, nullptr, nullptr, nullptr, amax_x, amax_w);
+}
+
+// Eval mode on the fp16 arithmetic: y = relu?(bn(conv(x)) [+ add]) with the BatchNorm scale folded into the weights BEFORE they are scaled
+// and split (their maximum is taken inside, where they are packed, and kept in wpack); amax_y receives the maximum of y for the next layer.
+extern "C" int mode_conv3d_fwd_split_f16_bn(const float* x, const float* w, const float* amax_x, const mode_bn_epilogue* bn, float* y,
+                                            float* amax_y, float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
+  const char* who = "mode_conv3d_fwd_split_f16_bn";
+  int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 1, who);
+  if (rc == MODE_OK) {
+    MODE_REQUIRE(bn, MODE_ERR_BAD_ARG, "%s: null BatchNorm epilogue", who);
+    rc = mode::check_bn(bn, who);
+  }
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(amax_x && amax_y, MODE_ERR_BAD_ARG, "%s: null maximum buffer", who);
+  if (B == 0) return mode::absmax_begin(amax_y, mode::as_stream(stream), who);  // (an empty output's maximum is zero)
+  return mode::conv3d_s1_split(x, w, y, wpack, B, Ci, Co, D, H, W, 0, mode::as_stream(stream), who, bn, nullptr, nullptr, amax_x, nullptr, amax_y);
 }
 
 // gx = conv^T(gy) [+ acc]; amax_g = max |gy|, amax_w = max |w|

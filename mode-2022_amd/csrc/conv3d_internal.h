@@ -30,10 +30,11 @@ size_t conv3d_split_wpack_floats(int K, int rows);
 int conv3d_split_stat_partials();
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats = nullptr, const float* acc_in = nullptr,
-                    const float* amax_x = nullptr, const float* amax_w = nullptr);
+                    const float* amax_x = nullptr, const float* amax_w = nullptr, float* amax_y = nullptr);
 // (acc_in: y = conv(x) + acc_in -- a gradient that is already there added in the store, instead of a separate pass; not with bn / stats.
 //  amax_x / amax_w: device floats max |x|, max |w| (both or neither) -> the two-piece fp16 arithmetic (three MFMAs per product) with
-//  power-of-two scales; not with bn / stats)
+//  power-of-two scales; not with stats.  With bn (eval mode): amax_x and amax_y, NO amax_w -- the maximum of the folded weights is taken
+//  where they are packed and kept in wpack; amax_y (MODE_BN_ABSMAX_FLOATS floats) receives the maximum of the stored output)
 
 // out[0] (device) = the largest magnitude in x[0..n): the scale source of the fp16 arithmetic (order-independent, graph-capturable)
 int abs_max(const float* x, long long n, float* out, hipStream_t st, const char* who);

@@ -202,11 +202,14 @@ __global__ __launch_bounds__(64) void first_voxel_kernel(const float* __restrict
   if (lane == 0) pivot[o] = acc;
 }
 
-template <int MT, int EPI, bool F16 = false, int TH_ = 8>
+// AMAX (the eval epilogues of the fp16 arithmetic): the largest finite magnitude of what the kernel stores goes to amax_y (the buffer of
+// bn_internal.h, zeroed by the host in front of the launch) -- the operand maximum of the NEXT layer, which has no BatchNorm pass to
+// take it from in eval mode.  One v_and + v_cmp + v_cndmask + v_max per stored value, one request per workgroup at the end.
+template <int MT, int EPI, bool F16 = false, int TH_ = 8, bool AMAX = false>
 __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                           float* __restrict__ y, SDims d, Epi epi, float* __restrict__ stats,
                                                           const float* __restrict__ stat_pivot, const float* __restrict__ amax_x,
-                                                          const float* __restrict__ amax_w) {
+                                                          const float* __restrict__ amax_w, unsigned* __restrict__ amax_y) {
   constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16, TH_>();
   using Ge = Geo<TH_>;
   constexpr int TH = Ge::TH, IH = Ge::IH, ITEMS = Ge::ITEMS, KIT = Ge::KIT, PIECE = Ge::PIECE, R = Ge::R, RB = Ge::RB;
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
         stK[m][qq] = stat_pivot ? stat_pivot[min(d.o0 + m * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * half, d.Co - 1)] : 0.f;
       }
   }
+  unsigned out_mag = 0;  // (AMAX)
   const float relu_floor = (EPI == 1 || EPI == 2) && epi.relu ? 0.f : -__builtin_inff();
   if (EPI == 1 || EPI == 2) {
 #pragma unroll
@@ -541,7 +545,9 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
                   st0[m][qq] += dv;
                   st1[m][qq] = __builtin_fmaf(dv, dv, st1[m][qq]);
                 }
-                yb[idx] = ((EPI == 1 || EPI == 2) && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+                const float vo = ((EPI == 1 || EPI == 2) && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+                if (AMAX) out_mag = max(out_mag, mode::absmax_mag(vo));
+                yb[idx] = vo;
               }
             }
         }
@@ -553,6 +559,10 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
     }
     ch = ch_next;
     lds_barrier();
+  }
+  if (AMAX) {
+    __syncthreads();
+    mode::absmax_block_commit(out_mag, amax_y, reinterpret_cast<unsigned*>(sm));
   }
   if (EPI == 3) {
     // lanes 0..31 / 32..63 hold the same 16 channels each (o = (qq & 3) + 8 (qq >> 2) + 4 half): butterfly over the 32 lanes of a half,
@@ -594,22 +604,28 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
 
 template <int MT>
 int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblocks, hipStream_t st, const char* who, Epi epi,
-                 float* stats = nullptr, const float* stat_pivot = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr) {
+                 float* stats = nullptr, const float* stat_pivot = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr,
+                 float* amax_y = nullptr) {
   const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const int grid = kNumCU;  // persistent, one workgroup per CU (130 KB of LDS each)
-#define MODE_SPLIT_LAUNCH_TH(EPIV, F16V, THV, STATS, PIVOT)                                                                  \
+#define MODE_SPLIT_LAUNCH_TH(EPIV, F16V, THV, AMAXV, STATS, PIVOT)                                                           \
   {                                                                                                                          \
-    int rc = mode::allow_lds(conv3d_split_kernel<MT, EPIV, F16V, THV>, lds_bytes<F16V, THV>(), who);                         \
+    int rc = mode::allow_lds(conv3d_split_kernel<MT, EPIV, F16V, THV, AMAXV>, lds_bytes<F16V, THV>(), who);                  \
     if (rc != MODE_OK) return rc;                                                                                            \
-    hipLaunchKernelGGL((conv3d_split_kernel<MT, EPIV, F16V, THV>), dim3(grid, nblocks), dim3(NT), (lds_bytes<F16V, THV>()), st, x, wp, y, d, \
-                       epi, STATS, PIVOT, amax_x, amax_w);                                                                   \
+    hipLaunchKernelGGL((conv3d_split_kernel<MT, EPIV, F16V, THV, AMAXV>), dim3(grid, nblocks), dim3(NT), (lds_bytes<F16V, THV>()), st, x, wp, \
+                       y, d, epi, STATS, PIVOT, amax_x, amax_w, reinterpret_cast<unsigned*>(amax_y));                        \
     return mode::check_launch(who);                                                                                          \
   }
-#define MODE_SPLIT_LAUNCH(EPIV, F16V, STATS, PIVOT) MODE_SPLIT_LAUNCH_TH(EPIV, F16V, 8, STATS, PIVOT)
+#define MODE_SPLIT_LAUNCH(EPIV, F16V, STATS, PIVOT) MODE_SPLIT_LAUNCH_TH(EPIV, F16V, 8, false, STATS, PIVOT)
+  if (amax_x && amax_y) {  // eval mode on the two-piece fp16 arithmetic: folded BatchNorm (+ residual) (+ ReLU), the output's maximum
+    MODE_REQUIRE(!stats && epi.shift, MODE_ERR_BAD_ARG, "%s: the output maximum belongs to the eval epilogues", who);
+    if (epi.add) MODE_SPLIT_LAUNCH_TH(2, true, 8, true, nullptr, nullptr)
+    MODE_SPLIT_LAUNCH_TH(1, true, 8, true, nullptr, nullptr)
+  }
   if (amax_x) {  // the two-piece fp16 arithmetic: plain store and the accumulate form (training)
     MODE_REQUIRE(!stats && (!epi.shift || epi.add), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no BatchNorm epilogues", who);
     if (epi.shift && epi.add) MODE_SPLIT_LAUNCH(2, true, nullptr, nullptr)
-    if (d.TH == 16) MODE_SPLIT_LAUNCH_TH(0, true, 16, nullptr, nullptr)
+    if (d.TH == 16) MODE_SPLIT_LAUNCH_TH(0, true, 16, false, nullptr, nullptr)
     MODE_SPLIT_LAUNCH(0, true, nullptr, nullptr)
   }
   if (stats) MODE_SPLIT_LAUNCH(3, false, stats, stat_pivot)
@@ -683,6 +699,26 @@ __global__ __launch_bounds__(1024) void abs_max_batch_kernel(const float* const*
   }
 }
 
+// The maximum buffer of an eval layer's FOLDED weights w[o][..] * scale[o] (scale = gamma / sqrt(var + eps): what pack_w3d_split splits
+// when fold == 1), one block: word 0 the value, the slots zero.  n = elements per output row.
+__global__ __launch_bounds__(1024) void abs_max_folded_kernel(const float* __restrict__ w, mode_bn_epilogue bn, int rows, int n,
+                                                              unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < rows * n; i += 1024) m = max(m, finite_mag(__builtin_bit_cast(unsigned, w[i] * fold_scale(bn, i / n))));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned sh[16];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  for (int k = threadIdx.x + 1; k < MODE_BN_ABSMAX_FLOATS; k += 1024) out[k] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = max(r, sh[k]);
+    out[0] = r;
+  }
+}
+
 }  // namespace
 
 namespace mode {
@@ -715,11 +751,15 @@ int conv3d_split_stat_partials() { return kNumCU; }  // partial pairs per channe
 
 int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, int flip,
                     hipStream_t st, const char* who, const mode_bn_epilogue* bn, float* stats, const float* acc_in, const float* amax_x,
-                    const float* amax_w) {
+                    const float* amax_w, float* amax_y) {
   const float* absmax = amax_x;  // (non-null: the fp16 arithmetic)
-  MODE_REQUIRE((amax_x == nullptr) == (amax_w == nullptr), MODE_ERR_BAD_ARG, "%s: both operand maxima, or neither", who);
+  // eval mode on the fp16 arithmetic (bn, amax_x, amax_y; no amax_w): the weights' maximum is that of the FOLDED weights, taken when they
+  // are packed and kept in the workspace behind the shifts -- the third piece's room is free there
+  const bool eval16 = absmax && bn;
+  MODE_REQUIRE(eval16 ? (!amax_w && amax_y && !stats && !acc_in) : ((amax_x == nullptr) == (amax_w == nullptr) && !amax_y), MODE_ERR_BAD_ARG,
+               "%s: both operand maxima, or neither (eval epilogue: the input's and the output's)", who);
   MODE_REQUIRE(!(acc_in && (bn || stats)), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue and no statistics", who);
-  MODE_REQUIRE(!(absmax && (bn || stats)), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no BatchNorm epilogue and no statistics", who);
+  MODE_REQUIRE(!(absmax && stats), MODE_ERR_UNSUPPORTED, "%s: the fp16 arithmetic has no statistics epilogue", who);
   SDims d;
   d.B = B; d.K = K; d.Co = rows; d.D = D; d.H = H; d.W = W;
   d.MT = cdiv(rows, 32);
@@ -732,7 +772,7 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   static const char* tall_env = getenv("MODE_SPLIT_TALL");  // (tuning override: 0 keeps the 8-row tile everywhere)
   const bool tall_ok = !tall_env || tall_env[0] != '0';
   d.TH = 8;
-  if (absmax && !acc_in && H % 16 == 0 && (long long)B * cdiv(D, TD) * (H / 8) * cdiv(W, 32) >= 4ll * kNumCU && tall_ok)
+  if (absmax && !acc_in && !bn && H % 16 == 0 && (long long)B * cdiv(D, TD) * (H / 8) * cdiv(W, 32) >= 4ll * kNumCU && tall_ok)
     d.TH = 16;
   d.nWt = cdiv(W, 32);
   d.nHt = cdiv(H, d.TH);
@@ -740,6 +780,19 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   d.ntiles = B * d.nDt * d.nHt * d.nWt;
   const long long npack = (long long)d.MT * d.NCHUNK * NPAIR * 64;
   const int NP = absmax ? 2 : 3;
+  if (eval16) {
+    float* wmax = wpack + npack * NP * 4 + 32 * d.MT;  // (npack * 4 >= 3 584 floats of the third piece's room: MODE_BN_ABSMAX_FLOATS fit)
+    static_assert(NPAIR * 64 * 4 >= MODE_BN_ABSMAX_FLOATS + 64, "the folded weights' maximum does not fit behind the shifts");
+    if (mode::pack_needed()) {
+      hipLaunchKernelGGL(abs_max_folded_kernel, dim3(1), dim3(1024), 0, st, w, *bn, rows, K * 27, reinterpret_cast<unsigned*>(wmax));
+      hipLaunchKernelGGL(pack_w3d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT, d.NCHUNK,
+                         flip, 1, *bn, wmax);
+    }
+    int rc = mode::absmax_begin(amax_y, st, who);
+    if (rc != MODE_OK) return rc;
+    d.o0 = 0;
+    return launch_split<1>(x, wpack, y, d, d.MT, st, who, make_epi(bn, wpack + npack * NP * 4), nullptr, nullptr, amax_x, wmax, amax_y);
+  }
   if (mode::pack_needed()) {
     if (absmax)
       hipLaunchKernelGGL(pack_w3d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, d.MT, d.NCHUNK,

@@ -109,6 +109,7 @@ SIGNATURES = {
     'mode_abs_max': (_c_int, [_c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr]),
     'mode_abs_max_batch': (_c_int, [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'mode_conv3d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv3d_fwd_split_f16_bn': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_acc': (_c_int, [_c_ptr] * 5 + [_c_int] * 7 + [_c_ptr]),
@@ -160,7 +161,7 @@ SIGNATURES = {
     'mode_conv1x1_sigmoid_bwd': (_c_int, [_c_ptr] * 7 + [_c_int] + [_c_ptr] + [_c_int] * 2 + [ctypes.c_longlong, _c_ptr]),
 }
 
-ABI_VERSION = 30  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
+ABI_VERSION = 31  # MODE_HIP_ABI_VERSION of include/mode_hip.h this binding was written against
 _lib = None
 _lock = threading.Lock()
 

@@ -1384,6 +1384,9 @@ def _tag3(name, ci, co, stride, d, h, w):
 # Precision contract (include/mode_hip.h): an element keeps 22 significant bits down to ~2^-17 of its tensor's maximum, fewer below,
 # none below ~2^-39 of it; three bf16 pieces (CONV3D_S1_F16 = False, and every inference call) keep 24 bits for every element.
 CONV3D_S1_F16 = True
+# ... and of an INFERENCE forward (conv3d_bn_eval: the folded-BatchNorm epilogues on the same arithmetic, the activations' maxima out of the
+# kernels' epilogues; mode_conv3d_fwd_split_f16_bn)
+CONV3D_EVAL_F16 = True
 
 
 BN_ABSMAX_FLOATS = 2064  # MODE_BN_ABSMAX_FLOATS of include/mode_hip.h: the buffer a tensor's maximum lives in
@@ -2353,7 +2356,17 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   flops = 2 * y.numel() * Ci * 27
   with torch.cuda.device_of(x), profiling.region(_tag3('conv3d_bn_eval', Ci, Co, stride, D, H, W), 4 * (x.numel() + y.numel() + w.numel()),
                                                  flops, x.device):
-    if stride == 1 and _split3d(Ci, Co, stride, False):
+    if stride == 1 and _split3d(Ci, Co, stride, False) and CONV3D_EVAL_F16:
+      # two fp16 pieces (round 6): the input's maximum is the tag the producing eval kernel left (this one: y's below), else a pass;
+      # the folded weights' maximum is taken inside the call, with the pack, and lives in the kept workspace
+      wp, reuse = _eval_wpack(bn, 'conv3d_fwd_split_f16_bn', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
+      ax = _tagged_abs_max(x)
+      ay = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=x.device)
+      with reuse:
+        check(lib().mode_conv3d_fwd_split_f16_bn(ptr(x), ptr(w), ptr(ax), ctypes.byref(e), ptr(y), ptr(ay), ptr(wp), B, Ci, D, H, W, Co,
+                                                 stream_of(x)), 'mode_conv3d_fwd_split_f16_bn')
+      y._mode_amax = (ay, y._version, y.data_ptr())
+    elif stride == 1 and _split3d(Ci, Co, stride, False):
       wp, reuse = _eval_wpack(bn, 'conv3d_fwd_split', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
       with reuse:
         check(lib().mode_conv3d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),

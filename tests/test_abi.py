@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 30
+  assert mode_hip.lib().mode_hip_abi_version() == mode_hip.ABI_VERSION == 31
 
 
 def test_maximum_buffer_size_matches_the_header():

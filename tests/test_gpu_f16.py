@@ -105,6 +105,82 @@ def test_the_16_row_tile_is_the_8_row_tile_bit_for_bit(f16_switch):
   assert torch.equal(y, y8)
 
 
+def _eval_bn3(C, seed):
+  bn = torch.nn.BatchNorm3d(C).to(DEV).eval()
+  r = np.random.RandomState(seed)
+  with torch.no_grad():
+    bn.weight.copy_(torch.from_numpy(r.uniform(0.5, 1.5, C).astype(np.float32)))
+    bn.bias.copy_(torch.from_numpy(r.standard_normal(C).astype(np.float32) * 0.3))
+    bn.running_mean.copy_(torch.from_numpy(r.standard_normal(C).astype(np.float32) * 0.5))
+    bn.running_var.copy_(torch.from_numpy(r.uniform(0.3, 2.0, C).astype(np.float32)))
+  return bn
+
+
+def _bn_eval64(bn, y, add, relu):
+  y = F.batch_norm(y.double(), bn.running_mean.double().cpu(), bn.running_var.double().cpu(), bn.weight.double().cpu(), bn.bias.double().cpu(),
+                   False, 0.0, bn.eps)
+  if add is not None:
+    y = y + add.double().cpu()
+  return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True), (False, False)])
+def test_eval_epilogues_on_two_fp16_pieces(case, relu, with_add, f16_switch, monkeypatch):
+  """Round 6 (mode_conv3d_fwd_split_f16_bn, functional.CONV3D_EVAL_F16): the stride-1 3-D layers of an INFERENCE forward on two fp16 pieces.
+  The BatchNorm scale is folded into the weights before they are scaled (their maximum is the folded weights'); the kernel leaves the
+  maximum of what it stored as the output's tag, so that a chain of such layers runs no maximum pass after its first input.
+  Against float64 at the bound of the training kernels, and against the three-piece result."""
+  passes = []
+  real = HF.abs_max
+  monkeypatch.setattr(HF, 'abs_max', lambda t: (passes.append(tuple(t.shape)), real(t))[1])
+  with torch.no_grad():
+    for ci, co, shape in ((32, 32, (2, 6, 20, 40)), (64, 64, (1, 5, 9, 33)), (16, 24, (1, 4, 8, 70))):
+      x = _case(case, ci, shape, 801)
+      w1, w2 = _rand((co, ci, 3, 3, 3), 802, 0.05), _rand((co, co, 3, 3, 3), 803, 0.05)
+      bn1, bn2 = _eval_bn3(co, 804), _eval_bn3(co, 805)
+      add = (_rand((shape[0], co) + shape[1:], 806) * float(x.abs().max()) * 0.1) if with_add else None
+      h64 = _bn_eval64(bn1, F.conv3d(x.double().cpu(), w1.double().cpu(), None, 1, 1), None, True)
+      want = _bn_eval64(bn2, F.conv3d(h64, w2.double().cpu(), None, 1, 1), add, relu)
+      got = {}
+      for f16 in (False, True):
+        HF.CONV3D_EVAL_F16 = f16
+        del passes[:]
+        h = HF.conv3d_bn_eval(x, w1, bn1, 1, None, True)
+        y = HF.conv3d_bn_eval(h, w2, bn2, 1, add, relu)
+        got[f16] = y
+        if f16:
+          assert passes == [tuple(x.shape)], passes  # the first input only: h carries the tag its kernel left
+          for t in (h, y):  # the tag is exactly the largest finite magnitude of the stored tensor
+            assert HF.abs_max_value(HF.known_abs_max(t)) == float(t[torch.isfinite(t)].abs().max()), case
+      scale = float(want.abs().max())
+      # (two layers deep: the first layer's error passes through the second's weights, |w2| * sqrt(27 co) ~ 1)
+      bound = 2.0**-22 * (27 * max(ci, co))**0.5 * 0.5 * max(scale, float(h64.abs().max()))  # (~6 x the errors recorded in round 6)
+      e16 = float((got[True].double().cpu() - want).abs().max())
+      eb = float((got[False].double().cpu() - want).abs().max())
+      print('%-24s %d->%d relu %d add %d: f16x3 %.2e  bf16x6 %.2e  bound %.2e' % (case, ci, co, relu, with_add, e16, eb, bound))
+      assert e16 <= bound, (case, ci, co, e16, bound)
+      assert e16 <= 2 * eb + bound / 4, (case, ci, co, e16, eb)
+  HF.CONV3D_EVAL_F16 = True
+
+
+def test_eval_f16_layers_propagate_nan_like_the_bf16_ones(f16_switch):
+  with torch.no_grad():
+    x = _rand((1, 32, 4, 8, 32), 811)
+    w = _rand((32, 32, 3, 3, 3), 812, 0.05)
+    bn = _eval_bn3(32, 813)
+    x[0, 3, 2, 4, 7] = float('nan')
+    for f16 in (False, True):
+      HF.CONV3D_EVAL_F16 = f16
+      y = HF.conv3d_bn_eval(x, w, bn, 1, None, True)
+      near = y[0, :, 1:4, 3:6, 6:9]
+      assert bool(torch.isnan(near).all()), f16
+      assert int(torch.isnan(y).sum()) == near.numel() and not bool(torch.isinf(y).any()), f16
+      if f16:  # the maximum is over the finite values: the next layer's scale fits them
+        assert HF.abs_max_value(HF.known_abs_max(y)) == float(y[torch.isfinite(y)].abs().max())
+  HF.CONV3D_EVAL_F16 = True
+
+
 def test_abs_max_is_exact_and_order_independent():
   x = _rand((3, 1000003), 601)
   x[1, 77] = -123.5
