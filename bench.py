@@ -38,11 +38,14 @@ CONV3D_S1_F16 = True
 # Set from --no-sphere-f16.
 SPHERE_FWD_F16 = True
 CONV2D_F16 = True  # (functional.CONV2D_F16: forward and input gradient of the extractor's stride-1 3 x 3 layers; --no-conv2d-f16)
+CONV3D_EVAL_F16 = True  # (functional.CONV3D_EVAL_F16: the stride-1 3-D layers of an INFERENCE forward on the same arithmetic; --no-eval-f16)
 
 
 def _on_f16_path(label):
   import re
   if CONV3D_S1_F16 and re.match(r'(conv3d_fwd|conv3d_bwd_data|conv3d_bwd_weight)\[(\d+)->(\d+) s1 ', label) and not re.search(r'->1 ', label):
+    return True
+  if CONV3D_EVAL_F16 and re.match(r'conv3d_bn_eval\[(\d+)->(\d+) s1 ', label):
     return True
   m = re.match(r'sphere_conv_(fwd|bwd_data|bwd_weight)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
   if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
@@ -102,6 +105,8 @@ def parse():
   ap.add_argument('--no-conv3d-f16', action='store_true',
                   help='A/B: the stride-1 3-D layers of the training step on three bf16 pieces / six MFMAs per product like every other split '
                        'kernel, instead of two fp16 pieces / three MFMAs with a power-of-two scale per operand tensor (functional.CONV3D_S1_F16)')
+  ap.add_argument('--no-eval-f16', action='store_true',
+                  help='A/B: the stride-1 3-D layers of an inference forward on three bf16 pieces (functional.CONV3D_EVAL_F16 = False)')
   ap.add_argument('--no-sphere-f16', action='store_true',
                   help='A/B: the windowed spherical forward and gradients of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
   ap.add_argument('--no-conv2d-f16', action='store_true',
@@ -210,9 +215,11 @@ def kernel_of(label, conv_arith, on_split=None):
     if split and stride == 2:
       return 'deconv3d_split_kernel' if name == 'conv3d_bwd_data' else 'conv3d_s2_split_kernel'
     if split:
-      if _on_f16_path(label):  # (<1,2,true,8> where a gradient is added in the store)
-        return 'conv3d_split_kernel<1,0,true,16>' if _tall_tile(label) else 'conv3d_split_kernel<1,0,true,8>'
-      return 'conv3d_split_kernel<1,0,false,8>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1,false,8>'  # (<1,2,false,8> with a residual)
+      if _on_f16_path(label) and name == 'conv3d_bn_eval':  # (<1,2,true,8,true> with a residual: always the 8-row tile)
+        return 'conv3d_split_kernel<1,1,true,16,true>' if _tall_tile(label) else 'conv3d_split_kernel<1,1,true,8,true>'
+      if _on_f16_path(label):  # (<1,2,true,8,false> where a gradient is added in the store)
+        return 'conv3d_split_kernel<1,0,true,16,false>' if _tall_tile(label) else 'conv3d_split_kernel<1,0,true,8,false>'
+      return 'conv3d_split_kernel<1,0,false,8,false>' if name != 'conv3d_bn_eval' else 'conv3d_split_kernel<1,1,false,8,false>'  # (<1,2,false,8,false> with a residual)
     return 'conv3d_kernel' if not (name == 'conv3d_bwd_data' and stride == 2) else 'deconv3d_kernel'
   if name == 'conv3d_bwd_weight':
     if re.search(r'->1 ', label):
@@ -705,7 +712,8 @@ def main():
   HF.CONV3D_BN_STATS = bool(args.fused_bn_stats)
   HF.CLASSIF_FUSED = not args.no_fused_classif
   HF.GRAD_CARRIERS = not args.no_grad_carriers
-  global CONV3D_S1_F16, SPHERE_FWD_F16, CONV2D_F16
+  global CONV3D_S1_F16, SPHERE_FWD_F16, CONV2D_F16, CONV3D_EVAL_F16
+  CONV3D_EVAL_F16 = HF.CONV3D_EVAL_F16 = not args.no_eval_f16 and args.conv_arith == 'bf16x6'
   HF.CONV2D_F16 = not args.no_conv2d_f16
   CONV2D_F16 = HF.CONV2D_F16 and args.conv_arith == 'bf16x6' and args.mode == 'train'
   CONV3D_S1_F16 = HF.CONV3D_S1_F16 = not args.no_conv3d_f16 and args.conv_arith == 'bf16x6'

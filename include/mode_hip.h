@@ -292,6 +292,10 @@ int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, 
  * applied on the way out (bn->add must be NULL). */
 int mode_cost_conv_assemble_fwd_bn(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, int B, int Co, int D,
                                    int H, int W, mode_stream_t stream);
+/* ... and (ABI 31) the maximum buffer of `out` filled on the way (MODE_BN_ABSMAX_FLOATS floats, zeroed by the call; NULL = the plain call):
+ * the operand maximum of the next layer when it runs on the fp16 arithmetic in eval mode (mode_conv3d_fwd_split_f16_bn). */
+int mode_cost_conv_assemble_fwd_bn_amax(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, float* out_absmax, int B,
+                                        int Co, int D, int H, int W, mode_stream_t stream);
 
 /* Weight gradient of the regular 3x3 Conv2d layers of the extractor (nn.Conv2d inside convbn, models/submodule.py:15-17):
  * stride 1, padding = dilation in {1, 2}, no bias, groups 1.  gw (Co, Ci, 3, 3) (+)= sum_{b,h,w} gy[b,o,h,w] * x[b,c,h+(kh-1)*dil,
@@ -401,6 +405,10 @@ int mode_conv3d_split_supported(int Ci, int Co, int stride, int which /* 0 forwa
  * eval-mode BatchNorm (+ residual) (+ ReLU) epilogue as in mode_conv3d_fwd_split. */
 int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilogue* bn /* optional: eval-mode fold, NULL = plain */,
                              float* y, float* wpack, int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream);
+/* (ABI 31) the same with the maximum buffer of y out of the eval epilogue (out_absmax: MODE_BN_ABSMAX_FLOATS floats, zeroed by the call;
+ * needs bn; NULL = the plain call) -- see mode_conv3d_fwd_split_f16_bn. */
+int mode_conv3d_fwd_s2_split_amax(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* out_absmax, float* wpack, int B,
+                                  int Ci, int D, int H, int W, int Co, mode_stream_t stream);
 
 /* The transposed convolution (ConvTranspose3d k3 s2 p1 op1, hourglass conv5 / conv6, mode_disparity.py:23-25) and the input gradient
  * of the stride-2 convolution -- one operator -- on the split-bf16 kernel of csrc/conv3d_split_deconv.hip: input channels of the
@@ -451,6 +459,8 @@ int mode_conv3d_bwd_data_split_acc(const float* gy, const float* w, const float*
 int mode_deconv3d_split_bn_supported(int Cin, int Cout);
 int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin, int D,
                                int H, int W, int Cout, mode_stream_t stream);
+int mode_deconv3d_fwd_split_bn_amax(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* out_absmax /* as above */,
+                                    float* wpack, int B, int Cin, int D, int H, int W, int Cout, mode_stream_t stream);
 int mode_conv3d_bwd_data_s2_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W, int Co,
                                   mode_stream_t stream);
 /* The weight gradient of the stride-2 convolution on the split-bf16 kernel of csrc/conv3d_split_wgrad_s2.hip (the gradients cuDNN

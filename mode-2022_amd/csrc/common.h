@@ -96,6 +96,7 @@ struct Epi {
   const float* shift;
   const float* add;
   int relu;
+  unsigned* amax;  // eval mode: where the kernel leaves the largest finite magnitude it stored (bn_internal.h's buffer, zeroed), or null
 };
 
 inline Epi make_epi(const mode_bn_epilogue* e, const float* shift) {
@@ -103,6 +104,7 @@ inline Epi make_epi(const mode_bn_epilogue* e, const float* shift) {
   r.shift = e ? shift : nullptr;
   r.add = e ? e->add : nullptr;
   r.relu = e ? e->relu : 0;
+  r.amax = nullptr;
   return r;
 }
 

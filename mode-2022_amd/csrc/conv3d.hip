@@ -615,13 +615,20 @@ extern "C" int mode_conv3d_fwd_split_stats(const float* x, const float* w, float
 
 // Stride-2 forward on the split-bf16 kernel of conv3d_split_s2.hip (also the input gradient of the transposed convolution, with
 // w = its (Cin, Cout, 27) weight read as (Co = Cin, Ci = Cout)); needs mode_conv3d_split_supported(Ci, Co, 2, 0) == 1.
-extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
-                                        int D, int H, int W, int Co, mode_stream_t stream) {
+extern "C" int mode_conv3d_fwd_s2_split_amax(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* out_absmax, float* wpack,
+                                             int B, int Ci, int D, int H, int W, int Co, mode_stream_t stream) {
   const char* who = "mode_conv3d_fwd_s2_split";
   int rc = check_conv_args(x, w, y, wpack, B, Ci, D, H, W, Co, 2, who, true);
   if (rc == MODE_OK && bn) rc = mode::check_bn(bn, who);
-  if (rc != MODE_OK || B == 0) return rc;
-  return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who, bn);
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(!out_absmax || bn, MODE_ERR_BAD_ARG, "%s: the output maximum comes out of the eval epilogue (bn is NULL)", who);
+  if (B == 0) return out_absmax ? mode::absmax_begin(out_absmax, mode::as_stream(stream), who) : MODE_OK;
+  return mode::conv3d_s2_split(x, w, y, wpack, B, Ci, Co, D, H, W, mode::as_stream(stream), who, bn, out_absmax);
+}
+
+extern "C" int mode_conv3d_fwd_s2_split(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Ci,
+                                        int D, int H, int W, int Co, mode_stream_t stream) {
+  return mode_conv3d_fwd_s2_split_amax(x, w, bn, y, nullptr, wpack, B, Ci, D, H, W, Co, stream);
 }
 
 // Input gradient of the stride-2 convolution = the transposed convolution of gy with the same (Co, Ci, 27) weight, on the split-bf16
@@ -712,13 +719,19 @@ extern "C" int mode_deconv3d_fwd_split(const float* x, const float* w, float* y,
 
 extern "C" int mode_deconv3d_split_bn_supported(int Cin, int Cout) { return mode::deconv3d_split_bn_supported(Cin, Cout) ? 1 : 0; }
 
-extern "C" int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin,
-                                          int D, int H, int W, int Cout, mode_stream_t stream) {
+extern "C" int mode_deconv3d_fwd_split_bn_amax(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* out_absmax,
+                                               float* wpack, int B, int Cin, int D, int H, int W, int Cout, mode_stream_t stream) {
   const char* who = "mode_deconv3d_fwd_split_bn";
   int rc = check_conv_args(x, w, y, wpack, B, Cin, D, H, W, Cout, 1, who);
   if (rc == MODE_OK) rc = mode::check_bn(bn, who);
-  if (rc != MODE_OK || B == 0) return rc;
-  return mode::deconv3d_split(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who, bn);
+  if (rc != MODE_OK) return rc;
+  if (B == 0) return out_absmax ? mode::absmax_begin(out_absmax, mode::as_stream(stream), who) : MODE_OK;
+  return mode::deconv3d_split(x, w, y, wpack, B, Cin, Cout, D, H, W, mode::as_stream(stream), who, bn, nullptr, out_absmax);
+}
+
+extern "C" int mode_deconv3d_fwd_split_bn(const float* x, const float* w, const mode_bn_epilogue* bn, float* y, float* wpack, int B, int Cin,
+                                          int D, int H, int W, int Cout, mode_stream_t stream) {
+  return mode_deconv3d_fwd_split_bn_amax(x, w, bn, y, nullptr, wpack, B, Cin, D, H, W, Cout, stream);
 }
 
 extern "C" int mode_conv3d_bwd_data_split(const float* gy, const float* w, float* gx, float* wpack, int B, int Ci, int D, int H, int W,

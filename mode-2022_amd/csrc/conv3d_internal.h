@@ -45,7 +45,8 @@ int abs_max_batch(const float* const* ptrs, const long long* sizes, int n, float
 bool conv3d_s2_split_supported(int K, int rows);
 size_t conv3d_s2_split_wpack_floats(int K, int rows);
 int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
-                    const char* who, const mode_bn_epilogue* bn = nullptr);  // bn: optional folded-BatchNorm epilogue (eval mode)
+                    const char* who, const mode_bn_epilogue* bn = nullptr, float* amax_y = nullptr);
+// bn: optional folded-BatchNorm epilogue (eval mode); amax_y (with bn): receives the maximum buffer of the stored output
 
 // conv3d_split_deconv.hip: ConvTranspose3d k3 s2 p1 op1 (= the input gradient of the stride-2 convolution) on the same arithmetic;
 // x (B, K, D, H, W), w (K, Co, 27) -> y (B, Co, 2D, 2H, 2W); K a multiple of 8, 2..64 output channels.
@@ -53,8 +54,9 @@ bool deconv3d_split_supported(int K, int Co);
 bool deconv3d_split_bn_supported(int K, int Co);  // with the folded-BatchNorm epilogue: whole 32-channel output tiles
 size_t deconv3d_split_wpack_floats(int K, int Co);
 int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int Co, int D, int H, int W, hipStream_t st,
-                   const char* who, const mode_bn_epilogue* bn = nullptr, const float* acc_in = nullptr);
-// bn: optional folded-BatchNorm epilogue (eval mode); acc_in: y = deconv(x) + acc_in (whole 32-channel output tiles, not with bn)
+                   const char* who, const mode_bn_epilogue* bn = nullptr, const float* acc_in = nullptr, float* amax_y = nullptr);
+// bn: optional folded-BatchNorm epilogue (eval mode; amax_y: receives the maximum buffer of the stored output); acc_in: y = deconv(x) +
+// acc_in (whole 32-channel output tiles, not with bn)
 
 // conv3d_split_wgrad.hip: split-K partials of the stride-1 weight gradient on the split-bf16 matrix path, written in the layout of
 // conv3d.hip's weight-gradient kernels (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT) void conv3d_split_kernel(const float* __restric
   constexpr int NP = Arith<F16>::NP, NTERM = Arith<F16>::NTERM, BUF = buf_of<F16, TH_>();
   using Ge = Geo<TH_>;
   constexpr int TH = Ge::TH, IH = Ge::IH, ITEMS = Ge::ITEMS, KIT = Ge::KIT, PIECE = Ge::PIECE, R = Ge::R, RB = Ge::RB;
-  static_assert(EPI == 0 || TH_ == 8, "the tall tile exists for the plain store only");
+  static_assert(EPI == 0 || EPI == 1 || TH_ == 8, "the tall tile exists for the plain store and the shift epilogue (a residual's values do not fit)");
   // (F16) x is multiplied by sx when it is staged, the weights by sw when they are packed, the sums by 1 / (sx sw) when they are stored
   const float sx = F16 ? f16_scale_of(mode::absmax_load(amax_x)) : 1.f;
   const float unscale = F16 ? (1.f / sx) * (1.f / f16_scale_of(mode::absmax_load(amax_w))) : 1.f;
@@ -620,6 +620,7 @@ int launch_split(const float* x, const float* wpack, float* y, SDims d, int nblo
   if (amax_x && amax_y) {  // eval mode on the two-piece fp16 arithmetic: folded BatchNorm (+ residual) (+ ReLU), the output's maximum
     MODE_REQUIRE(!stats && epi.shift, MODE_ERR_BAD_ARG, "%s: the output maximum belongs to the eval epilogues", who);
     if (epi.add) MODE_SPLIT_LAUNCH_TH(2, true, 8, true, nullptr, nullptr)
+    if (d.TH == 16) MODE_SPLIT_LAUNCH_TH(1, true, 16, true, nullptr, nullptr)
     MODE_SPLIT_LAUNCH_TH(1, true, 8, true, nullptr, nullptr)
   }
   if (amax_x) {  // the two-piece fp16 arithmetic: plain store and the accumulate form (training)
@@ -767,12 +768,12 @@ int conv3d_s1_split(const float* x, const float* w, float* y, float* wpack, int 
   MODE_REQUIRE(conv3d_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the split kernel", who,
                rows, K);
   MODE_REQUIRE((long long)rows * D * H * W < (1ll << 31), MODE_ERR_UNSUPPORTED, "%s: a sample of the output has 2^31 elements or more", who);
-  // The 16-row tile: the plain-store fp16 instantiation, where the rows divide and the 8-row tiling has at least four rounds of
+  // The 16-row tile: the plain-store fp16 instantiation (and the eval epilogue without a residual), where the rows divide and the 8-row tiling has at least four rounds of
   // tiles per output block (half as many tiles: fewer would leave CUs without one)
   static const char* tall_env = getenv("MODE_SPLIT_TALL");  // (tuning override: 0 keeps the 8-row tile everywhere)
   const bool tall_ok = !tall_env || tall_env[0] != '0';
   d.TH = 8;
-  if (absmax && !acc_in && !bn && H % 16 == 0 && (long long)B * cdiv(D, TD) * (H / 8) * cdiv(W, 32) >= 4ll * kNumCU && tall_ok)
+  if (absmax && !acc_in && !(bn && bn->add) && H % 16 == 0 && (long long)B * cdiv(D, TD) * (H / 8) * cdiv(W, 32) >= 4ll * kNumCU && tall_ok)
     d.TH = 16;
   d.nWt = cdiv(W, 32);
   d.nHt = cdiv(H, d.TH);

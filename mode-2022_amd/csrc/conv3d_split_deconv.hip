@@ -20,6 +20,7 @@
 
 #include <type_traits>
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
   for (int r = 0; r < 2; ++r) rowpos[r] = (2 * rp + r) * IW + (lane & 31);
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
   const uint4* wpm = wp + m * mstride + set * (7 * 192);
+  unsigned out_mag = 0;  // (EPI) the largest finite magnitude this thread stored: the next eval layer's operand maximum (epi.amax)
   float shv[16];  // (EPI) the folded shifts of this lane's 16 output channels, once per kernel
   if (EPI) {
 #pragma unroll
@@ -408,7 +410,9 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
               asm volatile("" : "+v"(y1), "+v"(y2a), "+v"(y2b));
               auto fin = [&](float v, float res) {
                 v = (v + shv[qq]) + res;
-                return epi.relu ? relu_nan(v) : v;
+                v = epi.relu ? relu_nan(v) : v;
+                out_mag = max(out_mag, mode::absmax_mag(v));
+                return v;
               };
               y[y1] = fin(acc[r][0][qq], r1[qq]);
               *reinterpret_cast<float2*>(y + y2a) = make_float2(fin(acc[r][1][qq], r2a[qq].x), fin(acc[r][2][qq], r2a[qq].y));
@@ -434,6 +438,12 @@ __global__ __launch_bounds__(NT, 1) void deconv3d_split_kernel(const float* __re
     run(std::integral_constant<int, 0>{});
   else
     run(std::integral_constant<int, 1>{});
+  if (EPI) {
+    if (epi.amax) {  // (uniform)
+      __syncthreads();
+      mode::absmax_block_commit(out_mag, epi.amax, reinterpret_cast<unsigned*>(sm));
+    }
+  }
 }
 
 }  // namespace
@@ -450,7 +460,8 @@ bool deconv3d_split_supported(int K, int Co) { return Co > 1 && Co <= 64 && K > 
 
 // x (B, K, D, H, W), w (K, Co, 27) -> y (B, Co, 2D, 2H, 2W)
 int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int Co, int D, int H, int W, hipStream_t st,
-                   const char* who, const mode_bn_epilogue* bn, const float* acc_in) {
+                   const char* who, const mode_bn_epilogue* bn, const float* acc_in, float* amax_y) {
+  MODE_REQUIRE(!amax_y || bn, MODE_ERR_BAD_ARG, "%s: the output maximum belongs to the eval epilogue", who);
   MODE_REQUIRE(!(acc_in && bn), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue", who);
   MODE_REQUIRE(deconv3d_split_supported(K, Co), MODE_ERR_UNSUPPORTED, "%s: %d output / %d input channels not supported by the split kernel", who, Co, K);
   MODE_REQUIRE(!(bn || acc_in) || deconv3d_split_bn_supported(K, Co), MODE_ERR_UNSUPPORTED,
@@ -476,6 +487,11 @@ int deconv3d_split(const float* x, const float* w, float* y, float* wpack, int B
   const bool with_epi = bn || acc_in;
   const uint4* wq = reinterpret_cast<const uint4*>(wpack);
   int rc;
+  if (amax_y) {
+    rc = mode::absmax_begin(amax_y, st, who);
+    if (rc != MODE_OK) return rc;
+    epi.amax = reinterpret_cast<unsigned*>(amax_y);
+  }
 #define MODE_DC_LAUNCH(MTV, EPIV)                                                                                     \
   {                                                                                                                   \
     rc = mode::allow_lds(deconv3d_split_kernel<MTV, EPIV>, LDS_BYTES, who);                                           \

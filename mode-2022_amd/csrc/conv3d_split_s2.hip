@@ -22,6 +22,7 @@
 // Persistent workgroups, XCD-contiguous tile ranges, weights split and packed once per launch: conv3d_split.hip.
 #include "common.h"
 
+#include "bn_internal.h"
 #include "conv3d_internal.h"
 
 namespace {
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
   f32x16 acc[TH];
 #pragma unroll
   for (int r = 0; r < TH; ++r) acc[r] = (f32x16){0};
+  unsigned out_mag = 0;  // (EPI) the largest finite magnitude this thread stored: the next eval layer's operand maximum (epi.amax)
   const int half = lane >> 5;
   const int rowpos = lane & 31;  // origin of this lane's output voxel of row 0 (row r: + 2 r IW; TD = 1: plane 0)
   const long long mstride = (long long)d.NCHUNK * NPAIR * 192;
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
                   if (EPI) {
                     v = (v + shv[q8]) + res[q8];
                     v = epi.relu ? relu_nan(v) : v;
+                    out_mag = max(out_mag, mode::absmax_mag(v));
                   }
                   yb[o * oDHW] = v;
                 }
@@ -398,6 +401,12 @@ __global__ __launch_bounds__(NT, PHASED ? 2 : 1) void conv3d_s2_split_kernel(con
       lds_barrier();
     }
   }
+  if (EPI) {
+    if (epi.amax) {  // (uniform)
+      __syncthreads();
+      mode::absmax_block_commit(out_mag, epi.amax, reinterpret_cast<unsigned*>(sm));
+    }
+  }
 }
 
 }  // namespace
@@ -410,7 +419,8 @@ size_t conv3d_s2_split_wpack_floats(int K, int rows) { return (size_t)cdiv(rows,
 bool conv3d_s2_split_supported(int K, int rows) { return rows > 32 && rows <= 64 && K > 0 && K % 8 == 0; }
 
 int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int D, int H, int W, hipStream_t st,
-                    const char* who, const mode_bn_epilogue* bn) {
+                    const char* who, const mode_bn_epilogue* bn, float* amax_y) {
+  MODE_REQUIRE(!amax_y || bn, MODE_ERR_BAD_ARG, "%s: the output maximum belongs to the eval epilogue", who);
   MODE_REQUIRE(conv3d_s2_split_supported(K, rows), MODE_ERR_UNSUPPORTED, "%s: %d output / %d reduction channels not supported by the stride-2 split kernel",
                who, rows, K);
   MODE_REQUIRE((long long)D * H * W < (1ll << 26), MODE_ERR_UNSUPPORTED, "%s: volume beyond the 32-bit lane offsets of the split kernel", who);  // (8 planes < 2^31 bytes)
@@ -423,7 +433,12 @@ int conv3d_s2_split(const float* x, const float* w, float* y, float* wpack, int 
   const long long npack = (long long)MT * d.NCHUNK * NPAIR * 64;
   if (mode::pack_needed()) hipLaunchKernelGGL(pack_w3d_s2_split, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wpack), rows, K, MT, d.NCHUNK,
                      bn ? 1 : 0, bn ? *bn : mode_bn_epilogue());
-  const Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  Epi epi = make_epi(bn, wpack + npack * 3 * 4);
+  if (amax_y) {
+    int rc = mode::absmax_begin(amax_y, st, who);
+    if (rc != MODE_OK) return rc;
+    epi.amax = reinterpret_cast<unsigned*>(amax_y);
+  }
   constexpr size_t LDS1 = (size_t)BUF * sizeof(uint4) + (size_t)RED_FLOATS * sizeof(float);  // 65 536 B: two workgroups per CU
   auto kern = epi.shift ? conv3d_s2_split_kernel<true, true> : conv3d_s2_split_kernel<true, false>;
   int rc = mode::allow_lds(kern, LDS1, who);

@@ -12,6 +12,8 @@
 // HBM-bound: the forward writes B*Co*D*H*W floats once (9 LDS reads per element), the adjoint reads them once.
 #include "common.h"
 
+#include "bn_internal.h"
+
 namespace {
 
 constexpr int NT = 128;
@@ -23,8 +25,11 @@ constexpr int NTB = 256;  // the backward assembly: two halves of 128 threads sh
 template <bool EPI>
 __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float* __restrict__ R, const float* __restrict__ T,
                                                                     float* __restrict__ out, int B, int Co, int D, int H, int W,
-                                                                    mode_bn_epilogue bn) {
+                                                                    mode_bn_epilogue bn, unsigned* __restrict__ amax) {
+  // (EPI) amax: the maximum buffer of `out` for the fp16 arithmetic of the next eval layer (bn_internal.h; zeroed by the host), or null
   extern __shared__ float sm[];
+  __shared__ unsigned amax_sh[NT / 64];
+  unsigned out_mag = 0;
   float* Rl = sm;                  // [9][W+2], columns -1 and W are zeros
   float* Tl = sm + 9 * (W + 2);    // [9][W]
   int t0 = blockIdx.x;
@@ -66,9 +71,13 @@ __global__ __launch_bounds__(NT) void cost_conv_assemble_fwd_kernel(const float*
       if (EPI) {
         acc = fmaf(acc, sc, sh);
         if (bn.relu) acc = relu_nan(acc);
+        out_mag = max(out_mag, mode::absmax_mag(acc));
       }
       ob[(long long)d * HW + w] = acc;
     }
+  }
+  if (EPI) {
+    if (amax) mode::absmax_block_commit(out_mag, amax, amax_sh);  // (uniform)
   }
 }
 
@@ -183,15 +192,16 @@ int check_args(const void* a, const void* b, const void* c, int B, int Co, int D
 namespace {
 template <bool EPI>
 int assemble_fwd(const float* R, const float* T, float* out, int B, int Co, int D, int H, int W, mode_stream_t stream,
-                 const mode_bn_epilogue& bn, const char* who) {
+                 const mode_bn_epilogue& bn, const char* who, float* out_absmax = nullptr) {
   int rc = check_args(R, T, out, B, Co, D, H, W, who);
+  if (rc == MODE_OK && out_absmax) rc = mode::absmax_begin(out_absmax, mode::as_stream(stream), who);
   if (rc != MODE_OK || B == 0) return rc;
   const size_t lds = (size_t)(9 * (W + 2) + 9 * W) * sizeof(float);
   MODE_REQUIRE(lds <= 160 * 1024, MODE_ERR_UNSUPPORTED, "%s: W = %d too wide for the row buffers", who, W);
   rc = mode::allow_lds(cost_conv_assemble_fwd_kernel<EPI>, lds, who);
   if (rc != MODE_OK) return rc;
   hipLaunchKernelGGL(cost_conv_assemble_fwd_kernel<EPI>, dim3(B * Co * H), dim3(NT), lds, mode::as_stream(stream), R, T, out, B, Co, D,
-                     H, W, bn);
+                     H, W, bn, reinterpret_cast<unsigned*>(out_absmax));
   return mode::check_launch(who);
 }
 }  // namespace
@@ -201,13 +211,18 @@ extern "C" int mode_cost_conv_assemble_fwd(const float* R, const float* T, float
   return assemble_fwd<false>(R, T, out, B, Co, D, H, W, stream, mode_bn_epilogue(), "mode_cost_conv_assemble_fwd");
 }
 
-extern "C" int mode_cost_conv_assemble_fwd_bn(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, int B, int Co,
-                                              int D, int H, int W, mode_stream_t stream) {
+extern "C" int mode_cost_conv_assemble_fwd_bn_amax(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, float* out_absmax,
+                                                   int B, int Co, int D, int H, int W, mode_stream_t stream) {
   const char* who = "mode_cost_conv_assemble_fwd_bn";
   int rc = mode::check_bn(bn, who);
   if (rc != MODE_OK) return rc;
   MODE_REQUIRE(bn->add == nullptr, MODE_ERR_UNSUPPORTED, "%s: no residual input on this layer", who);
-  return assemble_fwd<true>(R, T, out, B, Co, D, H, W, stream, *bn, who);
+  return assemble_fwd<true>(R, T, out, B, Co, D, H, W, stream, *bn, who, out_absmax);
+}
+
+extern "C" int mode_cost_conv_assemble_fwd_bn(const float* R, const float* T, const mode_bn_epilogue* bn, float* out, int B, int Co,
+                                              int D, int H, int W, mode_stream_t stream) {
+  return mode_cost_conv_assemble_fwd_bn_amax(R, T, bn, out, nullptr, B, Co, D, H, W, stream);
 }
 
 extern "C" int mode_cost_conv_assemble_bwd(const float* gout, float* gR, float* gT, int B, int Co, int D, int H, int W,

@@ -85,6 +85,7 @@ SIGNATURES = {
     'mode_conv_stem_bwd_weight': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_conv_assemble_fwd_bn': (_c_int, [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr]),
+    'mode_cost_conv_assemble_fwd_bn_amax': (_c_int, [_c_ptr] * 5 + [_c_int] * 5 + [_c_ptr]),
     'mode_cost_conv_assemble_bwd': (_c_int, [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr]),
     'mode_conv3d_wpack_bytes': (_c_size, [_c_int] * 2),
     'mode_conv3d_fwd': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     'mode_conv3d_split_supported': (_c_int, [_c_int] * 4),
     'mode_conv3d_fwd_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_fwd_s2_split': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv3d_fwd_s2_split_amax': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_deconv3d_split_supported': (_c_int, [_c_int] * 2),
     'mode_deconv3d_fwd_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_deconv3d_split_bn_supported': (_c_int, [_c_int] * 2),
@@ -114,6 +116,7 @@ SIGNATURES = {
     'mode_conv3d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv3d_bwd_data_split_acc': (_c_int, [_c_ptr] * 5 + [_c_int] * 7 + [_c_ptr]),
     'mode_deconv3d_fwd_split_bn': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
+    'mode_deconv3d_fwd_split_bn_amax': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_s2_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv3d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),

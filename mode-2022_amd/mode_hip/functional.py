@@ -2344,6 +2344,20 @@ def _epilogue(bn, add, relu, out):
   return e, keep
 
 
+def _eval_amax_buffer(device):
+  """The buffer an eval kernel leaves its output's maximum in -- or None (the plain call) when no eval layer runs on the fp16 arithmetic."""
+  return torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=device) if (CONV3D_EVAL_F16 and CONV_ARITH == 'bf16x6') else None
+
+
+def _optr(t):
+  return ptr(t) if t is not None else None
+
+
+def _tag_amax(y, ay):
+  if ay is not None:
+    y._mode_amax = (ay, y._version, y.data_ptr())
+
+
 def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
   """relu?(bn(conv3d(x, w, stride, padding 1)) [+ add]) with bn in eval mode; Co > 1."""
   require_gpu(x, w)
@@ -2373,9 +2387,11 @@ def conv3d_bn_eval(x, w, bn, stride=1, add=None, relu=False):
               'mode_conv3d_fwd_split')
     elif stride == 2 and _split3d(Ci, Co, stride, False) and D * H * W < 2**26:
       wp, reuse = _eval_wpack(bn, 'conv3d_fwd_s2_split', w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
+      ay = _eval_amax_buffer(x.device)  # (the stride-1 layer behind it runs on the fp16 arithmetic: its operand maximum out of this epilogue)
       with reuse:
-        check(lib().mode_conv3d_fwd_s2_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
-              'mode_conv3d_fwd_s2_split')
+        check(lib().mode_conv3d_fwd_s2_split_amax(ptr(x), ptr(w), ctypes.byref(e), ptr(y), _optr(ay), ptr(wp), B, Ci, D, H, W, Co, stream_of(x)),
+              'mode_conv3d_fwd_s2_split_amax')
+      _tag_amax(y, ay)
     else:
       wp, reuse = _eval_wpack(bn, 'conv3d_fwd_bn s%d' % stride, w, lib().mode_conv3d_wpack_bytes(Ci, Co) // 4, x.device)
       with reuse:
@@ -2398,9 +2414,11 @@ def deconv3d_bn_eval(x, w, bn, add=None, relu=False):
       # (round 5: the split kernel with its own epilogue instantiation -- residual values of four channels requested ahead of their
       # stores; round 3 had measured it no faster than the fp32 kernel with one load next to every store)
       wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_split_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
+      ay = _eval_amax_buffer(x.device)
       with reuse:
-        check(lib().mode_deconv3d_fwd_split_bn(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Cin, D, H, W, Cout, stream_of(x)),
-              'mode_deconv3d_fwd_split_bn')
+        check(lib().mode_deconv3d_fwd_split_bn_amax(ptr(x), ptr(w), ctypes.byref(e), ptr(y), _optr(ay), ptr(wp), B, Cin, D, H, W, Cout,
+                                                    stream_of(x)), 'mode_deconv3d_fwd_split_bn_amax')
+      _tag_amax(y, ay)
     else:
       wp, reuse = _eval_wpack(bn, 'deconv3d_fwd_bn', w, lib().mode_conv3d_wpack_bytes(Cin, Cout) // 4, x.device)
       with reuse:
@@ -2540,6 +2558,8 @@ def cost_conv_bn_eval(ref, tgt, weight, d4, bn, relu=True):
   out = torch.empty((B, Co, d4, H, W), dtype=R.dtype, device=R.device)
   e, keep = _epilogue(bn, None, relu, out)
   with torch.cuda.device_of(R), profiling.region('cost_conv_assemble_fwd', 4 * (R.numel() + T.numel() + out.numel()), 0, R.device):
-    check(lib().mode_cost_conv_assemble_fwd_bn(ptr(R), ptr(T), ctypes.byref(e), ptr(out), B, Co, d4, H, W, stream_of(R)),
-          'mode_cost_conv_assemble_fwd_bn')
+    ay = _eval_amax_buffer(R.device)
+    check(lib().mode_cost_conv_assemble_fwd_bn_amax(ptr(R), ptr(T), ctypes.byref(e), ptr(out), _optr(ay), B, Co, d4, H, W, stream_of(R)),
+          'mode_cost_conv_assemble_fwd_bn_amax')
+    _tag_amax(out, ay)
   return out

@@ -42,6 +42,14 @@ def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
   for name in ('conv3d_fwd', 'conv3d_bwd_data', 'conv3d_bwd_weight'):
     assert bench.label_peak(name + '[32->32 s1 48x256x128]', 'bf16x6', _split) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('conv3d_fwd[32->32 s1 48x256x128]', 'f32', _split) == ('mfma', 157.3, 'TFLOP/s')
+  # (round 6: the eval label too, unless --no-eval-f16; the stride-2 eval layers stay on three bf16 pieces)
+  monkeypatch.setattr(bench, 'CONV3D_EVAL_F16', True)
+  assert bench.label_peak('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
+  assert bench.label_peak('conv3d_bn_eval[32->64 s2 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  monkeypatch.setattr(bench, 'TIMED_BATCH', 1)
+  assert bench.kernel_of('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1,true,16,true>'
+  assert bench.kernel_of('conv3d_bn_eval[64->64 s1 12x64x32]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1,true,8,true>'
+  monkeypatch.setattr(bench, 'CONV3D_EVAL_F16', False)
   assert bench.label_peak('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
   assert bench.label_peak('conv3d_fwd[32->64 s2 48x256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
   monkeypatch.setattr(bench, 'SPHERE_FWD_F16', True)  # (functional.SPHERE_FWD_F16: the windowed spherical forward of the training step too)
@@ -58,13 +66,13 @@ def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
   # (round 6: the plain-store fp16 instantiation has a 16-row tile where the volume has >= 4 x 256 of the 8-row tiles -- its own device kernel)
   monkeypatch.setattr(bench, 'TIMED_BATCH', 2)
   monkeypatch.delenv('MODE_SPLIT_TALL', raising=False)
-  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,16>'
-  assert bench.kernel_of('conv3d_bwd_data[64->64 s1 24x128x64]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8>'
+  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,16,false>'
+  assert bench.kernel_of('conv3d_bwd_data[64->64 s1 24x128x64]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8,false>'
   monkeypatch.setattr(bench, 'TIMED_BATCH', 1)
-  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,16>'
-  assert bench.kernel_of('conv3d_fwd[32->32 s1 16x64x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8>'
-  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x252x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8>'
-  assert bench.kernel_of('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1,false,8>'
+  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,16,false>'
+  assert bench.kernel_of('conv3d_fwd[32->32 s1 16x64x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8,false>'
+  assert bench.kernel_of('conv3d_fwd[32->32 s1 48x252x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8,false>'
+  assert bench.kernel_of('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1,false,8,false>'
   assert bench.kernel_of('conv3d_bwd_weight[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_bww_split_kernel'
   k = _kern()
   f = bench.blended_mfma_fraction(k, 'bf16x6', _split)
@@ -99,7 +107,7 @@ def test_by_kernel_groups_labels_of_one_device_kernel():
   k = _kern()
   k['conv3d_bwd_data[32->32 s1 48x256x128]'] = dict(k['conv3d_fwd[32->32 s1 48x256x128]'])
   g = bench.by_kernel(k, 'bf16x6', _split)
-  a = g['conv3d_split_kernel<1,0,false,8>']
+  a = g['conv3d_split_kernel<1,0,false,8,false>']
   assert a['calls'] == 24 and abs(a['total_ms'] - 2 * 12 * 0.80) < 1e-9 and len(a['labels']) == 2
   assert abs(a['need_s'] / (a['total_ms'] * 1e-3) - (173.95e9 / (2500e12 / 6)) / 0.80e-3) < 1e-9
   assert g['conv3d_bww_split_kernel']['calls'] == 6 and g['conv3d_kernel']['calls'] == 6
@@ -118,7 +126,7 @@ def test_roofline_block_names_the_dominant_device_kernel():
     v['bytes_per_call'] = v['bytes'] / v['calls']
     v['flops_per_call'] = v['flops'] / v['calls']
   r = bench.roofline_block(k, 'bf16x6', 2, 2, 'test', _split)
-  assert r['kernel'] == 'conv3d_split_kernel<1,0,false,8>' and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
+  assert r['kernel'] == 'conv3d_split_kernel<1,0,false,8,false>' and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
   # launches, as rocprofv3 counts them (a 64-channel stride-1 layer is one launch with two y-slices)
   assert r['calls'] == 30 and abs(r['avg_ms'] - (24 * 0.80 + 6 * 0.40) / 30) < 1e-12 and abs(r['ms_per_step'] - (24 * 0.80 + 6 * 0.40) / 2) < 1e-12
   flops, sec = 24 * 173.95e9 + 6 * 86.97e9, (24 * 0.80 + 6 * 0.40) * 1e-3

@@ -561,6 +561,84 @@ def test_whole_model_with_an_activation_tensor_spanning_2_to_the_20(f16_switch, 
     assert e16 <= 1e-3 and e3 <= 1e-3 and same <= 2e-4
 
 
+def test_eval_forward_on_fp16_pieces_runs_no_maximum_pass_and_keeps_the_north_star(f16_switch, monkeypatch):
+  """Round 6: the stride-1 3-D layers of an INFERENCE forward run on two fp16 pieces (functional.CONV3D_EVAL_F16).  Their operand maxima come
+  out of the epilogues of the eval kernels that wrote the operands -- the cost-volume assembly, the stride-1 / stride-2 / transposed 3-D
+  kernels -- so that a forward of the model contains no maximum pass over an activation; the eval-mode output (train_disparity.py:167-170:
+  the last prediction) stays within the north_star's 1e-3 px of the float64 oracle and within 1e-4 px of the three-piece arithmetic."""
+  import recipe
+  import models
+  from oracle import mode_ref
+  maxdisp, H, W, B = 16, 64, 32, 1
+  left, right = recipe.recipe_images(B, H, W, 32)
+  # running statistics that fit the data (the recipe's state has the initial 0 / 1, under which the untrained network saturates): one
+  # training-mode forward with momentum 1 leaves the batch statistics there
+  HF.CONV3D_EVAL_F16 = False
+  net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
+  net.load_state_dict(recipe.recipe_state_wc(recipe.load_manifest(), 31))
+  for m in net.modules():
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+      m.momentum = 1.0
+  net.train()
+  with torch.no_grad():
+    net(left.to(DEV), right.to(DEV))
+  state = {n: v.detach().cpu().clone() for n, v in net.state_dict().items()}
+  pos = mode_ref.sphere_position(H // 4, W // 4, 'Cassini')
+  P64 = {n: (v.double() if v.is_floating_point() else v.clone()) for n, v in state.items()}
+  with torch.no_grad():
+    want = mode_ref.mode_disparity(P64, left.double(), right.double(), maxdisp, pos, False)
+  want = (want[-1] if isinstance(want, (list, tuple)) else want).numpy()
+  passes = []
+  real = HF.abs_max
+  monkeypatch.setattr(HF, 'abs_max', lambda t: (passes.append(tuple(t.shape)), real(t))[1])
+  entries = []
+  real_check = HF.check
+  monkeypatch.setattr(HF, 'check', lambda rc, name: (entries.append(name), real_check(rc, name))[1])
+  got = {}
+  for f16 in (True, False):
+    HF.CONV3D_EVAL_F16 = f16
+    net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
+    net.load_state_dict({n: v.clone() for n, v in state.items()})
+    net.eval()
+    del passes[:], entries[:]
+    with torch.no_grad():
+      out = net(left.to(DEV), right.to(DEV))
+    got[f16] = (out[-1] if isinstance(out, (list, tuple)) else out).cpu().numpy().astype(np.float64)
+    if f16:
+      assert passes == [], passes
+      assert entries.count('mode_conv3d_fwd_split_f16_bn') == 12 and 'mode_conv3d_fwd_split' not in entries, sorted(set(entries))
+    else:
+      assert 'mode_conv3d_fwd_split_f16_bn' not in entries
+  e16, e3 = np.abs(got[True] - want).max(), np.abs(got[False] - want).max()
+  print('eval forward: |fp16 pieces - float64| %.2e px   |bf16 pieces - float64| %.2e px   |fp16 - bf16| %.2e px; the prediction spans %.2f .. %.2f px' %
+        (e16, e3, np.abs(got[True] - got[False]).max(), want.min(), want.max()))
+  assert want.max() - want.min() > 0.5  # (not a saturated, constant prediction)
+  assert e16 <= 1e-3 and e3 <= 1e-3 and np.abs(got[True] - got[False]).max() <= 1e-4
+  HF.CONV3D_EVAL_F16 = True
+
+
+def test_eval_kernels_leave_exactly_their_outputs_maximum(f16_switch):
+  """The tags of the stride-2, transposed and cost-volume-assembly eval kernels (mode_conv3d_fwd_s2_split_amax, mode_deconv3d_fwd_split_bn_amax,
+  mode_cost_conv_assemble_fwd_bn_amax): exactly the largest finite magnitude of the tensor they wrote, with ReLU and with a residual."""
+  with torch.no_grad():
+    x = _rand((1, 32, 6, 12, 40), 821)
+    y = HF.conv3d_bn_eval(x, _rand((64, 32, 3, 3, 3), 822, 0.05), _eval_bn3(64, 823), 2, None, True)
+    assert HF.abs_max_value(HF.known_abs_max(y)) == float(y.abs().max()) > 0
+    z = HF.deconv3d_bn_eval(y, _rand((64, 32, 3, 3, 3), 824, 0.05), _eval_bn3(32, 825), x * 3.0, False)
+    assert tuple(z.shape) == tuple(x.shape) and HF.abs_max_value(HF.known_abs_max(z)) == float(z.abs().max()) > 0
+    z2 = HF.deconv3d_bn_eval(y, _rand((64, 64, 3, 3, 3), 826, 0.05), _eval_bn3(64, 827), None, True)
+    assert HF.abs_max_value(HF.known_abs_max(z2)) == float(z2.abs().max()) > 0
+    ref, tgt = _rand((1, 32, 16, 24), 828), _rand((1, 32, 16, 24), 829)
+    w0 = _rand((32, 64, 3, 3, 3), 830, 0.05)
+    if HF.cost_conv_supported(ref, 8, 32):
+      c = HF.cost_conv_bn_eval(ref, tgt, w0, 8, _eval_bn3(32, 831), relu=True)
+      assert HF.abs_max_value(HF.known_abs_max(c)) == float(c.abs().max()) > 0
+    HF.CONV3D_EVAL_F16 = False  # the three-piece arithmetic asks for no maxima: the plain entries, no tags
+    y = HF.conv3d_bn_eval(x, _rand((64, 32, 3, 3, 3), 822, 0.05), _eval_bn3(64, 823), 2, None, True)
+    assert HF.known_abs_max(y) is None
+  HF.CONV3D_EVAL_F16 = True
+
+
 def test_weight_maxima_from_one_launch_are_the_per_layer_ones(f16_switch, monkeypatch):
   """functional.weight_maxima: inside ModeDisparity.forward every convolution weight's maximum comes from ONE mode_abs_max_batch launch
   instead of a fill + a pass per layer.  Same buffers' values, hence the same bits in every prediction and gradient as with the table
