@@ -47,6 +47,8 @@ def _on_f16_path(label):
     return True
   if CONV3D_EVAL_F16 and re.match(r'conv3d_bn_eval\[(\d+)->(\d+) s1 ', label):
     return True
+  if CONV3D_EVAL_F16 and re.match(r'conv2d_bn_eval\[', label):  # (functional.CONV2D_EVAL_F16: the same switch in this script)
+    return True
   m = re.match(r'sphere_conv_(fwd|bwd_data|bwd_weight)\[(\d+)->(\d+) ', label)  # (the windowed 3x3 gnomonic layers: kernel_of below)
   if SPHERE_FWD_F16 and m and int(m.group(3)) % 128 == 0 and int(m.group(2)) % 16 == 0:
     return True
@@ -106,7 +108,7 @@ def parse():
                   help='A/B: the stride-1 3-D layers of the training step on three bf16 pieces / six MFMAs per product like every other split '
                        'kernel, instead of two fp16 pieces / three MFMAs with a power-of-two scale per operand tensor (functional.CONV3D_S1_F16)')
   ap.add_argument('--no-eval-f16', action='store_true',
-                  help='A/B: the stride-1 3-D layers of an inference forward on three bf16 pieces (functional.CONV3D_EVAL_F16 = False)')
+                  help='A/B: the stride-1 3-D and 3 x 3 layers of an inference forward on three bf16 pieces (functional.CONV3D_EVAL_F16 = CONV2D_EVAL_F16 = False)')
   ap.add_argument('--no-sphere-f16', action='store_true',
                   help='A/B: the windowed spherical forward and gradients of the training step on three bf16 pieces (functional.SPHERE_FWD_F16 = SPHERE_BWD_F16 = False)')
   ap.add_argument('--no-conv2d-f16', action='store_true',
@@ -321,7 +323,11 @@ def roofline_block(kern, conv_arith, batch, profile_steps, timed_over, on_split=
   time, the finer-grained view the per-label table `kernels` is keyed by."""
   steps = max(profile_steps, 1)
   groups = by_kernel(kern, conv_arith, on_split)
-  kdom = max(groups, key=lambda k: groups[k]['total_ms'])
+  # the dominant DEVICE KERNEL: groups named a+b are operators made of several kernels (BatchNorm backward = statistics + apply), which
+  # rocprofv3 --stats lists as the separate rows they are; the largest of those operators is reported beside it (`largest_operator`)
+  single = [k for k in groups if '+' not in k] or list(groups)
+  kdom = max(single, key=lambda k: groups[k]['total_ms'])
+  kop = max(groups, key=lambda k: groups[k]['total_ms'])
   g = groups[kdom]
   g_sec = g['total_ms'] * 1e-3
   heavy = max(g['labels'], key=lambda k: kern[k]['total_ms'])
@@ -340,6 +346,8 @@ def roofline_block(kern, conv_arith, batch, profile_steps, timed_over, on_split=
           'by_label': {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                        'traffic': calibrated_traffic(dom, batch, conv_arith, on_split), 'algorithmic_per_launch': per_launch,
                        'avg_ms': a['avg_ms'], 'calls': a['calls']},
+          'largest_operator': {'kernels': kop, 'bound': groups[kop]['bound'], 'frac': groups[kop]['need_s'] / (groups[kop]['total_ms'] * 1e-3),
+                               'ms_per_step': groups[kop]['total_ms'] / steps, 'launches_per_step': groups[kop]['calls'] / steps},
           'timed_over': timed_over}
 
 
@@ -714,6 +722,7 @@ def main():
   HF.GRAD_CARRIERS = not args.no_grad_carriers
   global CONV3D_S1_F16, SPHERE_FWD_F16, CONV2D_F16, CONV3D_EVAL_F16
   CONV3D_EVAL_F16 = HF.CONV3D_EVAL_F16 = not args.no_eval_f16 and args.conv_arith == 'bf16x6'
+  HF.CONV2D_EVAL_F16 = CONV3D_EVAL_F16
   HF.CONV2D_F16 = not args.no_conv2d_f16
   CONV2D_F16 = HF.CONV2D_F16 and args.conv_arith == 'bf16x6' and args.mode == 'train'
   CONV3D_S1_F16 = HF.CONV3D_S1_F16 = not args.no_conv3d_f16 and args.conv_arith == 'bf16x6'
@@ -952,7 +961,7 @@ def main():
     if args.value_1gpu:
       out['scaling_vs_1gpu'] = {'value_1gpu': args.value_1gpu, 'efficiency': out['value'] / (world * args.value_1gpu)}
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline_subprocess(args)
+      out['cpu_baseline'] = cpu_baseline_subprocess(args, 'eval' if args.mode == 'eval' else 'train')  # (the metric's own pass)
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()

@@ -499,6 +499,11 @@ int mode_conv2d_fwd_split_f16(const float* x, const float* w, const float* amax_
                               int H, int W, int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc, float* gx,
                                    float* wpack, int B, int Ci, int H, int W, int Co, int dilation, mode_stream_t stream);
+/* INFERENCE on that arithmetic (ABI 31), the 2-D twin of mode_conv3d_fwd_split_f16_bn: mode_conv2d_fwd_split with a non-NULL epilogue on two
+ * fp16 pieces; the folded weights' maximum is taken inside with the pack and kept in wpack (mode_conv2d_wpack_bytes has the room since
+ * ABI 31), amax_x = the input's maximum buffer, amax_y = the stored output's (zeroed and filled by the call: the next layer's amax_x). */
+int mode_conv2d_fwd_split_f16_bn(const float* x, const float* w, const float* amax_x, const mode_bn_epilogue* bn, float* y, float* amax_y,
+                                 float* wpack, int B, int Ci, int H, int W, int Co, int dilation, mode_stream_t stream);
 int mode_conv2d_bwd_weight_split(const float* gy, const float* x, float* gw, float* workspace, int B, int Ci, int H, int W, int Co,
                                  int dilation, int accumulate, mode_stream_t stream);
 /* ... on the two-piece fp16 arithmetic (mode_conv2d_fwd_split_f16): amax_g / amax_x = the maximum buffers of gy and of x. */

@@ -292,6 +292,19 @@ extern "C" int mode_conv2d_fwd_split_f16(const float* x, const float* w, const f
                                 nullptr, amax_x, amax_w);
 }
 
+// Inference on the same arithmetic (ABI 31; mode_conv3d_fwd_split_f16_bn is the 3-D twin): folded BatchNorm (+ residual) (+ ReLU), the
+// folded weights' maximum taken inside with the pack, the stored output's maximum left in amax_y for the next layer.
+extern "C" int mode_conv2d_fwd_split_f16_bn(const float* x, const float* w, const float* amax_x, const mode_bn_epilogue* bn, float* y,
+                                            float* amax_y, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
+                                            mode_stream_t stream) {
+  const char* who = "mode_conv2d_fwd_split_f16_bn";
+  MODE_REQUIRE(bn, MODE_ERR_BAD_ARG, "%s: null BatchNorm epilogue", who);
+  int rc = mode::check_bn(bn, who);
+  if (rc != MODE_OK) return rc;
+  MODE_REQUIRE(amax_x && amax_y, MODE_ERR_BAD_ARG, "%s: null maximum buffer", who);
+  return mode::conv2d_split_run(x, w, y, wpack, B, Ci, Co, H, W, dilation, 0, mode::as_stream(stream), who, bn, nullptr, amax_x, nullptr, amax_y);
+}
+
 extern "C" int mode_conv2d_bwd_data_split_f16(const float* gy, const float* w, const float* amax_g, const float* amax_w, const float* acc,
                                               float* gx, float* wpack, int B, int Ci, int H, int W, int Co, int dilation,
                                               mode_stream_t stream) {

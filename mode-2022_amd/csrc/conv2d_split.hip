@@ -132,13 +132,13 @@ __global__ void pack_w2d_split(const float* __restrict__ w, uint4* __restrict__ 
 }
 
 // EPI: 0 plain store; 1 folded-BatchNorm shift (+ ReLU); 2 shift + residual add (+ ReLU)
-// F16 (EPI 0 and 2 -- the training step): two fp16 pieces, three MFMAs per product; x is scaled when a tile is staged, the accumulators
-// unscaled in front of the epilogue's additions.  The LDS and weight-fragment layouts keep room for three pieces.
+// F16 (EPI 0 and 2 -- the training step; EPI 1 and 2 with epi.amax -- inference since round 6): two fp16 pieces, three MFMAs
+// per product; x is scaled when a tile is staged, the accumulators unscaled in front of the epilogue's additions.  The LDS and
+// weight-fragment layouts keep room for three pieces.  epi.amax (eval): the largest finite magnitude the kernel stored goes there.
 template <int MT, int TH, int DIL, int EPI, bool F16 = false>
 __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, float* __restrict__ y,
                                                           S2Dims d, Epi epi, const float* __restrict__ amax_x,
                                                           const float* __restrict__ amax_w) {
-  static_assert(!(F16 && EPI == 1), "the fp16 arithmetic has no folded-BatchNorm epilogue");
   constexpr int NP = F16 ? 2 : 3;  // pieces per value
   float sx = 1.f, unscale = 1.f;
   if (F16) {
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
   constexpr bool ADD_AHEAD = EPI == 2 && MT * R * 16 <= 64;
   float shiftv[MT][16], addv[ADD_AHEAD ? MT : 1][ADD_AHEAD ? R : 1][16];
   const float relu_floor = (EPI && epi.relu) ? 0.f : -__builtin_inff();
+  unsigned out_mag = 0;  // (EPI on fp16: the output's maximum for the next eval layer, epi.amax)
   // (the variant with the residual in its epilogue has no registers left for 32 shifts: kept across the tap loop they were spilled, and
   // every store of the epilogue waited for its reload; it requests them with the residual values instead)
   constexpr bool SHIFT_LATE = EPI == 2 && !ADD_AHEAD;
@@ -428,7 +429,9 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
               float v = F16 ? acc[m][r][qq] * unscale : acc[m][r][qq];
               if (EPI) v += SHIFT_LATE ? shl[qq] : shiftv[m][qq];
               if (EPI == 2) v += ADD_AHEAD ? addv[ADD_AHEAD ? m : 0][ADD_AHEAD ? r : 0][qq] : res[qq];
-              yb[(long long)o * HWi + sp] = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+              const float vo = (EPI && v < relu_floor) ? relu_floor : v;  // (NaN passes, as in torch.relu and the fp32 kernels)
+              if (EPI && F16) out_mag = max(out_mag, mode::absmax_mag(vo));
+              yb[(long long)o * HWi + sp] = vo;
             };
             if (d.o0 + m * 32 + 32 <= d.Co) {
 #pragma unroll
@@ -450,6 +453,32 @@ __global__ __launch_bounds__(NT) void conv2d_split_kernel(const float* __restric
     ch = ch_next;
     lds_barrier();
   }
+  if (EPI && F16) {
+    if (epi.amax) {  // (uniform)
+      __syncthreads();
+      mode::absmax_block_commit(out_mag, epi.amax, reinterpret_cast<unsigned*>(sm));
+    }
+  }
+}
+
+// The maximum buffer of an eval layer's FOLDED weights w[o][..] * scale[o] (what pack_w2d_split splits when fold == 1), one block: word 0
+// the value, the slots zero.  n = elements per output row.  (conv3d_split.hip has the same kernel for its layers.)
+__global__ __launch_bounds__(1024) void abs_max_folded2d_kernel(const float* __restrict__ w, mode_bn_epilogue bn, int rows, int n,
+                                                                unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < rows * n; i += 1024) m = max(m, mode::absmax_mag(w[i] * fold_scale(bn, i / n)));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned sh[16];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  for (int k = threadIdx.x + 1; k < MODE_BN_ABSMAX_FLOATS; k += 1024) out[k] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = max(r, sh[k]);
+    out[0] = r;
+  }
 }
 
 template <int MT, int TH, int DIL>
@@ -468,7 +497,7 @@ int launch2(const float* x, const uint4* wp, float* y, S2Dims d, hipStream_t st,
   if (epi.shift && epi.add) {
     if (amax_x) MODE_C2D_LAUNCH(2, true) else MODE_C2D_LAUNCH(2, false)
   } else if (epi.shift) {
-    MODE_C2D_LAUNCH(1, false)
+    if (amax_x) MODE_C2D_LAUNCH(1, true) else MODE_C2D_LAUNCH(1, false)
   } else {
     if (amax_x) MODE_C2D_LAUNCH(0, true) else MODE_C2D_LAUNCH(0, false)
   }
@@ -491,7 +520,8 @@ int launch_tile(const float* x, const uint4* wp, float* y, const S2Dims& d, int 
 namespace mode {
 
 size_t conv2d_split_wpack_floats(int K, int rows) {
-  return (size_t)cdiv(rows, 32) * cdiv(K, 16) * 9 * 3 * 64 * 4 + 32 * (size_t)cdiv(rows, 32);
+  // fragments + the folded BatchNorm shifts + (eval on the fp16 arithmetic) the maximum buffer of the folded weights
+  return (size_t)cdiv(rows, 32) * cdiv(K, 16) * 9 * 3 * 64 * 4 + 32 * (size_t)cdiv(rows, 32) + MODE_BN_ABSMAX_FLOATS;
 }
 
 bool conv2d_split_supported(int K, int rows, int dilation) {
@@ -502,16 +532,19 @@ bool conv2d_split_supported(int K, int rows, int dilation) {
 // rows = output channels of THIS GEMM (Co forward, Ci for the input gradient), K = its reduction channels; flip 0 / 1 as pack_w2d_split
 int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
                      hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in, const float* amax_x,
-                     const float* amax_w) {
+                     const float* amax_w, float* amax_y) {
   MODE_REQUIRE(B >= 0 && K > 0 && rows > 0 && H > 0 && W > 0, MODE_ERR_BAD_ARG, "%s: non-positive size", who);
-  MODE_REQUIRE((amax_x == nullptr) == (amax_w == nullptr) && !(amax_x && bn), MODE_ERR_BAD_ARG,
-               "%s: the fp16 arithmetic takes both operand maxima and no BatchNorm epilogue", who);
+  // eval mode on the fp16 arithmetic (bn, amax_x, amax_y; no amax_w): the weights' maximum is the FOLDED weights', taken with the pack
+  // and kept in the workspace behind the shifts (conv3d_split.hip)
+  const bool eval16 = amax_x && bn;
+  MODE_REQUIRE(eval16 ? (!amax_w && amax_y && !acc_in && flip == 0) : ((amax_x == nullptr) == (amax_w == nullptr) && !amax_y), MODE_ERR_BAD_ARG,
+               "%s: the fp16 arithmetic takes both operand maxima (eval epilogue: the input's and the output's)", who);
   MODE_REQUIRE(!(acc_in && bn), MODE_ERR_BAD_ARG, "%s: the accumulate form takes no BatchNorm epilogue", who);
   MODE_REQUIRE(!acc_in || acc_in != y, MODE_ERR_BAD_ARG, "%s: acc must not be the output tensor", who);
   MODE_REQUIRE(conv2d_split_supported(K, rows, dilation), MODE_ERR_UNSUPPORTED,
                "%s: %d output / %d reduction channels, dilation %d not covered by the split kernel", who, rows, K, dilation);
   MODE_REQUIRE((long long)std::max(K, rows) * H * W < (1ll << 29), MODE_ERR_UNSUPPORTED, "%s: a sample larger than 2^29 elements", who);
-  if (B == 0) return MODE_OK;
+  if (B == 0) return amax_y ? mode::absmax_begin(amax_y, st, who) : MODE_OK;
   MODE_REQUIRE(x && w && y && wpack, MODE_ERR_BAD_ARG, "%s: null pointer", who);
   S2Dims d;
   d.B = B; d.K = K; d.Co = rows; d.H = H; d.W = W;
@@ -520,8 +553,13 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
   const int MT = cdiv(rows, 32);
   const long long npack = (long long)MT * d.NCHUNK * 9 * 64;
   uint4* wp = reinterpret_cast<uint4*>(wpack);
+  float* wmax = wpack + npack * 3 * 4 + 32 * MT;  // (eval16)
+  if (eval16) amax_w = wmax;
   if (mode::pack_needed()) {
-    if (amax_x)
+    if (eval16) {
+      hipLaunchKernelGGL(abs_max_folded2d_kernel, dim3(1), dim3(1024), 0, st, w, *bn, rows, K * 9, reinterpret_cast<unsigned*>(wmax));
+      hipLaunchKernelGGL(pack_w2d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, 1, *bn, wmax);
+    } else if (amax_x)
       hipLaunchKernelGGL(pack_w2d_split<true>, dim3(cdiv(npack, 256)), dim3(256), 0, st, w, wp, rows, K, MT, d.NCHUNK, flip, acc_in ? 2 : 0,
                          mode_bn_epilogue(), amax_w);
     else
@@ -533,6 +571,11 @@ int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int
     epi.shift = wpack + npack * 3 * 4;
     epi.add = acc_in;
     epi.relu = 0;
+  }
+  if (amax_y) {
+    int rc = mode::absmax_begin(amax_y, st, who);
+    if (rc != MODE_OK) return rc;
+    epi.amax = reinterpret_cast<unsigned*>(amax_y);
   }
   // two output-channel tiles per workgroup (64 channels); the layer's 64-channel blocks are the y-slices of ONE launch (round 6; a
   // launch per block before), an odd 32-channel block at the end a launch of its own

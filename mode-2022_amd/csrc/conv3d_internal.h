@@ -83,7 +83,9 @@ bool conv2d_split_supported(int K, int rows, int dilation);
 size_t conv2d_split_wpack_floats(int K, int rows);
 int conv2d_split_run(const float* x, const float* w, float* y, float* wpack, int B, int K, int rows, int H, int W, int dilation, int flip,
                      hipStream_t st, const char* who, const mode_bn_epilogue* bn, const float* acc_in = nullptr,
-                     const float* amax_x = nullptr, const float* amax_w = nullptr);  // (maxima: the two-piece fp16 arithmetic)  // acc_in: y = conv(x) + acc_in
+                     const float* amax_x = nullptr, const float* amax_w = nullptr, float* amax_y = nullptr);
+// acc_in: y = conv(x) + acc_in.  amax_x / amax_w: the two-piece fp16 arithmetic.  With bn (eval): amax_x and amax_y (the stored output's
+// maximum, out), no amax_w -- the folded weights' maximum is taken with the pack and kept in wpack.
 
 // conv2d_split_wgrad.hip: split-K partials of the 3x3 Conv2d weight gradient on the split-bf16 path, in the layout of conv2d_wgrad.hip
 // (part[s][o / 32][c / 32][tap][o % 32][c % 32]); the caller reduces them.

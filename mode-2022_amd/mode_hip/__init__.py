@@ -97,6 +97,7 @@ SIGNATURES = {
     'mode_conv2d_bwd_data_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data_split_acc': (_c_int, [_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_fwd_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr]),
+    'mode_conv2d_fwd_split_f16_bn': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_data_split_f16': (_c_int, [_c_ptr] * 7 + [_c_int] * 6 + [_c_ptr]),
     'mode_conv2d_bwd_weight_split': (_c_int, [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr]),
     'mode_conv2d_bwd_weight_split_f16': (_c_int, [_c_ptr] * 6 + [_c_int] * 7 + [_c_ptr]),

@@ -1387,6 +1387,7 @@ CONV3D_S1_F16 = True
 # ... and of an INFERENCE forward (conv3d_bn_eval: the folded-BatchNorm epilogues on the same arithmetic, the activations' maxima out of the
 # kernels' epilogues; mode_conv3d_fwd_split_f16_bn)
 CONV3D_EVAL_F16 = True
+CONV2D_EVAL_F16 = True  # (the extractor's stride-1 3 x 3 layers of an inference forward: mode_conv2d_fwd_split_f16_bn)
 
 
 BN_ABSMAX_FLOATS = 2064  # MODE_BN_ABSMAX_FLOATS of include/mode_hip.h: the buffer a tensor's maximum lives in
@@ -2439,7 +2440,16 @@ def conv2d_bn_eval(x, w, bn, dilation=1, add=None, relu=False):
   flops = 2 * y.numel() * Ci * 9
   with torch.cuda.device_of(x), profiling.region('conv2d_bn_eval[%d->%d d%d %dx%d]' % (Ci, Co, dilation, H, W) if profiling.ENABLED
                                                  else 'conv2d_bn_eval', 4 * (x.numel() + y.numel() + w.numel()), flops, x.device):
-    if CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 0) == 1:
+    if CONV_ARITH == 'bf16x6' and CONV2D_EVAL_F16 and lib().mode_conv2d_split_supported(Ci, Co, dilation, 0) == 1:
+      # two fp16 pieces (round 6): the input's maximum from its producer's tag (this kernel's own, in the residual blocks) or a pass
+      wp, reuse = _eval_wpack(bn, 'conv2d_fwd_split_f16_bn', w, lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, x.device)
+      ax = _tagged_abs_max(x)
+      ay = torch.empty(BN_ABSMAX_FLOATS, dtype=torch.float32, device=x.device)
+      with reuse:
+        check(lib().mode_conv2d_fwd_split_f16_bn(ptr(x), ptr(w), ptr(ax), ctypes.byref(e), ptr(y), ptr(ay), ptr(wp), B, Ci, H, W, Co, dilation,
+                                                 stream_of(x)), 'mode_conv2d_fwd_split_f16_bn')
+      _tag_amax(y, ay)
+    elif CONV_ARITH == 'bf16x6' and lib().mode_conv2d_split_supported(Ci, Co, dilation, 0) == 1:
       wp, reuse = _eval_wpack(bn, 'conv2d_fwd_split', w, lib().mode_conv2d_wpack_bytes(Ci, Co) // 4, x.device)
       with reuse:
         check(lib().mode_conv2d_fwd_split(ptr(x), ptr(w), ctypes.byref(e), ptr(y), ptr(wp), B, Ci, H, W, Co, dilation, stream_of(x)),

@@ -61,7 +61,10 @@ def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
   assert bench.label_peak('conv2d_fwd[64->64 d1 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('conv2d_bwd_data[128->128 d2 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('conv2d_bwd_weight[128->128 d2 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
+  monkeypatch.setattr(bench, 'CONV3D_EVAL_F16', False)
   assert bench.label_peak('conv2d_bn_eval[64->64 d1 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 6.0, 'TFLOP/s')
+  monkeypatch.setattr(bench, 'CONV3D_EVAL_F16', True)  # (round 6: the eval forward's 3 x 3 layers on two fp16 pieces too)
+  assert bench.label_peak('conv2d_bn_eval[64->64 d1 256x128]', 'bf16x6', lambda l: True) == ('mfma', 2500.0 / 3.0, 'TFLOP/s')
   assert bench.label_peak('sphere_conv_fwd[32->288 256x128]', 'bf16x6', lambda l: False)[1] == 157.3  # (the integer-table layers: gather kernels)
   # (round 6: the plain-store fp16 instantiation has a 16-row tile where the volume has >= 4 x 256 of the 8-row tiles -- its own device kernel)
   monkeypatch.setattr(bench, 'TIMED_BATCH', 2)
@@ -72,6 +75,7 @@ def test_stride1_labels_are_priced_against_three_mfmas_per_product(monkeypatch):
   assert bench.kernel_of('conv3d_fwd[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,16,false>'
   assert bench.kernel_of('conv3d_fwd[32->32 s1 16x64x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8,false>'
   assert bench.kernel_of('conv3d_fwd[32->32 s1 48x252x128]', 'bf16x6', _split) == 'conv3d_split_kernel<1,0,true,8,false>'
+  monkeypatch.setattr(bench, 'CONV3D_EVAL_F16', False)
   assert bench.kernel_of('conv3d_bn_eval[32->32 s1 48x256x128]', 'bf16x6', lambda l: True) == 'conv3d_split_kernel<1,1,false,8,false>'
   assert bench.kernel_of('conv3d_bwd_weight[32->32 s1 48x256x128]', 'bf16x6', _split) == 'conv3d_bww_split_kernel'
   k = _kern()

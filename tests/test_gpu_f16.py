@@ -164,6 +164,59 @@ def test_eval_epilogues_on_two_fp16_pieces(case, relu, with_add, f16_switch, mon
   HF.CONV3D_EVAL_F16 = True
 
 
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True), (True, True)])
+def test_eval_epilogues_of_the_3x3_layers_on_two_fp16_pieces(case, relu, with_add, f16_switch, monkeypatch):
+  """mode_conv2d_fwd_split_f16_bn (functional.CONV2D_EVAL_F16): the 2-D twin of the test above -- two chained 3 x 3 layers (dilation 1 then 2,
+  as in the extractor's residual blocks), against float64 and against the three-piece arithmetic; one maximum pass (the first input), the
+  tags exact."""
+  passes = []
+  real = HF.abs_max
+  monkeypatch.setattr(HF, 'abs_max', lambda t: (passes.append(tuple(t.shape)), real(t))[1])
+
+  def bn2(C, seed):
+    b3 = _eval_bn3(C, seed)
+    b = torch.nn.BatchNorm2d(C).to(DEV).eval()
+    b.load_state_dict(b3.state_dict())
+    return b
+
+  def ref(bn, y, add, relu_):
+    y = F.batch_norm(y, bn.running_mean.double().cpu(), bn.running_var.double().cpu(), bn.weight.double().cpu(), bn.bias.double().cpu(), False, 0.0, bn.eps)
+    if add is not None:
+      y = y + add.double().cpu()
+    return torch.relu(y) if relu_ else y
+
+  with torch.no_grad():
+    for ci, co, shape in ((64, 64, (2, 40, 72)), (32, 128, (1, 19, 33)), (128, 96, (1, 24, 40))):
+      x = _case(case, ci, (shape[0], 2) + shape[1:], 841)[:, :, 1].contiguous()  # (plane 1 holds the outlier of that case)
+      w1, w2 = _rand((co, ci, 3, 3), 842, 0.05), _rand((co, co, 3, 3), 843, 0.05)
+      bn1, bn2_ = bn2(co, 844), bn2(co, 845)
+      add = (_rand((shape[0], co) + shape[1:], 846) * float(x.abs().max()) * 0.1) if with_add else None
+      h64 = ref(bn1, F.conv2d(x.double().cpu(), w1.double().cpu(), None, 1, 1), None, True)
+      want = ref(bn2_, F.conv2d(h64, w2.double().cpu(), None, 1, 2, 2), add, relu)
+      got = {}
+      for f16 in (False, True):
+        HF.CONV2D_EVAL_F16 = f16
+        del passes[:]
+        h = HF.conv2d_bn_eval(x, w1, bn1, 1, None, True)
+        y = HF.conv2d_bn_eval(h, w2, bn2_, 2, add, relu)
+        got[f16] = y
+        if f16:
+          assert passes == [tuple(x.shape)], passes
+          for t in (h, y):
+            assert HF.abs_max_value(HF.known_abs_max(t)) == float(t[torch.isfinite(t)].abs().max()), case
+        else:
+          assert passes == [] and HF.known_abs_max(y) is None
+      scale = max(float(want.abs().max()), float(h64.abs().max()))
+      bound = 2.0**-22 * (9 * max(ci, co))**0.5 * scale
+      e16 = float((got[True].double().cpu() - want).abs().max())
+      eb = float((got[False].double().cpu() - want).abs().max())
+      print('%-24s 3x3 %d->%d relu %d add %d: f16x3 %.2e  bf16x6 %.2e  bound %.2e' % (case, ci, co, relu, with_add, e16, eb, bound))
+      assert e16 <= bound, (case, ci, co, e16, bound)
+      assert e16 <= 2 * eb + bound / 4, (case, ci, co, e16, eb)
+  HF.CONV2D_EVAL_F16 = True
+
+
 def test_eval_f16_layers_propagate_nan_like_the_bf16_ones(f16_switch):
   with torch.no_grad():
     x = _rand((1, 32, 4, 8, 32), 811)
@@ -573,7 +626,6 @@ def test_eval_forward_on_fp16_pieces_runs_no_maximum_pass_and_keeps_the_north_st
   left, right = recipe.recipe_images(B, H, W, 32)
   # running statistics that fit the data (the recipe's state has the initial 0 / 1, under which the untrained network saturates): one
   # training-mode forward with momentum 1 leaves the batch statistics there
-  HF.CONV3D_EVAL_F16 = False
   net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
   net.load_state_dict(recipe.recipe_state_wc(recipe.load_manifest(), 31))
   for m in net.modules():
@@ -596,7 +648,7 @@ def test_eval_forward_on_fp16_pieces_runs_no_maximum_pass_and_keeps_the_north_st
   monkeypatch.setattr(HF, 'check', lambda rc, name: (entries.append(name), real_check(rc, name))[1])
   got = {}
   for f16 in (True, False):
-    HF.CONV3D_EVAL_F16 = f16
+    HF.CONV3D_EVAL_F16 = HF.CONV2D_EVAL_F16 = f16
     net = models.ModeDisparity(maxdisp, 'Sphere', H, W, 'Cassini').to(DEV)
     net.load_state_dict({n: v.clone() for n, v in state.items()})
     net.eval()
@@ -605,7 +657,11 @@ def test_eval_forward_on_fp16_pieces_runs_no_maximum_pass_and_keeps_the_north_st
       out = net(left.to(DEV), right.to(DEV))
     got[f16] = (out[-1] if isinstance(out, (list, tuple)) else out).cpu().numpy().astype(np.float64)
     if f16:
-      assert passes == [], passes
+      # (no pass over a 3-D activation; the extractor's 3 x 3 layers take a pass where their input comes from a kernel without the epilogue
+      # -- the stem, the 1 x 1 and the spherical layers -- on tensors of at most 67 MB)
+      assert [p for p in passes if len(p) == 5] == [], passes
+      assert len(passes) <= 12, passes
+      assert 'mode_conv2d_fwd_split_f16_bn' in entries and 'mode_conv2d_fwd_split' not in entries
       assert entries.count('mode_conv3d_fwd_split_f16_bn') == 12 and 'mode_conv3d_fwd_split' not in entries, sorted(set(entries))
     else:
       assert 'mode_conv3d_fwd_split_f16_bn' not in entries
@@ -614,7 +670,7 @@ def test_eval_forward_on_fp16_pieces_runs_no_maximum_pass_and_keeps_the_north_st
         (e16, e3, np.abs(got[True] - got[False]).max(), want.min(), want.max()))
   assert want.max() - want.min() > 0.5  # (not a saturated, constant prediction)
   assert e16 <= 1e-3 and e3 <= 1e-3 and np.abs(got[True] - got[False]).max() <= 1e-4
-  HF.CONV3D_EVAL_F16 = True
+  HF.CONV3D_EVAL_F16 = HF.CONV2D_EVAL_F16 = True
 
 
 def test_eval_kernels_leave_exactly_their_outputs_maximum(f16_switch):
