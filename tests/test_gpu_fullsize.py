@@ -7,6 +7,8 @@ layer -- oracle/conv_ref.py, 27 float64 GEMMs per layer, pinned against torch's 
 library.  Tolerances are fp32 accumulation round-off of sums of Ci * 27 (forward / input gradient) or D*H*W (weight gradient)
 terms, relative to the result's scale.
 """
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -199,3 +201,4 @@ def test_whole_model_at_config4_per_gpu_share():
   peak = torch.cuda.max_memory_allocated() / 2**30
   print('configs[4] per-GPU share: losses %s, peak memory %.1f GB' % (losses, peak))
   assert peak < 100.0
+

@@ -187,6 +187,30 @@ def test_eval_output_within_1e3_of_the_reference(golden, tag, arith):
   assert diff[stable].max() < 1e-3, diff[stable].max()
 
 
+def test_eval_output_at_config4_size_against_the_float64_oracle(golden):
+  """BASELINE configs[4] with an ORACLE ("per-GPU share exercised by property checks only"): the inference forward of one
+  2048 x 1024 pair at 256 disparities -- test_disparity.py:120-154 at the largest size the north_star names -- against
+  tests/golden/model_wc_config4_eval.npz, the float64 evaluation of oracle/mode_ref.py stored by make_golden_config4_eval.py (nine CPU
+  minutes on the box's host cores: stored, not recomputed per run; recomputed live once in round 6: max 2.8e-4 px).  Well-conditioned
+  recipe weights, running statistics from the fixture (the batch statistics of the pair, float32).  On the default arithmetic of an eval
+  forward (two fp16 pieces in the stride-1 3-D and 3 x 3 layers) AND on three bf16 pieces, under the no-vendor guard; every
+  stored pixel and every 8 x 8 block mean within the north_star's 1e-3 px."""
+  from mode_hip import no_vendor
+  from mode_hip import functional as HF
+  z = golden('model_wc_config4_eval.npz')
+  net, left, right, gt, seed = _load(z, bn_from_fixture=True)
+  net.eval()
+  keep = HF.CONV3D_EVAL_F16, HF.CONV2D_EVAL_F16
+  try:
+    for f16 in (True, False):
+      HF.CONV3D_EVAL_F16 = HF.CONV2D_EVAL_F16 = f16
+      with torch.no_grad(), no_vendor.no_vendor_arithmetic():
+        pred = net(left, right)
+      _check_pred('config4 eval pred3 [%s]' % ('two fp16 pieces' if f16 else 'three bf16 pieces'), pred, z, 'eval/pred3', 0.0)
+  finally:
+    HF.CONV3D_EVAL_F16, HF.CONV2D_EVAL_F16 = keep
+
+
 def test_config2_batch_of_two_at_full_size(golden, arith):
   """BASELINE configs[2]: 1024 x 512, 192 disparities, batch 2, forward + backward.  The reference fixture holds ONE pair (a CPU
   run of two costs minutes and ~50 GB); a batch of two copies of that pair has the same BatchNorm statistics as the pair alone, so
