@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/golden/model_wc_config4_eval.npz: the INFERENCE forward of one 2048 x 1024 pair at 256 disparities (BASELINE configs[4], the
+"""tests/golden/model_wc_config4_eval.npz: the INFERENCE forward (and the training-mode forward) of one 2048 x 1024 pair at 256 disparities (BASELINE configs[4], the
 per-GPU share of its batch) evaluated by the CPU oracle in float64.
 
 Unlike model_wc_{tiny,cfg1,full}.npz this fixture is NOT made by the imported reference: at this size its CPU run needs more memory
@@ -15,6 +15,7 @@ Same layout as the model_wc_* fixtures (recipe.fixture_state / fixture_inputs re
   cfg = [maxdisp, H, W, B, seed], wc = [mix, logit_scale], shift, sub
   bn/<key>            running statistics := the batch statistics of the same pair (one train-mode forward of the oracle with momentum 1),
                       rounded to float32 -- the values the eval pass below uses and the test loads
+  train/pred{1,2,3}(_block)  the three predictions of the TRAINING-mode forward (batch statistics; the calibration pass itself), as below
   eval/pred3          the eval-mode output (train_disparity.py:167-170: the last prediction), every `sub`-th pixel, float64
   eval/pred3_block    8 x 8 block means of ALL pixels (float64)
 """
@@ -61,9 +62,13 @@ def main():
   mode_ref.BN_MOMENTUM = 1.0  # the calibration pass of make_golden_wc.py: running statistics := this batch's
   try:
     with torch.no_grad():
-      mode_ref.mode_disparity(P, left.double(), right.double(), MAXDISP, pos, True)
+      tr = mode_ref.mode_disparity(P, left.double(), right.double(), MAXDISP, pos, True)
   finally:
     mode_ref.BN_MOMENTUM = keep
+  for i, p in enumerate(tr):  # the calibration pass IS a training-mode forward: its three predictions come for free
+    out['train/pred%d' % (i + 1)] = p[:, :, ::SUB, ::SUB].numpy().astype(np.float32)  # (float32: 8e-6 px at 128 px, and half the file)
+    out['train/pred%d_block' % (i + 1)] = F.avg_pool2d(p.double(), 8).numpy().astype(np.float32)
+  del tr
   print('calibration pass done (%.0f s)' % (time.time() - t0), flush=True)
   for k in list(P):
     if k.endswith('running_mean') or k.endswith('running_var'):

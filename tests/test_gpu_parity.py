@@ -194,7 +194,9 @@ def test_eval_output_at_config4_size_against_the_float64_oracle(golden):
   minutes on the box's host cores: stored, not recomputed per run; recomputed live once in round 6: max 2.8e-4 px).  Well-conditioned
   recipe weights, running statistics from the fixture (the batch statistics of the pair, float32).  On the default arithmetic of an eval
   forward (two fp16 pieces in the stride-1 3-D and 3 x 3 layers) AND on three bf16 pieces, under the no-vendor guard; every
-  stored pixel and every 8 x 8 block mean within the north_star's 1e-3 px."""
+  stored pixel and every 8 x 8 block mean within the north_star's 1e-3 px.  And the three predictions of the TRAINING-mode forward of the
+  same pair (the fixture's calibration pass) on a training step's arithmetic: the forward half of configs[4]'s step, same bound (its
+  backward stays on the size-independent properties of test_gpu_fullsize.py: a float64 backward of the oracle at this size needs > 300 GB)."""
   from mode_hip import no_vendor
   from mode_hip import functional as HF
   z = golden('model_wc_config4_eval.npz')
@@ -209,6 +211,13 @@ def test_eval_output_at_config4_size_against_the_float64_oracle(golden):
       _check_pred('config4 eval pred3 [%s]' % ('two fp16 pieces' if f16 else 'three bf16 pieces'), pred, z, 'eval/pred3', 0.0)
   finally:
     HF.CONV3D_EVAL_F16, HF.CONV2D_EVAL_F16 = keep
+  # the training-mode forward of the same pair (batch statistics; the generator's calibration pass): its three predictions, on the
+  # arithmetic of a training step (two fp16 pieces in the stride-1 3-D, spherical and 3 x 3 layers)
+  net.train()
+  with torch.no_grad(), no_vendor.no_vendor_arithmetic():
+    preds = net(left, right)
+  for i, p in enumerate(preds):
+    _check_pred('config4 train-mode forward pred%d' % (i + 1), p, z, 'train/pred%d' % (i + 1), 0.0)
 
 
 def test_config2_batch_of_two_at_full_size(golden, arith):
