@@ -118,6 +118,8 @@ def parse():
   ap.add_argument('--no-fused-classif', action='store_true',
                   help='A/B: the classifier heads as separate BatchNorm / 32->1 convolution operators (functional.CLASSIF_FUSED = False)')
   ap.add_argument('--no-collective-self-test', action='store_true', help='skip the world-size-1 RCCL all-reduce self-test after the timed region')
+  ap.add_argument('--no-clock-sample', action='store_true',
+                  help='skip the 4 s of extra steps after the timed region during which rocm-smi is polled for the engine clock and socket power')
   ap.add_argument('--no-eval-b1', action='store_true', help='skip the BASELINE configs[1] leg (eval forward, batch 1) after the timed region')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'nccl' is RCCL on ROCm (xGMI inside the node); 'gloo' lets several ranks share ONE GPU in the tests "
@@ -491,6 +493,69 @@ def cpu_baseline_subprocess(args, which='train'):
                 sample='timed out after %d s (1 pair fwd+bwd at Cassini 512x256, D=64)' % args.cpu_baseline_timeout)
 
 
+NOMINAL_SCLK_MHZ = 2400.0  # the engine clock the guide's matrix peaks are quoted at
+
+
+def sample_clocks(step, fence, device_index, seconds=4.0):
+  """Engine clock and socket power WHILE the step replays (the step runs at the socket's power limit, ~10 % under the clock
+  the matrix peaks are quoted at).  After the timed region: `seconds` more of back-to-back steps, `rocm-smi --showclocks --showpower`
+  polled from a thread meanwhile (a child process per poll; nothing of it touches the timed steps).  None when rocm-smi is not there
+  or prints nothing for this device."""
+  import re
+  import shutil
+  import subprocess
+  import threading
+  smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+  if not os.path.exists(smi):
+    return None
+  pat_c = re.compile(r'GPU\[%d\]\s*:\s*sclk clock level:[^(]*\((\d+)Mhz\)' % device_index)
+  pat_p = re.compile(r'GPU\[%d\]\s*:\s*Current Socket Graphics Package Power \(W\):\s*([\d.]+)' % device_index)
+
+  def poll_once():
+    try:
+      r = subprocess.run([smi, '--showclocks', '--showpower'], capture_output=True, text=True, timeout=10)
+    except (OSError, subprocess.SubprocessError):
+      return None
+    c, w = pat_c.search(r.stdout), pat_p.search(r.stdout)
+    return (int(c.group(1)), float(w.group(1)) if w else None) if c else None
+
+  samples, stop = [], threading.Event()
+
+  def poll():
+    while not stop.is_set():
+      v = poll_once()
+      if v is None:
+        return
+      samples.append(v)
+
+  th = threading.Thread(target=poll, daemon=True)
+  t0 = time.time()
+  for _ in range(5):  # (the governor's time constant: let the load settle before the first sample)
+    step()
+  fence()
+  th.start()
+  n = 0
+  while time.time() - t0 < seconds or (not samples and th.is_alive() and time.time() - t0 < 4 * seconds):
+    for _ in range(5):
+      step()
+    fence()
+    n += 5
+  stop.set()
+  th.join(timeout=12)
+  if len(samples) > 1:
+    samples = samples[:-1]  # (the last poll may have straddled the end of the load)
+  if not samples:
+    return None
+  time.sleep(1.0)
+  idle = poll_once()
+  clk = sorted(c for c, _ in samples)
+  pw = sorted(w for _, w in samples if w is not None)
+  return {'sclk_mhz_under_step': clk[len(clk) // 2], 'sclk_mhz_range': [clk[0], clk[-1]], 'socket_power_w_under_step': pw[len(pw) // 2] if pw else None,
+          'samples': len(samples), 'extra_steps': n + 5, 'sclk_mhz_idle_after': idle[0] if idle else None, 'socket_power_w_idle_after': idle[1] if idle else None,
+          'nominal_sclk_mhz': NOMINAL_SCLK_MHZ,
+          'method': 'rocm-smi --showclocks --showpower polled from a thread while the step replays back to back AFTER the timed region'}
+
+
 def eval_b1_leg(net, left, right, args, steps=20, warmup=3):
   """BASELINE configs[1]: eval forward of ONE pair (BatchNorm folded into the convolution kernels, hipGraph replay), timed right
   after the training steps on the same weights: ms per pair, pairs/s, and the dominant kernel label of two profiled eager passes."""
@@ -838,6 +903,12 @@ def main():
   fence()
   elapsed = time.time() - t0
   allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else None
+  clocks = None
+  if world == 1 and not args.no_clock_sample:
+    try:
+      clocks = sample_clocks(step, fence, dev.index if dev.index is not None else 0)
+    except Exception as e:  # (a reported extra, never a reason to lose the bench line)
+      sys.stderr.write('bench.py: clock sampling failed (%s: %s)\n' % (type(e).__name__, e))
   if args.launch == 'graph' and not args.no_kernel_timing:
     eager_step()  # re-warm the eager allocator pool (the replayed steps lived in the graph's private pool): an allocation
     fence()       # that falls through to hipMalloc stalls the stream between the two events of a region
@@ -921,6 +992,8 @@ def main():
                                else 'per-kernel HIP events inside the timed region',
         },
     }
+    if clocks:
+      out['clocks'] = clocks
     if kern:
       out['roofline'] = roofline_block(kern, args.conv_arith, args.batch, args.profile_steps,
                                        ('%d eager steps after the timed region (the timed steps replay a hipGraph)' % args.profile_steps)
@@ -949,6 +1022,10 @@ def main():
       for k, v in out['targets'].items():  # (and as scalar keys of `roofline`: the driver's parser keeps scalars, not nested objects)
         if isinstance(v, (int, float)) or v is None:
           out['roofline'][k] = v
+      if clocks and out['roofline'].get('bound') == 'mfma':
+        # the same fraction against the matrix peak at the clock the chip SUSTAINS under this step (peak scales with the engine clock)
+        out['roofline']['sclk_mhz_under_step'] = clocks['sclk_mhz_under_step']
+        out['roofline']['frac_at_sustained_clock'] = round(out['roofline']['frac'] * NOMINAL_SCLK_MHZ / clocks['sclk_mhz_under_step'], 4)
       out['config']['vendor_guard'] = 'first eager step ran under mode_hip.no_vendor (%d aten ops seen, none of them vendor arithmetic)' % guard.seen
       out['kernels'] = {k: {'calls': v['calls'], 'avg_ms': round(v['avg_ms'], 4), 'GBps': round(v['GBps'], 1),
                             'TFLOPs': round(v['TFLOPs'], 2)} for k, v in kern.items()}

@@ -175,3 +175,21 @@ def test_kernel_of_names_device_kernels_that_really_ran():
   assert bench.kernel_of('sphere_conv_bwd_weight[128->128 256x128]', 'bf16x6') == 'sphere_bww_split_kernel'
   assert bench.kernel_of('sphere_conv_fwd[32->288 256x128]', 'bf16x6') == 'sphere_fwd_kernel'
   assert bench.kernel_of('sphere_conv_bwd_data[128->128 256x128]', 'f32') == 'sphere_bwd_data_adj9_kernel'
+
+
+def test_clock_sampling_parses_rocm_smi_and_never_raises(monkeypatch):
+  """bench.sample_clocks: the engine clock / socket power of THIS device out of `rocm-smi --showclocks --showpower` (the format of the
+  MI355X box, profiles/r06v_clocks_under_load.txt), polled while `step` runs; None when the tool prints nothing for the device."""
+  import subprocess
+  import types
+  text = ('GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: S: (2165Mhz)\n'
+          'GPU[1]\t\t: sclk clock level: S: (95Mhz)\n====== Power Consumption ======\nGPU[0]\t\t: Current Socket Graphics Package Power (W): 1208.0\n'
+          'GPU[1]\t\t: Current Socket Graphics Package Power (W): 239.0\n')
+  monkeypatch.setattr(bench.os.path, 'exists', lambda p: True)
+  monkeypatch.setattr(subprocess, 'run', lambda *a, **k: types.SimpleNamespace(stdout=text, returncode=0))
+  monkeypatch.setattr(bench.time, 'sleep', lambda s: None)
+  steps = []
+  c = bench.sample_clocks(lambda: steps.append(1), lambda: None, 0, seconds=0.05)
+  assert c['sclk_mhz_under_step'] == 2165 and c['socket_power_w_under_step'] == 1208.0 and c['sclk_mhz_idle_after'] == 2165 and len(steps) == c['extra_steps']
+  assert bench.sample_clocks(lambda: None, lambda: None, 1, seconds=0.05)['sclk_mhz_under_step'] == 95
+  assert bench.sample_clocks(lambda: None, lambda: None, 3, seconds=0.05) is None  # no such device in the listing
