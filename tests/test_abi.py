@@ -46,6 +46,24 @@ def test_maximum_buffer_size_matches_the_header():
   assert lib.mode_conv2d_bwd_weight_split_f16(one, one, one, null, one, one, 1, 16, 8, 8, 16, 1, 0, null) == -1 and b'maximum' in lib.mode_last_error()
 
 
+def test_inference_entries_on_fp16_pieces_validate_on_the_host():
+  """ABI 31 (mode_conv3d_fwd_split_f16_bn, mode_conv2d_fwd_split_f16_bn and the `_amax` eval entries): a missing epilogue or maximum buffer
+  is refused before any launch, with a message."""
+  from mode_hip import BnEpilogue
+  lib = mode_hip.lib()
+  null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+  e = BnEpilogue(one, one, one, one, 1e-5, None, 1)
+  args3 = (1, 32, 4, 8, 32, 32, null)
+  assert lib.mode_conv3d_fwd_split_f16_bn(one, one, one, None, one, one, one, *args3) == -1 and b'BatchNorm' in lib.mode_last_error()
+  assert lib.mode_conv3d_fwd_split_f16_bn(one, one, null, ctypes.byref(e), one, one, one, *args3) == -1 and b'maximum' in lib.mode_last_error()
+  assert lib.mode_conv3d_fwd_split_f16_bn(one, one, one, ctypes.byref(e), one, null, one, *args3) == -1 and b'maximum' in lib.mode_last_error()
+  args2 = (1, 32, 8, 32, 32, 1, null)
+  assert lib.mode_conv2d_fwd_split_f16_bn(one, one, one, None, one, one, one, *args2) == -1 and b'BatchNorm' in lib.mode_last_error()
+  assert lib.mode_conv2d_fwd_split_f16_bn(one, one, null, ctypes.byref(e), one, one, one, *args2) == -1 and b'maximum' in lib.mode_last_error()
+  # the output maximum of the stride-2 entry comes out of the eval epilogue: without one there is nothing to fill it
+  assert lib.mode_conv3d_fwd_s2_split_amax(one, one, None, one, one, one, 1, 32, 4, 8, 32, 64, null) == -1 and b'maximum' in lib.mode_last_error()
+
+
 def test_argument_validation_without_gpu():
   """Bad arguments are rejected on the host before any launch, with a message (reference: TORCH_CHECK)."""
   lib = mode_hip.lib()
