@@ -217,6 +217,36 @@ def test_eval_epilogues_of_the_3x3_layers_on_two_fp16_pieces(case, relu, with_ad
   HF.CONV2D_EVAL_F16 = True
 
 
+def test_eval_f16_with_one_channel_whose_folded_scale_dwarfs_the_others(f16_switch):
+  """The weights of an eval layer are scaled by ONE power of two taken from the maximum of the FOLDED weights w[o] * gamma[o] / sqrt(var[o] +
+  eps).  A channel with a large gamma / sigma (a nearly constant feature: tiny running variance) owns that maximum, and the other channels'
+  weights sit far below it: the precision contract (22 bits down to ~2^-17 of the tensor's maximum, fewer below) must
+  still give every OTHER output channel an fp32-grade result.  Channel 0's folded scale is made 1e4 x and 1e6 x the others'; each channel is
+  held to its own scale.  Measured in round 6: 8.9e-7 of a channel's own maximum at 1e4 (three bf16 pieces: 1.0e-6), 3.4e-6 at 1e6."""
+  with torch.no_grad():
+    x = _rand((1, 32, 5, 12, 40), 851)
+    w = _rand((32, 32, 3, 3, 3), 852, 0.05)
+    for ratio in (1e4, 1e6):
+      bn = _eval_bn3(32, 853)
+      bn.running_var.fill_(1.0)
+      bn.weight.fill_(1.0)
+      bn.weight[0] = ratio  # (the fold multiplies row 0 of the weights by `ratio`)
+      want = _bn_eval64(bn, F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, 1), None, False)
+      HF.CONV3D_EVAL_F16 = True
+      got = HF.conv3d_bn_eval(x, w, bn, 1, None, False).double().cpu()
+      HF.CONV3D_EVAL_F16 = False
+      got3 = HF.conv3d_bn_eval(x, w, bn, 1, None, False).double().cpu()
+      per_channel = want.abs().amax((0, 2, 3, 4))
+      e16 = ((got - want).abs().amax((0, 2, 3, 4)) / per_channel)
+      e3 = ((got3 - want).abs().amax((0, 2, 3, 4)) / per_channel)
+      # 2^-22 sqrt(864) = 7e-6 of a channel's own maximum while its weights are within 2^17 of the tensor's; 2^20 below, three bits fewer
+      bound = 2.0**-22 * (27 * 32)**0.5 * (1.0 if ratio < 2.0**17 else ratio / 2.0**17)
+      print('folded scale of channel 0 x %.0e: worst channel error / its own maximum: fp16 pieces %.2e (channel 0: %.2e), bf16 pieces %.2e, bound %.2e'
+            % (ratio, float(e16[1:].max()), float(e16[0]), float(e3[1:].max()), bound))
+      assert float(e16.max()) <= bound, (ratio, e16)
+  HF.CONV3D_EVAL_F16 = True
+
+
 def test_eval_f16_layers_propagate_nan_like_the_bf16_ones(f16_switch):
   with torch.no_grad():
     x = _rand((1, 32, 4, 8, 32), 811)
