@@ -13,4 +13,8 @@ echo "== bench f32" ; timeout 600 python bench.py --steps 5 --warmup 2 --conv-ar
 echo "== rocprofv3 kernel-trace" ; cd /tmp ; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-eval-b1 > $OUT/rocprof.log 2>&1 ; tail -2 $OUT/rocprof.log | cut -c1-300
 cd $R ; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -101 $f > $OUT/kernel_stats_top100.csv; python3 tools/profile_summary.py $f 60 > $OUT/profile_summary_per_step.txt; head -14 $OUT/profile_summary_per_step.txt; done
 find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete
+# the inference line (BASELINE configs[1]), the fusion network's line and the driver's smoke call (typed by hand next to this script up to r06zz)
+echo "== bench eval / fusion, smoke" ; timeout 600 python bench.py --mode eval --batch 1 --steps 20 --warmup 5 2>/dev/null | grep '^{' > $OUT/bench_eval_b1.json
+timeout 600 python bench.py --mode fusion --steps 20 --warmup 3 2>/dev/null | grep '^{' > $OUT/bench_fusion.json
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $OUT/smoke.txt ; cat $OUT/smoke.txt
 du -sh $OUT
